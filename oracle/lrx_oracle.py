@@ -1,0 +1,484 @@
+"""CPU oracle for the LightRetriever dense corpus-embedding + flat-IP search path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain-numpy restatement of the arithmetic
+the reference performs on its dense asymmetric eval path.  It may be imported only by
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` --
+and there only as the checker.  The product path (``lightretriever_amd``) never imports
+it and has no CPU fallback.
+
+Parity pin status
+-----------------
+* Encoder forward / pooling / normalise / EmbeddingBag / packing: PINNED by golden
+  vectors under ``tests/golden/`` that were produced in the build container by running
+  the reference's own Python (``/root/reference/src/lightretriever``) on top of the
+  third-party stack it delegates to (HF ``transformers`` 5.15.0, ``torch`` 2.10) --
+  see ``tests/golden/gen_goldens.py``.
+* Flat inner-product search (Faiss ``IndexFlatIP``): **parity unpinned** against Faiss
+  itself -- ``faiss`` (pyproject.toml:6, ``faiss>=1.7.4``) is neither vendored in the
+  reference nor installed here, and the reference has no tests.  The restatement follows
+  the published semantics (exact fp32 inner product, descending top-k, ids = insertion
+  order, ``-1`` ids / ``-inf``... padding when k > ntotal) and the reference's own call
+  sites (retriever/faiss_index.py:27-58, retriever/faiss_search.py:143-173); it is pinned
+  only against ``torch.matmul`` + ``torch.topk`` goldens.
+
+Every function cites the reference ``file:line`` (relative to /root/reference) or the
+third-party source it restates.
+"""
+from __future__ import annotations
+
+import heapq
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# bf16 helpers (round-to-nearest-even on the fp32 bit pattern, NaN preserved)
+# --------------------------------------------------------------------------------------
+
+
+def round_bf16(x: np.ndarray) -> np.ndarray:
+    """Round fp32 -> bf16 -> fp32 (RNE), the rounding torch applies to every bf16 op result."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    rounded = ((u.astype(np.uint64) + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    out = rounded.view(np.float32).copy()
+    nan = np.isnan(x)
+    if nan.any():
+        out[nan] = np.nan
+    return out.reshape(x.shape)
+
+
+def to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 array -> uint16 bf16 bit patterns (RNE)."""
+    return (round_bf16(x).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Config
+# --------------------------------------------------------------------------------------
+
+
+@dataclass
+class EncoderConfig:
+    """Subset of the HF Llama/Qwen2 ``config.json`` that decides the dense-path arithmetic."""
+
+    vocab_size: int
+    hidden_size: int
+    num_layers: int
+    num_q_heads: int
+    num_kv_heads: int
+    head_dim: int
+    intermediate_size: int
+    rms_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_type: str = "default"  # "default" | "llama3"
+    rope_factor: float = 32.0
+    rope_low_freq_factor: float = 1.0
+    rope_high_freq_factor: float = 4.0
+    rope_original_max_position: int = 8192
+    qkv_bias: bool = False  # Qwen2.5: True
+    max_positions: int = 512
+
+    @staticmethod
+    def llama32_1b(max_positions: int = 512) -> "EncoderConfig":
+        return EncoderConfig(128256, 2048, 16, 32, 8, 64, 8192, 1e-5, 500000.0, "llama3", 32.0, 1.0, 4.0, 8192,
+                             False, max_positions)
+
+    @staticmethod
+    def llama31_8b(max_positions: int = 512) -> "EncoderConfig":
+        return EncoderConfig(128256, 4096, 32, 32, 8, 128, 14336, 1e-5, 500000.0, "llama3", 8.0, 1.0, 4.0, 8192,
+                             False, max_positions)
+
+
+# --------------------------------------------------------------------------------------
+# RoPE  (transformers/modeling_rope_utils.py: _compute_default_rope_parameters,
+#        _compute_llama3_parameters; models/llama/modeling_llama.py LlamaRotaryEmbedding.forward,
+#        rotate_half / apply_rotary_pos_emb)
+# --------------------------------------------------------------------------------------
+
+
+def rope_inv_freq(cfg: EncoderConfig) -> np.ndarray:
+    d = cfg.head_dim
+    inv_freq = 1.0 / (np.float32(cfg.rope_theta) ** (np.arange(0, d, 2, dtype=np.int64).astype(np.float32) / np.float32(d)))
+    inv_freq = inv_freq.astype(np.float32)
+    if cfg.rope_type == "default":
+        return inv_freq
+    if cfg.rope_type != "llama3":
+        raise NotImplementedError(cfg.rope_type)
+    factor = cfg.rope_factor
+    low, high = cfg.rope_low_freq_factor, cfg.rope_high_freq_factor
+    old = cfg.rope_original_max_position
+    low_wl = old / low
+    high_wl = old / high
+    wavelen = (2 * math.pi / inv_freq).astype(np.float32)
+    inv_llama = np.where(wavelen > low_wl, inv_freq / np.float32(factor), inv_freq).astype(np.float32)
+    smooth = ((old / wavelen - low) / (high - low)).astype(np.float32)
+    smoothed = ((1 - smooth) * inv_llama / np.float32(factor) + smooth * inv_llama).astype(np.float32)
+    is_medium = (~(wavelen < high_wl)) & (~(wavelen > low_wl))
+    return np.where(is_medium, smoothed, inv_llama).astype(np.float32)
+
+
+def rope_table(cfg: EncoderConfig, n_pos: Optional[int] = None) -> tuple[np.ndarray, np.ndarray]:
+    """cos/sin [n_pos, head_dim/2] in fp32 (HF duplicates the halves: emb = cat(freqs, freqs))."""
+    n_pos = n_pos or cfg.max_positions
+    inv = rope_inv_freq(cfg)
+    pos = np.arange(n_pos, dtype=np.float32)
+    freqs = (pos[:, None] * inv[None, :]).astype(np.float32)
+    return np.cos(freqs).astype(np.float32), np.sin(freqs).astype(np.float32)
+
+
+def apply_rope(x: np.ndarray, cos: np.ndarray, sin: np.ndarray) -> np.ndarray:
+    """x [T, heads, d]; cos/sin [T, d/2].  q*cos + rotate_half(q)*sin with half-split pairing."""
+    d2 = x.shape[-1] // 2
+    x1, x2 = x[..., :d2], x[..., d2:]
+    c, s = cos[:, None, :], sin[:, None, :]
+    return np.concatenate([x1 * c - x2 * s, x2 * c + x1 * s], axis=-1).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Encoder forward (HF LlamaModel.forward, modeling_llama.py:367-418; decoder layer :284-325;
+# LlamaRMSNorm :53-67; LlamaMLP :163-176; eager attention :179-281).  Reached from
+# finetune/modeling_hybrid.py:248-260 (lm_p_base_unwrap(**forward_kwargs)).
+# --------------------------------------------------------------------------------------
+
+
+def rmsnorm(x: np.ndarray, w: np.ndarray, eps: float, bf16: bool) -> np.ndarray:
+    x = x.astype(np.float32)
+    var = np.mean(x * x, axis=-1, keepdims=True, dtype=np.float32)
+    y = x * (1.0 / np.sqrt(var + np.float32(eps))).astype(np.float32)
+    if bf16:
+        return round_bf16(w * round_bf16(y))  # weight * x.to(in_dtype), each op rounds
+    return (w * y).astype(np.float32)
+
+
+def _mm(a: np.ndarray, w: np.ndarray, bf16: bool) -> np.ndarray:
+    """a [T, K] @ w[N, K]^T (nn.Linear layout), fp32 accumulate."""
+    y = a.astype(np.float32) @ w.astype(np.float32).T
+    return round_bf16(y) if bf16 else y.astype(np.float32)
+
+
+def _silu(x: np.ndarray) -> np.ndarray:
+    return (x / (1.0 + np.exp(-x))).astype(np.float32)
+
+
+def weight_names(cfg: EncoderConfig) -> list[str]:
+    names = ["embed_tokens.weight", "norm.weight"]
+    for i in range(cfg.num_layers):
+        p = f"layers.{i}."
+        names += [p + "input_layernorm.weight", p + "post_attention_layernorm.weight",
+                  p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight",
+                  p + "self_attn.o_proj.weight", p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight",
+                  p + "mlp.down_proj.weight"]
+        if cfg.qkv_bias:
+            names += [p + "self_attn.q_proj.bias", p + "self_attn.k_proj.bias", p + "self_attn.v_proj.bias"]
+    return names
+
+
+def random_weights(cfg: EncoderConfig, seed: int = 0, std: float = 0.02, bf16: bool = True, norm_std: float = 0.1,
+                   bias_std: float = 0.05) -> dict[str, np.ndarray]:
+    """N(0, std) matrices, norm weights 1 + N(0, norm_std), biases N(0, bias_std); pre-rounded to bf16-representable
+    fp32 when ``bf16``.  numpy Generator(PCG64) stream -> the same values on every machine with this numpy."""
+    rng = np.random.default_rng(seed)
+    H, d = cfg.hidden_size, cfg.head_dim
+    shapes = {"embed_tokens.weight": (cfg.vocab_size, H), "norm.weight": (H,)}
+    for i in range(cfg.num_layers):
+        p = f"layers.{i}."
+        shapes.update({
+            p + "input_layernorm.weight": (H,), p + "post_attention_layernorm.weight": (H,),
+            p + "self_attn.q_proj.weight": (cfg.num_q_heads * d, H), p + "self_attn.k_proj.weight": (cfg.num_kv_heads * d, H),
+            p + "self_attn.v_proj.weight": (cfg.num_kv_heads * d, H), p + "self_attn.o_proj.weight": (H, cfg.num_q_heads * d),
+            p + "mlp.gate_proj.weight": (cfg.intermediate_size, H), p + "mlp.up_proj.weight": (cfg.intermediate_size, H),
+            p + "mlp.down_proj.weight": (H, cfg.intermediate_size)})
+        if cfg.qkv_bias:
+            shapes.update({p + "self_attn.q_proj.bias": (cfg.num_q_heads * d,), p + "self_attn.k_proj.bias": (cfg.num_kv_heads * d,),
+                           p + "self_attn.v_proj.bias": (cfg.num_kv_heads * d,)})
+    out = {}
+    for name in weight_names(cfg):
+        w = rng.standard_normal(shapes[name], dtype=np.float32)
+        if name.endswith("norm.weight"):
+            w = 1.0 + w * np.float32(norm_std)
+        elif name.endswith(".bias"):
+            w = w * np.float32(bias_std)
+        else:
+            w = w * np.float32(std)
+        out[name] = round_bf16(w) if bf16 else w.astype(np.float32)
+    return out
+
+
+def encoder_forward_packed(cfg: EncoderConfig, w: dict[str, np.ndarray], ids: np.ndarray, cu_seqlens: np.ndarray,
+                           bf16: bool = False, return_layers: bool = False, final_norm: bool = True):
+    """Packed-varlen causal forward.  ids [T] int, cu_seqlens [B+1]; position restarts at 0 per
+    sequence (utils/nested_input.py:15-39 builds exactly these position ids).  Returns
+    last_hidden_state [T, H] fp32.  ``bf16=True`` rounds to bf16 wherever a bf16 HF model rounds."""
+    rnd = round_bf16 if bf16 else (lambda a: np.asarray(a, dtype=np.float32))
+    T = int(ids.shape[0])
+    H, d, nq, nkv = cfg.hidden_size, cfg.head_dim, cfg.num_q_heads, cfg.num_kv_heads
+    grp = nq // nkv
+    x = w["embed_tokens.weight"][ids].astype(np.float32)
+    pos = np.zeros(T, dtype=np.int64)
+    for b in range(len(cu_seqlens) - 1):
+        s, e = int(cu_seqlens[b]), int(cu_seqlens[b + 1])
+        pos[s:e] = np.arange(e - s)
+    cos_t, sin_t = rope_table(cfg, int(pos.max()) + 1 if T else 1)
+    cos, sin = rnd(cos_t[pos]), rnd(sin_t[pos])  # HF casts cos/sin to the activation dtype
+    scale = np.float32(d ** -0.5)
+    layers = []
+    for i in range(cfg.num_layers):
+        p = f"layers.{i}."
+        h = rmsnorm(x, w[p + "input_layernorm.weight"], cfg.rms_eps, bf16)
+        q = _mm(h, w[p + "self_attn.q_proj.weight"], False)
+        k = _mm(h, w[p + "self_attn.k_proj.weight"], False)
+        v = _mm(h, w[p + "self_attn.v_proj.weight"], False)
+        if cfg.qkv_bias:
+            q = q + w[p + "self_attn.q_proj.bias"]
+            k = k + w[p + "self_attn.k_proj.bias"]
+            v = v + w[p + "self_attn.v_proj.bias"]
+        q, k, v = rnd(q).reshape(T, nq, d), rnd(k).reshape(T, nkv, d), rnd(v).reshape(T, nkv, d)
+        q, k = rnd(apply_rope(q, cos, sin)), rnd(apply_rope(k, cos, sin))
+        attn = np.zeros((T, nq, d), dtype=np.float32)
+        for b in range(len(cu_seqlens) - 1):
+            s, e = int(cu_seqlens[b]), int(cu_seqlens[b + 1])
+            L = e - s
+            if L == 0:
+                continue
+            causal = np.tril(np.ones((L, L), dtype=bool))
+            for hq in range(nq):
+                hk = hq // grp
+                sc = (q[s:e, hq] @ k[s:e, hk].T) * scale
+                sc = np.where(causal, sc, -np.inf).astype(np.float32)
+                sc = sc - sc.max(axis=-1, keepdims=True)
+                pexp = np.exp(sc).astype(np.float32)
+                pr = pexp / pexp.sum(axis=-1, keepdims=True, dtype=np.float32)
+                attn[s:e, hq] = rnd(pr) @ v[s:e, hk]
+        attn = rnd(attn).reshape(T, nq * d)
+        x = rnd(x + _mm(attn, w[p + "self_attn.o_proj.weight"], bf16))
+        h = rmsnorm(x, w[p + "post_attention_layernorm.weight"], cfg.rms_eps, bf16)
+        g = _mm(h, w[p + "mlp.gate_proj.weight"], bf16)
+        u = _mm(h, w[p + "mlp.up_proj.weight"], bf16)
+        act = rnd(rnd(_silu(g)) * u)
+        x = rnd(x + _mm(act, w[p + "mlp.down_proj.weight"], bf16))
+        if return_layers:
+            layers.append(x.copy())
+    out = rmsnorm(x, w["norm.weight"], cfg.rms_eps, bf16) if final_norm else x
+    return (out, layers) if return_layers else out
+
+
+# --------------------------------------------------------------------------------------
+# Packing (utils/nested_input.py:15-39 unpad_to_seqlen_dim) -- integer work, bit-exact
+# --------------------------------------------------------------------------------------
+
+
+def pack_padded(input_ids: np.ndarray, attention_mask: np.ndarray):
+    """[B,S] right- (or left-) padded ids+mask -> (ids_nested [T], position_ids [T], indices [T], cu_seqlens [B+1], max_len)."""
+    mask = attention_mask.astype(bool)
+    seqlens = mask.sum(axis=1).astype(np.int32)
+    indices = np.flatnonzero(mask.reshape(-1)).astype(np.int64)
+    ids_nested = input_ids.reshape(-1)[indices]
+    cu = np.zeros(len(seqlens) + 1, dtype=np.int32)
+    cu[1:] = np.cumsum(seqlens)
+    position_ids = np.concatenate([np.arange(n, dtype=np.int64) for n in seqlens]) if len(seqlens) else np.zeros(0, np.int64)
+    return ids_nested, position_ids, indices, cu, int(seqlens.max()) if len(seqlens) else 0
+
+
+# --------------------------------------------------------------------------------------
+# Pooling + normalise (finetune/dense_pooling.py:48-55; finetune/modeling_hybrid.py:272-278)
+# --------------------------------------------------------------------------------------
+
+
+def lasttoken_pool_packed(last_hidden: np.ndarray, cu_seqlens: np.ndarray) -> np.ndarray:
+    """In the packed layout 'lasttoken' is h[cu_seqlens[1:] - 1] (both branches of dense_pooling.py:48-55
+    select the last non-pad token of each right-padded row)."""
+    return last_hidden[np.asarray(cu_seqlens[1:], dtype=np.int64) - 1]
+
+
+def lasttoken_pool_padded(last_hidden: np.ndarray, attention_mask: np.ndarray) -> np.ndarray:
+    """Literal restatement of dense_pooling.py:48-55 on [B,S,H]."""
+    B = last_hidden.shape[0]
+    left_padding = attention_mask[:, -1].sum() == B
+    if left_padding:
+        return last_hidden[:, -1]
+    idx = attention_mask.sum(axis=1) - 1
+    return last_hidden[np.arange(B), idx]
+
+
+def l2_normalize(x: np.ndarray, eps: float = 1e-12) -> np.ndarray:
+    """torch.nn.functional.normalize(p=2, dim=-1): x / max(||x||, eps)."""
+    x = x.astype(np.float32)
+    n = np.sqrt(np.sum(x * x, axis=-1, keepdims=True, dtype=np.float32))
+    return (x / np.maximum(n, np.float32(eps))).astype(np.float32)
+
+
+def encode_passage(cfg: EncoderConfig, w, ids, cu_seqlens, dense_shrink_dim: Optional[int] = None,
+                   normalize: bool = True, bf16: bool = False) -> np.ndarray:
+    """finetune/modeling_hybrid.py:205-278 dense branch: forward -> pooling('lasttoken') -> MRL slice -> F.normalize."""
+    h = encoder_forward_packed(cfg, w, ids, cu_seqlens, bf16=bf16)
+    p = lasttoken_pool_packed(h, cu_seqlens)
+    if dense_shrink_dim:
+        p = p[..., :dense_shrink_dim]
+    return l2_normalize(p) if normalize else p.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Query side: EmbeddingBag(mode='mean', padding_idx) (finetune/nonctx_emb_utils.py:197-219, :310-313;
+# finetune/modeling_hybrid.py:472-490)
+# --------------------------------------------------------------------------------------
+
+
+def nonctx_offsets(lengths: list[int]) -> np.ndarray:
+    """offsets = cumsum([0] + len[:-1])   (nonctx_emb_utils.py:217)."""
+    return np.cumsum([0] + list(lengths[:-1])).astype(np.int64)
+
+
+def embedding_bag_mean(table: np.ndarray, ids: np.ndarray, offsets: np.ndarray, padding_idx: Optional[int] = None) -> np.ndarray:
+    """torch.nn.EmbeddingBag(mode='mean', padding_idx=p): mean over the non-padding ids of each bag; empty bag -> 0."""
+    Q = len(offsets)
+    out = np.zeros((Q, table.shape[1]), dtype=np.float32)
+    ends = list(offsets[1:]) + [len(ids)]
+    for i in range(Q):
+        bag = ids[int(offsets[i]):int(ends[i])]
+        if padding_idx is not None:
+            bag = bag[bag != padding_idx]
+        if len(bag):
+            acc = np.zeros(table.shape[1], dtype=np.float32)
+            for t in bag:  # sequential fp32 accumulation like the torch CPU kernel
+                acc += table[int(t)].astype(np.float32)
+            out[i] = acc / np.float32(len(bag))
+    return out
+
+
+def encode_query_emb(table, ids, offsets, padding_idx=None, dense_shrink_dim=None, normalize=True):
+    e = embedding_bag_mean(table, ids, offsets, padding_idx)
+    if dense_shrink_dim:
+        e = e[..., :dense_shrink_dim]
+    return l2_normalize(e) if normalize else e
+
+
+def construct_embedding_bag(cfg: EncoderConfig, w, bos_id: Optional[int], eos_id: int, prompt_ids: list[int],
+                            vocab_len: Optional[int] = None, bf16: bool = False) -> np.ndarray:
+    """finetune/nonctx_emb_utils.py:239-313: for every tok in [0, len(tokenizer)) run the encoder on
+    [bos] + prompt + [tok] + [eos] and keep last_hidden_state[:, -1] un-normalised, fp32."""
+    V = vocab_len or cfg.vocab_size
+    prefix = ([bos_id] if bos_id is not None else []) + list(prompt_ids)
+    L = len(prefix) + 2
+    ids = np.empty((V, L), dtype=np.int64)
+    ids[:, :len(prefix)] = np.asarray(prefix, dtype=np.int64)[None, :] if prefix else 0
+    ids[:, -2] = np.arange(V)
+    ids[:, -1] = eos_id
+    cu = (np.arange(V + 1) * L).astype(np.int32)
+    h = encoder_forward_packed(cfg, w, ids.reshape(-1), cu, bf16=bf16)
+    return h[cu[1:] - 1].astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Flat inner-product index (retriever/faiss_index.py:20-73; faiss.IndexFlatIP published semantics)
+# --------------------------------------------------------------------------------------
+
+
+def flat_ip_topk(q: np.ndarray, X: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
+    """scores = q @ X.T (fp32), per-query top-k descending.  Ties broken by LOWER row id (deterministic rule
+    this build defines; Faiss leaves tie order unspecified).  If k > N the tail is (-inf... faiss uses
+    -3.4e38, id -1): we return score = -FLT_MAX, id = -1 like faiss' heap initialisation."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    Q, N = q.shape[0], X.shape[0]
+    S = (q @ X.T).astype(np.float32) if N else np.zeros((Q, 0), np.float32)
+    D = np.full((Q, k), -np.finfo(np.float32).max, dtype=np.float32)
+    I = np.full((Q, k), -1, dtype=np.int64)
+    kk = min(k, N)
+    if kk:
+        order = np.lexsort((np.broadcast_to(np.arange(N), S.shape), -S), axis=-1)[:, :kk]
+        D[:, :kk] = np.take_along_axis(S, order, axis=1)
+        I[:, :kk] = order
+    return D, I
+
+
+def merge_topk(D_parts: list[np.ndarray], I_parts: list[np.ndarray], k: int) -> tuple[np.ndarray, np.ndarray]:
+    """Merge per-shard (score, global row) lists -> top-k by (score desc, row asc); id -1 entries sink."""
+    D = np.concatenate(D_parts, axis=1)
+    I = np.concatenate(I_parts, axis=1)
+    Q = D.shape[0]
+    outD = np.full((Q, k), -np.finfo(np.float32).max, dtype=np.float32)
+    outI = np.full((Q, k), -1, dtype=np.int64)
+    for qi in range(Q):
+        valid = I[qi] >= 0
+        d, i = D[qi][valid], I[qi][valid]
+        order = np.lexsort((i, -d))[:k]
+        outD[qi, :len(order)] = d[order]
+        outI[qi, :len(order)] = i[order]
+    return outD, outI
+
+
+class FlatIPIndexOracle:
+    """faiss.IndexFlatIP surface used by retriever/faiss_index.py: add / search / reset / ntotal."""
+
+    def __init__(self, d: int):
+        self.d = d
+        self._chunks: list[np.ndarray] = []
+        self.ntotal = 0
+
+    def add(self, x: np.ndarray):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.ndim == 2 and x.shape[1] == self.d
+        self._chunks.append(x)
+        self.ntotal += x.shape[0]
+
+    def search(self, q: np.ndarray, k: int):
+        X = np.concatenate(self._chunks, axis=0) if self._chunks else np.zeros((0, self.d), np.float32)
+        return flat_ip_topk(q, X, k)
+
+    def reset(self):
+        self._chunks, self.ntotal = [], 0
+
+
+# --------------------------------------------------------------------------------------
+# search(): chunk loop + heap merge (retriever/hybrid_search.py:182-205, :273-358;
+# retriever/faiss_search.py:143-173, :228-291)
+# --------------------------------------------------------------------------------------
+
+
+def sort_corpus_ids_longest_first(corpus: dict) -> list[str]:
+    """hybrid_search.py:273-276 / faiss_search.py:214-216: sorted(..., key=len(text), reverse=True) (stable)."""
+    return sorted(corpus, key=lambda k: len(corpus[k].get("text", "")) if isinstance(corpus[k], dict) else len(corpus[k]),
+                  reverse=True)
+
+
+def add_to_heap(sub_results: dict, heaps: dict, top_k: int, ignore_identical_ids: bool):
+    """hybrid_search.py:182-205: per-query min-heap of (score, pid) capped at top_k."""
+    for qid, pid_to_score in sub_results.items():
+        for pid, score in pid_to_score.items():
+            if ignore_identical_ids and qid == pid:
+                continue
+            if len(heaps[qid]) < top_k:
+                heapq.heappush(heaps[qid], (score, pid))
+            else:
+                heapq.heappushpop(heaps[qid], (score, pid))
+
+
+def search_chunks(query_emb: np.ndarray, query_ids: list[str], corpus_emb: np.ndarray, corpus_ids: list[str],
+                  top_k: int, corpus_chunk_size: int, ignore_identical_ids: bool = False) -> dict[str, dict[str, float]]:
+    """Dense part of HybridSearch.search / DenseRetrievalFaissSearch.search given already-encoded, already
+    length-sorted embeddings: per chunk index -> retrieve_with_emb -> heap merge -> {qid: {pid: score}}."""
+    heaps = {qid: [] for qid in query_ids}
+    for s in range(0, len(corpus_ids), corpus_chunk_size):
+        e = min(s + corpus_chunk_size, len(corpus_ids))
+        D, I = flat_ip_topk(query_emb, corpus_emb[s:e], top_k)
+        sub = {}
+        for qi, qid in enumerate(query_ids):
+            sub[qid] = {corpus_ids[s + int(r)]: float(sc) for sc, r in zip(D[qi], I[qi]) if r >= 0}
+        add_to_heap(sub, heaps, top_k, ignore_identical_ids)
+    return {qid: {pid: score for score, pid in heaps[qid]} for qid in query_ids}
+
+
+# --------------------------------------------------------------------------------------
+# LoRA merge (finetune/modeling_encoder.py:616-625 -> peft merge_and_unload: W + (alpha/r) * B @ A)
+# --------------------------------------------------------------------------------------
+
+
+def lora_merge(W: np.ndarray, A: np.ndarray, B: np.ndarray, alpha: float, r: int) -> np.ndarray:
+    return (W.astype(np.float32) + np.float32(alpha / r) * (B.astype(np.float32) @ A.astype(np.float32))).astype(np.float32)

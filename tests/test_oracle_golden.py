@@ -1,0 +1,159 @@
+"""Pin the CPU oracle (oracle/lrx_oracle.py) against the golden vectors produced by the real reference
+(tests/golden/gen_goldens.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import lrx_oracle as O
+from helpers import GOLDEN, MODEL_GOLDENS, load_model_golden, min_cos
+
+
+@pytest.mark.parametrize("name", MODEL_GOLDENS)
+def test_encoder_fp32_matches_reference(name):
+    cfg, w, g, ids, cu, _ = load_model_golden(name)
+    h, layers = O.encoder_forward_packed(cfg, w, ids, cu, bf16=False, return_layers=True)
+    pooled = O.lasttoken_pool_packed(h, cu)
+    np.testing.assert_allclose(pooled, g["pooled"], atol=2e-4, rtol=2e-4)
+    dense = O.l2_normalize(pooled)
+    np.testing.assert_allclose(dense, g["dense_reps"], atol=2e-5)
+    s = int(g["shrink"])
+    np.testing.assert_allclose(O.l2_normalize(pooled[:, :s]), g["dense_reps_mrl"], atol=2e-5)
+    np.testing.assert_allclose(O.encode_passage(cfg, w, ids, cu, dense_shrink_dim=s), g["dense_reps_mrl"], atol=2e-5)
+    if g["last_hidden_state"].size:
+        mask = g["attention_mask"].astype(bool)
+        np.testing.assert_allclose(h, g["last_hidden_state"][mask], atol=3e-4, rtol=3e-4)
+        # padded-layout restatement of dense_pooling.py:48-55 agrees with the packed gather
+        hp = np.zeros(g["last_hidden_state"].shape, np.float32)
+        hp[mask] = h
+        np.testing.assert_allclose(O.lasttoken_pool_padded(hp, g["attention_mask"]), pooled, atol=0)
+    if g["layer_hidden"].size:
+        mask = g["attention_mask"].astype(bool)
+        for i in range(g["layer_hidden"].shape[0]):
+            np.testing.assert_allclose(layers[i], g["layer_hidden"][i][mask], atol=3e-4, rtol=3e-4)
+
+
+@pytest.mark.parametrize("name", MODEL_GOLDENS)
+def test_encoder_bf16_emulation_close_to_reference_bf16(name):
+    """The bf16-rounding mode of the oracle tracks the reference's bf16 model (CPU HF bf16) at least as well as
+    fp32 does; both sit inside the bf16 noise band of these tiny random models."""
+    cfg, w, g, ids, cu, _ = load_model_golden(name)
+    d16 = O.encode_passage(cfg, w, ids, cu, bf16=True)
+    c_ref = min_cos(d16, g["dense_reps_bf16"])
+    c_fp32 = min_cos(g["dense_reps"], g["dense_reps_bf16"])
+    assert c_ref > 0.995, (c_ref, c_fp32)
+    assert min_cos(d16, g["dense_reps"]) > 0.995
+
+
+def test_packing_bit_exact():
+    g = np.load(os.path.join(GOLDEN, "packing.npz"))
+    for sfx in ("", "2"):
+        nested, pos, indices, cu, max_len = O.pack_padded(g["ids" + sfx], g["mask" + sfx])
+        np.testing.assert_array_equal(nested, g["nested" + sfx])
+        np.testing.assert_array_equal(pos, g["pos" + sfx])
+        np.testing.assert_array_equal(indices, g["indices" + sfx])
+        assert cu[-1] == len(nested) and max_len == g["mask" + sfx].sum(1).max()
+
+
+def test_embedding_bag_matches_torch_and_reference():
+    g = np.load(os.path.join(GOLDEN, "embbag.npz"))
+    raw = O.embedding_bag_mean(g["table"], g["ids_b"], g["offs_b"], padding_idx=int(g["pad"]))
+    np.testing.assert_allclose(raw, g["raw_b"], atol=1e-6)
+    assert np.all(raw[1] == 0)  # empty bag
+    emb = O.encode_query_emb(g["table"], g["q_ids"], g["q_offsets"], padding_idx=int(g["pad"]))
+    np.testing.assert_allclose(emb, g["emb_reps"], atol=1e-6)
+
+
+def test_construct_embedding_bag_matches_reference():
+    cfg, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    g = np.load(os.path.join(GOLDEN, "embbag.npz"))
+    table = O.construct_embedding_bag(cfg, w, int(g["bos"]), int(g["eos"]), [int(t) for t in g["prompt_ids"]],
+                                      vocab_len=g["table"].shape[0])
+    # the reference builds the table under torch.autocast (bf16 matmuls, nonctx_emb_utils.py:296) -> bf16 noise band
+    assert min_cos(table, g["table"]) > 0.9995
+    assert np.abs(table - g["table"]).max() < 0.06 * np.abs(g["table"]).max()
+
+
+def test_nonctx_offsets():
+    g = np.load(os.path.join(GOLDEN, "embbag.npz"))
+    offs = g["q_offsets"]
+    lens = list(np.diff(list(offs) + [len(g["q_ids"])]))
+    np.testing.assert_array_equal(O.nonctx_offsets(lens), offs)
+
+
+@pytest.mark.parametrize("k", [1, 10, 100])
+def test_flat_ip_topk_matches_torch(k):
+    g = np.load(os.path.join(GOLDEN, "search.npz"))
+    D, I = O.flat_ip_topk(g["Q"], g["X"], k)
+    np.testing.assert_allclose(D, g[f"D{k}"], atol=2e-6)
+    # ids identical wherever scores are not within float noise of the neighbouring rank
+    same = I == g[f"I{k}"]
+    if not same.all():
+        bad = ~same
+        gaps = np.abs(D[bad] - g[f"D{k}"][bad])
+        assert gaps.max() < 2e-6
+    assert same.mean() > 0.999
+
+
+def test_flat_ip_topk_edge_cases():
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((7, 8)).astype(np.float32)
+    q = rng.standard_normal((3, 8)).astype(np.float32)
+    D, I = O.flat_ip_topk(q, X, 10)  # k > N -> id -1 tail
+    assert (I[:, 7:] == -1).all() and (I[:, :7] >= 0).all()
+    assert np.all(np.diff(D[:, :7], axis=1) <= 0)
+    # duplicate rows -> tie broken by lower row id
+    X2 = np.concatenate([X, X], 0)
+    D2, I2 = O.flat_ip_topk(q, X2, 4)
+    assert np.all(I2[:, 0] + 7 == I2[:, 1])
+    # empty index
+    D0, I0 = O.flat_ip_topk(q, np.zeros((0, 8), np.float32), 3)
+    assert (I0 == -1).all()
+    # merge of shards == search over the concatenation
+    Da, Ia = O.flat_ip_topk(q, X2[:5], 4)
+    Db, Ib = O.flat_ip_topk(q, X2[5:], 4)
+    Ib = np.where(Ib >= 0, Ib + 5, -1)
+    Dm, Im = O.merge_topk([Da, Db], [Ia, Ib], 4)
+    np.testing.assert_array_equal(Im, I2)
+    np.testing.assert_allclose(Dm, D2)
+
+
+def test_search_chunks_heap_merge():
+    rng = np.random.default_rng(1)
+    X = O.l2_normalize(rng.standard_normal((300, 16)).astype(np.float32))
+    X[17] = X[250]  # exact duplicate score across chunks
+    q = O.l2_normalize(rng.standard_normal((5, 16)).astype(np.float32))
+    cids = [f"d{i}" for i in range(300)]
+    qids = ["d3", "q1", "q2", "d250", "q4"]
+    res = O.search_chunks(q, qids, X, cids, top_k=10, corpus_chunk_size=64, ignore_identical_ids=True)
+    D, I = O.flat_ip_topk(q, X, 12)
+    for qi, qid in enumerate(qids):
+        want = [(cids[r], float(s)) for s, r in zip(D[qi], I[qi]) if cids[r] != qid][:10]
+        got = res[qid]
+        assert len(got) == 10 and qid not in got
+        # same score multiset (pids may differ only where scores tie exactly)
+        np.testing.assert_allclose(sorted(got.values(), reverse=True), [s for _, s in want], atol=1e-6)
+
+
+def test_collator_fixture_is_consistent():
+    """tokenizer fixture + collator.json: right padding, EOS is the last real token even when truncated,
+    offsets = cumsum of lengths (the product collator is tested against the same fixture in test_host.py)."""
+    c = json.load(open(os.path.join(GOLDEN, "collator.json")))
+    ids, mask = np.array(c["doc_input_ids"]), np.array(c["doc_attention_mask"])
+    assert ids.shape[1] <= c["p_max_len"]
+    for r in range(ids.shape[0]):
+        n = mask[r].sum()
+        assert mask[r, :n].all() and not mask[r, n:].any()
+        assert ids[r, 0] == c["bos"] and ids[r, n - 1] == c["eos"]
+        assert (ids[r, n:] == c["pad"]).all()
+    assert max(mask.sum(1)) == c["p_max_len"]  # the long doc was truncated to max_len with EOS kept
+    offs = c["qry_nonctx_offsets"]
+    assert offs[0] == 0 and all(b >= a for a, b in zip(offs, offs[1:]))
+    assert c["bos"] not in c["qry_nonctx_input_ids"] and c["eos"] not in c["qry_nonctx_input_ids"]
+
+
+def test_lora_merge_formula():
+    rng = np.random.default_rng(2)
+    W, A, B = rng.standard_normal((6, 5)), rng.standard_normal((2, 5)), rng.standard_normal((6, 2))
+    np.testing.assert_allclose(O.lora_merge(W, A, B, 8, 2), W + 4.0 * (B @ A), rtol=1e-5)
