@@ -1,0 +1,179 @@
+/*
+ * lrx.h -- C ABI of liblrx.so: the MI355X (gfx950) corpus-embedding + flat-IP search hot path of LightRetriever.
+ *
+ * The reference (caskcsg/lightretriever) is pure Python and has no FFI of its own; its
+ * per-batch operator boundary is HybridModel.encode_passage / encode_query and faiss.IndexFlatIP.  Each entry
+ * point below names the reference interface (file:line under /root/reference) it replaces.  All pointers are
+ * DEVICE pointers unless the name says `host`; all sizes are element counts unless the name says `bytes`;
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).  No entry point allocates device memory,
+ * synchronises the device or touches torch: the caller (PyTorch-ROCm in this build) owns memory and streams.
+ * Every function returns LRX_OK (0) or a negative error; lrx_last_error() gives the message (thread-local).
+ */
+#ifndef LRX_H
+#define LRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRX_ABI_VERSION 1
+
+enum {
+  LRX_OK = 0,
+  LRX_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+  LRX_ERR_HIP = -2,       /* a HIP runtime call failed */
+  LRX_ERR_WORKSPACE = -3, /* workspace too small */
+};
+
+int lrx_abi_version(void);
+const char* lrx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Encoder model description: the subset of HF config.json that decides the dense-path arithmetic
+ * (transformers LlamaConfig / Qwen2Config; reference loads it at finetune/modeling_encoder.py:602-633).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct lrx_encoder_config {
+  int32_t vocab_size;
+  int32_t hidden_size;        /* H; multiple of 64 */
+  int32_t num_layers;
+  int32_t num_q_heads;
+  int32_t num_kv_heads;
+  int32_t head_dim;           /* 64 or 128 */
+  int32_t intermediate_size;  /* multiple of 64 */
+  float rms_eps;
+  int32_t qkv_bias;           /* 1 for Qwen2.5 */
+  int32_t max_positions;      /* rows of the RoPE table */
+} lrx_encoder_config;
+
+/* Per-layer weights, bf16, nn.Linear layout [out, in] row-major (K contiguous).
+ *   wqkv  [(nq + 2 nkv) * d, H]   rows = q_proj | k_proj | v_proj concatenated
+ *   wo    [H, nq * d]
+ *   wgu   [2 * I, H]              gate/up interleaved in 32-row groups: rows [64j,64j+32) = gate[32j..], [64j+32,64j+64) = up[32j..]
+ *   wdown [H, I]
+ *   ln1, ln2 [H] bf16 (input_layernorm, post_attention_layernorm); bqkv [(nq+2nkv)*d] bf16 or NULL            */
+typedef struct lrx_layer_weights {
+  const void* wqkv;
+  const void* bqkv;
+  const void* wo;
+  const void* wgu;
+  const void* wdown;
+  const void* ln1;
+  const void* ln2;
+} lrx_layer_weights;
+
+typedef struct lrx_encoder_weights {
+  const void* embed;             /* [V, H] bf16 */
+  const void* final_norm;        /* [H] bf16 */
+  const float* rope_cos;         /* [max_positions, d/2] fp32 (values already rounded to bf16, as HF casts cos/sin) */
+  const float* rope_sin;
+  const lrx_layer_weights* layers; /* HOST array of num_layers structs (device pointers inside) */
+} lrx_encoder_weights;
+
+/* Workspace (device bytes) needed by lrx_encode_packed for `total_tokens` packed tokens in `n_seqs` sequences. */
+size_t lrx_encode_workspace_bytes(const lrx_encoder_config* cfg, int32_t total_tokens, int32_t n_seqs);
+
+/* Document-side encoder forward on a packed batch.
+ * Replaces: HybridModel.encode_passage dense branch (finetune/modeling_hybrid.py:205-278) including the HF
+ * LlamaModel/Qwen2Model forward it calls (:248-260), utils/nested_input.py:114-166 (packing: the packed layout is
+ * native here), finetune/dense_pooling.py:48-55 ('lasttoken'), the MRL slice and F.normalize (:272-278).
+ *   ids        [total_tokens] int32 token ids, sequences back to back
+ *   cu_seqlens [n_seqs + 1] int32, cu_seqlens[0] = 0, cu_seqlens[n_seqs] = total_tokens; every sequence non-empty
+ *   out        fp32 rows, row b at out + b * out_row_stride, out_dim (<= H) floats each: the L2-normalised
+ *              (if normalize != 0) last-token embedding, first out_dim dims (dense_shrink_dim / MRL).  May point
+ *              directly into the index shard (the encoder writes in place; no host round trip).
+ * max_seqlen: upper bound on any sequence length (<= cfg->max_positions).                                       */
+int lrx_encode_packed(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids,
+                      const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen,
+                      float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* Same forward, but returns the un-pooled final hidden states (after the final RMSNorm), bf16 [total_tokens, H]:
+ * the `last_hidden_state` of lm(...) at finetune/modeling_hybrid.py:260.  Used by EmbeddingBag construction
+ * (finetune/nonctx_emb_utils.py:296-306 takes last_hidden_state[:, -1]) and by tests.                           */
+int lrx_encode_hidden(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids,
+                      const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen,
+                      void* hidden_out_bf16, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-kernel-class timing of the LAST lrx_encode_* call when profiling is enabled: HIP events are recorded on
+ * `stream` around every launch and the call synchronises the stream at its end (so never leave it on in production).
+ * classes: 0 gemm/store (qkv), 1 gemm/residual (o, down), 2 gemm/swiglu (gate-up), 3 attention, 4 rmsnorm, 5 rope,
+ * 6 other (embedding gather, positions, pool).  Arrays of LRX_PROF_CLASSES entries; flops are algorithmic
+ * (2*M*N*K for GEMMs, 2*2*d*sum_s(s*(s+1)/2)*nq for causal attention), 0 for the memory-bound classes.            */
+#define LRX_PROF_CLASSES 7
+void lrx_set_profiling(int32_t enabled);
+int lrx_get_profile(float* ms, double* flops, int32_t* launches);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Individual kernels (unit-tested one by one against the oracle; same arithmetic the fused path uses)
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* out[t,:] = table[ids[t],:]  (nn.Embedding inside LlamaModel.forward)  bf16 */
+int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, void* out, void* stream);
+
+/* LlamaRMSNorm (modeling_llama.py:53-67): y = w * bf16(x * rsqrt(mean(x^2) + eps)); x, w, y bf16; rows x hidden */
+int lrx_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps, void* stream);
+
+/* C[M,N] = A[M,K] * B[N,K]^T, bf16 in, fp32 accumulate, bf16 out.  K % 64 == 0, N % 4 == 0.
+ *   epilogue 0: C = acc (+ bias[n] if bias != NULL)          ldc = N
+ *   epilogue 1: C = acc + resid[m,n]  (resid may alias C)    ldc = N
+ *   epilogue 2: SwiGLU on gate/up-interleaved B (see wgu):   C[M, N/2] = silu(gate) * up, ldc = N/2           */
+int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M,
+                     int32_t N, int32_t K, int32_t epilogue, void* stream);
+
+/* positions[t] = t - cu_seqlens[seq(t)] */
+int lrx_build_positions(const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t* positions, void* stream);
+
+/* In-place rotary embedding (apply_rotary_pos_emb, modeling_llama.py:130-160, half-split pairing) on the q and k
+ * column blocks of the fused qkv activation [T, (nq + 2 nkv) * d] bf16.                                          */
+int lrx_rope_inplace(void* qkv, const int32_t* positions, const float* cos, const float* sin, int32_t total_tokens,
+                     int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* stream);
+
+/* Varlen causal GQA attention (flash_attention_2 varlen call the reference requires for packing,
+ * utils/nested_input.py:137-146): out[T, nq*d] bf16 = softmax(q k^T / sqrt(d), causal within each sequence) v   */
+int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens,
+                           int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                           void* out, void* stream);
+
+/* Last-token pooling + final RMSNorm on the pooled rows only + MRL slice + L2 normalise -> fp32 rows.
+ * hidden = residual stream BEFORE the final norm [T, H] bf16.                                                    */
+int lrx_pool_norm(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
+                  int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim,
+                  int32_t normalize, void* stream);
+
+/* Query side.  Replaces emb_bag.forward + slice + F.normalize at finetune/modeling_hybrid.py:472-490
+ * (torch.nn.EmbeddingBag mode='mean', padding_idx) with inputs from tokenize_nonctx_qry_emb_bag
+ * (finetune/nonctx_emb_utils.py:197-219).  table fp32 [V, H]; ids int64 [n_ids]; offsets int64 [n_bags];
+ * padding_idx < 0 = none; empty bag -> zero row.  out fp32 [n_bags, out_dim].                                    */
+int lrx_embedding_bag_mean(const float* table, int32_t vocab, int32_t hidden, const int64_t* ids, int64_t n_ids,
+                           const int64_t* offsets, int32_t n_bags, int64_t padding_idx, float* out,
+                           int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Flat inner-product index shard resident in HBM.  Replaces faiss.IndexFlatIP.search as called from
+ * FaissIndex.search (retriever/faiss_index.py:27-40): exact fp32 scores, descending top-k, ids = row numbers
+ * (+ id_base, so shards can return global rows), ties broken by lower row id, id -1 / score -FLT_MAX when k > N.
+ *   X [N, D] fp32 row-major (row stride ldx floats), q [Q, D] fp32, D % 32 == 0, k <= 2048.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t lrx_flat_ip_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k);
+
+int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries,
+                       int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* Score pass only: scores[Q, ld] fp32 with ld = lrx_flat_ip_score_ld(N); columns >= N hold -FLT_MAX. */
+int64_t lrx_flat_ip_score_ld(int64_t n_rows);
+int lrx_flat_ip_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries,
+                       float* scores, void* stream);
+
+/* Merge R per-shard result lists (after the RCCL all-gather of [Q,k] pairs; replaces faiss IndexShards' host merge
+ * used via index_cpu_to_all_gpus, retriever/faiss_index.py:65-68) : in_scores/in_ids [R, Q, k] -> out [Q, k].    */
+int lrx_merge_topk(const float* in_scores, const int64_t* in_ids, int32_t n_parts, int32_t n_queries, int32_t k,
+                   float* out_scores, int64_t* out_ids, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRX_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of liblrx.so (include/lrx.h).  There is NO fallback: if the HIP library is missing or fails to load
+every entry point raises -- the product path never runs on a CPU/PyTorch substitute."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblrx.so")
+LRX_PROF_CLASSES = 7
+PROF_CLASS_NAMES = ["gemm_store", "gemm_resid", "gemm_swiglu", "attention", "rmsnorm", "rope", "other"]
+
+
+class LrxError(RuntimeError):
+    pass
+
+
+class EncoderConfigC(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_q_heads", C.c_int32),
+                ("num_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("intermediate_size", C.c_int32), ("rms_eps", C.c_float),
+                ("qkv_bias", C.c_int32), ("max_positions", C.c_int32)]
+
+
+class LayerWeightsC(C.Structure):
+    _fields_ = [("wqkv", C.c_void_p), ("bqkv", C.c_void_p), ("wo", C.c_void_p), ("wgu", C.c_void_p), ("wdown", C.c_void_p),
+                ("ln1", C.c_void_p), ("ln2", C.c_void_p)]
+
+
+class EncoderWeightsC(C.Structure):
+    _fields_ = [("embed", C.c_void_p), ("final_norm", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+                ("layers", C.POINTER(LayerWeightsC))]
+
+
+_P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes): exactly the entry points include/lrx.h declares
+SIGNATURES = {
+    "lrx_abi_version": (_I32, []),
+    "lrx_last_error": (C.c_char_p, []),
+    "lrx_encode_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I32, _I32]),
+    "lrx_encode_packed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),
+    "lrx_encode_hidden": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    "lrx_set_profiling": (None, [_I32]),
+    "lrx_get_profile": (_I32, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "lrx_embedding_gather": (_I32, [_P, _P, _I32, _I32, _P, _P]),
+    "lrx_rmsnorm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P]),
+    "lrx_gemm_bf16_nt": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "lrx_build_positions": (_I32, [_P, _I32, _I32, _P, _P]),
+    "lrx_rope_inplace": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "lrx_attn_varlen_causal": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "lrx_pool_norm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P]),
+    "lrx_embedding_bag_mean": (_I32, [_P, _I32, _I32, _P, _I64, _P, _I32, _I64, _P, _I64, _I32, _I32, _P]),
+    "lrx_flat_ip_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
+    "lrx_flat_ip_search": (_I32, [_P, _I64, _I64, _I32, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _P]),
+    "lrx_flat_ip_score_ld": (_I64, [_I64]),
+    "lrx_flat_ip_scores": (_I32, [_P, _I64, _I64, _I32, _P, _I32, _P, _P]),
+    "lrx_merge_topk": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load liblrx.so once.  Raises LrxError (never falls back) when the extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LrxError(f"{LIB_PATH} not found: build it with `python -m lightretriever_amd.build` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+        try:
+            l = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise LrxError(f"failed to load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        if l.lrx_abi_version() != 1:
+            raise LrxError("liblrx.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise LrxError(f"liblrx error {rc}: {lib().lrx_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise LrxError("lightretriever_amd needs a ROCm GPU (MI355X / gfx950); no CPU path exists")

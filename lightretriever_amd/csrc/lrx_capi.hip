@@ -1,0 +1,195 @@
+// C-ABI glue: error state, the fused encoder forward (launch sequence over the kernels in this directory), profiling.
+#include "lrx_common.h"
+#include <stdarg.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+void lrx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* lrx_last_error(void) { return g_err; }
+extern "C" int lrx_abi_version(void) { return LRX_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// profiling (HIP events on the caller's stream)
+// ---------------------------------------------------------------------------------------------------------------
+static bool g_prof = false;
+static float g_prof_ms[LRX_PROF_CLASSES];
+static double g_prof_flops[LRX_PROF_CLASSES];
+static int32_t g_prof_launches[LRX_PROF_CLASSES];
+struct ProfRec { hipEvent_t a, b; int cls; };
+static std::vector<hipEvent_t> g_ev_pool;
+static std::vector<ProfRec> g_recs;
+static size_t g_ev_used = 0;
+
+static hipEvent_t prof_event() {
+  if (g_ev_used == g_ev_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    g_ev_pool.push_back(e);
+  }
+  return g_ev_pool[g_ev_used++];
+}
+struct ProfScope {
+  hipStream_t s; int cls; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(hipStream_t s_, int cls_, double flops) : s(s_), cls(cls_) {
+    if (!g_prof) return;
+    a = prof_event(); b = prof_event();
+    if (a) (void)hipEventRecord(a, s);
+    g_prof_flops[cls] += flops;
+    g_prof_launches[cls] += 1;
+  }
+  ~ProfScope() {
+    if (!g_prof || !a || !b) return;
+    (void)hipEventRecord(b, s);
+    g_recs.push_back({a, b, cls});
+  }
+};
+static void prof_begin() {
+  if (!g_prof) return;
+  g_ev_used = 0;
+  g_recs.clear();
+  for (int i = 0; i < LRX_PROF_CLASSES; ++i) { g_prof_ms[i] = 0.f; g_prof_flops[i] = 0.0; g_prof_launches[i] = 0; }
+}
+static int prof_end(hipStream_t s) {
+  if (!g_prof) return LRX_OK;
+  LRX_HIP(hipStreamSynchronize(s));
+  for (auto& r : g_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) g_prof_ms[r.cls] += ms;
+  }
+  return LRX_OK;
+}
+extern "C" void lrx_set_profiling(int32_t enabled) { g_prof = enabled != 0; }
+extern "C" int lrx_get_profile(float* ms, double* flops, int32_t* launches) {
+  for (int i = 0; i < LRX_PROF_CLASSES; ++i) {
+    if (ms) ms[i] = g_prof_ms[i];
+    if (flops) flops[i] = g_prof_flops[i];
+    if (launches) launches[i] = g_prof_launches[i];
+  }
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// encoder forward
+// ---------------------------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct EncWs {
+  char *x, *h, *qkv, *act;
+  int32_t* pos;
+  size_t total;
+};
+static EncWs carve(const lrx_encoder_config* c, int64_t T, char* base) {
+  const int64_t H = c->hidden_size, QD = (int64_t)c->num_q_heads * c->head_dim;
+  const int64_t QKV = (int64_t)(c->num_q_heads + 2 * c->num_kv_heads) * c->head_dim, I = c->intermediate_size;
+  const int64_t HM = H > QD ? H : QD;
+  EncWs w;
+  size_t off = 0;
+  w.x = base + off; off += align_up((size_t)T * H * 2, 1024);
+  w.h = base + off; off += align_up((size_t)T * HM * 2, 1024);
+  w.qkv = base + off; off += align_up((size_t)T * QKV * 2, 1024);
+  w.act = base + off; off += align_up((size_t)T * I * 2, 1024);
+  w.pos = (int32_t*)(base + off); off += align_up((size_t)T * 4, 1024);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t lrx_encode_workspace_bytes(const lrx_encoder_config* cfg, int32_t total_tokens, int32_t n_seqs) {
+  (void)n_seqs;
+  if (!cfg) return 0;
+  return carve(cfg, total_tokens > 0 ? total_tokens : 1, nullptr).total;
+}
+
+static int check_cfg(const lrx_encoder_config* c) {
+  LRX_CHECK_ARG(c != nullptr, "encode: null config");
+  LRX_CHECK_ARG(c->hidden_size > 0 && c->hidden_size % 64 == 0, "encode: hidden_size=%d must be a multiple of 64", c->hidden_size);
+  LRX_CHECK_ARG(c->intermediate_size > 0 && c->intermediate_size % 64 == 0, "encode: intermediate_size=%d must be a multiple of 64",
+                c->intermediate_size);
+  LRX_CHECK_ARG(c->head_dim == 64 || c->head_dim == 128, "encode: head_dim=%d unsupported", c->head_dim);
+  LRX_CHECK_ARG(c->num_kv_heads > 0 && c->num_q_heads % c->num_kv_heads == 0, "encode: bad head counts %d/%d", c->num_q_heads, c->num_kv_heads);
+  LRX_CHECK_ARG(c->num_layers > 0 && c->vocab_size > 0 && c->max_positions > 0, "encode: bad config");
+  return LRX_OK;
+}
+
+// runs embedding + all layers; leaves the residual stream (before the final norm) in ws.x
+static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu, int n_seqs,
+                          int T, int max_seqlen, EncWs& ws, hipStream_t s) {
+  const int H = c->hidden_size, d = c->head_dim, nq = c->num_q_heads, nkv = c->num_kv_heads, I = c->intermediate_size;
+  const int QKV = (nq + 2 * nkv) * d, QD = nq * d;
+  int rc;
+  { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, ids, T, H, ws.x, s))) return rc; }
+  { ProfScope p(s, 6, 0); if ((rc = lrx_build_positions(cu, n_seqs, T, ws.pos, s))) return rc; }
+  // causal attention flops: sum over sequences is not known on the host without a sync; use the dense upper bound for
+  // equal-length batches: n_seqs * S*(S+1)/2 with S = T / n_seqs (exact when all sequences have the same length)
+  const double S = (double)T / (double)(n_seqs > 0 ? n_seqs : 1);
+  const double attn_flops = 2.0 * 2.0 * d * nq * (double)n_seqs * (S * (S + 1.0) / 2.0);
+  for (int l = 0; l < c->num_layers; ++l) {
+    const lrx_layer_weights& L = w->layers[l];
+    { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
+    { ProfScope p(s, 0, 2.0 * T * (double)QKV * H); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, nullptr, T, QKV, H, 0, s))) return rc; }
+    { ProfScope p(s, 5, 0); if ((rc = lrx_rope_inplace(ws.qkv, ws.pos, w->rope_cos, w->rope_sin, T, nq, nkv, d, s))) return rc; }
+    { ProfScope p(s, 3, attn_flops); if ((rc = lrx_attn_varlen_causal(ws.qkv, cu, n_seqs, T, max_seqlen, nq, nkv, d, ws.h, s))) return rc; }
+    { ProfScope p(s, 1, 2.0 * T * (double)H * QD); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wo, ws.x, nullptr, ws.x, T, H, QD, 1, s))) return rc; }
+    { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, T, H, c->rms_eps, s))) return rc; }
+    { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, s))) return rc; }
+    { ProfScope p(s, 1, 2.0 * T * (double)H * I); if ((rc = lrx_gemm_bf16_nt(ws.act, L.wdown, ws.x, nullptr, ws.x, T, H, I, 1, s))) return rc; }
+  }
+  return LRX_OK;
+}
+
+static int check_call(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu, int n_seqs, int T,
+                      int max_seqlen, void* workspace, size_t workspace_bytes) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  LRX_CHECK_ARG(w && w->embed && w->final_norm && w->rope_cos && w->rope_sin && w->layers, "encode: null weights");
+  LRX_CHECK_ARG(ids && cu && n_seqs > 0 && T > 0, "encode: empty batch (n_seqs=%d, tokens=%d)", n_seqs, T);
+  LRX_CHECK_ARG(max_seqlen > 0 && max_seqlen <= cfg->max_positions, "encode: max_seqlen=%d exceeds RoPE table (%d)", max_seqlen,
+                cfg->max_positions);
+  LRX_CHECK_ARG(workspace != nullptr, "encode: null workspace");
+  size_t need = lrx_encode_workspace_bytes(cfg, T, n_seqs);
+  if (workspace_bytes < need) {
+    lrx_set_error("encode: workspace %zu B < required %zu B", workspace_bytes, need);
+    return LRX_ERR_WORKSPACE;
+  }
+  return LRX_OK;
+}
+
+extern "C" int lrx_encode_packed(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,
+                                 int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, float* out, int64_t out_row_stride,
+                                 int32_t out_dim, int32_t normalize, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_call(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, workspace, workspace_bytes);
+  if (rc) return rc;
+  LRX_CHECK_ARG(out && out_dim > 0 && out_dim <= cfg->hidden_size && out_row_stride >= out_dim, "encode: bad output spec (dim=%d stride=%lld)",
+                out_dim, (long long)out_row_stride);
+  hipStream_t s = (hipStream_t)stream;
+  EncWs ws = carve(cfg, total_tokens, (char*)workspace);
+  prof_begin();
+  if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, s))) return rc;
+  {
+    ProfScope p(s, 6, 0);
+    if ((rc = lrx_pool_norm(ws.x, w->final_norm, cu_seqlens, n_seqs, cfg->hidden_size, cfg->rms_eps, out, out_row_stride, out_dim, normalize, s)))
+      return rc;
+  }
+  return prof_end(s);
+}
+
+extern "C" int lrx_encode_hidden(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,
+                                 int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, void* hidden_out_bf16, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  int rc = check_call(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, workspace, workspace_bytes);
+  if (rc) return rc;
+  LRX_CHECK_ARG(hidden_out_bf16 != nullptr, "encode_hidden: null output");
+  hipStream_t s = (hipStream_t)stream;
+  EncWs ws = carve(cfg, total_tokens, (char*)workspace);
+  prof_begin();
+  if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, s))) return rc;
+  {
+    ProfScope p(s, 4, 0);
+    if ((rc = lrx_rmsnorm(ws.x, w->final_norm, hidden_out_bf16, total_tokens, cfg->hidden_size, cfg->rms_eps, s))) return rc;
+  }
+  return prof_end(s);
+}

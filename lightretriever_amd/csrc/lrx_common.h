@@ -1,0 +1,55 @@
+// Shared device/host helpers for liblrx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/lrx.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define LRX_WAVE 64
+
+// bf16 <-> f32.  A plain cast lowers to v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950.
+__device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
+__device__ __forceinline__ __bf16 f2bf(float v) { return (__bf16)v; }
+__device__ __forceinline__ float bfbits2f(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// host-side error plumbing -----------------------------------------------------------------------------------
+void lrx_set_error(const char* fmt, ...);
+#define LRX_CHECK_ARG(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      lrx_set_error(__VA_ARGS__);         \
+      return LRX_ERR_INVALID;             \
+    }                                     \
+  } while (0)
+#define LRX_HIP(call)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      lrx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return LRX_ERR_HIP;                                                                 \
+    }                                                                                     \
+  } while (0)
+#define LRX_LAUNCH_CHECK() LRX_HIP(hipGetLastError())
+
+static inline int64_t lrx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,232 @@
+// Memory-bound row kernels of the encoder: embedding gather, RMSNorm, RoPE, positions, last-token pool + final norm +
+// L2 normalise, and the query-side EmbeddingBag(mean).  All bf16 traffic is 16 B per lane (Guideline 13).
+#include "lrx_common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// embedding gather: one wave per token row
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_embedding_gather(const bf16x8* __restrict__ table, const int32_t* __restrict__ ids,
+                                                          int n_tokens, int chunks /* H/8 */, bf16x8* __restrict__ out) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_tokens) return;
+  int lane = threadIdx.x & 63;
+  int64_t src = (int64_t)ids[row] * chunks;
+  int64_t dst = (int64_t)row * chunks;
+  for (int c = lane; c < chunks; c += 64) out[dst + c] = table[src + c];
+}
+
+extern "C" int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, void* out,
+                                    void* stream) {
+  LRX_CHECK_ARG(hidden % 8 == 0 && n_tokens >= 0, "embedding_gather: hidden %% 8 != 0");
+  if (n_tokens == 0) return LRX_OK;
+  hipLaunchKernelGGL(k_embedding_gather, dim3(lrx_cdiv(n_tokens, 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16x8*)table, ids, n_tokens, hidden / 8, (bf16x8*)out);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RMSNorm: one wave per row, row cached in registers (H <= 8192), HF rounding order:
+//   y = bf16( w * bf16( x * rsqrt(mean(x^2) + eps) ) )
+// ---------------------------------------------------------------------------------------------------------------
+#define RMS_MAXC 16
+__global__ void __launch_bounds__(256) k_rmsnorm(const bf16x8* __restrict__ x, const bf16x8* __restrict__ w, bf16x8* __restrict__ y,
+                                                 int rows, int chunks, float inv_h, float eps) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  int lane = threadIdx.x & 63;
+  const bf16x8* xr = x + (int64_t)row * chunks;
+  bf16x8 v[RMS_MAXC];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < RMS_MAXC; ++i) {
+    int c = lane + i * 64;
+    if (c < chunks) {
+      v[i] = xr[c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float f = bf2f(v[i][j]); ss += f * f; }
+    }
+  }
+  ss = wave_sum(ss);
+  float rstd = rsqrtf(ss * inv_h + eps);
+  bf16x8* yr = y + (int64_t)row * chunks;
+#pragma unroll
+  for (int i = 0; i < RMS_MAXC; ++i) {
+    int c = lane + i * 64;
+    if (c < chunks) {
+      bf16x8 wv = w[c], o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * bf2f(f2bf(bf2f(v[i][j]) * rstd)));
+      yr[c] = o;
+    }
+  }
+}
+
+extern "C" int lrx_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps, void* stream) {
+  LRX_CHECK_ARG(hidden % 8 == 0 && hidden / 8 <= 64 * RMS_MAXC, "rmsnorm: hidden=%d unsupported", hidden);
+  if (rows == 0) return LRX_OK;
+  hipLaunchKernelGGL(k_rmsnorm, dim3(lrx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, (const bf16x8*)w,
+                     (bf16x8*)y, rows, hidden / 8, 1.0f / (float)hidden, eps);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// positions[t] = t - cu[seq(t)]  (binary search; n_seqs is small)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_build_positions(const int32_t* __restrict__ cu, int n_seqs, int total, int32_t* __restrict__ pos) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int lo = 0, hi = n_seqs;  // find largest b with cu[b] <= t
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (cu[mid] <= t) lo = mid; else hi = mid;
+  }
+  pos[t] = t - cu[lo];
+}
+
+extern "C" int lrx_build_positions(const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t* positions,
+                                   void* stream) {
+  if (total_tokens == 0) return LRX_OK;
+  LRX_CHECK_ARG(n_seqs > 0, "build_positions: n_seqs must be > 0");
+  hipLaunchKernelGGL(k_build_positions, dim3(lrx_cdiv(total_tokens, 256)), dim3(256), 0, (hipStream_t)stream, cu_seqlens, n_seqs,
+                     total_tokens, positions);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RoPE in place on the q | k column blocks of qkv [T, (nq + 2nkv) * d].  One thread = 8 elements of the first half of a
+// head and the 8 paired elements of the second half.  cos/sin are the bf16-rounded table values (HF casts them to the
+// activation dtype); the rotation itself is done in fp32 and rounded once.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rope(bf16x8* __restrict__ qkv, const int32_t* __restrict__ pos, const float* __restrict__ cosT,
+                                              const float* __restrict__ sinT, int total, int rot_heads /* nq + nkv */, int row_chunks,
+                                              int half_chunks /* d/16 */) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int per_tok = rot_heads * half_chunks;
+  int64_t t = gid / per_tok;
+  if (t >= total) return;
+  int rem = (int)(gid - t * per_tok);
+  int head = rem / half_chunks, c = rem - head * half_chunks;
+  int p = pos[t];
+  int64_t base = t * row_chunks + (int64_t)head * (2 * half_chunks);
+  bf16x8 x1 = qkv[base + c], x2 = qkv[base + half_chunks + c];
+  const float* cs = cosT + (int64_t)p * (half_chunks * 8) + c * 8;
+  const float* sn = sinT + (int64_t)p * (half_chunks * 8) + c * 8;
+  bf16x8 o1, o2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float a = bf2f(x1[j]), b = bf2f(x2[j]), cc = cs[j], ss = sn[j];
+    o1[j] = f2bf(a * cc - b * ss);
+    o2[j] = f2bf(b * cc + a * ss);
+  }
+  qkv[base + c] = o1;
+  qkv[base + half_chunks + c] = o2;
+}
+
+extern "C" int lrx_rope_inplace(void* qkv, const int32_t* positions, const float* cos, const float* sin, int32_t total_tokens,
+                                int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* stream) {
+  LRX_CHECK_ARG(head_dim % 16 == 0, "rope: head_dim %% 16 != 0");
+  if (total_tokens == 0) return LRX_OK;
+  int rot_heads = num_q_heads + num_kv_heads;
+  int row_chunks = (num_q_heads + 2 * num_kv_heads) * head_dim / 8;
+  int half_chunks = head_dim / 16;
+  int64_t threads = (int64_t)total_tokens * rot_heads * half_chunks;
+  hipLaunchKernelGGL(k_rope, dim3(lrx_cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, (bf16x8*)qkv, positions, cos, sin,
+                     total_tokens, rot_heads, row_chunks, half_chunks);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// last-token pool + final RMSNorm (on the pooled rows only) + MRL slice + L2 normalise -> fp32 row.
+// One 256-thread block per sequence.  Row cached in LDS as fp32.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hidden, const __bf16* __restrict__ w,
+                                                   const int32_t* __restrict__ cu, int H, float eps, float* __restrict__ out,
+                                                   int64_t out_stride, int out_dim, int normalize) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* row = (float*)smem_raw;  // H floats
+  float* red = row + H;           // 4 floats
+  int b = blockIdx.x;
+  int64_t t = (int64_t)cu[b + 1] - 1;
+  const __bf16* x = hidden + t * H;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < H; i += 256) { float f = bf2f(x[i]); row[i] = f; ss += f * f; }
+  ss = block_sum_256(ss, red);
+  float rstd = rsqrtf(ss / (float)H + eps);
+  float n2 = 0.f;
+  for (int i = threadIdx.x; i < out_dim; i += 256) {
+    float y = bf2f(f2bf(bf2f(w[i]) * bf2f(f2bf(row[i] * rstd))));  // HF LlamaRMSNorm rounding order, bf16 result
+    row[i] = y;
+    n2 += y * y;
+  }
+  n2 = block_sum_256(n2, red);
+  float scale = normalize ? 1.0f / fmaxf(sqrtf(n2), 1e-12f) : 1.0f;
+  float* o = out + (int64_t)b * out_stride;
+  for (int i = threadIdx.x; i < out_dim; i += 256) o[i] = normalize ? row[i] * scale : row[i];
+}
+
+extern "C" int lrx_pool_norm(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
+                             int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize,
+                             void* stream) {
+  LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden_size, "pool_norm: out_dim=%d out of range (H=%d)", out_dim, hidden_size);
+  if (n_seqs == 0) return LRX_OK;
+  size_t smem = (size_t)(hidden_size + 4) * sizeof(float);
+  hipLaunchKernelGGL(k_pool_norm, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, (const __bf16*)hidden, (const __bf16*)final_norm_w,
+                     cu_seqlens, hidden_size, eps, out, out_row_stride, out_dim, normalize);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// EmbeddingBag(mode='mean', padding_idx): one block per bag, thread = column, ids walked in order (same fp32 summation
+// order as the sequential CPU kernel), then slice + optional L2 normalise.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_embedding_bag(const float* __restrict__ table, int vocab, int H, const int64_t* __restrict__ ids,
+                                                       int64_t n_ids, const int64_t* __restrict__ offsets, int n_bags, int64_t pad,
+                                                       float* __restrict__ out, int64_t out_stride, int out_dim, int normalize) {
+  __shared__ float red[4];
+  int b = blockIdx.x;
+  int64_t s = offsets[b], e = (b + 1 < n_bags) ? offsets[b + 1] : n_ids;
+  int cnt = 0;
+  for (int64_t i = s; i < e; ++i) cnt += (ids[i] != pad) ? 1 : 0;
+  float n2 = 0.f;
+  float* o = out + (int64_t)b * out_stride;
+  // out_dim <= H; each thread owns columns threadIdx.x + 256*j
+  for (int c = threadIdx.x; c < out_dim; c += 256) {
+    float acc = 0.f;
+    for (int64_t i = s; i < e; ++i) {
+      int64_t id = ids[i];
+      if (id != pad && id >= 0 && id < vocab) acc += table[id * (int64_t)H + c];
+    }
+    float m = cnt > 0 ? acc / (float)cnt : 0.f;
+    o[c] = m;
+    n2 += m * m;
+  }
+  if (!normalize) return;
+  n2 = block_sum_256(n2, red);
+  float scale = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+  for (int c = threadIdx.x; c < out_dim; c += 256) o[c] *= scale;  // same thread wrote o[c]
+}
+
+extern "C" int lrx_embedding_bag_mean(const float* table, int32_t vocab, int32_t hidden, const int64_t* ids, int64_t n_ids,
+                                      const int64_t* offsets, int32_t n_bags, int64_t padding_idx, float* out, int64_t out_row_stride,
+                                      int32_t out_dim, int32_t normalize, void* stream) {
+  LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden, "embedding_bag: out_dim=%d out of range (H=%d)", out_dim, hidden);
+  if (n_bags == 0) return LRX_OK;
+  hipLaunchKernelGGL(k_embedding_bag, dim3(n_bags), dim3(256), 0, (hipStream_t)stream, table, vocab, hidden, ids, n_ids, offsets, n_bags,
+                     padding_idx, out, out_row_stride, out_dim, normalize);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}

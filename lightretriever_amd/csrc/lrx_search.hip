@@ -1,0 +1,360 @@
+// Flat inner-product search over an HBM-resident fp32 corpus shard (replaces faiss.IndexFlatIP.search).
+//
+//  1. k_flat_ip_scores<QT>: scores[Q, ld] = q . X^T with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: bitwise an fp32 fma
+//     chain).  HBM-bound for Q <= ~48 (X is streamed exactly once per <=128 queries), fp32-matrix bound above.
+//     Workgroup = 4 waves x 64 corpus rows; X and q k-slices (32 floats = one 128-B line per row) are staged with
+//     16-byte global_load_lds into 2 LDS stages, XOR-swizzled on the source address for conflict-free ds_read_b128.
+//     The k summation order is permuted (lane group g of a 16-k block owns k = 4g..4g+3) so one ds_read_b128 feeds
+//     four MFMA steps; both operands use the same permutation.
+//  2. k_topk_select: one workgroup per query, exact 4 x 8-bit radix select of the k-th largest score, then an
+//     unordered gather of everything strictly greater plus the lowest-row-id ties, then an LDS bitonic sort on
+//     (score desc, row asc).  Deterministic output regardless of atomics order.
+//  3. k_merge_topk: merge of R per-shard [Q,k] lists (after the RCCL all-gather) with the same ordering rule.
+#include "lrx_common.h"
+#include <float.h>
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define S_ROWS 256       // corpus rows per workgroup
+#define S_BK 32          // floats per k-slice (128 B per row)
+#define S_XTILE (S_ROWS * S_BK * 4)
+
+template <int QT>
+__global__ void __launch_bounds__(256, 1)
+k_flat_ip_scores(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ Q, int nq,
+                 float* __restrict__ scores, int64_t ld) {
+  constexpr int QTILE = QT * 16 * S_BK * 4;
+  constexpr int STAGE = S_XTILE + QTILE;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n0 = (int64_t)blockIdx.x * S_ROWS;
+
+  // staging sources.  X: 32 wave instructions per tile (8 per wave); q: 2*QT instructions (round-robin over waves)
+  const float* px[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int s = (wave * 8 + i) * 64 + lane;
+    int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
+    int64_t g = min(n0 + row, N - 1);
+    px[i] = X + g * ldx + c * 4;
+  }
+  constexpr int QI = (2 * QT + 3) / 4;  // q instructions per wave (upper bound)
+  const float* pq[QI];
+#pragma unroll
+  for (int i = 0; i < QI; ++i) {
+    int j = wave + 4 * i;
+    int s = j * 64 + lane;
+    int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
+    int g = min(row, nq - 1);
+    pq[i] = Q + (int64_t)g * D + c * 4;
+  }
+  auto stage = [&](int st, int k0) {
+    char* sX = smem + st * STAGE;
+    char* sQ = sX + S_XTILE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + k0), (lptr_t)(sX + (wave * 8 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+      int j = wave + 4 * i;
+      if (j < 2 * QT) __builtin_amdgcn_global_load_lds((gptr_t)(pq[i] + k0), (lptr_t)(sQ + j * 1024), 16, 0, 0);
+    }
+  };
+
+  const int fi = lane & 15, fg = lane >> 4;
+  int loff[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) loff[kb] = fi * 128 + (((kb * 4 + fg) ^ (fi >> 1)) << 4);
+
+  f32x4 acc[4][QT];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = D / S_BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * S_BK);
+    const char* sX = smem + cur * STAGE + (wave * 64) * 128;
+    const char* sQ = smem + cur * STAGE + S_XTILE;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 xf[4], qf[QT];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xf[a] = *(const f32x4*)(sX + a * 2048 + loff[kb]);
+#pragma unroll
+      for (int b = 0; b < QT; ++b) qf[b] = *(const f32x4*)(sQ + b * 2048 + loff[kb]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < QT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[a][t], qf[b][t], acc[a][b], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // D[i = corpus row][j = query]: lane holds query j = fi, rows fg*4 + {0..3}
+#pragma unroll
+  for (int b = 0; b < QT; ++b) {
+    int qi = b * 16 + fi;
+    if (qi >= nq) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int64_t n = n0 + wave * 64 + a * 16 + fg * 4;
+      f32x4 v = acc[a][b];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e >= N) v[e] = -FLT_MAX;
+      *(f32x4*)(scores + (int64_t)qi * ld + n) = v;
+    }
+  }
+}
+
+extern "C" int64_t lrx_flat_ip_score_ld(int64_t n_rows) { return lrx_cdiv(n_rows > 0 ? n_rows : 1, S_ROWS) * S_ROWS; }
+
+extern "C" int lrx_flat_ip_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries,
+                                  float* scores, void* stream) {
+  LRX_CHECK_ARG(dim > 0 && dim % S_BK == 0, "flat_ip: dim=%d must be a multiple of %d", dim, S_BK);
+  LRX_CHECK_ARG(ldx >= dim && ldx % 4 == 0, "flat_ip: ldx=%lld must be >= dim and a multiple of 4", (long long)ldx);
+  if (n_rows <= 0 || n_queries <= 0) return LRX_OK;
+  const int64_t ld = lrx_flat_ip_score_ld(n_rows);
+  dim3 grid((unsigned)(ld / S_ROWS)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  for (int q0 = 0; q0 < n_queries; q0 += 128) {
+    int nq = n_queries - q0 < 128 ? n_queries - q0 : 128;
+    int qt = (nq + 15) / 16;
+    const float* qp = q + (int64_t)q0 * dim;
+    float* sp = scores + (int64_t)q0 * ld;
+#define LRX_SC(QQ) case QQ: hipLaunchKernelGGL(k_flat_ip_scores<QQ>, grid, block, 0, s, X, n_rows, ldx, dim, qp, nq, sp, ld); break;
+    switch (qt) { LRX_SC(1) LRX_SC(2) LRX_SC(3) LRX_SC(4) LRX_SC(5) LRX_SC(6) LRX_SC(7) LRX_SC(8) }
+#undef LRX_SC
+    LRX_LAUNCH_CHECK();
+  }
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// top-k select
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2key(float f) {  // monotone: larger float -> larger key
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(u);
+}
+
+// sort buf[0..P) descending (P power of two), all threads of the block participate
+__device__ void bitonic_sort_desc(unsigned long long* buf, int P) {
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long a = buf[i], b = buf[ixj];
+          bool up = (i & k) == 0;  // descending overall
+          if (up ? (a < b) : (a > b)) { buf[i] = b; buf[ixj] = a; }
+        }
+      }
+    }
+  __syncthreads();
+}
+
+#define SEL_THREADS 1024
+#define SEL_MAXK 2048
+#define SEL_EQCAP 2048
+
+__global__ void __launch_bounds__(SEL_THREADS)
+k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base, float* __restrict__ out_scores,
+              int64_t* __restrict__ out_ids) {
+  __shared__ unsigned int hist[16][256];
+  __shared__ unsigned long long cand[SEL_MAXK];
+  __shared__ unsigned int eqidx[SEL_EQCAP];
+  __shared__ unsigned int sh_bucket, sh_kk, sh_cnt, sh_ngt, sh_neq;
+  const float* row = scores + (int64_t)blockIdx.x * ld;
+  float* os = out_scores + (int64_t)blockIdx.x * k;
+  int64_t* oi = out_ids + (int64_t)blockIdx.x * k;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
+  for (int i = keff + tid; i < k; i += SEL_THREADS) { os[i] = -FLT_MAX; oi[i] = -1; }
+  if (keff == 0) return;
+
+  // ---- exact radix select of the keff-th largest key
+  uint32_t prefix = 0, mask = 0;
+  unsigned int kk = keff;  // rank (1-based, from the top) inside the current prefix bucket
+  unsigned int neq = 0;
+  const int64_t N4 = N >> 2;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 16 * 256; i += SEL_THREADS) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < N4; i += SEL_THREADS) {
+      f32x4 v = *(const f32x4*)(row + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t key = f2key(v[e]);
+        if ((key & mask) == prefix) atomicAdd(&hist[wave][(key >> shift) & 255], 1u);
+      }
+    }
+    for (int64_t i = 4 * N4 + tid; i < N; i += SEL_THREADS) {
+      uint32_t key = f2key(row[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[wave][(key >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (tid < 256) {
+      unsigned int sum = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) sum += hist[w][tid];
+      hist[0][tid] = sum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int cum = 0;
+      int bsel = 0;
+      for (int bkt = 255; bkt >= 0; --bkt) {
+        unsigned int c = hist[0][bkt];
+        if (cum + c >= kk) { bsel = bkt; sh_kk = kk - cum; sh_cnt = c; break; }
+        cum += c;
+      }
+      sh_bucket = bsel;
+    }
+    __syncthreads();
+    prefix |= (uint32_t)sh_bucket << shift;
+    mask |= 0xFFu << shift;
+    kk = sh_kk;
+    neq = sh_cnt;
+    __syncthreads();
+  }
+  const uint32_t kth = prefix;          // key of the keff-th largest element
+  const unsigned int need_eq = kk;      // how many elements equal to kth belong to the result (lowest row ids first)
+  const unsigned int ngt = keff - kk;   // elements strictly greater
+  if (tid == 0) { sh_ngt = 0; sh_neq = 0; }
+  __syncthreads();
+
+  // ---- gather: everything > kth (unordered), ties == kth (unordered, capped) -> deterministic after sorting
+  const bool eq_fits = neq <= SEL_EQCAP;
+  for (int64_t i = tid; i < N; i += SEL_THREADS) {
+    uint32_t key = f2key(row[i]);
+    if (key > kth) {
+      unsigned int p = atomicAdd(&sh_ngt, 1u);
+      cand[p] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+    } else if (key == kth && eq_fits) {
+      unsigned int p = atomicAdd(&sh_neq, 1u);
+      eqidx[p] = (uint32_t)i;
+    }
+  }
+  __syncthreads();
+  if (eq_fits) {
+    // smallest `need_eq` row ids among the ties: sort eqidx ascending == sort (~idx) descending
+    int P = 1;
+    while (P < (int)neq) P <<= 1;
+    __shared__ unsigned long long eqs[SEL_EQCAP];
+    for (int i = tid; i < P; i += SEL_THREADS) eqs[i] = i < (int)neq ? (unsigned long long)(0xFFFFFFFFu - eqidx[i]) : 0ull;
+    bitonic_sort_desc(eqs, P);
+    for (int i = tid; i < (int)need_eq; i += SEL_THREADS) cand[ngt + i] = ((unsigned long long)kth << 32) | eqs[i];
+  } else {
+    // massive tie (degenerate data): ordered scan by one wave, lowest row ids first
+    if (tid < 64) {
+      unsigned int taken = 0;
+      for (int64_t base = 0; base < N && taken < need_eq; base += 64) {
+        int64_t i = base + tid;
+        bool hit = i < N && f2key(row[i]) == kth;
+        unsigned long long bal = __ballot(hit);
+        unsigned int before = __popcll(bal & ((1ull << tid) - 1ull));
+        if (hit && taken + before < need_eq)
+          cand[ngt + taken + before] = ((unsigned long long)kth << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+        taken += __popcll(bal);
+      }
+    }
+  }
+  __syncthreads();
+  int P = 1;
+  while (P < keff) P <<= 1;
+  for (int i = keff + tid; i < P; i += SEL_THREADS) cand[i] = 0ull;
+  bitonic_sort_desc(cand, P);
+  for (int i = tid; i < keff; i += SEL_THREADS) {
+    unsigned long long c = cand[i];
+    os[i] = key2f((uint32_t)(c >> 32));
+    oi[i] = id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
+  }
+}
+
+extern "C" size_t lrx_flat_ip_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
+  (void)dim; (void)k;
+  return (size_t)lrx_flat_ip_score_ld(n_rows) * (size_t)(n_queries > 0 ? n_queries : 1) * sizeof(float);
+}
+
+extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, int32_t k,
+                                  int64_t id_base, float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  LRX_CHECK_ARG(k > 0 && k <= SEL_MAXK, "flat_ip_search: k=%d out of range (1..%d)", k, SEL_MAXK);
+  LRX_CHECK_ARG(n_rows >= 0 && n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
+  if (n_queries <= 0) return LRX_OK;
+  if (workspace_bytes < lrx_flat_ip_workspace_bytes(n_rows, dim, n_queries, k)) {
+    lrx_set_error("flat_ip_search: workspace %zu B < required %zu B", workspace_bytes, lrx_flat_ip_workspace_bytes(n_rows, dim, n_queries, k));
+    return LRX_ERR_WORKSPACE;
+  }
+  float* scores = (float*)workspace;
+  int rc = lrx_flat_ip_scores(X, n_rows, ldx, dim, q, n_queries, scores, stream);
+  if (rc != LRX_OK) return rc;
+  hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, scores, lrx_flat_ip_score_ld(n_rows), n_rows, k,
+                     id_base, out_scores, out_ids);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// merge of R shard-local top-k lists
+// ---------------------------------------------------------------------------------------------------------------
+#define MERGE_MAX 8192
+__global__ void __launch_bounds__(1024)
+k_merge_topk(const float* __restrict__ in_scores, const int64_t* __restrict__ in_ids, int R, int Q, int k, float* __restrict__ out_scores,
+             int64_t* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  unsigned long long* buf = (unsigned long long*)smem_raw;
+  const int qi = blockIdx.x, n = R * k;
+  int P = 1;
+  while (P < n) P <<= 1;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    unsigned long long c = 0ull;
+    if (i < n) {
+      int rr = i / k, j = i - rr * k;
+      int64_t src = ((int64_t)rr * Q + qi) * k + j;
+      int64_t id = in_ids[src];
+      if (id >= 0) c = ((unsigned long long)f2key(in_scores[src]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+    }
+    buf[i] = c;
+  }
+  bitonic_sort_desc(buf, P);
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    unsigned long long c = i < P ? buf[i] : 0ull;
+    int64_t o = (int64_t)qi * k + i;
+    if (c == 0ull) { out_scores[o] = -FLT_MAX; out_ids[o] = -1; }
+    else { out_scores[o] = key2f((uint32_t)(c >> 32)); out_ids[o] = (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull)); }
+  }
+}
+
+extern "C" int lrx_merge_topk(const float* in_scores, const int64_t* in_ids, int32_t n_parts, int32_t n_queries, int32_t k,
+                              float* out_scores, int64_t* out_ids, void* stream) {
+  LRX_CHECK_ARG(n_parts > 0 && k > 0 && (int64_t)n_parts * k <= MERGE_MAX, "merge_topk: parts*k=%lld exceeds %d", (long long)n_parts * k, MERGE_MAX);
+  if (n_queries <= 0) return LRX_OK;
+  int P = 1;
+  while (P < n_parts * k) P <<= 1;
+  size_t smem = (size_t)P * 8;
+  if (smem > 48 * 1024) {
+    LRX_HIP(hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  }
+  hipLaunchKernelGGL(k_merge_topk, dim3(n_queries), dim3(1024), smem, (hipStream_t)stream, in_scores, in_ids, n_parts, n_queries, k, out_scores,
+                     out_ids);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}

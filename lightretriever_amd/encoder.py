@@ -1,0 +1,237 @@
+"""Document-side encoder on MI355X: weight packing + the lrx_encode_* entry points.
+
+Host-side mirror of what the reference does around its LM call: load weights (finetune/modeling_encoder.py:602-633, LoRA
+merge :616-625 restated as W + (alpha/r) B A), build the RoPE table (transformers modeling_rope_utils: default and
+llama3 scaling), then run HybridModel.encode_passage's dense branch (finetune/modeling_hybrid.py:205-278) -- here one
+call into liblrx.so on a packed (ids, cu_seqlens) batch."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class EncoderConfig:
+    vocab_size: int
+    hidden_size: int
+    num_layers: int
+    num_q_heads: int
+    num_kv_heads: int
+    head_dim: int
+    intermediate_size: int
+    rms_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_type: str = "default"
+    rope_factor: float = 32.0
+    rope_low_freq_factor: float = 1.0
+    rope_high_freq_factor: float = 4.0
+    rope_original_max_position: int = 8192
+    qkv_bias: bool = False
+    max_positions: int = 512
+
+    @staticmethod
+    def llama32_1b(max_positions: int = 512) -> "EncoderConfig":
+        return EncoderConfig(128256, 2048, 16, 32, 8, 64, 8192, 1e-5, 500000.0, "llama3", 32.0, 1.0, 4.0, 8192, False, max_positions)
+
+    @staticmethod
+    def llama31_8b(max_positions: int = 512) -> "EncoderConfig":
+        return EncoderConfig(128256, 4096, 32, 32, 8, 128, 14336, 1e-5, 500000.0, "llama3", 8.0, 1.0, 4.0, 8192, False, max_positions)
+
+    @staticmethod
+    def from_hf_dict(c: dict, max_positions: int = 512) -> "EncoderConfig":
+        """Fields of an HF Llama/Qwen2 config.json (transformers 4.x `rope_scaling` or 5.x `rope_parameters`)."""
+        rp = c.get("rope_parameters") or c.get("rope_scaling") or {}
+        rt = rp.get("rope_type", rp.get("type", "default")) or "default"
+        nq = c["num_attention_heads"]
+        return EncoderConfig(
+            vocab_size=c["vocab_size"], hidden_size=c["hidden_size"], num_layers=c["num_hidden_layers"], num_q_heads=nq,
+            num_kv_heads=c.get("num_key_value_heads", nq), head_dim=c.get("head_dim") or c["hidden_size"] // nq,
+            intermediate_size=c["intermediate_size"], rms_eps=c.get("rms_norm_eps", 1e-5),
+            rope_theta=float(rp.get("rope_theta", c.get("rope_theta", 10000.0))), rope_type=rt,
+            rope_factor=float(rp.get("factor", 1.0)), rope_low_freq_factor=float(rp.get("low_freq_factor", 1.0)),
+            rope_high_freq_factor=float(rp.get("high_freq_factor", 4.0)),
+            rope_original_max_position=int(rp.get("original_max_position_embeddings", 8192)),
+            qkv_bias=c.get("model_type", "") == "qwen2" or bool(c.get("attention_bias", False)), max_positions=max_positions)
+
+    def flops_per_doc(self, seq_len: int) -> float:
+        """Algorithmic bf16 FLOPs per document, F(S) = 2 S P_ne + 2 L S^2 H."""
+        d = self.head_dim
+        p_layer = (self.hidden_size * (self.num_q_heads + 2 * self.num_kv_heads) * d + self.num_q_heads * d * self.hidden_size
+                   + 3 * self.hidden_size * self.intermediate_size + 2 * self.hidden_size)
+        p_ne = self.num_layers * p_layer + self.hidden_size
+        return 2.0 * seq_len * p_ne + 2.0 * self.num_layers * seq_len * seq_len * self.hidden_size
+
+
+def rope_tables(cfg: EncoderConfig) -> tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin [max_positions, d/2] fp32, values rounded to bf16 (HF casts cos/sin to the activation dtype)."""
+    d = cfg.head_dim
+    inv = 1.0 / (torch.tensor(cfg.rope_theta, dtype=torch.float32) ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
+    if cfg.rope_type == "llama3":
+        old = cfg.rope_original_max_position
+        low_wl, high_wl = old / cfg.rope_low_freq_factor, old / cfg.rope_high_freq_factor
+        wavelen = 2 * math.pi / inv
+        inv_l = torch.where(wavelen > low_wl, inv / cfg.rope_factor, inv)
+        smooth = (old / wavelen - cfg.rope_low_freq_factor) / (cfg.rope_high_freq_factor - cfg.rope_low_freq_factor)
+        smoothed = (1 - smooth) * inv_l / cfg.rope_factor + smooth * inv_l
+        medium = ~(wavelen < high_wl) & ~(wavelen > low_wl)
+        inv = torch.where(medium, smoothed, inv_l)
+    elif cfg.rope_type != "default":
+        raise NotImplementedError(f"rope_type {cfg.rope_type}")
+    pos = torch.arange(cfg.max_positions, dtype=torch.float32)
+    freqs = pos[:, None] * inv[None, :].float()
+    return freqs.cos().to(torch.bfloat16).float().contiguous(), freqs.sin().to(torch.bfloat16).float().contiguous()
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[I,H],[I,H] -> [2I,H] with 32-row groups alternating gate/up (the layout lrx_gemm's SwiGLU epilogue expects)."""
+    I, H = gate.shape
+    assert I % 32 == 0
+    return torch.stack([gate.view(I // 32, 32, H), up.view(I // 32, 32, H)], dim=1).reshape(2 * I, H).contiguous()
+
+
+def lora_merge(W: torch.Tensor, A: torch.Tensor, B: torch.Tensor, alpha: float, r: int) -> torch.Tensor:
+    """peft merge_and_unload for one Linear: W + (alpha / r) * B @ A   (finetune/modeling_encoder.py:616-625)."""
+    return (W.float() + (alpha / r) * (B.float() @ A.float())).to(W.dtype)
+
+
+class LrxEncoder:
+    """Weights resident in HBM as bf16 + a reusable workspace; encode_packed() is the B3 operator of SURVEY.md 8b."""
+
+    def __init__(self, cfg: EncoderConfig, state_dict: dict, device: Optional[torch.device] = None):
+        """state_dict: HF names without the leading `model.` (embed_tokens.weight, layers.N.self_attn.q_proj.weight, ...);
+        values are torch tensors or numpy arrays (any float dtype) -- cast to bf16 and packed here."""
+        _lib.require_gpu()
+        self.lib = _lib.lib()
+        self.cfg = cfg
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        bf = torch.bfloat16
+
+        def g(name):
+            v = state_dict[name]
+            if not isinstance(v, torch.Tensor):
+                v = torch.from_numpy(v)
+            return v
+
+        def dev(t):
+            return t.to(device=self.device, dtype=bf).contiguous()
+
+        self.embed = dev(g("embed_tokens.weight"))
+        self.final_norm = dev(g("norm.weight"))
+        cos, sin = rope_tables(cfg)
+        self.rope_cos, self.rope_sin = cos.to(self.device), sin.to(self.device)
+        self.layers = []
+        for i in range(cfg.num_layers):
+            p = f"layers.{i}."
+            wqkv = torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"), g(p + "self_attn.v_proj.weight")], 0)
+            bqkv = None
+            if cfg.qkv_bias:
+                bqkv = dev(torch.cat([g(p + "self_attn.q_proj.bias"), g(p + "self_attn.k_proj.bias"), g(p + "self_attn.v_proj.bias")], 0))
+            self.layers.append(dict(
+                wqkv=dev(wqkv), bqkv=bqkv, wo=dev(g(p + "self_attn.o_proj.weight")),
+                wgu=dev(interleave_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"))),
+                wdown=dev(g(p + "mlp.down_proj.weight")), ln1=dev(g(p + "input_layernorm.weight")),
+                ln2=dev(g(p + "post_attention_layernorm.weight"))))
+        self._build_c_structs()
+        self._ws = None
+
+    @classmethod
+    def random_init(cls, cfg: EncoderConfig, seed: int = 0, std: float = 0.02, device: Optional[torch.device] = None) -> "LrxEncoder":
+        """Random weights of the real architecture generated directly on the GPU (benchmarks: no checkpoints offline)."""
+        _lib.require_gpu()
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        gen = torch.Generator(device=device).manual_seed(seed)
+        H, d, I = cfg.hidden_size, cfg.head_dim, cfg.intermediate_size
+
+        def rn(*shape, s=std):
+            return (torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * s).to(torch.bfloat16)
+
+        sd = {"embed_tokens.weight": rn(cfg.vocab_size, H), "norm.weight": (1.0 + rn(H)).to(torch.bfloat16)}
+        for i in range(cfg.num_layers):
+            p = f"layers.{i}."
+            sd[p + "self_attn.q_proj.weight"] = rn(cfg.num_q_heads * d, H)
+            sd[p + "self_attn.k_proj.weight"] = rn(cfg.num_kv_heads * d, H)
+            sd[p + "self_attn.v_proj.weight"] = rn(cfg.num_kv_heads * d, H)
+            sd[p + "self_attn.o_proj.weight"] = rn(H, cfg.num_q_heads * d)
+            sd[p + "mlp.gate_proj.weight"] = rn(I, H)
+            sd[p + "mlp.up_proj.weight"] = rn(I, H)
+            sd[p + "mlp.down_proj.weight"] = rn(H, I)
+            sd[p + "input_layernorm.weight"] = (1.0 + rn(H)).to(torch.bfloat16)
+            sd[p + "post_attention_layernorm.weight"] = (1.0 + rn(H)).to(torch.bfloat16)
+            if cfg.qkv_bias:
+                sd[p + "self_attn.q_proj.bias"] = rn(cfg.num_q_heads * d)
+                sd[p + "self_attn.k_proj.bias"] = rn(cfg.num_kv_heads * d)
+                sd[p + "self_attn.v_proj.bias"] = rn(cfg.num_kv_heads * d)
+        return cls(cfg, sd, device)
+
+    def _build_c_structs(self):
+        c = self.cfg
+        self._ccfg = _lib.EncoderConfigC(c.vocab_size, c.hidden_size, c.num_layers, c.num_q_heads, c.num_kv_heads, c.head_dim,
+                                         c.intermediate_size, c.rms_eps, int(c.qkv_bias), c.max_positions)
+        arr = (_lib.LayerWeightsC * c.num_layers)()
+        for i, L in enumerate(self.layers):
+            arr[i] = _lib.LayerWeightsC(L["wqkv"].data_ptr(), L["bqkv"].data_ptr() if L["bqkv"] is not None else None,
+                                        L["wo"].data_ptr(), L["wgu"].data_ptr(), L["wdown"].data_ptr(), L["ln1"].data_ptr(),
+                                        L["ln2"].data_ptr())
+        self._clayers = arr
+        self._cw = _lib.EncoderWeightsC(self.embed.data_ptr(), self.final_norm.data_ptr(), self.rope_cos.data_ptr(),
+                                        self.rope_sin.data_ptr(), C.cast(arr, C.POINTER(_lib.LayerWeightsC)))
+
+    def workspace_bytes(self, total_tokens: int, n_seqs: int) -> int:
+        return int(self.lib.lrx_encode_workspace_bytes(C.byref(self._ccfg), total_tokens, n_seqs))
+
+    def _workspace(self, total_tokens: int, n_seqs: int) -> torch.Tensor:
+        need = self.workspace_bytes(total_tokens, n_seqs)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    @staticmethod
+    def _check_batch(ids: torch.Tensor, cu_seqlens: torch.Tensor):
+        if ids.dtype != torch.int32 or cu_seqlens.dtype != torch.int32:
+            raise TypeError("ids and cu_seqlens must be int32 device tensors")
+        if not (ids.is_cuda and cu_seqlens.is_cuda and ids.is_contiguous() and cu_seqlens.is_contiguous()):
+            raise ValueError("ids and cu_seqlens must be contiguous CUDA tensors")
+
+    def encode_packed(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, out: Optional[torch.Tensor] = None,
+                      out_dim: Optional[int] = None, normalize: bool = True) -> torch.Tensor:
+        """ids int32 [T], cu_seqlens int32 [B+1] (device).  Writes fp32 [B, out_dim] rows into `out` (e.g. a slice of the
+        index shard: no host round trip) and returns it."""
+        self._check_batch(ids, cu_seqlens)
+        T, B = ids.numel(), cu_seqlens.numel() - 1
+        D = out_dim or self.cfg.hidden_size
+        if out is None:
+            out = torch.empty(B, D, dtype=torch.float32, device=self.device)
+        if out.dtype != torch.float32 or out.shape[0] < B or out.shape[1] < D or out.stride(1) != 1:
+            raise ValueError("out must be fp32 [>=B, >=out_dim] with unit inner stride")
+        ws = self._workspace(T, B)
+        _lib.check(self.lib.lrx_encode_packed(C.byref(self._ccfg), C.byref(self._cw), _lib.ptr(ids), _lib.ptr(cu_seqlens), B, T,
+                                              int(max_seqlen), _lib.ptr(out), out.stride(0), D, int(normalize), _lib.ptr(ws),
+                                              ws.numel(), _lib.current_stream()))
+        return out[:B, :D]
+
+    def encode_hidden(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int) -> torch.Tensor:
+        """last_hidden_state (after the final norm) bf16 [T, H]."""
+        self._check_batch(ids, cu_seqlens)
+        T, B = ids.numel(), cu_seqlens.numel() - 1
+        out = torch.empty(T, self.cfg.hidden_size, dtype=torch.bfloat16, device=self.device)
+        ws = self._workspace(T, B)
+        _lib.check(self.lib.lrx_encode_hidden(C.byref(self._ccfg), C.byref(self._cw), _lib.ptr(ids), _lib.ptr(cu_seqlens), B, T,
+                                              int(max_seqlen), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+        return out
+
+    # profiling hooks used by bench.py ------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self.lib.lrx_set_profiling(int(on))
+
+    def get_profile(self) -> dict:
+        n = _lib.LRX_PROF_CLASSES
+        ms, fl, la = (C.c_float * n)(), (C.c_double * n)(), (C.c_int32 * n)()
+        self.lib.lrx_get_profile(ms, fl, la)
+        return {name: {"ms": ms[i], "flops": fl[i], "launches": la[i]} for i, name in enumerate(_lib.PROF_CLASS_NAMES)}

@@ -1,0 +1,92 @@
+"""HBM-resident flat inner-product index shard: the faiss.IndexFlatIP surface the reference uses
+(retriever/faiss_index.py:20-73: add / search / reset / ntotal), backed by lrx_flat_ip_search."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+class FlatIPIndex:
+    def __init__(self, d: int, capacity: int = 0, device: Optional[torch.device] = None, id_base: int = 0):
+        _lib.require_gpu()
+        if d % 32 != 0:
+            raise ValueError(f"FlatIPIndex: d={d} must be a multiple of 32")
+        self.lib = _lib.lib()
+        self.d = d
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.ntotal = 0
+        self.id_base = id_base  # added to local row numbers (global row of this shard's row 0)
+        self._x = torch.empty(max(capacity, 0), d, dtype=torch.float32, device=self.device)
+        self._ws = None
+
+    # -- storage -------------------------------------------------------------------------------------------------
+    def reserve(self, n_rows: int):
+        if n_rows > self._x.shape[0]:
+            new = torch.empty(n_rows, self.d, dtype=torch.float32, device=self.device)
+            if self.ntotal:
+                new[:self.ntotal].copy_(self._x[:self.ntotal])
+            self._x = new
+
+    def append_slot(self, n_rows: int) -> torch.Tensor:
+        """Rows [ntotal, ntotal+n) of the shard as a writable view (the encoder writes embeddings straight into it);
+        call commit(n) afterwards."""
+        if self.ntotal + n_rows > self._x.shape[0]:
+            self.reserve(max(self.ntotal + n_rows, int(self._x.shape[0] * 1.5) + 1))
+        return self._x[self.ntotal:self.ntotal + n_rows]
+
+    def commit(self, n_rows: int):
+        self.ntotal += n_rows
+
+    def add(self, x):
+        """faiss add(x f32[n,d]); accepts torch (any device) or numpy."""
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(x)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"add: expected [n,{self.d}], got {tuple(x.shape)}")
+        slot = self.append_slot(x.shape[0])
+        slot.copy_(x.to(dtype=torch.float32))
+        self.commit(x.shape[0])
+
+    def reset(self):
+        self.ntotal = 0
+
+    @property
+    def vectors(self) -> torch.Tensor:
+        return self._x[:self.ntotal]
+
+    # -- search --------------------------------------------------------------------------------------------------
+    def search(self, q, k: int):
+        """-> (D f32[Q,k], I i64[Q,k]) device tensors, descending scores, ids = id_base + row, ties -> lower id,
+        (-FLT_MAX, -1) padding when k > ntotal."""
+        if not isinstance(q, torch.Tensor):
+            q = torch.from_numpy(q)
+        q = q.to(device=self.device, dtype=torch.float32).contiguous()
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"search: expected [Q,{self.d}], got {tuple(q.shape)}")
+        Q = q.shape[0]
+        D = torch.empty(Q, k, dtype=torch.float32, device=self.device)
+        I = torch.empty(Q, k, dtype=torch.int64, device=self.device)
+        if Q == 0:
+            return D, I
+        need = int(self.lib.lrx_flat_ip_workspace_bytes(self.ntotal, self.d, Q, k))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, self._x.stride(0) if self._x.shape[0] else self.d,
+                                               self.d, _lib.ptr(q), Q, k, self.id_base, _lib.ptr(D), _lib.ptr(I), _lib.ptr(self._ws),
+                                               self._ws.numel(), _lib.current_stream()))
+        return D, I
+
+
+def merge_topk(D_parts: torch.Tensor, I_parts: torch.Tensor):
+    """[R,Q,k] per-shard lists -> ([Q,k], [Q,k]) with the same ordering rule (score desc, id asc)."""
+    lib = _lib.lib()
+    R, Q, k = D_parts.shape
+    D_parts, I_parts = D_parts.contiguous(), I_parts.contiguous()
+    D = torch.empty(Q, k, dtype=torch.float32, device=D_parts.device)
+    I = torch.empty(Q, k, dtype=torch.int64, device=D_parts.device)
+    _lib.check(lib.lrx_merge_topk(_lib.ptr(D_parts), _lib.ptr(I_parts), R, Q, k, _lib.ptr(D), _lib.ptr(I), _lib.current_stream()))
+    return D, I

@@ -1,0 +1,84 @@
+"""Thin torch-tensor wrappers over the individual liblrx kernels (unit tests, query side, EmbeddingBag construction)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _s():
+    return _lib.current_stream()
+
+
+def embedding_gather(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(ids.numel(), table.shape[1], dtype=torch.bfloat16, device=table.device)
+    _lib.check(_lib.lib().lrx_embedding_gather(_lib.ptr(table), _lib.ptr(ids), ids.numel(), table.shape[1], _lib.ptr(out), _s()))
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().lrx_rmsnorm(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), x.shape[0], x.shape[1], eps, _s()))
+    return y
+
+
+def gemm_bf16_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+                 epilogue: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    M, K = A.shape
+    N = B.shape[0]
+    assert B.shape[1] == K and A.is_contiguous() and B.is_contiguous()
+    if out is None:
+        out = torch.empty(M, N // 2 if epilogue == 2 else N, dtype=torch.bfloat16, device=A.device)
+    _lib.check(_lib.lib().lrx_gemm_bf16_nt(_lib.ptr(A), _lib.ptr(B), _lib.ptr(out), _lib.ptr(bias), _lib.ptr(resid), M, N, K, epilogue, _s()))
+    return out
+
+
+def build_positions(cu_seqlens: torch.Tensor, total_tokens: int) -> torch.Tensor:
+    pos = torch.empty(total_tokens, dtype=torch.int32, device=cu_seqlens.device)
+    _lib.check(_lib.lib().lrx_build_positions(_lib.ptr(cu_seqlens), cu_seqlens.numel() - 1, total_tokens, _lib.ptr(pos), _s()))
+    return pos
+
+
+def rope_inplace(qkv: torch.Tensor, positions: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, nq: int, nkv: int, d: int):
+    _lib.check(_lib.lib().lrx_rope_inplace(_lib.ptr(qkv), _lib.ptr(positions), _lib.ptr(cos), _lib.ptr(sin), qkv.shape[0], nq, nkv, d, _s()))
+    return qkv
+
+
+def attn_varlen_causal(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, nq: int, nkv: int, d: int) -> torch.Tensor:
+    T = qkv.shape[0]
+    out = torch.empty(T, nq * d, dtype=torch.bfloat16, device=qkv.device)
+    _lib.check(_lib.lib().lrx_attn_varlen_causal(_lib.ptr(qkv), _lib.ptr(cu_seqlens), cu_seqlens.numel() - 1, T, max_seqlen, nq, nkv, d,
+                                                 _lib.ptr(out), _s()))
+    return out
+
+
+def pool_norm(hidden: torch.Tensor, w: torch.Tensor, cu_seqlens: torch.Tensor, eps: float, out_dim: Optional[int] = None,
+              normalize: bool = True) -> torch.Tensor:
+    B, H = cu_seqlens.numel() - 1, hidden.shape[1]
+    D = out_dim or H
+    out = torch.empty(B, D, dtype=torch.float32, device=hidden.device)
+    _lib.check(_lib.lib().lrx_pool_norm(_lib.ptr(hidden), _lib.ptr(w), _lib.ptr(cu_seqlens), B, H, eps, _lib.ptr(out), D, D, int(normalize), _s()))
+    return out
+
+
+def embedding_bag_mean(table: torch.Tensor, ids: torch.Tensor, offsets: torch.Tensor, padding_idx: Optional[int] = None,
+                       out_dim: Optional[int] = None, normalize: bool = False) -> torch.Tensor:
+    """table fp32 [V,H] (device), ids/offsets int64 (device) -> fp32 [n_bags, out_dim]."""
+    V, H = table.shape
+    D = out_dim or H
+    nb = offsets.numel()
+    out = torch.empty(nb, D, dtype=torch.float32, device=table.device)
+    _lib.check(_lib.lib().lrx_embedding_bag_mean(_lib.ptr(table), V, H, _lib.ptr(ids), ids.numel(), _lib.ptr(offsets), nb,
+                                                 -1 if padding_idx is None else int(padding_idx), _lib.ptr(out), D, D, int(normalize), _s()))
+    return out
+
+
+def flat_ip_scores(X: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+    lib = _lib.lib()
+    N, D = X.shape
+    ld = int(lib.lrx_flat_ip_score_ld(N))
+    s = torch.empty(q.shape[0], ld, dtype=torch.float32, device=X.device)
+    _lib.check(lib.lrx_flat_ip_scores(_lib.ptr(X), N, X.stride(0), D, _lib.ptr(q), q.shape[0], _lib.ptr(s), _s()))
+    return s

@@ -1,0 +1,37 @@
+"""CPU: liblrx.so builds, loads and exports every symbol include/lrx.h declares; the ctypes table covers them all."""
+import ctypes
+import os
+import re
+
+from lightretriever_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "lrx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lrx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    path = build.build(verbose=False)
+    assert os.path.exists(path)
+    l = ctypes.CDLL(path)
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(l, s), f"{s} declared in include/lrx.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table out of sync with include/lrx.h"
+    assert _lib.lib().lrx_abi_version() == 1
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    l = _lib.lib()
+    # invalid shapes are rejected on the host before any launch
+    assert l.lrx_gemm_bf16_nt(None, None, None, None, None, 4, 8, 7, 0, None) == -1
+    assert b"K=7" in l.lrx_last_error()
+    assert l.lrx_attn_varlen_causal(None, None, 1, 4, 4, 4, 2, 16, None, None) == -1
+    assert l.lrx_flat_ip_scores(None, 10, 48, 48, None, 1, None, None) == -1
+    assert l.lrx_flat_ip_score_ld(1000) == 1024
+    assert l.lrx_encode_workspace_bytes(None, 1, 1) == 0

@@ -1,0 +1,157 @@
+"""GPU parity of the fused encoder path (lrx_encode_packed / lrx_encode_hidden) against the oracle and the goldens made
+from the reference; plus size-independent properties at the BASELINE model size (Llama-3.2-1B dims)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lrx_oracle as O
+from helpers import load_model_golden, min_cos
+
+pytestmark = pytest.mark.gpu
+
+# NORTH-STAR TOLERANCE: embeddings within 1e-3 cosine of the reference.  The tiny golden models are so small that the
+# reference's OWN bf16 run sits up to 3.6e-3 away from its fp32 run (see dense_reps_bf16 in the fixtures), so for them the
+# bar is "inside the reference's bf16 noise band"; the 1e-3 bar itself is asserted on the larger models below.
+COS_TOL = 1e-3
+
+
+def make_encoder(cfg_o, w):
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    from dataclasses import asdict
+    cfg = EncoderConfig(**asdict(cfg_o))
+    return LrxEncoder(cfg, {k: torch.from_numpy(v) for k, v in w.items()})
+
+
+def to_dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+@pytest.mark.parametrize("name", ["llama_small_d64", "llama_small_d128"])
+def test_golden_models_within_reference_bf16_band(name):
+    cfg, w, g, ids, cu, max_len = load_model_golden(name)
+    enc = make_encoder(cfg, w)
+    out = enc.encode_packed(to_dev(ids, torch.int32), to_dev(cu, torch.int32), max_len).cpu().numpy()
+    ref32, ref16 = g["dense_reps"], g["dense_reps_bf16"]
+    band = 1 - min_cos(ref16, ref32)                      # how far the reference's bf16 run is from its fp32 run
+    ours = 1 - min_cos(out, ref32)
+    assert ours <= max(COS_TOL, 1.25 * band), (ours, band)
+    assert 1 - min_cos(out, ref16) <= max(COS_TOL, 2.0 * band)
+    np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+    # MRL slice
+    s = int(g["shrink"])
+    out_mrl = enc.encode_packed(to_dev(ids, torch.int32), to_dev(cu, torch.int32), max_len, out_dim=s).cpu().numpy()
+    assert 1 - min_cos(out_mrl, g["dense_reps_mrl"]) <= max(COS_TOL, 1.5 * band)
+    np.testing.assert_allclose(out_mrl, O.l2_normalize(out[:, :s]), atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["llama_small_d64", "llama_small_d128"])
+def test_hidden_states_track_bf16_oracle(name):
+    cfg, w, g, ids, cu, max_len = load_model_golden(name)
+    enc = make_encoder(cfg, w)
+    h = enc.encode_hidden(to_dev(ids, torch.int32), to_dev(cu, torch.int32), max_len).float().cpu().numpy()
+    want = O.encoder_forward_packed(cfg, w, ids, cu, bf16=True)
+    # bf16 pipelines with different rounding points: compare per-token direction and overall scale
+    assert min_cos(h, want) > 0.995
+    assert abs(np.linalg.norm(h) / np.linalg.norm(want) - 1) < 1e-2
+
+
+def medium_case(d, qkv_bias=False, seed=3):
+    nq, nkv = (8, 2) if d == 64 else (4, 1)
+    cfg = O.EncoderConfig(vocab_size=1000, hidden_size=512, num_layers=4, num_q_heads=nq, num_kv_heads=nkv, head_dim=d,
+                          intermediate_size=1024, rope_type="llama3", rope_factor=8.0, rope_original_max_position=128,
+                          qkv_bias=qkv_bias, max_positions=512)
+    w = O.random_weights(cfg, seed=seed, std=0.03)
+    rng = np.random.default_rng(seed)
+    lens = [192, 1, 64, 65, 130, 17]
+    ids = rng.integers(0, 1000, size=sum(lens)).astype(np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    return cfg, w, ids, cu, max(lens)
+
+
+@pytest.mark.parametrize("d,bias", [(64, False), (128, False), (64, True)])
+def test_medium_model_within_1e3_cosine_of_fp32_oracle(d, bias):
+    cfg, w, ids, cu, max_len = medium_case(d, bias)
+    want = O.encode_passage(cfg, w, ids, cu, bf16=False)
+    enc = make_encoder(cfg, w)
+    out = enc.encode_packed(to_dev(ids, torch.int32), to_dev(cu, torch.int32), max_len).cpu().numpy()
+    assert 1 - min_cos(out, want) <= COS_TOL, 1 - min_cos(out, want)
+
+
+def test_writes_in_place_into_index_rows_and_is_batch_invariant():
+    cfg, w, ids, cu, max_len = medium_case(64)
+    enc = make_encoder(cfg, w)
+    shard = torch.zeros(10, 512, device="cuda")
+    enc.encode_packed(to_dev(ids, torch.int32), to_dev(cu, torch.int32), max_len, out=shard[2:8])
+    assert torch.all(shard[:2] == 0) and torch.all(shard[8:] == 0)
+    full = shard[2:8].cpu().numpy()
+    # each document alone gives bit-identical rows (no cross-sequence leakage, order preserved)
+    for b in range(len(cu) - 1):
+        sl = ids[cu[b]:cu[b + 1]]
+        one = enc.encode_packed(to_dev(sl, torch.int32), to_dev(np.array([0, len(sl)], np.int32), torch.int32), len(sl)).cpu().numpy()
+        np.testing.assert_array_equal(one[0], full[b])
+    # reversed batch order -> rows permuted identically
+    order = list(range(len(cu) - 1))[::-1]
+    ids_r = np.concatenate([ids[cu[b]:cu[b + 1]] for b in order])
+    cu_r = np.concatenate([[0], np.cumsum([cu[b + 1] - cu[b] for b in order])]).astype(np.int32)
+    rev = enc.encode_packed(to_dev(ids_r, torch.int32), to_dev(cu_r, torch.int32), max_len).cpu().numpy()
+    np.testing.assert_array_equal(rev, full[order])
+
+
+def test_argument_errors():
+    from lightretriever_amd._lib import LrxError
+    cfg, w, ids, cu, max_len = medium_case(64)
+    enc = make_encoder(cfg, w)
+    with pytest.raises(TypeError):
+        enc.encode_packed(to_dev(ids, torch.int64), to_dev(cu, torch.int32), max_len)
+    with pytest.raises(LrxError):
+        enc.encode_packed(to_dev(ids, torch.int32), to_dev(cu, torch.int32), 4096)  # beyond the RoPE table
+
+
+def test_full_size_llama32_1b_properties_and_hf_parity():
+    """BASELINE config 2 model size (Llama-3.2-1B dims, S=512): properties + parity with HF transformers fp32 on the same
+    GPU (the third-party model the reference calls), tolerance 1e-3 cosine."""
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    cfg = EncoderConfig.llama32_1b()
+    enc = LrxEncoder.random_init(cfg, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    lens = [512, 512, 300, 64, 1, 512, 17, 129]
+    ids = torch.randint(1000, 127000, (sum(lens),), generator=g, dtype=torch.int64).to(torch.int32).cuda()
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32).cuda()
+    out = enc.encode_packed(ids, cu, 512)
+    out2 = enc.encode_packed(ids, cu, 512)
+    assert torch.equal(out, out2)                                         # deterministic
+    assert torch.allclose(out.norm(dim=1), torch.ones(len(lens), device="cuda"), atol=1e-5)
+    assert torch.isfinite(out).all()
+    one = enc.encode_packed(ids[:512].contiguous(), torch.tensor([0, 512], dtype=torch.int32).cuda(), 512)
+    assert torch.equal(one[0], out[0])                                    # batch invariance at full size
+
+    from transformers import LlamaConfig, LlamaModel
+    hf_cfg = LlamaConfig(vocab_size=cfg.vocab_size, hidden_size=2048, intermediate_size=8192, num_hidden_layers=16, num_attention_heads=32,
+                         num_key_value_heads=8, head_dim=64, rms_norm_eps=1e-5, max_position_embeddings=131072,
+                         rope_parameters={"rope_type": "llama3", "rope_theta": 500000.0, "factor": 32.0, "low_freq_factor": 1.0,
+                                          "high_freq_factor": 4.0, "original_max_position_embeddings": 8192},
+                         attn_implementation="sdpa")
+    with torch.device("cuda"):
+        hf = LlamaModel(hf_cfg).float().eval()
+    sd = {"embed_tokens.weight": enc.embed, "norm.weight": enc.final_norm}
+    H, d = 2048, 64
+    for i, L in enumerate(enc.layers):
+        p = f"layers.{i}."
+        sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = \
+            L["wqkv"][:2048], L["wqkv"][2048:2560], L["wqkv"][2560:]
+        sd[p + "self_attn.o_proj.weight"] = L["wo"]
+        gu = L["wgu"].view(8192 // 32, 2, 32, H)
+        sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = gu[:, 0].reshape(8192, H), gu[:, 1].reshape(8192, H)
+        sd[p + "mlp.down_proj.weight"] = L["wdown"]
+        sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = L["ln1"], L["ln2"]
+    missing, unexpected = hf.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
+    assert not unexpected and all("rotary" in m for m in missing)
+    refs = []
+    with torch.no_grad():
+        for b in range(len(lens)):
+            x = ids[cu[b]:cu[b + 1]].long()[None]
+            h = hf(input_ids=x, use_cache=False).last_hidden_state[0, -1]
+            refs.append(torch.nn.functional.normalize(h, dim=-1))
+    ref = torch.stack(refs)
+    cos = (ref * out).sum(-1)
+    assert (1 - cos).max().item() <= COS_TOL, (1 - cos)

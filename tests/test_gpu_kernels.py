@@ -1,0 +1,218 @@
+"""GPU parity: every liblrx kernel (called through the C ABI) against the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lrx_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def bf16_t(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev()).to(torch.bfloat16).contiguous()
+
+
+def f32(t: torch.Tensor) -> np.ndarray:
+    return t.float().cpu().numpy()
+
+
+def rnd(rng, *shape, scale=1.0):
+    return O.round_bf16(rng.standard_normal(shape).astype(np.float32) * scale)
+
+
+def bf16_ulp_close(got, want, ulps=1.0, atol=1e-6):
+    """|got-want| <= ulps * 2^-8 * |want| (one bf16 ulp is 2^-7 relative at worst; allow rounding-boundary flips)."""
+    tol = ulps * (2.0 ** -7) * np.abs(want) + atol
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), f"{bad.sum()} / {bad.size} mismatches, max abs diff {np.abs(got - want).max()}"
+
+
+def test_embedding_gather_exact():
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(0)
+    table = rnd(rng, 500, 192)
+    ids = rng.integers(0, 500, size=1031).astype(np.int32)
+    out = ops.embedding_gather(bf16_t(table), torch.from_numpy(ids).to(dev()))
+    np.testing.assert_array_equal(f32(out), table[ids])
+
+
+@pytest.mark.parametrize("rows,H", [(1, 64), (37, 256), (300, 2048), (9, 4096)])
+def test_rmsnorm(rows, H):
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(rows)
+    x, w = rnd(rng, rows, H, scale=3.0), O.round_bf16(1 + 0.1 * rng.standard_normal(H).astype(np.float32))
+    y = ops.rmsnorm(bf16_t(x), bf16_t(w), 1e-5)
+    bf16_ulp_close(f32(y), O.rmsnorm(x, w, 1e-5, bf16=True), ulps=1.01)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (300, 192, 128), (256, 256, 64), (777, 1000, 512), (1024, 3072, 2048), (515, 2048, 8192)])
+def test_gemm_plain_and_bias(M, N, K):
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    A, B = rnd(rng, M, K), rnd(rng, N, K, scale=0.05)
+    bias = rnd(rng, N)
+    want = A @ B.T
+    got = ops.gemm_bf16_nt(bf16_t(A), bf16_t(B))
+    bf16_ulp_close(f32(got), want, ulps=1.01, atol=2e-3)
+    got_b = ops.gemm_bf16_nt(bf16_t(A), bf16_t(B), bias=bf16_t(bias))
+    bf16_ulp_close(f32(got_b), want + bias, ulps=1.01, atol=2e-3)
+
+
+def test_gemm_identity_asymmetric():
+    """A = I against an asymmetric B catches a transposed C write or a wrong fragment map exactly."""
+    from lightretriever_amd import ops
+    K = 256
+    A = np.eye(K, dtype=np.float32)
+    B = (np.arange(320)[:, None] * 3 + np.arange(K)[None, :] % 7).astype(np.float32) % 61  # small ints, bf16-exact
+    got = ops.gemm_bf16_nt(bf16_t(A), bf16_t(B))
+    np.testing.assert_array_equal(f32(got), O.round_bf16(B.T))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 2048, 2048), (131, 64, 8192)])
+def test_gemm_residual_inplace(M, N, K):
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(K + M)
+    A, B, R = rnd(rng, M, K), rnd(rng, N, K, scale=0.05), rnd(rng, M, N)
+    r = bf16_t(R)
+    got = ops.gemm_bf16_nt(bf16_t(A), bf16_t(B), resid=r, epilogue=1, out=r)  # C aliases resid
+    bf16_ulp_close(f32(got), A @ B.T + R, ulps=1.01, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,I,K", [(200, 128, 64), (513, 512, 256), (300, 8192, 2048)])
+def test_gemm_swiglu(M, I, K):
+    from lightretriever_amd import ops, interleave_gate_up
+    rng = np.random.default_rng(I)
+    A, Wg, Wu = rnd(rng, M, K), rnd(rng, I, K, scale=0.05), rnd(rng, I, K, scale=0.05)
+    wgu = interleave_gate_up(torch.from_numpy(Wg), torch.from_numpy(Wu)).to(dev()).to(torch.bfloat16)
+    got = ops.gemm_bf16_nt(bf16_t(A), wgu, epilogue=2)
+    g, u = A @ Wg.T, A @ Wu.T
+    want = g / (1 + np.exp(-g)) * u
+    bf16_ulp_close(f32(got), want, ulps=1.05, atol=2e-3)
+
+
+def test_positions_match_packing_oracle():
+    from lightretriever_amd import ops
+    lens = [5, 1, 64, 17, 1, 130]
+    mask = np.zeros((len(lens), max(lens)), np.int64)
+    for i, n in enumerate(lens):
+        mask[i, :n] = 1
+    _, pos, _, cu, _ = O.pack_padded(mask.copy(), mask)
+    got = ops.build_positions(torch.from_numpy(cu).to(dev()), int(cu[-1]))
+    np.testing.assert_array_equal(got.cpu().numpy(), pos)
+
+
+@pytest.mark.parametrize("d,nq,nkv,rope_type", [(64, 4, 2, "llama3"), (128, 2, 1, "default"), (64, 32, 8, "llama3")])
+def test_rope(d, nq, nkv, rope_type):
+    from lightretriever_amd import ops, rope_tables, EncoderConfig
+    rng = np.random.default_rng(d)
+    T = 77
+    ocfg = O.EncoderConfig(100, nq * d, 1, nq, nkv, d, 64, rope_type=rope_type, rope_original_max_position=64, max_positions=128)
+    cfg = EncoderConfig(100, nq * d, 1, nq, nkv, d, 64, rope_type=rope_type, rope_original_max_position=64, max_positions=128)
+    cos, sin = rope_tables(cfg)
+    oc, osn = O.rope_table(ocfg, 128)
+    np.testing.assert_allclose(cos.numpy(), O.round_bf16(oc), atol=2 ** -8)   # table itself vs the HF restatement
+    np.testing.assert_allclose(sin.numpy(), O.round_bf16(osn), atol=2 ** -8)
+    qkv = rnd(rng, T, (nq + 2 * nkv) * d)
+    pos = rng.integers(0, 128, size=T).astype(np.int32)
+    t = bf16_t(qkv)
+    ops.rope_inplace(t, torch.from_numpy(pos).to(dev()), cos.to(dev()), sin.to(dev()), nq, nkv, d)
+    got = f32(t)
+    c, s = cos.numpy()[pos], sin.numpy()[pos]
+    want = qkv.copy()
+    rot = O.apply_rope(qkv[:, :(nq + nkv) * d].reshape(T, nq + nkv, d), c, s).reshape(T, -1)
+    want[:, :(nq + nkv) * d] = rot
+    bf16_ulp_close(got, O.round_bf16(want), ulps=1.01, atol=1e-6)
+    np.testing.assert_array_equal(got[:, (nq + nkv) * d:], qkv[:, (nq + nkv) * d:])  # v untouched
+
+
+def attn_oracle(qkv, cu, nq, nkv, d):
+    T = qkv.shape[0]
+    q = qkv[:, :nq * d].reshape(T, nq, d)
+    k = qkv[:, nq * d:(nq + nkv) * d].reshape(T, nkv, d)
+    v = qkv[:, (nq + nkv) * d:].reshape(T, nkv, d)
+    out = np.zeros((T, nq, d), np.float32)
+    grp = nq // nkv
+    for b in range(len(cu) - 1):
+        s, e = cu[b], cu[b + 1]
+        L = e - s
+        causal = np.tril(np.ones((L, L), bool))
+        for hq in range(nq):
+            sc = (q[s:e, hq] @ k[s:e, hq // grp].T) * np.float32(d ** -0.5)
+            sc = np.where(causal, sc, -np.inf)
+            p = np.exp(sc - sc.max(-1, keepdims=True))
+            out[s:e, hq] = (p / p.sum(-1, keepdims=True)) @ v[s:e, hq // grp]
+    return out.reshape(T, nq * d)
+
+
+@pytest.mark.parametrize("d,nq,nkv,lens", [
+    (64, 4, 2, [1, 2, 31, 32, 33, 63, 64, 65, 100, 128, 129, 200]),
+    (64, 8, 2, [512, 7, 300]),
+    (64, 2, 2, [96, 5]),
+    (128, 2, 1, [1, 64, 65, 130, 257]),
+    (128, 4, 1, [512, 33]),
+    (64, 6, 1, [70, 129]),
+])
+def test_attention_varlen_causal(d, nq, nkv, lens):
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(sum(lens) + d)
+    T = sum(lens)
+    qkv = rnd(rng, T, (nq + 2 * nkv) * d)
+    qkv[:, :nq * d] *= 2.0  # peaky softmax
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    got = ops.attn_varlen_causal(bf16_t(qkv), torch.from_numpy(cu).to(dev()), max(lens), nq, nkv, d)
+    want = attn_oracle(qkv, cu, nq, nkv, d)
+    np.testing.assert_allclose(f32(got), want, atol=2e-2, rtol=2e-2)
+    # rows are convex combinations of v: a tighter relative check on the row norms catches scale errors
+    assert abs(np.linalg.norm(f32(got)) / np.linalg.norm(want) - 1) < 3e-3
+
+
+def test_attention_forced_max_jump():
+    """One key with a huge score late in the sequence forces the online-softmax rescale branch (alpha << 1)."""
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(5)
+    d, nq, nkv, L = 64, 4, 2, 160
+    qkv = rnd(rng, L, (nq + 2 * nkv) * d, scale=0.3)
+    qkv[100, nq * d:nq * d + d] = O.round_bf16(qkv[150, :d] * 40)  # key 100 (kv head 0) aligned with q row 150 of head 0
+    cu = np.array([0, L], np.int32)
+    got = ops.attn_varlen_causal(bf16_t(qkv), torch.from_numpy(cu).to(dev()), L, nq, nkv, d)
+    np.testing.assert_allclose(f32(got), attn_oracle(qkv, cu, nq, nkv, d), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("H,out_dim,normalize", [(256, 256, True), (256, 64, True), (2048, 2048, True), (2048, 256, False)])
+def test_pool_norm(H, out_dim, normalize):
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(H + out_dim)
+    lens = [3, 1, 40, 17]
+    T = sum(lens)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x, w = rnd(rng, T, H, scale=2.0), O.round_bf16(1 + 0.1 * rng.standard_normal(H).astype(np.float32))
+    got = ops.pool_norm(bf16_t(x), bf16_t(w), torch.from_numpy(cu).to(dev()), 1e-5, out_dim, normalize)
+    pooled = O.lasttoken_pool_packed(O.rmsnorm(x, w, 1e-5, bf16=True), cu)[:, :out_dim]
+    want = O.l2_normalize(pooled) if normalize else pooled
+    np.testing.assert_allclose(f32(got), want, atol=3e-3 if not normalize else 3e-4, rtol=1e-2)
+    if normalize:
+        np.testing.assert_allclose(np.linalg.norm(f32(got), axis=1), 1.0, atol=1e-5)
+
+
+def test_embedding_bag_bit_exact():
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(11)
+    V, H, pad = 300, 256, 7
+    table = rng.standard_normal((V, H)).astype(np.float32)
+    lens = [5, 0, 1, 17, 3, 0]
+    ids = rng.integers(0, V, size=sum(lens)).astype(np.int64)
+    ids[2] = pad
+    ids[-1] = pad
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    tt, ti, to = torch.from_numpy(table).to(dev()), torch.from_numpy(ids).to(dev()), torch.from_numpy(offs).to(dev())
+    raw = ops.embedding_bag_mean(tt, ti, to, padding_idx=pad)
+    np.testing.assert_array_equal(f32(raw), O.embedding_bag_mean(table, ids, offs, pad))   # same fp32 summation order
+    emb = ops.embedding_bag_mean(tt, ti, to, padding_idx=pad, out_dim=64, normalize=True)
+    np.testing.assert_allclose(f32(emb), O.encode_query_emb(table, ids, offs, pad, dense_shrink_dim=64), atol=1e-6)
+    # and against torch.nn.EmbeddingBag itself (the reference's query operator) on the same device
+    bag = torch.nn.EmbeddingBag.from_pretrained(tt, padding_idx=pad)
+    np.testing.assert_allclose(f32(raw), f32(bag(ti, to)), atol=1e-6)

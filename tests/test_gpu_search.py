@@ -1,0 +1,154 @@
+"""GPU parity of the flat-IP index (lrx_flat_ip_search / lrx_merge_topk) against the oracle, the torch goldens and
+size-independent properties at the BASELINE index size (1M x 2048 fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lrx_oracle as O
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+FLT_MAX = np.finfo(np.float32).max
+
+
+def check_against_oracle(D, I, q, X, k, id_base=0, score_tol=2e-6):
+    """Scores within fp32 summation noise; ids identical except where the oracle's own neighbouring scores are within
+    that noise (near-ties may swap); every returned (id, score) pair is self-consistent."""
+    Do, Io = O.flat_ip_topk(q, X, k)
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    valid = Io >= 0
+    np.testing.assert_allclose(D[valid], Do[valid], atol=score_tol, rtol=1e-5)
+    assert (I[~valid] == -1).all() and (D[~valid] == -FLT_MAX).all()
+    Iloc = I - id_base
+    mism = (Iloc != Io) & valid
+    if mism.any():
+        qi, ri = np.nonzero(mism)
+        s_ours = np.einsum("ij,ij->i", q[qi], X[Iloc[qi, ri]])
+        assert np.abs(s_ours - Do[qi, ri]).max() < score_tol * 4       # a near-tie, not a wrong row
+    assert mism.mean() < 0.01
+    for r in range(D.shape[0]):                                        # sorted descending, ids unique
+        dv = D[r][valid[r]]
+        assert np.all(np.diff(dv) <= 0)
+        assert len(set(Iloc[r][valid[r]].tolist())) == valid[r].sum()
+
+
+@pytest.mark.parametrize("k", [1, 10, 100])
+def test_golden_search_fixture(k):
+    from lightretriever_amd import FlatIPIndex
+    g = np.load(os.path.join(GOLDEN, "search.npz"))
+    idx = FlatIPIndex(64)
+    for s in range(0, 5000, 1300):       # add in slices like FaissIndex.build does (faiss_index.py:54-56)
+        idx.add(g["X"][s:s + 1300])
+    assert idx.ntotal == 5000
+    D, I = idx.search(g["Q"], k)
+    np.testing.assert_allclose(D.cpu().numpy(), g[f"D{k}"], atol=2e-6)
+    assert (I.cpu().numpy() == g[f"I{k}"]).mean() > 0.999
+    check_against_oracle(D, I, g["Q"], g["X"], k)
+
+
+@pytest.mark.parametrize("N,D,Q,k", [(70000, 128, 100, 100), (1000, 32, 1, 5), (257, 64, 17, 300), (4096, 256, 200, 10), (33333, 96, 48, 1000)])
+def test_random_vs_oracle(N, D, Q, k):
+    from lightretriever_amd import FlatIPIndex
+    rng = np.random.default_rng(N + Q)
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32))
+    q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))
+    idx = FlatIPIndex(D, capacity=N, id_base=7000)
+    idx.add(X)
+    Dg, Ig = idx.search(q, k)
+    check_against_oracle(Dg, Ig, q, X, k, id_base=7000)
+
+
+def test_ties_and_degenerate_inputs():
+    from lightretriever_amd import FlatIPIndex
+    rng = np.random.default_rng(4)
+    base = O.l2_normalize(rng.standard_normal((700, 64)).astype(np.float32))
+    X = np.concatenate([base, base, base[:100]], 0)          # exact duplicates -> ties broken by lower row id
+    q = base[:9].copy()
+    idx = FlatIPIndex(64)
+    idx.add(X)
+    D, I = idx.search(q, 7)
+    Do, Io = O.flat_ip_topk(q, X, 7)
+    np.testing.assert_array_equal(I.cpu().numpy()[:, :3], Io[:, :3])   # the three copies of the query row, ascending ids
+    np.testing.assert_allclose(D.cpu().numpy(), Do, atol=2e-6)
+    # massive tie: every row identical -> ids 0..k-1 (ordered-scan fallback path)
+    idx.reset()
+    idx.add(np.tile(base[:1], (6000, 1)))
+    D, I = idx.search(q[:3], 10)
+    np.testing.assert_array_equal(I.cpu().numpy(), np.tile(np.arange(10), (3, 1)))
+    # k > ntotal and the empty index
+    idx.reset()
+    idx.add(base[:5])
+    D, I = idx.search(q[:2], 8)
+    assert (I.cpu().numpy()[:, 5:] == -1).all() and (I.cpu().numpy()[:, :5] >= 0).all()
+    idx.reset()
+    D, I = idx.search(q[:2], 4)
+    assert (I.cpu().numpy() == -1).all()
+
+
+def test_merge_topk_matches_oracle_and_single_index():
+    from lightretriever_amd import FlatIPIndex, merge_topk
+    rng = np.random.default_rng(8)
+    N, Dm, Q, k, R = 9000, 64, 33, 50, 4
+    X = O.l2_normalize(rng.standard_normal((N, Dm)).astype(np.float32))
+    X[100] = X[8000]                                          # a cross-shard tie
+    q = O.l2_normalize(rng.standard_normal((Q, Dm)).astype(np.float32))
+    bounds = [0, 1000, 4096, 4097, N]                         # ragged shards, one with a single row (k > shard rows)
+    Dp, Ip = [], []
+    for r in range(R):
+        sh = FlatIPIndex(Dm, id_base=bounds[r])
+        sh.add(X[bounds[r]:bounds[r + 1]])
+        d, i = sh.search(q, k)
+        Dp.append(d), Ip.append(i)
+    Dm_, Im_ = merge_topk(torch.stack(Dp), torch.stack(Ip))
+    whole = FlatIPIndex(Dm)
+    whole.add(X)
+    Dw, Iw = whole.search(q, k)
+    np.testing.assert_array_equal(Im_.cpu().numpy(), Iw.cpu().numpy())
+    np.testing.assert_array_equal(Dm_.cpu().numpy(), Dw.cpu().numpy())
+    Do, Io = O.merge_topk([d.cpu().numpy() for d in Dp], [i.cpu().numpy() for i in Ip], k)
+    np.testing.assert_array_equal(Im_.cpu().numpy(), Io)
+
+
+def test_full_size_1m_x_2048_properties():
+    """BASELINE config 2 index size.  Properties: sorted, unique ids, every score equals the recomputed dot product, the
+    top-1 equals a chunked torch argmax, planted exact matches are found at rank 0, shard-merge equals whole-index."""
+    from lightretriever_amd import FlatIPIndex, merge_topk
+    N, D, Q, k = 1_000_000, 2048, 100, 100
+    g = torch.Generator(device="cuda").manual_seed(7)
+    idx = FlatIPIndex(D, capacity=N)
+    slot = idx.append_slot(N)
+    for s in range(0, N, 100_000):
+        blk = torch.randn(100_000, D, generator=g, device="cuda")
+        slot[s:s + 100_000] = torch.nn.functional.normalize(blk, dim=-1)
+    idx.commit(N)
+    q = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device="cuda"), dim=-1)
+    planted = torch.randint(0, N, (10,), generator=g, device="cuda")
+    q[:10] = idx.vectors[planted]
+    Dg, Ig = idx.search(q, k)
+    assert (Ig[:10, 0] == planted).all() and torch.allclose(Dg[:10, 0], torch.ones(10, device="cuda"), atol=1e-5)
+    assert (Dg[:, 1:] <= Dg[:, :-1]).all()
+    assert all(len(set(r.tolist())) == k for r in Ig.cpu())
+    rec = torch.einsum("qkd,qd->qk", idx.vectors[Ig.reshape(-1)].view(Q, k, D), q)
+    assert torch.allclose(rec, Dg, atol=3e-6)
+    best = torch.full((Q,), -2.0, device="cuda")
+    arg = torch.zeros(Q, dtype=torch.int64, device="cuda")
+    kth = torch.full((Q,), 0.0, device="cuda")
+    for s in range(0, N, 250_000):
+        sc = q @ idx.vectors[s:s + 250_000].T
+        m, a = sc.max(dim=1)
+        upd = m > best
+        best, arg = torch.where(upd, m, best), torch.where(upd, a + s, arg)
+        kth = kth + (sc > Dg[:, -1:] + 3e-6).sum(1)
+    assert torch.allclose(best, Dg[:, 0], atol=3e-6)
+    assert ((arg == Ig[:, 0]) | ((best - Dg[:, 0]).abs() < 3e-6)).all()
+    assert (kth <= k - 1).all()          # nothing clearly better than the k-th result was missed
+    # two-shard merge == whole index
+    a, b = FlatIPIndex(D, id_base=0), FlatIPIndex(D, id_base=600_000)
+    a._x, a.ntotal = idx._x[:600_000], 600_000
+    b._x, b.ntotal = idx._x[600_000:], 400_000
+    Da, Ia = a.search(q, k)
+    Db, Ib = b.search(q, k)
+    Dm, Im = merge_topk(torch.stack([Da, Db]), torch.stack([Ia, Ib]))
+    assert torch.equal(Im, Ig) and torch.equal(Dm, Dg)
