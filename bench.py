@@ -63,16 +63,19 @@ def cpu_baseline(cfg, seq_len, topk, dim):
                                           "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192},
                          attn_implementation="sdpa")
     torch.manual_seed(0)
-    model = LlamaModel(hf_cfg).to(torch.bfloat16).eval()
-    docs = 4
+    # fp32: the GPU box's host has no AMX-bf16 (bf16 measured 0.05 docs/s there, 20x slower than fp32)
+    model = LlamaModel(hf_cfg).float().eval()
+    docs = 2
     ids = torch.randint(1000, 127000, (docs, seq_len))
+    with torch.no_grad():
+        model(input_ids=ids[:1, :32], use_cache=False)  # touch the weights once (page-in), untimed
     n_done, t0 = 0, time.perf_counter()
     with torch.no_grad():
         while True:
             h = model(input_ids=ids, use_cache=False).last_hidden_state[:, -1]
             torch.nn.functional.normalize(h.float(), dim=-1)
             n_done += docs
-            if time.perf_counter() - t0 > 12.0 or n_done >= 64:
+            if time.perf_counter() - t0 > 10.0 or n_done >= 64:
                 break
     enc_s = time.perf_counter() - t0
     del model
@@ -87,7 +90,7 @@ def cpu_baseline(cfg, seq_len, topk, dim):
     return {
         "value": round(n_done / enc_s, 4), "unit": "docs/s", "cores": cores, "kind": "reference",
         "sample": f"HF transformers LlamaModel (the third-party forward the reference's encode_passage calls), random-init {cfg.num_layers}L/"
-                  f"H{cfg.hidden_size}, bf16, sdpa, {n_done} docs x {seq_len} tokens in {enc_s:.1f}s on {cores} threads",
+                  f"H{cfg.hidden_size}, fp32, sdpa, {n_done} docs x {seq_len} tokens in {enc_s:.1f}s on {cores} threads",
         "search": {"value": round(nq / srch_s, 2), "unit": "queries/s", "kind": "port", "cores": cores,
                    "sample": f"oracle flat_ip_topk (numpy sgemm + lexsort) Q={nq}, k={topk} over {n_sample} x {dim} fp32 rows "
                              f"({srch_s:.2f}s); per-query cost scales linearly with rows",
