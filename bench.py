@@ -49,12 +49,25 @@ def barrier_sync(distributed):
     torch.cuda.synchronize()
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256 CPUs
+    but grants 16; running 256 threads on a 16-CPU quota is 50x slower than 16 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, seq_len, topk, dim):
     """The reference's CPU path on this box's host cores, bounded to ~10-30 s: (a) HF transformers LlamaModel (the model
     code the reference's encode_passage executes) at the real config, bf16, sdpa; (b) flat IP via the oracle port."""
     import numpy as np
     from transformers import LlamaConfig, LlamaModel
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     hf_cfg = LlamaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
                          num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_q_heads, num_key_value_heads=cfg.num_kv_heads,
@@ -63,7 +76,7 @@ def cpu_baseline(cfg, seq_len, topk, dim):
                                           "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192},
                          attn_implementation="sdpa")
     torch.manual_seed(0)
-    # fp32: the GPU box's host has no AMX-bf16 (bf16 measured 0.05 docs/s there, 20x slower than fp32)
+    # fp32: the GPU box's host (EPYC 9575F) has no AMX-bf16; torch CPU bf16 GEMMs are far slower than fp32 there
     model = LlamaModel(hf_cfg).float().eval()
     docs = 2
     ids = torch.randint(1000, 127000, (docs, seq_len))
@@ -237,7 +250,7 @@ def main():
                 cb["search"]["scaled_to_index_rows"] = round(cb["search"]["value"] * 50_000 / args.index_rows, 3)
             line["cpu_baseline"] = cb
         except Exception as e:  # noqa: BLE001  (the baseline is a reported number, never the product path)
-            line["cpu_baseline"] = {"value": None, "unit": "docs/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
+            line["cpu_baseline"] = {"value": None, "unit": "docs/s", "cores": usable_cores(), "kind": "reference", "sample": "failed: %r" % (e,)}
     print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

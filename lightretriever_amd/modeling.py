@@ -1,0 +1,243 @@
+"""Host-side mirror of the reference's model-side interfaces for the dense asymmetric path.
+
+    EncodeCollator      <- inference/exact_search_base.py:267-437   (text -> token ids; here: packed, no second tokenisation)
+    LrxHybridModel      <- finetune/modeling_hybrid.py:205-278 (encode_passage), :327-500 (encode_query, emb branch),
+                           finetune/emb_bag_mixin.py / nonctx_emb_utils.py:239-313 (EmbeddingBag construction)
+    LrxExactSearchModel <- inference/exact_search_base.py:42-200 + exact_search_torchrpc.py:122-295
+                           (encode_queries / encode_corpus / encode with prompts; one process per GPU, no RPC)
+
+Same names for arguments and result keys (`dense_reps`, `emb_reps`), same text formatting rules; tensors stay on the GPU.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .encoder import LrxEncoder
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# text -> token ids
+# ------------------------------------------------------------------------------------------------------------------
+def format_text(item: dict, prepend_prompt: bool = False) -> str:
+    """`title + " " + text` when a non-empty title exists; the prompt (if the item carries one) is string-prepended
+    with no separator (exact_search_base.py:289-309)."""
+    text = item["title"] + " " + item["text"] if item.get("title") else item["text"]
+    if prepend_prompt and "prompt" in item:
+        text = item["prompt"] + text
+    return text
+
+
+@dataclass
+class EncodeCollator:
+    """Tokenises a list of {"title"?, "text", "prompt"?} items.
+
+    Documents: specials added (`<bos> A <eos>` template of the tokenizer), truncation 'only_first' to p_max_len (EOS is
+    kept as the last token), output PACKED: `input_ids` int32 [T], `cu_seqlens` int32 [B+1], `max_seqlen` -- plus, on
+    request, the reference's right-padded `[B, S]` ids/mask for callers that want the original layout.
+    Queries (noncontextual_query_embedding): raw text, no prompt, no specials, truncated to q_max_len;
+    `nonctx_tok_emb_input_ids` int64 [sum len], `nonctx_tok_emb_offsets` int64 [Q] = cumsum([0] + len[:-1])
+    (nonctx_emb_utils.py:197-219)."""
+    tokenizer: object
+    encode_is_query: bool
+    q_max_len: int = 512
+    p_max_len: int = 512
+    noncontextual_query_embedding: bool = True
+    return_padded: bool = False
+
+    def __call__(self, texts: list[dict]) -> dict:
+        if self.encode_is_query and self.noncontextual_query_embedding:
+            enc = self.tokenizer([format_text(t) for t in texts], max_length=self.q_max_len, truncation=True,
+                                 add_special_tokens=False, return_attention_mask=False)["input_ids"]
+            lens = [len(e) for e in enc]
+            flat = np.concatenate([np.asarray(e, dtype=np.int64) for e in enc]) if sum(lens) else np.zeros(0, np.int64)
+            offsets = np.cumsum([0] + lens[:-1]).astype(np.int64)
+            return {"nonctx_tok_emb_input_ids": torch.from_numpy(flat), "nonctx_tok_emb_offsets": torch.from_numpy(offsets)}
+        max_len = self.q_max_len if self.encode_is_query else self.p_max_len
+        enc = self.tokenizer([format_text(t, prepend_prompt=True) for t in texts], max_length=max_len, truncation="only_first",
+                             padding=False, add_special_tokens=True, return_attention_mask=False)["input_ids"]
+        lens = np.asarray([len(e) for e in enc], dtype=np.int64)
+        if (lens == 0).any():
+            raise ValueError("EncodeCollator: a document tokenised to zero tokens (tokenizer adds no special tokens?)")
+        out = {"input_ids": torch.from_numpy(np.concatenate([np.asarray(e, dtype=np.int32) for e in enc])),
+               "cu_seqlens": torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)),
+               "max_seqlen": int(lens.max())}
+        if self.return_padded:
+            pad = self.tokenizer.pad_token_id
+            ids = np.full((len(enc), int(lens.max())), pad, dtype=np.int64)
+            mask = np.zeros_like(ids)
+            for i, e in enumerate(enc):
+                ids[i, :len(e)], mask[i, :len(e)] = e, 1
+            out["padded_input_ids"], out["padded_attention_mask"] = torch.from_numpy(ids), torch.from_numpy(mask)
+        return out
+
+
+def pack_padded_batch(input_ids: torch.Tensor, attention_mask: torch.Tensor):
+    """[B,S] ids + mask (the reference's psg dict) -> packed (ids int32 [T], cu_seqlens int32 [B+1], max_seqlen);
+    the integer work of utils/nested_input.py:15-39."""
+    mask = attention_mask.bool()
+    lens = mask.sum(dim=1)
+    ids = input_ids[mask].to(torch.int32).contiguous()
+    cu = torch.zeros(lens.numel() + 1, dtype=torch.int32, device=input_ids.device)
+    cu[1:] = torch.cumsum(lens, 0)
+    return ids, cu, int(lens.max().item())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# per-batch operators (B3)
+# ------------------------------------------------------------------------------------------------------------------
+class LrxHybridModel:
+    """encode_passage / encode_query of the reference's HybridModel restricted to the dense asymmetric configuration
+    (`hybrid_use_emb_vector` + `noncontextual_query_embedding`; score_function cos_sim -> normalize=True)."""
+
+    def __init__(self, encoder: LrxEncoder, normalize: bool = True, dense_shrink_dim: Optional[int] = None,
+                 pad_token_id: Optional[int] = None):
+        self.encoder = encoder
+        self.normalize = normalize
+        self.dense_shrink_dim = dense_shrink_dim
+        self.pad_token_id = pad_token_id
+        self.emb_bag: Optional[torch.Tensor] = None      # fp32 [V, H] on the GPU (weight of the reference's nn.EmbeddingBag)
+        self.emb_bag_prompt: Optional[str] = None
+
+    @property
+    def device(self):
+        return self.encoder.device
+
+    def encode_passage(self, psg: Optional[dict], normalize: Optional[bool] = None, out: Optional[torch.Tensor] = None, **kwargs):
+        """psg: packed {"input_ids" [T] i32, "cu_seqlens" [B+1] i32, "max_seqlen"} or the reference's padded
+        {"input_ids" [B,S], "attention_mask" [B,S]}.  -> {"dense_reps": fp32 [B, D] (GPU; `out` lets the caller pass index rows)}."""
+        if psg is None:
+            return None
+        normalize = self.normalize if normalize is None else normalize
+        ids = psg["input_ids"]
+        if "cu_seqlens" in psg:
+            ids = ids.to(self.device, non_blocking=True)
+            cu = psg["cu_seqlens"].to(self.device, non_blocking=True)
+            max_len = int(psg["max_seqlen"])
+        else:
+            if psg.get("attention_mask") is None:
+                raise KeyError("encode_passage: padded input needs attention_mask")
+            ids, cu, max_len = pack_padded_batch(ids.to(self.device), psg["attention_mask"].to(self.device))
+        reps = self.encoder.encode_packed(ids.to(torch.int32), cu.to(torch.int32), max_len, out=out, out_dim=self.dense_shrink_dim,
+                                          normalize=bool(normalize))
+        return {"dense_reps": reps}
+
+    def encode_query(self, qry: Optional[dict], normalize: Optional[bool] = None, **kwargs):
+        """-> {"emb_reps": fp32 [Q, D]} from nonctx_tok_emb_input_ids / nonctx_tok_emb_offsets (modeling_hybrid.py:472-490)."""
+        if qry is None:
+            return None
+        if self.emb_bag is None:
+            raise AssertionError("Please load or construct an EmbeddingBag before encoding queries")
+        normalize = self.normalize if normalize is None else normalize
+        ids = qry["nonctx_tok_emb_input_ids"].to(self.device, dtype=torch.int64)
+        offs = qry["nonctx_tok_emb_offsets"].to(self.device, dtype=torch.int64)
+        reps = ops.embedding_bag_mean(self.emb_bag, ids, offs, padding_idx=self.pad_token_id, out_dim=self.dense_shrink_dim,
+                                      normalize=bool(normalize))
+        return {"emb_reps": reps}
+
+    # -- EmbeddingBag construction (nonctx_emb_utils.py:239-313) --------------------------------------------------------
+    def construct_embedding_bag(self, tokenizer, prompt: Optional[str] = None, batch_size: int = 5000, vocab_len: Optional[int] = None):
+        """For every tok in [0, len(tokenizer)): encode [bos] + prompt + [tok] + [eos] and keep the final hidden state of
+        the last position, un-normalised, fp32.  Runs on this GPU through lrx_encode_packed (normalize=0) writing straight
+        into the table."""
+        V = vocab_len or len(tokenizer)
+        bos, eos = tokenizer.bos_token_id, tokenizer.eos_token_id
+        add_bos = bos is not None and bos in tokenizer.encode("", add_special_tokens=True)
+        prefix = ([bos] if add_bos else []) + (tokenizer.encode(prompt, add_special_tokens=False) if prompt else [])
+        L = len(prefix) + 2
+        H = self.encoder.cfg.hidden_size
+        table = torch.empty(V, H, dtype=torch.float32, device=self.device)
+        base = torch.empty(batch_size, L, dtype=torch.int32, device=self.device)
+        if prefix:
+            base[:, :len(prefix)] = torch.tensor(prefix, dtype=torch.int32, device=self.device)
+        base[:, -1] = eos
+        for s in range(0, V, batch_size):
+            e = min(s + batch_size, V)
+            n = e - s
+            base[:n, -2] = torch.arange(s, e, dtype=torch.int32, device=self.device)
+            cu = (torch.arange(n + 1, device=self.device, dtype=torch.int64) * L).to(torch.int32)
+            self.encoder.encode_packed(base[:n].reshape(-1), cu, L, out=table[s:e], normalize=False)
+        self.emb_bag, self.emb_bag_prompt = table, prompt
+        return table
+
+    def load_embedding_bag(self, weight: torch.Tensor, prompt: Optional[str] = None):
+        """`torch.save(emb_bag.weight, '*.emb_bag.pt')` artefacts of scripts/cache_emb_bag.ipynb."""
+        self.emb_bag = weight.to(self.device, dtype=torch.float32).contiguous()
+        self.emb_bag_prompt = prompt
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# encode_queries / encode_corpus (B2)
+# ------------------------------------------------------------------------------------------------------------------
+def _as_items(texts) -> list[dict]:
+    try:
+        import datasets
+        if isinstance(texts, datasets.Dataset):
+            return [dict(r) for r in texts]
+    except ImportError:  # pragma: no cover
+        pass
+    if isinstance(texts, list):
+        assert len(texts) > 0, "Empty lists."
+        if isinstance(texts[0], str):
+            return [{"text": t} for t in texts]
+        if isinstance(texts[0], dict):
+            return texts
+        raise NotImplementedError(f"Unrecognized texts[0] type {type(texts[0])}")
+    raise NotImplementedError(f"Unrecognized type {type(texts)}")
+
+
+@dataclass
+class LrxExactSearchModel:
+    """DRES-style adapter: `encode_queries`, `encode_corpus`, `encode`; mutable `query_prompt`, `corpus_prompt`,
+    `encoding_kwargs` (set per task by eval/evaluate_mteb.py:96-98).  Results: dict with `emb_reps` (queries) /
+    `dense_reps` (corpus) like the reference's HybridModel path; row i of the output is input i."""
+    model: LrxHybridModel
+    tokenizer: object
+    q_max_len: int = 512
+    p_max_len: int = 512
+    append_prompt_sep: bool = False
+    eval_batch_size_embedding_bag: int = 5000
+    query_prompt: Optional[str] = None
+    corpus_prompt: Optional[str] = None
+    encoding_kwargs: dict = field(default_factory=dict)
+
+    def parse_texts(self, texts, prompt: Optional[str] = None) -> list[dict]:
+        items = _as_items(texts)
+        if prompt and not any("prompt" in it for it in items):   # `prompt` only applies when no prompt column exists
+            if self.append_prompt_sep:
+                prompt = prompt + self.tokenizer.sep_token + " "
+            items = [dict(it, prompt=prompt) for it in items]
+        return items
+
+    def encode_queries(self, queries, batch_size: int, show_progress_bar: bool = True, convert_to_tensor: bool = True, **kwargs):
+        # the query prompt lives inside the EmbeddingBag table (exact_search_torchrpc.py:139-160): rebuild when it changes
+        if self.model.emb_bag is None or self.model.emb_bag_prompt != self.query_prompt:
+            self.model.construct_embedding_bag(self.tokenizer, prompt=self.query_prompt, batch_size=self.eval_batch_size_embedding_bag)
+        items = _as_items(queries)
+        coll = EncodeCollator(self.tokenizer, encode_is_query=True, q_max_len=self.q_max_len, p_max_len=self.p_max_len)
+        outs = []
+        for s in range(0, len(items), batch_size):
+            outs.append(self.model.encode_query(coll(items[s:s + batch_size]))["emb_reps"])
+        reps = torch.cat(outs, 0)
+        return {"emb_reps": reps if convert_to_tensor else reps.cpu().numpy()}
+
+    def encode_corpus(self, corpus, batch_size: int, show_progress_bar: bool = True, convert_to_tensor: bool = True,
+                      out: Optional[torch.Tensor] = None, **kwargs):
+        return self.encode(corpus, batch_size, show_progress_bar, convert_to_tensor, out=out, **kwargs)
+
+    def encode(self, sentences, batch_size: int, show_progress_bar: bool = True, convert_to_tensor: bool = True,
+               out: Optional[torch.Tensor] = None, **kwargs):
+        items = self.parse_texts(sentences, prompt=self.corpus_prompt)
+        coll = EncodeCollator(self.tokenizer, encode_is_query=False, q_max_len=self.q_max_len, p_max_len=self.p_max_len)
+        D = self.model.dense_shrink_dim or self.model.encoder.cfg.hidden_size
+        if out is None:
+            out = torch.empty(len(items), D, dtype=torch.float32, device=self.model.device)
+        for s in range(0, len(items), batch_size):
+            e = min(s + batch_size, len(items))
+            self.model.encode_passage(coll(items[s:e]), out=out[s:e])
+        reps = out[:len(items)]
+        return {"dense_reps": reps if convert_to_tensor else reps.cpu().numpy()}

@@ -1,0 +1,301 @@
+"""Host-side mirror of the reference's searcher interfaces, dense branch only.
+
+    FaissIndex          <- retriever/faiss_index.py:20-73      (build / search / reset over the HBM-resident FlatIPIndex)
+    FlatIPFaissSearch   <- retriever/faiss_search.py:46-293, :477-510   (BEIR-style dense searcher)
+    HybridSearch        <- retriever/hybrid_search.py:25-403   (dense `den` / `emb` branches; sparse + fusion out of scope)
+
+Design differences, results preserved: corpus embeddings are encoded straight into the index shard (no CPU round trip, no
+`index.add` copy); the per-chunk (score, pid) heaps of hybrid_search.py:182-205 are a running [Q, top_k] list kept on the
+GPU and merged with lrx_merge_topk, so Python touches O(Q*k) values once at the end instead of once per corpus chunk.
+`ignore_identical_ids` keeps the reference's order of operations (per-chunk top_k first, then the qid == pid hit is dropped).
+"""
+from __future__ import annotations
+
+import logging
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .index import FlatIPIndex, merge_topk
+
+logger = logging.getLogger(__name__)
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+class FaissIndex:
+    """`FaissIndex(index, passage_ids)` of the reference: search() maps row numbers through `_passage_ids` and logs QPS."""
+
+    def __init__(self, index: FlatIPIndex, passage_ids: Optional[list] = None):
+        self.index = index
+        self._passage_ids = None if passage_ids is None else torch.as_tensor(np.asarray(passage_ids, dtype=np.int64), device=index.device)
+
+    def search(self, query_embeddings, k: int, **kwargs):
+        n = query_embeddings.shape[0]
+        t0 = time.time()
+        scores, ids = self.index.search(query_embeddings, k)
+        if self._passage_ids is not None:
+            ids = torch.where(ids >= 0, self._passage_ids[ids.clamp(min=0)], ids)
+        torch.cuda.synchronize(self.index.device)
+        dt = max(time.time() - t0, 1e-9)
+        logger.info("Num of queries: %d\tSearch time (s): %.3f\tQPS: %.3f", n, dt, n / dt)
+        return scores, ids
+
+    @classmethod
+    def build(cls, passage_ids: list, passage_embeddings, index: Optional[FlatIPIndex] = None, buffer_size: int = 50000):
+        if index is None:
+            index = FlatIPIndex(passage_embeddings.shape[1], capacity=len(passage_ids))
+        for s in range(0, len(passage_ids), buffer_size):
+            index.add(passage_embeddings[s:s + buffer_size])
+        return cls(index, passage_ids)
+
+    def to_gpu(self):
+        return self.index   # already HBM-resident; multi-GPU = one process per GPU (sharded.ShardedFlatIPIndex)
+
+    def reset(self):
+        self.index.reset()
+
+
+def _ids_and_list(queries):
+    if isinstance(queries, dict):
+        return list(queries.keys()), [queries[q] for q in queries]
+    try:
+        import datasets
+        if isinstance(queries, datasets.Dataset):
+            name = None
+            for c in ["id", "_id", "query_id"]:
+                if c in queries.column_names:
+                    name = c
+            if name is None:
+                raise KeyError(f"No id column in queries dataset {queries.column_names}")
+            return list(queries[name]), queries
+    except ImportError:  # pragma: no cover
+        pass
+    raise NotImplementedError(f"Unrecognized type {type(queries)}")
+
+
+def _sorted_corpus(corpus):
+    """Longest text first (faiss_search.py:214-216 / hybrid_search.py:273-276); returns (corpus_ids, list of docs)."""
+    if isinstance(corpus, dict):
+        ids = sorted(corpus, key=lambda k: len(corpus[k].get("text", "")) if isinstance(corpus[k], dict) else len(corpus[k]), reverse=True)
+        return ids, [corpus[c] for c in ids]
+    try:
+        import datasets
+        if isinstance(corpus, datasets.Dataset):
+            name = None
+            for c in ["id", "_id", "docid", "doc_id"]:
+                if c in corpus.column_names:
+                    name = c
+            if name is None:
+                raise KeyError(f"No id column in corpus dataset {corpus.column_names}")
+            order = sorted(range(len(corpus)), key=lambda i: len(corpus[i]["text"]), reverse=True)
+            rows = [dict(corpus[i]) for i in order]
+            return [r[name] for r in rows], rows
+    except ImportError:  # pragma: no cover
+        pass
+    raise NotImplementedError(f"Unrecognized type {type(corpus)}")
+
+
+class DenseRetrievalFaissSearch:
+    def __init__(self, model, batch_size: int = 128, corpus_chunk_size: Optional[int] = None, use_single_gpu: bool = False,
+                 use_multiple_gpu: bool = False, **kwargs):
+        self.model = model       # provides encode_corpus() and encode_queries()
+        self.batch_size = batch_size
+        self.corpus_chunk_size = batch_size * 800 if corpus_chunk_size is None else corpus_chunk_size
+        self.show_progress_bar = kwargs.get("show_progress_bar", True)
+        self.convert_to_tensor = kwargs.get("convert_to_tensor", True)
+        self.faiss_index: Optional[FaissIndex] = None
+        self.use_single_gpu, self.use_multiple_gpu = use_single_gpu, use_multiple_gpu
+        self.dim_size = None
+        self.mapping, self.rev_mapping = {}, {}
+        self.mteb_model_meta = None
+
+    @classmethod
+    def name(cls):
+        return "faiss_search"
+
+    def encode(self, sentences, batch_size, show_progress_bar=True, convert_to_tensor=True, **kwargs):
+        return self.model.encode(sentences=sentences, batch_size=batch_size, show_progress_bar=show_progress_bar, convert_to_tensor=convert_to_tensor, **kwargs)
+
+    def encode_queries(self, queries, batch_size, show_progress_bar=True, convert_to_tensor=True, **kwargs):
+        return self.model.encode_queries(queries=queries, batch_size=batch_size, show_progress_bar=show_progress_bar, convert_to_tensor=convert_to_tensor, **kwargs)
+
+    def encode_corpus(self, corpus, batch_size, show_progress_bar=True, convert_to_tensor=True, **kwargs):
+        return self.model.encode_corpus(corpus=corpus, batch_size=batch_size, show_progress_bar=show_progress_bar, convert_to_tensor=convert_to_tensor, **kwargs)
+
+    def _create_mapping_ids(self, corpus_ids):
+        if not all(isinstance(d, int) for d in corpus_ids):
+            for i, d in enumerate(corpus_ids):
+                self.mapping[d] = i
+                self.rev_mapping[i] = d
+
+    def _clear(self):
+        if self.faiss_index is not None:
+            self.faiss_index.reset()
+        self.faiss_index = None
+        self.dim_size = None
+        self.mapping, self.rev_mapping = {}, {}
+
+    def index(self, corpus_emb, corpus_ids):
+        raise NotImplementedError("Base class function. Please implement this depands on index type.")
+
+    # -- device-level retrieval used by the chunk loop ---------------------------------------------------------------
+    def _retrieve_device(self, query_emb, top_k: int):
+        return self.faiss_index.search(_as_device(query_emb, self.faiss_index.index.device), top_k)
+
+    def retrieve_with_emb(self, query_emb, query_ids: list, top_k: int, **kwargs) -> dict:
+        """-> {qid: {pid: score}} (faiss_search.py:143-173).  Rows beyond the index size (id -1) are dropped."""
+        scores, ids = self._retrieve_device(query_emb, top_k)
+        return _to_result_dict(scores, ids, query_ids, self.rev_mapping)
+
+    def search(self, corpus, queries, top_k: int = 1000, score_function: str = None, return_sorted: bool = False,
+               ignore_identical_ids: bool = False, **kwargs) -> dict:
+        query_ids, queries_list = _ids_and_list(queries)
+        q = self.model.encode_queries(queries_list, batch_size=self.batch_size, show_progress_bar=self.show_progress_bar,
+                                      convert_to_tensor=self.convert_to_tensor)
+        if isinstance(q, dict):
+            q = q["dense_reps"] if "dense_reps" in q else q["emb_reps"]
+        return _chunked_dense_search(self, q, query_ids, corpus, top_k, ignore_identical_ids)
+
+
+class FlatIPFaissSearch(DenseRetrievalFaissSearch):
+    def index(self, corpus_emb, corpus_ids):
+        """Index already-encoded embeddings (Tensor on any device / ndarray) -- faiss_search.py:490-504."""
+        self._create_mapping_ids(corpus_ids)
+        self.dim_size = corpus_emb.shape[1]
+        rows = [self.mapping.get(c, c) for c in corpus_ids]
+        self.faiss_index = FaissIndex.build(rows, corpus_emb)
+
+    def _index_in_place(self, docs: list, corpus_ids: list, dim: int):
+        """Encode a corpus chunk straight into a fresh shard (embeddings never leave HBM)."""
+        self._create_mapping_ids(corpus_ids)
+        self.dim_size = dim
+        idx = FlatIPIndex(dim, capacity=len(docs))
+        slot = idx.append_slot(len(docs))
+        emb = self.model.encode_corpus(docs, batch_size=self.batch_size, show_progress_bar=self.show_progress_bar,
+                                       convert_to_tensor=True, out=slot)
+        if isinstance(emb, dict):
+            emb = emb["dense_reps"]
+        if emb.data_ptr() != slot.data_ptr():       # a model that does not support `out=`: one device copy
+            slot.copy_(emb.to(slot.device))
+        idx.commit(len(docs))
+        self.faiss_index = FaissIndex(idx, [self.mapping.get(c, c) for c in corpus_ids])
+
+    def get_index_name(self):
+        return "flat_faiss_index"
+
+
+class HybridSearch:
+    """Dense half of the reference's HybridSearch: routes `dense_reps` -> results["den"], `emb_reps` -> results["emb"]
+    (hybrid_search.py:121-180); `search()` returns the last enabled type unless return_all_results."""
+
+    def __init__(self, model, batch_size: int = 128, corpus_chunk_size: Optional[int] = None, use_multiple_gpu: bool = False,
+                 fuse_weights=(0.7, 0.3), return_all_results: bool = False, **kwargs):
+        self.model = model
+        self.batch_size = batch_size
+        self.corpus_chunk_size = batch_size * 800 if corpus_chunk_size is None else corpus_chunk_size
+        self.show_progress_bar = kwargs.get("show_progress_bar", True)
+        self.convert_to_tensor = kwargs.get("convert_to_tensor", True)
+        self.dense_search = FlatIPFaissSearch(model, batch_size=batch_size, corpus_chunk_size=corpus_chunk_size, use_multiple_gpu=use_multiple_gpu)
+        self.return_all_results = return_all_results
+        self.mteb_model_meta = None
+
+    @classmethod
+    def name(cls):
+        return "hybrid_search"
+
+    def encode(self, sentences, batch_size, **kw):
+        return self.model.encode(sentences=sentences, batch_size=batch_size, **kw)
+
+    def encode_queries(self, queries, batch_size, **kw):
+        return self.model.encode_queries(queries=queries, batch_size=batch_size, **kw)
+
+    def encode_corpus(self, corpus, batch_size, **kw):
+        return self.model.encode_corpus(corpus=corpus, batch_size=batch_size, **kw)
+
+    def _clear(self, dense: bool = True, sparse: bool = True):
+        if dense:
+            self.dense_search._clear()
+
+    def index(self, corpus_emb: dict, corpus_ids: list):
+        assert isinstance(corpus_emb, dict) and corpus_emb.get("dense_reps") is not None
+        self.dense_search.index(corpus_emb["dense_reps"], corpus_ids)
+
+    def retrieve_with_emb(self, query_emb: dict, query_ids: list, top_k: int, dense: bool = True, sparse: bool = True, **kwargs):
+        assert isinstance(query_emb, dict) and (query_emb.get("dense_reps") is not None or query_emb.get("emb_reps") is not None)
+        results = {}
+        if dense:
+            if query_emb.get("dense_reps") is not None:
+                results["den"] = self.dense_search.retrieve_with_emb(query_emb["dense_reps"], query_ids, top_k=top_k)
+            if query_emb.get("emb_reps") is not None:
+                results["emb"] = self.dense_search.retrieve_with_emb(query_emb["emb_reps"], query_ids, top_k=top_k)
+        return results
+
+    def search(self, corpus, queries, top_k: int = 1000, score_function: str = None, return_sorted: bool = False,
+               ignore_identical_ids: bool = False, **kwargs):
+        query_ids, queries_list = _ids_and_list(queries)
+        qe = self.model.encode_queries(queries_list, batch_size=self.batch_size, show_progress_bar=self.show_progress_bar,
+                                       convert_to_tensor=self.convert_to_tensor)
+        assert isinstance(qe, dict) and ("dense_reps" in qe or "emb_reps" in qe)
+        results, default = {}, None
+        # one corpus pass serves every enabled query representation (they share the document `dense_reps`)
+        kinds = [(k, name) for k, name in (("dense_reps", "den"), ("emb_reps", "emb")) if qe.get(k) is not None]
+        multi = _chunked_dense_search(self.dense_search, [qe[k] for k, _ in kinds], query_ids, corpus, top_k, ignore_identical_ids)
+        for (_, name), res in zip(kinds, multi):
+            results[name] = res
+            default = res
+        self._clear()
+        return results if self.return_all_results else default
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _as_device(x, device):
+    if not isinstance(x, torch.Tensor):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    return x.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _to_result_dict(scores: torch.Tensor, ids: torch.Tensor, query_ids: list, rev_mapping: dict) -> dict:
+    S, I = scores.cpu().numpy(), ids.cpu().numpy()
+    out = {}
+    for qi, qid in enumerate(query_ids):
+        row = {}
+        for s, r in zip(S[qi], I[qi]):
+            if r < 0:
+                continue
+            row[rev_mapping[int(r)] if rev_mapping else str(int(r))] = float(s)
+        out[qid] = row
+    return out
+
+
+def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: list, corpus, top_k: int, ignore_identical_ids: bool):
+    """Chunk loop of faiss_search.py:228-291 / hybrid_search.py:301-358: encode chunk -> index -> retrieve -> merge.
+    `query_embs` may be one tensor or a list of tensors (several query representations scored against the same docs)."""
+    single = not isinstance(query_embs, (list, tuple))
+    qlist = [query_embs] if single else list(query_embs)
+    corpus_ids, docs = _sorted_corpus(corpus)
+    n = len(docs)
+    device = searcher.model.model.device if hasattr(searcher.model, "model") and hasattr(searcher.model.model, "device") else torch.device("cuda", torch.cuda.current_device())
+    qlist = [_as_device(q, device) for q in qlist]
+    dim = qlist[0].shape[1]
+    Q = len(query_ids)
+    row_of = {c: i for i, c in enumerate(corpus_ids)}
+    ident = torch.tensor([row_of.get(q, -2) for q in query_ids], dtype=torch.int64, device=device) if ignore_identical_ids else None
+    run_D = [torch.full((Q, top_k), -FLT_MAX, dtype=torch.float32, device=device) for _ in qlist]
+    run_I = [torch.full((Q, top_k), -1, dtype=torch.int64, device=device) for _ in qlist]
+    for s in range(0, n, searcher.corpus_chunk_size):
+        e = min(s + searcher.corpus_chunk_size, n)
+        logger.info("Encoding Batch %d/%d...", s // searcher.corpus_chunk_size + 1, -(-n // searcher.corpus_chunk_size))
+        searcher._index_in_place(docs[s:e], list(range(s, e)), dim)   # rows carry their global sorted position
+        for j, q in enumerate(qlist):
+            D, I = searcher._retrieve_device(q, top_k)
+            if ident is not None:                     # drop the qid == pid hit AFTER the per-chunk top_k, like the reference
+                hit = I == ident[:, None]
+                D = torch.where(hit, torch.full_like(D, -FLT_MAX), D)
+                I = torch.where(hit, torch.full_like(I, -1), I)
+            run_D[j], run_I[j] = merge_topk(torch.stack([run_D[j], D]), torch.stack([run_I[j], I]))
+        searcher._clear()
+    rev = {i: c for i, c in enumerate(corpus_ids)}
+    outs = [_to_result_dict(d, i, query_ids, rev) for d, i in zip(run_D, run_I)]
+    return outs[0] if single else outs

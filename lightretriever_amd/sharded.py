@@ -46,9 +46,10 @@ def exchange_topk(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.Process
     packed = pack_pairs(D, I)
     if world == 1:
         return D.unsqueeze(0), I.unsqueeze(0)
-    out = torch.empty((world,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
-    return unpack_pairs(out)
+    Q = packed.shape[0]
+    out = torch.empty((world * Q,) + tuple(packed.shape[1:]), dtype=torch.int64, device=packed.device)   # concat form: nccl + gloo
+    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
+    return unpack_pairs(out.view((world, Q) + tuple(packed.shape[1:])))
 
 
 class ShardedFlatIPIndex:

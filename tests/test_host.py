@@ -1,0 +1,149 @@
+"""CPU tests of the host-side logic: collator vs the fixture produced by the reference's EncodeCollator, text formatting,
+corpus sorting, shard assignment, pair packing, and the N>1 exchange over gloo (world_size 2)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lrx_oracle as O
+from helpers import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def tok():
+    from transformers import PreTrainedTokenizerFast
+    return PreTrainedTokenizerFast.from_pretrained(os.path.join(GOLDEN, "tok"))
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return json.load(open(os.path.join(GOLDEN, "collator.json")))
+
+
+def test_doc_collator_matches_reference_tokens(tok, fx):
+    from lightretriever_amd.modeling import EncodeCollator
+    coll = EncodeCollator(tok, encode_is_query=False, q_max_len=fx["q_max_len"], p_max_len=fx["p_max_len"], return_padded=True)
+    out = coll(fx["docs"])
+    ids, mask = np.array(fx["doc_input_ids"]), np.array(fx["doc_attention_mask"])
+    np.testing.assert_array_equal(out["padded_input_ids"].numpy(), ids)
+    np.testing.assert_array_equal(out["padded_attention_mask"].numpy(), mask)
+    nested, _, _, cu, max_len = O.pack_padded(ids, mask)             # packed output == the reference's unpad of its own batch
+    np.testing.assert_array_equal(out["input_ids"].numpy(), nested)
+    np.testing.assert_array_equal(out["cu_seqlens"].numpy(), cu)
+    assert out["max_seqlen"] == max_len == fx["p_max_len"]
+    assert out["input_ids"].dtype == torch.int32 and out["cu_seqlens"].dtype == torch.int32
+    # prompt column is string-prepended
+    p = coll([fx["doc_prompted"]])
+    np.testing.assert_array_equal(p["padded_input_ids"].numpy(), np.array(fx["doc_prompted_input_ids"]))
+
+
+def test_query_collator_matches_reference_tokens(tok, fx):
+    from lightretriever_amd.modeling import EncodeCollator
+    coll = EncodeCollator(tok, encode_is_query=True, q_max_len=fx["q_max_len"], p_max_len=fx["p_max_len"])
+    out = coll(fx["queries"])
+    np.testing.assert_array_equal(out["nonctx_tok_emb_input_ids"].numpy(), np.array(fx["qry_nonctx_input_ids"]))
+    np.testing.assert_array_equal(out["nonctx_tok_emb_offsets"].numpy(), np.array(fx["qry_nonctx_offsets"]))
+    assert out["nonctx_tok_emb_input_ids"].dtype == torch.int64
+
+
+def test_format_text_rules():
+    from lightretriever_amd.modeling import format_text
+    assert format_text({"title": "T", "text": "x"}) == "T x"
+    assert format_text({"title": "", "text": "x"}) == "x"
+    assert format_text({"text": "x", "prompt": "p: "}) == "x"
+    assert format_text({"title": "T", "text": "x", "prompt": "p: "}, prepend_prompt=True) == "p: T x"
+
+
+def test_parse_texts_prompt_rules(tok):
+    from lightretriever_amd.modeling import LrxExactSearchModel
+    m = LrxExactSearchModel(model=None, tokenizer=tok)
+    assert m.parse_texts(["a", "b"], prompt="P ") == [{"text": "a", "prompt": "P "}, {"text": "b", "prompt": "P "}]
+    assert m.parse_texts([{"text": "a", "prompt": "X"}], prompt="P ") == [{"text": "a", "prompt": "X"}]   # existing prompt wins
+    assert m.parse_texts(["a"], prompt="") == [{"text": "a"}]
+    m.append_prompt_sep = True
+    assert m.parse_texts(["a"], prompt="P")[0]["prompt"] == "P" + tok.sep_token + " "
+    with pytest.raises(NotImplementedError):
+        m.parse_texts(("a",))
+    with pytest.raises(AssertionError):
+        m.parse_texts([])
+
+
+def test_corpus_sort_and_id_columns():
+    from lightretriever_amd.retriever import _sorted_corpus, _ids_and_list
+    corpus = {"a": {"text": "xx"}, "b": {"text": "xxxx", "title": "t"}, "c": {"text": "xx"}, "d": "xxxxxxx"}
+    ids, docs = _sorted_corpus(corpus)
+    assert ids == O.sort_corpus_ids_longest_first(corpus) == ["d", "b", "a", "c"]      # stable for equal lengths
+    assert docs[1] == corpus["b"]
+    assert _ids_and_list({"q1": "x", "q2": "y"}) == (["q1", "q2"], ["x", "y"])
+    with pytest.raises(NotImplementedError):
+        _sorted_corpus([1, 2])
+    with pytest.raises(NotImplementedError):
+        _ids_and_list(["x"])
+    import datasets
+    ds = datasets.Dataset.from_list([{"foo": "1", "text": "abc"}])
+    with pytest.raises(KeyError):
+        _sorted_corpus(ds)
+    with pytest.raises(KeyError):
+        _ids_and_list(ds)
+    ds2 = datasets.Dataset.from_list([{"_id": "1", "text": "a"}, {"_id": "2", "text": "abc"}])
+    assert _sorted_corpus(ds2)[0] == ["2", "1"]
+
+
+def test_shard_assignment_is_a_partition():
+    from lightretriever_amd.sharded import batches_for_rank, local_to_global_rows
+    n, bs = 1003, 64
+    for world in (1, 2, 3, 8):
+        rows = [local_to_global_rows(n, bs, r, world) for r in range(world)]
+        allrows = torch.cat(rows).sort().values
+        assert torch.equal(allrows, torch.arange(n))
+        sizes = [len(r) for r in rows]
+        assert max(sizes) - min(sizes) <= bs
+        assert batches_for_rank(n, bs, 0, world)[0] == (0, 64)
+
+
+def test_pair_packing_roundtrip():
+    from lightretriever_amd.sharded import pack_pairs, unpack_pairs
+    D = torch.tensor([[0.5, -1.25, -3.4028235e38, 1e-20], [1.0, 0.0, -0.0, 3.0]], dtype=torch.float32)
+    I = torch.tensor([[0, 123456789, -1, 2 ** 31 - 1], [5, 6, 7, 9_999_999]], dtype=torch.int64)
+    d, i = unpack_pairs(pack_pairs(D, I))
+    assert torch.equal(d.view(torch.int32), D.view(torch.int32)) and torch.equal(i, I)
+
+
+def _gloo_worker(rank, world, port, q, X, k, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lightretriever_amd.sharded import exchange_topk, local_to_global_rows
+    rows = local_to_global_rows(X.shape[0], 16, rank, world).numpy()      # interleaved batches of 16 rows
+    D, I = O.flat_ip_topk(q, X[rows], k)                                    # oracle stands in for the HIP shard search on CPU
+    I = np.where(I >= 0, rows[np.clip(I, 0, None)], -1)                      # local -> global rows (row_map)
+    Dp, Ip = exchange_topk(torch.from_numpy(D), torch.from_numpy(I))
+    Dm, Im = O.merge_topk(list(Dp.numpy()), list(Ip.numpy()), k)
+    ret[rank] = (Dm, Im)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_search_over_gloo_world2():
+    """N>1 path on CPU: two processes, interleaved row shards, all-gather of packed pairs, merge == whole-index search."""
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(3)
+    X = O.l2_normalize(rng.standard_normal((150, 32)).astype(np.float32))
+    X[7] = X[140]                      # a cross-shard tie
+    q = O.l2_normalize(rng.standard_normal((6, 32)).astype(np.float32))
+    k = 20
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q, X, k, ret)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    Dw, Iw = O.flat_ip_topk(q, X, k)
+    for r in range(2):
+        np.testing.assert_array_equal(ret[r][1], Iw)
+        np.testing.assert_array_equal(ret[r][0], Dw)
