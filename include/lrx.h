@@ -51,7 +51,7 @@ typedef struct lrx_encoder_config {
 /* Per-layer weights, bf16, nn.Linear layout [out, in] row-major (K contiguous).
  *   wqkv  [(nq + 2 nkv) * d, H]   rows = q_proj | k_proj | v_proj concatenated
  *   wo    [H, nq * d]
- *   wgu   [2 * I, H]              gate/up interleaved in 32-row groups: rows [64j,64j+32) = gate[32j..], [64j+32,64j+64) = up[32j..]
+ *   wgu   [2 * I, H]              gate/up interleaved in 16-row groups: rows [32j,32j+16) = gate[16j..], [32j+16,32j+32) = up[16j..]
  *   wdown [H, I]
  *   ln1, ln2 [H] bf16 (input_layernorm, post_attention_layernorm); bqkv [(nq+2nkv)*d] bf16 or NULL            */
 typedef struct lrx_layer_weights {

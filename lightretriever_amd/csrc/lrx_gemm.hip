@@ -1,163 +1,209 @@
 // bf16 GEMM  C[M,N] = A[M,K] * B[N,K]^T  (nn.Linear layout, both operands K-contiguous) on gfx950 MFMA.
 //
-// Tile 256 x 256 x 64, 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 tiles
-// (128 fp32 accumulators per lane).  Operands are staged global -> LDS with 16-byte global_load_lds (LDS-DMA, no
-// VGPR round trip); the LDS image is lane-linear per wave instruction, so the bank-conflict swizzle is applied to
-// the per-lane SOURCE address and undone on the ds_read_b128 side (16-B chunk index ^= (row >> 1) & 7, which makes
-// every 16-lane ds_read_b128 group hit 16 distinct 16-B slots of the 256-B bank row).  Two LDS stages (128 KiB):
-// tile t+1 streams in while tile t feeds the matrix cores.
+// Tile 256 x 256 x 64, 512 threads = 8 waves as 2 (M) x 4 (N).  Each operand tile is split into two 128-row HALF-TILES
+// (16 KiB each, A0/A1/B0/B1); wave (wr, wc) owns rows wr*64..+63 of EACH A half and columns wc*32..+31 of EACH B half, so
+// its 128 x 64 output is four 64 x 32 quadrants (A-half h) x (B-half h'), one quadrant = 16 MFMA 16x16x32 per K-tile.
 //
-// The MFMA is issued with the WEIGHT fragment as the A operand and the ACTIVATION fragment as the B operand, so a
-// lane ends up holding 4 consecutive output columns of one output row -> 8-byte stores and lane-local SwiGLU pairs.
+// 8-phase schedule (4 phases per K-tile, 2 K-tiles of LDS = 8 half-tile slots, 128 KiB):
+//   phase = { ds_read the register sub-tile this quadrant needs ; issue ONE half-tile of LDS-DMA (2 x global_load_lds
+//             dwordx4 per lane) ; s_waitcnt lgkmcnt(0) ; s_barrier ; 16 MFMA under s_setprio(1) ; s_barrier }
+//   quadrant walk (0,0) (0,1) (1,1) (1,0): reads B0+A0 | B1 | A1 | B0, so a half-tile dies early and its slot is
+//   refilled one phase after its last read:  p1 issues B0(t+1), p2 A0(t+2), p3 B1(t+2), p4 A1(t+2).
+//   One counted wait per K-tile: s_waitcnt vmcnt(6) in p4 (three half-tiles stay in flight across the barriers; never 0
+//   in steady state), followed by the barrier, retires everything K-tile t+1 reads.
+//   The two wave groups (waves 0-3 / 4-7, one wave of each per SIMD) run offset by one barrier, so one group's MFMA
+//   section overlaps the other group's LDS-read/issue section on every SIMD.
+// LDS image per half-tile is lane-linear per LDS-DMA instruction; the bank swizzle (16-B chunk ^= (row>>1)&7) is applied
+// to the per-lane SOURCE address and undone on the ds_read_b128 side -> conflict-free fragment reads.
 //
-// Workgroup -> tile map: bijective XCD-chunked remap (blocks b and b+8 share an XCD's L2) and, inside an XCD's
-// chunk, 8-m-tile groups walked n-fastest so the 32 co-resident tiles of an XCD share 8 A panels and 4 B panels.
+// The MFMA takes the WEIGHT fragment as A and the ACTIVATION fragment as B, so a lane holds 4 consecutive output columns
+// of one row: 8-byte stores, fused bias / residual, and lane-local SwiGLU pairs (gate/up interleaved in 16-row groups).
+//
+// Workgroup -> tile map: bijective XCD-chunked remap (blocks b and b+8 share an XCD L2) + 8-m-tile groups walked
+// n-fastest inside an XCD chunk, so the 32 co-resident tiles of an XCD share 8 A panels and 4 B panels.
 #include "lrx_common.h"
 
 #define GBM 256
 #define GBN 256
 #define GBK 64
-#define G_TILE_BYTES (GBM * GBK * 2)  // 32 KiB per operand per stage
+#define HALF_BYTES 16384
 
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+#define G_BAR()                            \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+#define G_LSYNC()                                          \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    G_BAR();                                               \
+  } while (0)
+
 template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
                const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(1024))) char smem[4 * G_TILE_BYTES];  // [stage][A|B]
+  __shared__ __attribute__((aligned(1024))) char smem[8 * HALF_BYTES];  // [buf 0/1][A0 | A1 | B0 | B1]
 
   // ---- workgroup -> tile
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
-  const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int t_lin = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   const int GM = 8;
   const int width = GM * tiles_n;
-  const int group = t / width, first_m = group * GM;
+  const int group = t_lin / width, first_m = group * GM;
   const int gsz = min(tiles_m - first_m, GM);
-  const int tin = t - group * width;
+  const int tin = t_lin - group * width;
   const int tm = first_m + tin % gsz, tn = tin / gsz;
   const int m0 = tm * GBM, n0 = tn * GBN;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
 
-  // ---- staging sources: 4 LDS-DMA instructions per operand per wave per tile; lane l of instruction i fills slot
-  //      s = (wave*4+i)*64 + l  ->  row = s>>3, swizzled chunk position cs = s&7 holding logical chunk cs ^ ((row>>1)&7)
-  const __bf16* pa[4];
-  const __bf16* pb[4];
+  // ---- LDS-DMA sources: per half-tile 2 instructions per lane; lane l of instruction i fills 16-B slot
+  //      s = (wave*2+i)*64 + l  ->  row = s>>3 (0..127), chunk position s&7 holding logical chunk (s&7) ^ ((row>>1)&7)
+  const __bf16 *pA0[2], *pA1[2], *pB0[2], *pB1[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int s = (wave * 4 + i) * 64 + lane;
+  for (int i = 0; i < 2; ++i) {
+    int s = (wave * 2 + i) * 64 + lane;
     int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
-    int ga = min(m0 + row, M - 1), gb = min(n0 + row, N - 1);
-    pa[i] = A + (int64_t)ga * K + c * 8;
-    pb[i] = B + (int64_t)gb * K + c * 8;
+    pA0[i] = A + (int64_t)min(m0 + row, M - 1) * K + c * 8;
+    pA1[i] = A + (int64_t)min(m0 + 128 + row, M - 1) * K + c * 8;
+    pB0[i] = B + (int64_t)min(n0 + row, N - 1) * K + c * 8;
+    pB1[i] = B + (int64_t)min(n0 + 128 + row, N - 1) * K + c * 8;
   }
-  auto stage = [&](int st, int k0) {
-    char* sA = smem + st * (2 * G_TILE_BYTES);
-    char* sB = sA + G_TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(pa[i] + k0), (lptr_t)(sA + (wave * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pb[i] + k0), (lptr_t)(sB + (wave * 4 + i) * 1024), 16, 0, 0);
-    }
-  };
+  char* const dma_dst = smem + wave * 2048;  // + buf*65536 + slot*16384 + i*1024
+#define G_ISSUE(P, SLOT, BUF, KT)                                                                                          \
+  do {                                                                                                                     \
+    __builtin_amdgcn_global_load_lds((gptr_t)(P[0] + (KT) * GBK), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES), 16, 0, 0);        \
+    __builtin_amdgcn_global_load_lds((gptr_t)(P[1] + (KT) * GBK), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES + 1024), 16, 0, 0); \
+  } while (0)
 
-  // ---- fragment read offsets (bytes inside an operand tile), lane part
+  // ---- fragment read offsets
   const int fr = lane & 15, fq = lane >> 4;
-  const int xs = fr >> 1;  // (row>>1)&7 for row = 16*k + fr
+  const int xs = fr >> 1;
   int laneoff[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) laneoff[ks] = fr * 128 + (((ks * 4 + fq) ^ xs) << 4);
-  const int a_base = (wm * 128) * 128, b_base = (wn * 64) * 128;
+  const int a_off = (wr * 64) * 128, b_off = 2 * HALF_BYTES + (wc * 32) * 128;
 
-  f32x4 acc[8][4];
+  f32x4 acc[2][2][4][2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[h][hp][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 a[4][2], b[2][2];
+
+#define G_LDA(H)                                                                                     \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)  \
+      a[mi][ks] = *(const bf16x8*)(sbuf + (H) * HALF_BYTES + a_off + mi * 2048 + laneoff[ks]);
+#define G_LDB(HP)                                                                                    \
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)  \
+      b[ni][ks] = *(const bf16x8*)(sbuf + (HP) * HALF_BYTES + b_off + ni * 2048 + laneoff[ks]);
+#define G_MM(H, HP)                                                                                   \
+  do {                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[H][HP][mi][ni] =                        \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][ks], a[mi][ks], acc[H][HP][mi][ni], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+  } while (0)
 
   const int nk = K / GBK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * GBK);
-    const char* sA = smem + cur * (2 * G_TILE_BYTES) + a_base;
-    const char* sB = smem + cur * (2 * G_TILE_BYTES) + G_TILE_BYTES + b_base;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[8], bfr[4];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) bfr[ni] = *(const bf16x8*)(sB + ni * 2048 + laneoff[ks]);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) af[mi] = *(const bf16x8*)(sA + mi * 2048 + laneoff[ks]);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ---- epilogue: lane holds row m = .. + fr, columns n = .. + fq*4 + {0,1,2,3}
-  const int mrow0 = m0 + wm * 128 + fr;
-  const int ncol0 = n0 + wn * 64 + fq * 4;
-  if (EPI == EPI_SWIGLU) {
-    const int ldc = N >> 1;
-    const int oc0 = ((n0 + wn * 64) >> 1) + fq * 4;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      int m = mrow0 + mi * 16;
-      if (m >= M) continue;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        int n = ncol0 + ni * 16;  // gate column in the interleaved layout; its up partner is n + 32
-        if (n >= N) continue;
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float g = acc[mi][ni][r], u = acc[mi][ni + 2][r];
-          o[r] = f2bf(g / (1.0f + __expf(-g)) * u);
-        }
-        *(bf16x4*)(C + (int64_t)m * ldc + oc0 + ni * 16) = o;
-      }
-    }
+  // ---- prologue: K-tile 0 complete, first three half-tiles of K-tile 1 in flight (same issue order as steady state)
+  G_ISSUE(pA0, 0, 0, 0); G_ISSUE(pB1, 3, 0, 0); G_ISSUE(pA1, 1, 0, 0); G_ISSUE(pB0, 2, 0, 0);
+  if (nk > 1) {
+    G_ISSUE(pA0, 0, 1, 1); G_ISSUE(pB1, 3, 1, 1); G_ISSUE(pA1, 1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  G_BAR();
+  if (wr == 1) G_BAR();  // stagger: group 1 runs one barrier behind group 0
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    const char* sbuf = smem + cur * 65536;
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    // p1: quadrant (A0, B0)
+    G_LDB(0) G_LDA(0)
+    if (n1) G_ISSUE(pB0, 2, cur ^ 1, t + 1);
+    G_LSYNC(); G_MM(0, 0); G_BAR();
+    // p2: (A0, B1)
+    G_LDB(1)
+    if (n2) G_ISSUE(pA0, 0, cur, t + 2);
+    G_LSYNC(); G_MM(0, 1); G_BAR();
+    // p3: (A1, B1)
+    G_LDA(1)
+    if (n2) G_ISSUE(pB1, 3, cur, t + 2);
+    G_LSYNC(); G_MM(1, 1); G_BAR();
+    // p4: (A1, B0)
+    G_LDB(0)
+    if (n2) {
+      G_ISSUE(pA1, 1, cur, t + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    G_LSYNC(); G_MM(1, 0); G_BAR();
+  }
+  if (wr == 0) G_BAR();
+
+  // ---- epilogue: lane holds row m (.. + fr) and 4 consecutive columns (.. + fq*4 + {0..3}) of each 16x16 tile
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      int m = mrow0 + mi * 16;
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = m0 + h * 128 + wr * 64 + mi * 16 + fr;
       if (m >= M) continue;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        int n = ncol0 + ni * 16;
-        if (n >= N) continue;
-        f32x4 v = acc[mi][ni];
-        if (EPI == EPI_STORE && bias != nullptr) {
-          bf16x4 bv = *(const bf16x4*)(bias + n);
+      for (int hp = 0; hp < 2; ++hp) {
+        const int nb = n0 + hp * 128 + wc * 32;  // first column of this wave's 32-column block
+        if (EPI == EPI_SWIGLU) {
+          // columns [nb, nb+16) = gate tile, [nb+16, nb+32) = up tile of output columns nb/2 .. nb/2+15
+          if (nb >= N) continue;
+          bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += bf2f(bv[r]);
+          for (int r = 0; r < 4; ++r) {
+            float g = acc[h][hp][mi][0][r], u = acc[h][hp][mi][1][r];
+            o[r] = f2bf(g / (1.0f + __expf(-g)) * u);
+          }
+          *(bf16x4*)(C + (int64_t)m * (N >> 1) + (nb >> 1) + fq * 4) = o;
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const int n = nb + ni * 16 + fq * 4;
+            if (n >= N) continue;
+            f32x4 v = acc[h][hp][mi][ni];
+            if (EPI == EPI_STORE && bias != nullptr) {
+              bf16x4 bv = *(const bf16x4*)(bias + n);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(bv[r]);
+            }
+            if (EPI == EPI_RESID) {
+              bf16x4 rv = *(const bf16x4*)(resid + (int64_t)m * N + n);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(rv[r]);
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+            *(bf16x4*)(C + (int64_t)m * N + n) = o;
+          }
         }
-        if (EPI == EPI_RESID) {
-          bf16x4 rv = *(const bf16x4*)(resid + (int64_t)m * N + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += bf2f(rv[r]);
-        }
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
-        *(bf16x4*)(C + (int64_t)m * N + n) = o;
       }
     }
-  }
 }
 
 extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N,
@@ -166,7 +212,7 @@ extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const voi
   LRX_CHECK_ARG(K % GBK == 0, "gemm: K=%d must be a multiple of %d", K, GBK);
   LRX_CHECK_ARG(N % 4 == 0, "gemm: N=%d must be a multiple of 4", N);
   LRX_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "gemm: unknown epilogue %d", epilogue);
-  LRX_CHECK_ARG(epilogue != EPI_SWIGLU || N % 64 == 0, "gemm: SwiGLU epilogue needs N %% 64 == 0 (N=%d)", N);
+  LRX_CHECK_ARG(epilogue != EPI_SWIGLU || N % 32 == 0, "gemm: SwiGLU epilogue needs N %% 32 == 0 (N=%d)", N);
   LRX_CHECK_ARG(epilogue != EPI_RESID || resid != nullptr, "gemm: residual epilogue without resid");
   if (M == 0) return LRX_OK;
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);

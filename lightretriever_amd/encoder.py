@@ -89,10 +89,11 @@ def rope_tables(cfg: EncoderConfig) -> tuple[torch.Tensor, torch.Tensor]:
 
 
 def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
-    """[I,H],[I,H] -> [2I,H] with 32-row groups alternating gate/up (the layout lrx_gemm's SwiGLU epilogue expects)."""
+    """[I,H],[I,H] -> [2I,H] with 16-row groups alternating gate/up (the layout lrx_gemm's SwiGLU epilogue expects:
+    rows [32j, 32j+16) = gate[16j..], rows [32j+16, 32j+32) = up[16j..])."""
     I, H = gate.shape
-    assert I % 32 == 0
-    return torch.stack([gate.view(I // 32, 32, H), up.view(I // 32, 32, H)], dim=1).reshape(2 * I, H).contiguous()
+    assert I % 16 == 0
+    return torch.stack([gate.view(I // 16, 16, H), up.view(I // 16, 16, H)], dim=1).reshape(2 * I, H).contiguous()
 
 
 def lora_merge(W: torch.Tensor, A: torch.Tensor, B: torch.Tensor, alpha: float, r: int) -> torch.Tensor:

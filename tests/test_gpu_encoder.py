@@ -140,7 +140,7 @@ def test_full_size_llama32_1b_properties_and_hf_parity():
         sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = \
             L["wqkv"][:2048], L["wqkv"][2048:2560], L["wqkv"][2560:]
         sd[p + "self_attn.o_proj.weight"] = L["wo"]
-        gu = L["wgu"].view(8192 // 32, 2, 32, H)
+        gu = L["wgu"].view(8192 // 16, 2, 16, H)
         sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = gu[:, 0].reshape(8192, H), gu[:, 1].reshape(8192, H)
         sd[p + "mlp.down_proj.weight"] = L["wdown"]
         sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = L["ln1"], L["ln2"]
