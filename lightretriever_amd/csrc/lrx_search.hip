@@ -6,9 +6,12 @@
 //     16-byte global_load_lds into 2 LDS stages, XOR-swizzled on the source address for conflict-free ds_read_b128.
 //     The k summation order is permuted (lane group g of a 16-k block owns k = 4g..4g+3) so one ds_read_b128 feeds
 //     four MFMA steps; both operands use the same permutation.
-//  2. k_topk_select: one workgroup per query, exact 4 x 8-bit radix select of the k-th largest score, then an
-//     unordered gather of everything strictly greater plus the lowest-row-id ties, then an LDS bitonic sort on
-//     (score desc, row asc).  Deterministic output regardless of atomics order.
+//     The epilogue also emits the per-(query, 256-row block) maximum.
+//  2. k_topk_select: one workgroup per query.  Fast path: threshold = k-th largest block maximum (at least k elements
+//     are >= it, so the true top-k all pass), ONE scan of the row gathering everything >= threshold (typically ~k
+//     elements), LDS bitonic sort on (score desc, row asc).  Fallback when the gather overflows (heavy ties) or the
+//     index is small: exact 4 x 8-bit radix select of the k-th largest score + gather of everything strictly greater
+//     plus the lowest-row-id ties.  Deterministic output regardless of atomics order on both paths.
 //  3. k_merge_topk: merge of R per-shard [Q,k] lists (after the RCCL all-gather) with the same ordering rule.
 #include "lrx_common.h"
 #include <float.h>
@@ -23,7 +26,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <int QT>
 __global__ void __launch_bounds__(256, 1)
 k_flat_ip_scores(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ Q, int nq,
-                 float* __restrict__ scores, int64_t ld) {
+                 float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk) {
   constexpr int QTILE = QT * 16 * S_BK * 4;
   constexpr int STAGE = S_XTILE + QTILE;
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
@@ -101,44 +104,63 @@ k_flat_ip_scores(const float* __restrict__ X, int64_t N, int64_t ldx, int D, con
     __syncthreads();
   }
 
-  // D[i = corpus row][j = query]: lane holds query j = fi, rows fg*4 + {0..3}
+  // D[i = corpus row][j = query]: lane holds query j = fi, rows fg*4 + {0..3}.  Also the per-(query, 256-row block)
+  // maximum, which gives k_topk_select a safe threshold without an extra pass over the scores.
+  float* wmax = (float*)smem;  // [4 waves][QT*16]   (LDS is free: the k loop ended with a barrier)
 #pragma unroll
   for (int b = 0; b < QT; ++b) {
     int qi = b * 16 + fi;
-    if (qi >= nq) continue;
+    float mx = -FLT_MAX;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       int64_t n = n0 + wave * 64 + a * 16 + fg * 4;
       f32x4 v = acc[a][b];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e) {
         if (n + e >= N) v[e] = -FLT_MAX;
-      *(f32x4*)(scores + (int64_t)qi * ld + n) = v;
+        mx = fmaxf(mx, v[e]);
+      }
+      if (qi < nq) *(f32x4*)(scores + (int64_t)qi * ld + n) = v;
     }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (fg == 0) wmax[wave * (QT * 16) + qi] = mx;
+  }
+  __syncthreads();
+  if (blkmax != nullptr && tid < QT * 16 && tid < nq) {
+    float mx = fmaxf(fmaxf(wmax[tid], wmax[QT * 16 + tid]), fmaxf(wmax[2 * QT * 16 + tid], wmax[3 * QT * 16 + tid]));
+    blkmax[(int64_t)tid * nblk + blockIdx.x] = mx;
   }
 }
 
 extern "C" int64_t lrx_flat_ip_score_ld(int64_t n_rows) { return lrx_cdiv(n_rows > 0 ? n_rows : 1, S_ROWS) * S_ROWS; }
 
-extern "C" int lrx_flat_ip_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries,
-                                  float* scores, void* stream) {
+static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, float* scores,
+                         float* blkmax, void* stream) {
   LRX_CHECK_ARG(dim > 0 && dim % S_BK == 0, "flat_ip: dim=%d must be a multiple of %d", dim, S_BK);
   LRX_CHECK_ARG(ldx >= dim && ldx % 4 == 0, "flat_ip: ldx=%lld must be >= dim and a multiple of 4", (long long)ldx);
   if (n_rows <= 0 || n_queries <= 0) return LRX_OK;
   const int64_t ld = lrx_flat_ip_score_ld(n_rows);
-  dim3 grid((unsigned)(ld / S_ROWS)), block(256);
+  const int nblk = (int)(ld / S_ROWS), nblk_ld = (nblk + 3) & ~3;   // row stride of blkmax (16-B aligned rows)
+  dim3 grid((unsigned)nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   for (int q0 = 0; q0 < n_queries; q0 += 128) {
     int nq = n_queries - q0 < 128 ? n_queries - q0 : 128;
     int qt = (nq + 15) / 16;
     const float* qp = q + (int64_t)q0 * dim;
     float* sp = scores + (int64_t)q0 * ld;
-#define LRX_SC(QQ) case QQ: hipLaunchKernelGGL(k_flat_ip_scores<QQ>, grid, block, 0, s, X, n_rows, ldx, dim, qp, nq, sp, ld); break;
+    float* bp = blkmax ? blkmax + (int64_t)q0 * nblk_ld : nullptr;
+#define LRX_SC(QQ) case QQ: hipLaunchKernelGGL(k_flat_ip_scores<QQ>, grid, block, 0, s, X, n_rows, ldx, dim, qp, nq, sp, ld, bp, nblk_ld); break;
     switch (qt) { LRX_SC(1) LRX_SC(2) LRX_SC(3) LRX_SC(4) LRX_SC(5) LRX_SC(6) LRX_SC(7) LRX_SC(8) }
 #undef LRX_SC
     LRX_LAUNCH_CHECK();
   }
   return LRX_OK;
+}
+
+extern "C" int lrx_flat_ip_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries,
+                                  float* scores, void* stream) {
+  return launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -172,117 +194,169 @@ __device__ void bitonic_sort_desc(unsigned long long* buf, int P) {
 
 #define SEL_THREADS 1024
 #define SEL_MAXK 2048
+#define SEL_CAND 4096   // candidate capacity of the fast path (and of the exact path's output list)
 #define SEL_EQCAP 2048
 
-__global__ void __launch_bounds__(SEL_THREADS)
-k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base, float* __restrict__ out_scores,
-              int64_t* __restrict__ out_ids) {
-  __shared__ unsigned int hist[16][256];
-  __shared__ unsigned long long cand[SEL_MAXK];
-  __shared__ unsigned int eqidx[SEL_EQCAP];
-  __shared__ unsigned int sh_bucket, sh_kk, sh_cnt, sh_ngt, sh_neq;
-  const float* row = scores + (int64_t)blockIdx.x * ld;
-  float* os = out_scores + (int64_t)blockIdx.x * k;
-  int64_t* oi = out_ids + (int64_t)blockIdx.x * k;
-  const int tid = threadIdx.x, wave = tid >> 6;
-  const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
-  for (int i = keff + tid; i < k; i += SEL_THREADS) { os[i] = -FLT_MAX; oi[i] = -1; }
-  if (keff == 0) return;
+struct SelShared {
+  unsigned int hist[16][256];
+  unsigned long long cand[SEL_CAND];
+  unsigned long long eqs[SEL_EQCAP];
+  unsigned int eqidx[SEL_EQCAP];
+  unsigned int bucket, kk, cnt, ngt, neq;
+};
 
-  // ---- exact radix select of the keff-th largest key
+// exact radix select (4 x 8 bit) of the kk-th largest key of row[0..n): returns the key, the number of elements
+// equal to it that belong to the top-kk (need_eq) and how many elements carry that key in total (neq).
+__device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, unsigned int kk, SelShared& sh, unsigned int& need_eq,
+                                     unsigned int& neq) {
+  const int tid = threadIdx.x, wave = tid >> 6;
   uint32_t prefix = 0, mask = 0;
-  unsigned int kk = keff;  // rank (1-based, from the top) inside the current prefix bucket
-  unsigned int neq = 0;
-  const int64_t N4 = N >> 2;
+  const int64_t n4 = n >> 2;
   for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = tid; i < 16 * 256; i += SEL_THREADS) (&hist[0][0])[i] = 0;
+    for (int i = tid; i < 16 * 256; i += SEL_THREADS) (&sh.hist[0][0])[i] = 0;
     __syncthreads();
-    for (int64_t i = tid; i < N4; i += SEL_THREADS) {
+    for (int64_t i = tid; i < n4; i += SEL_THREADS) {
       f32x4 v = *(const f32x4*)(row + 4 * i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         uint32_t key = f2key(v[e]);
-        if ((key & mask) == prefix) atomicAdd(&hist[wave][(key >> shift) & 255], 1u);
+        if ((key & mask) == prefix) atomicAdd(&sh.hist[wave][(key >> shift) & 255], 1u);
       }
     }
-    for (int64_t i = 4 * N4 + tid; i < N; i += SEL_THREADS) {
+    for (int64_t i = 4 * n4 + tid; i < n; i += SEL_THREADS) {
       uint32_t key = f2key(row[i]);
-      if ((key & mask) == prefix) atomicAdd(&hist[wave][(key >> shift) & 255], 1u);
+      if ((key & mask) == prefix) atomicAdd(&sh.hist[wave][(key >> shift) & 255], 1u);
     }
     __syncthreads();
     if (tid < 256) {
       unsigned int sum = 0;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) sum += hist[w][tid];
-      hist[0][tid] = sum;
+      for (int w = 0; w < 16; ++w) sum += sh.hist[w][tid];
+      sh.hist[0][tid] = sum;
     }
     __syncthreads();
     if (tid == 0) {
       unsigned int cum = 0;
       int bsel = 0;
       for (int bkt = 255; bkt >= 0; --bkt) {
-        unsigned int c = hist[0][bkt];
-        if (cum + c >= kk) { bsel = bkt; sh_kk = kk - cum; sh_cnt = c; break; }
+        unsigned int c = sh.hist[0][bkt];
+        if (cum + c >= kk) { bsel = bkt; sh.kk = kk - cum; sh.cnt = c; break; }
         cum += c;
       }
-      sh_bucket = bsel;
+      sh.bucket = bsel;
     }
     __syncthreads();
-    prefix |= (uint32_t)sh_bucket << shift;
+    prefix |= (uint32_t)sh.bucket << shift;
     mask |= 0xFFu << shift;
-    kk = sh_kk;
-    neq = sh_cnt;
+    kk = sh.kk;
+    neq = sh.cnt;
     __syncthreads();
   }
-  const uint32_t kth = prefix;          // key of the keff-th largest element
-  const unsigned int need_eq = kk;      // how many elements equal to kth belong to the result (lowest row ids first)
-  const unsigned int ngt = keff - kk;   // elements strictly greater
-  if (tid == 0) { sh_ngt = 0; sh_neq = 0; }
-  __syncthreads();
+  need_eq = kk;
+  return prefix;
+}
 
-  // ---- gather: everything > kth (unordered), ties == kth (unordered, capped) -> deterministic after sorting
-  const bool eq_fits = neq <= SEL_EQCAP;
-  for (int64_t i = tid; i < N; i += SEL_THREADS) {
-    uint32_t key = f2key(row[i]);
-    if (key > kth) {
-      unsigned int p = atomicAdd(&sh_ngt, 1u);
-      cand[p] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-    } else if (key == kth && eq_fits) {
-      unsigned int p = atomicAdd(&sh_neq, 1u);
-      eqidx[p] = (uint32_t)i;
+__device__ __forceinline__ unsigned long long sel_pack(uint32_t key, int64_t i) {
+  return ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+}
+
+__global__ void __launch_bounds__(SEL_THREADS)
+k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base, const float* __restrict__ blkmax, int nblk,
+              int nblk_ld, float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
+  __shared__ SelShared sh;
+  const float* row = scores + (int64_t)blockIdx.x * ld;
+  float* os = out_scores + (int64_t)blockIdx.x * k;
+  int64_t* oi = out_ids + (int64_t)blockIdx.x * k;
+  const int tid = threadIdx.x;
+  const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
+  for (int i = keff + tid; i < k; i += SEL_THREADS) { os[i] = -FLT_MAX; oi[i] = -1; }
+  if (keff == 0) return;
+  int ncand = 0;  // number of valid entries in sh.cand, of which the best keff are the answer
+
+  // ---- fast path: threshold = keff-th largest of the per-block maxima (>= keff elements are >= it, so the true top-keff
+  //      all pass), then ONE scan of the row gathering everything >= threshold.
+  bool done = false;
+  if (N <= SEL_CAND) {
+    for (int64_t i = tid; i < N; i += SEL_THREADS) sh.cand[i] = sel_pack(f2key(row[i]), i);
+    ncand = (int)N;
+    done = true;
+  } else if (blkmax != nullptr && nblk >= keff) {
+    unsigned int ne, nq_;
+    const uint32_t thr = radix_select_kth(blkmax + (int64_t)blockIdx.x * nblk_ld, nblk, keff, sh, ne, nq_);
+    if (tid == 0) sh.ngt = 0;
+    __syncthreads();
+    const int64_t n4 = N >> 2;
+    for (int64_t i = tid; i < n4; i += SEL_THREADS) {
+      f32x4 v = *(const f32x4*)(row + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t key = f2key(v[e]);
+        if (key >= thr) {
+          unsigned int p = atomicAdd(&sh.ngt, 1u);
+          if (p < SEL_CAND) sh.cand[p] = sel_pack(key, 4 * i + e);
+        }
+      }
     }
+    for (int64_t i = 4 * n4 + tid; i < N; i += SEL_THREADS) {
+      uint32_t key = f2key(row[i]);
+      if (key >= thr) {
+        unsigned int p = atomicAdd(&sh.ngt, 1u);
+        if (p < SEL_CAND) sh.cand[p] = sel_pack(key, i);
+      }
+    }
+    __syncthreads();
+    if (sh.ngt <= SEL_CAND) { ncand = (int)sh.ngt; done = true; }
+    __syncthreads();
   }
-  __syncthreads();
-  if (eq_fits) {
-    // smallest `need_eq` row ids among the ties: sort eqidx ascending == sort (~idx) descending
-    int P = 1;
-    while (P < (int)neq) P <<= 1;
-    __shared__ unsigned long long eqs[SEL_EQCAP];
-    for (int i = tid; i < P; i += SEL_THREADS) eqs[i] = i < (int)neq ? (unsigned long long)(0xFFFFFFFFu - eqidx[i]) : 0ull;
-    bitonic_sort_desc(eqs, P);
-    for (int i = tid; i < (int)need_eq; i += SEL_THREADS) cand[ngt + i] = ((unsigned long long)kth << 32) | eqs[i];
-  } else {
-    // massive tie (degenerate data): ordered scan by one wave, lowest row ids first
-    if (tid < 64) {
+
+  if (!done) {
+    // ---- exact path: radix select over the whole row, gather > kth (unordered) + the lowest-row-id ties
+    unsigned int need_eq, neq;
+    const uint32_t kth = radix_select_kth(row, N, keff, sh, need_eq, neq);
+    const unsigned int ngt = keff - need_eq;
+    if (tid == 0) { sh.ngt = 0; sh.neq = 0; }
+    __syncthreads();
+    const bool eq_fits = neq <= SEL_EQCAP;
+    for (int64_t i = tid; i < N; i += SEL_THREADS) {
+      uint32_t key = f2key(row[i]);
+      if (key > kth) {
+        unsigned int p = atomicAdd(&sh.ngt, 1u);
+        sh.cand[p] = sel_pack(key, i);
+      } else if (key == kth && eq_fits) {
+        unsigned int p = atomicAdd(&sh.neq, 1u);
+        sh.eqidx[p] = (uint32_t)i;
+      }
+    }
+    __syncthreads();
+    if (eq_fits) {
+      int P = 1;
+      while (P < (int)neq) P <<= 1;
+      for (int i = tid; i < P; i += SEL_THREADS) sh.eqs[i] = i < (int)neq ? (unsigned long long)(0xFFFFFFFFu - sh.eqidx[i]) : 0ull;
+      bitonic_sort_desc(sh.eqs, P);   // descending (~idx) == ascending row id
+      for (int i = tid; i < (int)need_eq; i += SEL_THREADS) sh.cand[ngt + i] = ((unsigned long long)kth << 32) | sh.eqs[i];
+    } else if (tid < 64) {
+      // massive tie (degenerate data): ordered scan by one wave, lowest row ids first
       unsigned int taken = 0;
       for (int64_t base = 0; base < N && taken < need_eq; base += 64) {
         int64_t i = base + tid;
         bool hit = i < N && f2key(row[i]) == kth;
         unsigned long long bal = __ballot(hit);
         unsigned int before = __popcll(bal & ((1ull << tid) - 1ull));
-        if (hit && taken + before < need_eq)
-          cand[ngt + taken + before] = ((unsigned long long)kth << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+        if (hit && taken + before < need_eq) sh.cand[ngt + taken + before] = sel_pack(kth, i);
         taken += __popcll(bal);
       }
     }
+    __syncthreads();
+    ncand = keff;
   }
-  __syncthreads();
+
   int P = 1;
-  while (P < keff) P <<= 1;
-  for (int i = keff + tid; i < P; i += SEL_THREADS) cand[i] = 0ull;
-  bitonic_sort_desc(cand, P);
+  while (P < ncand) P <<= 1;
+  __syncthreads();
+  for (int i = ncand + tid; i < P; i += SEL_THREADS) sh.cand[i] = 0ull;
+  bitonic_sort_desc(sh.cand, P);
   for (int i = tid; i < keff; i += SEL_THREADS) {
-    unsigned long long c = cand[i];
+    unsigned long long c = sh.cand[i];
     os[i] = key2f((uint32_t)(c >> 32));
     oi[i] = id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
   }
@@ -290,7 +364,8 @@ k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, in
 
 extern "C" size_t lrx_flat_ip_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
   (void)dim; (void)k;
-  return (size_t)lrx_flat_ip_score_ld(n_rows) * (size_t)(n_queries > 0 ? n_queries : 1) * sizeof(float);
+  const size_t ld = (size_t)lrx_flat_ip_score_ld(n_rows), nq = (size_t)(n_queries > 0 ? n_queries : 1);
+  return (ld * nq + ((ld / S_ROWS + 3) & ~(size_t)3) * nq) * sizeof(float);   // scores [Q, ld] + per-block maxima [Q, ~ld/256]
 }
 
 extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, int32_t k,
@@ -304,10 +379,15 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
     return LRX_ERR_WORKSPACE;
   }
   float* scores = (float*)workspace;
-  int rc = lrx_flat_ip_scores(X, n_rows, ldx, dim, q, n_queries, scores, stream);
-  if (rc != LRX_OK) return rc;
-  hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, scores, lrx_flat_ip_score_ld(n_rows), n_rows, k,
-                     id_base, out_scores, out_ids);
+  const int64_t ld = lrx_flat_ip_score_ld(n_rows);
+  float* blkmax = scores + ld * (int64_t)n_queries;
+  const int nblk = (int)(ld / S_ROWS), nblk_ld = (nblk + 3) & ~3;
+  if (n_rows > 0) {
+    int rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, stream);
+    if (rc != LRX_OK) return rc;
+  }
+  hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, scores, ld, n_rows, k, id_base, blkmax, nblk,
+                     nblk_ld, out_scores, out_ids);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
