@@ -1,6 +1,6 @@
 // Flat inner-product search over an HBM-resident fp32 corpus shard (replaces faiss.IndexFlatIP.search).
 //
-//  1. k_flat_ip_scores<QT>: scores[Q, ld] = q . X^T with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: bitwise an fp32 fma
+//  1. k_flat_ip_scores<QT> (Q <= 32; k_flat_ip_scores_split<QT> above that, see its header): scores[Q, ld] = q . X^T with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: bitwise an fp32 fma
 //     chain).  HBM-bound for Q <= ~48 (X is streamed exactly once per <=128 queries), fp32-matrix bound above.
 //     Workgroup = 4 waves x 64 corpus rows; X and q k-slices (32 floats = one 128-B line per row) are staged with
 //     16-byte global_load_lds into 2 LDS stages, XOR-swizzled on the source address for conflict-free ds_read_b128.
@@ -22,6 +22,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define S_ROWS 256       // corpus rows per workgroup
 #define S_BK 32          // floats per k-slice (128 B per row)
 #define S_XTILE (S_ROWS * S_BK * 4)
+#define SP_ROWS 128      // corpus rows per workgroup of the split-bf16 kernel
 
 template <int QT>
 __global__ void __launch_bounds__(256, 1)
@@ -127,21 +128,183 @@ k_flat_ip_scores(const float* __restrict__ X, int64_t N, int64_t ldx, int D, con
     if (fg == 0) wmax[wave * (QT * 16) + qi] = mx;
   }
   __syncthreads();
-  if (blkmax != nullptr && tid < QT * 16 && tid < nq) {
-    float mx = fmaxf(fmaxf(wmax[tid], wmax[QT * 16 + tid]), fmaxf(wmax[2 * QT * 16 + tid], wmax[3 * QT * 16 + tid]));
-    blkmax[(int64_t)tid * nblk + blockIdx.x] = mx;
+  // maxima at 128-row granularity (two per workgroup) so both score kernels feed k_topk_select the same layout
+  if (blkmax != nullptr && tid < 2 * QT * 16) {
+    const int hh = tid / (QT * 16), qq = tid - hh * (QT * 16);
+    if (qq < nq) blkmax[(int64_t)qq * nblk + 2 * blockIdx.x + hh] = fmaxf(wmax[(2 * hh) * QT * 16 + qq], wmax[(2 * hh + 1) * QT * 16 + qq]);
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Q > 32: split-bf16 score kernel.  Each fp32 value v is written EXACTLY as hi + mid + lo (three bf16, 24 mantissa bits);
+// q . x = sum over the six products hh, hm, mh, mm, hl, lh (the three dropped ones are <= 2^-24 relative, i.e. below the
+// rounding of an fp32 product), each product exact in the bf16 MFMA's fp32 accumulation -> fp32-grade scores at 6/16 of
+// the fp32-matrix time, which brings Q = 100 from fp32-MFMA-bound to (nearly) HBM-bound.  X is split in registers by the
+// wave that owns the rows (each element once); the queries are split once per search by k_split_queries into fragment
+// order so every q fragment is one linear 1-KiB LDS-DMA + one linear ds_read_b128.
+// k permutation inside a 32-wide slice (same on both operands): element j of lane group fq is k = 4fq + j (j < 4) or
+// 16 + 4fq + (j - 4): keeps both 16-B X reads of a lane conflict-free under the 128-B-row swizzle.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)v;
+  float r1 = v - (float)h;
+  m = (__bf16)r1;
+  float r2 = r1 - (float)m;
+  l = (__bf16)r2;
+}
+
+// qs layout: [D/32 slices][3 planes][QT][64 lanes][8] bf16
+__global__ void k_split_queries(const float* __restrict__ Q, int nq, int D, int QT, __bf16* __restrict__ qs) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  int lane = gid & 63, rest = gid >> 6;
+  int qt = rest % QT, kt = rest / QT;
+  if (kt >= D / 32) return;
+  int fi = lane & 15, fq = lane >> 4;
+  int row = qt * 16 + fi;
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int k = kt * 32 + (j < 4 ? 4 * fq + j : 16 + 4 * fq + (j - 4));
+    float v = row < nq ? Q[(int64_t)row * D + k] : 0.f;
+    __bf16 a, b, c;
+    split3(v, a, b, c);
+    h[j] = a; m[j] = b; l[j] = c;
+  }
+  int64_t base = (((int64_t)kt * 3) * QT + qt) * 64 + lane;
+  bf16x8* out = (bf16x8*)qs;
+  out[base] = h;
+  out[base + (int64_t)QT * 64] = m;
+  out[base + 2 * (int64_t)QT * 64] = l;
+}
+
+template <int QT>
+__global__ void __launch_bounds__(256, 2)
+k_flat_ip_scores_split(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
+                       float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld) {
+  constexpr int QBYTES = 3 * QT * 1024;          // q planes of one k-slice
+  constexpr int XT = SP_ROWS * S_BK * 4;         // 16 KiB: 128 corpus rows per workgroup -> 2 workgroups per CU
+  constexpr int STAGE = XT + QBYTES;
+  constexpr int QINST = 3 * QT;                  // 1-KiB LDS-DMA instructions per q slice
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n0 = (int64_t)blockIdx.x * SP_ROWS;
+
+  const float* px[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int s = (wave * 4 + i) * 64 + lane;
+    int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
+    int64_t g = min(n0 + row, N - 1);
+    px[i] = X + g * ldx + c * 4;
+  }
+  const __bf16* pq = qs + (int64_t)lane * 8;     // + (kt*QINST + j) * 512 elements
+  auto stage = [&](int st, int kt) {
+    char* sX = smem + st * STAGE;
+    char* sQ = sX + XT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + kt * S_BK), (lptr_t)(sX + (wave * 4 + i) * 1024), 16, 0, 0);
+    for (int j = wave; j < QINST; j += 4)
+      __builtin_amdgcn_global_load_lds((gptr_t)(pq + ((int64_t)kt * QINST + j) * 512), (lptr_t)(sQ + j * 1024), 16, 0, 0);
+  };
+
+  const int fi = lane & 15, fq = lane >> 4;
+  const int xs = fi >> 1;
+  const int xoff0 = fi * 128 + ((fq ^ xs) << 4);          // chunk fq      : k = 4fq .. 4fq+3
+  const int xoff1 = fi * 128 + (((4 + fq) ^ xs) << 4);    // chunk 4 + fq  : k = 16+4fq ..
+
+  f32x4 acc[2][QT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = D / S_BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sX = smem + cur * STAGE + (wave * 32) * 128;
+    const char* sQ = smem + cur * STAGE + XT + lane * 16;
+    bf16x8 xh[2], xm[2], xl[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      f32x4 v0 = *(const f32x4*)(sX + a * 2048 + xoff0);
+      f32x4 v1 = *(const f32x4*)(sX + a * 2048 + xoff1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __bf16 h, m, l;
+        split3(v0[j], h, m, l);
+        xh[a][j] = h; xm[a][j] = m; xl[a][j] = l;
+        split3(v1[j], h, m, l);
+        xh[a][4 + j] = h; xm[a][4 + j] = m; xl[a][4 + j] = l;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < QT; ++b) {
+      bf16x8 qh = *(const bf16x8*)(sQ + b * 1024);
+      bf16x8 qm = *(const bf16x8*)(sQ + (QT + b) * 1024);
+      bf16x8 ql = *(const bf16x8*)(sQ + (2 * QT + b) * 1024);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        f32x4 c = acc[a][b];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[a], qh, c, 0, 0, 0);   // small terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], ql, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm[a], qm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm[a], qh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], qm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], qh, c, 0, 0, 0);
+        acc[a][b] = c;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // D[i = corpus row][j = query]: lane holds query j = fi, rows fq*4 + {0..3}.  Also the per-(query, 256-row block)
+  // maximum, which gives k_topk_select a safe threshold without an extra pass over the scores.
+  float* wmax = (float*)smem;  // [4 waves][QT*16]   (LDS is free: the k loop ended with a barrier)
+#pragma unroll
+  for (int b = 0; b < QT; ++b) {
+    int qi = b * 16 + fi;
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int64_t n = n0 + wave * 32 + a * 16 + fq * 4;
+      f32x4 v = acc[a][b];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= N) v[e] = -FLT_MAX;
+        mx = fmaxf(mx, v[e]);
+      }
+      if (qi < nq) *(f32x4*)(scores + (int64_t)qi * ld + n) = v;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (fq == 0) wmax[wave * (QT * 16) + qi] = mx;
+  }
+  __syncthreads();
+  if (blkmax != nullptr && tid < QT * 16 && tid < nq) {
+    float mx = fmaxf(fmaxf(wmax[tid], wmax[QT * 16 + tid]), fmaxf(wmax[2 * QT * 16 + tid], wmax[3 * QT * 16 + tid]));
+    blkmax[(int64_t)tid * nblk_ld + blockIdx.x] = mx;
+  }
+}
+
+
 extern "C" int64_t lrx_flat_ip_score_ld(int64_t n_rows) { return lrx_cdiv(n_rows > 0 ? n_rows : 1, S_ROWS) * S_ROWS; }
 
+#define SPLIT_MIN_QT 3   // Q > 32 -> split-bf16 kernel (fp32-MFMA-bound otherwise); Q <= 32 stays on the exact-fp32 kernel (HBM-bound)
+static size_t split_ws_bytes(int32_t dim) { return (size_t)(dim / 32) * 3 * 8 * 1024; }   // one chunk of <=128 queries
+
 static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, float* scores,
-                         float* blkmax, void* stream) {
+                         float* blkmax, __bf16* qsplit, void* stream) {
   LRX_CHECK_ARG(dim > 0 && dim % S_BK == 0, "flat_ip: dim=%d must be a multiple of %d", dim, S_BK);
   LRX_CHECK_ARG(ldx >= dim && ldx % 4 == 0, "flat_ip: ldx=%lld must be >= dim and a multiple of 4", (long long)ldx);
   if (n_rows <= 0 || n_queries <= 0) return LRX_OK;
   const int64_t ld = lrx_flat_ip_score_ld(n_rows);
-  const int nblk = (int)(ld / S_ROWS), nblk_ld = (nblk + 3) & ~3;   // row stride of blkmax (16-B aligned rows)
+  const int nblk = (int)(ld / S_ROWS), nblk_ld = (int)((ld / SP_ROWS + 3) & ~3);   // blkmax row stride (sized for the finer blocks)
   dim3 grid((unsigned)nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   for (int q0 = 0; q0 < n_queries; q0 += 128) {
@@ -150,6 +313,15 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
     const float* qp = q + (int64_t)q0 * dim;
     float* sp = scores + (int64_t)q0 * ld;
     float* bp = blkmax ? blkmax + (int64_t)q0 * nblk_ld : nullptr;
+    if (qsplit != nullptr && qt >= SPLIT_MIN_QT) {
+      int threads = (dim / 32) * qt * 64;
+      hipLaunchKernelGGL(k_split_queries, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit);
+#define LRX_SS(QQ) case QQ: hipLaunchKernelGGL(k_flat_ip_scores_split<QQ>, dim3((unsigned)(ld / SP_ROWS)), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld); break;
+      switch (qt) { LRX_SS(3) LRX_SS(4) LRX_SS(5) LRX_SS(6) LRX_SS(7) LRX_SS(8) }
+#undef LRX_SS
+      LRX_LAUNCH_CHECK();
+      continue;
+    }
 #define LRX_SC(QQ) case QQ: hipLaunchKernelGGL(k_flat_ip_scores<QQ>, grid, block, 0, s, X, n_rows, ldx, dim, qp, nq, sp, ld, bp, nblk_ld); break;
     switch (qt) { LRX_SC(1) LRX_SC(2) LRX_SC(3) LRX_SC(4) LRX_SC(5) LRX_SC(6) LRX_SC(7) LRX_SC(8) }
 #undef LRX_SC
@@ -160,7 +332,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
 
 extern "C" int lrx_flat_ip_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries,
                                   float* scores, void* stream) {
-  return launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, nullptr, stream);
+  return launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -363,9 +535,10 @@ k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, in
 }
 
 extern "C" size_t lrx_flat_ip_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
-  (void)dim; (void)k;
+  (void)k;
   const size_t ld = (size_t)lrx_flat_ip_score_ld(n_rows), nq = (size_t)(n_queries > 0 ? n_queries : 1);
-  return (ld * nq + ((ld / S_ROWS + 3) & ~(size_t)3) * nq) * sizeof(float);   // scores [Q, ld] + per-block maxima [Q, ~ld/256]
+  // scores [Q, ld] + per-block maxima [Q, ~ld/256] + split-bf16 query planes of one 128-query chunk
+  return (ld * nq + ((ld / SP_ROWS + 3) & ~(size_t)3) * nq) * sizeof(float) + split_ws_bytes(dim);
 }
 
 extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, int32_t k,
@@ -381,9 +554,10 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
   float* scores = (float*)workspace;
   const int64_t ld = lrx_flat_ip_score_ld(n_rows);
   float* blkmax = scores + ld * (int64_t)n_queries;
-  const int nblk = (int)(ld / S_ROWS), nblk_ld = (nblk + 3) & ~3;
+    const int nblk = (int)(ld / SP_ROWS), nblk_ld = (nblk + 3) & ~3;   // block maxima at 128-row granularity on both paths
   if (n_rows > 0) {
-    int rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, stream);
+    __bf16* qsplit = (__bf16*)(blkmax + (int64_t)nblk_ld * n_queries);
+    int rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, qsplit, stream);
     if (rc != LRX_OK) return rc;
   }
   hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, scores, ld, n_rows, k, id_base, blkmax, nblk,
