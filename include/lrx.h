@@ -132,13 +132,19 @@ int lrx_rope_inplace(void* qkv, const int32_t* positions, const float* cos, cons
                      int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* stream);
 
 /* Varlen causal GQA attention (flash_attention_2 varlen call the reference requires for packing,
- * utils/nested_input.py:137-146): out[T, nq*d] bf16 = softmax(q k^T / sqrt(d), causal within each sequence) v   */
+ * utils/nested_input.py:137-146): out[T, nq*d] bf16 = softmax(q k^T / sqrt(d), causal within each sequence) v.
+ * last_tile_only != 0: only the 64-row q tile that holds each sequence's LAST token is computed (other rows of `out`
+ * are left untouched) -- all the pooled path needs from the final layer.                                          */
 int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens,
                            int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
-                           void* out, void* stream);
+                           void* out, int32_t last_tile_only, void* stream);
+
+/* dst[b, :] = src[cu_seqlens[b+1]-1, :]  (bf16 rows of `width` elements): the last-token rows, compacted. */
+int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, int32_t width, void* dst, void* stream);
 
 /* Last-token pooling + final RMSNorm on the pooled rows only + MRL slice + L2 normalise -> fp32 rows.
- * hidden = residual stream BEFORE the final norm [T, H] bf16.                                                    */
+ * hidden = residual stream BEFORE the final norm [T, H] bf16; cu_seqlens == NULL means `hidden` already holds the
+ * n_seqs pooled rows compacted ([n_seqs, H]).                                                                      */
 int lrx_pool_norm(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                   int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim,
                   int32_t normalize, void* stream);

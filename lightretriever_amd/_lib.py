@@ -45,7 +45,8 @@ SIGNATURES = {
     "lrx_gemm_bf16_nt": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "lrx_build_positions": (_I32, [_P, _I32, _I32, _P, _P]),
     "lrx_rope_inplace": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
-    "lrx_attn_varlen_causal": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "lrx_attn_varlen_causal": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "lrx_gather_last_rows": (_I32, [_P, _P, _I32, _I32, _P, _P]),
     "lrx_pool_norm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P]),
     "lrx_embedding_bag_mean": (_I32, [_P, _I32, _I32, _P, _I64, _P, _I32, _I64, _P, _I64, _I32, _I32, _P]),
     "lrx_flat_ip_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),

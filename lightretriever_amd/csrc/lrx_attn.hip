@@ -34,17 +34,18 @@ struct AttnGeom {
 template <int D, int GRP>
 __global__ void __launch_bounds__(128 * GRP)
 k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu, int nqt, int nq, int nkv,
-                     __bf16* __restrict__ out, float scale_log2) {
+                     __bf16* __restrict__ out, float scale_log2, int last_tile_only) {
   using G = AttnGeom<D>;
   constexpr int NW = 2 * GRP;
   constexpr int KS = D / 16;  // k-steps of the QK^T product
   constexpr int DT = D / 32;  // 32-row tiles of O^T
   __shared__ __attribute__((aligned(1024))) char smem[4 * G::TILE_BYTES];  // [stage][K|V]
 
-  const int b = blockIdx.x / nqt;
-  const int qt = nqt - 1 - (blockIdx.x - b * nqt);  // heavy (late) q tiles first
+  const int b = last_tile_only ? blockIdx.x : blockIdx.x / nqt;
   const int hk = blockIdx.y;
   const int s0 = cu[b], len = cu[b + 1] - s0;
+  // last_tile_only: one q tile per sequence, the one holding its last token (all the pooled path needs of the last layer)
+  const int qt = last_tile_only ? ((len - 1) >> 6) : nqt - 1 - (blockIdx.x - b * nqt);  // else: heavy (late) q tiles first
   const int qtile0 = qt * 64;
   if (qtile0 >= len) return;
 
@@ -152,10 +153,12 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
           psum += p;
         }
         l = l * alpha + psum;
+        if (!__all(alpha == 1.0f)) {  // wave-uniform: no q row of this wave raised its running max -> nothing to rescale (exact)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+          for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-          for (int t = 0; t < 16; ++t) o[dt][t] *= alpha;
+            for (int t = 0; t < 16; ++t) o[dt][t] *= alpha;
+        }
         // ---- P^T -> bf16 B fragments: k-step sp uses regs 8sp .. 8sp+7
         bf16x8 pf[2];
 #pragma unroll
@@ -200,18 +203,19 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
 }
 
 template <int D, int GRP>
-static int launch_attn(const void* qkv, const int32_t* cu, int n_seqs, int max_seqlen, int nq, int nkv, void* out, hipStream_t s) {
+static int launch_attn(const void* qkv, const int32_t* cu, int n_seqs, int max_seqlen, int nq, int nkv, void* out, int last_tile_only,
+                       hipStream_t s) {
   int nqt = (int)lrx_cdiv(max_seqlen, 64);
   float scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-  hipLaunchKernelGGL((k_attn_varlen_causal<D, GRP>), dim3(n_seqs * nqt, nkv), dim3(128 * GRP), 0, s, (const __bf16*)qkv, cu, nqt, nq, nkv,
-                     (__bf16*)out, scale_log2);
+  hipLaunchKernelGGL((k_attn_varlen_causal<D, GRP>), dim3(last_tile_only ? n_seqs : n_seqs * nqt, nkv), dim3(128 * GRP), 0, s, (const __bf16*)qkv,
+                     cu, nqt, nq, nkv, (__bf16*)out, scale_log2, last_tile_only);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
 
 extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens,
                                       int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out,
-                                      void* stream) {
+                                      int32_t last_tile_only, void* stream) {
   LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "attn: head_dim=%d unsupported (64 or 128)", head_dim);
   LRX_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "attn: nq=%d not a multiple of nkv=%d", num_q_heads, num_kv_heads);
   LRX_CHECK_ARG(max_seqlen > 0 || total_tokens == 0, "attn: max_seqlen must be > 0");
@@ -219,7 +223,7 @@ extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens
   int grp = num_q_heads / num_kv_heads;
   hipStream_t s = (hipStream_t)stream;
 #define LRX_ATTN_CASE(DD, GG) \
-  if (head_dim == DD && grp == GG) return launch_attn<DD, GG>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, s);
+  if (head_dim == DD && grp == GG) return launch_attn<DD, GG>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s);
   LRX_ATTN_CASE(64, 1) LRX_ATTN_CASE(64, 2) LRX_ATTN_CASE(64, 4) LRX_ATTN_CASE(64, 6) LRX_ATTN_CASE(64, 7) LRX_ATTN_CASE(64, 8)
   LRX_ATTN_CASE(128, 1) LRX_ATTN_CASE(128, 2) LRX_ATTN_CASE(128, 4) LRX_ATTN_CASE(128, 6) LRX_ATTN_CASE(128, 7) LRX_ATTN_CASE(128, 8)
 #undef LRX_ATTN_CASE

@@ -80,10 +80,11 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 struct EncWs {
   char *x, *h, *qkv, *act;
+  char *xr, *ar, *hr, *actr;  // compact [n_seqs, .] buffers of the pooled tail of the final layer
   int32_t* pos;
   size_t total;
 };
-static EncWs carve(const lrx_encoder_config* c, int64_t T, char* base) {
+static EncWs carve(const lrx_encoder_config* c, int64_t T, int64_t B, char* base) {
   const int64_t H = c->hidden_size, QD = (int64_t)c->num_q_heads * c->head_dim;
   const int64_t QKV = (int64_t)(c->num_q_heads + 2 * c->num_kv_heads) * c->head_dim, I = c->intermediate_size;
   const int64_t HM = H > QD ? H : QD;
@@ -94,14 +95,17 @@ static EncWs carve(const lrx_encoder_config* c, int64_t T, char* base) {
   w.qkv = base + off; off += align_up((size_t)T * QKV * 2, 1024);
   w.act = base + off; off += align_up((size_t)T * I * 2, 1024);
   w.pos = (int32_t*)(base + off); off += align_up((size_t)T * 4, 1024);
+  w.xr = base + off; off += align_up((size_t)B * H * 2, 1024);
+  w.ar = base + off; off += align_up((size_t)B * HM * 2, 1024);
+  w.hr = base + off; off += align_up((size_t)B * H * 2, 1024);
+  w.actr = base + off; off += align_up((size_t)B * I * 2, 1024);
   w.total = off;
   return w;
 }
 
 extern "C" size_t lrx_encode_workspace_bytes(const lrx_encoder_config* cfg, int32_t total_tokens, int32_t n_seqs) {
-  (void)n_seqs;
   if (!cfg) return 0;
-  return carve(cfg, total_tokens > 0 ? total_tokens : 1, nullptr).total;
+  return carve(cfg, total_tokens > 0 ? total_tokens : 1, n_seqs > 0 ? n_seqs : 1, nullptr).total;
 }
 
 static int check_cfg(const lrx_encoder_config* c) {
@@ -115,9 +119,11 @@ static int check_cfg(const lrx_encoder_config* c) {
   return LRX_OK;
 }
 
-// runs embedding + all layers; leaves the residual stream (before the final norm) in ws.x
+// runs embedding + all layers; leaves the residual stream (before the final norm) in ws.x -- or, with pooled_tail, only
+// the n_seqs last-token rows of it, compacted, in ws.xr: after the final layer's attention nothing but those rows
+// reaches the pooled output, so its O-projection and MLP run on [n_seqs, H] instead of [T, H] (bit-identical rows).
 static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu, int n_seqs,
-                          int T, int max_seqlen, EncWs& ws, hipStream_t s) {
+                          int T, int max_seqlen, EncWs& ws, bool pooled_tail, hipStream_t s) {
   const int H = c->hidden_size, d = c->head_dim, nq = c->num_q_heads, nkv = c->num_kv_heads, I = c->intermediate_size;
   const int QKV = (nq + 2 * nkv) * d, QD = nq * d;
   int rc;
@@ -132,7 +138,18 @@ static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights
     { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
     { ProfScope p(s, 0, 2.0 * T * (double)QKV * H); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, nullptr, T, QKV, H, 0, s))) return rc; }
     { ProfScope p(s, 5, 0); if ((rc = lrx_rope_inplace(ws.qkv, ws.pos, w->rope_cos, w->rope_sin, T, nq, nkv, d, s))) return rc; }
-    { ProfScope p(s, 3, attn_flops); if ((rc = lrx_attn_varlen_causal(ws.qkv, cu, n_seqs, T, max_seqlen, nq, nkv, d, ws.h, s))) return rc; }
+    if (pooled_tail && l == c->num_layers - 1) {
+      const int B = n_seqs;
+      { ProfScope p(s, 3, attn_flops * 64.0 / (S > 64.0 ? S : 64.0)); if ((rc = lrx_attn_varlen_causal(ws.qkv, cu, n_seqs, T, max_seqlen, nq, nkv, d, ws.h, 1, s))) return rc; }
+      { ProfScope p(s, 6, 0); if ((rc = lrx_gather_last_rows(ws.h, cu, B, QD, ws.ar, s))) return rc; }
+      { ProfScope p(s, 6, 0); if ((rc = lrx_gather_last_rows(ws.x, cu, B, H, ws.xr, s))) return rc; }
+      { ProfScope p(s, 1, 2.0 * B * (double)H * QD); if ((rc = lrx_gemm_bf16_nt(ws.ar, L.wo, ws.xr, nullptr, ws.xr, B, H, QD, 1, s))) return rc; }
+      { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.xr, L.ln2, ws.hr, B, H, c->rms_eps, s))) return rc; }
+      { ProfScope p(s, 2, 2.0 * B * (double)(2 * I) * H); if ((rc = lrx_gemm_bf16_nt(ws.hr, L.wgu, ws.actr, nullptr, nullptr, B, 2 * I, H, 2, s))) return rc; }
+      { ProfScope p(s, 1, 2.0 * B * (double)H * I); if ((rc = lrx_gemm_bf16_nt(ws.actr, L.wdown, ws.xr, nullptr, ws.xr, B, H, I, 1, s))) return rc; }
+      break;
+    }
+    { ProfScope p(s, 3, attn_flops); if ((rc = lrx_attn_varlen_causal(ws.qkv, cu, n_seqs, T, max_seqlen, nq, nkv, d, ws.h, 0, s))) return rc; }
     { ProfScope p(s, 1, 2.0 * T * (double)H * QD); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wo, ws.x, nullptr, ws.x, T, H, QD, 1, s))) return rc; }
     { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, T, H, c->rms_eps, s))) return rc; }
     { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, s))) return rc; }
@@ -166,12 +183,12 @@ extern "C" int lrx_encode_packed(const lrx_encoder_config* cfg, const lrx_encode
   LRX_CHECK_ARG(out && out_dim > 0 && out_dim <= cfg->hidden_size && out_row_stride >= out_dim, "encode: bad output spec (dim=%d stride=%lld)",
                 out_dim, (long long)out_row_stride);
   hipStream_t s = (hipStream_t)stream;
-  EncWs ws = carve(cfg, total_tokens, (char*)workspace);
+  EncWs ws = carve(cfg, total_tokens, n_seqs, (char*)workspace);
   prof_begin();
-  if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, s))) return rc;
+  if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, true, s))) return rc;
   {
-    ProfScope p(s, 6, 0);
-    if ((rc = lrx_pool_norm(ws.x, w->final_norm, cu_seqlens, n_seqs, cfg->hidden_size, cfg->rms_eps, out, out_row_stride, out_dim, normalize, s)))
+    ProfScope p(s, 6, 0);  // ws.xr holds the compacted last-token rows -> cu_seqlens = NULL
+    if ((rc = lrx_pool_norm(ws.xr, w->final_norm, nullptr, n_seqs, cfg->hidden_size, cfg->rms_eps, out, out_row_stride, out_dim, normalize, s)))
       return rc;
   }
   return prof_end(s);
@@ -184,9 +201,9 @@ extern "C" int lrx_encode_hidden(const lrx_encoder_config* cfg, const lrx_encode
   if (rc) return rc;
   LRX_CHECK_ARG(hidden_out_bf16 != nullptr, "encode_hidden: null output");
   hipStream_t s = (hipStream_t)stream;
-  EncWs ws = carve(cfg, total_tokens, (char*)workspace);
+  EncWs ws = carve(cfg, total_tokens, n_seqs, (char*)workspace);
   prof_begin();
-  if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, s))) return rc;
+  if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, false, s))) return rc;
   {
     ProfScope p(s, 4, 0);
     if ((rc = lrx_rmsnorm(ws.x, w->final_norm, hidden_out_bf16, total_tokens, cfg->hidden_size, cfg->rms_eps, s))) return rc;

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hi
   float* row = (float*)smem_raw;  // H floats
   float* red = row + H;           // 4 floats
   int b = blockIdx.x;
-  int64_t t = (int64_t)cu[b + 1] - 1;
+  int64_t t = cu ? (int64_t)cu[b + 1] - 1 : (int64_t)b;
   const __bf16* x = hidden + t * H;
   float ss = 0.f;
   for (int i = threadIdx.x; i < H; i += 256) { float f = bf2f(x[i]); row[i] = f; ss += f * f; }
@@ -185,6 +185,27 @@ extern "C" int lrx_pool_norm(const void* hidden, const void* final_norm_w, const
   size_t smem = (size_t)(hidden_size + 4) * sizeof(float);
   hipLaunchKernelGGL(k_pool_norm, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, (const __bf16*)hidden, (const __bf16*)final_norm_w,
                      cu_seqlens, hidden_size, eps, out, out_row_stride, out_dim, normalize);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gather of the last-token rows (compaction for the pooled tail of the final layer): one wave per sequence
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_last_rows(const bf16x8* __restrict__ src, const int32_t* __restrict__ cu, int n_seqs, int chunks,
+                                                          bf16x8* __restrict__ dst) {
+  int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n_seqs) return;
+  int lane = threadIdx.x & 63;
+  int64_t s = ((int64_t)cu[b + 1] - 1) * chunks, d = (int64_t)b * chunks;
+  for (int c = lane; c < chunks; c += 64) dst[d + c] = src[s + c];
+}
+
+extern "C" int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, int32_t width, void* dst, void* stream) {
+  LRX_CHECK_ARG(width % 8 == 0, "gather_last_rows: width %% 8 != 0");
+  if (n_seqs == 0) return LRX_OK;
+  hipLaunchKernelGGL(k_gather_last_rows, dim3(lrx_cdiv(n_seqs, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)src, cu_seqlens, n_seqs,
+                     width / 8, (bf16x8*)dst);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

@@ -46,12 +46,20 @@ def rope_inplace(qkv: torch.Tensor, positions: torch.Tensor, cos: torch.Tensor, 
     return qkv
 
 
-def attn_varlen_causal(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, nq: int, nkv: int, d: int) -> torch.Tensor:
+def attn_varlen_causal(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, nq: int, nkv: int, d: int,
+                       last_tile_only: bool = False) -> torch.Tensor:
     T = qkv.shape[0]
-    out = torch.empty(T, nq * d, dtype=torch.bfloat16, device=qkv.device)
+    out = (torch.zeros if last_tile_only else torch.empty)(T, nq * d, dtype=torch.bfloat16, device=qkv.device)
     _lib.check(_lib.lib().lrx_attn_varlen_causal(_lib.ptr(qkv), _lib.ptr(cu_seqlens), cu_seqlens.numel() - 1, T, max_seqlen, nq, nkv, d,
-                                                 _lib.ptr(out), _s()))
+                                                 _lib.ptr(out), int(last_tile_only), _s()))
     return out
+
+
+def gather_last_rows(src: torch.Tensor, cu_seqlens: torch.Tensor) -> torch.Tensor:
+    B = cu_seqlens.numel() - 1
+    dst = torch.empty(B, src.shape[1], dtype=torch.bfloat16, device=src.device)
+    _lib.check(_lib.lib().lrx_gather_last_rows(_lib.ptr(src), _lib.ptr(cu_seqlens), B, src.shape[1], _lib.ptr(dst), _s()))
+    return dst
 
 
 def pool_norm(hidden: torch.Tensor, w: torch.Tensor, cu_seqlens: torch.Tensor, eps: float, out_dim: Optional[int] = None,

@@ -31,7 +31,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     # invalid shapes are rejected on the host before any launch
     assert l.lrx_gemm_bf16_nt(None, None, None, None, None, 4, 8, 7, 0, None) == -1
     assert b"K=7" in l.lrx_last_error()
-    assert l.lrx_attn_varlen_causal(None, None, 1, 4, 4, 4, 2, 16, None, None) == -1
+    assert l.lrx_attn_varlen_causal(None, None, 1, 4, 4, 4, 2, 16, None, 0, None) == -1
     assert l.lrx_flat_ip_scores(None, 10, 48, 48, None, 1, None, None) == -1
     assert l.lrx_flat_ip_score_ld(1000) == 1024
     assert l.lrx_encode_workspace_bytes(None, 1, 1) == 0

@@ -97,6 +97,18 @@ def test_writes_in_place_into_index_rows_and_is_batch_invariant():
     np.testing.assert_array_equal(rev, full[order])
 
 
+def test_pooled_tail_equals_full_forward():
+    """encode_packed (final layer's O-proj/MLP only on the pooled rows) == pooling the full encode_hidden output."""
+    for d in (64, 128):
+        cfg, w, ids, cu, max_len = medium_case(d)
+        enc = make_encoder(cfg, w)
+        tid, tcu = to_dev(ids, torch.int32), to_dev(cu, torch.int32)
+        h = enc.encode_hidden(tid, tcu, max_len).float()
+        want = torch.nn.functional.normalize(h[tcu[1:].long() - 1], dim=-1)
+        got = enc.encode_packed(tid, tcu, max_len)
+        assert torch.allclose(got, want, atol=1e-6), (got - want).abs().max()
+
+
 def test_argument_errors():
     from lightretriever_amd._lib import LrxError
     cfg, w, ids, cu, max_len = medium_case(64)

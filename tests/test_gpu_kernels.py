@@ -216,3 +216,24 @@ def test_embedding_bag_bit_exact():
     # and against torch.nn.EmbeddingBag itself (the reference's query operator) on the same device
     bag = torch.nn.EmbeddingBag.from_pretrained(tt, padding_idx=pad)
     np.testing.assert_allclose(f32(raw), f32(bag(ti, to)), atol=1e-6)
+
+
+def test_attention_last_tile_only_and_gather():
+    """The pooled tail of the final layer: only the q tile holding each sequence's last token is computed, and those
+    rows are bit-identical to the full kernel's rows; gather_last_rows compacts them."""
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(21)
+    d, nq, nkv, lens = 64, 8, 2, [1, 64, 65, 200, 512, 129]
+    T = sum(lens)
+    qkv = bf16_t(rnd(rng, T, (nq + 2 * nkv) * d))
+    cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev())
+    full = ops.attn_varlen_causal(qkv, cu, max(lens), nq, nkv, d)
+    last = ops.attn_varlen_causal(qkv, cu, max(lens), nq, nkv, d, last_tile_only=True)
+    g_full, g_last = ops.gather_last_rows(full, cu), ops.gather_last_rows(last, cu)
+    assert torch.equal(g_full, g_last)
+    cu_h = cu.cpu().numpy()
+    np.testing.assert_array_equal(f32(g_full), f32(full)[cu_h[1:] - 1])
+    for b, n in enumerate(lens):      # rows outside the last tile were not touched (zeros), rows inside match
+        t0 = ((n - 1) // 64) * 64
+        assert torch.equal(last[cu_h[b] + t0:cu_h[b + 1]], full[cu_h[b] + t0:cu_h[b + 1]])
+        assert (last[cu_h[b]:cu_h[b] + t0] == 0).all()
