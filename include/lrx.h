@@ -116,7 +116,7 @@ int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens
 /* LlamaRMSNorm (modeling_llama.py:53-67): y = w * bf16(x * rsqrt(mean(x^2) + eps)); x, w, y bf16; rows x hidden */
 int lrx_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps, void* stream);
 
-/* C[M,N] = A[M,K] * B[N,K]^T, bf16 in, fp32 accumulate, bf16 out.  K % 64 == 0, N % 4 == 0.
+/* C[M,N] = A[M,K] * B[N,K]^T, bf16 in, fp32 accumulate, bf16 out.  K % 64 == 0, N % 8 == 0.
  *   epilogue 0: C = acc (+ bias[n] if bias != NULL)          ldc = N
  *   epilogue 1: C = acc + resid[m,n]  (resid may alias C)    ldc = N
  *   epilogue 2: SwiGLU on gate/up-interleaved B (see wgu):   C[M, N/2] = silu(gate) * up, ldc = N/2           */

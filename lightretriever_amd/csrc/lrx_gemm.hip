@@ -160,57 +160,74 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   }
   if (wr == 0) G_BAR();
 
-  // ---- epilogue: lane holds row m (.. + fr) and 4 consecutive columns (.. + fq*4 + {0..3}) of each 16x16 tile
+  // ---- epilogue.  The accumulator layout (lane = 1 row x 4 columns per 16x16 tile) would give 8-byte stores that touch 16
+  //      partial lines per wave instruction (measured: 6-20 us per tile).  Instead the bf16 C tile is staged through the
+  //      (now idle) 128 KiB of LDS -- 16-B chunk index XOR (row & 15): conflict-free ds_write_b64 and ds_read_b128 -- and
+  //      written row-major, 16 B per lane: every wave instruction moves two full 512-B row segments.  The residual is
+  //      read the same way and added to the bf16-rounded product (exactly the reference's bf16 `residual + linear(x)`).
+  constexpr int CW = (EPI == EPI_SWIGLU) ? 128 : 256;  // output columns of this tile
+  constexpr int CPR = CW / 8;                          // 16-B chunks per staged row
+  // all LDS reads of the K loop are complete (lgkmcnt(0) precedes every barrier; the last barrier was passed by all waves)
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-      const int m = m0 + h * 128 + wr * 64 + mi * 16 + fr;
-      if (m >= M) continue;
+      const int row = h * 128 + wr * 64 + mi * 16 + fr;
 #pragma unroll
       for (int hp = 0; hp < 2; ++hp) {
-        const int nb = n0 + hp * 128 + wc * 32;  // first column of this wave's 32-column block
         if (EPI == EPI_SWIGLU) {
-          // columns [nb, nb+16) = gate tile, [nb+16, nb+32) = up tile of output columns nb/2 .. nb/2+15
-          if (nb >= N) continue;
+          // wave columns [nb, nb+16) = gate, [nb+16, nb+32) = up of output columns nb/2 .. nb/2+15
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float g = acc[h][hp][mi][0][r], u = acc[h][hp][mi][1][r];
             o[r] = f2bf(g / (1.0f + __expf(-g)) * u);
           }
-          *(bf16x4*)(C + (int64_t)m * (N >> 1) + (nb >> 1) + fq * 4) = o;
+          const int col = hp * 64 + wc * 16 + fq * 4;  // within the 128-column output tile
+          *(bf16x4*)(smem + row * (CW * 2) + ((((col >> 3) ^ (row & 15)) << 4) | ((col & 4) << 1))) = o;
         } else {
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
-            const int n = nb + ni * 16 + fq * 4;
-            if (n >= N) continue;
+            const int col = hp * 128 + wc * 32 + ni * 16 + fq * 4;
             f32x4 v = acc[h][hp][mi][ni];
             if (EPI == EPI_STORE && bias != nullptr) {
+              const int n = min(n0 + col, N - 4);
               bf16x4 bv = *(const bf16x4*)(bias + n);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += bf2f(bv[r]);
             }
-            if (EPI == EPI_RESID) {
-              bf16x4 rv = *(const bf16x4*)(resid + (int64_t)m * N + n);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += bf2f(rv[r]);
-            }
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
-            *(bf16x4*)(C + (int64_t)m * N + n) = o;
+            *(bf16x4*)(smem + row * (CW * 2) + ((((col >> 3) ^ (row & 15)) << 4) | ((col & 4) << 1))) = o;
           }
         }
       }
     }
+  __syncthreads();
+  const int ldc = (EPI == EPI_SWIGLU) ? (N >> 1) : N;
+  const int c0 = (EPI == EPI_SWIGLU) ? (n0 >> 1) : n0;
+#pragma unroll 4
+  for (int it = 0; it < (256 * CPR) / 512; ++it) {
+    const int q = it * 512 + tid;
+    const int row = q / CPR, ch = q % CPR;
+    const int m = m0 + row, n = c0 + ch * 8;
+    if (m >= M || n >= ldc) continue;
+    bf16x8 v = *(const bf16x8*)(smem + row * (CW * 2) + ((ch ^ (row & 15)) << 4));
+    if (EPI == EPI_RESID) {
+      bf16x8 rv = *(const bf16x8*)(resid + (int64_t)m * N + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[e]));
+    }
+    *(bf16x8*)(C + (int64_t)m * ldc + n) = v;
+  }
 }
 
 extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N,
                                 int32_t K, int32_t epilogue, void* stream) {
   LRX_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   LRX_CHECK_ARG(K % GBK == 0, "gemm: K=%d must be a multiple of %d", K, GBK);
-  LRX_CHECK_ARG(N % 4 == 0, "gemm: N=%d must be a multiple of 4", N);
+  LRX_CHECK_ARG(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
   LRX_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "gemm: unknown epilogue %d", epilogue);
   LRX_CHECK_ARG(epilogue != EPI_SWIGLU || N % 32 == 0, "gemm: SwiGLU epilogue needs N %% 32 == 0 (N=%d)", N);
   LRX_CHECK_ARG(epilogue != EPI_RESID || resid != nullptr, "gemm: residual epilogue without resid");

@@ -79,7 +79,14 @@ def test_gemm_residual_inplace(M, N, K):
     A, B, R = rnd(rng, M, K), rnd(rng, N, K, scale=0.05), rnd(rng, M, N)
     r = bf16_t(R)
     got = ops.gemm_bf16_nt(bf16_t(A), bf16_t(B), resid=r, epilogue=1, out=r)  # C aliases resid
-    bf16_ulp_close(f32(got), A @ B.T + R, ulps=1.01, atol=2e-3)
+    # reference arithmetic of a bf16 model: residual + linear(x), both bf16 -> bf16(bf16(A B^T) + R).  A 1-ulp flip of the
+    # inner rounding (fp32 summation order) moves the result by one ulp of the product, hence the |P| term.
+    P = A @ B.T
+    want = O.round_bf16(O.round_bf16(P) + R)
+    tol = 1.01 * 2.0 ** -7 * (np.abs(P) + np.abs(want)) + 1e-6
+    bad = np.abs(f32(got) - want) > tol
+    assert not bad.any(), f"{bad.sum()} mismatches, max diff {np.abs(f32(got) - want).max()}"
+    assert (f32(got) == want).mean() > 0.97      # and the vast majority is bit-identical to the bf16 reference arithmetic
 
 
 @pytest.mark.parametrize("M,I,K", [(200, 128, 64), (513, 512, 256), (300, 8192, 2048)])
