@@ -111,6 +111,16 @@ def cpu_baseline(cfg, seq_len, topk, dim):
     }
 
 
+def pmc_traffic(kernel_key):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC summary (tools/pmc_traffic.sh: separate
+    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction); None when no summary is present."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        return round(d[kernel_key]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,7 +218,9 @@ def main():
             "unit": "queries/s", "ms_per_pass": round(1e3 * srch_s / args.steps, 4), "queries": args.queries, "index_rows": args.index_rows,
             "dim": D, "shard_rows": shard_rows, "scaling": "strong (fixed index row-sharded over ranks)",
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (local_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(alg_bytes / (local_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                         "frac": round(alg_bytes / (local_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                         "traffic": pmc_traffic("k_flat_ip_scores_split") if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100) else None,
+                         "algorithmic_bytes": alg_bytes,
                          "kernel": "k_split_queries + k_flat_ip_scores_split<7> (bf16x3 split, 6 MFMA products) + k_topk_select (local shard search, HIP events)", "ms": round(local_ms, 4),
                          "fp32_equiv_tflops": round(2.0 * args.queries * D * shard_rows / (local_ms * 1e-3) / 1e12, 2),
                          "fp32_mfma_peak_for_reference": PEAK_F32_MFMA_TFLOPS},
@@ -226,7 +238,8 @@ def main():
     achieved = gu["flops"] / (gu["ms"] * 1e-3) / 1e12 if gu["ms"] > 0 else 0.0
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-        "traffic": None, "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (gate-up projection, M=%d N=%d K=%d)" % (B * S, 2 * cfg.intermediate_size, D),
+        "traffic": pmc_traffic("k_gemm_bf16_nt<2>") if (args.model == "llama3.2-1b" and B == 256 and S == 512) else None,
+        "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (gate-up projection, M=%d N=%d K=%d)" % (B * S, 2 * cfg.intermediate_size, D),
         "avg_launch_ms": round(gu["ms"] / max(gu["launches"], 1), 4), "launches": gu["launches"],
         "all_gemms_tflops": round(gemm_all_fl / (gemm_all_ms * 1e-3) / 1e12, 2) if gemm_all_ms > 0 else None,
         "per_class_ms_per_step": {k_: round(v["ms"] / args.steps, 3) for k_, v in prof.items()},
