@@ -17,32 +17,36 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = True, defines=(), out: str = None) -> str:
+    """defines/out: diagnostic variant builds (tools/ only); the product library is always LIB."""
+    if out is None and not force and not _stale():
         return LIB
+    lib_path = out or LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = obj if out is None else obj.replace(".o", "." + os.path.basename(out) + ".o")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[lrx build]", " ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:
-        out, _ = p.communicate()
+        log, _ = p.communicate()
         if p.returncode != 0:
-            sys.stderr.write(out.decode())
+            sys.stderr.write(log.decode())
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print("[lrx build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a[6:] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build(force="--force" in sys.argv, defines=defs, out=outs[0] if outs else None))

@@ -19,6 +19,7 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+typedef __attribute__((address_space(3))) const char* lds_char_ptr;
 
 template <int D>
 struct AttnGeom {
@@ -39,7 +40,13 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
   constexpr int NW = 2 * GRP;
   constexpr int KS = D / 16;  // k-steps of the QK^T product
   constexpr int DT = D / 32;  // 32-row tiles of O^T
-  __shared__ __attribute__((aligned(1024))) char smem[4 * G::TILE_BYTES];  // [stage][K|V]
+  // K/V ring: 3 stages with a counted vmcnt (two tiles in flight; a tile's compute, ~0.5 us, is shorter than the load
+  // latency, so one tile of prefetch leaves every barrier waiting on HBM) whenever every wave issues the same number of
+  // LDS-DMA instructions per tile; otherwise 2 stages with a full drain.
+  constexpr bool RING3 = (G::INSTS % NW == 0) && (3 * 2 * G::TILE_BYTES <= 96 * 1024);
+  constexpr int NST = RING3 ? 3 : 2;
+  constexpr int PER_TILE = RING3 ? 2 * (G::INSTS / NW) : 0;  // LDS-DMA instructions per wave per tile (K + V)
+  __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * G::TILE_BYTES];  // [stage][K|V]
 
   const int b = last_tile_only ? blockIdx.x : blockIdx.x / nqt;
   const int hk = blockIdx.y;
@@ -49,7 +56,8 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
   const int qtile0 = qt * 64;
   if (qtile0 >= len) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: branches on it stay scalar
   const int r = lane & 31, h = lane >> 5;
   const int hq = hk * GRP + (wave % GRP);
   const int q0 = qtile0 + (wave / GRP) * 32;
@@ -75,7 +83,11 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     for (int j = wave; j < G::INSTS; j += NW) {
       int s = j * 64 + lane;
       int row = s / G::CH, cs = s % G::CH;
+#if defined(ATTN_EXP) && ATTN_EXP == 1
+      int grow = min(row, len - 1);   // DIAG: always tile 0 (L2-hot), same instruction stream
+#else
       int grow = min(kt * 64 + row, len - 1);
+#endif
       const __bf16* kp = kbase + (int64_t)grow * RS + ((cs ^ G::xk(row)) << 3);
       const __bf16* vp = vbase + (int64_t)grow * RS + ((cs ^ G::xv(row)) << 3);
       __builtin_amdgcn_global_load_lds((gptr_t)kp, (lptr_t)(sK + j * 1024), 16, 0, 0);
@@ -104,88 +116,152 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     for (int t = 0; t < 16; ++t) o[dt][t] = 0.f;
   float m = -1e30f, l = 0.f;
 
+  auto qk_product = [&](const char* kt_base, const int (&koff_)[KS], const bf16x8 (&qf_)[KS]) -> f32x16 {
+    bf16x8 kf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kt_base + koff_[ks]);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // inline-constant C operand
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf_[0], zero, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf_[ks], acc, 0, 0, 0);
+    return acc;
+  };
+  // lane <-> lane^32 exchange on the VALU (v_permlane32_swap) instead of an LDS round trip (ds_bpermute)
+  auto xhalf_max = [](float x) -> float {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  };
+  auto softmax_pv = [&](f32x16& s, const char* v_base, bool diag) {
+    // ---- V^T fragments: issued now (latency hides under the softmax VALU) as inline asm: the ds_read_tr builtin makes
+    //      hipcc drain ALL in-flight LDS-DMA (s_waitcnt vmcnt(0)) before every read, serialising the prefetch ring.
+    s16x4 vt[2][DT][2];
+    {
+      const uint32_t vb = (uint32_t)(uintptr_t)(lds_char_ptr)(v_base + 4 * h * G::ROW_BYTES);
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const uint32_t a = vb + sp * 16 * G::ROW_BYTES + voff[dt];
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[sp][dt][0]) : "v"(a));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[sp][dt][1]) : "v"(a), "i"(8 * G::ROW_BYTES));
+        }
+    }
+    // ---- causal mask (diagonal sub-tile only: scalar branch); online softmax in the exp2 domain with the
+    //      1/sqrt(d)*log2(e) scale folded into the exponent FMA: p = exp2(s*c - m*c), m tracked on the raw scores
+    if (diag) {
+      const int lim = r - 4 * h;   // reg t holds key (t&3) + 8*(t>>2) + 4h (relative): masked iff that exceeds r
+#pragma unroll
+      for (int t = 0; t < 16; ++t) s[t] = ((t & 3) + 8 * (t >> 2) > lim) ? -1e30f : s[t];
+    }
+    float mloc = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+    for (int t = 3; t < 15; t += 2) mloc = fmaxf(fmaxf(mloc, s[t]), s[t + 1]);
+    mloc = xhalf_max(fmaxf(mloc, s[15]));
+    const float mnew = fmaxf(m, mloc);
+    const float alpha = __builtin_amdgcn_exp2f((m - mnew) * scale_log2);
+    m = mnew;
+    const float mc = -mnew * scale_log2;
+    {
+      const f32x2 c2 = {scale_log2, scale_log2}, m2 = {mc, mc};
+      f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        f32x2 e = f32x2{s[t], s[t + 1]} * c2 + m2;
+        e[0] = __builtin_amdgcn_exp2f(e[0]);
+        e[1] = __builtin_amdgcn_exp2f(e[1]);
+        s[t] = e[0];
+        s[t + 1] = e[1];
+        ps2 += e;
+      }
+      l = l * alpha + (ps2[0] + ps2[1]);
+    }
+    if (!__all(alpha == 1.0f)) {  // wave-uniform: no q row of this wave raised its running max -> nothing to rescale (exact)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[dt][t] *= alpha;
+    }
+    // ---- P^T -> bf16 B fragments: k-step sp uses regs 8sp .. 8sp+7
+    bf16x8 pf[2];
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) pf[sp][jj] = f2bf(s[8 * sp + jj]);
+    // ---- O^T += V^T P^T
+    if (DT == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]), "+v"(vt[1][0][0]), "+v"(vt[1][0][1]),
+                     "+v"(vt[1][1][0]), "+v"(vt[1][1][1])
+                   :
+                   : "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]), "+v"(vt[0][2 % DT][0]), "+v"(vt[0][2 % DT][1]),
+                     "+v"(vt[0][3 % DT][0]), "+v"(vt[0][3 % DT][1]), "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]),
+                     "+v"(vt[1][2 % DT][0]), "+v"(vt[1][2 % DT][1]), "+v"(vt[1][3 % DT][0]), "+v"(vt[1][3 % DT][1])
+                   :
+                   : "memory");
+    }
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = vt[sp][dt][0]; u.s.b = vt[sp][dt][1];
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pf[sp], o[dt], 0, 0, 0);
+      }
+  };
+
   const int nkt = qt + 1;
   stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (RING3 && nkt > 1) {
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
 
+  int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    if (RING3) {
+      if (kt + 2 < nkt) stage(cur == 0 ? 2 : cur - 1, kt + 2);   // (cur + 2) % 3
+    } else {
+      if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    }
+#if defined(ATTN_EXP) && ATTN_EXP == 2
+    if (false) {   // DIAG: loads + barriers only
+#else
     if (active) {
+#endif
       const char* sK = smem + cur * (2 * G::TILE_BYTES);
       const char* sV = sK + G::TILE_BYTES;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int key0 = kt * 64 + j * 32;
-        if (key0 > q0) continue;  // wave-uniform: sub-tile entirely above the diagonal
-        // ---- S^T = K Q^T
-        f32x16 s;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) s[t] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          bf16x8 kf = *(const bf16x8*)(sK + j * 32 * G::ROW_BYTES + koff[ks]);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-        }
-        // ---- scale, causal mask (diagonal sub-tile only), online softmax
-        const bool diag = (key0 == q0);
-        float mloc = -1e30f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          float v = s[t] * scale_log2;
-          if (diag) {
-            int key = (t & 3) + 8 * (t >> 2) + 4 * h;  // relative to key0 ; q relative to q0 is r
-            v = key > r ? -1e30f : v;
-          }
-          s[t] = v;
-          mloc = fmaxf(mloc, v);
-        }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float mnew = fmaxf(m, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-        m = mnew;
-        float psum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          float p = __builtin_amdgcn_exp2f(s[t] - mnew);
-          s[t] = p;
-          psum += p;
-        }
-        l = l * alpha + psum;
-        if (!__all(alpha == 1.0f)) {  // wave-uniform: no q row of this wave raised its running max -> nothing to rescale (exact)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) o[dt][t] *= alpha;
-        }
-        // ---- P^T -> bf16 B fragments: k-step sp uses regs 8sp .. 8sp+7
-        bf16x8 pf[2];
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) pf[sp][jj] = f2bf(s[8 * sp + jj]);
-        // ---- O^T += V^T P^T
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          const char* vrow = sV + (j * 32 + 16 * sp + 4 * h) * G::ROW_BYTES;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vrow + voff[dt]));
-            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vrow + 8 * G::ROW_BYTES + voff[dt]));
-            union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-            u.s.a = lo; u.s.b = hi;
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pf[sp], o[dt], 0, 0, 0);
-          }
-        }
-      }
+      // Software pipeline inside the wave: the QK^T MFMAs of BOTH 32-key sub-tiles are issued first (K fragments read in
+      // one batch), so the second product runs on the matrix pipe while the VALU does the first sub-tile's softmax, and
+      // the first P.V runs under the second softmax.
+      const bool two = (kt * 64 + 32 <= q0);   // wave-uniform: second sub-tile not entirely above the diagonal
+      f32x16 s0 = qk_product(sK, koff, qf);
+      f32x16 s1;
+      if (two) s1 = qk_product(sK + 32 * G::ROW_BYTES, koff, qf);
+      softmax_pv(s0, sV, kt * 64 == q0);
+      if (two) softmax_pv(s1, sV + 32 * G::ROW_BYTES, kt * 64 + 32 == q0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (RING3 && kt + 2 < nkt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // tile kt+1 landed, tile kt+2 may stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cur = RING3 ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
   }
 
   if (!active) return;
-  const float ltot = l + __shfl_xor(l, 32, 64);
+  float ltot;
+  {
+    auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+    ltot = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+  }
   const float inv = 1.0f / ltot;
   const int q = q0 + r;
   if (q < len) {
@@ -199,6 +275,199 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
         for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g4 + e] * inv);
         *(bf16x4*)(op + dt * 32 + 8 * g4) = v;
       }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// d = 64, S <= 512: K/V-resident kernel.  One workgroup = (sequence, kv head): the whole K and V of that kv head
+// (<= 512 keys x 128 B, 64 KiB each) is staged ONCE into LDS (the tiled kernel above re-loads every K/V tile for each of
+// the q tiles that needs it: 4.5x the bytes at S = 512, which saturates the per-CU load path), then 16 waves walk the
+// (q head, 32-row q block) tasks with no barrier in the main loop: wave w -> head w % GRP, q blocks g, 2NG-1-g, 2NG+g,
+// 4NG-1-g, ... (g = w / GRP, NG = 16 / GRP) so every wave gets the same number of 32x32 sub-tiles under the causal
+// triangle.  Inside a task the QK^T product of sub-tile u+1 is issued before the softmax of sub-tile u.
+// ---------------------------------------------------------------------------------------------------------------
+template <int GRP>
+__global__ void __launch_bounds__(1024)
+k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu, int nq, int nkv, __bf16* __restrict__ out,
+                  float scale_log2) {
+  constexpr int D = 64;
+  using G = AttnGeom<D>;
+  constexpr int KS = D / 16, DT = D / 32, NG = 16 / GRP;
+  constexpr int MAXK = 512;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * MAXK * G::ROW_BYTES];  // K [512][128 B] | V [512][128 B]
+  char* const sKb = smem;
+  char* const sVb = smem + MAXK * G::ROW_BYTES;
+
+  const int b = blockIdx.x, hk = blockIdx.y;
+  const int s0 = cu[b], len = cu[b + 1] - s0;
+  if (len <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t RS = (int64_t)(nq + 2 * nkv) * D;
+  const __bf16* kbase = qkv + (int64_t)s0 * RS + (int64_t)(nq + hk) * D;
+  const __bf16* vbase = kbase + (int64_t)nkv * D;
+
+  // ---- stage all K/V rows of this kv head (rows >= len are clamped copies; the causal mask hides them)
+  const int ninst = ((len + 63) >> 6) * G::INSTS;   // 1-KiB LDS-DMA instructions per operand
+  for (int j = wave; j < ninst; j += 16) {
+    int s = j * 64 + lane;
+    int row = s / G::CH, cs = s % G::CH;
+    int grow = min(row, len - 1);
+    const __bf16* kp = kbase + (int64_t)grow * RS + ((cs ^ G::xk(row)) << 3);
+    const __bf16* vp = vbase + (int64_t)grow * RS + ((cs ^ G::xv(row)) << 3);
+    __builtin_amdgcn_global_load_lds((gptr_t)kp, (lptr_t)(sKb + j * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)vp, (lptr_t)(sVb + j * 1024), 16, 0, 0);
+  }
+
+  int koff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) koff[ks] = r * G::ROW_BYTES + (((2 * ks + h) ^ G::xk(r)) << 4);
+  int voff[DT];
+  {
+    const int g4 = lane >> 4, i4 = lane & 15, qd = i4 >> 2, p4 = i4 & 3;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+      voff[dt] = qd * G::ROW_BYTES + (((dt * 4 + 2 * (g4 & 1) + (p4 >> 1)) ^ G::xv(qd)) << 4) + 8 * (p4 & 1);
+  }
+  const int head = wave % GRP, g = wave / GRP;
+  const int hq = hk * GRP + head;
+  const int nsub = (len + 31) >> 5;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int k = 0;; ++k) {
+    const int blk = (k >> 1) * 2 * NG;
+    if (blk >= nsub) break;
+    const int i = blk + ((k & 1) ? 2 * NG - 1 - g : g);   // this wave's q block (32 rows), wave-uniform
+    if (i >= nsub) continue;
+    const int q0 = i * 32;
+    bf16x8 qf[KS];
+    {
+      const int qrow = min(q0 + r, len - 1);
+      const __bf16* qp = qkv + ((int64_t)s0 + qrow) * RS + (int64_t)hq * D + h * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) o[dt][t] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    auto qk_product = [&](const char* kt_base) -> f32x16 {
+      bf16x8 kf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kt_base + koff[ks]);
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], zero, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], acc, 0, 0, 0);
+      return acc;
+    };
+
+    auto softmax_pv = [&](f32x16& sc, const int u) {
+      // ---- V^T fragments (inline asm: see the tiled kernel)
+      s16x4 vt[2][DT][2];
+      {
+        const uint32_t vb = (uint32_t)(uintptr_t)(lds_char_ptr)(sVb + (u * 32 + 4 * h) * G::ROW_BYTES);
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const uint32_t a = vb + sp * 16 * G::ROW_BYTES + voff[dt];
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[sp][dt][0]) : "v"(a));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[sp][dt][1]) : "v"(a), "i"(8 * G::ROW_BYTES));
+          }
+      }
+      if (u == i) {   // diagonal sub-tile
+        const int lim = r - 4 * h;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sc[t] = ((t & 3) + 8 * (t >> 2) > lim) ? -1e30f : sc[t];
+      }
+      float mloc = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+      for (int t = 3; t < 15; t += 2) mloc = fmaxf(fmaxf(mloc, sc[t]), sc[t + 1]);
+      mloc = fmaxf(mloc, sc[15]);
+      {
+        auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+        mloc = fmaxf(__uint_as_float(rr[0]), __uint_as_float(rr[1]));
+      }
+      const float mnew = fmaxf(m, mloc);
+      const float alpha = __builtin_amdgcn_exp2f((m - mnew) * scale_log2);
+      m = mnew;
+      const float mc = -mnew * scale_log2;
+      {
+        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two scores per VALU slot); exp2 itself is scalar-per-lane
+        const f32x2 c2 = {scale_log2, scale_log2}, m2 = {mc, mc};
+        f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+          f32x2 e = f32x2{sc[t], sc[t + 1]} * c2 + m2;
+          e[0] = __builtin_amdgcn_exp2f(e[0]);
+          e[1] = __builtin_amdgcn_exp2f(e[1]);
+          sc[t] = e[0];
+          sc[t + 1] = e[1];
+          ps2 += e;
+        }
+        l = l * alpha + (ps2[0] + ps2[1]);
+      }
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int t = 0; t < 16; ++t) o[dt][t] *= alpha;
+      }
+      bf16x8 pf[2];
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) pf[sp][jj] = f2bf(sc[8 * sp + jj]);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]), "+v"(vt[1][0][0]), "+v"(vt[1][0][1]),
+                     "+v"(vt[1][1][0]), "+v"(vt[1][1][1])
+                   :
+                   : "memory");
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
+          uu.s.a = vt[sp][dt][0]; uu.s.b = vt[sp][dt][1];
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uu.v, pf[sp], o[dt], 0, 0, 0);
+        }
+    };
+    // two named score accumulators ping-pong (no register copies): product u+1 is issued before softmax u
+    f32x16 sa = qk_product(sKb), sb;
+    for (int u = 0; u <= i; u += 2) {
+      if (u + 1 <= i) sb = qk_product(sKb + (u + 1) * 32 * G::ROW_BYTES);
+      softmax_pv(sa, u);
+      if (u + 1 > i) break;
+      if (u + 2 <= i) sa = qk_product(sKb + (u + 2) * 32 * G::ROW_BYTES);
+      softmax_pv(sb, u + 1);
+    }
+    // ---- normalise and store this task's rows
+    float ltot;
+    {
+      auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+      ltot = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+    }
+    const float inv = 1.0f / ltot;
+    const int q = q0 + r;
+    if (q < len) {
+      __bf16* op = out + ((int64_t)s0 + q) * ((int64_t)nq * D) + (int64_t)hq * D + 4 * h;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          bf16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g4 + e] * inv);
+          *(bf16x4*)(op + dt * 32 + 8 * g4) = v;
+        }
+    }
   }
 }
 
@@ -222,6 +491,20 @@ extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens
   if (total_tokens == 0 || n_seqs == 0) return LRX_OK;
   int grp = num_q_heads / num_kv_heads;
   hipStream_t s = (hipStream_t)stream;
+  if (head_dim == 64 && max_seqlen <= 512 && !last_tile_only && (grp == 1 || grp == 2 || grp == 4 || grp == 8)) {
+    const float scale_log2 = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
+    dim3 grid(n_seqs, num_kv_heads), block(1024);
+    const __bf16* in = (const __bf16*)qkv;
+    __bf16* o = (__bf16*)out;
+    switch (grp) {
+      case 1: hipLaunchKernelGGL(k_attn_resident64<1>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2); break;
+      case 2: hipLaunchKernelGGL(k_attn_resident64<2>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2); break;
+      case 4: hipLaunchKernelGGL(k_attn_resident64<4>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2); break;
+      default: hipLaunchKernelGGL(k_attn_resident64<8>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2); break;
+    }
+    LRX_LAUNCH_CHECK();
+    return LRX_OK;
+  }
 #define LRX_ATTN_CASE(DD, GG) \
   if (head_dim == DD && grp == GG) return launch_attn<DD, GG>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s);
   LRX_ATTN_CASE(64, 1) LRX_ATTN_CASE(64, 2) LRX_ATTN_CASE(64, 4) LRX_ATTN_CASE(64, 6) LRX_ATTN_CASE(64, 7) LRX_ATTN_CASE(64, 8)

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Dev micro-benchmark of lrx_attn_varlen_causal at the encoder's shapes."""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lightretriever_amd import ops
+
+def main():
+    B, S = int(os.environ.get("B", 256)), int(os.environ.get("S", 512))
+    for (nq, nkv, d) in [(32, 8, 64), (32, 8, 128)]:
+        T = B * S
+        g = torch.Generator(device="cuda").manual_seed(0)
+        qkv = torch.randn(T, (nq + 2 * nkv) * d, generator=g, device="cuda").to(torch.bfloat16)
+        cu = (torch.arange(B + 1, device="cuda") * S).to(torch.int32)
+        for _ in range(2):
+            ops.attn_varlen_causal(qkv, cu, S, nq, nkv, d)
+        ts = []
+        for _ in range(int(os.environ.get("REPS", 8))):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); ops.attn_varlen_causal(qkv, cu, S, nq, nkv, d); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+        med = statistics.median(ts)
+        fl = 4.0 * d * nq * B * (S * (S + 1) / 2)
+        print(f"attn nq={nq} nkv={nkv} d={d} B={B} S={S}: {med:.3f} ms = {fl/med/1e9:.1f} TF/s (causal flops)", flush=True)
+
+if __name__ == "__main__":
+    main()
