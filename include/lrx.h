@@ -123,6 +123,13 @@ int lrx_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hid
 int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M,
                      int32_t N, int32_t K, int32_t epilogue, void* stream);
 
+/* Fused QKV projection + rotary embedding: C[M, (nq+2nkv)*d] = A[M,K] * Wqkv^T (+ bias), then apply_rotary_pos_emb
+ * (modeling_llama.py:130-160) to the q and k column blocks in the epilogue; v columns are stored unrotated.
+ * Equivalent to lrx_gemm_bf16_nt(epilogue 0) followed by lrx_rope_inplace, without the extra pass over qkv.        */
+int lrx_gemm_qkv_rope(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions,
+                      const float* cos, const float* sin, int32_t M, int32_t K, int32_t num_q_heads,
+                      int32_t num_kv_heads, int32_t head_dim, void* stream);
+
 /* positions[t] = t - cu_seqlens[seq(t)] */
 int lrx_build_positions(const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t* positions, void* stream);
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     "lrx_embedding_gather": (_I32, [_P, _P, _I32, _I32, _P, _P]),
     "lrx_rmsnorm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P]),
     "lrx_gemm_bf16_nt": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "lrx_gemm_qkv_rope": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "lrx_build_positions": (_I32, [_P, _I32, _I32, _P, _P]),
     "lrx_rope_inplace": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "lrx_attn_varlen_causal": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),

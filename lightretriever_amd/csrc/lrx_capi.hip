@@ -136,8 +136,8 @@ static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights
   for (int l = 0; l < c->num_layers; ++l) {
     const lrx_layer_weights& L = w->layers[l];
     { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
-    { ProfScope p(s, 0, 2.0 * T * (double)QKV * H); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, nullptr, T, QKV, H, 0, s))) return rc; }
-    { ProfScope p(s, 5, 0); if ((rc = lrx_rope_inplace(ws.qkv, ws.pos, w->rope_cos, w->rope_sin, T, nq, nkv, d, s))) return rc; }
+    { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);   // QKV projection with bias + RoPE fused into the epilogue
+      if ((rc = lrx_gemm_qkv_rope(ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, s))) return rc; }
     if (pooled_tail && l == c->num_layers - 1) {
       const int B = n_seqs;
       { ProfScope p(s, 3, attn_flops * 64.0 / (S > 64.0 ? S : 64.0)); if ((rc = lrx_attn_varlen_causal(ws.qkv, cu, n_seqs, T, max_seqlen, nq, nkv, d, ws.h, 1, s))) return rc; }

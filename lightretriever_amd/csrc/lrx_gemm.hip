@@ -28,7 +28,15 @@
 #define GBK 64
 #define HALF_BYTES 16384
 
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE = 3 };
+
+struct RopeArgs {
+  const int32_t* positions;  // [M]
+  const float* cos;          // [max_pos, d/2]
+  const float* sin;
+  int rope_cols;             // columns [0, rope_cols) are q|k heads to rotate; the rest (v) is stored as is
+  int head_dim;
+};
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -48,7 +56,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
-               const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n) {
+               const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope) {
   __shared__ __attribute__((aligned(1024))) char smem[8 * HALF_BYTES];  // [buf 0/1][A0 | A1 | B0 | B1]
 
   // ---- workgroup -> tile
@@ -190,7 +198,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
           for (int ni = 0; ni < 2; ++ni) {
             const int col = hp * 128 + wc * 32 + ni * 16 + fq * 4;
             f32x4 v = acc[h][hp][mi][ni];
-            if (EPI == EPI_STORE && bias != nullptr) {
+            if ((EPI == EPI_STORE || EPI == EPI_ROPE) && bias != nullptr) {
               const int n = min(n0 + col, N - 4);
               bf16x4 bv = *(const bf16x4*)(bias + n);
 #pragma unroll
@@ -219,6 +227,26 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[e]));
     }
+    if (EPI == EPI_ROPE && n < rope.rope_cols) {
+      // rotary embedding on the staged bf16 q|k values (same arithmetic as k_rope): the rotate_half partner sits half a
+      // head away in the same staged row (heads never straddle a 256-column tile: head_dim divides 256)
+      const int half = rope.head_dim >> 1;
+      const int within = n % rope.head_dim;
+      const bool first = within < half;
+      const int j = first ? within : within - half;
+      const int pch = ch + (first ? (half >> 3) : -(half >> 3));
+      bf16x8 pv = *(const bf16x8*)(smem + row * (CW * 2) + ((pch ^ (row & 15)) << 4));
+      const int pos = rope.positions[m];
+      const float* cs = rope.cos + (int64_t)pos * half + j;
+      const float* sn = rope.sin + (int64_t)pos * half + j;
+      const f32x4 c0 = *(const f32x4*)cs, c1 = *(const f32x4*)(cs + 4), s0 = *(const f32x4*)sn, s1 = *(const f32x4*)(sn + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = bf2f(v[e]), b = bf2f(pv[e]);
+        const float cc = e < 4 ? c0[e & 3] : c1[e & 3], ss = e < 4 ? s0[e & 3] : s1[e & 3];
+        v[e] = f2bf(first ? a * cc - b * ss : a * cc + b * ss);
+      }
+    }
     *(bf16x8*)(C + (int64_t)m * ldc + n) = v;
   }
 }
@@ -237,11 +265,28 @@ extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const voi
   hipStream_t s = (hipStream_t)stream;
   const __bf16 *a = (const __bf16*)A, *b = (const __bf16*)B, *bi = (const __bf16*)bias, *re = (const __bf16*)resid;
   __bf16* c = (__bf16*)C;
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   switch (epilogue) {
-    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n); break;
-    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n); break;
-    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n); break;
+    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none); break;
+    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none); break;
+    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none); break;
   }
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+extern "C" int lrx_gemm_qkv_rope(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos,
+                                 const float* sin, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                 void* stream) {
+  const int N = (num_q_heads + 2 * num_kv_heads) * head_dim;
+  LRX_CHECK_ARG(M >= 0 && K > 0 && K % GBK == 0, "gemm_qkv_rope: bad shape M=%d K=%d", M, K);
+  LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "gemm_qkv_rope: head_dim=%d unsupported", head_dim);
+  LRX_CHECK_ARG(positions && cos && sin, "gemm_qkv_rope: null rope inputs");
+  if (M == 0) return LRX_OK;
+  int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
+  RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim};
+  hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)Wqkv,
+                     (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

@@ -35,6 +35,15 @@ def gemm_bf16_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] 
     return out
 
 
+def gemm_qkv_rope(A: torch.Tensor, Wqkv: torch.Tensor, positions: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, nq: int, nkv: int,
+                  d: int, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    M, K = A.shape
+    out = torch.empty(M, (nq + 2 * nkv) * d, dtype=torch.bfloat16, device=A.device)
+    _lib.check(_lib.lib().lrx_gemm_qkv_rope(_lib.ptr(A), _lib.ptr(Wqkv), _lib.ptr(out), _lib.ptr(bias), _lib.ptr(positions), _lib.ptr(cos),
+                                            _lib.ptr(sin), M, K, nq, nkv, d, _s()))
+    return out
+
+
 def build_positions(cu_seqlens: torch.Tensor, total_tokens: int) -> torch.Tensor:
     pos = torch.empty(total_tokens, dtype=torch.int32, device=cu_seqlens.device)
     _lib.check(_lib.lib().lrx_build_positions(_lib.ptr(cu_seqlens), cu_seqlens.numel() - 1, total_tokens, _lib.ptr(pos), _s()))

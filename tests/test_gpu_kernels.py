@@ -244,3 +244,22 @@ def test_attention_last_tile_only_and_gather():
         t0 = ((n - 1) // 64) * 64
         assert torch.equal(last[cu_h[b] + t0:cu_h[b + 1]], full[cu_h[b] + t0:cu_h[b + 1]])
         assert (last[cu_h[b]:cu_h[b] + t0] == 0).all()
+
+
+@pytest.mark.parametrize("d,nq,nkv,bias", [(64, 4, 2, False), (128, 2, 1, True), (64, 32, 8, False)])
+def test_gemm_qkv_rope_fused_equals_gemm_then_rope(d, nq, nkv, bias):
+    from lightretriever_amd import ops, rope_tables, EncoderConfig
+    rng = np.random.default_rng(d + nq)
+    T, K = 333, 256
+    N = (nq + 2 * nkv) * d
+    cfg = EncoderConfig(100, nq * d, 1, nq, nkv, d, 64, rope_type="llama3", rope_original_max_position=64, max_positions=128)
+    cos, sin = rope_tables(cfg)
+    cos, sin = cos.to(dev()), sin.to(dev())
+    A, W = bf16_t(rnd(rng, T, K)), bf16_t(rnd(rng, N, K, scale=0.05))
+    b = bf16_t(rnd(rng, N)) if bias else None
+    pos = torch.from_numpy(rng.integers(0, 128, size=T).astype(np.int32)).to(dev())
+    want = ops.rope_inplace(ops.gemm_bf16_nt(A, W, bias=b), pos, cos, sin, nq, nkv, d)
+    got = ops.gemm_qkv_rope(A, W, pos, cos, sin, nq, nkv, d, bias=b)
+    diff = (got.float() - want.float()).abs()
+    assert (got == want).float().mean() > 0.999          # identical arithmetic up to fma contraction in the last bit
+    assert (diff <= 2.0 ** -7 * want.float().abs() + 1e-6).all()
