@@ -170,6 +170,27 @@ class LrxEncoder:
                 sd[p + "self_attn.v_proj.bias"] = rn(cfg.num_kv_heads * d)
         return cls(cfg, sd, device)
 
+    def hf_state_dict(self) -> dict:
+        """The packed weights mapped back to HF parameter names (un-fused q/k/v, de-interleaved gate/up): lets tests load
+        the very same values into a transformers model."""
+        c = self.cfg
+        H, d, I = c.hidden_size, c.head_dim, c.intermediate_size
+        nq, nkv = c.num_q_heads * d, c.num_kv_heads * d
+        sd = {"embed_tokens.weight": self.embed, "norm.weight": self.final_norm}
+        for i, L in enumerate(self.layers):
+            p = f"layers.{i}."
+            sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = \
+                L["wqkv"][:nq], L["wqkv"][nq:nq + nkv], L["wqkv"][nq + nkv:]
+            if L["bqkv"] is not None:
+                sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"] = \
+                    L["bqkv"][:nq], L["bqkv"][nq:nq + nkv], L["bqkv"][nq + nkv:]
+            sd[p + "self_attn.o_proj.weight"] = L["wo"]
+            gu = L["wgu"].view(I // 16, 2, 16, H)
+            sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = gu[:, 0].reshape(I, H), gu[:, 1].reshape(I, H)
+            sd[p + "mlp.down_proj.weight"] = L["wdown"]
+            sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = L["ln1"], L["ln2"]
+        return sd
+
     def _build_c_structs(self):
         c = self.cfg
         self._ccfg = _lib.EncoderConfigC(c.vocab_size, c.hidden_size, c.num_layers, c.num_q_heads, c.num_kv_heads, c.head_dim,

@@ -313,6 +313,28 @@ def main():
                         emb_reps=emb_reps, ids_b=ids_b.numpy(), offs_b=offs_b.numpy(), raw_b=raw_b)
     print("[embbag] table", table.shape, "emb_reps", emb_reps.shape)
 
+    # ---- G5b: tokenizer surgery contract (utils/data_utils.py:29-271): a RAW byte-level BPE tokenizer (no normaliser,
+    #      no template, no pad/sep) -> reference load_tokenizer(lowercase, <bos> A <eos>, pad/sep reserved tokens)
+    from tokenizers import Tokenizer, models, pre_tokenizers, decoders, trainers
+    from lightretriever.utils.data_utils import load_tokenizer as ref_load_tokenizer
+    raw = Tokenizer(models.BPE())
+    raw.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    raw.decoder = decoders.ByteLevel()
+    specials = ["<|begin_of_text|>", "<|end_of_text|>", "<|reserved_special_token_0|>", "<|reserved_special_token_1|>"]
+    raw.train_from_iterator(["The Quick Brown Fox Jumps", "Dense Retrieval With LLMs", "Paris Is The Capital Of France"] * 4,
+                            trainers.BpeTrainer(vocab_size=300, special_tokens=specials, initial_alphabet=pre_tokenizers.ByteLevel.alphabet()))
+    raw_dir = os.path.join(HERE, "tok_raw")
+    os.makedirs(raw_dir, exist_ok=True)
+    PreTrainedTokenizerFast(tokenizer_object=raw, bos_token=specials[0], eos_token=specials[1]).save_pretrained(raw_dir)
+    rt = ref_load_tokenizer(raw_dir, lowercase=True, add_bos_num=1, add_eos_num=1, add_pad_token=True, pad_token=specials[2],
+                            add_sep_token=True, sep_token=specials[3])
+    texts = ["The Quick BROWN fox", "Paris", "Dense retrieval with LLMs is FUN " * 5]
+    enc = rt(texts, max_length=24, truncation="only_first", padding=True, add_special_tokens=True)
+    with open(os.path.join(HERE, "tokenizer_surgery.json"), "w") as f:
+        json.dump({"texts": texts, "max_length": 24, "input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"],
+                   "pad": rt.pad_token_id, "sep": rt.sep_token_id, "bos": rt.bos_token_id, "eos": rt.eos_token_id,
+                   "padding_side": rt.padding_side, "nospecial": rt(texts[0], add_special_tokens=False)["input_ids"]}, f, indent=1)
+
     # ---- G7: flat-IP search goldens: torch.matmul fp32 + topk (faiss not installed -> stand-in, see oracle header)
     g = torch.Generator().manual_seed(7)
     X = F.normalize(torch.randn(5000, 64, generator=g), dim=-1)

@@ -148,3 +148,44 @@ def test_baseline_config0_plumbing_1k_docs_100_queries_llama1b_dims():
         np.testing.assert_allclose(sorted(res[qid].values(), reverse=True), sorted(want[qid].values(), reverse=True), atol=3e-6)
         agree.append(len(set(res[qid]) & set(want[qid])) / 100)
     assert min(agree) >= 0.98        # identical top-100 recall up to fp32 near-ties
+
+
+def test_checkpoint_dir_to_search_via_reference_entry_point(tmp_path):
+    """eval/eval_utils.py:179 path: InferenceArguments -> PytorchRPCExactSearchModel(args) from an HF checkpoint directory
+    (safetensors + tokenizer files) -> HybridSearch.search; embeddings checked against the oracle on the same weights."""
+    import shutil
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from lightretriever.inference.arguments import InferenceArguments
+    from lightretriever.inference.exact_search_torchrpc import PytorchRPCExactSearchModel
+    from lightretriever.retriever.hybrid_search import HybridSearch
+    tok = tokenizer()
+    torch.manual_seed(3)
+    hf_cfg = LlamaConfig(vocab_size=len(tok), hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                         num_key_value_heads=1, head_dim=64, rms_norm_eps=1e-5, tie_word_embeddings=True,
+                         rope_parameters={"rope_type": "llama3", "rope_theta": 5e5, "factor": 8.0, "low_freq_factor": 1.0,
+                                          "high_freq_factor": 4.0, "original_max_position_embeddings": 64})
+    m = LlamaForCausalLM(hf_cfg).to(torch.bfloat16)
+    ckpt = str(tmp_path / "tiny-llama-ckpt")
+    m.save_pretrained(ckpt, safe_serialization=True)
+    for f in os.listdir(os.path.join(GOLDEN, "tok")):
+        shutil.copy(os.path.join(GOLDEN, "tok", f), ckpt)
+    args = InferenceArguments(model_name_or_path=ckpt, q_max_len=16, p_max_len=48, batch_size=8, eval_batch_size_embedding_bag=128)
+    model = PytorchRPCExactSearchModel(args)
+    model.query_prompt = "query: "
+    rng = np.random.default_rng(5)
+    corpus = synth_corpus(rng, 30, 3, 40)
+    queries = {"q0": "capital of france", "q1": "dense retrieval"}
+    res = HybridSearch(model, batch_size=8, corpus_chunk_size=16).search(corpus, queries, top_k=5)
+    assert set(res) == {"q0", "q1"} and all(len(v) == 5 for v in res.values())
+    # oracle on the same checkpoint weights + same tokenisation
+    from dataclasses import asdict
+    cfg_o = O.EncoderConfig(**asdict(model.model.encoder.cfg))
+    w = {k: v.float().numpy() for k, v in m.model.state_dict().items()}
+    cids = O.sort_corpus_ids_longest_first(corpus)
+    docs = [corpus[c] for c in cids]
+    emb = model.encode_corpus(docs, batch_size=8)["dense_reps"].cpu().numpy()
+    ref = oracle_doc_embeddings(cfg_o, w, model.tokenizer, docs, 48)
+    assert 1 - min_cos(emb, ref) < 5e-3
+    table = O.construct_embedding_bag(cfg_o, w, model.tokenizer.bos_token_id, model.tokenizer.eos_token_id,
+                                      model.tokenizer.encode("query: ", add_special_tokens=False), vocab_len=len(model.tokenizer))
+    assert min_cos(model.model.emb_bag.cpu().numpy(), table) > 0.995
