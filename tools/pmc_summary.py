@@ -13,7 +13,7 @@ def load(d, counter):
     return rows
 
 def short(name):
-    for k in ("k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_gemm_bf16_nt<0>", "k_attn_varlen_causal", "k_rmsnorm", "k_rope", "k_flat_ip_scores_split", "k_flat_ip_scores", "k_topk_select"):
+    for k in ("k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_gemm_bf16_nt<0>", "k_attn_resident64", "k_attn_varlen_causal", "k_rmsnorm", "k_rope", "k_flat_ip_scores_split", "k_flat_ip_scores", "k_topk_select"):
         if k in name:
             return k
     return None
