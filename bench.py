@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--model", default="llama3.2-1b", choices=["llama3.2-1b", "llama3.1-8b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--ragged", action="store_true",
+                    help="document lengths ~ clip(lognormal(5.3, 0.6), 16, seq_len), sorted longest first (mirrors hybrid_search.py:273-276) "
+                         "instead of the fixed-length headline workload")
     return ap.parse_args()
 
 
@@ -147,6 +150,18 @@ def main():
     ids_all[:, :, 0] = 128000
     ids_all[:, :, -1] = 128001
     cu = (torch.arange(B + 1, device=dev, dtype=torch.int64) * S).to(torch.int32)
+    batches = None
+    if args.ragged:
+        import numpy as np
+        rng = np.random.default_rng(1234 + rank)
+        lens = np.clip(rng.lognormal(5.3, 0.6, size=n_batches * B), 16, S).astype(np.int64)
+        lens = np.sort(lens)[::-1]                                  # longest first, like the reference's corpus sort
+        batches = []
+        for i in range(n_batches):
+            l = lens[i * B:(i + 1) * B]
+            cu_i = torch.tensor(np.concatenate([[0], np.cumsum(l)]), dtype=torch.int32, device=dev)
+            ids_i = torch.randint(1000, 127000, (int(l.sum()),), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+            batches.append((ids_i, cu_i, int(l.max()), int(l.sum())))
 
     # ---- index shard: rows/world rows of L2-normalised N(0,1) fp32 (seed 7); encoded batches overwrite its first rows
     shard_rows = args.index_rows // world
@@ -161,7 +176,10 @@ def main():
 
     def encode_step(i):
         out = index._x[i * B:(i + 1) * B]           # in place into the shard (no host round trip)
-        enc.encode_packed(ids_all[i].reshape(-1), cu, S, out=out)
+        if batches is None:
+            enc.encode_packed(ids_all[i].reshape(-1), cu, S, out=out)
+        else:
+            enc.encode_packed(batches[i][0], batches[i][1], batches[i][2], out=out)
 
     # ---- encode leg
     for i in range(args.warmup):
@@ -251,8 +269,11 @@ def main():
         "value": round(docs_per_s, 2), "unit": "docs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * enc_s / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights, uniform random token ids, N(0,1) normalised index rows)",
-        "config": {"workload": "lightretriever-%s bf16, %d docs/step x seq_len %d per GPU, dense top-%d over %d x %d fp32 index (BASELINE configs[1])"
-                               % (args.model, B, S, args.topk, args.index_rows, D), "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world},
+        "config": {"workload": ("lightretriever-%s bf16, %d docs/step x seq_len %d per GPU, dense top-%d over %d x %d fp32 index (BASELINE configs[1])"
+                                % (args.model, B, S, args.topk, args.index_rows, D)) if batches is None else
+                               ("RAGGED variant (not the headline): lightretriever-%s bf16, %d docs/step, lengths clip(lognormal(5.3,0.6),16,%d) sorted "
+                                "longest first, mean %.0f tokens/doc" % (args.model, B, S, sum(b_[3] for b_ in batches[args.warmup:]) / (args.steps * B))),
+                   "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world},
         "roofline": roofline,
         "search": search,
     }

@@ -39,12 +39,13 @@ def unpack_pairs(P: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     return D, I
 
 
-def exchange_topk(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> tuple[torch.Tensor, torch.Tensor]:
+def exchange_topk(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
+                  force_collective: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
     """all-gather the packed [Q,k] lists of every rank -> ([R,Q,k] scores, [R,Q,k] global rows) on every rank.
     Payload R*Q*k*8 bytes (640 KB at R=8,Q=100,k=100): latency-bound on xGMI, one collective, no pipelining."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     packed = pack_pairs(D, I)
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return D.unsqueeze(0), I.unsqueeze(0)
     Q = packed.shape[0]
     out = torch.empty((world * Q,) + tuple(packed.shape[1:]), dtype=torch.int64, device=packed.device)   # concat form: nccl + gloo

@@ -1,0 +1,40 @@
+"""GPU: the sharded search path over RCCL (backend "nccl") with a 1-rank process group on cuda:0 -- exercises
+init_process_group, all_gather_into_tensor of the packed [Q,k] pairs and the on-device merge exactly as bench.py --gpus N
+does (N>1 itself is covered on CPU by the gloo world-2 test; multi-GPU runs are the driver's)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lrx_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sharded_finish_over_rccl_single_rank():
+    import torch.distributed as dist
+    from lightretriever_amd import FlatIPIndex
+    from lightretriever_amd.sharded import ShardedFlatIPIndex, exchange_topk, local_to_global_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 1000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(0)
+        X = O.l2_normalize(rng.standard_normal((3000, 64)).astype(np.float32))
+        q = O.l2_normalize(rng.standard_normal((9, 64)).astype(np.float32))
+        rows = local_to_global_rows(3000, 64, 0, 1)
+        idx = FlatIPIndex(64)
+        idx.add(X)
+        sh = ShardedFlatIPIndex(idx, row_map=rows.cuda())
+        D, I = idx.search(torch.from_numpy(q).cuda(), 10)
+        Dp, Ip = exchange_topk(D, I, force_collective=True)          # real RCCL all-gather even with one rank
+        assert Dp.shape == (1, 9, 10) and torch.equal(Dp[0], D) and torch.equal(Ip[0], I)
+        Dm, Im = sh.search(torch.from_numpy(q).cuda(), 10)
+        Do, Io = O.flat_ip_topk(q, X, 10)
+        np.testing.assert_array_equal(Im.cpu().numpy(), Io)
+        t = torch.tensor([1.5], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                       # the timing reduction bench.py uses
+        dist.barrier()
+        assert t.item() == 1.5
+    finally:
+        dist.destroy_process_group()
