@@ -4,13 +4,14 @@
 // (16 KiB each, A0/A1/B0/B1); wave (wr, wc) owns rows wr*64..+63 of EACH A half and columns wc*32..+31 of EACH B half, so
 // its 128 x 64 output is four 64 x 32 quadrants (A-half h) x (B-half h'), one quadrant = 16 MFMA 16x16x32 per K-tile.
 //
-// 8-phase schedule (4 phases per K-tile, 2 K-tiles of LDS = 8 half-tile slots, 128 KiB):
-//   phase = { ds_read the register sub-tile this quadrant needs ; issue ONE half-tile of LDS-DMA (2 x global_load_lds
-//             dwordx4 per lane) ; s_waitcnt lgkmcnt(0) ; s_barrier ; 16 MFMA under s_setprio(1) ; s_barrier }
-//   quadrant walk (0,0) (0,1) (1,1) (1,0): reads B0+A0 | B1 | A1 | B0, so a half-tile dies early and its slot is
-//   refilled one phase after its last read:  p1 issues B0(t+1), p2 A0(t+2), p3 B1(t+2), p4 A1(t+2).
-//   One counted wait per K-tile: s_waitcnt vmcnt(6) in p4 (three half-tiles stay in flight across the barriers; never 0
-//   in steady state), followed by the barrier, retires everything K-tile t+1 reads.
+// 4-phase ping-pong schedule (2 phases per K-tile, 2 K-tiles of LDS = 8 half-tile slots, 128 KiB):
+//   phase = { ds_read the register sub-tiles of TWO quadrants ; issue LDS-DMA half-tiles (2 x global_load_lds dwordx4 per lane
+//             each) ; counted s_waitcnt vmcnt(8) ; s_waitcnt lgkmcnt(0) ; s_barrier ; 32 MFMA under s_setprio(1) ; s_barrier }
+//   P1(t): quadrants (A0,B0),(A0,B1): reads A0, B0, B1 (both B sub-tiles then stay in registers);  P2(t): (A1,B1),(A1,B0): reads A1.
+//   A half-tile slot is refilled one phase after its last read (safe under the group stagger): P2(t) issues A0,B0,B1 of K-tile
+//   t+2, P1(t+1) issues A1 of t+2; the 2 + 6 youngest DMA instructions stay in flight across every barrier (never vmcnt(0) in
+//   steady state).  An 8-phase version (16 MFMA per barrier pair, one half-tile per phase, vmcnt(6)) measured 2.5-5 % slower on
+//   all four encoder shapes: the barrier pairs, not the LDS reads, were the overhead.
 //   The two wave groups (waves 0-3 / 4-7, one wave of each per SIMD) run offset by one barrier, so one group's MFMA
 //   section overlaps the other group's LDS-read/issue section on every SIMD.
 // LDS image per half-tile is lane-linear per LDS-DMA instruction; the bank swizzle (16-B chunk ^= (row>>1)&7) is applied
@@ -121,50 +122,63 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
       b[ni][ks] = *(const bf16x8*)(sbuf + (HP) * HALF_BYTES + b_off + ni * 2048 + laneoff[ks]);
 #define G_MM(H, HP)                                                                                   \
   do {                                                                                                \
-    __builtin_amdgcn_s_setprio(1);                                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[H][HP][mi][ni] =                        \
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][ks], a[mi][ks], acc[H][HP][mi][ni], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                    \
   } while (0)
 
   const int nk = K / GBK;
-  // ---- prologue: K-tile 0 complete, first three half-tiles of K-tile 1 in flight (same issue order as steady state)
+  // ---- prologue: K-tile 0 landed, K-tile 1 (issued in the steady-state order A0,B0,B1 then A1) stays in flight
   G_ISSUE(pA0, 0, 0, 0); G_ISSUE(pB1, 3, 0, 0); G_ISSUE(pA1, 1, 0, 0); G_ISSUE(pB0, 2, 0, 0);
   if (nk > 1) {
-    G_ISSUE(pA0, 0, 1, 1); G_ISSUE(pB1, 3, 1, 1); G_ISSUE(pA1, 1, 1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    G_ISSUE(pA0, 0, 1, 1); G_ISSUE(pB0, 2, 1, 1); G_ISSUE(pB1, 3, 1, 1); G_ISSUE(pA1, 1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+
   G_BAR();
   if (wr == 1) G_BAR();  // stagger: group 1 runs one barrier behind group 0
 
+  bf16x8 b2[2][2];
+#define G_LDB2(HP)                                                                                   \
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)  \
+      b2[ni][ks] = *(const bf16x8*)(sbuf + (HP) * HALF_BYTES + b_off + ni * 2048 + laneoff[ks]);
+#define G_MM2(H, HP)                                                                                  \
+  do {                                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[H][HP][mi][ni] =                        \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[ni][ks], a[mi][ks], acc[H][HP][mi][ni], 0, 0, 0); \
+  } while (0)
+  // Lifetimes: A0,B0,B1 of K-tile t are read in P1(t) (B fragments stay in registers), A1 in P2(t).  Refill one phase after
+  // the last read (stagger-safe): P2(t) issues A0,B0,B1 of t+2, P1(t) issues A1 of t+1 (t >= 1; K-tile 1's comes from the
+  // prologue).  Counted waits: vmcnt(8) in both phases = the 2 + 6 youngest DMA instructions stay in flight.
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     const char* sbuf = smem + cur * 65536;
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-    // p1: quadrant (A0, B0)
-    G_LDB(0) G_LDA(0)
-    if (n1) G_ISSUE(pB0, 2, cur ^ 1, t + 1);
-    G_LSYNC(); G_MM(0, 0); G_BAR();
-    // p2: (A0, B1)
-    G_LDB(1)
-    if (n2) G_ISSUE(pA0, 0, cur, t + 2);
-    G_LSYNC(); G_MM(0, 1); G_BAR();
-    // p3: (A1, B1)
+    // P1: quadrants (A0,B0) and (A0,B1)
+    G_LDB(0) G_LDB2(1) G_LDA(0)
+    if (t >= 1 && n1) G_ISSUE(pA1, 1, cur ^ 1, t + 1);          // A1(t+1): its slot (A1 of t-1) was last read in P2(t-1)
+    if (n1 && n2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A1(t) landed
+    G_LSYNC();
+    __builtin_amdgcn_s_setprio(1);
+    G_MM(0, 0); G_MM2(0, 1);
+    __builtin_amdgcn_s_setprio(0);
+    G_BAR();
+    // P2: quadrants (A1,B1) and (A1,B0)
     G_LDA(1)
-    if (n2) G_ISSUE(pB1, 3, cur, t + 2);
-    G_LSYNC(); G_MM(1, 1); G_BAR();
-    // p4: (A1, B0)
-    G_LDB(0)
     if (n2) {
-      G_ISSUE(pA1, 1, cur, t + 2);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      G_ISSUE(pA0, 0, cur, t + 2); G_ISSUE(pB0, 2, cur, t + 2); G_ISSUE(pB1, 3, cur, t + 2);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    G_LSYNC(); G_MM(1, 0); G_BAR();
+    G_LSYNC();
+    __builtin_amdgcn_s_setprio(1);
+    G_MM2(1, 1); G_MM(1, 0);
+    __builtin_amdgcn_s_setprio(0);
+    G_BAR();
   }
   if (wr == 0) G_BAR();
 
