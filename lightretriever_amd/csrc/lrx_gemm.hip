@@ -229,17 +229,33 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   __syncthreads();
   const int ldc = (EPI == EPI_SWIGLU) ? (N >> 1) : N;
   const int c0 = (EPI == EPI_SWIGLU) ? (n0 >> 1) : n0;
-#pragma unroll 4
-  for (int it = 0; it < (256 * CPR) / 512; ++it) {
+  constexpr int NIT = (256 * CPR) / 512;
+  bf16x8 rv[EPI == EPI_RESID ? NIT : 1];
+  if (EPI == EPI_RESID) {
+    // all residual loads of this thread are issued before the first one is consumed (the accumulators are dead, registers
+    // are free): 16 loads in flight per lane instead of a load -> use chain per chunk
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 512 + tid;
+      const int m = min(m0 + q / CPR, M - 1), n = min(c0 + (q % CPR) * 8, N - 8);
+      rv[it] = *(const bf16x8*)(resid + (int64_t)m * N + n);
+    }
+  }
+  int rpos[EPI == EPI_ROPE ? NIT : 1];
+  if (EPI == EPI_ROPE) {   // positions of this thread's rows, loaded up front (the cos/sin lookups depend on them)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) rpos[it] = rope.positions[min(m0 + (it * 512 + tid) / CPR, M - 1)];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
     const int q = it * 512 + tid;
     const int row = q / CPR, ch = q % CPR;
     const int m = m0 + row, n = c0 + ch * 8;
     if (m >= M || n >= ldc) continue;
     bf16x8 v = *(const bf16x8*)(smem + row * (CW * 2) + ((ch ^ (row & 15)) << 4));
     if (EPI == EPI_RESID) {
-      bf16x8 rv = *(const bf16x8*)(resid + (int64_t)m * N + n);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[e]));
+      for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[it][e]));
     }
     if (EPI == EPI_ROPE && n < rope.rope_cols) {
       // rotary embedding on the staged bf16 q|k values (same arithmetic as k_rope): the rotate_half partner sits half a
@@ -250,7 +266,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
       const int j = first ? within : within - half;
       const int pch = ch + (first ? (half >> 3) : -(half >> 3));
       bf16x8 pv = *(const bf16x8*)(smem + row * (CW * 2) + ((pch ^ (row & 15)) << 4));
-      const int pos = rope.positions[m];
+      const int pos = rpos[it];
       const float* cs = rope.cos + (int64_t)pos * half + j;
       const float* sn = rope.sin + (int64_t)pos * half + j;
       const f32x4 c0 = *(const f32x4*)cs, c1 = *(const f32x4*)(cs + 4), s0 = *(const f32x4*)sn, s1 = *(const f32x4*)(sn + 4);
