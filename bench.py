@@ -124,6 +124,15 @@ def pmc_traffic(kernel_key):
         return None
 
 
+def pmc_mfma(kernel_key):
+    """(mfma busy fraction, effective clock GHz) of a kernel from the committed PMC pass (tools/pmc_mfma.sh) or (None, None)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")))[kernel_key]
+        return d["mfma_busy_frac"], d["effective_clock_GHz"]
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,6 +268,7 @@ def main():
         "traffic": pmc_traffic("k_gemm_bf16_nt<2>") if (args.model == "llama3.2-1b" and B == 256 and S == 512) else None,
         "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (gate-up projection, M=%d N=%d K=%d)" % (B * S, 2 * cfg.intermediate_size, D),
         "avg_launch_ms": round(gu["ms"] / max(gu["launches"], 1), 4), "launches": gu["launches"],
+        "pmc_mfma_busy_frac": pmc_mfma("k_gemm_bf16_nt<2>")[0], "pmc_effective_clock_ghz": pmc_mfma("k_gemm_bf16_nt<2>")[1],
         "all_gemms_tflops": round(gemm_all_fl / (gemm_all_ms * 1e-3) / 1e12, 2) if gemm_all_ms > 0 else None,
         "per_class_ms_per_step": {k_: round(v["ms"] / args.steps, 3) for k_, v in prof.items()},
         "model_flops_per_doc": cfg.flops_per_doc(S),
