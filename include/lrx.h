@@ -97,6 +97,17 @@ int lrx_encode_hidden(const lrx_encoder_config* cfg, const lrx_encoder_weights* 
                       const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen,
                       void* hidden_out_bf16, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Shared-prefix encode.  Replaces the inner loop of construct_embedding_bag (finetune/nonctx_emb_utils.py:262-306: for every
+ * vocabulary token run the LM on [bos] + prompt + [tok] + [eos] and keep last_hidden_state[:, -1]): all n_seqs sequences share
+ * the same prefix_ids [prefix_len]; sequence i continues with suffix_ids[i*suffix_len .. +suffix_len).  The prefix is encoded
+ * once (its per-layer K/V are captured), only the suffix tokens run through the layers.  out: fp32 rows [n_seqs, out_dim], the
+ * final-norm hidden state of each sequence's LAST token (normalize = 0 for the EmbeddingBag table).                          */
+size_t lrx_encode_prefixed_workspace_bytes(const lrx_encoder_config* cfg, int32_t prefix_len, int32_t n_seqs, int32_t suffix_len);
+int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* prefix_ids,
+                        int32_t prefix_len, const int32_t* suffix_ids, int32_t n_seqs, int32_t suffix_len, float* out,
+                        int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* Per-kernel-class timing of the LAST lrx_encode_* call when profiling is enabled: HIP events are recorded on
  * `stream` around every launch and the call synchronises the stream at its end (so never leave it on in production).
  * classes: 0 gemm/store (qkv), 1 gemm/residual (o, down), 2 gemm/swiglu (gate-up), 3 attention, 4 rmsnorm, 5 rope,
@@ -145,6 +156,15 @@ int lrx_rope_inplace(void* qkv, const int32_t* positions, const float* cos, cons
 int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens,
                            int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
                            void* out, int32_t last_tile_only, void* stream);
+
+/* Attention of suffix queries over a shared prefix: qkv [n_seqs*suffix_len, (nq+2nkv)*d] (RoPE applied), prefix_kv
+ * [prefix_len, 2*nkv*d] (k block | v block of one layer, RoPE applied); query j of a sequence sees the prefix keys and its own
+ * suffix keys 0..j.  out [n_seqs*suffix_len, nq*d] bf16.                                                                      */
+int lrx_attn_prefix_suffix(const void* qkv, const void* prefix_kv, int32_t n_seqs, int32_t suffix_len, int32_t prefix_len,
+                           int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out, void* stream);
+
+/* cu_seqlens[i] = i*len (i = 0..n_seqs), positions[t] = position_offset + t % len : equal-length batch layout built on device */
+int lrx_uniform_layout(int32_t* cu_seqlens, int32_t* positions, int32_t n_seqs, int32_t len, int32_t position_offset, void* stream);
 
 /* dst[b, :] = src[cu_seqlens[b+1]-1, :]  (bf16 rows of `width` elements): the last-token rows, compacted. */
 int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, int32_t width, void* dst, void* stream);

@@ -38,6 +38,10 @@ SIGNATURES = {
     "lrx_encode_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I32, _I32]),
     "lrx_encode_packed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),
     "lrx_encode_hidden": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    "lrx_encode_prefixed_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I32, _I32, _I32]),
+    "lrx_encode_prefixed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _I32, _P, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),
+    "lrx_attn_prefix_suffix": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "lrx_uniform_layout": (_I32, [_P, _P, _I32, _I32, _I32, _P]),
     "lrx_set_profiling": (None, [_I32]),
     "lrx_get_profile": (_I32, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "lrx_embedding_gather": (_I32, [_P, _P, _I32, _I32, _P, _P]),

@@ -471,6 +471,127 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Suffix-over-shared-prefix attention (EmbeddingBag construction, finetune/nonctx_emb_utils.py:239-313): every sequence
+// is [prefix (identical for all sequences)] + [S2 own tokens].  The prefix K/V of this layer were computed once; here
+// each suffix query attends to the P1 prefix keys plus its own suffix keys up to itself.  Tiny per-row work (P1 + S2 keys),
+// so no MFMA: one wave per (sequence, q head), lane = head-dim element, scores by wave reduction.
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(512)
+k_attn_prefix(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_kv, int n_seqs, int S2, int P1, int nq, int nkv,
+              __bf16* __restrict__ out, float scale) {
+  constexpr int E = D / 64;   // output elements per lane
+  constexpr int JB = 4;       // queries handled per pass (they share the K/V reads)
+  __shared__ float q_lds[8][JB][D];
+  const int seq = blockIdx.x, hk = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int grp = nq / nkv;
+  const int hq = hk * grp + wave;
+  const int64_t RS = (int64_t)(nq + 2 * nkv) * D;          // suffix qkv row stride
+  const int64_t PS = (int64_t)2 * nkv * D;                 // prefix kv row stride (k block | v block)
+  const __bf16* kpre = prefix_kv + (int64_t)hk * D;
+  const __bf16* vpre = prefix_kv + (int64_t)(nkv + hk) * D;
+  const __bf16* ksuf = qkv + (int64_t)seq * S2 * RS + (int64_t)(nq + hk) * D;
+  const __bf16* vsuf = qkv + (int64_t)seq * S2 * RS + (int64_t)(nq + nkv + hk) * D;
+  for (int j0 = 0; j0 < S2; j0 += JB) {
+    const int nj = min(JB, S2 - j0);
+    // scaled queries of this pass -> LDS (every lane reads every element of them below)
+    for (int jj = 0; jj < nj; ++jj)
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        q_lds[wave][jj][lane * E + e] = bf2f(qkv[((int64_t)seq * S2 + j0 + jj) * RS + (int64_t)hq * D + lane * E + e]) * scale;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same-wave LDS writes visible to the reads below
+    float m[JB], l[JB], o[JB][E];
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) { m[jj] = -1e30f; l[jj] = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[jj][e] = 0.f; }
+    const int nkeys = P1 + j0 + nj;                        // keys visible to the last query of this pass
+    for (int c0 = 0; c0 < nkeys; c0 += 64) {
+      // ---- scores: lane = key, full head-dim dot product per lane
+      const int key = c0 + lane;
+      const bool valid = key < nkeys;
+      const __bf16* kp = key < P1 ? kpre + (int64_t)key * PS : ksuf + (int64_t)(key - P1) * RS;
+      float sc[JB];
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) sc[jj] = 0.f;
+      if (valid) {
+#pragma unroll
+        for (int e8 = 0; e8 < D / 8; ++e8) {
+          const bf16x8 kv = *(const bf16x8*)(kp + e8 * 8);
+          float kf[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) kf[i] = bf2f(kv[i]);
+#pragma unroll
+          for (int jj = 0; jj < JB; ++jj) {
+            if (jj < nj) {
+              const f32x4 qa = *(const f32x4*)&q_lds[wave][jj][e8 * 8], qb = *(const f32x4*)&q_lds[wave][jj][e8 * 8 + 4];
+              sc[jj] += qa[0] * kf[0] + qa[1] * kf[1] + qa[2] * kf[2] + qa[3] * kf[3] + qb[0] * kf[4] + qb[1] * kf[5] + qb[2] * kf[6] + qb[3] * kf[7];
+            }
+          }
+        }
+      }
+      float pr[JB], alpha[JB];
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        const bool vis = valid && key <= P1 + j0 + jj;     // causal: query j0+jj sees prefix + own suffix keys <= itself
+        const float s_ = vis ? sc[jj] : -1e30f;
+        const float mn = fmaxf(m[jj], wave_max(s_));
+        alpha[jj] = __expf(m[jj] - mn);
+        const float pw = vis ? __expf(s_ - mn) : 0.f;
+        l[jj] = l[jj] * alpha[jj] + wave_sum(pw);
+        pr[jj] = bf2f(f2bf(pw));                           // P is rounded to bf16 before P.V like the tiled kernels
+        m[jj] = mn;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[jj][e] *= alpha[jj];
+      }
+      // ---- P.V: lane = head-dim element, uniform loop over the keys of this chunk
+      const int kend = min(64, nkeys - c0);
+      for (int kk = 0; kk < kend; ++kk) {
+        const int key_u = c0 + kk;
+        const __bf16* vp = key_u < P1 ? vpre + (int64_t)key_u * PS : vsuf + (int64_t)(key_u - P1) * RS;
+        float vf[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) vf[e] = bf2f(vp[lane * E + e]);
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+          const float pk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[jj]), kk));
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[jj][e] += pk * vf[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+      if (jj < nj) {
+        const float inv = 1.0f / l[jj];
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          out[((int64_t)seq * S2 + j0 + jj) * ((int64_t)nq * D) + (int64_t)hq * D + lane * E + e] = f2bf(o[jj][e] * inv);
+      }
+    }
+  }
+}
+
+extern "C" int lrx_attn_prefix_suffix(const void* qkv, const void* prefix_kv, int32_t n_seqs, int32_t suffix_len, int32_t prefix_len,
+                                      int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out, void* stream) {
+  LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "attn_prefix: head_dim=%d unsupported", head_dim);
+  LRX_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0 && num_q_heads / num_kv_heads <= 8, "attn_prefix: bad head counts");
+  LRX_CHECK_ARG(suffix_len > 0 && prefix_len >= 0, "attn_prefix: bad lengths");
+  if (n_seqs == 0) return LRX_OK;
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  dim3 grid(n_seqs, num_kv_heads), block(64 * (num_q_heads / num_kv_heads));
+  if (head_dim == 64)
+    hipLaunchKernelGGL(k_attn_prefix<64>, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (const __bf16*)prefix_kv, n_seqs, suffix_len,
+                       prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, scale);
+  else
+    hipLaunchKernelGGL(k_attn_prefix<128>, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (const __bf16*)prefix_kv, n_seqs, suffix_len,
+                       prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, scale);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
 template <int D, int GRP>
 static int launch_attn(const void* qkv, const int32_t* cu, int n_seqs, int max_seqlen, int nq, int nkv, void* out, int last_tile_only,
                        hipStream_t s) {

@@ -210,3 +210,85 @@ extern "C" int lrx_encode_hidden(const lrx_encoder_config* cfg, const lrx_encode
   }
   return prof_end(s);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Shared-prefix encode (EmbeddingBag construction): n_seqs sequences = prefix (same for all) + suffix_len own tokens.
+// The prefix runs ONCE through the encoder while its per-layer K/V (post-RoPE) are captured; then only the
+// n_seqs * suffix_len suffix tokens are pushed through the layers, attending to the captured prefix K/V plus their own
+// suffix keys.  Same result as encoding every [prefix + suffix] sequence in full, (P + S2) / S2 times fewer FLOPs.
+// ---------------------------------------------------------------------------------------------------------------
+struct PrefWs { EncWs e; char* kvcap; int32_t* cu; size_t total; };
+static PrefWs carve_prefixed(const lrx_encoder_config* c, int64_t P1, int64_t n_seqs, int64_t S2, char* base) {
+  const int64_t T = (n_seqs * S2 > P1 ? n_seqs * S2 : P1);
+  PrefWs w;
+  w.e = carve(c, T, n_seqs > 0 ? n_seqs : 1, base);
+  size_t off = w.e.total;
+  w.kvcap = base + off; off += align_up((size_t)c->num_layers * (size_t)(P1 > 0 ? P1 : 1) * 2 * c->num_kv_heads * c->head_dim * 2, 1024);
+  w.cu = (int32_t*)(base + off); off += align_up((size_t)(n_seqs + 2) * 4, 1024);
+  w.total = off;
+  return w;
+}
+extern "C" size_t lrx_encode_prefixed_workspace_bytes(const lrx_encoder_config* cfg, int32_t prefix_len, int32_t n_seqs, int32_t suffix_len) {
+  if (!cfg) return 0;
+  return carve_prefixed(cfg, prefix_len, n_seqs, suffix_len, nullptr).total;
+}
+
+extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* prefix_ids, int32_t prefix_len,
+                                   const int32_t* suffix_ids, int32_t n_seqs, int32_t suffix_len, float* out, int64_t out_row_stride,
+                                   int32_t out_dim, int32_t normalize, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  LRX_CHECK_ARG(w && w->embed && w->final_norm && w->rope_cos && w->rope_sin && w->layers, "encode_prefixed: null weights");
+  LRX_CHECK_ARG(suffix_ids && n_seqs > 0 && suffix_len > 0 && prefix_len >= 0 && (prefix_len == 0 || prefix_ids), "encode_prefixed: bad batch");
+  LRX_CHECK_ARG(prefix_len + suffix_len <= cfg->max_positions, "encode_prefixed: prefix+suffix=%d exceeds RoPE table (%d)", prefix_len + suffix_len,
+                cfg->max_positions);
+  LRX_CHECK_ARG(out && out_dim > 0 && out_dim <= cfg->hidden_size && out_row_stride >= out_dim, "encode_prefixed: bad output spec");
+  LRX_CHECK_ARG(workspace != nullptr, "encode_prefixed: null workspace");
+  const size_t need = lrx_encode_prefixed_workspace_bytes(cfg, prefix_len, n_seqs, suffix_len);
+  if (workspace_bytes < need) { lrx_set_error("encode_prefixed: workspace %zu B < required %zu B", workspace_bytes, need); return LRX_ERR_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const lrx_encoder_config* c = cfg;
+  PrefWs pw = carve_prefixed(c, prefix_len, n_seqs, suffix_len, (char*)workspace);
+  EncWs& ws = pw.e;
+  const int H = c->hidden_size, d = c->head_dim, nq = c->num_q_heads, nkv = c->num_kv_heads, I = c->intermediate_size;
+  const int QKV = (nq + 2 * nkv) * d, QD = nq * d, KVW = 2 * nkv * d;
+  prof_begin();
+  // ---- pass 1: the prefix alone (one sequence), capturing K|V of every layer
+  if (prefix_len > 0) {
+    const int P1 = prefix_len;
+    if ((rc = lrx_uniform_layout(pw.cu, ws.pos, 1, P1, 0, s))) return rc;
+    if ((rc = lrx_embedding_gather(w->embed, prefix_ids, P1, H, ws.x, s))) return rc;
+    for (int l = 0; l < c->num_layers; ++l) {
+      const lrx_layer_weights& L = w->layers[l];
+      if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, P1, H, c->rms_eps, s))) return rc;
+      if ((rc = lrx_gemm_qkv_rope(ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, P1, H, nq, nkv, d, s))) return rc;
+      LRX_HIP(hipMemcpy2DAsync(pw.kvcap + (size_t)l * P1 * KVW * 2, (size_t)KVW * 2, ws.qkv + (size_t)QD * 2, (size_t)QKV * 2, (size_t)KVW * 2, P1,
+                               hipMemcpyDeviceToDevice, s));
+      if (l == c->num_layers - 1) break;   // nothing after the last layer's K/V is needed from the prefix
+      if ((rc = lrx_attn_varlen_causal(ws.qkv, pw.cu, 1, P1, P1, nq, nkv, d, ws.h, 0, s))) return rc;
+      if ((rc = lrx_gemm_bf16_nt(ws.h, L.wo, ws.x, nullptr, ws.x, P1, H, QD, 1, s))) return rc;
+      if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, P1, H, c->rms_eps, s))) return rc;
+      if ((rc = lrx_gemm_bf16_nt(ws.h, L.wgu, ws.act, nullptr, nullptr, P1, 2 * I, H, 2, s))) return rc;
+      if ((rc = lrx_gemm_bf16_nt(ws.act, L.wdown, ws.x, nullptr, ws.x, P1, H, I, 1, s))) return rc;
+    }
+  }
+  // ---- pass 2: the suffix tokens of all sequences
+  const int T = n_seqs * suffix_len;
+  if ((rc = lrx_uniform_layout(pw.cu, ws.pos, n_seqs, suffix_len, prefix_len, s))) return rc;
+  { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, suffix_ids, T, H, ws.x, s))) return rc; }
+  for (int l = 0; l < c->num_layers; ++l) {
+    const lrx_layer_weights& L = w->layers[l];
+    { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
+    { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);
+      if ((rc = lrx_gemm_qkv_rope(ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, s))) return rc; }
+    { ProfScope p(s, 3, 0);
+      if ((rc = lrx_attn_prefix_suffix(ws.qkv, pw.kvcap + (size_t)l * prefix_len * KVW * 2, n_seqs, suffix_len, prefix_len, nq, nkv, d, ws.h, s))) return rc; }
+    { ProfScope p(s, 1, 2.0 * T * (double)H * QD); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wo, ws.x, nullptr, ws.x, T, H, QD, 1, s))) return rc; }
+    { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, T, H, c->rms_eps, s))) return rc; }
+    { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, s))) return rc; }
+    { ProfScope p(s, 1, 2.0 * T * (double)H * I); if ((rc = lrx_gemm_bf16_nt(ws.act, L.wdown, ws.x, nullptr, ws.x, T, H, I, 1, s))) return rc; }
+  }
+  { ProfScope p(s, 6, 0);
+    if ((rc = lrx_pool_norm(ws.x, w->final_norm, pw.cu, n_seqs, H, c->rms_eps, out, out_row_stride, out_dim, normalize, s))) return rc; }
+  return prof_end(s);
+}

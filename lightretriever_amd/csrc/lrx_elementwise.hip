@@ -95,6 +95,21 @@ extern "C" int lrx_build_positions(const int32_t* cu_seqlens, int32_t n_seqs, in
   return LRX_OK;
 }
 
+// cu[i] = i * len (i = 0..n) and positions[t] = offset + t % len : equal-length batches built on the device (no H2D copy)
+__global__ void k_uniform_layout(int32_t* __restrict__ cu, int32_t* __restrict__ pos, int n_seqs, int len, int offset) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t <= n_seqs) cu[t] = t * len;
+  if (t < n_seqs * len) pos[t] = offset + t % len;
+}
+
+extern "C" int lrx_uniform_layout(int32_t* cu_seqlens, int32_t* positions, int32_t n_seqs, int32_t len, int32_t position_offset, void* stream) {
+  LRX_CHECK_ARG(n_seqs >= 0 && len > 0, "uniform_layout: bad sizes");
+  int n = n_seqs * len + 1;
+  hipLaunchKernelGGL(k_uniform_layout, dim3(lrx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, cu_seqlens, positions, n_seqs, len, position_offset);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // RoPE in place on the q | k column blocks of qkv [T, (nq + 2nkv) * d].  One thread = 8 elements of the first half of a
 // head and the 8 paired elements of the second half.  cos/sin are the bf16-rounded table values (HF casts them to the

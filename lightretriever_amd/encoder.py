@@ -248,6 +248,31 @@ class LrxEncoder:
                                               int(max_seqlen), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
         return out
 
+    def encode_prefixed(self, prefix_ids: torch.Tensor, suffix_ids: torch.Tensor, out: Optional[torch.Tensor] = None,
+                        normalize: bool = False) -> torch.Tensor:
+        """Sequences `prefix_ids + suffix_ids[i]` for every row i of suffix_ids [n, S2]; the shared prefix is encoded once
+        (lrx_encode_prefixed).  Returns fp32 [n, H]: final-norm hidden state of each sequence's last token."""
+        if prefix_ids.dtype != torch.int32 or suffix_ids.dtype != torch.int32:
+            raise TypeError("prefix_ids and suffix_ids must be int32 device tensors")
+        if not (prefix_ids.is_cuda and suffix_ids.is_cuda and prefix_ids.is_contiguous() and suffix_ids.is_contiguous()):
+            raise ValueError("prefix_ids and suffix_ids must be contiguous CUDA tensors")
+        if suffix_ids.dim() != 2:
+            raise ValueError("suffix_ids must be [n_seqs, suffix_len]")
+        n, S2 = suffix_ids.shape
+        P1, H = prefix_ids.numel(), self.cfg.hidden_size
+        if out is None:
+            out = torch.empty(n, H, dtype=torch.float32, device=self.device)
+        if out.dtype != torch.float32 or out.stride(-1) != 1 or out.shape[0] < n or out.shape[1] != H:
+            raise ValueError("out must be fp32 [>=n, H] with unit inner stride")
+        need = self.lib.lrx_encode_prefixed_workspace_bytes(C.byref(self._ccfg), P1, n, S2)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.lrx_encode_prefixed(C.byref(self._ccfg), C.byref(self._cw), _lib.ptr(prefix_ids) if P1 else None, P1,
+                                                _lib.ptr(suffix_ids), n, S2, _lib.ptr(out), out.stride(0), H, int(normalize),
+                                                _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))
+        return out[:n]
+
     # profiling hooks used by bench.py ------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         self.lib.lrx_set_profiling(int(on))

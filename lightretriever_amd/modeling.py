@@ -140,32 +140,80 @@ class LrxHybridModel:
         return {"emb_reps": reps}
 
     # -- EmbeddingBag construction (nonctx_emb_utils.py:239-313) --------------------------------------------------------
-    def construct_embedding_bag(self, tokenizer, prompt: Optional[str] = None, batch_size: int = 5000, vocab_len: Optional[int] = None):
+    def construct_embedding_bag(self, tokenizer, prompt: Optional[str] = None, batch_size: int = 5000, vocab_len: Optional[int] = None,
+                                shared_prefix: bool = True, vocab_range: Optional[tuple[int, int]] = None):
         """For every tok in [0, len(tokenizer)): encode [bos] + prompt + [tok] + [eos] and keep the final hidden state of
-        the last position, un-normalised, fp32.  Runs on this GPU through lrx_encode_packed (normalize=0) writing straight
-        into the table."""
+        the last position, un-normalised, fp32 (nonctx_emb_utils.py:239-313).
+
+        shared_prefix=True (default): [bos] + prompt is the same for every token, so it is encoded once and only the
+        [tok, eos] suffixes go through the layers (lrx_encode_prefixed) - (P+3)/2 times fewer FLOPs, same table.
+        shared_prefix=False: every sequence in full through lrx_encode_packed (the reference's literal loop).
+        vocab_range=(lo, hi): build only those rows (one rank's slice, see construct_embedding_bag_distributed)."""
         V = vocab_len or len(tokenizer)
+        lo, hi = vocab_range if vocab_range is not None else (0, V)
+        assert 0 <= lo <= hi <= V
         bos, eos = tokenizer.bos_token_id, tokenizer.eos_token_id
         add_bos = bos is not None and bos in tokenizer.encode("", add_special_tokens=True)
         prefix = ([bos] if add_bos else []) + (tokenizer.encode(prompt, add_special_tokens=False) if prompt else [])
-        L = len(prefix) + 2
         H = self.encoder.cfg.hidden_size
-        table = torch.empty(V, H, dtype=torch.float32, device=self.device)
-        base = torch.empty(batch_size, L, dtype=torch.int32, device=self.device)
-        if prefix:
-            base[:, :len(prefix)] = torch.tensor(prefix, dtype=torch.int32, device=self.device)
-        base[:, -1] = eos
-        for s in range(0, V, batch_size):
-            e = min(s + batch_size, V)
-            n = e - s
-            base[:n, -2] = torch.arange(s, e, dtype=torch.int32, device=self.device)
-            cu = (torch.arange(n + 1, device=self.device, dtype=torch.int64) * L).to(torch.int32)
-            self.encoder.encode_packed(base[:n].reshape(-1), cu, L, out=table[s:e], normalize=False)
-        self.emb_bag, self.emb_bag_prompt = table, prompt
+        table = torch.empty(hi - lo, H, dtype=torch.float32, device=self.device)
+        if shared_prefix:
+            pre = torch.tensor(prefix, dtype=torch.int32, device=self.device)
+            # 2 suffix tokens per row: six times the row count of the full path fits the same activation workspace
+            step = batch_size * max(1, (len(prefix) + 2) // 2)
+            for s in range(lo, hi, step):
+                e = min(s + step, hi)
+                suf = torch.empty(e - s, 2, dtype=torch.int32, device=self.device)
+                suf[:, 0] = torch.arange(s, e, dtype=torch.int32, device=self.device)
+                suf[:, 1] = eos
+                self.encoder.encode_prefixed(pre, suf, out=table[s - lo:e - lo], normalize=False)
+        else:
+            L = len(prefix) + 2
+            base = torch.empty(batch_size, L, dtype=torch.int32, device=self.device)
+            if prefix:
+                base[:, :len(prefix)] = torch.tensor(prefix, dtype=torch.int32, device=self.device)
+            base[:, -1] = eos
+            for s in range(lo, hi, batch_size):
+                e = min(s + batch_size, hi)
+                n = e - s
+                base[:n, -2] = torch.arange(s, e, dtype=torch.int32, device=self.device)
+                cu = (torch.arange(n + 1, device=self.device, dtype=torch.int64) * L).to(torch.int32)
+                self.encoder.encode_packed(base[:n].reshape(-1), cu, L, out=table[s - lo:e - lo], normalize=False)
+        if vocab_range is None:
+            self.emb_bag, self.emb_bag_prompt = table, prompt
         return table
 
-    def load_embedding_bag(self, weight: torch.Tensor, prompt: Optional[str] = None):
-        """`torch.save(emb_bag.weight, '*.emb_bag.pt')` artefacts of scripts/cache_emb_bag.ipynb."""
+    def construct_embedding_bag_distributed(self, tokenizer, prompt: Optional[str] = None, batch_size: int = 5000,
+                                            vocab_len: Optional[int] = None, group=None, shared_prefix: bool = True):
+        """One vocabulary slice per rank, then an all-gather of the fp32 rows so every rank holds the whole table (the
+        reference builds the full table on every rank; the rows are independent so the build shards with one collective)."""
+        import torch.distributed as dist
+        V = vocab_len or len(tokenizer)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self.construct_embedding_bag(tokenizer, prompt, batch_size, vocab_len, shared_prefix)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        per = (V + world - 1) // world
+        lo, hi = min(rank * per, V), min((rank + 1) * per, V)
+        H = self.encoder.cfg.hidden_size
+        mine = torch.zeros(per, H, dtype=torch.float32, device=self.device)
+        if hi > lo:
+            mine[:hi - lo] = self.construct_embedding_bag(tokenizer, prompt, batch_size, V, shared_prefix, vocab_range=(lo, hi))
+        full = torch.empty(world * per, H, dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(full, mine, group=group)
+        self.emb_bag, self.emb_bag_prompt = full[:V].contiguous(), prompt
+        return self.emb_bag
+
+    def save_embedding_bag(self, path: str):
+        """`torch.save(emb_bag.weight, path)`: the `*.emb_bag.pt` artefact of scripts/cache_emb_bag.ipynb."""
+        assert self.emb_bag is not None, "construct_embedding_bag first"
+        torch.save(self.emb_bag.detach().cpu(), path)
+
+    def load_embedding_bag(self, weight, prompt: Optional[str] = None):
+        """`torch.save(emb_bag.weight, '*.emb_bag.pt')` artefacts of scripts/cache_emb_bag.ipynb (tensor or path)."""
+        if isinstance(weight, (str, bytes)) or hasattr(weight, "__fspath__"):
+            weight = torch.load(weight, map_location="cpu", weights_only=True)
+        if weight.dim() != 2 or weight.shape[1] != self.encoder.cfg.hidden_size:
+            raise ValueError(f"EmbeddingBag table {tuple(weight.shape)} does not match hidden size {self.encoder.cfg.hidden_size}")
         self.emb_bag = weight.to(self.device, dtype=torch.float32).contiguous()
         self.emb_bag_prompt = prompt
 

@@ -64,6 +64,23 @@ def attn_varlen_causal(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: 
     return out
 
 
+def attn_prefix_suffix(qkv: torch.Tensor, prefix_kv: torch.Tensor, n_seqs: int, suffix_len: int, nq: int, nkv: int, d: int) -> torch.Tensor:
+    """qkv [n_seqs*suffix_len, (nq+2nkv)d] bf16, prefix_kv [P1, 2*nkv*d] bf16 (k | v) -> [n_seqs*suffix_len, nq*d] bf16."""
+    if qkv.shape != (n_seqs * suffix_len, (nq + 2 * nkv) * d) or prefix_kv.shape[1:] != (2 * nkv * d,):
+        raise ValueError("attn_prefix_suffix: operand shapes do not match the head layout")
+    out = torch.empty(n_seqs * suffix_len, nq * d, dtype=torch.bfloat16, device=qkv.device)
+    _lib.check(_lib.lib().lrx_attn_prefix_suffix(_lib.ptr(qkv), _lib.ptr(prefix_kv) if prefix_kv.shape[0] else None, n_seqs, suffix_len,
+                                                 prefix_kv.shape[0], nq, nkv, d, _lib.ptr(out), _s()))
+    return out
+
+
+def uniform_layout(n_seqs: int, length: int, position_offset: int, device) -> tuple[torch.Tensor, torch.Tensor]:
+    cu = torch.empty(n_seqs + 1, dtype=torch.int32, device=device)
+    pos = torch.empty(n_seqs * length, dtype=torch.int32, device=device)
+    _lib.check(_lib.lib().lrx_uniform_layout(_lib.ptr(cu), _lib.ptr(pos), n_seqs, length, position_offset, _s()))
+    return cu, pos
+
+
 def gather_last_rows(src: torch.Tensor, cu_seqlens: torch.Tensor) -> torch.Tensor:
     B = cu_seqlens.numel() - 1
     dst = torch.empty(B, src.shape[1], dtype=torch.bfloat16, device=src.device)

@@ -67,6 +67,46 @@ def test_embedding_bag_construction_matches_reference_table():
     assert min_cos(q["emb_reps"].cpu().numpy(), g["emb_reps"]) > 0.999
 
 
+@pytest.mark.parametrize("prompt", [PROMPT, None])
+def test_embedding_bag_shared_prefix_equals_full_sequences(prompt, tmp_path):
+    """N1: encoding the shared [bos]+prompt prefix once gives the table the reference's full-sequence loop gives."""
+    cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    tok, enc, hm, model = build_stack(cfg_o, w)
+    full = hm.construct_embedding_bag(tok, prompt=prompt, batch_size=97, shared_prefix=False).cpu().numpy()
+    fast = hm.construct_embedding_bag(tok, prompt=prompt, batch_size=31, shared_prefix=True).cpu().numpy()
+    assert fast.shape == full.shape
+    assert min_cos(fast, full) > 0.9995                       # both bf16 pipelines of the same math
+    g = np.load(os.path.join(GOLDEN, "embbag.npz"))
+    prefix_ids = [int(t) for t in g["prompt_ids"]] if prompt else []
+    want = O.construct_embedding_bag(cfg_o, w, int(g["bos"]), int(g["eos"]), prefix_ids, vocab_len=full.shape[0])
+    assert min_cos(fast, want) > 0.998                        # vs the fp32 oracle: same band as the full path
+    assert abs(np.linalg.norm(fast) / np.linalg.norm(want) - 1) < 1e-2
+    # slice build == rows of the whole build; persistence round trip (the *.emb_bag.pt artefact)
+    part = hm.construct_embedding_bag(tok, prompt=prompt, batch_size=31, vocab_range=(40, 175)).cpu().numpy()
+    np.testing.assert_array_equal(part, fast[40:175])
+    path = str(tmp_path / "t.emb_bag.pt")
+    hm.save_embedding_bag(path)
+    saved = torch.load(path, weights_only=True)
+    assert saved.dtype == torch.float32 and saved.device.type == "cpu"
+    hm.emb_bag = None
+    hm.load_embedding_bag(path, prompt)
+    np.testing.assert_array_equal(hm.emb_bag.cpu().numpy(), fast)
+    with pytest.raises(ValueError):
+        hm.load_embedding_bag(torch.zeros(10, 7))
+
+
+def test_encode_prefixed_argument_errors():
+    from lightretriever_amd._lib import LrxError
+    cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    tok, enc, hm, model = build_stack(cfg_o, w)
+    pre = torch.zeros(enc.cfg.max_positions, dtype=torch.int32, device="cuda")
+    suf = torch.zeros(4, 2, dtype=torch.int32, device="cuda")
+    with pytest.raises(LrxError):
+        enc.encode_prefixed(pre, suf)                          # prefix + suffix beyond the RoPE table
+    with pytest.raises(TypeError):
+        enc.encode_prefixed(pre[:3].long(), suf)
+
+
 @pytest.mark.parametrize("shrink", [None, 64])
 def test_search_equals_oracle_pipeline_on_same_embeddings(shrink):
     cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")

@@ -263,3 +263,29 @@ def test_gemm_qkv_rope_fused_equals_gemm_then_rope(d, nq, nkv, bias):
     diff = (got.float() - want.float()).abs()
     assert (got == want).float().mean() > 0.999          # identical arithmetic up to fma contraction in the last bit
     assert (diff <= 2.0 ** -7 * want.float().abs() + 1e-6).all()
+
+
+@pytest.mark.parametrize("d,nq,nkv,P1,S2,n", [(64, 4, 2, 9, 2, 37), (64, 32, 8, 22, 2, 5), (128, 8, 1, 3, 3, 11), (64, 2, 2, 0, 2, 4), (128, 4, 4, 40, 1, 3)])
+def test_attention_prefix_suffix_equals_full_causal(d, nq, nkv, P1, S2, n):
+    """Suffix queries over a shared prefix == the suffix rows of full causal attention on [prefix + suffix] per sequence."""
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(d + nq + P1 + n)
+    W = (nq + 2 * nkv) * d
+    pre = rnd(rng, P1, W)
+    suf = rnd(rng, n * S2, W)
+    suf[:, :nq * d] *= 2.0
+    prefix_kv = np.ascontiguousarray(pre[:, nq * d:])
+    got = f32(ops.attn_prefix_suffix(bf16_t(suf), bf16_t(prefix_kv).reshape(P1, 2 * nkv * d), n, S2, nq, nkv, d))
+    L = P1 + S2
+    full = np.concatenate([np.concatenate([pre, suf[i * S2:(i + 1) * S2]]) for i in range(n)])
+    cu = (np.arange(n + 1) * L).astype(np.int32)
+    want = attn_oracle(full, cu, nq, nkv, d).reshape(n, L, nq * d)[:, P1:].reshape(n * S2, nq * d)
+    np.testing.assert_allclose(got, want, atol=2e-2, rtol=2e-2)
+    assert abs(np.linalg.norm(got) / np.linalg.norm(want) - 1) < 3e-3
+
+
+def test_uniform_layout():
+    from lightretriever_amd import ops
+    cu, pos = ops.uniform_layout(7, 3, 11, dev())
+    assert cu.cpu().tolist() == [0, 3, 6, 9, 12, 15, 18, 21]
+    assert pos.cpu().tolist() == [11, 12, 13] * 7

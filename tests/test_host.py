@@ -147,3 +147,56 @@ def test_sharded_search_over_gloo_world2():
     for r in range(2):
         np.testing.assert_array_equal(ret[r][1], Iw)
         np.testing.assert_array_equal(ret[r][0], Dw)
+
+
+class _StubEncoder:
+    """Deterministic stand-in for LrxEncoder.encode_prefixed on CPU: row = f(prefix, suffix ids); tests the slicing only."""
+    class cfg:
+        hidden_size = 8
+    device = torch.device("cpu")
+
+    def encode_prefixed(self, prefix_ids, suffix_ids, out=None, normalize=False):
+        base = float(prefix_ids.sum())
+        rows = suffix_ids[:, :1].float() * torch.arange(1, 9).float()[None, :] + base + suffix_ids[:, 1:2].float()
+        out[:rows.shape[0]] = rows
+        return out[:rows.shape[0]]
+
+
+class _StubTok:
+    bos_token_id, eos_token_id = 1, 2
+
+    def __len__(self):
+        return 203                                         # not divisible by the world size
+
+    def encode(self, text, add_special_tokens=True):
+        return ([1] if add_special_tokens else []) + [10 + len(w) for w in text.split()]
+
+
+def _embbag_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lightretriever_amd.modeling import LrxHybridModel
+    hm = LrxHybridModel(_StubEncoder(), normalize=True)
+    table = hm.construct_embedding_bag_distributed(_StubTok(), prompt="query: find it", batch_size=16)
+    ret[rank] = table.numpy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_embedding_bag_vocab_slices_over_gloo_world2():
+    """N1 multi-rank build: each rank builds one vocabulary slice, the all-gather gives every rank the whole table."""
+    import torch.multiprocessing as mp
+    from lightretriever_amd.modeling import LrxHybridModel
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_embbag_worker, args=(r, 2, port, ret)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    want = LrxHybridModel(_StubEncoder()).construct_embedding_bag(_StubTok(), prompt="query: find it", batch_size=16).numpy()
+    assert want.shape == (203, 8)
+    for r in range(2):
+        np.testing.assert_array_equal(ret[r], want)
