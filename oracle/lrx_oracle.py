@@ -21,6 +21,11 @@ Parity pin status
   sites (retriever/faiss_index.py:27-58, retriever/faiss_search.py:143-173); it is pinned
   only against ``torch.matmul`` + ``torch.topk`` goldens.
 
+* Sparse document vectors (row N2: prompt/first/last mask, LM-head max aggregation, relu/log1p, top-k / top-p, quantised
+  JSON): PINNED by ``tests/golden/sparse.npz`` / ``sparse_json.json`` (``tests/golden/gen_sparse_goldens.py``, the real
+  reference functions).  The JSON converter is pinned against the reference's own torch variant
+  (``convert_sparse_reps_to_json_pt``); its Rust crate ``sparse_emb_util`` is not in the reference tree -> **unpinned**.
+
 Every function cites the reference ``file:line`` (relative to /root/reference) or the
 third-party source it restates.
 """
@@ -482,3 +487,136 @@ def search_chunks(query_emb: np.ndarray, query_ids: list[str], corpus_emb: np.nd
 
 def lora_merge(W: np.ndarray, A: np.ndarray, B: np.ndarray, alpha: float, r: int) -> np.ndarray:
     return (W.astype(np.float32) + np.float32(alpha / r) * (B.astype(np.float32) @ A.astype(np.float32))).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Sparse document vectors
+# --------------------------------------------------------------------------------------
+BF16_MIN = np.float32(-3.3895313892515355e38)      # torch.finfo(torch.bfloat16).min
+F32_MIN = np.float32(np.finfo(np.float32).min)
+
+
+def sparse_attention_mask(input_ids: np.ndarray, attention_mask: np.ndarray, sep_token_id: Optional[int], remove_prompt: bool = False) -> np.ndarray:
+    """finetune/sparse_pooling.py:23-59 (get_sparse_attention_mask + get_prompt_mask) on the padded [B,S] layout: valid tokens
+    minus column 0, minus each row's last valid token, minus (remove_prompt) everything up to and including the first
+    sep token -- with the reference's quirks: rows without a sep lose only column 0; no masking at all when no row holds a
+    sep, or when every row's first sep sits in the last COLUMN."""
+    ids = np.asarray(input_ids)
+    m = np.asarray(attention_mask).astype(bool).copy()
+    B, S = ids.shape
+    if remove_prompt and sep_token_id is not None and (ids == sep_token_id).any():
+        pos = np.argmax((ids == sep_token_id).astype(np.int64), axis=-1)
+        if not np.all(pos == S - 1):
+            m[np.arange(S)[None, :] <= pos[:, None]] = False
+    last = np.asarray(attention_mask).sum(1) - 1          # -1 (empty row) indexes the last column like torch does
+    m[:, 0] = False
+    m[np.arange(B), last] = False
+    return m
+
+
+def max_aggregate(hidden: np.ndarray, W: np.ndarray, bias: Optional[np.ndarray], mask: np.ndarray, bf16: bool = False) -> np.ndarray:
+    """utils/max_linear_map.py:8-88 (MaxLinearMapperFunction.forward): out[b, v] = max over valid t of hidden[b, t] . W[v] (+ bias),
+    starting from finfo(dtype).min (rows with no valid token keep it).  hidden [B,S,H], W [V,H] (= lm_head.weight), mask [B,S].
+    bf16=True restates the autocast run: every logit is rounded to bf16 before the max (dtype of `input_sliced @ weight`)."""
+    B, S, H = hidden.shape
+    lo = BF16_MIN if bf16 else F32_MIN
+    out = np.full((B, W.shape[0]), lo, np.float32)
+    Wt = np.ascontiguousarray(W.T, dtype=np.float32)
+    for t in range(S):
+        logits = hidden[:, t].astype(np.float32) @ Wt
+        if bias is not None:
+            logits = logits + bias
+        if bf16:
+            logits = round_bf16(logits)
+        logits = np.where(mask[:, t:t + 1], logits, lo)
+        out = np.where(logits > out, logits, out)
+    return out
+
+
+def max_aggregate_packed(hidden: np.ndarray, cu_seqlens: np.ndarray, tok_mask: np.ndarray, W: np.ndarray, bias: Optional[np.ndarray] = None,
+                         bf16: bool = True) -> np.ndarray:
+    """Same on the packed layout: hidden [T,H], tok_mask [T] (the sparse attention mask selected at the valid tokens)."""
+    B = len(cu_seqlens) - 1
+    lo = BF16_MIN if bf16 else F32_MIN
+    out = np.full((B, W.shape[0]), lo, np.float32)
+    logits = hidden.astype(np.float32) @ np.ascontiguousarray(W.T, dtype=np.float32)
+    if bias is not None:
+        logits = logits + bias
+    if bf16:
+        logits = round_bf16(logits)
+    for b in range(B):
+        s, e = int(cu_seqlens[b]), int(cu_seqlens[b + 1])
+        sel = logits[s:e][np.asarray(tok_mask[s:e]).astype(bool)]
+        if sel.shape[0]:
+            out[b] = np.maximum(out[b], sel.max(0))
+    return out
+
+
+def top_k_sampling(scores: np.ndarray, top_k: int, filter_value: float = 0.0, min_tokens_to_keep: int = 1) -> np.ndarray:
+    """finetune/sparse_pooling.py:92-109: everything below the k-th largest value of the row -> filter_value (ties with the
+    k-th value all survive)."""
+    if top_k <= 0:
+        return scores
+    k = min(max(top_k, min_tokens_to_keep), scores.shape[-1])
+    kth = np.sort(scores, axis=-1)[:, ::-1][:, k - 1:k]
+    return np.where(scores < kth, np.float32(filter_value), scores)
+
+
+def top_p_sampling(scores: np.ndarray, top_p: float, filter_value: float = 0.0, min_tokens_to_keep: int = 1) -> np.ndarray:
+    """finetune/sparse_pooling.py:64-90: ascending sort, softmax, cumulative sum; entries with cumulative probability
+    <= 1 - top_p are dropped, the last min_tokens_to_keep of the sorted order always stay."""
+    if top_p <= 0 or top_p >= 1:
+        return scores
+    order = np.argsort(scores, axis=-1, kind="stable")
+    srt = np.take_along_axis(scores, order, -1).astype(np.float32)
+    e = np.exp(srt - srt.max(-1, keepdims=True))
+    cum = np.cumsum((e / e.sum(-1, keepdims=True)).astype(np.float32), axis=-1, dtype=np.float32)
+    remove_sorted = cum <= np.float32(1 - top_p)
+    remove_sorted[:, -min_tokens_to_keep:] = False
+    remove = np.zeros_like(remove_sorted)
+    np.put_along_axis(remove, order, remove_sorted, -1)
+    return np.where(remove, np.float32(filter_value), scores)
+
+
+def sparsify(logits: np.ndarray, relu: bool = True, log1p: bool = True, top_p: float = 1.0, top_k: int = 0, min_tokens_to_keep: int = 8,
+             bf16: bool = False) -> np.ndarray:
+    """finetune/modeling_hybrid.py:176-203 (get_sparse_emb, the branches the asymmetric config uses): relu -> log1p -> top-p ->
+    top-k.  bf16=True: the tensor is bf16 in the autocast run, so log1p's result is rounded to bf16."""
+    x = logits.astype(np.float32)
+    if relu:
+        x = np.maximum(x, np.float32(0))
+    if log1p:
+        x = np.log1p(x).astype(np.float32)
+        if bf16:
+            x = round_bf16(x)
+    x = top_p_sampling(x, top_p, min_tokens_to_keep=min_tokens_to_keep)
+    x = top_k_sampling(x, top_k, min_tokens_to_keep=min_tokens_to_keep)
+    return x
+
+
+def quantize_sparse(reps: np.ndarray, quantization_factor: int = 100) -> np.ndarray:
+    """finetune/sparse_converter_mixin.py:129-133: clamp(min=0) -> round-half-even(reps * q) -> int32."""
+    return np.rint(np.maximum(reps.astype(np.float32), np.float32(0)) * np.float32(quantization_factor)).astype(np.int32)
+
+
+def sparse_reps_to_json(reps: np.ndarray, quantization_factor: int = 100, vocab: Optional[dict] = None) -> list[dict]:
+    """finetune/sparse_converter_mixin.py:105-160 (convert_sparse_reps_to_json_pt): {str(token id) | token: integer weight} for
+    the non-zero quantised entries in ascending token id order; an empty vector becomes {"-1": 1} ({"[PAD]": 1} with a vocab)."""
+    q = quantize_sparse(np.atleast_2d(reps), quantization_factor)
+    out = []
+    for row in q:
+        nz = np.nonzero(row)[0]
+        d = {(vocab[int(i)] if vocab is not None else str(int(i))): int(row[i]) for i in nz}
+        if not d:
+            d = {"[PAD]": 1} if vocab is not None else {"-1": 1}
+        out.append(d)
+    return out
+
+
+def encode_passage_sparse(cfg: EncoderConfig, w, ids, cu_seqlens, tok_mask, lm_head: Optional[np.ndarray] = None, bf16: bool = True, **sparsify_kw):
+    """HybridModel.encode_passage's sparse branch (modeling_hybrid.py:280-323) on packed input: LM forward -> final-norm hidden
+    states -> max aggregation with the (tied unless given) LM head -> sparsify."""
+    hidden = encoder_forward_packed(cfg, w, ids, cu_seqlens, bf16=bf16)
+    W = lm_head if lm_head is not None else w["embed_tokens.weight"]
+    agg = max_aggregate_packed(hidden, cu_seqlens, tok_mask, W, None, bf16=bf16)
+    return sparsify(agg, bf16=bf16, **sparsify_kw)

@@ -157,3 +157,65 @@ def test_lora_merge_formula():
     rng = np.random.default_rng(2)
     W, A, B = rng.standard_normal((6, 5)), rng.standard_normal((2, 5)), rng.standard_normal((6, 2))
     np.testing.assert_allclose(O.lora_merge(W, A, B, 8, 2), W + 4.0 * (B @ A), rtol=1e-5)
+
+
+# ---- sparse document vectors (N2) -------------------------------------------------------------------------------------
+def _sparse_golden():
+    return np.load(os.path.join(GOLDEN, "sparse.npz"))
+
+
+def test_sparse_attention_mask_matches_reference():
+    g = _sparse_golden()
+    sep = int(g["sep_token_id"])
+    np.testing.assert_array_equal(O.sparse_attention_mask(g["input_ids"], g["attention_mask"], sep, False), g["mask_plain"])
+    np.testing.assert_array_equal(O.sparse_attention_mask(g["input_ids"], g["attention_mask"], sep, True), g["mask_noprompt"])
+    np.testing.assert_array_equal(O.sparse_attention_mask(g["quirk_ids"], g["attention_mask"][[0, 6]], sep, True), g["quirk_mask"])
+    # no sep anywhere == plain
+    np.testing.assert_array_equal(O.sparse_attention_mask(g["input_ids"], g["attention_mask"], 10 ** 6, True), g["mask_plain"])
+
+
+def test_max_aggregation_and_sparsify_match_reference():
+    g = _sparse_golden()
+    cfg, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    ids, _, _, cu, _ = O.pack_padded(g["input_ids"], g["attention_mask"])
+    hidden = O.encoder_forward_packed(cfg, w, ids, cu, bf16=False)
+    am = g["attention_mask"].astype(bool)
+    for key, mask in (("agg_plain", g["mask_plain"]), ("agg_noprompt", g["mask_noprompt"])):
+        agg = O.max_aggregate_packed(hidden, cu, mask[am], w["embed_tokens.weight"], None, bf16=False)
+        want = g[key]
+        empty = want == O.F32_MIN
+        np.testing.assert_array_equal(agg == O.F32_MIN, empty)                 # rows without a valid token keep finfo.min
+        np.testing.assert_allclose(agg[~empty], want[~empty], atol=2e-5, rtol=1e-5)
+    # padded-layout restatement agrees with the packed one
+    B, S = g["input_ids"].shape
+    hp = np.zeros((B, S, hidden.shape[1]), np.float32)
+    hp[am] = hidden
+    np.testing.assert_allclose(O.max_aggregate(hp, w["embed_tokens.weight"], None, g["mask_noprompt"]), agg, atol=2e-6, rtol=1e-6)
+    reps = O.sparsify(agg, relu=True, log1p=True)
+    np.testing.assert_allclose(reps, g["sparse_reps"], atol=2e-5)
+    np.testing.assert_array_equal(reps > 0, g["sparse_reps"] > 0)
+    raw = O.max_aggregate_packed(hidden, cu, g["mask_plain"][am], w["embed_tokens.weight"], None, bf16=False)
+    np.testing.assert_allclose(O.sparsify(raw, relu=False, log1p=False), g["sparse_reps_raw"], atol=2e-5, rtol=1e-5)
+    for key, kw in (("sparse_reps_top16", dict(top_k=16)), ("sparse_reps_top3_min8", dict(top_k=3)), ("sparse_reps_topp", dict(top_p=0.3))):
+        # thresholding on the reference's own pre-threshold values: exact same support
+        got = O.sparsify(g["agg_noprompt"], relu=True, log1p=True, min_tokens_to_keep=8, **kw)
+        np.testing.assert_allclose(got, g[key], atol=1e-6)
+        np.testing.assert_array_equal(got > 0, g[key] > 0)
+    assert (g["sparse_reps_top3_min8"] > 0).sum(1).max() == 8                 # min_tokens_to_keep raises k
+    np.testing.assert_array_equal(O.top_k_sampling(g["tie_in"], 2), g["tie_top2"])   # ties at the threshold all survive
+    np.testing.assert_array_equal(O.top_p_sampling(g["tie_in"], 0.5), g["tie_topp"])
+    # autocast golden is the bf16 restatement within bf16 noise
+    hid16 = O.encoder_forward_packed(cfg, w, ids, cu, bf16=True)
+    reps16 = O.sparsify(O.max_aggregate_packed(hid16, cu, g["mask_noprompt"][am], w["embed_tokens.weight"], None, bf16=True), bf16=True)
+    assert np.abs(reps16 - g["sparse_reps_autocast"]).max() < 0.06
+
+
+def test_sparse_json_matches_reference_converter():
+    g = _sparse_golden()
+    with open(os.path.join(GOLDEN, "sparse_json.json")) as f:
+        want = json.load(f)
+    assert O.sparse_reps_to_json(g["sparse_reps"], 100) == want["quant100"]
+    assert O.sparse_reps_to_json(g["sparse_reps_top16"], 100) == want["quant100_top16"]
+    halves = np.array([[0.5 / 7, 1.5 / 7, 2.5 / 7, -3.0, 0.0, 0.07]], np.float32)
+    assert O.sparse_reps_to_json(halves, 7) == want["quant7_halves"]
+    assert want["quant100"][2] == {"-1": 1}                                   # empty vector placeholder
