@@ -108,12 +108,27 @@ int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_encoder_weights
                         int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* Dense + sparse document vectors in one pass.  Replaces HybridModel.encode_passage with encode_sparse
+ * (finetune/modeling_hybrid.py:248-323): LM forward -> dense_reps (as lrx_encode_packed; dense_out may be NULL) and
+ * sparse_reps = sparsify(max over the tokens tok_mask selects of hidden_t . lm_head^T)  (aggregate, sparse_pooling.py:244-278;
+ * MaxLinearMapperFunction, utils/max_linear_map.py:8-88; get_sparse_emb, modeling_hybrid.py:176-203).
+ * lm_head: bf16 [vocab, hidden] (NULL = tied to the embedding matrix), lm_head_bias: bf16 [vocab] or NULL.
+ * tok_mask: uint8 [total_tokens] = get_sparse_attention_mask at the valid tokens (NULL = drop each sequence's first and last
+ * token).  sparse_out: fp32 [n_seqs, sparse_row_stride >= vocab]; a sequence without any selected token gets finfo(bf16).min
+ * before relu, like the reference.  round_bf16 = 1: log1p's result is rounded to bf16 (the tensor is bf16 in a bf16 run).   */
+int lrx_encode_packed_sparse(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const void* lm_head,
+                             const void* lm_head_bias, const int32_t* ids, const int32_t* cu_seqlens,
+                             const uint8_t* tok_mask, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen,
+                             float* dense_out, int64_t dense_row_stride, int32_t dense_dim, int32_t normalize,
+                             float* sparse_out, int64_t sparse_row_stride, int32_t relu, int32_t log1p, int32_t round_bf16,
+                             int32_t top_k, int32_t min_tokens_to_keep, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Per-kernel-class timing of the LAST lrx_encode_* call when profiling is enabled: HIP events are recorded on
  * `stream` around every launch and the call synchronises the stream at its end (so never leave it on in production).
  * classes: 0 gemm/store (qkv), 1 gemm/residual (o, down), 2 gemm/swiglu (gate-up), 3 attention, 4 rmsnorm, 5 rope,
- * 6 other (embedding gather, positions, pool).  Arrays of LRX_PROF_CLASSES entries; flops are algorithmic
+ * 6 other (embedding gather, positions, pool), 7 gemm_maxagg (LM-head GEMM with the max-aggregation epilogue).  Arrays of LRX_PROF_CLASSES entries; flops are algorithmic
  * (2*M*N*K for GEMMs, 2*2*d*sum_s(s*(s+1)/2)*nq for causal attention), 0 for the memory-bound classes.            */
-#define LRX_PROF_CLASSES 7
+#define LRX_PROF_CLASSES 8
 void lrx_set_profiling(int32_t enabled);
 int lrx_get_profile(float* ms, double* flops, int32_t* launches);
 
@@ -165,6 +180,25 @@ int lrx_attn_prefix_suffix(const void* qkv, const void* prefix_kv, int32_t n_seq
 
 /* cu_seqlens[i] = i*len (i = 0..n_seqs), positions[t] = position_offset + t % len : equal-length batch layout built on device */
 int lrx_uniform_layout(int32_t* cu_seqlens, int32_t* positions, int32_t n_seqs, int32_t len, int32_t position_offset, void* stream);
+
+/* out[b, v] = max(finfo(bf16).min, max over tokens t of sequence b with tok_mask[t] of bf16(hidden[t,:] . lm_head[v,:] + bias[v])).
+ * hidden bf16 [total_tokens, hidden_size] (hidden_size % 64 == 0), lm_head bf16 [vocab_size, hidden_size], out fp32
+ * [n_seqs, out_row_stride]; row_seg_workspace: int32 [total_tokens] scratch.  The [tokens, vocab] logits are never written:
+ * the maximum is taken per 256x256 tile in the GEMM epilogue and merged with integer atomics.                               */
+int lrx_sparse_max_aggregate(const void* hidden, const void* lm_head, const void* bias, const int32_t* cu_seqlens,
+                             const uint8_t* tok_mask, int32_t n_seqs, int32_t total_tokens, int32_t hidden_size,
+                             int32_t vocab_size, float* out, int64_t out_row_stride, int32_t* row_seg_workspace, void* stream);
+
+/* In place on fp32 [n_rows, row_stride]: relu -> log1p (-> bf16 rounding) -> top-k threshold (entries below the k-th largest
+ * value of the row become 0, ties survive; k = max(top_k, min_tokens_to_keep); top_k = 0 disables)  (sparse_pooling.py:92-109). */
+int lrx_sparsify(float* reps, int32_t n_rows, int32_t vocab_size, int64_t row_stride, int32_t relu, int32_t log1p,
+                 int32_t round_bf16, int32_t top_k, int32_t min_tokens_to_keep, void* stream);
+
+/* Quantise + compact (sparse_converter_mixin.py:129-137): per row the token ids whose round-half-even(max(x,0) * q) != 0, in
+ * ascending id order, with that integer weight: ids_out / weights_out int32 [n_rows, capacity] (first `capacity` kept),
+ * counts_out int32 [n_rows] = true number of non-zeros.                                                                    */
+int lrx_sparse_compact(const float* reps, int32_t n_rows, int32_t vocab_size, int64_t row_stride, int32_t quantization_factor,
+                       int32_t capacity, int32_t* ids_out, int32_t* weights_out, int32_t* counts_out, void* stream);
 
 /* dst[b, :] = src[cu_seqlens[b+1]-1, :]  (bf16 rows of `width` elements): the last-token rows, compacted. */
 int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, int32_t width, void* dst, void* stream);

@@ -5,8 +5,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRX_LIB_DEV_VARIANT") or os.path.join(HERE, "liblrx.so")   # env override: tools/ diagnostics only
-LRX_PROF_CLASSES = 7
-PROF_CLASS_NAMES = ["gemm_store", "gemm_resid", "gemm_swiglu", "attention", "rmsnorm", "rope", "other"]
+LRX_PROF_CLASSES = 8
+PROF_CLASS_NAMES = ["gemm_store", "gemm_resid", "gemm_swiglu", "attention", "rmsnorm", "rope", "other", "gemm_maxagg"]
 
 
 class LrxError(RuntimeError):
@@ -42,6 +42,11 @@ SIGNATURES = {
     "lrx_encode_prefixed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _I32, _P, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),
     "lrx_attn_prefix_suffix": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "lrx_uniform_layout": (_I32, [_P, _P, _I32, _I32, _I32, _P]),
+    "lrx_encode_packed_sparse": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32,
+                                        _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _SZ, _P]),
+    "lrx_sparse_max_aggregate": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P, _P]),
+    "lrx_sparsify": (_I32, [_P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
+    "lrx_sparse_compact": (_I32, [_P, _I32, _I32, _I64, _I32, _I32, _P, _P, _P, _P]),
     "lrx_set_profiling": (None, [_I32]),
     "lrx_get_profile": (_I32, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "lrx_embedding_gather": (_I32, [_P, _P, _I32, _I32, _P, _P]),

@@ -211,6 +211,36 @@ extern "C" int lrx_encode_hidden(const lrx_encoder_config* cfg, const lrx_encode
   return prof_end(s);
 }
 
+// Dense + sparse document vectors in one pass (HybridModel.encode_passage with encode_sparse, modeling_hybrid.py:248-323):
+// all layers on all tokens, dense = pooled last token (as lrx_encode_packed), sparse = LM-head max aggregation over the
+// final-norm hidden states of the tokens tok_mask selects, then relu / log1p / top-k.
+extern "C" int lrx_encode_packed_sparse(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const void* lm_head, const void* lm_head_bias,
+                                        const int32_t* ids, const int32_t* cu_seqlens, const uint8_t* tok_mask, int32_t n_seqs, int32_t total_tokens,
+                                        int32_t max_seqlen, float* dense_out, int64_t dense_row_stride, int32_t dense_dim, int32_t normalize,
+                                        float* sparse_out, int64_t sparse_row_stride, int32_t relu, int32_t log1p, int32_t round_bf16, int32_t top_k,
+                                        int32_t min_tokens_to_keep, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_call(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, workspace, workspace_bytes);
+  if (rc) return rc;
+  LRX_CHECK_ARG(sparse_out && sparse_row_stride >= cfg->vocab_size, "encode_sparse: bad sparse output spec");
+  LRX_CHECK_ARG(!dense_out || (dense_dim > 0 && dense_dim <= cfg->hidden_size && dense_row_stride >= dense_dim), "encode_sparse: bad dense output spec");
+  hipStream_t s = (hipStream_t)stream;
+  const int H = cfg->hidden_size, V = cfg->vocab_size;
+  EncWs ws = carve(cfg, total_tokens, n_seqs, (char*)workspace);
+  prof_begin();
+  if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, false, s))) return rc;
+  if (dense_out) {
+    ProfScope p(s, 6, 0);
+    if ((rc = lrx_pool_norm(ws.x, w->final_norm, cu_seqlens, n_seqs, H, cfg->rms_eps, dense_out, dense_row_stride, dense_dim, normalize, s))) return rc;
+  }
+  { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, w->final_norm, ws.h, total_tokens, H, cfg->rms_eps, s))) return rc; }
+  { ProfScope p(s, 7, 2.0 * total_tokens * (double)V * H);   // positions are dead after the layers: ws.pos holds the row -> sequence map
+    if ((rc = lrx_sparse_max_aggregate(ws.h, lm_head ? lm_head : w->embed, lm_head_bias, cu_seqlens, tok_mask, n_seqs, total_tokens, H, V, sparse_out,
+                                       sparse_row_stride, ws.pos, s))) return rc; }
+  { ProfScope p(s, 6, 0);
+    if ((rc = lrx_sparsify(sparse_out, n_seqs, V, sparse_row_stride, relu, log1p, round_bf16, top_k, min_tokens_to_keep, s))) return rc; }
+  return prof_end(s);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Shared-prefix encode (EmbeddingBag construction): n_seqs sequences = prefix (same for all) + suffix_len own tokens.
 // The prefix runs ONCE through the encoder while its per-layer K/V (post-RoPE) are captured; then only the

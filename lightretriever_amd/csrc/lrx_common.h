@@ -54,3 +54,7 @@ void lrx_set_error(const char* fmt, ...);
 #define LRX_LAUNCH_CHECK() LRX_HIP(hipGetLastError())
 
 static inline int64_t lrx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// lrx_gemm.hip: the GEMM kernel with the segmented-maximum epilogue (used by lrx_sparse_max_aggregate)
+int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias, const int32_t* row_seg, float* out, int64_t ldo, int M, int N,
+                                  int K, hipStream_t stream);

@@ -29,7 +29,7 @@
 #define GBK 64
 #define HALF_BYTES 16384
 
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE = 3 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE = 3, EPI_MAXAGG = 4 };
 
 struct RopeArgs {
   const int32_t* positions;  // [M]
@@ -38,6 +38,19 @@ struct RopeArgs {
   int rope_cols;             // columns [0, rope_cols) are q|k heads to rotate; the rest (v) is stored as is
   int head_dim;
 };
+
+struct MaxAggArgs {
+  const int32_t* row_seg;    // [M] output row (sequence index) each A row is reduced into, -1 = row takes no part
+  float* out;                // [n_seqs, ldo] running maxima (pre-filled by the caller)
+  int64_t ldo;
+};
+
+// max(*p, v) for floats with integer atomics: non-negative floats order like ints, negative ones inversely like uints
+__device__ __forceinline__ void atomic_fmax_bits(float* p, float v) {
+  const unsigned b = __float_as_uint(v);
+  if (!(b & 0x80000000u)) __hip_atomic_fetch_max((int*)p, (int)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_fetch_min((unsigned*)p, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -57,7 +70,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
-               const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope) {
+               const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope, MaxAggArgs mx) {
   __shared__ __attribute__((aligned(1024))) char smem[8 * HALF_BYTES];  // [buf 0/1][A0 | A1 | B0 | B1]
 
   // ---- workgroup -> tile
@@ -218,6 +231,10 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += bf2f(bv[r]);
             }
+            if (EPI == EPI_MAXAGG && bias != nullptr) {    // N is arbitrary here: element-wise clamped reads
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(bias[min(n0 + col + r, N - 1)]);
+            }
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
@@ -227,6 +244,58 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
       }
     }
   __syncthreads();
+  if (EPI == EPI_MAXAGG) {
+    // Segmented column maximum of the staged bf16 logits tile (utils/max_linear_map.py:8-88 without the [B,S,V] tensor):
+    // wave w owns columns [32w, 32w+32); a lane walks rows (lane>>3) + 8*step holding 4 columns.  Rows map to output rows
+    // through row_seg (non-decreasing where >= 0); a lane flushes its 4 maxima with integer atomics whenever its segment
+    // changes, and at the end the 8 row-lanes of a column group are combined first when the whole wave ended in one segment
+    // (the common case: a 256-row tile inside one document -> 256 atomics per tile).
+    const int colq = wave * 32 + (lane & 7) * 4;
+    const int choff = colq >> 3, hb = (colq & 4) << 1;
+    const float NEG = -__builtin_inff();
+    float m4[4] = {NEG, NEG, NEG, NEG};
+    int cur = -1;
+    auto flush = [&](int seg) {
+      if (seg < 0) return;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n0 + colq + r < N && m4[r] != NEG) atomic_fmax_bits(mx.out + (int64_t)seg * mx.ldo + n0 + colq + r, m4[r]);
+    };
+    for (int step = 0; step < 32; ++step) {
+      const int row = step * 8 + (lane >> 3);
+      const int m = m0 + row;
+      const int seg = m < M ? mx.row_seg[m] : -1;
+      if (seg >= 0) {
+        if (seg != cur) {
+          flush(cur);
+          cur = seg;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m4[r] = NEG;
+        }
+        const bf16x4 v = *(const bf16x4*)(smem + row * 512 + (((choff ^ (row & 15)) << 4) | hb));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m4[r] = fmaxf(m4[r], bf2f(v[r]));
+      }
+    }
+    int cmax = cur;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+    const bool uniform = __all(cur == cmax || cur == -1);
+    if (uniform) {
+      if (cur == -1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m4[r] = NEG;
+      }
+#pragma unroll
+      for (int o = 8; o <= 32; o <<= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m4[r] = fmaxf(m4[r], __shfl_xor(m4[r], o));
+      if ((lane >> 3) == 0) flush(cmax);
+    } else {
+      flush(cur);
+    }
+    return;
+  }
   const int ldc = (EPI == EPI_SWIGLU) ? (N >> 1) : N;
   const int c0 = (EPI == EPI_SWIGLU) ? (n0 >> 1) : n0;
   constexpr int NIT = (256 * CPR) / 512;
@@ -296,10 +365,11 @@ extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const voi
   const __bf16 *a = (const __bf16*)A, *b = (const __bf16*)B, *bi = (const __bf16*)bias, *re = (const __bf16*)resid;
   __bf16* c = (__bf16*)C;
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  MaxAggArgs nomx = {nullptr, nullptr, 0};
   switch (epilogue) {
-    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none); break;
-    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none); break;
-    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none); break;
+    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx); break;
+    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx); break;
+    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx); break;
   }
   LRX_LAUNCH_CHECK();
   return LRX_OK;
@@ -316,7 +386,22 @@ extern "C" int lrx_gemm_qkv_rope(const void* A, const void* Wqkv, void* C, const
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
   RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)Wqkv,
-                     (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope);
+                     (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0});
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// out[row_seg[m], n] = max(out[row_seg[m], n], bf16(A[m,:] . B[n,:] + bias[n])) over the rows with row_seg >= 0 (lrx_sparse.hip)
+int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias, const int32_t* row_seg, float* out, int64_t ldo, int M, int N,
+                                  int K, hipStream_t stream) {
+  LRX_CHECK_ARG(M >= 0 && N > 0 && K > 0 && K % GBK == 0, "max_aggregate: bad shape M=%d N=%d K=%d (K must be a multiple of %d)", M, N, K, GBK);
+  LRX_CHECK_ARG(row_seg && out && ldo >= N, "max_aggregate: bad output spec");
+  if (M == 0) return LRX_OK;
+  int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  MaxAggArgs mx = {row_seg, out, ldo};
+  hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
+                     (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

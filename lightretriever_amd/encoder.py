@@ -138,6 +138,8 @@ class LrxEncoder:
                 wgu=dev(interleave_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"))),
                 wdown=dev(g(p + "mlp.down_proj.weight")), ln1=dev(g(p + "input_layernorm.weight")),
                 ln2=dev(g(p + "post_attention_layernorm.weight"))))
+        # LM head for the sparse branch: tied to the embedding unless the checkpoint carries its own (`lm_head.weight`)
+        self.lm_head = dev(g("lm_head.weight")) if "lm_head.weight" in state_dict else None
         self._build_c_structs()
         self._ws = None
 
@@ -247,6 +249,27 @@ class LrxEncoder:
         _lib.check(self.lib.lrx_encode_hidden(C.byref(self._ccfg), C.byref(self._cw), _lib.ptr(ids), _lib.ptr(cu_seqlens), B, T,
                                               int(max_seqlen), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
         return out
+
+    def encode_packed_sparse(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, tok_mask: Optional[torch.Tensor] = None,
+                             dense_dim: Optional[int] = None, normalize: bool = True, want_dense: bool = True, relu: bool = True,
+                             log1p: bool = True, round_bf16: bool = True, top_k: int = 0, min_tokens_to_keep: int = 8):
+        """Dense + sparse document vectors in one pass (lrx_encode_packed_sparse).  tok_mask: uint8 [T] on the GPU (None = drop
+        each sequence's first and last token).  -> (dense fp32 [B,D] or None, sparse fp32 [B,V])."""
+        self._check_batch(ids, cu_seqlens)
+        T, B = ids.numel(), cu_seqlens.numel() - 1
+        if tok_mask is not None and not (tok_mask.is_cuda and tok_mask.dtype == torch.uint8 and tok_mask.numel() == T and tok_mask.is_contiguous()):
+            raise ValueError("tok_mask must be a contiguous uint8 CUDA tensor with one entry per token")
+        D = dense_dim or self.cfg.hidden_size
+        dense = torch.empty(B, D, dtype=torch.float32, device=self.device) if want_dense else None
+        sparse = torch.empty(B, self.cfg.vocab_size, dtype=torch.float32, device=self.device)
+        ws = self._workspace(T, B)
+        lm_head = getattr(self, "lm_head", None)
+        _lib.check(self.lib.lrx_encode_packed_sparse(
+            C.byref(self._ccfg), C.byref(self._cw), _lib.ptr(lm_head) if lm_head is not None else None, None, _lib.ptr(ids), _lib.ptr(cu_seqlens),
+            _lib.ptr(tok_mask) if tok_mask is not None else None, B, T, int(max_seqlen), _lib.ptr(dense) if want_dense else None,
+            dense.stride(0) if want_dense else 0, D, int(normalize), _lib.ptr(sparse), sparse.stride(0), int(relu), int(log1p), int(round_bf16),
+            int(top_k), int(min_tokens_to_keep), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+        return dense, sparse
 
     def encode_prefixed(self, prefix_ids: torch.Tensor, suffix_ids: torch.Tensor, out: Optional[torch.Tensor] = None,
                         normalize: bool = False) -> torch.Tensor:

@@ -48,6 +48,9 @@ class EncodeCollator:
     p_max_len: int = 512
     noncontextual_query_embedding: bool = True
     return_padded: bool = False
+    sparse_mask: bool = False                 # also emit `sparse_mask` uint8 [T] (get_sparse_attention_mask) for the sparse branch
+    sep_token_id: Optional[int] = None
+    add_sep_token: bool = False
 
     def __call__(self, texts: list[dict]) -> dict:
         if self.encode_is_query and self.noncontextual_query_embedding:
@@ -66,6 +69,9 @@ class EncodeCollator:
         out = {"input_ids": torch.from_numpy(np.concatenate([np.asarray(e, dtype=np.int32) for e in enc])),
                "cu_seqlens": torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)),
                "max_seqlen": int(lens.max())}
+        if self.sparse_mask:
+            out["sparse_mask"] = torch.from_numpy(sparse_token_mask(out["input_ids"].numpy(), out["cu_seqlens"].numpy(), self.sep_token_id,
+                                                                    self.add_sep_token))
         if self.return_padded:
             pad = self.tokenizer.pad_token_id
             ids = np.full((len(enc), int(lens.max())), pad, dtype=np.int64)
@@ -74,6 +80,33 @@ class EncodeCollator:
                 ids[i, :len(e)], mask[i, :len(e)] = e, 1
             out["padded_input_ids"], out["padded_attention_mask"] = torch.from_numpy(ids), torch.from_numpy(mask)
         return out
+
+
+def sparse_token_mask(input_ids: np.ndarray, cu_seqlens: np.ndarray, sep_token_id: Optional[int] = None, remove_prompt: bool = False) -> np.ndarray:
+    """get_sparse_attention_mask (finetune/sparse_pooling.py:23-59) on the packed layout -> uint8 [T]: every token except each
+    sequence's first and last one and, with remove_prompt, everything up to and including the sequence's first sep token.
+    Reference quirks kept: a sequence without a sep loses nothing more; no prompt masking when no sequence of the batch
+    holds a sep, or when every sequence's first sep is in the last column of the padded batch (= all sequences full length
+    with their only sep at the end)."""
+    ids = np.asarray(input_ids)
+    cu = np.asarray(cu_seqlens, dtype=np.int64)
+    lens = np.diff(cu)
+    T = int(cu[-1])
+    seg = np.repeat(np.arange(len(lens)), lens)
+    pos = np.arange(T) - cu[seg]
+    mask = np.ones(T, dtype=bool)
+    if remove_prompt and sep_token_id is not None and T > 0:
+        is_sep = ids[:T] == sep_token_id
+        if is_sep.any():
+            BIG = np.iinfo(np.int64).max
+            first = np.full(len(lens), BIG, dtype=np.int64)
+            np.minimum.at(first, seg, np.where(is_sep, pos, BIG))
+            first[first == BIG] = 0                               # argmax of an all-False row
+            if not np.all(first == int(lens.max()) - 1):
+                mask &= pos > first[seg]
+    mask &= pos != 0
+    mask &= pos != lens[seg] - 1
+    return mask.astype(np.uint8)
 
 
 def pack_padded_batch(input_ids: torch.Tensor, attention_mask: torch.Tensor):
@@ -87,6 +120,17 @@ def pack_padded_batch(input_ids: torch.Tensor, attention_mask: torch.Tensor):
     return ids, cu, int(lens.max().item())
 
 
+def _top_p_filter(scores: torch.Tensor, top_p: float, min_tokens_to_keep: int) -> torch.Tensor:
+    """top_p_sampling (finetune/sparse_pooling.py:64-90) with device tensor ops; an option that is off (top_p = 1) in the
+    published configuration, so it is not a kernel."""
+    srt, idx = torch.sort(scores, descending=False, stable=True)
+    cum = srt.softmax(dim=-1).cumsum(dim=-1)
+    rem = cum <= (1 - top_p)
+    rem[..., -min_tokens_to_keep:] = False
+    remove = torch.zeros_like(rem).scatter(1, idx, rem)
+    return scores.masked_fill(remove, 0.0)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # per-batch operators (B3)
 # ------------------------------------------------------------------------------------------------------------------
@@ -95,11 +139,25 @@ class LrxHybridModel:
     (`hybrid_use_emb_vector` + `noncontextual_query_embedding`; score_function cos_sim -> normalize=True)."""
 
     def __init__(self, encoder: LrxEncoder, normalize: bool = True, dense_shrink_dim: Optional[int] = None,
-                 pad_token_id: Optional[int] = None):
+                 pad_token_id: Optional[int] = None, encode_sparse: bool = False, sep_token_id: Optional[int] = None,
+                 add_sep_token: bool = False, sparse_use_relu: bool = True, sparse_use_log_saturation: bool = True,
+                 sparse_top_k_psg: int = 0, sparse_top_p_psg: float = 1.0, sparse_min_tokens_to_keep: int = 8,
+                 sparse_round_bf16: bool = True):
+        """The sparse_* / add_sep_token / sep_token_id fields carry the reference's ModelArguments of the same names
+        (finetune/arguments.py:220-290); encode_sparse = hybrid_use_sparse_vector or hybrid_use_token_id_vector."""
         self.encoder = encoder
         self.normalize = normalize
         self.dense_shrink_dim = dense_shrink_dim
         self.pad_token_id = pad_token_id
+        self.encode_sparse = encode_sparse
+        self.sep_token_id = sep_token_id
+        self.add_sep_token = add_sep_token
+        self.sparse_use_relu = sparse_use_relu
+        self.sparse_use_log_saturation = sparse_use_log_saturation
+        self.sparse_top_k_psg = sparse_top_k_psg
+        self.sparse_top_p_psg = sparse_top_p_psg
+        self.sparse_min_tokens_to_keep = sparse_min_tokens_to_keep
+        self.sparse_round_bf16 = sparse_round_bf16
         self.emb_bag: Optional[torch.Tensor] = None      # fp32 [V, H] on the GPU (weight of the reference's nn.EmbeddingBag)
         self.emb_bag_prompt: Optional[str] = None
 
@@ -107,12 +165,16 @@ class LrxHybridModel:
     def device(self):
         return self.encoder.device
 
-    def encode_passage(self, psg: Optional[dict], normalize: Optional[bool] = None, out: Optional[torch.Tensor] = None, **kwargs):
+    def encode_passage(self, psg: Optional[dict], normalize: Optional[bool] = None, out: Optional[torch.Tensor] = None,
+                       encode_sparse: Optional[bool] = None, **kwargs):
         """psg: packed {"input_ids" [T] i32, "cu_seqlens" [B+1] i32, "max_seqlen"} or the reference's padded
-        {"input_ids" [B,S], "attention_mask" [B,S]}.  -> {"dense_reps": fp32 [B, D] (GPU; `out` lets the caller pass index rows)}."""
+        {"input_ids" [B,S], "attention_mask" [B,S]}.  -> {"dense_reps": fp32 [B, D] (GPU; `out` lets the caller pass index rows)}
+        and, with encode_sparse, {"sparse_reps": fp32 [B, V]} (modeling_hybrid.py:280-323)."""
         if psg is None:
             return None
         normalize = self.normalize if normalize is None else normalize
+        if encode_sparse or (encode_sparse is None and self.encode_sparse):
+            return self._encode_passage_sparse(psg, bool(normalize), out)
         ids = psg["input_ids"]
         if "cu_seqlens" in psg:
             ids = ids.to(self.device, non_blocking=True)
@@ -125,6 +187,56 @@ class LrxHybridModel:
         reps = self.encoder.encode_packed(ids.to(torch.int32), cu.to(torch.int32), max_len, out=out, out_dim=self.dense_shrink_dim,
                                           normalize=bool(normalize))
         return {"dense_reps": reps}
+
+    def _encode_passage_sparse(self, psg: dict, normalize: bool, out: Optional[torch.Tensor]):
+        ids = psg["input_ids"]
+        if "cu_seqlens" in psg:
+            cu_host, ids_host = psg["cu_seqlens"], ids
+            max_len = int(psg["max_seqlen"])
+        else:
+            ids_host, cu_host, max_len = pack_padded_batch(ids.cpu(), psg["attention_mask"].cpu())
+        tok_mask = psg.get("sparse_mask")
+        if tok_mask is None:       # the collator normally ships it; built here from the host copy of the ids otherwise
+            tok_mask = torch.from_numpy(sparse_token_mask(ids_host.cpu().numpy(), cu_host.cpu().numpy(), self.sep_token_id, self.add_sep_token))
+        dense, sparse = self.encoder.encode_packed_sparse(
+            ids_host.to(self.device, dtype=torch.int32), cu_host.to(self.device, dtype=torch.int32), max_len,
+            tok_mask=tok_mask.to(self.device, dtype=torch.uint8).contiguous(), dense_dim=self.dense_shrink_dim, normalize=normalize,
+            relu=self.sparse_use_relu, log1p=self.sparse_use_log_saturation, round_bf16=self.sparse_round_bf16,
+            top_k=0 if 0 < self.sparse_top_p_psg < 1 else self.sparse_top_k_psg, min_tokens_to_keep=self.sparse_min_tokens_to_keep)
+        if 0 < self.sparse_top_p_psg < 1:
+            # optional nucleus filter (sparse_pooling.py:64-90), off in the published configuration: plain device tensor ops,
+            # then the top-k threshold kernel on its result (the reference's order: top-p before top-k)
+            sparse = _top_p_filter(sparse, self.sparse_top_p_psg, self.sparse_min_tokens_to_keep)
+            ops.sparsify_(sparse, relu=False, log1p=False, top_k=self.sparse_top_k_psg, min_tokens_to_keep=self.sparse_min_tokens_to_keep)
+        if out is not None:
+            out[:dense.shape[0]].copy_(dense)
+            dense = out[:dense.shape[0]]
+        return {"dense_reps": dense, "sparse_reps": sparse}
+
+    def convert_sparse_reps_to_json(self, reps: torch.Tensor, quantization_factor: int = 100, convert_id_to_token: bool = False,
+                                    vocab_dict: Optional[dict] = None) -> list[dict]:
+        """[{token id (str) | token: integer weight}] per row (finetune/sparse_converter_mixin.py:25-60, :105-160): weights =
+        round(max(x, 0) * quantization_factor), zeros dropped, an empty vector becomes {"-1": 1} / {"[PAD]": 1}.  Quantise +
+        compaction run on the GPU (lrx_sparse_compact); only the non-zeros come to the host."""
+        if reps.dim() == 1:
+            reps = reps.unsqueeze(0)
+        reps = reps.to(self.device, dtype=torch.float32).contiguous()
+        ids, w, cnt = ops.sparse_compact(reps, quantization_factor)
+        cnt = cnt.cpu().numpy()
+        ncap = int(cnt.max()) if cnt.size else 0
+        ids, w = ids[:, :ncap].cpu().numpy(), w[:, :ncap].cpu().numpy()
+        if convert_id_to_token and vocab_dict is None:
+            raise ValueError("convert_id_to_token needs vocab_dict {id: token}")
+        out = []
+        for b in range(reps.shape[0]):
+            n = int(cnt[b])
+            if n == 0:
+                out.append({"[PAD]": 1} if convert_id_to_token else {"-1": 1})
+            elif convert_id_to_token:
+                out.append({vocab_dict[int(i)]: int(v) for i, v in zip(ids[b, :n], w[b, :n])})
+            else:
+                out.append({str(int(i)): int(v) for i, v in zip(ids[b, :n], w[b, :n])})
+        return out
 
     def encode_query(self, qry: Optional[dict], normalize: Optional[bool] = None, **kwargs):
         """-> {"emb_reps": fp32 [Q, D]} from nonctx_tok_emb_input_ids / nonctx_tok_emb_offsets (modeling_hybrid.py:472-490)."""

@@ -116,3 +116,41 @@ def flat_ip_scores(X: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
     s = torch.empty(q.shape[0], ld, dtype=torch.float32, device=X.device)
     _lib.check(lib.lrx_flat_ip_scores(_lib.ptr(X), N, X.stride(0), D, _lib.ptr(q), q.shape[0], _lib.ptr(s), _s()))
     return s
+
+
+# -- sparse document vectors (N2) ------------------------------------------------------------------------------------------
+def sparse_max_aggregate(hidden: torch.Tensor, lm_head: torch.Tensor, cu_seqlens: torch.Tensor, tok_mask: Optional[torch.Tensor] = None,
+                         bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """hidden bf16 [T,H], lm_head bf16 [V,H], tok_mask uint8 [T] (None = drop first/last token) -> fp32 [B,V] running maxima."""
+    T, H = hidden.shape
+    V, B = lm_head.shape[0], cu_seqlens.numel() - 1
+    if lm_head.shape[1] != H or hidden.dtype != torch.bfloat16 or lm_head.dtype != torch.bfloat16:
+        raise ValueError("sparse_max_aggregate: hidden [T,H] / lm_head [V,H] must be bf16 with matching H")
+    if tok_mask is not None and (tok_mask.dtype != torch.uint8 or tok_mask.numel() != T):
+        raise ValueError("sparse_max_aggregate: tok_mask must be uint8 [T]")
+    out = torch.empty(B, V, dtype=torch.float32, device=hidden.device)
+    seg = torch.empty(T, dtype=torch.int32, device=hidden.device)
+    _lib.check(_lib.lib().lrx_sparse_max_aggregate(_lib.ptr(hidden), _lib.ptr(lm_head), _lib.ptr(bias) if bias is not None else None,
+                                                   _lib.ptr(cu_seqlens), _lib.ptr(tok_mask) if tok_mask is not None else None, B, T, H, V,
+                                                   _lib.ptr(out), out.stride(0), _lib.ptr(seg), _s()))
+    return out
+
+
+def sparsify_(reps: torch.Tensor, relu: bool = True, log1p: bool = True, round_bf16: bool = True, top_k: int = 0, min_tokens_to_keep: int = 8) -> torch.Tensor:
+    if reps.dtype != torch.float32 or reps.dim() != 2 or reps.stride(1) != 1:
+        raise ValueError("sparsify_: fp32 [B,V] with unit inner stride")
+    _lib.check(_lib.lib().lrx_sparsify(_lib.ptr(reps), reps.shape[0], reps.shape[1], reps.stride(0), int(relu), int(log1p), int(round_bf16),
+                                       int(top_k), int(min_tokens_to_keep), _s()))
+    return reps
+
+
+def sparse_compact(reps: torch.Tensor, quantization_factor: int = 100, capacity: Optional[int] = None):
+    """-> (ids int32 [B,cap], weights int32 [B,cap], counts int32 [B]); ascending token ids, weights = rint(max(x,0)*q) != 0."""
+    B, V = reps.shape
+    cap = int(capacity or V)
+    ids = torch.empty(B, cap, dtype=torch.int32, device=reps.device)
+    w = torch.empty(B, cap, dtype=torch.int32, device=reps.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=reps.device)
+    _lib.check(_lib.lib().lrx_sparse_compact(_lib.ptr(reps), B, V, reps.stride(0), int(quantization_factor), cap, _lib.ptr(ids), _lib.ptr(w),
+                                             _lib.ptr(cnt), _s()))
+    return ids, w, cnt

@@ -1,0 +1,210 @@
+"""GPU parity for the sparse document-vector row: LM-head max aggregation in the GEMM epilogue, sparsify,
+quantise + compaction and the encode_passage(encode_sparse) operator, against the oracle and the reference's goldens."""
+import json
+import os
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lrx_oracle as O
+from helpers import GOLDEN, load_model_golden, min_cos
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF16_ULP = 2.0 ** -7
+
+
+def bf16_t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV).to(torch.bfloat16).contiguous()
+
+
+def close_bf16(got, want, frac_exact=0.98):
+    """logits are bf16 values of fp32 sums: a different accumulation order may flip the last bf16 bit now and then."""
+    assert got.shape == want.shape
+    tol = BF16_ULP * np.abs(want) + 1e-6
+    assert (np.abs(got - want) <= tol).all(), float(np.abs(got - want).max())
+    assert (got == want).mean() >= frac_exact, float((got == want).mean())
+
+
+@pytest.mark.parametrize("lens,V,H,masked", [
+    ([40, 3, 2, 17, 33, 1, 40, 25], 290, 256, "default"),      # ragged, vocab not a multiple of 8, empty rows (len <= 2)
+    ([7] * 90 + [1, 2, 3], 1000, 128, "random"),                # dozens of documents inside one 256-row tile
+    ([700, 5, 300], 520, 64, "random"),                          # a document spanning three row tiles
+    ([256, 256, 512], 256, 192, None),                           # tile-aligned boundaries, every token counted
+])
+def test_max_aggregate_kernel_equals_oracle(lens, V, H, masked):
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(len(lens) + V)
+    T = sum(lens)
+    hid = O.round_bf16(rng.standard_normal((T, H)).astype(np.float32))
+    W = O.round_bf16(rng.standard_normal((V, H)).astype(np.float32) * 0.1)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    if masked == "default":
+        tm = None                                             # kernel default: drop each sequence's first and last token
+        tm_np = np.ones(T, bool)
+        tm_np[cu[:-1]] = False
+        tm_np[cu[1:] - 1] = False
+    elif masked == "random":
+        tm_np = rng.random(T) < 0.6
+        tm = torch.from_numpy(tm_np.astype(np.uint8)).to(DEV)
+    else:
+        tm_np = np.ones(T, bool)
+        tm = torch.from_numpy(tm_np.astype(np.uint8)).to(DEV)
+    got = ops.sparse_max_aggregate(bf16_t(hid), bf16_t(W), torch.from_numpy(cu).to(DEV), tm).cpu().numpy()
+    want = O.max_aggregate_packed(hid, cu, tm_np, W, None, bf16=True)
+    empty = want == O.BF16_MIN
+    np.testing.assert_array_equal(got == O.BF16_MIN, empty)
+    close_bf16(got[~empty], want[~empty])
+
+
+def test_max_aggregate_with_bias_and_negative_maxima():
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(5)
+    lens, V, H = [30, 9, 300], 264, 64
+    T = sum(lens)
+    hid = O.round_bf16(rng.standard_normal((T, H)).astype(np.float32))
+    W = O.round_bf16(rng.standard_normal((V, H)).astype(np.float32) * 0.05)
+    bias = O.round_bf16((rng.standard_normal(V) - 6.0).astype(np.float32))          # pushes whole columns below zero
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    tm_np = rng.random(T) < 0.5
+    got = ops.sparse_max_aggregate(bf16_t(hid), bf16_t(W), torch.from_numpy(cu).to(DEV), torch.from_numpy(tm_np.astype(np.uint8)).to(DEV),
+                                   bias=bf16_t(bias)).cpu().numpy()
+    want = O.max_aggregate_packed(hid, cu, tm_np, W, bias, bf16=True)
+    assert (want < 0).mean() > 0.5
+    close_bf16(got, want)
+
+
+@pytest.mark.parametrize("relu,log1p,round_bf16,top_k,min_keep", [
+    (True, False, False, 0, 8), (True, False, False, 16, 8), (True, False, False, 3, 8), (False, False, False, 5, 1),
+    (True, True, False, 0, 8), (True, True, True, 32, 8), (True, True, True, 100000, 8)])
+def test_sparsify_equals_oracle(relu, log1p, round_bf16, top_k, min_keep):
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(top_k + 7)
+    x = O.round_bf16(rng.standard_normal((13, 3001)).astype(np.float32) * 2)          # bf16-valued: plenty of exact ties
+    x[3] = O.BF16_MIN                                                                  # a document without valid tokens
+    x[5, :] = -1.0                                                                      # all equal
+    got = ops.sparsify_(torch.from_numpy(x.copy()).to(DEV), relu, log1p, round_bf16, top_k, min_keep).cpu().numpy()
+    want = O.sparsify(x, relu=relu, log1p=log1p, top_k=top_k, min_tokens_to_keep=min_keep, bf16=round_bf16)
+    if not log1p:
+        np.testing.assert_array_equal(got, want)                                       # selection is exact, ties included
+    else:
+        np.testing.assert_allclose(got, want, rtol=2.0 ** -7 if round_bf16 else 2e-6, atol=1e-7)
+        assert ((got > 0) == (want > 0)).mean() > 0.9999
+    if relu:
+        assert (got[3] == 0).all()
+
+
+def test_compact_and_json_match_reference_converter():
+    from lightretriever_amd import ops
+    g = np.load(os.path.join(GOLDEN, "sparse.npz"))
+    with open(os.path.join(GOLDEN, "sparse_json.json")) as f:
+        want = json.load(f)
+    for key, jkey in (("sparse_reps", "quant100"), ("sparse_reps_top16", "quant100_top16")):
+        reps = torch.from_numpy(g[key]).to(DEV)
+        ids, w, cnt = ops.sparse_compact(reps, 100)
+        ids, w, cnt = ids.cpu().numpy(), w.cpu().numpy(), cnt.cpu().numpy()
+        got = [{str(int(i)): int(v) for i, v in zip(ids[b, :cnt[b]], w[b, :cnt[b]])} or {"-1": 1} for b in range(len(cnt))]
+        assert got == want[jkey]
+        assert all(list(map(int, d)) == sorted(map(int, d)) for d in got)             # ascending token ids
+    # round-half-even and capacity truncation
+    halves = torch.tensor([[0.5 / 7, 1.5 / 7, 2.5 / 7, -3.0, 0.0, 0.07]], device=DEV)
+    ids, w, cnt = ops.sparse_compact(halves, 7, capacity=2)
+    assert int(cnt[0]) == len(want["quant7_halves"][0])
+    assert [(str(int(i)), int(v)) for i, v in zip(ids[0].cpu(), w[0].cpu())] == list(want["quant7_halves"][0].items())[:2]
+
+
+def _sparse_model(**kw):
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    from lightretriever_amd.modeling import LrxHybridModel
+    cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    enc = LrxEncoder(EncoderConfig(**asdict(cfg_o)), {k: torch.from_numpy(v) for k, v in w.items()})
+    g = np.load(os.path.join(GOLDEN, "sparse.npz"))
+    hm = LrxHybridModel(enc, normalize=True, encode_sparse=True, sep_token_id=int(g["sep_token_id"]), add_sep_token=True, **kw)
+    return cfg_o, w, g, enc, hm
+
+
+def test_encode_passage_sparse_matches_reference_and_oracle():
+    cfg_o, w, g, enc, hm = _sparse_model(sparse_round_bf16=False)
+    psg = {"input_ids": torch.from_numpy(g["input_ids"]), "attention_mask": torch.from_numpy(g["attention_mask"])}
+    out = hm.encode_passage(psg)
+    sp, dn = out["sparse_reps"].cpu().numpy(), out["dense_reps"].cpu().numpy()
+    assert sp.shape == g["sparse_reps"].shape
+    # the reference's fp32 run and its autocast run differ by 0.019 on this fixture; the bf16 pipeline sits in the same band
+    assert np.abs(sp - g["sparse_reps"]).max() < 0.06
+    assert np.abs(sp - g["sparse_reps_autocast"]).max() < 0.06
+    np.testing.assert_array_equal((g["sparse_reps"] > 0).sum(1) == 0, (sp > 0).sum(1) == 0)      # same empty documents
+    assert ((sp > 0) == (g["sparse_reps"] > 0)).mean() > 0.985                                     # support differs only at |logit| ~ 0
+    assert min_cos(dn, g["dense_reps"]) > 0.998
+    # tight: the oracle's bf16 restatement of the same pipeline
+    ids, _, _, cu, _ = O.pack_padded(g["input_ids"], g["attention_mask"])
+    am = g["attention_mask"].astype(bool)
+    want = O.encode_passage_sparse(cfg_o, w, ids, cu, g["mask_noprompt"][am], bf16=True, relu=True, log1p=True)
+    assert np.abs(sp - want).max() < 0.04
+    # dense branch of the same call == the dense-only operator
+    dn2 = hm.encode_passage(psg, encode_sparse=False)["dense_reps"].cpu().numpy()
+    assert min_cos(dn, dn2) > 0.99999
+    # quantised JSON: same keys up to entries that quantise to 0/1, weights within 0.06 * 100
+    got = hm.convert_sparse_reps_to_json(out["sparse_reps"], 100)
+    with open(os.path.join(GOLDEN, "sparse_json.json")) as f:
+        ref = json.load(f)["quant100"]
+    for a, b in zip(got, ref):
+        if b == {"-1": 1}:
+            assert a == b
+            continue
+        for k in set(a) | set(b):
+            assert abs(a.get(k, 0) - b.get(k, 0)) <= 6, (k, a.get(k), b.get(k))
+
+
+@pytest.mark.parametrize("kw,key", [(dict(sparse_top_k_psg=16), "sparse_reps_top16"), (dict(sparse_top_k_psg=3), "sparse_reps_top3_min8"),
+                                    (dict(sparse_top_p_psg=0.3), "sparse_reps_topp")])
+def test_encode_passage_sparse_sampling_options(kw, key):
+    cfg_o, w, g, enc, hm = _sparse_model(sparse_round_bf16=False, **kw)
+    psg = {"input_ids": torch.from_numpy(g["input_ids"]), "attention_mask": torch.from_numpy(g["attention_mask"])}
+    sp = hm.encode_passage(psg)["sparse_reps"].cpu().numpy()
+    want = g[key]
+    np.testing.assert_array_equal((sp > 0).sum(1) == 0, (want > 0).sum(1) == 0)
+    nz_got, nz_want = (sp > 0).sum(1), (want > 0).sum(1)
+    if "sparse_top_k_psg" in kw:
+        assert (nz_got[nz_want > 0] >= nz_want[nz_want > 0]).all() and (nz_got <= nz_want + 2).all()    # k survivors (+ bf16 ties)
+    # the kept entries are the same tokens except where two logits are within bf16 noise of the threshold
+    overlap = ((sp > 0) & (want > 0)).sum() / max(1, (want > 0).sum())
+    assert overlap > 0.9
+    both = (sp > 0) & (want > 0)
+    assert np.abs(sp[both] - want[both]).max() < 0.06
+
+
+def test_packed_input_with_collator_mask_equals_padded_input():
+    cfg_o, w, g, enc, hm = _sparse_model()
+    from lightretriever_amd.modeling import sparse_token_mask
+    ids, _, _, cu, max_len = O.pack_padded(g["input_ids"], g["attention_mask"])
+    psg_packed = {"input_ids": torch.from_numpy(ids.astype(np.int32)), "cu_seqlens": torch.from_numpy(cu), "max_seqlen": max_len,
+                  "sparse_mask": torch.from_numpy(sparse_token_mask(ids, cu, int(g["sep_token_id"]), True))}
+    a = hm.encode_passage(psg_packed)["sparse_reps"]
+    b = hm.encode_passage({"input_ids": torch.from_numpy(g["input_ids"]), "attention_mask": torch.from_numpy(g["attention_mask"])})["sparse_reps"]
+    assert torch.equal(a, b)
+
+
+def test_max_aggregate_full_vocab_against_device_matmul():
+    """Llama-3.2-1B head dims (V = 128256, H = 2048): sampled vocabulary columns against a plain fp32 matmul on the device."""
+    from lightretriever_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    V, H, lens = 128256, 2048, [512, 100, 512, 1, 37, 300]
+    T = sum(lens)
+    hid = (torch.randn(T, H, generator=gen, device=DEV)).to(torch.bfloat16)
+    W = (torch.randn(V, H, generator=gen, device=DEV) * 0.02).to(torch.bfloat16)
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=DEV)
+    got = ops.sparse_max_aggregate(hid, W, cu, None)
+    cols = torch.cat([torch.arange(0, 300, device=DEV), torch.randint(0, V, (500,), generator=gen, device=DEV), torch.arange(V - 300, V, device=DEV)])
+    logits = (hid.float() @ W[cols].float().T).to(torch.bfloat16).float()
+    want = torch.full((len(lens), cols.numel()), float(O.BF16_MIN), device=DEV)
+    for b, n in enumerate(lens):
+        s = int(cu[b])
+        if n > 2:
+            want[b] = logits[s + 1:s + n - 1].max(0).values
+    g_, w_ = got[:, cols].cpu().numpy(), want.cpu().numpy()
+    empty = w_ == O.BF16_MIN
+    np.testing.assert_array_equal(g_ == O.BF16_MIN, empty)
+    close_bf16(g_[~empty], w_[~empty], frac_exact=0.97)
+    assert torch.isfinite(got).all()

@@ -200,3 +200,23 @@ def test_embedding_bag_vocab_slices_over_gloo_world2():
     assert want.shape == (203, 8)
     for r in range(2):
         np.testing.assert_array_equal(ret[r], want)
+
+
+def test_sparse_token_mask_matches_reference_rule(tok):
+    """N2 host rule: get_sparse_attention_mask restated on the packed layout == the reference's padded masks (golden)."""
+    from lightretriever_amd.modeling import sparse_token_mask, EncodeCollator
+    g = np.load(os.path.join(GOLDEN, "sparse.npz"))
+    sep = int(g["sep_token_id"])
+    am = g["attention_mask"].astype(bool)
+    ids, _, _, cu, _ = O.pack_padded(g["input_ids"], g["attention_mask"])
+    np.testing.assert_array_equal(sparse_token_mask(ids, cu, sep, False).astype(bool), g["mask_plain"][am])
+    np.testing.assert_array_equal(sparse_token_mask(ids, cu, sep, True).astype(bool), g["mask_noprompt"][am])
+    np.testing.assert_array_equal(sparse_token_mask(ids, cu, None, True).astype(bool), g["mask_plain"][am])
+    qm = g["attention_mask"][[0, 6]]
+    ids2, _, _, cu2, _ = O.pack_padded(g["quirk_ids"], qm)
+    np.testing.assert_array_equal(sparse_token_mask(ids2, cu2, sep, True).astype(bool), g["quirk_mask"][qm.astype(bool)])
+    # the collator ships it next to the packed ids
+    out = EncodeCollator(tok, encode_is_query=False, p_max_len=32, sparse_mask=True)([{"text": "dense retrieval with large models"}, {"text": "a"}])
+    m, cu3 = out["sparse_mask"].numpy(), out["cu_seqlens"].numpy()
+    assert m.dtype == np.uint8 and m.shape[0] == cu3[-1]
+    assert m[cu3[:-1]].sum() == 0 and m[cu3[1:] - 1].sum() == 0 and m.sum() == cu3[-1] - 2 * (len(cu3) - 1)
