@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--model", default="llama3.2-1b", choices=["llama3.2-1b", "llama3.1-8b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--no-sparse", action="store_true", help="skip the dense+sparse document-vector leg (SURVEY 8f N2)")
     ap.add_argument("--ragged", action="store_true",
                     help="document lengths ~ clip(lognormal(5.3, 0.6), 16, seq_len), sorted longest first (mirrors hybrid_search.py:273-276) "
                          "instead of the fixed-length headline workload")
@@ -253,6 +254,32 @@ def main():
                          "fp32_mfma_peak_for_reference": PEAK_F32_MFMA_TFLOPS},
         }
 
+    # ---- dense + sparse document vectors (row N2): same batches through lrx_encode_packed_sparse; not part of `value`
+    sparse = None
+    if not args.no_sparse and batches is None:
+        n_sp = min(2, args.steps)
+        enc.encode_packed_sparse(ids_all[0].reshape(-1), cu, S)
+        enc.set_profiling(True)
+        barrier_sync(distributed)
+        t0 = time.perf_counter()
+        mx_ms = 0.0
+        for i in range(n_sp):
+            enc.encode_packed_sparse(ids_all[args.warmup + i].reshape(-1), cu, S)
+            mx_ms += enc.get_profile()["gemm_maxagg"]["ms"]
+        barrier_sync(distributed)
+        sp_s = time.perf_counter() - t0
+        enc.set_profiling(False)
+        t = torch.tensor([sp_s], device=dev, dtype=torch.float64)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sp_s = float(t.item())
+        mx_fl = 2.0 * B * S * cfg.vocab_size * D
+        sparse = {"metric": "docs/sec with dense + sparse (LM-head max aggregation, relu, log1p) vectors", "value": round(world * B * n_sp / sp_s, 2),
+                  "unit": "docs/s", "steps": n_sp, "ms_per_step": round(1e3 * sp_s / n_sp, 3),
+                  "roofline": {"bound": "mfma", "kernel": "k_gemm_bf16_nt<EPI_MAXAGG> (M=%d N=%d K=%d, segmented column max in the epilogue)" % (B * S, cfg.vocab_size, D),
+                               "achieved": round(mx_fl / (mx_ms / n_sp * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(mx_fl / (mx_ms / n_sp * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(mx_ms / n_sp, 3)}}
+
     if rank != 0:
         if distributed:
             dist.destroy_process_group()
@@ -286,6 +313,7 @@ def main():
                    "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world},
         "roofline": roofline,
         "search": search,
+        "sparse": sparse,
     }
     if world == 1 and not args.no_cpu_baseline:
         try:

@@ -364,6 +364,18 @@ class LrxExactSearchModel:
     query_prompt: Optional[str] = None
     corpus_prompt: Optional[str] = None
     encoding_kwargs: dict = field(default_factory=dict)
+    token_id_vector_type: str = "sum"          # 'sum' | 'bow' (finetune/arguments.py:203-211): the parameter-free sparse query
+
+    def token_id_reps(self, items: list[dict]) -> list[dict]:
+        """Parameter-free sparse query vectors (exact_search_base.py:380-431): raw text with a leading whitespace, no specials,
+        {str(token id): count} ('sum') or {str(token id): 1} ('bow')."""
+        from collections import Counter
+        enc = self.tokenizer([" " + format_text(t) for t in items], max_length=self.q_max_len, truncation=True, add_special_tokens=False)["input_ids"]
+        if self.token_id_vector_type == "bow":
+            return [{str(t): 1 for t in set(e)} for e in enc]
+        if self.token_id_vector_type == "sum":
+            return [{str(k): v for k, v in Counter(e).items()} for e in enc]
+        raise NotImplementedError(self.token_id_vector_type)
 
     def parse_texts(self, texts, prompt: Optional[str] = None) -> list[dict]:
         items = _as_items(texts)
@@ -383,7 +395,10 @@ class LrxExactSearchModel:
         for s in range(0, len(items), batch_size):
             outs.append(self.model.encode_query(coll(items[s:s + batch_size]))["emb_reps"])
         reps = torch.cat(outs, 0)
-        return {"emb_reps": reps if convert_to_tensor else reps.cpu().numpy()}
+        res = {"emb_reps": reps if convert_to_tensor else reps.cpu().numpy()}
+        if self.model.encode_sparse:
+            res["token_id_reps"] = self.token_id_reps(items)
+        return res
 
     def encode_corpus(self, corpus, batch_size: int, show_progress_bar: bool = True, convert_to_tensor: bool = True,
                       out: Optional[torch.Tensor] = None, **kwargs):
@@ -392,12 +407,20 @@ class LrxExactSearchModel:
     def encode(self, sentences, batch_size: int, show_progress_bar: bool = True, convert_to_tensor: bool = True,
                out: Optional[torch.Tensor] = None, **kwargs):
         items = self.parse_texts(sentences, prompt=self.corpus_prompt)
-        coll = EncodeCollator(self.tokenizer, encode_is_query=False, q_max_len=self.q_max_len, p_max_len=self.p_max_len)
+        sparse = self.model.encode_sparse
+        coll = EncodeCollator(self.tokenizer, encode_is_query=False, q_max_len=self.q_max_len, p_max_len=self.p_max_len, sparse_mask=sparse,
+                              sep_token_id=self.model.sep_token_id, add_sep_token=self.model.add_sep_token)
         D = self.model.dense_shrink_dim or self.model.encoder.cfg.hidden_size
         if out is None:
             out = torch.empty(len(items), D, dtype=torch.float32, device=self.model.device)
+        sparse_json: list[dict] = []
         for s in range(0, len(items), batch_size):
             e = min(s + batch_size, len(items))
-            self.model.encode_passage(coll(items[s:e]), out=out[s:e])
+            r = self.model.encode_passage(coll(items[s:e]), out=out[s:e])
+            if sparse:   # quantised {token id: weight} per document, what call_batch_encode hands to the sparse engine
+                sparse_json.extend(self.model.convert_sparse_reps_to_json(r["sparse_reps"], quantization_factor=100))
         reps = out[:len(items)]
-        return {"dense_reps": reps if convert_to_tensor else reps.cpu().numpy()}
+        res = {"dense_reps": reps if convert_to_tensor else reps.cpu().numpy()}
+        if sparse:
+            res["sparse_reps"] = sparse_json
+        return res

@@ -208,3 +208,39 @@ def test_max_aggregate_full_vocab_against_device_matmul():
     np.testing.assert_array_equal(g_ == O.BF16_MIN, empty)
     close_bf16(g_[~empty], w_[~empty], frac_exact=0.97)
     assert torch.isfinite(got).all()
+
+
+def test_encode_corpus_and_queries_carry_sparse_vectors():
+    """B2 level: encode_corpus -> dense rows + one quantised JSON vector per document; encode_queries -> token-count vectors;
+    the notebook's similarity (scripts/asymmetric_sparse_infer.ipynb: sum over shared token ids) on them equals the oracle's."""
+    from transformers import PreTrainedTokenizerFast
+    from lightretriever_amd.modeling import LrxExactSearchModel, format_text
+    cfg_o, w, g, enc, hm = _sparse_model()
+    tok = PreTrainedTokenizerFast.from_pretrained(os.path.join(GOLDEN, "tok"))
+    hm.pad_token_id, hm.sep_token_id, hm.add_sep_token = tok.pad_token_id, None, False
+    model = LrxExactSearchModel(model=hm, tokenizer=tok, q_max_len=32, p_max_len=48, eval_batch_size_embedding_bag=100)
+    corpus = [{"title": "", "text": "dense retrieval with large language models"}, {"title": "amd", "text": "instinct memory search"},
+              {"title": "", "text": "a"}, {"title": "", "text": "the quick brown fox jumps over the lazy dog " * 3}]
+    res = model.encode_corpus(corpus, batch_size=3)
+    assert res["dense_reps"].shape == (4, cfg_o.hidden_size) and len(res["sparse_reps"]) == 4
+    encd = tok([format_text(d, prepend_prompt=True) for d in corpus], max_length=48, truncation="only_first", add_special_tokens=True)["input_ids"]
+    for b, e in enumerate(encd):                       # each document separately through the oracle (batching must not matter)
+        ids, cu = np.asarray(e, np.int32), np.array([0, len(e)], np.int32)
+        tm = np.ones(len(e), bool)
+        tm[0] = tm[-1] = False
+        want = O.sparse_reps_to_json(O.encode_passage_sparse(cfg_o, w, ids, cu, tm, bf16=True, relu=True, log1p=True), 100)[0]
+        got = res["sparse_reps"][b]
+        if want == {"-1": 1}:
+            assert got == want
+            continue
+        for k in set(got) | set(want):
+            assert abs(got.get(k, 0) - want.get(k, 0)) <= 5, (b, k, got.get(k), want.get(k))
+    q = model.encode_queries(["memory search search", "fox"], batch_size=2)
+    assert "emb_reps" in q and len(q["token_id_reps"]) == 2
+    from collections import Counter
+    want_q = Counter(tok(" memory search search", add_special_tokens=False)["input_ids"])       # 'sum': token -> count, leading blank
+    assert q["token_id_reps"][0] == {str(k): v for k, v in want_q.items()} and max(want_q.values()) >= 2
+    model.token_id_vector_type = "bow"
+    assert set(model.encode_queries(["memory search search"], batch_size=1)["token_id_reps"][0].values()) == {1}
+    score = lambda qr, pr: sum(v * pr[k] for k, v in qr.items() if k in pr)
+    assert score(q["token_id_reps"][0], res["sparse_reps"][1]) >= 0
