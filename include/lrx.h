@@ -200,6 +200,19 @@ int lrx_sparsify(float* reps, int32_t n_rows, int32_t vocab_size, int64_t row_st
 int lrx_sparse_compact(const float* reps, int32_t n_rows, int32_t vocab_size, int64_t row_stride, int32_t quantization_factor,
                        int32_t capacity, int32_t* ids_out, int32_t* weights_out, int32_t* counts_out, void* stream);
 
+/* Hit-list fusion (retriever/score_fuse_utils.py:3-91 on arrays; IEEE double like the reference's numpy float64).
+ * Stage 1, one retrieval system: scores f64 / ids i64 [n_queries, k] (id < 0 = empty slot) -> contribution per entry:
+ *   method 0 (fuse_scores_rrf):    1 / (param0 + rank), rank 1 = highest score of the row;
+ *   method 1 (fuse_scores_linear): param0 * (s - min) / (max - min + param1), min/max over the row's valid entries.
+ * Stage 2: the systems' (ids, contributions) concatenated per query in system order [n_queries, n_entries] -> union by id,
+ * contributions of one id summed in system order, rows sorted by fused score (descending, lower id first among equals):
+ * scores_out f64 / ids_out i64 [n_queries, n_entries] (-inf / -1 beyond counts_out[q]).  k, n_entries <= 2048.             */
+int lrx_hit_contributions(const double* scores, const int64_t* ids, int32_t n_queries, int32_t k, int64_t row_stride,
+                          int32_t method, double param0, double param1, double* contrib_out, int64_t contrib_row_stride,
+                          void* stream);
+int lrx_hit_union(const int64_t* ids, const double* contrib, int32_t n_queries, int32_t n_entries, int64_t row_stride,
+                  double* scores_out, int64_t* ids_out, int32_t* counts_out, void* stream);
+
 /* dst[b, :] = src[cu_seqlens[b+1]-1, :]  (bf16 rows of `width` elements): the last-token rows, compacted. */
 int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, int32_t width, void* dst, void* stream);
 

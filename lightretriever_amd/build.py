@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblrx.so")
-SOURCES = ["lrx_capi.hip", "lrx_elementwise.hip", "lrx_gemm.hip", "lrx_attn.hip", "lrx_search.hip", "lrx_sparse.hip"]
+SOURCES = ["lrx_capi.hip", "lrx_elementwise.hip", "lrx_gemm.hip", "lrx_attn.hip", "lrx_search.hip", "lrx_sparse.hip", "lrx_fuse.hip"]
 
 
 def _stale():

@@ -191,8 +191,15 @@ class HybridSearch:
     (hybrid_search.py:121-180); `search()` returns the last enabled type unless return_all_results."""
 
     def __init__(self, model, batch_size: int = 128, corpus_chunk_size: Optional[int] = None, use_multiple_gpu: bool = False,
-                 fuse_weights=(0.7, 0.3), return_all_results: bool = False, **kwargs):
+                 score_fuse_method: str = "linear", fuse_weights=(0.7, 0.3), return_all_results: bool = False, sparse_search=None, **kwargs):
+        """sparse_search: an engine with the reference's AnseriniSearch interface (`index(corpus_emb, corpus_ids)`,
+        `retrieve_with_emb(query_emb, query_ids, top_k)`, `_clear()`); the Lucene engine itself is outside this package.  When
+        one is given, `tok` / `emb_tok` (query token counts x sparse document vectors, and their fusion with the dense hits,
+        hybrid_search.py:160-180) are produced like the reference does; the fusion runs on the GPU (score_fuse_utils)."""
         self.model = model
+        self.score_fuse_method = score_fuse_method
+        self.fuse_weights = list(fuse_weights)
+        self.sparse_search = sparse_search
         self.batch_size = batch_size
         self.corpus_chunk_size = batch_size * 800 if corpus_chunk_size is None else corpus_chunk_size
         self.show_progress_bar = kwargs.get("show_progress_bar", True)
@@ -217,10 +224,29 @@ class HybridSearch:
     def _clear(self, dense: bool = True, sparse: bool = True):
         if dense:
             self.dense_search._clear()
+        if sparse and self.sparse_search is not None:
+            self.sparse_search._clear()
 
     def index(self, corpus_emb: dict, corpus_ids: list):
         assert isinstance(corpus_emb, dict) and corpus_emb.get("dense_reps") is not None
         self.dense_search.index(corpus_emb["dense_reps"], corpus_ids)
+        if self.sparse_search is not None and corpus_emb.get("sparse_reps") is not None:
+            self.sparse_search.index(corpus_emb["sparse_reps"], corpus_ids)
+
+    def _fuse_results(self, dense_results=None, sparse_results=None, weights=(0.7, 0.3)):
+        """hybrid_search.py:207-232: one of the lists alone, or their RRF / min-max linear fusion (on the GPU)."""
+        from .score_fuse_utils import fuse_scores_linear, fuse_scores_rrf
+        if dense_results is None and sparse_results is None:
+            raise ValueError("All scores are None. Please check model settings.")
+        if dense_results is None:
+            return sparse_results
+        if sparse_results is None:
+            return dense_results
+        if self.score_fuse_method == "rrf":
+            return fuse_scores_rrf([dense_results, sparse_results])
+        if self.score_fuse_method == "linear":
+            return fuse_scores_linear([dense_results, sparse_results], weights=weights)
+        raise NotImplementedError(f"score_fuse_method {self.score_fuse_method} is not supported.")
 
     def retrieve_with_emb(self, query_emb: dict, query_ids: list, top_k: int, dense: bool = True, sparse: bool = True, **kwargs):
         assert isinstance(query_emb, dict) and (query_emb.get("dense_reps") is not None or query_emb.get("emb_reps") is not None)
@@ -230,6 +256,10 @@ class HybridSearch:
                 results["den"] = self.dense_search.retrieve_with_emb(query_emb["dense_reps"], query_ids, top_k=top_k)
             if query_emb.get("emb_reps") is not None:
                 results["emb"] = self.dense_search.retrieve_with_emb(query_emb["emb_reps"], query_ids, top_k=top_k)
+        if sparse and self.sparse_search is not None and query_emb.get("token_id_reps") is not None:
+            results["tok"] = self.sparse_search.retrieve_with_emb(query_emb["token_id_reps"], query_ids, top_k=top_k)
+            if "emb" in results:
+                results["emb_tok"] = self._fuse_results(results["emb"], results["tok"], weights=self.fuse_weights)
         return results
 
     def search(self, corpus, queries, top_k: int = 1000, score_function: str = None, return_sorted: bool = False,

@@ -26,6 +26,9 @@ Parity pin status
   reference functions).  The JSON converter is pinned against the reference's own torch variant
   (``convert_sparse_reps_to_json_pt``); its Rust crate ``sparse_emb_util`` is not in the reference tree -> **unpinned**.
 
+* Hit-list fusion (row N3: RRF, min-max linear): PINNED by ``tests/golden/fusion.json`` (``gen_fusion_goldens.py`` runs
+  ``retriever/score_fuse_utils.py``), exact float64 equality.
+
 Every function cites the reference ``file:line`` (relative to /root/reference) or the
 third-party source it restates.
 """
@@ -620,3 +623,34 @@ def encode_passage_sparse(cfg: EncoderConfig, w, ids, cu_seqlens, tok_mask, lm_h
     W = lm_head if lm_head is not None else w["embed_tokens.weight"]
     agg = max_aggregate_packed(hidden, cu_seqlens, tok_mask, W, None, bf16=bf16)
     return sparsify(agg, bf16=bf16, **sparsify_kw)
+
+
+# --------------------------------------------------------------------------------------
+# Hit-list fusion -- retriever/score_fuse_utils.py:3-91, numpy float64 like the reference
+# --------------------------------------------------------------------------------------
+def fuse_scores_rrf(results_list: list[dict], k: int = 60) -> dict:
+    """score_fuse_utils.py:3-45: per system and query, rank by descending score, add 1 / (k + rank) per passage."""
+    fused: dict = {}
+    for res in results_list:
+        for qid, passages in res.items():
+            out = fused.setdefault(str(qid), {})
+            pids = list(passages.keys())
+            order = np.argsort(-np.array([float(passages[p]) for p in pids], dtype=np.float64), kind="stable")
+            for rank, j in enumerate(order, start=1):
+                out[str(pids[j])] = out.get(str(pids[j]), 0.0) + float(1 / np.float64(k + rank))
+    return fused
+
+
+def fuse_scores_linear(results_list: list[dict], weights=(0.7, 0.3), eps: float = 1e-8) -> dict:
+    """score_fuse_utils.py:47-91: (s - min) / (max - min + eps) * weight per system and query, summed per passage."""
+    assert len(results_list) == len(weights)
+    fused: dict = {}
+    for res, wgt in zip(results_list, weights):
+        for qid, passages in res.items():
+            out = fused.setdefault(str(qid), {})
+            pids = list(passages.keys())
+            sc = np.array([float(passages[p]) for p in pids], dtype=np.float64)
+            normed = (sc - sc.min()) / (sc.max() - sc.min() + eps) * wgt
+            for p, v in zip(pids, normed):
+                out[str(p)] = out.get(str(p), 0.0) + float(v)
+    return fused

@@ -219,3 +219,17 @@ def test_sparse_json_matches_reference_converter():
     halves = np.array([[0.5 / 7, 1.5 / 7, 2.5 / 7, -3.0, 0.0, 0.07]], np.float32)
     assert O.sparse_reps_to_json(halves, 7) == want["quant7_halves"]
     assert want["quant100"][2] == {"-1": 1}                                   # empty vector placeholder
+
+
+# ---- hit-list fusion (N3) ----------------------------------------------------------------------------------------------
+def test_fusion_restatement_is_bit_identical_to_reference():
+    with open(os.path.join(GOLDEN, "fusion.json")) as f:
+        g = json.load(f)
+    two, three = [g["dense"], g["sparse"]], [g["dense"], g["sparse"], g["third"]]
+    assert O.fuse_scores_rrf(two) == g["rrf"]
+    assert O.fuse_scores_rrf(two, k=10) == g["rrf_k10"]
+    assert O.fuse_scores_rrf(three) == g["rrf_three"]
+    assert O.fuse_scores_linear(two, [0.7, 0.3]) == g["linear"]
+    assert O.fuse_scores_linear(two, [0.5, 0.5], eps=1e-6) == g["linear_5050"]
+    assert O.fuse_scores_linear(three, [0.5, 0.3, 0.2]) == g["linear_three"]
+    assert set(g["rrf"]) == set(g["dense"]) | set(g["sparse"])                # queries of either system
