@@ -53,6 +53,24 @@ class FlatIPIndex:
     def reset(self):
         self.ntotal = 0
 
+    # -- persistence (faiss.write_index / read_index of an IndexFlatIP, see index_io.py) --------------------------
+    def save(self, fname: str, chunk_rows: int = 262144):
+        from .index_io import write_flat_ip
+        write_flat_ip(fname, (self._x[s:min(s + chunk_rows, self.ntotal)].cpu().numpy() for s in range(0, self.ntotal, chunk_rows)),
+                      self.d, self.ntotal)
+
+    @classmethod
+    def load(cls, fname: str, device: Optional[torch.device] = None, id_base: int = 0, chunk_rows: int = 262144) -> "FlatIPIndex":
+        from .index_io import read_flat_ip
+        import numpy as np
+        mm = read_flat_ip(fname)
+        idx = cls(mm.shape[1], capacity=mm.shape[0], device=device, id_base=id_base)
+        for s in range(0, mm.shape[0], chunk_rows):
+            e = min(s + chunk_rows, mm.shape[0])
+            idx._x[s:e].copy_(torch.from_numpy(np.ascontiguousarray(mm[s:e])), non_blocking=False)
+        idx.ntotal = mm.shape[0]
+        return idx
+
     @property
     def vectors(self) -> torch.Tensor:
         return self._x[:self.ntotal]

@@ -12,6 +12,7 @@ GPU and merged with lrx_merge_topk, so Python touches O(Q*k) values once at the 
 from __future__ import annotations
 
 import logging
+import os
 import time
 from typing import Optional
 
@@ -49,6 +50,9 @@ class FaissIndex:
         for s in range(0, len(passage_ids), buffer_size):
             index.add(passage_embeddings[s:s + buffer_size])
         return cls(index, passage_ids)
+
+    def save(self, fname: str):
+        self.index.save(fname)     # faiss.write_index layout (index_io.py)
 
     def to_gpu(self):
         return self.index   # already HBM-resident; multi-GPU = one process per GPU (sharded.ShardedFlatIPIndex)
@@ -140,6 +144,30 @@ class DenseRetrievalFaissSearch:
     def index(self, corpus_emb, corpus_ids):
         raise NotImplementedError("Base class function. Please implement this depands on index type.")
 
+    # -- persistence (faiss_search.py:99-123): {prefix}.{ext}.tsv id map + {prefix}.{ext}.faiss; one pair per rank ------------
+    mapping_tsv_keys = ["beir-docid", "faiss-docid"]
+
+    @staticmethod
+    def _rank_world():
+        import torch.distributed as dist
+        return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+    def _load(self, input_dir: str, prefix: str, ext: str):
+        from .index_io import load_tsv_to_dict, shard_prefix
+        prefix = shard_prefix(prefix, *self._rank_world())
+        self.mapping = load_tsv_to_dict(os.path.join(input_dir, "{}.{}.tsv".format(prefix, ext)), header=True)
+        self.rev_mapping = {v: k for k, v in self.mapping.items()}
+        return os.path.join(input_dir, "{}.{}.faiss".format(prefix, ext)), sorted(self.rev_mapping)
+
+    def save(self, output_dir: str, prefix: str, ext: str):
+        from .index_io import save_dict_to_tsv, shard_prefix
+        prefix = shard_prefix(prefix, *self._rank_world())
+        os.makedirs(output_dir, exist_ok=True)
+        save_dict_to_tsv(self.mapping, os.path.join(output_dir, "{}.{}.tsv".format(prefix, ext)), keys=self.mapping_tsv_keys)
+        path = os.path.join(output_dir, "{}.{}.faiss".format(prefix, ext))
+        self.faiss_index.save(path)
+        logger.info("Index size: {:.2f}MB".format(os.path.getsize(path) * 0.000001))
+
     # -- device-level retrieval used by the chunk loop ---------------------------------------------------------------
     def _retrieve_device(self, query_emb, top_k: int):
         return self.faiss_index.search(_as_device(query_emb, self.faiss_index.index.device), top_k)
@@ -181,6 +209,18 @@ class FlatIPFaissSearch(DenseRetrievalFaissSearch):
             slot.copy_(emb.to(slot.device))
         idx.commit(len(docs))
         self.faiss_index = FaissIndex(idx, [self.mapping.get(c, c) for c in corpus_ids])
+
+    def load(self, input_dir: str, prefix: str = "my-index", ext: str = "flat"):
+        """faiss_search.py:478-488: id map + index file -> HBM shard of this rank."""
+        path, passage_ids = self._load(input_dir, prefix, ext)
+        idx = FlatIPIndex.load(path)
+        if passage_ids and len(passage_ids) != idx.ntotal:
+            raise ValueError(f"{path}: {idx.ntotal} rows but {len(passage_ids)} ids in the map")
+        self.dim_size = idx.d
+        self.faiss_index = FaissIndex(idx, passage_ids or None)
+
+    def save(self, output_dir: str, prefix: str = "my-index", ext: str = "flat"):
+        super().save(output_dir, prefix, ext)
 
     def get_index_name(self):
         return "flat_faiss_index"

@@ -229,3 +229,27 @@ def test_checkpoint_dir_to_search_via_reference_entry_point(tmp_path):
     table = O.construct_embedding_bag(cfg_o, w, model.tokenizer.bos_token_id, model.tokenizer.eos_token_id,
                                       model.tokenizer.encode("query: ", add_special_tokens=False), vocab_len=len(model.tokenizer))
     assert min_cos(model.model.emb_bag.cpu().numpy(), table) > 0.995
+
+
+def test_index_save_load_round_trip(tmp_path):
+    """N4: FlatIPFaissSearch.save -> {prefix}.flat.faiss + .tsv -> load in a fresh searcher: same hits, no re-encoding."""
+    from lightretriever_amd.retriever import FlatIPFaissSearch
+    from lightretriever_amd.index_io import read_flat_ip
+    rng = np.random.default_rng(4)
+    N, D = 1234, 96
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32))
+    q = O.l2_normalize(rng.standard_normal((7, D)).astype(np.float32))
+    cids = ["doc/%d" % i for i in range(N)]
+    a = FlatIPFaissSearch(model=None, batch_size=8)
+    a.index(torch.from_numpy(X), cids)
+    want = a.retrieve_with_emb(torch.from_numpy(q).cuda(), ["q%d" % i for i in range(7)], top_k=25)
+    a.save(str(tmp_path), prefix="my-index")
+    assert sorted(os.listdir(tmp_path)) == ["my-index.flat.faiss", "my-index.flat.tsv"]
+    np.testing.assert_array_equal(np.asarray(read_flat_ip(str(tmp_path / "my-index.flat.faiss"))), X)
+    b = FlatIPFaissSearch(model=None, batch_size=8)
+    b.load(str(tmp_path), prefix="my-index")
+    assert b.dim_size == D and b.faiss_index.index.ntotal == N and b.mapping == a.mapping
+    got = b.retrieve_with_emb(torch.from_numpy(q).cuda(), ["q%d" % i for i in range(7)], top_k=25)
+    assert got == want
+    Dw, Iw = O.flat_ip_topk(q, X, 25)
+    assert [list(got["q0"].keys())[j] for j in range(25)] == ["doc/%d" % i for i in Iw[0]]

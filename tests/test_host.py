@@ -220,3 +220,37 @@ def test_sparse_token_mask_matches_reference_rule(tok):
     m, cu3 = out["sparse_mask"].numpy(), out["cu_seqlens"].numpy()
     assert m.dtype == np.uint8 and m.shape[0] == cu3[-1]
     assert m[cu3[:-1]].sum() == 0 and m[cu3[1:] - 1].sum() == 0 and m.sum() == cu3[-1] - 2 * (len(cu3) - 1)
+
+
+def test_flat_index_file_layout_and_round_trip(tmp_path):
+    """N4: the {prefix}.flat.faiss file is Faiss's IndexFlatIP serialisation (index_write.cpp): header bytes spelled out here."""
+    import struct
+    from lightretriever_amd import index_io as io
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1000, 64)).astype(np.float32)
+    f = str(tmp_path / "my-index.flat.faiss")
+    io.write_flat_ip(f, [x[:300], x[300:301], x[301:]], 64, 1000)
+    raw = open(f, "rb").read()
+    want = b"IxFI" + struct.pack("<i", 64) + struct.pack("<q", 1000) + struct.pack("<qq", 1 << 20, 1 << 20) + b"\x01" + struct.pack("<i", 0) \
+        + struct.pack("<Q", 64000)
+    assert raw[:len(want)] == want and len(want) == io.HEADER_BYTES == 45
+    assert raw[len(want):] == x.tobytes()
+    mm = io.read_flat_ip(f)
+    assert mm.shape == (1000, 64) and not mm.flags.writeable
+    np.testing.assert_array_equal(np.asarray(mm), x)
+    io.write_flat_ip(str(tmp_path / "empty.faiss"), [], 32, 0)                       # empty shard (a rank without rows)
+    assert io.read_flat_ip(str(tmp_path / "empty.faiss")).shape == (0, 32)
+    with pytest.raises(ValueError):
+        io.write_flat_ip(str(tmp_path / "bad.faiss"), [x[:10]], 64, 11)             # row count mismatch
+    assert not os.path.exists(str(tmp_path / "bad.faiss"))                          # nothing half-written under the final name
+    for corrupt in (b"IxF2" + raw[4:], raw[:-4], raw[:8] + struct.pack("<q", 999) + raw[16:]):
+        open(str(tmp_path / "c.faiss"), "wb").write(corrupt)
+        with pytest.raises(ValueError):
+            io.read_flat_ip(str(tmp_path / "c.faiss"))
+    # id map: same TSV as save_dict_to_tsv / load_tsv_to_dict (header row, QUOTE_MINIMAL)
+    mapping = {"doc-1": 0, "with\ttab": 1, 'quo"te': 2, "ünï": 3}
+    t = str(tmp_path / "my-index.flat.tsv")
+    io.save_dict_to_tsv(mapping, t, keys=io.MAPPING_TSV_KEYS)
+    assert open(t, encoding="utf-8").readline().rstrip("\r\n") == "beir-docid\tfaiss-docid"
+    assert io.load_tsv_to_dict(t) == mapping
+    assert io.shard_prefix("my-index") == "my-index" and io.shard_prefix("my-index", 3, 8) == "my-index.rank3-of-8"
