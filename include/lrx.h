@@ -243,6 +243,17 @@ int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim,
                        int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* Same result as lrx_flat_ip_search (exact top-k, ids ascending among equal scores) for shards whose rows satisfy
+ * |x_row| <= *row_norm_bound (DEVICE pointer to one float, e.g. 1 for L2-normalised embeddings), at close to one HBM pass for
+ * 32 < Q: a single-product bf16 filter pass bounds every score to +-0.0045 |q| R, the rows inside that band of the k-th filter
+ * score are rescored exactly from the fp32 rows (fp64 accumulation, one rounding) and sorted.  Queries whose band overflows the
+ * on-chip candidate list are redone by the six-product path (gated on a device flag, no host sync).  Scores returned are the
+ * exactly rescored ones.  A bound smaller than the true row norms voids the guarantee.                                       */
+size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k);
+int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* row_norm_bound,
+                               const float* q, int32_t n_queries, int32_t k, int64_t id_base, float* out_scores,
+                               int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Score pass only: scores[Q, ld] fp32 with ld = lrx_flat_ip_score_ld(N); columns >= N hold -FLT_MAX. */
 int64_t lrx_flat_ip_score_ld(int64_t n_rows);
 int lrx_flat_ip_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries,

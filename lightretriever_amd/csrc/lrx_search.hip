@@ -12,6 +12,11 @@
 //     elements), LDS bitonic sort on (score desc, row asc).  Fallback when the gather overflows (heavy ties) or the
 //     index is small: exact 4 x 8-bit radix select of the k-th largest score + gather of everything strictly greater
 //     plus the lowest-row-id ties.  Deterministic output regardless of atomics order on both paths.
+//  2b. Every path ends with exact rescoring of the selected rows (k_rescore_topk / k_refine_topk: fp64 accumulation, one rounding
+//     to fp32), so the reported scores do not depend on the path, the query batch size or the shard layout.  For Q > 32 and rows
+//     with a known norm bound the search is two-pass (lrx_flat_ip_search_bounded): a single-product bf16 FILTER pass
+//     (k_flat_ip_scores_split<QT, 1, ..>, HBM-bound) + exact refinement of the rows inside a rigorous error band, with the
+//     six-product pass as a device-gated fallback.
 //  3. k_merge_topk: merge of R per-shard [Q,k] lists (after the RCCL all-gather) with the same ordering rule.
 #include "lrx_common.h"
 #include <float.h>
@@ -153,8 +158,9 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)r2;
 }
 
-// qs layout: [D/32 slices][3 planes][QT][64 lanes][8] bf16
-__global__ void k_split_queries(const float* __restrict__ Q, int nq, int D, int QT, __bf16* __restrict__ qs) {
+// qs layout: [D/32 slices][NP planes][QT][64 lanes][8] bf16   (NP = 3: hi/mid/lo, NP = 1: hi only)
+__global__ void k_split_queries(const float* __restrict__ Q, int nq, int D, int QT, int NP, __bf16* __restrict__ qs, const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
   int gid = blockIdx.x * blockDim.x + threadIdx.x;
   int lane = gid & 63, rest = gid >> 6;
   int qt = rest % QT, kt = rest / QT;
@@ -170,29 +176,49 @@ __global__ void k_split_queries(const float* __restrict__ Q, int nq, int D, int 
     split3(v, a, b, c);
     h[j] = a; m[j] = b; l[j] = c;
   }
-  int64_t base = (((int64_t)kt * 3) * QT + qt) * 64 + lane;
+  int64_t base = (((int64_t)kt * NP) * QT + qt) * 64 + lane;
   bf16x8* out = (bf16x8*)qs;
   out[base] = h;
-  out[base + (int64_t)QT * 64] = m;
-  out[base + 2 * (int64_t)QT * 64] = l;
+  if (NP == 3) {
+    out[base + (int64_t)QT * 64] = m;
+    out[base + 2 * (int64_t)QT * 64] = l;
+  }
 }
 
-template <int QT>
-__global__ void __launch_bounds__(256, 2)
+// RT = 16-row tiles per wave (rows per workgroup = 64 RT), NST = LDS stages of the k-slice ring.  The six-product kernel runs
+// (RT 2, NST 2, two workgroups per CU: it is bound by the matrix pipe); the single-product filter kernel is HBM-bound and runs the
+// deeper / wider shape selected by SPF_RT / SPF_NST.
+#ifndef SPF_RT
+#define SPF_RT 2
+#endif
+#ifndef SPF_NST
+#define SPF_NST 2
+#endif
+#ifndef SPF_WV
+#define SPF_WV 8
+#endif
+template <int QT, int NP, int RT, int NST, int WV>
+__global__ void __launch_bounds__(64 * WV, (NST * (16 * RT * WV * 128 + ((NP * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1)
 k_flat_ip_scores_split(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
-                       float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld) {
-  constexpr int QBYTES = 3 * QT * 1024;          // q planes of one k-slice
-  constexpr int XT = SP_ROWS * S_BK * 4;         // 16 KiB: 128 corpus rows per workgroup -> 2 workgroups per CU
+                       float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate) {
+  constexpr int RB = 16 * RT * WV;               // corpus rows per workgroup (WV waves x RT 16-row tiles)
+  constexpr int QINST = NP * QT;                 // 1-KiB LDS-DMA instructions per q slice
+  constexpr int QI4 = (QINST + WV - 1) / WV;     // ... per wave (the last ones re-load the final plane into padding: equal counts per wave)
+  constexpr int QBYTES = QI4 * WV * 1024;
+  constexpr int XT = RB * S_BK * 4;              // X k-slice: RB rows x 128 B
   constexpr int STAGE = XT + QBYTES;
-  constexpr int QINST = 3 * QT;                  // 1-KiB LDS-DMA instructions per q slice
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t n0 = (int64_t)blockIdx.x * SP_ROWS;
+  constexpr int CW = 2 * RT + QI4;               // DMA instructions per wave per stage
+  static_assert((NST - 1) * CW <= 63, "vmcnt immediate");
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
+  if (gate != nullptr && *gate == 0) return;     // fallback launch of the bounded search: nothing overflowed
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t n0 = (int64_t)blockIdx.x * RB;
 
-  const float* px[4];
+  const float* px[2 * RT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int s = (wave * 4 + i) * 64 + lane;
+  for (int i = 0; i < 2 * RT; ++i) {
+    int s = (wave * 2 * RT + i) * 64 + lane;
     int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
     int64_t g = min(n0 + row, N - 1);
     px[i] = X + g * ldx + c * 4;
@@ -202,10 +228,14 @@ k_flat_ip_scores_split(const float* __restrict__ X, int64_t N, int64_t ldx, int 
     char* sX = smem + st * STAGE;
     char* sQ = sX + XT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + kt * S_BK), (lptr_t)(sX + (wave * 4 + i) * 1024), 16, 0, 0);
-    for (int j = wave; j < QINST; j += 4)
-      __builtin_amdgcn_global_load_lds((gptr_t)(pq + ((int64_t)kt * QINST + j) * 512), (lptr_t)(sQ + j * 1024), 16, 0, 0);
+    for (int i = 0; i < 2 * RT; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + kt * S_BK), (lptr_t)(sX + (wave * 2 * RT + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int jj = 0; jj < QI4; ++jj) {
+      const int j = wave + WV * jj;
+      const int jsrc = j < QINST ? j : QINST - 1;
+      __builtin_amdgcn_global_load_lds((gptr_t)(pq + ((int64_t)kt * QINST + jsrc) * 512), (lptr_t)(sQ + j * 1024), 16, 0, 0);
+    }
   };
 
   const int fi = lane & 15, fq = lane >> 4;
@@ -213,82 +243,128 @@ k_flat_ip_scores_split(const float* __restrict__ X, int64_t N, int64_t ldx, int 
   const int xoff0 = fi * 128 + ((fq ^ xs) << 4);          // chunk fq      : k = 4fq .. 4fq+3
   const int xoff1 = fi * 128 + (((4 + fq) ^ xs) << 4);    // chunk 4 + fq  : k = 16+4fq ..
 
-  f32x4 acc[2][QT];
+  f32x4 acc[RT][QT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = D / S_BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* sX = smem + cur * STAGE + (wave * 32) * 128;
-    const char* sQ = smem + cur * STAGE + XT + lane * 16;
-    bf16x8 xh[2], xm[2], xl[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nk) stage(st, st);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt % NST;
+    // stage kt has landed when at most the (NST-2) younger stages' instructions of this wave are outstanding
+    if (NST > 2 && kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * CW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // everyone's part of stage kt is in LDS; slot (kt-1) % NST is free
+    if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST, kt + NST - 1);
+    const char* sX = smem + cur * STAGE + (wave * 16 * RT) * 128;
+    const char* sQ = smem + cur * STAGE + XT + lane * 16;
+    bf16x8 xh[RT], xm[NP == 3 ? RT : 1], xl[NP == 3 ? RT : 1];
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
       f32x4 v0 = *(const f32x4*)(sX + a * 2048 + xoff0);
       f32x4 v1 = *(const f32x4*)(sX + a * 2048 + xoff1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        __bf16 h, m, l;
-        split3(v0[j], h, m, l);
-        xh[a][j] = h; xm[a][j] = m; xl[a][j] = l;
-        split3(v1[j], h, m, l);
-        xh[a][4 + j] = h; xm[a][4 + j] = m; xl[a][4 + j] = l;
+        if (NP == 3) {
+          __bf16 h, m, l;
+          split3(v0[j], h, m, l);
+          xh[a][j] = h; xm[a][j] = m; xl[a][j] = l;
+          split3(v1[j], h, m, l);
+          xh[a][4 + j] = h; xm[a][4 + j] = m; xl[a][4 + j] = l;
+        } else {
+          xh[a][j] = (__bf16)v0[j];
+          xh[a][4 + j] = (__bf16)v1[j];
+        }
       }
     }
 #pragma unroll
     for (int b = 0; b < QT; ++b) {
       bf16x8 qh = *(const bf16x8*)(sQ + b * 1024);
-      bf16x8 qm = *(const bf16x8*)(sQ + (QT + b) * 1024);
-      bf16x8 ql = *(const bf16x8*)(sQ + (2 * QT + b) * 1024);
+      if (NP == 3) {
+        bf16x8 qm = *(const bf16x8*)(sQ + (QT + b) * 1024);
+        bf16x8 ql = *(const bf16x8*)(sQ + (2 * QT + b) * 1024);
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        f32x4 c = acc[a][b];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[a], qh, c, 0, 0, 0);   // small terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], ql, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm[a], qm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm[a], qh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], qm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], qh, c, 0, 0, 0);
-        acc[a][b] = c;
+        for (int a = 0; a < RT; ++a) {
+          f32x4 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[a], qh, c, 0, 0, 0);   // small terms first
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], ql, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm[a], qm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm[a], qh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], qm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], qh, c, 0, 0, 0);
+          acc[a][b] = c;
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], qh, acc[a][b], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
+  __syncthreads();   // the k loop's last LDS reads are done before the epilogue reuses the buffer
 
-  // D[i = corpus row][j = query]: lane holds query j = fi, rows fq*4 + {0..3}.  Also the per-(query, 256-row block)
-  // maximum, which gives k_topk_select a safe threshold without an extra pass over the scores.
-  float* wmax = (float*)smem;  // [4 waves][QT*16]   (LDS is free: the k loop ended with a barrier)
+  // D[i = corpus row][j = query]: lane holds query j = fi, rows fq*4 + {0..3}.  First the per-(query, 128-row block) maximum,
+  // which gives k_topk_select a safe threshold without an extra pass over the scores.
+  constexpr int WPG = 8 / RT;                    // waves per 128-row group
+  float* wmax = (float*)smem;  // [WV waves][QT*16]
 #pragma unroll
   for (int b = 0; b < QT; ++b) {
     int qi = b * 16 + fi;
     float mx = -FLT_MAX;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      int64_t n = n0 + wave * 32 + a * 16 + fq * 4;
-      f32x4 v = acc[a][b];
+    for (int a = 0; a < RT; ++a) {
+      int64_t n = n0 + wave * 16 * RT + a * 16 + fq * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (n + e >= N) v[e] = -FLT_MAX;
-        mx = fmaxf(mx, v[e]);
+        if (n + e >= N) acc[a][b][e] = -FLT_MAX;
+        mx = fmaxf(mx, acc[a][b][e]);
       }
-      if (qi < nq) *(f32x4*)(scores + (int64_t)qi * ld + n) = v;
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (fq == 0) wmax[wave * (QT * 16) + qi] = mx;
   }
   __syncthreads();
-  if (blkmax != nullptr && tid < QT * 16 && tid < nq) {
-    float mx = fmaxf(fmaxf(wmax[tid], wmax[QT * 16 + tid]), fmaxf(wmax[2 * QT * 16 + tid], wmax[3 * QT * 16 + tid]));
-    blkmax[(int64_t)tid * nblk_ld + blockIdx.x] = mx;
+  if (blkmax != nullptr) {
+    for (int t = tid; t < (RB / 128) * QT * 16; t += 64 * WV) {
+      const int grp = t / (QT * 16), qi = t % (QT * 16);
+      if (qi < nq) {
+        float mx = -FLT_MAX;
+#pragma unroll
+        for (int w = 0; w < WPG; ++w) mx = fmaxf(mx, wmax[(grp * WPG + w) * (QT * 16) + qi]);
+        blkmax[(int64_t)qi * nblk_ld + (int64_t)blockIdx.x * (RB / 128) + grp] = mx;
+      }
+    }
+  }
+  // Scores: the accumulator layout would store 64-B pieces into 16 different query rows per instruction (measured: 0.18 ms of
+  // the 1.8 ms filter pass at Q = 100).  Staged through LDS instead -- [query][RB rows] with a 16-B pad per query, conflict-free
+  // ds_write_b128 -- and written as whole RB*4-byte row segments, 1 KiB contiguous per wave instruction.
+  constexpr int SEG = RB * 4 + 16;
+  constexpr int QPT = ((NST * STAGE) / SEG / 16) < QT ? ((NST * STAGE) / SEG / 16) : QT;   // q-tiles staged per pass
+  static_assert(QPT >= 1, "epilogue staging does not fit");
+  constexpr int NPASS = (QT + QPT - 1) / QPT;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < QT; ++b) {
+      if (b / QPT == ps) {
+#pragma unroll
+        for (int a = 0; a < RT; ++a)
+          *(f32x4*)(smem + ((b - ps * QPT) * 16 + fi) * SEG + (wave * 16 * RT + a * 16 + fq * 4) * 4) = acc[a][b];
+      }
+    }
+    __syncthreads();
+    const int nqt = (QT - ps * QPT) < QPT ? (QT - ps * QPT) : QPT;
+    for (int idx = tid; idx < nqt * 16 * (RB / 4); idx += 64 * WV) {
+      const int ql = idx / (RB / 4), c = idx % (RB / 4);
+      const int qi = ps * QPT * 16 + ql;
+      if (qi < nq)
+        *(f32x4*)(scores + (int64_t)qi * ld + n0 + c * 4) = *(const f32x4*)(smem + ql * SEG + c * 16);
+    }
   }
 }
 
@@ -298,8 +374,10 @@ extern "C" int64_t lrx_flat_ip_score_ld(int64_t n_rows) { return lrx_cdiv(n_rows
 #define SPLIT_MIN_QT 3   // Q > 32 -> split-bf16 kernel (fp32-MFMA-bound otherwise); Q <= 32 stays on the exact-fp32 kernel (HBM-bound)
 static size_t split_ws_bytes(int32_t dim) { return (size_t)(dim / 32) * 3 * 8 * 1024; }   // one chunk of <=128 queries
 
+// planes = 3: fp32-grade scores (six bf16 products); planes = 1: one bf16 product, |error| <= FILTER_EPS * |q| * |x| (filter pass
+// of the bounded search); gate != NULL: the whole pass is skipped unless *gate != 0.
 static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, float* scores,
-                         float* blkmax, __bf16* qsplit, void* stream) {
+                         float* blkmax, __bf16* qsplit, void* stream, int planes = 3, const int* gate = nullptr) {
   LRX_CHECK_ARG(dim > 0 && dim % S_BK == 0, "flat_ip: dim=%d must be a multiple of %d", dim, S_BK);
   LRX_CHECK_ARG(ldx >= dim && ldx % 4 == 0, "flat_ip: ldx=%lld must be >= dim and a multiple of 4", (long long)ldx);
   if (n_rows <= 0 || n_queries <= 0) return LRX_OK;
@@ -315,8 +393,12 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
     float* bp = blkmax ? blkmax + (int64_t)q0 * nblk_ld : nullptr;
     if (qsplit != nullptr && qt >= SPLIT_MIN_QT) {
       int threads = (dim / 32) * qt * 64;
-      hipLaunchKernelGGL(k_split_queries, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit);
-#define LRX_SS(QQ) case QQ: hipLaunchKernelGGL(k_flat_ip_scores_split<QQ>, dim3((unsigned)(ld / SP_ROWS)), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld); break;
+      hipLaunchKernelGGL(k_split_queries, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, planes, qsplit, gate);
+#define LRX_SS(QQ)                                                                                                                              \
+  case QQ:                                                                                                                                      \
+    if (planes == 3) hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 3, 2, 2, 4>), dim3((unsigned)(ld / 128)), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate); \
+    else hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPF_RT, SPF_NST, SPF_WV>), dim3((unsigned)(ld / (16 * SPF_RT * SPF_WV))), dim3(64 * SPF_WV), 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate); \
+    break;
       switch (qt) { LRX_SS(3) LRX_SS(4) LRX_SS(5) LRX_SS(6) LRX_SS(7) LRX_SS(8) }
 #undef LRX_SS
       LRX_LAUNCH_CHECK();
@@ -434,8 +516,11 @@ __device__ __forceinline__ unsigned long long sel_pack(uint32_t key, int64_t i) 
 
 __global__ void __launch_bounds__(SEL_THREADS)
 k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base, const float* __restrict__ blkmax, int nblk,
-              int nblk_ld, float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
+              int nblk_ld, float* __restrict__ out_scores, int64_t* __restrict__ out_ids, const int* __restrict__ gate,
+              const int* __restrict__ qflags) {
   __shared__ SelShared sh;
+  if (gate != nullptr && *gate == 0) return;                 // fallback launch of the bounded search: nothing overflowed
+  if (qflags != nullptr && qflags[blockIdx.x] == 0) return;  // ... or not this query
   const float* row = scores + (int64_t)blockIdx.x * ld;
   float* os = out_scores + (int64_t)blockIdx.x * k;
   int64_t* oi = out_ids + (int64_t)blockIdx.x * k;
@@ -454,30 +539,34 @@ k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, in
     done = true;
   } else if (blkmax != nullptr && nblk >= keff) {
     unsigned int ne, nq_;
-    const uint32_t thr = radix_select_kth(blkmax + (int64_t)blockIdx.x * nblk_ld, nblk, keff, sh, ne, nq_);
-    if (tid == 0) sh.ngt = 0;
+    const float* bm = blkmax + (int64_t)blockIdx.x * nblk_ld;
+    const uint32_t thr = radix_select_kth(bm, nblk, keff, sh, ne, nq_);
+    if (tid == 0) { sh.ngt = 0; sh.neq = 0; }
     __syncthreads();
-    const int64_t n4 = N >> 2;
-    for (int64_t i = tid; i < n4; i += SEL_THREADS) {
-      f32x4 v = *(const f32x4*)(row + 4 * i);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        uint32_t key = f2key(v[e]);
-        if (key >= thr) {
-          unsigned int p = atomicAdd(&sh.ngt, 1u);
-          if (p < SEL_CAND) sh.cand[p] = sel_pack(key, 4 * i + e);
+    // only 128-row blocks whose maximum reaches the threshold can hold an element >= threshold: list them (normally ~keff
+    // blocks), then scan just those instead of the whole row
+    unsigned int* blist = (unsigned int*)sh.eqs;            // 2 * SEL_EQCAP entries (the tie buffers are idle on this path)
+    for (int b = tid; b < nblk; b += SEL_THREADS)
+      if (f2key(bm[b]) >= thr) {
+        const unsigned int p = atomicAdd(&sh.neq, 1u);
+        if (p < 2 * SEL_EQCAP) blist[p] = (unsigned int)b;
+      }
+    __syncthreads();
+    const unsigned int nb = sh.neq;
+    if (nb <= 2 * SEL_EQCAP) {
+      for (unsigned int idx = tid; idx < nb * SP_ROWS; idx += SEL_THREADS) {
+        const int64_t i = (int64_t)blist[idx >> 7] * SP_ROWS + (idx & (SP_ROWS - 1));
+        if (i < N) {
+          const uint32_t key = f2key(row[i]);
+          if (key >= thr) {
+            const unsigned int p = atomicAdd(&sh.ngt, 1u);
+            if (p < SEL_CAND) sh.cand[p] = sel_pack(key, i);
+          }
         }
       }
+      __syncthreads();
+      if (sh.ngt <= SEL_CAND) { ncand = (int)sh.ngt; done = true; }
     }
-    for (int64_t i = 4 * n4 + tid; i < N; i += SEL_THREADS) {
-      uint32_t key = f2key(row[i]);
-      if (key >= thr) {
-        unsigned int p = atomicAdd(&sh.ngt, 1u);
-        if (p < SEL_CAND) sh.cand[p] = sel_pack(key, i);
-      }
-    }
-    __syncthreads();
-    if (sh.ngt <= SEL_CAND) { ncand = (int)sh.ngt; done = true; }
     __syncthreads();
   }
 
@@ -534,6 +623,60 @@ k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, in
   }
 }
 
+// q . x over D (multiple of 4) fp32 elements by one wave: fp64 accumulation of the exact fp32 products, one final rounding to
+// fp32 -- the value every search path reports, so scores do not depend on the path, the query batch size or the shard layout.
+__device__ __forceinline__ float exact_dot(const float* __restrict__ x, const float* __restrict__ qrow, int D, int lane) {
+  double acc = 0.0;
+  for (int i0 = lane * 4; i0 < D; i0 += 1024) {          // four 1-KiB row segments in flight per wave
+    f32x4 xv[4], qv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      const bool in = i < D;
+      xv[u] = in ? *(const f32x4*)(x + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      qv[u] = in ? *(const f32x4*)(qrow + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      acc += (double)xv[u][0] * (double)qv[u][0] + (double)xv[u][1] * (double)qv[u][1] + (double)xv[u][2] * (double)qv[u][2] +
+             (double)xv[u][3] * (double)qv[u][3];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  return (float)acc;
+}
+
+// Final step of the plain path: the k selected rows of each query are rescored with exact_dot and re-sorted (score desc, id asc).
+__global__ void __launch_bounds__(1024)
+k_rescore_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ q, int k, int64_t id_base,
+               float* __restrict__ out_scores, int64_t* __restrict__ out_ids, const int* __restrict__ gate, const int* __restrict__ qflags) {
+  __shared__ unsigned long long s_c[SEL_MAXK];
+  if (gate != nullptr && *gate == 0) return;
+  if (qflags != nullptr && qflags[blockIdx.x] == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* os = out_scores + (int64_t)blockIdx.x * k;
+  int64_t* oi = out_ids + (int64_t)blockIdx.x * k;
+  const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
+  if (keff == 0) return;
+  const float* qrow = q + (int64_t)blockIdx.x * D;
+  for (int c = wave; c < keff; c += 16) {
+    int64_t n = oi[c] - id_base;
+    n = n < 0 ? 0 : (n >= N ? N - 1 : n);          // never index outside the shard, whatever the select stage handed over
+    const float sc = exact_dot(X + n * ldx, qrow, D, lane);
+    if (lane == 0) s_c[c] = sel_pack(f2key(sc), n);
+  }
+  __syncthreads();
+  int P = 1;
+  while (P < keff) P <<= 1;
+  for (int i = keff + tid; i < P; i += 1024) s_c[i] = 0ull;
+  bitonic_sort_desc(s_c, P);
+  for (int i = tid; i < keff; i += 1024) {
+    const unsigned long long c = s_c[i];
+    os[i] = key2f((uint32_t)(c >> 32));
+    oi[i] = id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
+  }
+}
+
 extern "C" size_t lrx_flat_ip_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
   (void)k;
   const size_t ld = (size_t)lrx_flat_ip_score_ld(n_rows), nq = (size_t)(n_queries > 0 ? n_queries : 1);
@@ -561,7 +704,150 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
     if (rc != LRX_OK) return rc;
   }
   hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, scores, ld, n_rows, k, id_base, blkmax, nblk,
-                     nblk_ld, out_scores, out_ids);
+                     nblk_ld, out_scores, out_ids, (const int*)nullptr, (const int*)nullptr);
+  LRX_LAUNCH_CHECK();
+  if (n_rows > 0 && dim % 4 == 0) {
+    hipLaunchKernelGGL(k_rescore_topk, dim3(n_queries), dim3(1024), 0, (hipStream_t)stream, X, n_rows, ldx, dim, q, k, id_base, out_scores, out_ids,
+                       (const int*)nullptr, (const int*)nullptr);
+    LRX_LAUNCH_CHECK();
+  }
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Bounded two-pass search (Q > 32, rows with a known norm bound R): the same exact top-k at close to one HBM pass.
+//   pass 1  filter: s~ = bf16(q) . bf16(x) with ONE bf16 MFMA product (instead of six), fp32 accumulation.
+//           |s - s~| <= eps = FILTER_EPS * |q| * R, FILTER_EPS = 2^-8 + 2^-18 (two roundings to bf16, unit roundoff 2^-9 each, Cauchy-
+//           Schwarz over the element products) + 2048 * 2^-22 (a generous bound on the fp32 accumulation of <= 2048-term sums per
+//           2^-22-accurate addition) -> 0.0045.  k_topk_select on s~ gives kth~ = k-th largest s~.
+//   pass 2  refine (k_refine_topk, one workgroup per query): every row of the exact top-k has s~ >= kth~ - 2 eps (its exact score is
+//           >= the k-th largest exact score >= the k-th largest of (s~ - eps)), so all rows with s~ >= kth~ - 2 eps are gathered --
+//           whole 128-row blocks are skipped through the block maxima --, rescored exactly from the fp32 rows (fp64 accumulation,
+//           rounded once to fp32) and sorted (score desc, row asc).  Typical band content at 1M x 2048 normalised rows: ~500 rows.
+//   fallback: a query whose band holds more than REF_CAND rows or REF_BLK blocks (near-duplicate corpora) raises a device flag; the
+//           six-product pass + select are always enqueued behind it, gated on that flag (they return at once when it is 0), and
+//           overwrite only the flagged queries.  No host synchronisation anywhere.
+// ---------------------------------------------------------------------------------------------------------------
+#define FILTER_EPS 0.0045f
+#define REF_CAND 4096
+#define REF_BLK 8192
+
+__global__ void __launch_bounds__(1024)
+k_refine_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ q, const float* __restrict__ scores, int64_t ld,
+              const float* __restrict__ blkmax, int nblk, int nblk_ld, const float* __restrict__ row_norm_bound, int k, int64_t id_base,
+              float* __restrict__ out_scores, int64_t* __restrict__ out_ids, int* __restrict__ qflags, int* __restrict__ any_flag) {
+  __shared__ unsigned long long s_cand[REF_CAND];
+  __shared__ unsigned int s_blk[REF_BLK];
+  __shared__ float s_red[16];
+  __shared__ unsigned int s_nblk, s_ncand;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = blockIdx.x;
+  float* os = out_scores + (int64_t)qi * k;
+  int64_t* oi = out_ids + (int64_t)qi * k;
+  const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
+  if (tid == 0) { s_nblk = 0; s_ncand = 0; qflags[qi] = 0; }
+  if (keff == 0) return;                      // (outputs already padded by k_topk_select)
+  // |q|
+  const float* qrow = q + (int64_t)qi * D;
+  float ss = 0.f;
+  for (int i = tid; i < D; i += 1024) { const float v = qrow[i]; ss += v * v; }
+  ss = wave_sum(ss);
+  if (lane == 0) s_red[wave] = ss;
+  __syncthreads();
+  float qn2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) qn2 += s_red[w];
+  const float band = 2.0f * FILTER_EPS * sqrtf(qn2) * row_norm_bound[0] * 1.0001f + 1e-30f;
+  const float kth = os[keff - 1];             // k-th largest filter score (written by k_topk_select just before)
+  const float thr = kth - band;
+  // qualifying 128-row blocks
+  const float* bm = blkmax + (int64_t)qi * nblk_ld;
+  for (int b = tid; b < nblk; b += 1024)
+    if (bm[b] >= thr) {
+      const unsigned int p = atomicAdd(&s_nblk, 1u);
+      if (p < REF_BLK) s_blk[p] = (unsigned int)b;
+    }
+  __syncthreads();
+  const unsigned int nb = s_nblk;
+  bool overflow = nb > REF_BLK;
+  if (!overflow) {
+    const float* row = scores + (int64_t)qi * ld;
+    for (unsigned int idx = tid; idx < nb * SP_ROWS; idx += 1024) {
+      const int64_t n = (int64_t)s_blk[idx >> 7] * SP_ROWS + (idx & (SP_ROWS - 1));
+      if (n < N && row[n] >= thr) {
+        const unsigned int p = atomicAdd(&s_ncand, 1u);
+        if (p < REF_CAND) s_cand[p] = (unsigned long long)n;
+      }
+    }
+    __syncthreads();
+    overflow = s_ncand > REF_CAND;
+  }
+  if (overflow) {
+    if (tid == 0) { qflags[qi] = 1; atomicOr(any_flag, 1); }
+    return;
+  }
+  const int nc = (int)s_ncand;
+  // exact rescoring: one wave per candidate row, fp64 accumulation of the fp32 products, one rounding to fp32
+  for (int c = wave; c < nc; c += 16) {
+    const int64_t n = (int64_t)s_cand[c];
+    const float sc = exact_dot(X + n * ldx, qrow, D, lane);
+    if (lane == 0) s_cand[c] = sel_pack(f2key(sc), n);
+  }
+  __syncthreads();
+  int P = 1;
+  while (P < nc) P <<= 1;
+  for (int i = nc + tid; i < P; i += 1024) s_cand[i] = 0ull;
+  bitonic_sort_desc(s_cand, P);
+  for (int i = tid; i < keff; i += 1024) {
+    const unsigned long long c = s_cand[i];
+    os[i] = key2f((uint32_t)(c >> 32));
+    oi[i] = id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
+  }
+}
+
+extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
+  return lrx_flat_ip_workspace_bytes(n_rows, dim, n_queries, k) + ((size_t)(n_queries > 0 ? n_queries : 1) + 1) * sizeof(int) + 256;
+}
+
+extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* row_norm_bound, const float* q,
+                                          int32_t n_queries, int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  LRX_CHECK_ARG(row_norm_bound != nullptr, "flat_ip_search_bounded: null row_norm_bound (device pointer to max |x_row|)");
+  const int qt_max = ((n_queries < 128 ? n_queries : 128) + 15) / 16;
+  // small query batches are HBM-bound on the exact-fp32 kernel already; tiny shards and wide rows take the plain path too
+  if (qt_max < SPLIT_MIN_QT || n_rows <= REF_CAND || dim % 4 != 0)
+    return lrx_flat_ip_search(X, n_rows, ldx, dim, q, n_queries, k, id_base, out_scores, out_ids, workspace, workspace_bytes, stream);
+  LRX_CHECK_ARG(k > 0 && k <= SEL_MAXK, "flat_ip_search: k=%d out of range (1..%d)", k, SEL_MAXK);
+  LRX_CHECK_ARG(n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
+  if (workspace_bytes < lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k)) {
+    lrx_set_error("flat_ip_search_bounded: workspace %zu B < required %zu B", workspace_bytes, lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k));
+    return LRX_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* scores = (float*)workspace;
+  const int64_t ld = lrx_flat_ip_score_ld(n_rows);
+  float* blkmax = scores + ld * (int64_t)n_queries;
+  const int nblk = (int)(ld / SP_ROWS), nblk_ld = (nblk + 3) & ~3;
+  __bf16* qsplit = (__bf16*)(blkmax + (int64_t)nblk_ld * n_queries);
+  int* flags = (int*)(((uintptr_t)((char*)workspace + lrx_flat_ip_workspace_bytes(n_rows, dim, n_queries, k)) + 255) & ~(uintptr_t)255);
+  int* any_flag = flags + n_queries;
+  LRX_HIP(hipMemsetAsync(any_flag, 0, sizeof(int), s));
+  int rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, qsplit, stream, 1, nullptr);
+  if (rc != LRX_OK) return rc;
+  hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, s, scores, ld, n_rows, k, id_base, blkmax, nblk, nblk_ld, out_scores, out_ids,
+                     (const int*)nullptr, (const int*)nullptr);
+  LRX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_refine_topk, dim3(n_queries), dim3(1024), 0, s, X, n_rows, ldx, dim, q, scores, ld, blkmax, nblk, nblk_ld, row_norm_bound, k, id_base,
+                     out_scores, out_ids, flags, any_flag);
+  LRX_LAUNCH_CHECK();
+  // gated fallback for the flagged queries (returns immediately on the device when nothing overflowed)
+  rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, qsplit, stream, 3, any_flag);
+  if (rc != LRX_OK) return rc;
+  hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, s, scores, ld, n_rows, k, id_base, blkmax, nblk, nblk_ld, out_scores, out_ids,
+                     (const int*)any_flag, (const int*)flags);
+  LRX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_rescore_topk, dim3(n_queries), dim3(1024), 0, s, X, n_rows, ldx, dim, q, k, id_base, out_scores, out_ids, (const int*)any_flag,
+                     (const int*)flags);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

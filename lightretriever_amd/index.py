@@ -21,6 +21,10 @@ class FlatIPIndex:
         self.id_base = id_base  # added to local row numbers (global row of this shard's row 0)
         self._x = torch.empty(max(capacity, 0), d, dtype=torch.float32, device=self.device)
         self._ws = None
+        # max |row| over the committed rows, kept on the device (no host sync): the error bound of the bf16 filter pass of
+        # lrx_flat_ip_search_bounded scales with it.  two_pass = False forces the six-product path for every search.
+        self._norm_bound = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.two_pass = True
 
     # -- storage -------------------------------------------------------------------------------------------------
     def reserve(self, n_rows: int):
@@ -38,6 +42,9 @@ class FlatIPIndex:
         return self._x[self.ntotal:self.ntotal + n_rows]
 
     def commit(self, n_rows: int):
+        if n_rows > 0:
+            new = self._x[self.ntotal:self.ntotal + n_rows]
+            torch.maximum(self._norm_bound, torch.linalg.vector_norm(new, dim=1).max().reshape(1) * (1.0 + 1e-6), out=self._norm_bound)
         self.ntotal += n_rows
 
     def add(self, x):
@@ -50,8 +57,16 @@ class FlatIPIndex:
         slot.copy_(x.to(dtype=torch.float32))
         self.commit(x.shape[0])
 
+    def refresh_norm_bound(self):
+        """Recompute max |row| over all committed rows (call after writing into committed rows in place)."""
+        self._norm_bound.zero_()
+        for s in range(0, self.ntotal, 262144):
+            e = min(s + 262144, self.ntotal)
+            torch.maximum(self._norm_bound, torch.linalg.vector_norm(self._x[s:e], dim=1).max().reshape(1) * (1.0 + 1e-6), out=self._norm_bound)
+
     def reset(self):
         self.ntotal = 0
+        self._norm_bound.zero_()
 
     # -- persistence (faiss.write_index / read_index of an IndexFlatIP, see index_io.py) --------------------------
     def save(self, fname: str, chunk_rows: int = 262144):
@@ -68,7 +83,7 @@ class FlatIPIndex:
         for s in range(0, mm.shape[0], chunk_rows):
             e = min(s + chunk_rows, mm.shape[0])
             idx._x[s:e].copy_(torch.from_numpy(np.ascontiguousarray(mm[s:e])), non_blocking=False)
-        idx.ntotal = mm.shape[0]
+        idx.commit(mm.shape[0])
         return idx
 
     @property
@@ -89,13 +104,18 @@ class FlatIPIndex:
         I = torch.empty(Q, k, dtype=torch.int64, device=self.device)
         if Q == 0:
             return D, I
-        need = int(self.lib.lrx_flat_ip_workspace_bytes(self.ntotal, self.d, Q, k))
+        need = int(self.lib.lrx_flat_ip_bounded_workspace_bytes(self.ntotal, self.d, Q, k))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, self._x.stride(0) if self._x.shape[0] else self.d,
-                                               self.d, _lib.ptr(q), Q, k, self.id_base, _lib.ptr(D), _lib.ptr(I), _lib.ptr(self._ws),
-                                               self._ws.numel(), _lib.current_stream()))
+            self._ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        ldx = self._x.stride(0) if self._x.shape[0] else self.d
+        if self.two_pass:
+            _lib.check(self.lib.lrx_flat_ip_search_bounded(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(self._norm_bound), _lib.ptr(q), Q, k,
+                                                           self.id_base, _lib.ptr(D), _lib.ptr(I), _lib.ptr(self._ws), self._ws.numel(),
+                                                           _lib.current_stream()))
+        else:
+            _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(q), Q, k, self.id_base, _lib.ptr(D),
+                                                   _lib.ptr(I), _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))
         return D, I
 
 
