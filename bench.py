@@ -125,6 +125,12 @@ def pmc_traffic(kernel_key):
         return None
 
 
+def pmc_search_traffic():
+    """filter pass + select + refine of one search (same PMC summary); None when the summary predates the two-pass search."""
+    parts = [pmc_traffic(k) for k in ("k_flat_ip_scores_split<NP=1>", "k_topk_select", "k_refine_topk")]
+    return None if any(p is None for p in parts) else sum(parts)
+
+
 def pmc_mfma(kernel_key):
     """(mfma busy fraction, effective clock GHz) of a kernel from the committed PMC pass (tools/pmc_mfma.sh) or (None, None)."""
     try:
@@ -248,7 +254,7 @@ def main():
             "dim": D, "shard_rows": shard_rows, "scaling": "strong (fixed index row-sharded over ranks)",
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (local_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(alg_bytes / (local_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                         "traffic": pmc_traffic("k_flat_ip_scores_split") if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100) else None,
+                         "traffic": pmc_search_traffic() if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100) else None,
                          "algorithmic_bytes": alg_bytes,
                          "kernel": "two-pass exact search: k_flat_ip_scores_split<QT,1> (single-product bf16 filter, HBM-bound) + k_topk_select + k_refine_topk (exact fp64-accumulated rescoring of the error band); six-product pass as device-gated fallback (local shard search, HIP events)", "ms": round(local_ms, 4),
                          "fp32_equiv_tflops": round(2.0 * args.queries * D * shard_rows / (local_ms * 1e-3) / 1e12, 2),
@@ -279,7 +285,8 @@ def main():
                   "unit": "docs/s", "steps": n_sp, "ms_per_step": round(1e3 * sp_s / n_sp, 3),
                   "roofline": {"bound": "mfma", "kernel": "k_gemm_bf16_nt<EPI_MAXAGG> (M=%d N=%d K=%d, segmented column max in the epilogue)" % (B * S, cfg.vocab_size, D),
                                "achieved": round(mx_fl / (mx_ms / n_sp * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(mx_fl / (mx_ms / n_sp * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(mx_ms / n_sp, 3)}}
+                               "frac": round(mx_fl / (mx_ms / n_sp * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(mx_ms / n_sp, 3),
+                               "traffic": pmc_traffic("k_gemm_bf16_nt<4>") if (args.model == "llama3.2-1b" and B == 256 and S == 512) else None}}
 
     if rank != 0:
         if distributed:

@@ -12,8 +12,13 @@ def load(d, counter):
                 rows[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return rows
 
+import re
+
 def short(name):
-    for k in ("k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_gemm_bf16_nt<0>", "k_attn_resident64", "k_attn_varlen_causal", "k_rmsnorm", "k_rope", "k_flat_ip_scores_split", "k_flat_ip_scores", "k_topk_select"):
+    m = re.search(r"k_flat_ip_scores_split<(\d+), (\d+)", name)
+    if m:
+        return "k_flat_ip_scores_split<NP=%s>" % m.group(2)     # NP=1: filter pass, NP=3: six-product pass (gated fallback launches are dropped below)
+    for k in ("k_gemm_bf16_nt<4>", "k_refine_topk", "k_rescore_topk", "k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_gemm_bf16_nt<0>", "k_attn_resident64", "k_attn_varlen_causal", "k_rmsnorm", "k_rope", "k_flat_ip_scores_split", "k_flat_ip_scores", "k_topk_select"):
         if k in name:
             return k
     return None
@@ -25,6 +30,7 @@ for counter, sub, corr in (("FETCH_SIZE", "fetch", 2.0), ("WRITE_SIZE", "write",
         s = short(name)
         if not s:
             continue
+        vals = [v for v in vals if v >= 0.01 * max(vals)] if max(vals) > 0 else vals     # device-gated launches that returned at once
         e = out.setdefault(s, {})
         e[counter + "_KiB_avg_raw"] = sum(vals) / len(vals)
         e[counter + "_bytes_avg_corrected"] = sum(vals) / len(vals) * 1024 * corr
