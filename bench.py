@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--index-rows", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--topk", type=int, default=100)
-    ap.add_argument("--model", default="llama3.2-1b", choices=["llama3.2-1b", "llama3.1-8b"])
+    ap.add_argument("--model", default="llama3.2-1b", choices=["llama3.2-1b", "llama3.1-8b", "qwen2.5-1.5b", "qwen2.5-7b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the dense+sparse document-vector leg (SURVEY 8f N2)")
@@ -155,7 +155,8 @@ def main():
     from lightretriever_amd import EncoderConfig, FlatIPIndex, LrxEncoder
     from lightretriever_amd.sharded import ShardedFlatIPIndex
 
-    cfg = EncoderConfig.llama32_1b(args.seq_len) if args.model == "llama3.2-1b" else EncoderConfig.llama31_8b(args.seq_len)
+    cfg = {"llama3.2-1b": EncoderConfig.llama32_1b, "llama3.1-8b": EncoderConfig.llama31_8b, "qwen2.5-1.5b": EncoderConfig.qwen25_1_5b,
+           "qwen2.5-7b": EncoderConfig.qwen25_7b}[args.model](args.seq_len)
     enc = LrxEncoder.random_init(cfg, seed=0, device=dev)
     B, S, D = args.batch_docs, args.seq_len, cfg.hidden_size
 

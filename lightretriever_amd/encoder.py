@@ -44,6 +44,15 @@ class EncoderConfig:
         return EncoderConfig(128256, 4096, 32, 32, 8, 128, 14336, 1e-5, 500000.0, "llama3", 8.0, 1.0, 4.0, 8192, False, max_positions)
 
     @staticmethod
+    def qwen25_1_5b(max_positions: int = 512) -> "EncoderConfig":
+        """Qwen2.5-1.5B: the backbone of the released lightretriever-qwen2.5-1.5b adapters (scripts/*_infer.ipynb)."""
+        return EncoderConfig(151936, 1536, 28, 12, 2, 128, 8960, 1e-6, 1000000.0, "default", 1.0, 1.0, 4.0, 8192, True, max_positions)
+
+    @staticmethod
+    def qwen25_7b(max_positions: int = 512) -> "EncoderConfig":
+        return EncoderConfig(152064, 3584, 28, 28, 4, 128, 18944, 1e-6, 1000000.0, "default", 1.0, 1.0, 4.0, 8192, True, max_positions)
+
+    @staticmethod
     def from_hf_dict(c: dict, max_positions: int = 512) -> "EncoderConfig":
         """Fields of an HF Llama/Qwen2 config.json (transformers 4.x `rope_scaling` or 5.x `rope_parameters`)."""
         rp = c.get("rope_parameters") or c.get("rope_scaling") or {}
