@@ -32,10 +32,16 @@ struct AttnGeom {
   __device__ static __forceinline__ int xv(int row) { return D == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
 };
 
+constexpr int attn_dma_waves(int insts, int nw) {   // largest divisor of insts that is <= nw
+  int d = nw < insts ? nw : insts;
+  while (insts % d != 0) --d;
+  return d;
+}
+
 template <int D, int GRP>
 __global__ void __launch_bounds__(128 * GRP)
 k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu, int nqt, int nq, int nkv,
-                     __bf16* __restrict__ out, float scale_log2, int last_tile_only) {
+                     __bf16* __restrict__ out, float scale_log2, int last_tile_only, int nparts) {
   using G = AttnGeom<D>;
   constexpr int NW = 2 * GRP;
   constexpr int KS = D / 16;  // k-steps of the QK^T product
@@ -43,13 +49,19 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
   // K/V ring: 3 stages with a counted vmcnt (two tiles in flight; a tile's compute, ~0.5 us, is shorter than the load
   // latency, so one tile of prefetch leaves every barrier waiting on HBM) whenever every wave issues the same number of
   // LDS-DMA instructions per tile; otherwise 2 stages with a full drain.
-  constexpr bool RING3 = (G::INSTS % NW == 0) && (3 * 2 * G::TILE_BYTES <= 96 * 1024);
+  // The first DW waves (a divisor of the instruction count, e.g. 8 of the 12 waves of a GQA-6 group) issue the LDS-DMA, the same
+  // number each, so the counted wait is one immediate for everybody (waves without loads have nothing outstanding).
+  constexpr int DW = attn_dma_waves(G::INSTS, NW);
+  constexpr bool RING3 = (3 * 2 * G::TILE_BYTES <= 96 * 1024);
   constexpr int NST = RING3 ? 3 : 2;
-  constexpr int PER_TILE = RING3 ? 2 * (G::INSTS / NW) : 0;  // LDS-DMA instructions per wave per tile (K + V)
+  constexpr int PER_TILE = RING3 ? 2 * (G::INSTS / DW) : 0;  // LDS-DMA instructions per issuing wave per tile (K + V)
   __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * G::TILE_BYTES];  // [stage][K|V]
 
+  // GRP = q heads handled by this workgroup; a GQA group of nq/nkv heads is covered by nparts workgroups (head_dim 128 needs ~190
+  // VGPRs per wave: more than 8 waves per workgroup would spill, so groups of 6/7/8 heads are split in two)
   const int b = last_tile_only ? blockIdx.x : blockIdx.x / nqt;
-  const int hk = blockIdx.y;
+  const int hk = blockIdx.y / nparts, part = blockIdx.y - hk * nparts;
+  const int grp_total = nq / nkv;
   const int s0 = cu[b], len = cu[b + 1] - s0;
   // last_tile_only: one q tile per sequence, the one holding its last token (all the pooled path needs of the last layer)
   const int qt = last_tile_only ? ((len - 1) >> 6) : nqt - 1 - (blockIdx.x - b * nqt);  // else: heavy (late) q tiles first
@@ -59,9 +71,10 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: branches on it stay scalar
   const int r = lane & 31, h = lane >> 5;
-  const int hq = hk * GRP + (wave % GRP);
+  const int head_in_grp = part * GRP + (wave % GRP);
+  const int hq = hk * grp_total + min(head_in_grp, grp_total - 1);
   const int q0 = qtile0 + (wave / GRP) * 32;
-  const bool active = q0 < len;
+  const bool active = q0 < len && head_in_grp < grp_total;
   const int64_t RS = (int64_t)(nq + 2 * nkv) * D;
   const __bf16* kbase = qkv + (int64_t)s0 * RS + (int64_t)(nq + hk) * D;
   const __bf16* vbase = kbase + (int64_t)nkv * D;
@@ -80,7 +93,8 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
   auto stage = [&](int st, int kt) {
     char* sK = smem + st * (2 * G::TILE_BYTES);
     char* sV = sK + G::TILE_BYTES;
-    for (int j = wave; j < G::INSTS; j += NW) {
+    if (wave >= DW) return;
+    for (int j = wave; j < G::INSTS; j += DW) {
       int s = j * 64 + lane;
       int row = s / G::CH, cs = s % G::CH;
 #if defined(ATTN_EXP) && ATTN_EXP == 1
@@ -594,11 +608,11 @@ extern "C" int lrx_attn_prefix_suffix(const void* qkv, const void* prefix_kv, in
 
 template <int D, int GRP>
 static int launch_attn(const void* qkv, const int32_t* cu, int n_seqs, int max_seqlen, int nq, int nkv, void* out, int last_tile_only,
-                       hipStream_t s) {
+                       hipStream_t s, int nparts = 1) {
   int nqt = (int)lrx_cdiv(max_seqlen, 64);
   float scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-  hipLaunchKernelGGL((k_attn_varlen_causal<D, GRP>), dim3(last_tile_only ? n_seqs : n_seqs * nqt, nkv), dim3(128 * GRP), 0, s, (const __bf16*)qkv,
-                     cu, nqt, nq, nkv, (__bf16*)out, scale_log2, last_tile_only);
+  hipLaunchKernelGGL((k_attn_varlen_causal<D, GRP>), dim3(last_tile_only ? n_seqs : n_seqs * nqt, nkv * nparts), dim3(128 * GRP), 0, s,
+                     (const __bf16*)qkv, cu, nqt, nq, nkv, (__bf16*)out, scale_log2, last_tile_only, nparts);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -629,8 +643,12 @@ extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens
 #define LRX_ATTN_CASE(DD, GG) \
   if (head_dim == DD && grp == GG) return launch_attn<DD, GG>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s);
   LRX_ATTN_CASE(64, 1) LRX_ATTN_CASE(64, 2) LRX_ATTN_CASE(64, 4) LRX_ATTN_CASE(64, 6) LRX_ATTN_CASE(64, 7) LRX_ATTN_CASE(64, 8)
-  LRX_ATTN_CASE(128, 1) LRX_ATTN_CASE(128, 2) LRX_ATTN_CASE(128, 4) LRX_ATTN_CASE(128, 6) LRX_ATTN_CASE(128, 7) LRX_ATTN_CASE(128, 8)
+  LRX_ATTN_CASE(128, 1) LRX_ATTN_CASE(128, 2) LRX_ATTN_CASE(128, 4)
 #undef LRX_ATTN_CASE
+  // head_dim 128, groups of 6 / 7 / 8 q heads: two workgroups of 3 / 4 / 4 heads per kv head (the K/V tiles are staged twice, from L2)
+  if (head_dim == 128 && grp == 6) return launch_attn<128, 3>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s, 2);
+  if (head_dim == 128 && (grp == 7 || grp == 8))
+    return launch_attn<128, 4>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s, 2);
   lrx_set_error("attn: GQA group size %d unsupported", grp);
   return LRX_ERR_INVALID;
 }

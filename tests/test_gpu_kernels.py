@@ -161,6 +161,10 @@ def attn_oracle(qkv, cu, nq, nkv, d):
     (64, 2, 2, [96, 5]),
     (128, 2, 1, [1, 64, 65, 130, 257]),
     (128, 4, 1, [512, 33]),
+    (128, 12, 2, [200, 64, 1]),      # Qwen2.5-1.5B head layout: GQA group 6 -> two workgroups of 3 heads
+    (128, 14, 2, [130, 65]),         # group 7 (Qwen2.5-7B): parts of 4 + 3 heads, one idle wave pair
+    (128, 8, 1, [97, 256]),          # group 8: 4 + 4
+    (64, 12, 2, [140, 31]),
     (64, 6, 1, [70, 129]),
 ])
 def test_attention_varlen_causal(d, nq, nkv, lens):
