@@ -67,12 +67,36 @@ typedef __attribute__((address_space(3))) void* lptr_t;
     G_BAR();                                               \
   } while (0)
 
+#ifdef GEMM_TRACE
+// diagnostic build only (tools/gemm_timeline.py): per-workgroup wall-clock stamps {start, main loop done, end} + hardware id
+__device__ long long g_gemm_trace[4 * 65536];
+extern "C" int lrx_debug_read_gemm_trace(void* dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_trace), bytes) == hipSuccess ? 0 : 1;
+}
+#define G_TRACE(slot)                                                                                   \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 65536) g_gemm_trace[4 * blockIdx.x + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define G_TRACE(slot)
+#endif
+
 template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
                const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope, MaxAggArgs mx) {
   __shared__ __attribute__((aligned(1024))) char smem[8 * HALF_BYTES];  // [buf 0/1][A0 | A1 | B0 | B1]
 
+  G_TRACE(0);
+#ifdef GEMM_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 65536) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_gemm_trace[4 * blockIdx.x + 3] = ((long long)xcc << 32) | hw;
+  }
+#endif
   // ---- workgroup -> tile
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
@@ -194,6 +218,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     G_BAR();
   }
   if (wr == 0) G_BAR();
+  G_TRACE(1);
 
   // ---- epilogue.  The accumulator layout (lane = 1 row x 4 columns per 16x16 tile) would give 8-byte stores that touch 16
   //      partial lines per wave instruction (measured: 6-20 us per tile).  Instead the bf16 C tile is staged through the
@@ -348,6 +373,11 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     }
     *(bf16x8*)(C + (int64_t)m * ldc + n) = v;
   }
+#ifdef GEMM_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  G_TRACE(2);
+#endif
 }
 
 extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N,
