@@ -123,8 +123,10 @@ int lrx_encode_packed_sparse(const lrx_encoder_config* cfg, const lrx_encoder_we
                              float* sparse_out, int64_t sparse_row_stride, int32_t relu, int32_t log1p, int32_t round_bf16,
                              int32_t top_k, int32_t min_tokens_to_keep, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Per-kernel-class timing of the LAST lrx_encode_* call when profiling is enabled: HIP events are recorded on
- * `stream` around every launch and the call synchronises the stream at its end (so never leave it on in production).
+/* Per-kernel-class timing of the lrx_encode_* calls made since lrx_set_profiling / the previous lrx_get_profile: HIP events
+ * are recorded on `stream` around every launch of the selected classes; nothing synchronises until lrx_get_profile reads
+ * them (it waits for the recorded events, accumulates, and resets).  lrx_set_profiling(0) off, (1) every class, otherwise
+ * bit (c + 1) of the argument selects class c (e.g. 1 << 3 = only the gate-up GEMM).
  * classes: 0 gemm/store (qkv), 1 gemm/residual (o, down), 2 gemm/swiglu (gate-up), 3 attention, 4 rmsnorm, 5 rope,
  * 6 other (embedding gather, positions, pool), 7 gemm_maxagg (LM-head GEMM with the max-aggregation epilogue).  Arrays of LRX_PROF_CLASSES entries; flops are algorithmic
  * (2*M*N*K for GEMMs, 2*2*d*sum_s(s*(s+1)/2)*nq for causal attention), 0 for the memory-bound classes.            */

@@ -17,6 +17,7 @@ extern "C" int lrx_abi_version(void) { return LRX_ABI_VERSION; }
 // profiling (HIP events on the caller's stream)
 // ---------------------------------------------------------------------------------------------------------------
 static bool g_prof = false;
+static uint32_t g_prof_mask = 0xffffffffu;   // classes that get events
 static float g_prof_ms[LRX_PROF_CLASSES];
 static double g_prof_flops[LRX_PROF_CLASSES];
 static int32_t g_prof_launches[LRX_PROF_CLASSES];
@@ -36,7 +37,7 @@ static hipEvent_t prof_event() {
 struct ProfScope {
   hipStream_t s; int cls; hipEvent_t a = nullptr, b = nullptr;
   ProfScope(hipStream_t s_, int cls_, double flops) : s(s_), cls(cls_) {
-    if (!g_prof) return;
+    if (!g_prof || !((g_prof_mask >> cls_) & 1u)) return;
     a = prof_event(); b = prof_event();
     if (a) (void)hipEventRecord(a, s);
     g_prof_flops[cls] += flops;
@@ -48,28 +49,33 @@ struct ProfScope {
     g_recs.push_back({a, b, cls});
   }
 };
-static void prof_begin() {
-  if (!g_prof) return;
+// Events are only recorded while an lrx_encode_* call runs; nothing synchronises the stream until lrx_get_profile reads them, so
+// profiled calls keep the device queue full (a sync per call cost ~2 % of the step in the benchmark's timed region).
+static void prof_reset() {
   g_ev_used = 0;
   g_recs.clear();
   for (int i = 0; i < LRX_PROF_CLASSES; ++i) { g_prof_ms[i] = 0.f; g_prof_flops[i] = 0.0; g_prof_launches[i] = 0; }
 }
-static int prof_end(hipStream_t s) {
-  if (!g_prof) return LRX_OK;
-  LRX_HIP(hipStreamSynchronize(s));
-  for (auto& r : g_recs) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) g_prof_ms[r.cls] += ms;
-  }
-  return LRX_OK;
+static void prof_begin() {}
+static int prof_end(hipStream_t) { return LRX_OK; }
+extern "C" void lrx_set_profiling(int32_t enabled) {
+  g_prof = enabled != 0;
+  g_prof_mask = enabled > 1 ? ((uint32_t)enabled >> 1) : 0xffffffffu;   // 1 = every class, otherwise bit (c + 1) selects class c
+  prof_reset();
 }
-extern "C" void lrx_set_profiling(int32_t enabled) { g_prof = enabled != 0; }
 extern "C" int lrx_get_profile(float* ms, double* flops, int32_t* launches) {
+  for (auto& r : g_recs) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) g_prof_ms[r.cls] += t;
+  }
+  g_recs.clear();
+  g_ev_used = 0;
   for (int i = 0; i < LRX_PROF_CLASSES; ++i) {
     if (ms) ms[i] = g_prof_ms[i];
     if (flops) flops[i] = g_prof_flops[i];
     if (launches) launches[i] = g_prof_launches[i];
   }
+  for (int i = 0; i < LRX_PROF_CLASSES; ++i) { g_prof_ms[i] = 0.f; g_prof_flops[i] = 0.0; g_prof_launches[i] = 0; }
   return LRX_OK;
 }
 
