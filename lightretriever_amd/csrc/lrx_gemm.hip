@@ -69,13 +69,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 #ifdef GEMM_TRACE
 // diagnostic build only (tools/gemm_timeline.py): per-workgroup wall-clock stamps {start, main loop done, end} + hardware id
-__device__ long long g_gemm_trace[4 * 65536];
+__device__ long long g_gemm_trace[8 * 65536];
 extern "C" int lrx_debug_read_gemm_trace(void* dst, size_t bytes) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_trace), bytes) == hipSuccess ? 0 : 1;
 }
 #define G_TRACE(slot)                                                                                   \
   do {                                                                                                  \
-    if (threadIdx.x == 0 && blockIdx.x < 65536) g_gemm_trace[4 * blockIdx.x + (slot)] = wall_clock64(); \
+    if (threadIdx.x == 0 && blockIdx.x < 65536) g_gemm_trace[8 * blockIdx.x + (slot)] = wall_clock64(); \
   } while (0)
 #else
 #define G_TRACE(slot)
@@ -94,7 +94,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    g_gemm_trace[4 * blockIdx.x + 3] = ((long long)xcc << 32) | hw;
+    g_gemm_trace[8 * blockIdx.x + 3] = ((long long)xcc << 32) | hw;
   }
 #endif
   // ---- workgroup -> tile
@@ -175,6 +175,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   }
 
   G_BAR();
+  G_TRACE(4);
   if (wr == 1) G_BAR();  // stagger: group 1 runs one barrier behind group 0
 
   bf16x8 b2[2][2];
@@ -272,6 +273,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
       }
     }
   __syncthreads();
+  G_TRACE(5);
   if (EPI == EPI_MAXAGG) {
     // Segmented column maximum of the staged bf16 logits tile (utils/max_linear_map.py:8-88 without the [B,S,V] tensor):
     // wave w owns columns [32w, 32w+32); a lane walks rows (lane>>3) + 8*step holding 4 columns.  Rows map to output rows
@@ -377,6 +379,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     *(bf16x8*)(C + (int64_t)m * ldc + n) = v;
   }
 #ifdef GEMM_TRACE
+  G_TRACE(6);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   G_TRACE(2);

@@ -23,9 +23,9 @@ def main():
         torch.cuda.synchronize()
         ntiles = (M // 256) * ((N + 255) // 256)
         n = min(ntiles, 65536)
-        buf = np.zeros(4 * 65536, np.int64)
+        buf = np.zeros(8 * 65536, np.int64)
         assert lib.lrx_debug_read_gemm_trace(buf.ctypes.data, buf.nbytes) == 0
-        t = buf.reshape(-1, 4)[:n]
+        t = buf.reshape(-1, 8)[:n]
         t0, t1, t2, hw = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
         base = t0.min()
         us = lambda x: x / 100.0                                  # wall_clock64: 100 MHz
@@ -43,6 +43,9 @@ def main():
         sample = order[:: max(1, n // 2000)]
         conc = [(int(((t1 <= m) & (t2 >= m)).sum())) for m in mid[sample]]
         span = us(t2.max() - base)
+        t4, t5, t6 = t[:, 4], t[:, 5], t[:, 6]
+        print(f"{name:8s} phases (median us): prologue (first K-tile landed) {np.median(us(t4-t0)):.2f} | K loop {np.median(us(t1-t4)):.2f} | acc->LDS staging {np.median(us(t5-t1)):.2f} "
+              f"| LDS->global issue {np.median(us(t6-t5)):.2f} | store drain {np.median(us(t2-t6)):.2f}")
         print(f"{name:8s} tiles={ntiles} (traced {n}) distinct CUs={len(np.unique(cu))} launch span {span:.0f} us | tile {np.median(tile):.1f} us (p10 {np.percentile(tile,10):.1f}, p90 {np.percentile(tile,90):.1f}) "
               f"| main loop {np.median(us(t1-t0)):.1f} | epilogue {np.median(epi_t):.2f} (p90 {np.percentile(epi_t,90):.2f}) | gap between workgroups on a CU {np.median(gaps):.2f} us (p90 {np.percentile(gaps,90):.2f}) "
               f"| CUs in epilogue at once: median {int(np.median(conc))}, p90 {int(np.percentile(conc,90))}", flush=True)
