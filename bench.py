@@ -157,6 +157,8 @@ def main():
 
     cfg = {"llama3.2-1b": EncoderConfig.llama32_1b, "llama3.1-8b": EncoderConfig.llama31_8b, "qwen2.5-1.5b": EncoderConfig.qwen25_1_5b,
            "qwen2.5-7b": EncoderConfig.qwen25_7b}[args.model](args.seq_len)
+    if os.environ.get("LRX_FOLD_NORM") is not None:          # dev A/B switch; the default is the library's (folded)
+        cfg.fold_norm = os.environ["LRX_FOLD_NORM"] != "0"
     enc = LrxEncoder.random_init(cfg, seed=0, device=dev)
     B, S, D = args.batch_docs, args.seq_len, cfg.hidden_size
 

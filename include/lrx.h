@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define LRX_ABI_VERSION 1
+#define LRX_ABI_VERSION 2
 
 enum {
   LRX_OK = 0,
@@ -46,6 +46,11 @@ typedef struct lrx_encoder_config {
   float rms_eps;
   int32_t qkv_bias;           /* 1 for Qwen2.5 */
   int32_t max_positions;      /* rows of the RoPE table */
+  int32_t norm_folded;        /* 1: the caller pre-multiplied the RMSNorm weights into the next projection's columns (wqkv := W_qkv diag(ln1),
+                                 wgu := W_gu diag(ln2), fp32 product rounded to bf16); the layers then never materialise the normalised
+                                 activations: the row statistic rsqrt(mean(x^2)+eps) is applied to the GEMM's fp32 accumulator and the
+                                 residual GEMMs emit the sum of squares of the rows they write.  Same function; the two bf16 roundings of
+                                 the normalised activations disappear (closer to the fp32 model).  ln1 / ln2 are ignored.            */
 } lrx_encoder_config;
 
 /* Per-layer weights, bf16, nn.Linear layout [out, in] row-major (K contiguous).
@@ -214,6 +219,20 @@ int lrx_hit_contributions(const double* scores, const int64_t* ids, int32_t n_qu
                           void* stream);
 int lrx_hit_union(const int64_t* ids, const double* contrib, int32_t n_queries, int32_t n_entries, int64_t row_stride,
                   double* scores_out, int64_t* ids_out, int32_t* counts_out, void* stream);
+
+/* GEMMs with the folded-RMSNorm hooks: rscale [M] fp32 or NULL -- accumulator row m times rscale[m] before bias / RoPE / SwiGLU
+ * (store and SwiGLU epilogues); ss_part [ceil(N/256), M] fp32 or NULL -- residual epilogue: sum of squares of the output row's
+ * columns of each 256-wide n-tile, written (not accumulated) to slot [tile, m].                                                  */
+int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N,
+                           int32_t K, int32_t epilogue, const float* rscale, float* ss_part, void* stream);
+int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions,
+                            const float* cos, const float* sin, int32_t M, int32_t K, int32_t num_q_heads,
+                            int32_t num_kv_heads, int32_t head_dim, const float* rscale, void* stream);
+/* rscale_out[r] = rsqrt(mean(x[r,:]^2) + eps) for bf16 rows (LlamaRMSNorm's statistic, modeling_llama.py:53-67) */
+int lrx_row_rscale(const void* x, int32_t rows, int32_t hidden_size, float eps, float* rscale_out, void* stream);
+/* rscale_out[r] = rsqrt(sum_p ss_part[p, r] / hidden_size + eps), partials added in index order */
+int lrx_finalize_rscale(const float* ss_part, int32_t n_parts, int32_t rows, int32_t hidden_size, float eps, float* rscale_out,
+                        void* stream);
 
 /* dst[b, :] = src[cu_seqlens[b+1]-1, :]  (bf16 rows of `width` elements): the last-token rows, compacted. */
 int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, int32_t width, void* dst, void* stream);

@@ -16,7 +16,7 @@ class LrxError(RuntimeError):
 class EncoderConfigC(C.Structure):
     _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_q_heads", C.c_int32),
                 ("num_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("intermediate_size", C.c_int32), ("rms_eps", C.c_float),
-                ("qkv_bias", C.c_int32), ("max_positions", C.c_int32)]
+                ("qkv_bias", C.c_int32), ("max_positions", C.c_int32), ("norm_folded", C.c_int32)]
 
 
 class LayerWeightsC(C.Structure):
@@ -51,6 +51,10 @@ SIGNATURES = {
     "lrx_hit_union": (_I32, [_P, _P, _I32, _I32, _I64, _P, _P, _P, _P]),
     "lrx_flat_ip_bounded_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "lrx_flat_ip_search_bounded": (_I32, [_P, _I64, _I64, _I32, _P, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _P]),
+    "lrx_gemm_bf16_nt_fused": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "lrx_gemm_qkv_rope_fused": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "lrx_row_rscale": (_I32, [_P, _I32, _I32, C.c_float, _P, _P]),
+    "lrx_finalize_rscale": (_I32, [_P, _I32, _I32, _I32, C.c_float, _P, _P]),
     "lrx_set_profiling": (None, [_I32]),
     "lrx_get_profile": (_I32, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "lrx_embedding_gather": (_I32, [_P, _P, _I32, _I32, _P, _P]),
@@ -87,7 +91,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.lrx_abi_version() != 1:
+        if l.lrx_abi_version() != 2:
             raise LrxError("liblrx.so ABI version mismatch")
         _lib = l
     return _lib

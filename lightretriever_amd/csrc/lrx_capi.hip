@@ -88,6 +88,7 @@ struct EncWs {
   char *x, *h, *qkv, *act;
   char *xr, *ar, *hr, *actr;  // compact [n_seqs, .] buffers of the pooled tail of the final layer
   int32_t* pos;
+  float *rsA, *rsB, *ssp;     // folded RMSNorm: row scales for the two norms of a layer, per-n-tile sum-of-squares partials
   size_t total;
 };
 static EncWs carve(const lrx_encoder_config* c, int64_t T, int64_t B, char* base) {
@@ -101,6 +102,9 @@ static EncWs carve(const lrx_encoder_config* c, int64_t T, int64_t B, char* base
   w.qkv = base + off; off += align_up((size_t)T * QKV * 2, 1024);
   w.act = base + off; off += align_up((size_t)T * I * 2, 1024);
   w.pos = (int32_t*)(base + off); off += align_up((size_t)T * 4, 1024);
+  w.rsA = (float*)(base + off); off += align_up((size_t)T * 4, 1024);
+  w.rsB = (float*)(base + off); off += align_up((size_t)T * 4, 1024);
+  w.ssp = (float*)(base + off); off += align_up((size_t)((H + 255) / 256) * T * 4, 1024);
   w.xr = base + off; off += align_up((size_t)B * H * 2, 1024);
   w.ar = base + off; off += align_up((size_t)B * HM * 2, 1024);
   w.hr = base + off; off += align_up((size_t)B * H * 2, 1024);
@@ -139,27 +143,43 @@ static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights
   // equal-length batches: n_seqs * S*(S+1)/2 with S = T / n_seqs (exact when all sequences have the same length)
   const double S = (double)T / (double)(n_seqs > 0 ? n_seqs : 1);
   const double attn_flops = 2.0 * 2.0 * d * nq * (double)n_seqs * (S * (S + 1.0) / 2.0);
+  // norm_folded: the RMSNorm weights are pre-multiplied into wqkv / wgu; the row statistic travels as a [T] fp32 scale that the
+  // consuming GEMM applies to its fp32 accumulator, and the residual GEMMs emit the sum of squares of the rows they produce
+  // (per n-tile partials, summed in fixed order) -- the normalised activations are never written or re-read.
+  const bool fold = c->norm_folded != 0;
+  const int NP = (H + 255) / 256;   // n-tiles of a residual GEMM (N = H)
+  if (fold) { ProfScope p(s, 4, 0); if ((rc = lrx_row_rscale(ws.x, T, H, c->rms_eps, ws.rsA, s))) return rc; }
   for (int l = 0; l < c->num_layers; ++l) {
     const lrx_layer_weights& L = w->layers[l];
-    { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
-    { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);   // QKV projection with bias + RoPE fused into the epilogue
-      if ((rc = lrx_gemm_qkv_rope(ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, s))) return rc; }
-    if (pooled_tail && l == c->num_layers - 1) {
+    const bool last = l == c->num_layers - 1;
+    if (!fold) { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
+    { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);   // QKV projection with (row scale,) bias + RoPE fused into the epilogue
+      if ((rc = lrx_gemm_qkv_rope_fused(fold ? ws.x : ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv,
+                                        d, fold ? ws.rsA : nullptr, s))) return rc; }
+    if (pooled_tail && last) {
       const int B = n_seqs;
       { ProfScope p(s, 3, attn_flops * 64.0 / (S > 64.0 ? S : 64.0)); if ((rc = lrx_attn_varlen_causal(ws.qkv, cu, n_seqs, T, max_seqlen, nq, nkv, d, ws.h, 1, s))) return rc; }
       { ProfScope p(s, 6, 0); if ((rc = lrx_gather_last_rows(ws.h, cu, B, QD, ws.ar, s))) return rc; }
       { ProfScope p(s, 6, 0); if ((rc = lrx_gather_last_rows(ws.x, cu, B, H, ws.xr, s))) return rc; }
-      { ProfScope p(s, 1, 2.0 * B * (double)H * QD); if ((rc = lrx_gemm_bf16_nt(ws.ar, L.wo, ws.xr, nullptr, ws.xr, B, H, QD, 1, s))) return rc; }
-      { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.xr, L.ln2, ws.hr, B, H, c->rms_eps, s))) return rc; }
-      { ProfScope p(s, 2, 2.0 * B * (double)(2 * I) * H); if ((rc = lrx_gemm_bf16_nt(ws.hr, L.wgu, ws.actr, nullptr, nullptr, B, 2 * I, H, 2, s))) return rc; }
+      { ProfScope p(s, 1, 2.0 * B * (double)H * QD);
+        if ((rc = lrx_gemm_bf16_nt_fused(ws.ar, L.wo, ws.xr, nullptr, ws.xr, B, H, QD, 1, nullptr, fold ? ws.ssp : nullptr, s))) return rc; }
+      if (fold) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, B, H, c->rms_eps, ws.rsB, s))) return rc; }
+      else { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.xr, L.ln2, ws.hr, B, H, c->rms_eps, s))) return rc; }
+      { ProfScope p(s, 2, 2.0 * B * (double)(2 * I) * H);
+        if ((rc = lrx_gemm_bf16_nt_fused(fold ? ws.xr : ws.hr, L.wgu, ws.actr, nullptr, nullptr, B, 2 * I, H, 2, fold ? ws.rsB : nullptr, nullptr, s))) return rc; }
       { ProfScope p(s, 1, 2.0 * B * (double)H * I); if ((rc = lrx_gemm_bf16_nt(ws.actr, L.wdown, ws.xr, nullptr, ws.xr, B, H, I, 1, s))) return rc; }
       break;
     }
     { ProfScope p(s, 3, attn_flops); if ((rc = lrx_attn_varlen_causal(ws.qkv, cu, n_seqs, T, max_seqlen, nq, nkv, d, ws.h, 0, s))) return rc; }
-    { ProfScope p(s, 1, 2.0 * T * (double)H * QD); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wo, ws.x, nullptr, ws.x, T, H, QD, 1, s))) return rc; }
-    { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, T, H, c->rms_eps, s))) return rc; }
-    { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, s))) return rc; }
-    { ProfScope p(s, 1, 2.0 * T * (double)H * I); if ((rc = lrx_gemm_bf16_nt(ws.act, L.wdown, ws.x, nullptr, ws.x, T, H, I, 1, s))) return rc; }
+    { ProfScope p(s, 1, 2.0 * T * (double)H * QD);
+      if ((rc = lrx_gemm_bf16_nt_fused(ws.h, L.wo, ws.x, nullptr, ws.x, T, H, QD, 1, nullptr, fold ? ws.ssp : nullptr, s))) return rc; }
+    if (fold) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, T, H, c->rms_eps, ws.rsB, s))) return rc; }
+    else { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, T, H, c->rms_eps, s))) return rc; }
+    { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H);
+      if ((rc = lrx_gemm_bf16_nt_fused(fold ? ws.x : ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, fold ? ws.rsB : nullptr, nullptr, s))) return rc; }
+    { ProfScope p(s, 1, 2.0 * T * (double)H * I);
+      if ((rc = lrx_gemm_bf16_nt_fused(ws.act, L.wdown, ws.x, nullptr, ws.x, T, H, I, 1, nullptr, (fold && !last) ? ws.ssp : nullptr, s))) return rc; }
+    if (fold && !last) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, T, H, c->rms_eps, ws.rsA, s))) return rc; }
   }
   return LRX_OK;
 }
@@ -253,6 +273,18 @@ extern "C" int lrx_encode_packed_sparse(const lrx_encoder_config* cfg, const lrx
 // n_seqs * suffix_len suffix tokens are pushed through the layers, attending to the captured prefix K/V plus their own
 // suffix keys.  Same result as encoding every [prefix + suffix] sequence in full, (P + S2) / S2 times fewer FLOPs.
 // ---------------------------------------------------------------------------------------------------------------
+// Pre-GEMM norm of the simple paths: with folded norm weights only the row scale is computed (the GEMM applies it), otherwise the
+// normalised rows are written to h.  Returns the GEMM's A operand and row-scale pointer.
+static int pre_norm(const lrx_encoder_config* c, const void* x, const void* ln, void* h, int rows, float* rs, hipStream_t s, const void** a_out,
+                    const float** rs_out) {
+  if (c->norm_folded) {
+    *a_out = x; *rs_out = rs;
+    return lrx_row_rscale(x, rows, c->hidden_size, c->rms_eps, rs, s);
+  }
+  *a_out = h; *rs_out = nullptr;
+  return lrx_rmsnorm(x, ln, h, rows, c->hidden_size, c->rms_eps, s);
+}
+
 struct PrefWs { EncWs e; char* kvcap; int32_t* cu; size_t total; };
 static PrefWs carve_prefixed(const lrx_encoder_config* c, int64_t P1, int64_t n_seqs, int64_t S2, char* base) {
   const int64_t T = (n_seqs * S2 > P1 ? n_seqs * S2 : P1);
@@ -296,15 +328,16 @@ extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_enco
     if ((rc = lrx_embedding_gather(w->embed, prefix_ids, P1, H, ws.x, s))) return rc;
     for (int l = 0; l < c->num_layers; ++l) {
       const lrx_layer_weights& L = w->layers[l];
-      if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, P1, H, c->rms_eps, s))) return rc;
-      if ((rc = lrx_gemm_qkv_rope(ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, P1, H, nq, nkv, d, s))) return rc;
+      const void* a_in; const float* rs_in;
+      if ((rc = pre_norm(c, ws.x, L.ln1, ws.h, P1, ws.rsA, s, &a_in, &rs_in))) return rc;
+      if ((rc = lrx_gemm_qkv_rope_fused(a_in, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, P1, H, nq, nkv, d, rs_in, s))) return rc;
       LRX_HIP(hipMemcpy2DAsync(pw.kvcap + (size_t)l * P1 * KVW * 2, (size_t)KVW * 2, ws.qkv + (size_t)QD * 2, (size_t)QKV * 2, (size_t)KVW * 2, P1,
                                hipMemcpyDeviceToDevice, s));
       if (l == c->num_layers - 1) break;   // nothing after the last layer's K/V is needed from the prefix
       if ((rc = lrx_attn_varlen_causal(ws.qkv, pw.cu, 1, P1, P1, nq, nkv, d, ws.h, 0, s))) return rc;
       if ((rc = lrx_gemm_bf16_nt(ws.h, L.wo, ws.x, nullptr, ws.x, P1, H, QD, 1, s))) return rc;
-      if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, P1, H, c->rms_eps, s))) return rc;
-      if ((rc = lrx_gemm_bf16_nt(ws.h, L.wgu, ws.act, nullptr, nullptr, P1, 2 * I, H, 2, s))) return rc;
+      if ((rc = pre_norm(c, ws.x, L.ln2, ws.h, P1, ws.rsB, s, &a_in, &rs_in))) return rc;
+      if ((rc = lrx_gemm_bf16_nt_fused(a_in, L.wgu, ws.act, nullptr, nullptr, P1, 2 * I, H, 2, rs_in, nullptr, s))) return rc;
       if ((rc = lrx_gemm_bf16_nt(ws.act, L.wdown, ws.x, nullptr, ws.x, P1, H, I, 1, s))) return rc;
     }
   }
@@ -314,14 +347,16 @@ extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_enco
   { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, suffix_ids, T, H, ws.x, s))) return rc; }
   for (int l = 0; l < c->num_layers; ++l) {
     const lrx_layer_weights& L = w->layers[l];
-    { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
+    const void* a_in; const float* rs_in;
+    { ProfScope p(s, 4, 0); if ((rc = pre_norm(c, ws.x, L.ln1, ws.h, T, ws.rsA, s, &a_in, &rs_in))) return rc; }
     { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);
-      if ((rc = lrx_gemm_qkv_rope(ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, s))) return rc; }
+      if ((rc = lrx_gemm_qkv_rope_fused(a_in, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, rs_in, s))) return rc; }
     { ProfScope p(s, 3, 0);
       if ((rc = lrx_attn_prefix_suffix(ws.qkv, pw.kvcap + (size_t)l * prefix_len * KVW * 2, n_seqs, suffix_len, prefix_len, nq, nkv, d, ws.h, s))) return rc; }
     { ProfScope p(s, 1, 2.0 * T * (double)H * QD); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wo, ws.x, nullptr, ws.x, T, H, QD, 1, s))) return rc; }
-    { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, T, H, c->rms_eps, s))) return rc; }
-    { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, s))) return rc; }
+    { ProfScope p(s, 4, 0); if ((rc = pre_norm(c, ws.x, L.ln2, ws.h, T, ws.rsB, s, &a_in, &rs_in))) return rc; }
+    { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H);
+      if ((rc = lrx_gemm_bf16_nt_fused(a_in, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, rs_in, nullptr, s))) return rc; }
     { ProfScope p(s, 1, 2.0 * T * (double)H * I); if ((rc = lrx_gemm_bf16_nt(ws.act, L.wdown, ws.x, nullptr, ws.x, T, H, I, 1, s))) return rc; }
   }
   { ProfScope p(s, 6, 0);

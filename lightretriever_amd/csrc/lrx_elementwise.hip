@@ -95,6 +95,49 @@ extern "C" int lrx_build_positions(const int32_t* cu_seqlens, int32_t n_seqs, in
   return LRX_OK;
 }
 
+// rscale[r] = rsqrt(mean(x[r,:]^2) + eps): the RMSNorm row statistic alone (the folded-norm pipeline applies it in the next GEMM's
+// epilogue).  One wave per row, fp32 accumulation of the bf16 values like LlamaRMSNorm (modeling_llama.py:53-67).
+__global__ void k_row_rscale(const bf16x8* __restrict__ x, int rows, int H, float eps, float* __restrict__ rscale) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const bf16x8* p = x + (int64_t)row * (H >> 3);
+  float ss = 0.f;
+  for (int i = lane; i < (H >> 3); i += 64) {
+    const bf16x8 v = p[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float f = bf2f(v[e]); ss += f * f; }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) rscale[row] = rsqrtf(ss / (float)H + eps);
+}
+
+extern "C" int lrx_row_rscale(const void* x, int32_t rows, int32_t hidden_size, float eps, float* rscale_out, void* stream) {
+  LRX_CHECK_ARG(x && rscale_out && rows >= 0 && hidden_size > 0 && hidden_size % 8 == 0, "row_rscale: bad operand");
+  if (rows == 0) return LRX_OK;
+  hipLaunchKernelGGL(k_row_rscale, dim3(lrx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, rows, hidden_size, eps, rscale_out);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// rscale[r] = rsqrt(sum_p ss_part[p, r] / H + eps), partials added in index order (deterministic)
+__global__ void k_finalize_rscale(const float* __restrict__ ss_part, int n_parts, int rows, float inv_h, float eps, float* __restrict__ rscale) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float ss = 0.f;
+  for (int p = 0; p < n_parts; ++p) ss += ss_part[(int64_t)p * rows + r];
+  rscale[r] = rsqrtf(ss * inv_h + eps);
+}
+
+extern "C" int lrx_finalize_rscale(const float* ss_part, int32_t n_parts, int32_t rows, int32_t hidden_size, float eps, float* rscale_out,
+                                   void* stream) {
+  LRX_CHECK_ARG(ss_part && rscale_out && n_parts > 0 && rows >= 0 && hidden_size > 0, "finalize_rscale: bad operand");
+  if (rows == 0) return LRX_OK;
+  hipLaunchKernelGGL(k_finalize_rscale, dim3(lrx_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, ss_part, n_parts, rows, 1.0f / (float)hidden_size, eps,
+                     rscale_out);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
 // cu[i] = i * len (i = 0..n) and positions[t] = offset + t % len : equal-length batches built on the device (no H2D copy)
 __global__ void k_uniform_layout(int32_t* __restrict__ cu, int32_t* __restrict__ pos, int n_seqs, int len, int offset) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;

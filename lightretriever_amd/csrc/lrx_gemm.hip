@@ -45,6 +45,16 @@ struct MaxAggArgs {
   int64_t ldo;
 };
 
+// RMSNorm folded around the GEMM (norm weight pre-multiplied into B's columns by the caller):
+//   rscale  [M] fp32 or NULL: row m of the fp32 accumulator is multiplied by rscale[m] = rsqrt(mean(x_m^2) + eps) before bias /
+//           RoPE / SwiGLU -- x . (gamma (*) W)^T * r  ==  (r x (*) gamma) . W^T, without materialising the normalised rows;
+//   ss_part [tiles_n, M] fp32 or NULL (residual epilogue only): sum of squares of this tile's 256 columns of every OUTPUT row
+//           (the bf16-rounded residual stream), one slot per n-tile, summed in fixed order by lrx_finalize_rscale: deterministic.
+struct NormArgs {
+  const float* rscale;
+  float* ss_part;
+};
+
 // max(*p, v) for floats with integer atomics: non-negative floats order like ints, negative ones inversely like uints
 __device__ __forceinline__ void atomic_fmax_bits(float* p, float v) {
   const unsigned b = __float_as_uint(v);
@@ -84,7 +94,7 @@ extern "C" int lrx_debug_read_gemm_trace(void* dst, size_t bytes) {
 template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
-               const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope, MaxAggArgs mx) {
+               const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope, MaxAggArgs mx, NormArgs nrm) {
   __shared__ __attribute__((aligned(1024))) char smem[8 * HALF_BYTES];  // [buf 0/1][A0 | A1 | B0 | B1]
 
   G_TRACE(0);
@@ -164,6 +174,14 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][ks], a[mi][ks], acc[H][HP][mi][ni], 0, 0, 0); \
   } while (0)
 
+  // folded RMSNorm: this lane's 8 row scales, requested now so they have long arrived when the epilogue multiplies
+  float rsv[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+      rsv[h][mi] = (EPI != EPI_MAXAGG && EPI != EPI_RESID && nrm.rscale != nullptr) ? nrm.rscale[min(m0 + h * 128 + wr * 64 + mi * 16 + fr, M - 1)] : 1.0f;
+
   const int nk = K / GBK;
   // ---- prologue: K-tile 0 landed, K-tile 1 (issued in the steady-state order A0,B0,B1 then A1) stays in flight
   G_ISSUE(pA0, 0, 0, 0); G_ISSUE(pB1, 3, 0, 0); G_ISSUE(pA1, 1, 0, 0); G_ISSUE(pB0, 2, 0, 0);
@@ -234,6 +252,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const int row = h * 128 + wr * 64 + mi * 16 + fr;
+      const float rs = rsv[h][mi];
 #pragma unroll
       for (int hp = 0; hp < 2; ++hp) {
         if (EPI == EPI_SWIGLU) {
@@ -243,7 +262,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
           for (int r = 0; r < 4; ++r) {
             // silu(g) * u with the two raw transcendentals (v_exp_f32, v_rcp_f32: 1 ulp, far below the bf16 rounding that follows);
             // the IEEE division sequence of `g / (1 + expf(-g))` cost ~2 us per 256x256 tile (timeline, tools/gemm_timeline.py)
-            const float g = acc[h][hp][mi][0][r], u = acc[h][hp][mi][1][r];
+            const float g = acc[h][hp][mi][0][r] * rs, u = acc[h][hp][mi][1][r] * rs;
             const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f));
             o[r] = f2bf(g * sg * u);
           }
@@ -254,6 +273,10 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
           for (int ni = 0; ni < 2; ++ni) {
             const int col = hp * 128 + wc * 32 + ni * 16 + fq * 4;
             f32x4 v = acc[h][hp][mi][ni];
+            if (EPI == EPI_STORE || EPI == EPI_ROPE) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= rs;
+            }
             if ((EPI == EPI_STORE || EPI == EPI_ROPE) && bias != nullptr) {
               const int n = min(n0 + col, N - 4);
               bf16x4 bv = *(const bf16x4*)(bias + n);
@@ -350,11 +373,28 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     const int q = it * 512 + tid;
     const int row = q / CPR, ch = q % CPR;
     const int m = m0 + row, n = c0 + ch * 8;
-    if (m >= M || n >= ldc) continue;
+    const bool inb = m < M && n < ldc;
+    if (!(EPI == EPI_RESID && nrm.ss_part != nullptr) && !inb) continue;   // (with ss_part every lane stays for the row reduction)
     bf16x8 v = *(const bf16x8*)(smem + row * (CW * 2) + ((ch ^ (row & 15)) << 4));
     if (EPI == EPI_RESID) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[it][e]));
+      if (nrm.ss_part != nullptr) {
+        // sum of squares of the bf16 values just produced: 8 elements in order, then a fixed xor tree over the row's 32 chunks
+        float ssq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = bf2f(v[e]); ssq += f * f; }
+        if (!inb) ssq = 0.f;
+        // all-reduce over the row's 32 lanes: rotations inside the 16-lane DPP rows (row_ror 8, 4, then the two quad permutes), one
+        // cross-row exchange -- the same order in every lane and every run (five ds_bpermute per chunk cost ~4 us per tile)
+        ssq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssq), 0x128, 0xF, 0xF, true));   // row_ror:8
+        ssq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssq), 0x124, 0xF, 0xF, true));   // row_ror:4
+        ssq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssq), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        ssq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssq), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        ssq += __shfl_xor(ssq, 16, 64);
+        if ((tid & 31) == 0 && m < M) nrm.ss_part[(int64_t)tn * M + m] = ssq;
+        if (!inb) continue;
+      }
     }
     if (EPI == EPI_ROPE && n < rope.rope_cols) {
       // rotary embedding on the staged bf16 q|k values (same arithmetic as k_rope): the rotate_half partner sits half a
@@ -388,12 +428,19 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 
 extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N,
                                 int32_t K, int32_t epilogue, void* stream) {
+  return lrx_gemm_bf16_nt_fused(A, B, C, bias, resid, M, N, K, epilogue, nullptr, nullptr, stream);
+}
+
+extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N,
+                                      int32_t K, int32_t epilogue, const float* rscale, float* ss_part, void* stream) {
   LRX_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   LRX_CHECK_ARG(K % GBK == 0, "gemm: K=%d must be a multiple of %d", K, GBK);
   LRX_CHECK_ARG(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
   LRX_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "gemm: unknown epilogue %d", epilogue);
   LRX_CHECK_ARG(epilogue != EPI_SWIGLU || N % 32 == 0, "gemm: SwiGLU epilogue needs N %% 32 == 0 (N=%d)", N);
   LRX_CHECK_ARG(epilogue != EPI_RESID || resid != nullptr, "gemm: residual epilogue without resid");
+  LRX_CHECK_ARG(ss_part == nullptr || epilogue == EPI_RESID, "gemm: ss_part belongs to the residual epilogue");
+  LRX_CHECK_ARG(rscale == nullptr || epilogue != EPI_RESID, "gemm: rscale applies to the store / SwiGLU epilogues");
   if (M == 0) return LRX_OK;
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
   dim3 grid(tiles_m * tiles_n), block(512);
@@ -402,10 +449,11 @@ extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const voi
   __bf16* c = (__bf16*)C;
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   MaxAggArgs nomx = {nullptr, nullptr, 0};
+  NormArgs nrm = {rscale, ss_part};
   switch (epilogue) {
-    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx); break;
-    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx); break;
-    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx); break;
+    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm); break;
+    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm); break;
+    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm); break;
   }
   LRX_LAUNCH_CHECK();
   return LRX_OK;
@@ -414,6 +462,12 @@ extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const voi
 extern "C" int lrx_gemm_qkv_rope(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos,
                                  const float* sin, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
                                  void* stream) {
+  return lrx_gemm_qkv_rope_fused(A, Wqkv, C, bias, positions, cos, sin, M, K, num_q_heads, num_kv_heads, head_dim, nullptr, stream);
+}
+
+extern "C" int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos,
+                                       const float* sin, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                       const float* rscale, void* stream) {
   const int N = (num_q_heads + 2 * num_kv_heads) * head_dim;
   LRX_CHECK_ARG(M >= 0 && K > 0 && K % GBK == 0, "gemm_qkv_rope: bad shape M=%d K=%d", M, K);
   LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "gemm_qkv_rope: head_dim=%d unsupported", head_dim);
@@ -422,7 +476,8 @@ extern "C" int lrx_gemm_qkv_rope(const void* A, const void* Wqkv, void* C, const
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
   RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)Wqkv,
-                     (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0});
+                     (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0},
+                     NormArgs{rscale, nullptr});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -437,7 +492,7 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   MaxAggArgs mx = {row_seg, out, ldo};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
-                     (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx);
+                     (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

@@ -34,6 +34,7 @@ class EncoderConfig:
     rope_original_max_position: int = 8192
     qkv_bias: bool = False
     max_positions: int = 512
+    fold_norm: bool = True      # RMSNorm weights folded into the next projection at load time (lrx_encoder_config.norm_folded)
 
     @staticmethod
     def llama32_1b(max_positions: int = 512) -> "EncoderConfig":
@@ -147,6 +148,11 @@ class LrxEncoder:
                 wgu=dev(interleave_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"))),
                 wdown=dev(g(p + "mlp.down_proj.weight")), ln1=dev(g(p + "input_layernorm.weight")),
                 ln2=dev(g(p + "post_attention_layernorm.weight"))))
+        if cfg.fold_norm:
+            # W' = W diag(gamma): fp32 product, one rounding to bf16.  The originals stay (hf_state_dict, inspection); the C structs get W'.
+            for L in self.layers:
+                L["wqkv_f"] = (L["wqkv"].float() * L["ln1"].float()[None, :]).to(bf).contiguous()
+                L["wgu_f"] = (L["wgu"].float() * L["ln2"].float()[None, :]).to(bf).contiguous()
         # LM head for the sparse branch: tied to the embedding unless the checkpoint carries its own (`lm_head.weight`)
         self.lm_head = dev(g("lm_head.weight")) if "lm_head.weight" in state_dict else None
         self._build_c_structs()
@@ -205,11 +211,12 @@ class LrxEncoder:
     def _build_c_structs(self):
         c = self.cfg
         self._ccfg = _lib.EncoderConfigC(c.vocab_size, c.hidden_size, c.num_layers, c.num_q_heads, c.num_kv_heads, c.head_dim,
-                                         c.intermediate_size, c.rms_eps, int(c.qkv_bias), c.max_positions)
+                                         c.intermediate_size, c.rms_eps, int(c.qkv_bias), c.max_positions, int(c.fold_norm))
         arr = (_lib.LayerWeightsC * c.num_layers)()
+        fq, fg = ("wqkv_f", "wgu_f") if c.fold_norm else ("wqkv", "wgu")
         for i, L in enumerate(self.layers):
-            arr[i] = _lib.LayerWeightsC(L["wqkv"].data_ptr(), L["bqkv"].data_ptr() if L["bqkv"] is not None else None,
-                                        L["wo"].data_ptr(), L["wgu"].data_ptr(), L["wdown"].data_ptr(), L["ln1"].data_ptr(),
+            arr[i] = _lib.LayerWeightsC(L[fq].data_ptr(), L["bqkv"].data_ptr() if L["bqkv"] is not None else None,
+                                        L["wo"].data_ptr(), L[fg].data_ptr(), L["wdown"].data_ptr(), L["ln1"].data_ptr(),
                                         L["ln2"].data_ptr())
         self._clayers = arr
         self._cw = _lib.EncoderWeightsC(self.embed.data_ptr(), self.final_norm.data_ptr(), self.rope_cos.data_ptr(),

@@ -35,6 +35,30 @@ def gemm_bf16_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] 
     return out
 
 
+def gemm_bf16_nt_fused(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, epilogue: int = 0,
+                       rscale: Optional[torch.Tensor] = None, want_ss: bool = False):
+    """lrx_gemm_bf16_nt_fused: -> (out bf16, ss_part fp32 [ceil(N/256), M] or None)."""
+    M, K = A.shape
+    N = B.shape[0]
+    out = torch.empty(M, N // 2 if epilogue == 2 else N, dtype=torch.bfloat16, device=A.device)
+    ss = torch.full(((N + 255) // 256, M), float("nan"), dtype=torch.float32, device=A.device) if want_ss else None
+    _lib.check(_lib.lib().lrx_gemm_bf16_nt_fused(_lib.ptr(A), _lib.ptr(B), _lib.ptr(out), _lib.ptr(bias), _lib.ptr(resid), M, N, K, epilogue,
+                                                 _lib.ptr(rscale), _lib.ptr(ss), _s()))
+    return out, ss
+
+
+def row_rscale(x: torch.Tensor, eps: float) -> torch.Tensor:
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().lrx_row_rscale(_lib.ptr(x), x.shape[0], x.shape[1], float(eps), _lib.ptr(out), _s()))
+    return out
+
+
+def finalize_rscale(ss_part: torch.Tensor, hidden_size: int, eps: float) -> torch.Tensor:
+    out = torch.empty(ss_part.shape[1], dtype=torch.float32, device=ss_part.device)
+    _lib.check(_lib.lib().lrx_finalize_rscale(_lib.ptr(ss_part), ss_part.shape[0], ss_part.shape[1], hidden_size, float(eps), _lib.ptr(out), _s()))
+    return out
+
+
 def gemm_qkv_rope(A: torch.Tensor, Wqkv: torch.Tensor, positions: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, nq: int, nkv: int,
                   d: int, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     M, K = A.shape

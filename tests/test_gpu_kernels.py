@@ -293,3 +293,60 @@ def test_uniform_layout():
     cu, pos = ops.uniform_layout(7, 3, 11, dev())
     assert cu.cpu().tolist() == [0, 3, 6, 9, 12, 15, 18, 21]
     assert pos.cpu().tolist() == [11, 12, 13] * 7
+
+
+# ---- folded RMSNorm: row scale applied to the accumulator, sum of squares emitted by the residual epilogue ----------------
+@pytest.mark.parametrize("M,H,I", [(300, 256, 128), (1000, 2048, 512), (77, 1536, 256)])
+def test_folded_norm_gemms_equal_norm_then_gemm(M, H, I):
+    """x -> RMSNorm(gamma) -> SwiGLU GEMM == SwiGLU GEMM on x with gamma folded into the weights and the row scale applied to the fp32
+    accumulator, up to the two bf16 roundings of the normalised activations that the folded form no longer does; and the residual
+    epilogue's per-tile sums of squares reproduce the statistic of the rows it wrote."""
+    from lightretriever_amd import ops
+    from lightretriever_amd.encoder import interleave_gate_up
+    rng = np.random.default_rng(M + H)
+    eps = 1e-5
+    x = rnd(rng, M, H, scale=1.7)
+    gamma = O.round_bf16(1.0 + 0.3 * rng.standard_normal(H).astype(np.float32))
+    Wg, Wu = rnd(rng, I, H, scale=0.05), rnd(rng, I, H, scale=0.05)
+    r = (1.0 / np.sqrt((x.astype(np.float64) ** 2).mean(1) + eps)).astype(np.float32)
+    got_r = f32(ops.row_rscale(bf16_t(x), eps))
+    np.testing.assert_allclose(got_r, r, rtol=3e-6)
+    # exact-arithmetic target: silu(g) * u with g, u = (r x * gamma) . W^T in fp32/fp64
+    hn = (x * r[:, None] * gamma[None, :]).astype(np.float64)
+    g, u = hn @ Wg.T.astype(np.float64), hn @ Wu.T.astype(np.float64)
+    want = (g / (1 + np.exp(-g)) * u).astype(np.float32)
+    Wgu_f = interleave_gate_up(torch.from_numpy(O.round_bf16(Wg * gamma[None, :])), torch.from_numpy(O.round_bf16(Wu * gamma[None, :])))
+    got, _ = ops.gemm_bf16_nt_fused(bf16_t(x), Wgu_f.to("cuda").to(torch.bfloat16).contiguous(), epilogue=2, rscale=torch.from_numpy(r).cuda())
+    # the unfolded pipeline on the same inputs: normalised rows rounded to bf16 (twice, like LlamaRMSNorm), plain SwiGLU GEMM
+    hn16 = ops.rmsnorm(bf16_t(x), bf16_t(gamma), eps)
+    Wgu = interleave_gate_up(torch.from_numpy(Wg), torch.from_numpy(Wu)).to("cuda").to(torch.bfloat16).contiguous()
+    ref16 = f32(ops.gemm_bf16_nt(hn16, Wgu, epilogue=2))
+    rel = lambda a: np.linalg.norm(a - want) / np.linalg.norm(want)
+    assert rel(f32(got)) < 6e-3 and rel(f32(got)) <= 1.25 * rel(ref16)       # at least as close to exact arithmetic as the HF rounding order
+    assert abs(np.linalg.norm(f32(got)) / np.linalg.norm(want) - 1) < 2e-3
+    # residual epilogue: out = bf16(bf16(act . Wd^T) + x); ss_part sums to the sum of squares of the rows written
+    act, Wd = rnd(rng, M, I), rnd(rng, H, I, scale=0.05)
+    out, ss = ops.gemm_bf16_nt_fused(bf16_t(act), bf16_t(Wd), resid=bf16_t(x), epilogue=1, want_ss=True)
+    assert ss.shape == ((H + 255) // 256, M) and torch.isfinite(ss).all()
+    want_ss = (out.float() ** 2).sum(1)
+    np.testing.assert_allclose(f32(ss.sum(0)), f32(want_ss), rtol=2e-6)
+    np.testing.assert_allclose(f32(ops.finalize_rscale(ss, H, eps)), 1.0 / np.sqrt(f32(want_ss) / H + eps), rtol=3e-6)
+    out2, ss2 = ops.gemm_bf16_nt_fused(bf16_t(act), bf16_t(Wd), resid=bf16_t(x), epilogue=1, want_ss=True)
+    assert torch.equal(ss, ss2) and torch.equal(out, out2)                                         # no atomics: bitwise repeatable
+
+
+def test_folded_and_unfolded_encoders_agree_and_both_match_fp32():
+    """Same checkpoint through both pipelines: pooled embeddings within bf16 noise of each other, and the folded one is not
+    further from the fp32 oracle than the HF rounding order is."""
+    from dataclasses import asdict, replace
+    from helpers import load_model_golden, min_cos
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    cfg_o, w, g, ids, cu, max_len = load_model_golden("llama_small_d64")
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    outs = {}
+    for fold in (True, False):
+        enc = LrxEncoder(replace(EncoderConfig(**asdict(cfg_o)), fold_norm=fold), sd)
+        outs[fold] = enc.encode_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), max_len).cpu().numpy()
+    assert min_cos(outs[True], outs[False]) > 0.9995
+    ref = g["dense_reps"]
+    assert min_cos(outs[True], ref) > 0.999 and min_cos(outs[True], ref) >= min_cos(outs[False], ref) - 2e-4
