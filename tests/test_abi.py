@@ -35,3 +35,16 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert l.lrx_flat_ip_scores(None, 10, 48, 48, None, 1, None, None) == -1
     assert l.lrx_flat_ip_score_ld(1000) == 1024
     assert l.lrx_encode_workspace_bytes(None, 1, 1) == 0
+
+
+def test_graft_entry_build_runs_on_cpu():
+    """The driver's "does it build" check: compiles (or reuses) liblrx.so for gfx950, imports the package, checks the ABI version."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
+    assert callable(entry.smoke)
