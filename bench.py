@@ -127,7 +127,7 @@ def pmc_traffic(kernel_key):
 
 def pmc_search_traffic():
     """filter pass + select + refine of one search (same PMC summary); None when the summary predates the two-pass search."""
-    parts = [pmc_traffic(k) for k in ("k_flat_ip_scores_split<NP=1>", "k_topk_select", "k_refine_topk")]
+    parts = [pmc_traffic(k) for k in ("k_flat_ip_scores_split<NP=1>", "k_topk_select", "k_refine_topk", "k_refine_merge")]
     return None if any(p is None for p in parts) else sum(parts)
 
 
@@ -254,7 +254,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         srch_s = float(t.item())
         local_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.steps)) / args.steps
-        alg_bytes = shard_rows * D * 4 + args.queries * D * 4 + args.queries * args.topk * 12
+        # the filter pass streams the bf16 shadow of the shard (2 B/element); the exact rescoring of the few hundred band rows per
+        # query comes on top (measured: `traffic`) -- the fp32 rows themselves are never streamed
+        shadow = index._xb is not None and index.two_pass
+        alg_bytes = shard_rows * D * (2 if shadow else 4) + args.queries * D * 4 + args.queries * args.topk * 12
         search = {
             "metric": "queries/sec @ top-%d over %d-doc fp32 index" % (args.topk, args.index_rows), "value": round(args.queries * args.steps / srch_s, 2),
             "unit": "queries/s", "ms_per_pass": round(1e3 * srch_s / args.steps, 4), "queries": args.queries, "index_rows": args.index_rows,
@@ -263,7 +266,7 @@ def main():
                          "frac": round(alg_bytes / (local_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "traffic": pmc_search_traffic() if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100) else None,
                          "algorithmic_bytes": alg_bytes,
-                         "kernel": "two-pass exact search: k_flat_ip_scores_split<QT,1> (single-product bf16 filter, HBM-bound) + k_topk_select + k_refine_topk (exact fp64-accumulated rescoring of the error band); six-product pass as device-gated fallback (local shard search, HIP events)", "ms": round(local_ms, 4),
+                         "kernel": "two-pass exact search: k_flat_ip_scores_split<QT,1,..,XB> (single-product filter over the bf16 shadow of the shard, HBM-bound) + k_topk_select + k_refine_topk/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
                          "fp32_equiv_tflops": round(2.0 * args.queries * D * shard_rows / (local_ms * 1e-3) / 1e12, 2),
                          "fp32_mfma_peak_for_reference": PEAK_F32_MFMA_TFLOPS},
         }

@@ -32,10 +32,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <int QT>
 __global__ void __launch_bounds__(256, 1)
 k_flat_ip_scores(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ Q, int nq,
-                 float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk) {
+                 float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk, const int* __restrict__ gate) {
   constexpr int QTILE = QT * 16 * S_BK * 4;
   constexpr int STAGE = S_XTILE + QTILE;
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+  if (gate != nullptr && *gate == 0) return;     // fallback launch of the bounded search: nothing overflowed
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t n0 = (int64_t)blockIdx.x * S_ROWS;
 
@@ -185,6 +186,22 @@ __global__ void k_split_queries(const float* __restrict__ Q, int nq, int D, int 
   }
 }
 
+// bf16-shadow filter: natural k order, 64-wide slices.  qs layout: [D/64 slices][2 k-steps][QT][64 lanes][8] bf16, lane (fi = query in
+// tile, fq) of k-step ks holds k = slice*64 + ks*32 + fq*8 .. +7 (the MFMA 16x16x32 operand layout).
+__global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, int QT, __bf16* __restrict__ qs) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  int lane = gid & 63, rest = gid >> 6;
+  int qt = rest % QT, r2 = rest / QT;
+  int ks = r2 & 1, sl = r2 >> 1;
+  if (sl >= D / 64) return;
+  int fi = lane & 15, fq = lane >> 4;
+  int row = qt * 16 + fi;
+  bf16x8 h;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h[j] = (__bf16)(row < nq ? Q[(int64_t)row * D + sl * 64 + ks * 32 + fq * 8 + j] : 0.f);
+  ((bf16x8*)qs)[(((int64_t)sl * 2 + ks) * QT + qt) * 64 + lane] = h;
+}
+
 // RT = 16-row tiles per wave (rows per workgroup = 64 RT), NST = LDS stages of the k-slice ring.  The six-product kernel runs
 // (RT 2, NST 2, two workgroups per CU: it is bound by the matrix pipe); the single-product filter kernel is HBM-bound and runs the
 // deeper / wider shape selected by SPF_RT / SPF_NST.
@@ -197,12 +214,26 @@ __global__ void k_split_queries(const float* __restrict__ Q, int nq, int D, int 
 #ifndef SPF_WV
 #define SPF_WV 8
 #endif
-template <int QT, int NP, int RT, int NST, int WV>
-__global__ void __launch_bounds__(64 * WV, (NST * (16 * RT * WV * 128 + ((NP * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1)
-k_flat_ip_scores_split(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
+// shape of the bf16-shadow filter kernel (its q slice is twice as large per stage: 128-row workgroups keep two per CU)
+#ifndef SPX_RT
+#define SPX_RT 1
+#endif
+#ifndef SPX_NST
+#define SPX_NST 2
+#endif
+#ifndef SPX_WV
+#define SPX_WV 8
+#endif
+// XB: X is the bf16 shadow of the corpus (half the bytes; k-slices of 64 in natural order, fragments read straight from LDS).
+template <int QT, int NP, int RT, int NST, int WV, bool XB = false>
+__global__ void __launch_bounds__(64 * WV, (NST * (16 * RT * WV * 128 + (((XB ? 2 : NP) * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1)
+k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
                        float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate) {
+  static_assert(!XB || NP == 1, "the bf16 shadow is a single-product filter");
+  const float* X = (const float*)Xv;
+  const __bf16* Xb = (const __bf16*)Xv;
   constexpr int RB = 16 * RT * WV;               // corpus rows per workgroup (WV waves x RT 16-row tiles)
-  constexpr int QINST = NP * QT;                 // 1-KiB LDS-DMA instructions per q slice
+  constexpr int QINST = (XB ? 2 : NP) * QT;      // 1-KiB LDS-DMA instructions per q slice
   constexpr int QI4 = (QINST + WV - 1) / WV;     // ... per wave (the last ones re-load the final plane into padding: equal counts per wave)
   constexpr int QBYTES = QI4 * WV * 1024;
   constexpr int XT = RB * S_BK * 4;              // X k-slice: RB rows x 128 B
@@ -215,13 +246,13 @@ k_flat_ip_scores_split(const float* __restrict__ X, int64_t N, int64_t ldx, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t n0 = (int64_t)blockIdx.x * RB;
 
-  const float* px[2 * RT];
+  const char* px[2 * RT];                        // byte pointers: both element types move 128 B per row per k-slice
 #pragma unroll
   for (int i = 0; i < 2 * RT; ++i) {
     int s = (wave * 2 * RT + i) * 64 + lane;
     int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
     int64_t g = min(n0 + row, N - 1);
-    px[i] = X + g * ldx + c * 4;
+    px[i] = XB ? (const char*)(Xb + g * ldx + c * 8) : (const char*)(X + g * ldx + c * 4);
   }
   const __bf16* pq = qs + (int64_t)lane * 8;     // + (kt*QINST + j) * 512 elements
   auto stage = [&](int st, int kt) {
@@ -229,7 +260,7 @@ k_flat_ip_scores_split(const float* __restrict__ X, int64_t N, int64_t ldx, int 
     char* sQ = sX + XT;
 #pragma unroll
     for (int i = 0; i < 2 * RT; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + kt * S_BK), (lptr_t)(sX + (wave * 2 * RT + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + (int64_t)kt * 128), (lptr_t)(sX + (wave * 2 * RT + i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int jj = 0; jj < QI4; ++jj) {
       const int j = wave + WV * jj;
@@ -249,7 +280,7 @@ k_flat_ip_scores_split(const float* __restrict__ X, int64_t N, int64_t ldx, int 
 #pragma unroll
     for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = D / S_BK;
+  const int nk = XB ? D / 64 : D / S_BK;
 #pragma unroll
   for (int st = 0; st < NST - 1; ++st)
     if (st < nk) stage(st, st);
@@ -262,6 +293,21 @@ k_flat_ip_scores_split(const float* __restrict__ X, int64_t N, int64_t ldx, int 
     if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST, kt + NST - 1);
     const char* sX = smem + cur * STAGE + (wave * 16 * RT) * 128;
     const char* sQ = smem + cur * STAGE + XT + lane * 16;
+    if (XB) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 xf[RT];
+#pragma unroll
+        for (int a = 0; a < RT; ++a) xf[a] = *(const bf16x8*)(sX + a * 2048 + fi * 128 + (((ks * 4 + fq) ^ xs) << 4));
+#pragma unroll
+        for (int b = 0; b < QT; ++b) {
+          const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
+#pragma unroll
+          for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], qf, acc[a][b], 0, 0, 0);
+        }
+      }
+      continue;
+    }
     bf16x8 xh[RT], xm[NP == 3 ? RT : 1], xl[NP == 3 ? RT : 1];
 #pragma unroll
     for (int a = 0; a < RT; ++a) {
@@ -377,7 +423,8 @@ static size_t split_ws_bytes(int32_t dim) { return (size_t)(dim / 32) * 3 * 8 * 
 // planes = 3: fp32-grade scores (six bf16 products); planes = 1: one bf16 product, |error| <= FILTER_EPS * |q| * |x| (filter pass
 // of the bounded search); gate != NULL: the whole pass is skipped unless *gate != 0.
 static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, float* scores,
-                         float* blkmax, __bf16* qsplit, void* stream, int planes = 3, const int* gate = nullptr) {
+                         float* blkmax, __bf16* qsplit, void* stream, int planes = 3, const int* gate = nullptr, const void* Xb = nullptr,
+                         int64_t ldxb = 0) {
   LRX_CHECK_ARG(dim > 0 && dim % S_BK == 0, "flat_ip: dim=%d must be a multiple of %d", dim, S_BK);
   LRX_CHECK_ARG(ldx >= dim && ldx % 4 == 0, "flat_ip: ldx=%lld must be >= dim and a multiple of 4", (long long)ldx);
   if (n_rows <= 0 || n_queries <= 0) return LRX_OK;
@@ -391,6 +438,20 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
     const float* qp = q + (int64_t)q0 * dim;
     float* sp = scores + (int64_t)q0 * ld;
     float* bp = blkmax ? blkmax + (int64_t)q0 * nblk_ld : nullptr;
+    if (qsplit != nullptr && planes == 1 && Xb != nullptr) {   // any query count: the shadow pass beats the exact-fp32 kernel from Q = 1
+      // filter pass over the bf16 shadow of the corpus: half the bytes of the fp32 rows
+      int threads = (dim / 64) * 2 * qt * 64;
+      hipLaunchKernelGGL(k_pack_queries_xb, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit);
+#define LRX_SB(QQ)                                                                                                                                      \
+  case QQ:                                                                                                                                              \
+    hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPX_RT, SPX_NST, SPX_WV, true>), dim3((unsigned)(ld / (16 * SPX_RT * SPX_WV))), dim3(64 * SPX_WV), 0, \
+                       s, Xb, n_rows, ldxb, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate);                                                                 \
+    break;
+      switch (qt) { LRX_SB(1) LRX_SB(2) LRX_SB(3) LRX_SB(4) LRX_SB(5) LRX_SB(6) LRX_SB(7) LRX_SB(8) }
+#undef LRX_SB
+      LRX_LAUNCH_CHECK();
+      continue;
+    }
     if (qsplit != nullptr && qt >= SPLIT_MIN_QT) {
       int threads = (dim / 32) * qt * 64;
       hipLaunchKernelGGL(k_split_queries, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, planes, qsplit, gate);
@@ -404,7 +465,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
       LRX_LAUNCH_CHECK();
       continue;
     }
-#define LRX_SC(QQ) case QQ: hipLaunchKernelGGL(k_flat_ip_scores<QQ>, grid, block, 0, s, X, n_rows, ldx, dim, qp, nq, sp, ld, bp, nblk_ld); break;
+#define LRX_SC(QQ) case QQ: hipLaunchKernelGGL(k_flat_ip_scores<QQ>, grid, block, 0, s, X, n_rows, ldx, dim, qp, nq, sp, ld, bp, nblk_ld, gate); break;
     switch (qt) { LRX_SC(1) LRX_SC(2) LRX_SC(3) LRX_SC(4) LRX_SC(5) LRX_SC(6) LRX_SC(7) LRX_SC(8) }
 #undef LRX_SC
     LRX_LAUNCH_CHECK();
@@ -482,22 +543,25 @@ __device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, u
       if ((key & mask) == prefix) atomicAdd(&sh.hist[wave][(key >> shift) & 255], 1u);
     }
     __syncthreads();
+    // bucket holding the kk-th largest key: suffix sums S(b) = count of keys in buckets >= b, by a wave scan per 64 buckets plus the
+    // totals of the higher waves (a serial walk over 256 LDS entries by one thread cost ~8 us per pass)
+    unsigned int cnt_b = 0, suf = 0;
     if (tid < 256) {
-      unsigned int sum = 0;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) sum += sh.hist[w][tid];
-      sh.hist[0][tid] = sum;
+      for (int w = 0; w < 16; ++w) cnt_b += sh.hist[w][tid];
+      suf = cnt_b;                                   // inclusive suffix within the wave: lanes >= lane
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int up = __shfl_down(suf, o, 64);
+        if ((tid & 63) + o < 64) suf += up;
+      }
+      if ((tid & 63) == 0) sh.hist[1][tid >> 6] = suf;   // wave total (hist[1] is free: the per-wave histograms were just consumed)
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned int cum = 0;
-      int bsel = 0;
-      for (int bkt = 255; bkt >= 0; --bkt) {
-        unsigned int c = sh.hist[0][bkt];
-        if (cum + c >= kk) { bsel = bkt; sh.kk = kk - cum; sh.cnt = c; break; }
-        cum += c;
-      }
-      sh.bucket = bsel;
+    if (tid < 256) {
+      for (int w = (tid >> 6) + 1; w < 4; ++w) suf += sh.hist[1][w];
+      const unsigned int above = suf - cnt_b;        // keys in strictly higher buckets
+      if (suf >= kk && above < kk) { sh.bucket = tid; sh.kk = kk - above; sh.cnt = cnt_b; }
     }
     __syncthreads();
     prefix |= (uint32_t)sh.bucket << shift;
@@ -623,26 +687,32 @@ k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, in
   }
 }
 
-// q . x over D (multiple of 4) fp32 elements by one wave: fp64 accumulation of the exact fp32 products, one final rounding to
-// fp32 -- the value every search path reports, so scores do not depend on the path, the query batch size or the shard layout.
+// q . x over D (multiple of 4) fp32 elements by one HALF-wave (32 lanes, two rows per wave in flight): fp64 accumulation of the exact
+// fp32 products, one final rounding to fp32 -- the value every search path reports, so scores do not depend on the path, the query
+// batch size or the shard layout.  Up to 16 row segments of 512 B are requested before the first is consumed (a row of 2048 floats
+// is a single round trip; rescoring is latency-bound gather work).
 __device__ __forceinline__ float exact_dot(const float* __restrict__ x, const float* __restrict__ qrow, int D, int lane) {
+  const int sub = lane & 31;
   double acc = 0.0;
-  for (int i0 = lane * 4; i0 < D; i0 += 1024) {          // four 1-KiB row segments in flight per wave
-    f32x4 xv[4], qv[4];
+  for (int i0 = sub * 4; i0 < D; i0 += 2048) {
+    f32x4 xv[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 256;
-      const bool in = i < D;
-      xv[u] = in ? *(const f32x4*)(x + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-      qv[u] = in ? *(const f32x4*)(qrow + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u * 128;
+      xv[u] = i < D ? *(const f32x4*)(x + i) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      acc += (double)xv[u][0] * (double)qv[u][0] + (double)xv[u][1] * (double)qv[u][1] + (double)xv[u][2] * (double)qv[u][2] +
-             (double)xv[u][3] * (double)qv[u][3];
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u * 128;
+      if (i < D) {
+        const f32x4 qv = *(const f32x4*)(qrow + i);
+        acc += (double)xv[u][0] * (double)qv[0] + (double)xv[u][1] * (double)qv[1] + (double)xv[u][2] * (double)qv[2] +
+               (double)xv[u][3] * (double)qv[3];
+      }
+    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   return (float)acc;
 }
 
@@ -659,11 +729,12 @@ k_rescore_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const
   const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
   if (keff == 0) return;
   const float* qrow = q + (int64_t)blockIdx.x * D;
-  for (int c = wave; c < keff; c += 16) {
+  for (int c0 = wave * 2; c0 < keff; c0 += 32) {           // two rows per wave (one per half-wave)
+    const int c = min(c0 + (lane >> 5), keff - 1);
     int64_t n = oi[c] - id_base;
     n = n < 0 ? 0 : (n >= N ? N - 1 : n);          // never index outside the shard, whatever the select stage handed over
     const float sc = exact_dot(X + n * ldx, qrow, D, lane);
-    if (lane == 0) s_c[c] = sel_pack(f2key(sc), n);
+    if ((lane & 31) == 0 && c0 + (lane >> 5) < keff) s_c[c] = sel_pack(f2key(sc), n);
   }
   __syncthreads();
   int P = 1;
@@ -720,7 +791,7 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
 //           |s - s~| <= eps = FILTER_EPS * |q| * R, FILTER_EPS = 2^-8 + 2^-18 (two roundings to bf16, unit roundoff 2^-9 each, Cauchy-
 //           Schwarz over the element products) + 2048 * 2^-22 (a generous bound on the fp32 accumulation of <= 2048-term sums per
 //           2^-22-accurate addition) -> 0.0045.  k_topk_select on s~ gives kth~ = k-th largest s~.
-//   pass 2  refine (k_refine_topk, one workgroup per query): every row of the exact top-k has s~ >= kth~ - 2 eps (its exact score is
+//   pass 2  refine (k_refine_topk, REF_SPLIT workgroups per query, the last one to finish merges): every row of the exact top-k has s~ >= kth~ - 2 eps (its exact score is
 //           >= the k-th largest exact score >= the k-th largest of (s~ - eps)), so all rows with s~ >= kth~ - 2 eps are gathered --
 //           whole 128-row blocks are skipped through the block maxima --, rescored exactly from the fp32 rows (fp64 accumulation,
 //           rounded once to fp32) and sorted (score desc, row asc).  Typical band content at 1M x 2048 normalised rows: ~500 rows.
@@ -732,25 +803,53 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
 #define REF_CAND 4096
 #define REF_BLK 8192
 
+#ifdef SEARCH_TRACE
+// diagnostic build only: phase stamps of k_refine_topk (block = query), read back by tools via lrx_debug_read_search_trace
+__device__ long long g_search_trace[8 * 1024];
+extern "C" int lrx_debug_read_search_trace(void* dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_search_trace), bytes) == hipSuccess ? 0 : 1;
+}
+#define S_TRACE(slot)                                                                                         \
+  do {                                                                                                        \
+    __syncthreads();                                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_search_trace[8 * blockIdx.x + (slot)] = wall_clock64();      \
+  } while (0)
+#else
+#define S_TRACE(slot)
+#endif
+
+#define REF_SPLIT 4                       // workgroups per query (phase stamps: the exact rescoring is bound by what ONE CU can fetch)
+#define REF_PCAND (REF_CAND / REF_SPLIT)  // candidate capacity of one part
+#define REF_PBLK (REF_BLK / REF_SPLIT)
+#define REF_QLDS 8192                     // query rows up to this many floats are staged in LDS by k_refine_topk
+
+// grid (n_queries, REF_SPLIT): part s of query q owns the 128-row blocks b with b % REF_SPLIT == s: it gathers their rows inside the band,
+// rescores them exactly and publishes the packed (score, row) list (count -1 = the part's lists overflowed); k_refine_merge finishes.
 __global__ void __launch_bounds__(1024)
 k_refine_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ q, const float* __restrict__ scores, int64_t ld,
               const float* __restrict__ blkmax, int nblk, int nblk_ld, const float* __restrict__ row_norm_bound, int k, int64_t id_base,
-              float* __restrict__ out_scores, int64_t* __restrict__ out_ids, int* __restrict__ qflags, int* __restrict__ any_flag) {
-  __shared__ unsigned long long s_cand[REF_CAND];
-  __shared__ unsigned int s_blk[REF_BLK];
+              const float* __restrict__ out_scores, unsigned long long* __restrict__ parts, int* __restrict__ part_cnt) {
+  __shared__ unsigned long long s_cand[REF_PCAND];
+  __shared__ unsigned int s_blk[REF_PBLK];
+  __shared__ __attribute__((aligned(16))) float s_q[REF_QLDS];   // the query row (every rescoring re-reads it; from global its loads serialise)
   __shared__ float s_red[16];
   __shared__ unsigned int s_nblk, s_ncand;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qi = blockIdx.x;
-  float* os = out_scores + (int64_t)qi * k;
-  int64_t* oi = out_ids + (int64_t)qi * k;
+  const int qi = blockIdx.x, part = blockIdx.y;
+  const float* os = out_scores + (int64_t)qi * k;
   const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
-  if (tid == 0) { s_nblk = 0; s_ncand = 0; qflags[qi] = 0; }
+  if (tid == 0) { s_nblk = 0; s_ncand = 0; }
   if (keff == 0) return;                      // (outputs already padded by k_topk_select)
+  S_TRACE(0);
   // |q|
-  const float* qrow = q + (int64_t)qi * D;
+  const float* qglob = q + (int64_t)qi * D;
+  const float* qrow = D <= REF_QLDS ? s_q : qglob;
   float ss = 0.f;
-  for (int i = tid; i < D; i += 1024) { const float v = qrow[i]; ss += v * v; }
+  for (int i = tid; i < D; i += 1024) {
+    const float v = qglob[i];
+    if (D <= REF_QLDS) s_q[i] = v;
+    ss += v * v;
+  }
   ss = wave_sum(ss);
   if (lane == 0) s_red[wave] = ss;
   __syncthreads();
@@ -758,45 +857,94 @@ k_refine_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
 #pragma unroll
   for (int w = 0; w < 16; ++w) qn2 += s_red[w];
   const float band = 2.0f * FILTER_EPS * sqrtf(qn2) * row_norm_bound[0] * 1.0001f + 1e-30f;
-  const float kth = os[keff - 1];             // k-th largest filter score (written by k_topk_select just before)
+  const float kth = os[keff - 1];             // k-th largest filter score (written by k_topk_select; nobody writes os before the merge)
   const float thr = kth - band;
-  // qualifying 128-row blocks
+  S_TRACE(1);
+  // this part's qualifying 128-row blocks
   const float* bm = blkmax + (int64_t)qi * nblk_ld;
-  for (int b = tid; b < nblk; b += 1024)
+  for (int b = part + REF_SPLIT * tid; b < nblk; b += REF_SPLIT * 1024)
     if (bm[b] >= thr) {
       const unsigned int p = atomicAdd(&s_nblk, 1u);
-      if (p < REF_BLK) s_blk[p] = (unsigned int)b;
+      if (p < REF_PBLK) s_blk[p] = (unsigned int)b;
     }
   __syncthreads();
+  S_TRACE(2);
   const unsigned int nb = s_nblk;
-  bool overflow = nb > REF_BLK;
+  bool overflow = nb > REF_PBLK;
   if (!overflow) {
     const float* row = scores + (int64_t)qi * ld;
-    for (unsigned int idx = tid; idx < nb * SP_ROWS; idx += 1024) {
-      const int64_t n = (int64_t)s_blk[idx >> 7] * SP_ROWS + (idx & (SP_ROWS - 1));
-      if (n < N && row[n] >= thr) {
-        const unsigned int p = atomicAdd(&s_ncand, 1u);
-        if (p < REF_CAND) s_cand[p] = (unsigned long long)n;
+    const unsigned int total = nb * SP_ROWS;
+    for (unsigned int idx0 = tid; idx0 < total; idx0 += 4 * 1024) {     // four independent loads in flight per thread
+      float v[4];
+      int64_t n[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned int idx = idx0 + u * 1024;
+        n[u] = idx < total ? (int64_t)s_blk[idx >> 7] * SP_ROWS + (idx & (SP_ROWS - 1)) : N;
+        v[u] = n[u] < N ? row[n[u]] : -FLT_MAX;
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (n[u] < N && v[u] >= thr) {
+          const unsigned int p = atomicAdd(&s_ncand, 1u);
+          if (p < REF_PCAND) s_cand[p] = (unsigned long long)n[u];
+        }
     }
     __syncthreads();
-    overflow = s_ncand > REF_CAND;
+    overflow = s_ncand > REF_PCAND;
   }
-  if (overflow) {
+  S_TRACE(3);
+  const int nc = overflow ? 0 : (int)s_ncand;
+#ifdef SEARCH_TRACE
+  if (tid == 0 && blockIdx.x < 1024 && part == 0) { g_search_trace[8 * blockIdx.x + 6] = nc; g_search_trace[8 * blockIdx.x + 7] = nb; }
+#endif
+  // exact rescoring: one half-wave per candidate row (fp64 accumulation of the fp32 products, one rounding to fp32)
+  unsigned long long* mine = parts + ((int64_t)qi * REF_SPLIT + part) * REF_PCAND;
+  for (int c0 = wave * 2; c0 < nc; c0 += 32) {
+    const int c = min(c0 + (lane >> 5), nc - 1);
+    const int64_t n = (int64_t)s_cand[c];
+    const float sc = exact_dot(X + n * ldx, qrow, D, lane);
+    if ((lane & 31) == 0 && c0 + (lane >> 5) < nc) mine[c] = sel_pack(f2key(sc), n);
+  }
+  if (tid == 0) part_cnt[qi * REF_SPLIT + part] = overflow ? -1 : nc;
+  S_TRACE(4);
+}
+
+// Merge of the REF_SPLIT published lists of a query (one workgroup per query; the kernel boundary orders it after k_refine_topk --
+// an in-kernel "last part merges" ticket needed device-scope fences that cost more than this launch): sort, write the top-k; a part
+// that overflowed flags the query for the gated six-product fallback.
+__global__ void __launch_bounds__(1024)
+k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restrict__ part_cnt, int64_t N, int k, int64_t id_base,
+               float* __restrict__ out_scores, int64_t* __restrict__ out_ids, int* __restrict__ qflags, int* __restrict__ any_flag) {
+  __shared__ unsigned long long s_cand[REF_CAND];
+  const int tid = threadIdx.x, qi = blockIdx.x;
+  float* os = out_scores + (int64_t)qi * k;
+  int64_t* oi = out_ids + (int64_t)qi * k;
+  const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
+  if (keff == 0) return;
+  int cnt[REF_SPLIT], tot = 0;
+  bool any_over = false;
+#pragma unroll
+  for (int p = 0; p < REF_SPLIT; ++p) {
+    cnt[p] = part_cnt[qi * REF_SPLIT + p];
+    any_over |= cnt[p] < 0;
+    tot += cnt[p] < 0 ? 0 : cnt[p];
+  }
+  if (any_over) {
     if (tid == 0) { qflags[qi] = 1; atomicOr(any_flag, 1); }
     return;
   }
-  const int nc = (int)s_ncand;
-  // exact rescoring: one wave per candidate row, fp64 accumulation of the fp32 products, one rounding to fp32
-  for (int c = wave; c < nc; c += 16) {
-    const int64_t n = (int64_t)s_cand[c];
-    const float sc = exact_dot(X + n * ldx, qrow, D, lane);
-    if (lane == 0) s_cand[c] = sel_pack(f2key(sc), n);
+  int base = 0;
+#pragma unroll
+  for (int p = 0; p < REF_SPLIT; ++p) {
+    const unsigned long long* src = parts + ((int64_t)qi * REF_SPLIT + p) * REF_PCAND;
+    for (int i = tid; i < cnt[p]; i += 1024) s_cand[base + i] = src[i];
+    base += cnt[p];
   }
-  __syncthreads();
   int P = 1;
-  while (P < nc) P <<= 1;
-  for (int i = nc + tid; i < P; i += 1024) s_cand[i] = 0ull;
+  while (P < tot) P <<= 1;
+  __syncthreads();
+  for (int i = tot + tid; i < P; i += 1024) s_cand[i] = 0ull;
   bitonic_sort_desc(s_cand, P);
   for (int i = tid; i < keff; i += 1024) {
     const unsigned long long c = s_cand[i];
@@ -806,16 +954,19 @@ k_refine_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
 }
 
 extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
-  return lrx_flat_ip_workspace_bytes(n_rows, dim, n_queries, k) + ((size_t)(n_queries > 0 ? n_queries : 1) + 1) * sizeof(int) + 256;
+  const size_t nq = (size_t)(n_queries > 0 ? n_queries : 1);
+  // + flags[Q], any_flag, done[Q], part_cnt[Q, REF_SPLIT], parts[Q, REF_SPLIT, REF_PCAND] u64
+  return lrx_flat_ip_workspace_bytes(n_rows, dim, n_queries, k) + (nq * (2 + REF_SPLIT) + 1) * sizeof(int) + nq * REF_CAND * 8 + 512;
 }
 
-extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* row_norm_bound, const float* q,
-                                          int32_t n_queries, int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids, void* workspace,
-                                          size_t workspace_bytes, void* stream) {
+extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_bf16, int64_t ldx_bf16,
+                                          const float* row_norm_bound, const float* q, int32_t n_queries, int32_t k, int64_t id_base,
+                                          float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream) {
   LRX_CHECK_ARG(row_norm_bound != nullptr, "flat_ip_search_bounded: null row_norm_bound (device pointer to max |x_row|)");
   const int qt_max = ((n_queries < 128 ? n_queries : 128) + 15) / 16;
   // small query batches are HBM-bound on the exact-fp32 kernel already; tiny shards and wide rows take the plain path too
-  if (qt_max < SPLIT_MIN_QT || n_rows <= REF_CAND || dim % 4 != 0)
+  const bool shadow = X_bf16 != nullptr && dim % 64 == 0 && ldx_bf16 >= dim && ldx_bf16 % 8 == 0;
+  if ((qt_max < SPLIT_MIN_QT && !shadow) || n_rows <= REF_CAND || dim % 4 != 0)
     return lrx_flat_ip_search(X, n_rows, ldx, dim, q, n_queries, k, id_base, out_scores, out_ids, workspace, workspace_bytes, stream);
   LRX_CHECK_ARG(k > 0 && k <= SEL_MAXK, "flat_ip_search: k=%d out of range (1..%d)", k, SEL_MAXK);
   LRX_CHECK_ARG(n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
@@ -831,14 +982,19 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
   __bf16* qsplit = (__bf16*)(blkmax + (int64_t)nblk_ld * n_queries);
   int* flags = (int*)(((uintptr_t)((char*)workspace + lrx_flat_ip_workspace_bytes(n_rows, dim, n_queries, k)) + 255) & ~(uintptr_t)255);
   int* any_flag = flags + n_queries;
-  LRX_HIP(hipMemsetAsync(any_flag, 0, sizeof(int), s));
-  int rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, qsplit, stream, 1, nullptr);
+  int* part_cnt = any_flag + 1 + n_queries;   // (n_queries ints after any_flag are spare)
+  unsigned long long* parts = (unsigned long long*)(((uintptr_t)(part_cnt + (size_t)n_queries * REF_SPLIT) + 15) & ~(uintptr_t)15);
+  LRX_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * (size_t)n_queries + 1), s));     // flags, any_flag, done tickets
+  int rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16);
   if (rc != LRX_OK) return rc;
   hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, s, scores, ld, n_rows, k, id_base, blkmax, nblk, nblk_ld, out_scores, out_ids,
                      (const int*)nullptr, (const int*)nullptr);
   LRX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_refine_topk, dim3(n_queries), dim3(1024), 0, s, X, n_rows, ldx, dim, q, scores, ld, blkmax, nblk, nblk_ld, row_norm_bound, k, id_base,
-                     out_scores, out_ids, flags, any_flag);
+  hipLaunchKernelGGL(k_refine_topk, dim3(n_queries, REF_SPLIT), dim3(1024), 0, s, X, n_rows, ldx, dim, q, scores, ld, blkmax, nblk, nblk_ld, row_norm_bound,
+                     k, id_base, (const float*)out_scores, parts, part_cnt);
+  LRX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_refine_merge, dim3(n_queries), dim3(1024), 0, s, (const unsigned long long*)parts, (const int*)part_cnt, n_rows, k, id_base, out_scores,
+                     out_ids, flags, any_flag);
   LRX_LAUNCH_CHECK();
   // gated fallback for the flagged queries (returns immediately on the device when nothing overflowed)
   rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, qsplit, stream, 3, any_flag);

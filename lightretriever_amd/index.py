@@ -25,6 +25,10 @@ class FlatIPIndex:
         # lrx_flat_ip_search_bounded scales with it.  two_pass = False forces the six-product path for every search.
         self._norm_bound = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.two_pass = True
+        # bf16 shadow of the rows (round-to-nearest-even), maintained by commit(): the filter pass of the two-pass search streams
+        # it instead of the fp32 rows (half the bytes; the exact rescoring still reads fp32).  +50 % index memory; False = no shadow.
+        self.shadow_bf16 = True
+        self._xb: Optional[torch.Tensor] = None
 
     # -- storage -------------------------------------------------------------------------------------------------
     def reserve(self, n_rows: int):
@@ -41,10 +45,23 @@ class FlatIPIndex:
             self.reserve(max(self.ntotal + n_rows, int(self._x.shape[0] * 1.5) + 1))
         return self._x[self.ntotal:self.ntotal + n_rows]
 
+    def _shadow_rows(self, a: int, b: int):
+        if not self.shadow_bf16 or self.d % 64 != 0:
+            return
+        if self._xb is None or self._xb.shape[0] < self._x.shape[0]:
+            xb = torch.empty(self._x.shape[0], self.d, dtype=torch.bfloat16, device=self.device)
+            if self._xb is not None and self.ntotal:
+                xb[:self.ntotal].copy_(self._xb[:self.ntotal])
+            self._xb = xb
+        for s in range(a, b, 262144):
+            e = min(s + 262144, b)
+            self._xb[s:e].copy_(self._x[s:e])          # fp32 -> bf16, round-to-nearest-even
+
     def commit(self, n_rows: int):
         if n_rows > 0:
             new = self._x[self.ntotal:self.ntotal + n_rows]
             torch.maximum(self._norm_bound, torch.linalg.vector_norm(new, dim=1).max().reshape(1) * (1.0 + 1e-6), out=self._norm_bound)
+            self._shadow_rows(self.ntotal, self.ntotal + n_rows)
         self.ntotal += n_rows
 
     def add(self, x):
@@ -58,7 +75,8 @@ class FlatIPIndex:
         self.commit(x.shape[0])
 
     def refresh_norm_bound(self):
-        """Recompute max |row| over all committed rows (call after writing into committed rows in place)."""
+        """Recompute max |row| (and the bf16 shadow) over all committed rows: call after writing into committed rows in place."""
+        self._shadow_rows(0, self.ntotal)
         self._norm_bound.zero_()
         for s in range(0, self.ntotal, 262144):
             e = min(s + 262144, self.ntotal)
@@ -110,7 +128,9 @@ class FlatIPIndex:
             self._ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
         ldx = self._x.stride(0) if self._x.shape[0] else self.d
         if self.two_pass:
-            _lib.check(self.lib.lrx_flat_ip_search_bounded(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(self._norm_bound), _lib.ptr(q), Q, k,
+            xb = self._xb if (self.shadow_bf16 and self._xb is not None) else None
+            _lib.check(self.lib.lrx_flat_ip_search_bounded(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(xb) if xb is not None else None,
+                                                           xb.stride(0) if xb is not None else 0, _lib.ptr(self._norm_bound), _lib.ptr(q), Q, k,
                                                            self.id_base, _lib.ptr(D), _lib.ptr(I), _lib.ptr(self._ws), self._ws.numel(),
                                                            _lib.current_stream()))
         else:

@@ -223,3 +223,31 @@ def test_two_pass_adversarial_bf16_rounding():
     Do, Io = O.flat_ip_topk(q, X, k)
     np.testing.assert_array_equal(Ig.cpu().numpy(), Io)
     np.testing.assert_allclose(Dg.cpu().numpy(), Do, atol=2e-6)
+
+
+@pytest.mark.parametrize("Q", [1, 20, 100])
+def test_bf16_shadow_filter_gives_the_same_exact_result(Q):
+    """The filter pass may stream a bf16 copy of the rows instead of the fp32 rows (half the bytes): same error band, same exact
+    rescoring from fp32 -> bitwise the same scores and ids as without the shadow, for every query batch size."""
+    from lightretriever_amd import FlatIPIndex
+    rng = np.random.default_rng(40 + Q)
+    N, D, k = 60000, 256, 64
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32)) * rng.uniform(0.5, 1.5, size=(N, 1)).astype(np.float32)
+    q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))
+    a = FlatIPIndex(D, capacity=N)
+    a.add(X[:25000]); a.add(X[25000:])
+    assert a._xb is not None and a._xb.dtype == torch.bfloat16 and torch.equal(a._xb[:N], torch.from_numpy(X).cuda().to(torch.bfloat16))
+    Da, Ia = a.search(q, k)
+    b = FlatIPIndex(D, capacity=N)
+    b.shadow_bf16 = False
+    b.add(X)
+    assert b._xb is None
+    Db, Ib = b.search(q, k)
+    assert torch.equal(Ia, Ib) and torch.equal(Da, Db)
+    check_against_oracle(Da, Ia, q, X, k)
+    # rows rewritten in place after commit: refresh rebuilds bound and shadow
+    a._x[:10] = torch.from_numpy(X[100:110]).cuda() * 3.0
+    a.refresh_norm_bound()
+    X2 = X.copy(); X2[:10] = X[100:110] * 3.0
+    D2, I2 = a.search(q, k)
+    check_against_oracle(D2, I2, q, X2, k)

@@ -23,7 +23,8 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); idx.search(q, 100); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
         med = statistics.median(ts)
-        print(f"Q={Q:4d}: {med:.3f} ms  -> {N*D*4/med/1e6:.0f} GB/s corpus stream, {Q/med*1e3:.0f} q/s, {2*Q*D*N/med/1e9:.1f} TFLOP/s", flush=True)
+        bpe = 2 if (idx._xb is not None and idx.two_pass) else 4
+        print(f"Q={Q:4d}: {med:.3f} ms  -> {N*D*bpe/med/1e6:.0f} GB/s corpus stream ({bpe} B/element), {Q/med*1e3:.0f} q/s, {2*Q*D*N/med/1e9:.1f} TFLOP/s", flush=True)
 
 if __name__ == "__main__":
     main()
