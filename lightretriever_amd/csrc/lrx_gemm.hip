@@ -53,6 +53,7 @@ struct MaxAggArgs {
 struct NormArgs {
   const float* rscale;
   float* ss_part;
+  int group_m;               // m-tiles per group of the block -> tile map (rides along in this struct)
 };
 
 // max(*p, v) for floats with integer atomics: non-negative floats order like ints, negative ones inversely like uints
@@ -111,7 +112,9 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
   const int t_lin = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-  const int GM = 8;
+  // m-tiles per group (a group sweeps all n-tiles): measured per shape on one box -- gate-up 6 (5.97 ms vs 6.28 at 8), down/o 4
+  // (2.92 vs 3.02, 0.91 vs 0.93), qkv 8 (1.30 vs 1.34 at 6): the A group must share the 4-MiB L2 with the streaming B tiles
+  const int GM = nrm.group_m;
   const int width = GM * tiles_n;
   const int group = t_lin / width, first_m = group * GM;
   const int gsz = min(tiles_m - first_m, GM);
@@ -449,7 +452,7 @@ extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, con
   __bf16* c = (__bf16*)C;
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   MaxAggArgs nomx = {nullptr, nullptr, 0};
-  NormArgs nrm = {rscale, ss_part};
+  NormArgs nrm = {rscale, ss_part, epilogue == EPI_SWIGLU ? 6 : (epilogue == EPI_RESID ? 4 : 8)};
   switch (epilogue) {
     case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm); break;
     case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm); break;
@@ -477,11 +480,14 @@ extern "C" int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C,
   RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)Wqkv,
                      (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{rscale, nullptr});
+                     NormArgs{rscale, nullptr, 8});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
 
+#ifndef LRX_MAXAGG_GM
+#define LRX_MAXAGG_GM 8
+#endif
 // out[row_seg[m], n] = max(out[row_seg[m], n], bf16(A[m,:] . B[n,:] + bias[n])) over the rows with row_seg >= 0 (lrx_sparse.hip)
 int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias, const int32_t* row_seg, float* out, int64_t ldo, int M, int N,
                                   int K, hipStream_t stream) {
@@ -492,7 +498,7 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   MaxAggArgs mx = {row_seg, out, ldo};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
-                     (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr});
+                     (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, LRX_MAXAGG_GM});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
