@@ -156,7 +156,7 @@ def test_full_size_1m_x_2048_properties():
 
 # ---- two-pass bounded search (bf16 filter + exact rescoring), Q > 32 ---------------------------------------------------
 @pytest.mark.parametrize("N,D,Q,k,scale", [(120000, 256, 100, 100, "unit"), (50000, 128, 64, 10, "mixed"), (9000, 64, 33, 1000, "unit"),
-                                            (30000, 2048, 40, 50, "unit")])
+                                            (30000, 2048, 40, 50, "unit"), (20000, 128, 300, 7, "unit"), (6000, 64, 5, 2048, "mixed")])
 def test_two_pass_equals_six_product_path_and_oracle(N, D, Q, k, scale):
     from lightretriever_amd import FlatIPIndex
     rng = np.random.default_rng(N + D)
