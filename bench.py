@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--model", default="llama3.2-1b", choices=["llama3.2-1b", "llama3.1-8b", "qwen2.5-1.5b", "qwen2.5-7b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mrl-dim", type=int, default=0, help="index / embedding dimension D (dense_shrink_dim, e.g. 256 for BASELINE config 5); 0 = hidden size")
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the dense+sparse document-vector leg (SURVEY 8f N2)")
     ap.add_argument("--ragged", action="store_true",
@@ -160,7 +161,8 @@ def main():
     if os.environ.get("LRX_FOLD_NORM") is not None:          # dev A/B switch; the default is the library's (folded)
         cfg.fold_norm = os.environ["LRX_FOLD_NORM"] != "0"
     enc = LrxEncoder.random_init(cfg, seed=0, device=dev)
-    B, S, D = args.batch_docs, args.seq_len, cfg.hidden_size
+    B, S, H = args.batch_docs, args.seq_len, cfg.hidden_size
+    D = args.mrl_dim or H                       # embedding / index width (MRL slice of the pooled state when < H)
 
     # ---- synthetic inputs, resident in HBM: ids uniform in [1000,127000), bos first / eos last
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -196,9 +198,9 @@ def main():
     def encode_step(i):
         out = index._x[i * B:(i + 1) * B]           # in place into the shard (no host round trip)
         if batches is None:
-            enc.encode_packed(ids_all[i].reshape(-1), cu, S, out=out)
+            enc.encode_packed(ids_all[i].reshape(-1), cu, S, out=out, out_dim=D)
         else:
-            enc.encode_packed(batches[i][0], batches[i][1], batches[i][2], out=out)
+            enc.encode_packed(batches[i][0], batches[i][1], batches[i][2], out=out, out_dim=D)
 
     # ---- encode leg: W warmup steps, then EXACTLY K timed steps between barrier + synchronize.  Inside the timed region only the
     #      dominant kernel (gate-up GEMM, class 2) is bracketed by HIP events on the launch stream -- read after the region, no
@@ -289,10 +291,10 @@ def main():
         if distributed:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         sp_s = float(t.item())
-        mx_fl = 2.0 * B * S * cfg.vocab_size * D
+        mx_fl = 2.0 * B * S * cfg.vocab_size * H
         sparse = {"metric": "docs/sec with dense + sparse (LM-head max aggregation, relu, log1p) vectors", "value": round(world * B * n_sp / sp_s, 2),
                   "unit": "docs/s", "steps": n_sp, "ms_per_step": round(1e3 * sp_s / n_sp, 3),
-                  "roofline": {"bound": "mfma", "kernel": "k_gemm_bf16_nt<EPI_MAXAGG> (M=%d N=%d K=%d, segmented column max in the epilogue)" % (B * S, cfg.vocab_size, D),
+                  "roofline": {"bound": "mfma", "kernel": "k_gemm_bf16_nt<EPI_MAXAGG> (M=%d N=%d K=%d, segmented column max in the epilogue)" % (B * S, cfg.vocab_size, H),
                                "achieved": round(mx_fl / (mx_ms / n_sp * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(mx_fl / (mx_ms / n_sp * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(mx_ms / n_sp, 3),
                                "traffic": pmc_traffic("k_gemm_bf16_nt<4>") if (args.model == "llama3.2-1b" and B == 256 and S == 512) else None}}
@@ -310,7 +312,7 @@ def main():
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
         "traffic": pmc_traffic("k_gemm_bf16_nt<2>") if (args.model == "llama3.2-1b" and B == 256 and S == 512) else None,
-        "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (gate-up projection, M=%d N=%d K=%d)" % (B * S, 2 * cfg.intermediate_size, D),
+        "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (gate-up projection, M=%d N=%d K=%d)" % (B * S, 2 * cfg.intermediate_size, H),
         "avg_launch_ms": round(gu["ms"] / max(gu["launches"], 1), 4), "launches": gu["launches"],
         "pmc_mfma_busy_frac": pmc_mfma("k_gemm_bf16_nt<2>")[0], "pmc_effective_clock_ghz": pmc_mfma("k_gemm_bf16_nt<2>")[1],
         "all_gemms_tflops": round(gemm_all_fl / (gemm_all_ms * 1e-3) / 1e12, 2) if gemm_all_ms > 0 else None,
