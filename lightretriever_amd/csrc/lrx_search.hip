@@ -224,9 +224,15 @@ __global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, in
 #ifndef SPX_WV
 #define SPX_WV 8
 #endif
+#ifndef SPX_QSB
+#define SPX_QSB true
+#endif
 // XB: X is the bf16 shadow of the corpus (half the bytes; k-slices of 64 in natural order, fragments read straight from LDS).
-template <int QT, int NP, int RT, int NST, int WV, bool XB = false>
-__global__ void __launch_bounds__(64 * WV, (NST * (16 * RT * WV * 128 + (((XB ? 2 : NP) * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1)
+// QSB: the q k-slice is single-buffered (re-requested after a second barrier per iteration; it comes from L2) so that only the X
+// slices are double-buffered: 48 KiB of LDS per 128-row workgroup -> three workgroups per CU, i.e. 1.5x the HBM bytes in flight of the
+// two-per-CU layout (the shadow filter pass is bound by bytes in flight x latency, not by the matrix pipe or the LDS).
+template <int QT, int NP, int RT, int NST, int WV, bool XB = false, bool QSB = false>
+__global__ void __launch_bounds__(64 * WV, QSB ? 3 : ((NST * (16 * RT * WV * 128 + (((XB ? 2 : NP) * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1))
 k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
                        float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate) {
   static_assert(!XB || NP == 1, "the bf16 shadow is a single-product filter");
@@ -240,7 +246,9 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
   constexpr int STAGE = XT + QBYTES;
   constexpr int CW = 2 * RT + QI4;               // DMA instructions per wave per stage
   static_assert((NST - 1) * CW <= 63, "vmcnt immediate");
-  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
+  static_assert(!QSB || (XB && NST == 2), "single-buffered q: shadow filter with two X stages");
+  constexpr int LDS_BYTES = QSB ? (2 * XT + QBYTES) : NST * STAGE;
+  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
   if (gate != nullptr && *gate == 0) return;     // fallback launch of the bounded search: nothing overflowed
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -255,12 +263,14 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
     px[i] = XB ? (const char*)(Xb + g * ldx + c * 8) : (const char*)(X + g * ldx + c * 4);
   }
   const __bf16* pq = qs + (int64_t)lane * 8;     // + (kt*QINST + j) * 512 elements
-  auto stage = [&](int st, int kt) {
-    char* sX = smem + st * STAGE;
-    char* sQ = sX + XT;
+  auto stage_x = [&](int st, int kt) {
+    char* sX = smem + st * (QSB ? XT : STAGE);
 #pragma unroll
     for (int i = 0; i < 2 * RT; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + (int64_t)kt * 128), (lptr_t)(sX + (wave * 2 * RT + i) * 1024), 16, 0, 0);
+  };
+  auto stage_q = [&](int st, int kt) {
+    char* sQ = QSB ? smem + 2 * XT : smem + st * STAGE + XT;
 #pragma unroll
     for (int jj = 0; jj < QI4; ++jj) {
       const int j = wave + WV * jj;
@@ -268,6 +278,7 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
       __builtin_amdgcn_global_load_lds((gptr_t)(pq + ((int64_t)kt * QINST + jsrc) * 512), (lptr_t)(sQ + j * 1024), 16, 0, 0);
     }
   };
+  auto stage = [&](int st, int kt) { stage_x(st, kt); stage_q(st, kt); };
 
   const int fi = lane & 15, fq = lane >> 4;
   const int xs = fi >> 1;
@@ -281,18 +292,30 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
     for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = XB ? D / 64 : D / S_BK;
+  if (QSB) {
+    stage_x(0, 0); stage_q(0, 0);
+    if (nk > 1) stage_x(1, 1);
+  } else {
 #pragma unroll
-  for (int st = 0; st < NST - 1; ++st)
-    if (st < nk) stage(st, st);
+    for (int st = 0; st < NST - 1; ++st)
+      if (st < nk) stage(st, st);
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt % NST;
+    if (QSB) {
+      // in flight at most the X slice of kt+1 (issued last): X(kt) and q(kt) have landed
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else {
     // stage kt has landed when at most the (NST-2) younger stages' instructions of this wave are outstanding
     if (NST > 2 && kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * CW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // everyone's part of stage kt is in LDS; slot (kt-1) % NST is free
     if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST, kt + NST - 1);
-    const char* sX = smem + cur * STAGE + (wave * 16 * RT) * 128;
-    const char* sQ = smem + cur * STAGE + XT + lane * 16;
+    }
+    const char* sX = smem + cur * (QSB ? XT : STAGE) + (wave * 16 * RT) * 128;
+    const char* sQ = (QSB ? smem + 2 * XT : smem + cur * STAGE + XT) + lane * 16;
     if (XB) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -305,6 +328,12 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
 #pragma unroll
           for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], qf, acc[a][b], 0, 0, 0);
         }
+      }
+      if (QSB && kt + 1 < nk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // every wave has read q(kt) and X slot cur: both may be overwritten
+        stage_q(0, kt + 1);
+        if (kt + 2 < nk) stage_x(cur, kt + 2);             // issued after q: stays in flight across the next wait
       }
       continue;
     }
@@ -389,7 +418,7 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
   // the 1.8 ms filter pass at Q = 100).  Staged through LDS instead -- [query][RB rows] with a 16-B pad per query, conflict-free
   // ds_write_b128 -- and written as whole RB*4-byte row segments, 1 KiB contiguous per wave instruction.
   constexpr int SEG = RB * 4 + 16;
-  constexpr int QPT = ((NST * STAGE) / SEG / 16) < QT ? ((NST * STAGE) / SEG / 16) : QT;   // q-tiles staged per pass
+  constexpr int QPT = (LDS_BYTES / SEG / 16) < QT ? (LDS_BYTES / SEG / 16) : QT;   // q-tiles staged per pass
   static_assert(QPT >= 1, "epilogue staging does not fit");
   constexpr int NPASS = (QT + QPT - 1) / QPT;
 #pragma unroll
@@ -442,12 +471,14 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
       // filter pass over the bf16 shadow of the corpus: half the bytes of the fp32 rows
       int threads = (dim / 64) * 2 * qt * 64;
       hipLaunchKernelGGL(k_pack_queries_xb, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit);
-#define LRX_SB(QQ)                                                                                                                                      \
+#define LRX_SB(QQ, QSB_)                                                                                                                               \
   case QQ:                                                                                                                                              \
-    hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPX_RT, SPX_NST, SPX_WV, true>), dim3((unsigned)(ld / (16 * SPX_RT * SPX_WV))), dim3(64 * SPX_WV), 0, \
+    hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPX_RT, SPX_NST, SPX_WV, true, QSB_>), dim3((unsigned)(ld / (16 * SPX_RT * SPX_WV))), dim3(64 * SPX_WV), 0, \
                        s, Xb, n_rows, ldxb, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate);                                                                 \
     break;
-      switch (qt) { LRX_SB(1) LRX_SB(2) LRX_SB(3) LRX_SB(4) LRX_SB(5) LRX_SB(6) LRX_SB(7) LRX_SB(8) }
+      // q slices of one or two tiles are small enough for three workgroups per CU even double-buffered; from three tiles on the
+      // single-buffered q layout buys the third workgroup (Q = 100: 1.23 -> 1.19 ms)
+      switch (qt) { LRX_SB(1, false) LRX_SB(2, false) LRX_SB(3, SPX_QSB) LRX_SB(4, SPX_QSB) LRX_SB(5, SPX_QSB) LRX_SB(6, SPX_QSB) LRX_SB(7, SPX_QSB) LRX_SB(8, SPX_QSB) }
 #undef LRX_SB
       LRX_LAUNCH_CHECK();
       continue;
