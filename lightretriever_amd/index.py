@@ -100,7 +100,7 @@ class FlatIPIndex:
         idx = cls(mm.shape[1], capacity=mm.shape[0], device=device, id_base=id_base)
         for s in range(0, mm.shape[0], chunk_rows):
             e = min(s + chunk_rows, mm.shape[0])
-            idx._x[s:e].copy_(torch.from_numpy(np.ascontiguousarray(mm[s:e])), non_blocking=False)
+            idx._x[s:e].copy_(torch.from_numpy(np.array(mm[s:e], copy=True)), non_blocking=False)
         idx.commit(mm.shape[0])
         return idx
 

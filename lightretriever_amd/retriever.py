@@ -200,6 +200,9 @@ class FlatIPFaissSearch(DenseRetrievalFaissSearch):
         self._create_mapping_ids(corpus_ids)
         self.dim_size = dim
         idx = FlatIPIndex(dim, capacity=len(docs))
+        if not docs:                                  # a rank without a batch in this chunk: empty shard, searches return padding
+            self.faiss_index = FaissIndex(idx, None)
+            return
         slot = idx.append_slot(len(docs))
         emb = self.model.encode_corpus(docs, batch_size=self.batch_size, show_progress_bar=self.show_progress_bar,
                                        convert_to_tensor=True, out=slot)
@@ -354,12 +357,24 @@ def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: li
     ident = torch.tensor([row_of.get(q, -2) for q in query_ids], dtype=torch.int64, device=device) if ignore_identical_ids else None
     run_D = [torch.full((Q, top_k), -FLT_MAX, dtype=torch.float32, device=device) for _ in qlist]
     run_I = [torch.full((Q, top_k), -1, dtype=torch.int64, device=device) for _ in qlist]
+    rank, world = DenseRetrievalFaissSearch._rank_world()
+    if world > 1:
+        from .sharded import exchange_topk, local_to_global_rows
     for s in range(0, n, searcher.corpus_chunk_size):
         e = min(s + searcher.corpus_chunk_size, n)
         logger.info("Encoding Batch %d/%d...", s // searcher.corpus_chunk_size + 1, -(-n // searcher.corpus_chunk_size))
-        searcher._index_in_place(docs[s:e], list(range(s, e)), dim)   # rows carry their global sorted position
+        if world > 1:
+            # one process per GPU: batch j of this chunk's sorted documents belongs to rank j % world; every rank
+            # encodes its batches into its own HBM shard whose rows carry their global sorted position
+            rows = (local_to_global_rows(e - s, searcher.batch_size, rank, world) + s).tolist()
+            searcher._index_in_place([docs[i] for i in rows], rows, dim)
+        else:
+            searcher._index_in_place(docs[s:e], list(range(s, e)), dim)   # rows carry their global sorted position
         for j, q in enumerate(qlist):
             D, I = searcher._retrieve_device(q, top_k)
+            if world > 1:                             # one all-gather of the packed per-shard lists, merge on every rank
+                Dp, Ip = exchange_topk(D, I)
+                D, I = merge_topk(Dp, Ip)
             if ident is not None:                     # drop the qid == pid hit AFTER the per-chunk top_k, like the reference
                 hit = I == ident[:, None]
                 D = torch.where(hit, torch.full_like(D, -FLT_MAX), D)

@@ -48,9 +48,12 @@ def exchange_topk(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.Process
     if world == 1 and not (force_collective and dist.is_initialized()):
         return D.unsqueeze(0), I.unsqueeze(0)
     Q = packed.shape[0]
+    dev = packed.device
+    if packed.is_cuda and dist.get_backend(group) == "gloo":      # CPU-side process group (tests, debugging): stage the 8-byte pairs through the host
+        packed = packed.cpu()
     out = torch.empty((world * Q,) + tuple(packed.shape[1:]), dtype=torch.int64, device=packed.device)   # concat form: nccl + gloo
     dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
-    return unpack_pairs(out.view((world, Q) + tuple(packed.shape[1:])))
+    return unpack_pairs(out.view((world, Q) + tuple(packed.shape[1:])).to(dev))
 
 
 class ShardedFlatIPIndex:

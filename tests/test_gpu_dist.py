@@ -38,3 +38,56 @@ def test_sharded_finish_over_rccl_single_rank():
         assert t.item() == 1.5
     finally:
         dist.destroy_process_group()
+
+
+def _search_worker(rank, world, port, ret):
+    """One rank of a two-process run on the same GPU (gloo process group; RCCL refuses two ranks on one device): the full
+    B1 flow -- HybridSearch.search over a synthetic corpus -- with the chunk's batches sharded over the ranks."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from test_gpu_api import build_stack, synth_corpus
+        from helpers import load_model_golden
+        from lightretriever_amd.retriever import HybridSearch
+        cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+        tok, enc, hm, model = build_stack(cfg_o, w)
+        corpus = synth_corpus(np.random.default_rng(0), 150)
+        queries = {"q0": "capital of france", "q1": "dense retrieval models", "q2": "amd instinct memory"}
+        res = HybridSearch(model, batch_size=16, corpus_chunk_size=70).search(corpus, queries, top_k=12)
+        ret[rank] = {q: dict(v) for q, v in res.items()}
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_search_flow_sharded_over_two_ranks_equals_single_process():
+    """SURVEY 8e through the reference-shaped entry point: two processes, interleaved batches per chunk, all-gather + merge ->
+    the same hits (ids and scores) as one process holding the whole corpus."""
+    import torch.multiprocessing as mp
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_api import build_stack, synth_corpus
+    from helpers import load_model_golden
+    from lightretriever_amd.retriever import HybridSearch
+    cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    tok, enc, hm, model = build_stack(cfg_o, w)
+    corpus = synth_corpus(np.random.default_rng(0), 150)
+    queries = {"q0": "capital of france", "q1": "dense retrieval models", "q2": "amd instinct memory"}
+    want = HybridSearch(model, batch_size=16, corpus_chunk_size=70).search(corpus, queries, top_k=12)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 30500 + os.getpid() % 1000
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_search_worker, args=(r, 2, port, ret)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for r in range(2):
+        assert set(ret[r]) == set(want)
+        for q in want:
+            assert list(ret[r][q]) == list(want[q]) or set(ret[r][q]) == set(want[q])
+            for pid, sc in want[q].items():
+                assert abs(ret[r][q][pid] - sc) < 1e-6
