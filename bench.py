@@ -266,7 +266,7 @@ def main():
             "dim": D, "shard_rows": shard_rows, "scaling": "strong (fixed index row-sharded over ranks)",
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (local_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(alg_bytes / (local_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                         "traffic": pmc_search_traffic() if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100) else None,
+                         "traffic": pmc_search_traffic() if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100 and D == 2048) else None,
                          "algorithmic_bytes": alg_bytes,
                          "kernel": "two-pass exact search: k_flat_ip_scores_split<QT,1,..,XB> (single-product filter over the bf16 shadow of the shard, HBM-bound) + k_topk_select + k_refine_topk/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
                          "fp32_equiv_tflops": round(2.0 * args.queries * D * shard_rows / (local_ms * 1e-3) / 1e12, 2),
