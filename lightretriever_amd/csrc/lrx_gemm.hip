@@ -371,8 +371,29 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 #pragma unroll
     for (int it = 0; it < NIT; ++it) rpos[it] = rope.positions[min(m0 + (it * 512 + tid) / CPR, M - 1)];
   }
+  // RoPE: this thread's column chunk (hence its rotary pair and table offset j) is the same in every iteration; the cos/sin rows of
+  // eight iterations are requested together before the first is used (one dependent L2 round trip per iteration cost 6.6 us per tile)
+  constexpr int RBATCH = (EPI == EPI_ROPE) ? 8 : NIT;
+  const int rn = c0 + (tid % CPR) * 8;
+  const bool rot = EPI == EPI_ROPE && rn < rope.rope_cols;
+  const int rhalf = rope.head_dim >> 1;
+  const int rwithin = rn % rope.head_dim;
+  const bool rfirst = rwithin < rhalf;
+  const int rj = rot ? (rfirst ? rwithin : rwithin - rhalf) : 0;
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
+  for (int it0 = 0; it0 < NIT; it0 += RBATCH) {
+  f32x4 rcs[EPI == EPI_ROPE ? RBATCH : 1][4];
+  if (EPI == EPI_ROPE) {
+#pragma unroll
+    for (int u = 0; u < RBATCH; ++u) {
+      const float* cs = rope.cos + (int64_t)rpos[it0 + u] * rhalf + rj;
+      const float* sn = rope.sin + (int64_t)rpos[it0 + u] * rhalf + rj;
+      rcs[u][0] = *(const f32x4*)cs; rcs[u][1] = *(const f32x4*)(cs + 4); rcs[u][2] = *(const f32x4*)sn; rcs[u][3] = *(const f32x4*)(sn + 4);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < RBATCH; ++u) {
+    const int it = it0 + u;
     const int q = it * 512 + tid;
     const int row = q / CPR, ch = q % CPR;
     const int m = m0 + row, n = c0 + ch * 8;
@@ -399,28 +420,21 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
         if (!inb) continue;
       }
     }
-    if (EPI == EPI_ROPE && n < rope.rope_cols) {
+    if (EPI == EPI_ROPE && rot) {
       // rotary embedding on the staged bf16 q|k values (same arithmetic as k_rope): the rotate_half partner sits half a
       // head away in the same staged row (heads never straddle a 256-column tile: head_dim divides 256)
-      const int half = rope.head_dim >> 1;
-      const int within = n % rope.head_dim;
-      const bool first = within < half;
-      const int j = first ? within : within - half;
-      const int pch = ch + (first ? (half >> 3) : -(half >> 3));
+      const int pch = ch + (rfirst ? (rhalf >> 3) : -(rhalf >> 3));
       bf16x8 pv = *(const bf16x8*)(smem + row * (CW * 2) + ((pch ^ (row & 15)) << 4));
-      const int pos = rpos[it];
-      const float* cs = rope.cos + (int64_t)pos * half + j;
-      const float* sn = rope.sin + (int64_t)pos * half + j;
-      const f32x4 c0 = *(const f32x4*)cs, c1 = *(const f32x4*)(cs + 4), s0 = *(const f32x4*)sn, s1 = *(const f32x4*)(sn + 4);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float a = bf2f(v[e]), b = bf2f(pv[e]);
-        const float cc = e < 4 ? c0[e & 3] : c1[e & 3], ss = e < 4 ? s0[e & 3] : s1[e & 3];
-        v[e] = f2bf(first ? a * cc - b * ss : a * cc + b * ss);
+        const float cc = e < 4 ? rcs[u][0][e & 3] : rcs[u][1][e & 3], ss = e < 4 ? rcs[u][2][e & 3] : rcs[u][3][e & 3];
+        v[e] = f2bf(rfirst ? a * cc - b * ss : a * cc + b * ss);
       }
     }
     *(bf16x8*)(C + (int64_t)m * ldc + n) = v;
   }
+  }  // it0 batches
 #ifdef GEMM_TRACE
   G_TRACE(6);
   __builtin_amdgcn_s_waitcnt(0);

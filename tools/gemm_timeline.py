@@ -14,12 +14,19 @@ def main():
     lib.lrx_debug_read_gemm_trace.argtypes = [C.c_void_p, C.c_size_t]
     M = 131072
     g = torch.Generator(device="cuda").manual_seed(0)
-    for name, N, K, epi in [("gate_up", 16384, 2048, 2), ("o", 2048, 2048, 1), ("down", 2048, 8192, 1), ("qkv", 3072, 2048, 0)]:
+    from lightretriever_amd.encoder import EncoderConfig, rope_tables
+    cos, sin = rope_tables(EncoderConfig.llama32_1b(512))
+    cos, sin = cos.cuda(), sin.cuda()
+    pos = (torch.arange(M, device="cuda") % 512).to(torch.int32)
+    for name, N, K, epi in [("gate_up", 16384, 2048, 2), ("o", 2048, 2048, 1), ("down", 2048, 8192, 1), ("qkv", 3072, 2048, 0), ("qkv_rope", 3072, 2048, 3)]:
         A = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
         B = (torch.randn(N, K, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
         out = torch.empty(M, N // 2 if epi == 2 else N, dtype=torch.bfloat16, device="cuda")
         for _ in range(2):
-            ops.gemm_bf16_nt(A, B, resid=out if epi == 1 else None, epilogue=epi, out=out)
+            if epi == 3:
+                ops.gemm_qkv_rope(A, B, pos, cos, sin, 32, 8, 64)
+            else:
+                ops.gemm_bf16_nt(A, B, resid=out if epi == 1 else None, epilogue=epi, out=out)
         torch.cuda.synchronize()
         ntiles = (M // 256) * ((N + 255) // 256)
         n = min(ntiles, 65536)
