@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Randomised shape fuzz of the kernels against plain torch fp32 / the oracle (run on the GPU box): GEMM epilogues, varlen attention,
+two-pass search, encoder vs oracle.  Prints one line per failure and a summary; exit code 1 on any failure.
+usage: python tools/fuzz_gpu.py [--seed 0] [--rounds 40]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import lrx_oracle as O
+from lightretriever_amd import ops, FlatIPIndex
+from lightretriever_amd.encoder import interleave_gate_up
+
+def bf(a): return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda().to(torch.bfloat16).contiguous()
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--rounds", type=int, default=40)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    fails = 0
+    def check(name, ok, info):
+        nonlocal fails
+        if not ok:
+            fails += 1
+            print("FAIL", name, info, flush=True)
+    for r in range(a.rounds):
+        # ---- GEMM
+        M = int(rng.choice([1, 7, 255, 256, 257, 300, 511, 1000, 2049])); K = 64 * int(rng.integers(1, 40)); epi = int(rng.integers(0, 3))
+        N = 8 * int(rng.integers(1, 130)) if epi != 2 else 32 * int(rng.integers(1, 40))
+        A = O.round_bf16(rng.standard_normal((M, K)).astype(np.float32)); B = O.round_bf16(rng.standard_normal((N, K)).astype(np.float32) * 0.05)
+        At, Bt = bf(A), bf(B)
+        ref = At.float() @ Bt.float().T
+        if epi == 0:
+            bias = bf(O.round_bf16(rng.standard_normal(N).astype(np.float32)))
+            got = ops.gemm_bf16_nt(At, Bt, bias=bias, epilogue=0).float(); want = (ref + bias.float()).to(torch.bfloat16).float()
+        elif epi == 1:
+            R = bf(O.round_bf16(rng.standard_normal((M, N)).astype(np.float32)))
+            got = ops.gemm_bf16_nt(At, Bt, resid=R, epilogue=1).float(); want = (ref.to(torch.bfloat16).float() + R.float()).to(torch.bfloat16).float()
+        else:
+            g, u = ref[:, :N // 2], ref[:, N // 2:]
+            Bi = interleave_gate_up(Bt[:N // 2].float().cpu(), Bt[N // 2:].float().cpu()).cuda().to(torch.bfloat16).contiguous()
+            got = ops.gemm_bf16_nt(At, Bi, epilogue=2).float(); want = (torch.nn.functional.silu(g) * u).to(torch.bfloat16).float()
+        tol = 2.0 ** -7 * want.abs() + 2.0 ** -7 * ref.abs().max() * 0.02 + 1e-3
+        bad = ((got - want).abs() > tol).float().mean().item()
+        check("gemm", bad < 2e-3 and got.shape == want.shape, (M, N, K, epi, bad))
+        # ---- attention
+        d = int(rng.choice([64, 128])); nkv = int(rng.choice([1, 2, 4])); grp = int(rng.choice([1, 2, 4, 6, 7, 8])); nq = nkv * grp
+        lens = [int(x) for x in rng.integers(1, 300, size=int(rng.integers(1, 6)))]
+        T = sum(lens); W = (nq + 2 * nkv) * d
+        qkv = O.round_bf16(rng.standard_normal((T, W)).astype(np.float32)); cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        got = ops.attn_varlen_causal(bf(qkv), torch.from_numpy(cu).cuda(), max(lens), nq, nkv, d).float().cpu().numpy()
+        q = qkv[:, :nq * d].reshape(T, nq, d); k = qkv[:, nq * d:(nq + nkv) * d].reshape(T, nkv, d); v = qkv[:, (nq + nkv) * d:].reshape(T, nkv, d)
+        want = np.zeros((T, nq, d), np.float32)
+        for b in range(len(lens)):
+            s, e = cu[b], cu[b + 1]; L = e - s; causal = np.tril(np.ones((L, L), bool))
+            for h in range(nq):
+                sc = np.where(causal, (q[s:e, h] @ k[s:e, h // grp].T) * np.float32(d ** -0.5), -np.inf)
+                p = np.exp(sc - sc.max(-1, keepdims=True)); want[s:e, h] = (p / p.sum(-1, keepdims=True)) @ v[s:e, h // grp]
+        err = np.abs(got - want.reshape(T, nq * d)).max()
+        check("attn", err < 3e-2, (d, nq, nkv, lens, float(err)))
+        # ---- search
+        N_ = int(rng.choice([300, 4097, 5000, 20000, 70001])); D = int(rng.choice([32, 64, 96, 128, 256])); Q = int(rng.choice([1, 3, 17, 33, 100, 130])); kk = int(rng.choice([1, 5, 100, 257]))
+        X = O.l2_normalize(rng.standard_normal((N_, D)).astype(np.float32)) * rng.uniform(0.2, 2.0, size=(N_, 1)).astype(np.float32)
+        qq = rng.standard_normal((Q, D)).astype(np.float32)
+        idx = FlatIPIndex(D, capacity=N_); idx.add(X)
+        Dg, Ig = idx.search(qq, kk); Dg, Ig = Dg.cpu().numpy(), Ig.cpu().numpy()
+        Do, Io = O.flat_ip_topk(qq, X, kk)
+        valid = Io >= 0
+        ok = np.allclose(Dg[valid], Do[valid], atol=2e-5, rtol=2e-5) and (Ig[~valid] == -1).all()
+        mism = (Ig != Io) & valid
+        if ok and mism.any():
+            qi, ri = np.nonzero(mism)
+            ok = np.abs(np.einsum("ij,ij->i", qq[qi], X[Ig[qi, ri]]) - Do[qi, ri]).max() < 5e-5
+        check("search", ok, (N_, D, Q, kk, float(mism.mean())))
+    print("fuzz rounds", a.rounds, "failures", fails)
+    sys.exit(1 if fails else 0)
+
+if __name__ == "__main__":
+    main()
