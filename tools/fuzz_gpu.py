@@ -70,6 +70,26 @@ def main():
             qi, ri = np.nonzero(mism)
             ok = np.abs(np.einsum("ij,ij->i", qq[qi], X[Ig[qi, ri]]) - Do[qi, ri]).max() < 5e-5
         check("search", ok, (N_, D, Q, kk, float(mism.mean())))
+    # ---- encoder end to end vs the oracle (small random architectures)
+    from dataclasses import asdict
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    for r in range(max(1, a.rounds // 6)):
+        d = int(rng.choice([64, 128])); nkv = int(rng.choice([1, 2])); grp = int(rng.choice([1, 2, 4])); nq = nkv * grp
+        H = int(rng.choice([128, 256, 512])); I = 64 * int(rng.integers(1, 9)); L = int(rng.integers(1, 4))
+        cfg = O.EncoderConfig(vocab_size=400, hidden_size=H, num_layers=L, num_q_heads=nq, num_kv_heads=nkv, head_dim=d, intermediate_size=I,
+                              rms_eps=1e-5 if rng.random() < 0.5 else 1e-6, rope_theta=float(rng.choice([10000.0, 500000.0, 1e6])),
+                              rope_type=str(rng.choice(["default", "llama3"])), rope_factor=8.0, rope_original_max_position=64,
+                              qkv_bias=bool(rng.random() < 0.5), max_positions=256)
+        w = O.random_weights(cfg, seed=int(rng.integers(0, 1 << 30)), std=0.05)
+        lens = [int(x) for x in rng.integers(1, 200, size=int(rng.integers(1, 7)))]
+        ids = rng.integers(0, 400, size=sum(lens)).astype(np.int32); cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        fold = bool(rng.random() < 0.7)
+        enc = LrxEncoder(EncoderConfig(**asdict(cfg), fold_norm=fold), {k: torch.from_numpy(v) for k, v in w.items()})
+        shrink = int(rng.choice([H, H // 2]))
+        got = enc.encode_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), max(lens), out_dim=shrink).cpu().numpy()
+        want = O.encode_passage(cfg, w, ids, cu, dense_shrink_dim=shrink)
+        cos = (got * want).sum(-1)
+        check("encoder", cos.min() > 1 - 6e-3 and np.isfinite(got).all(), (H, I, L, nq, nkv, d, cfg.rope_type, cfg.qkv_bias, fold, lens, float(1 - cos.min())))
     print("fuzz rounds", a.rounds, "failures", fails)
     sys.exit(1 if fails else 0)
 
