@@ -90,6 +90,51 @@ def main():
         want = O.encode_passage(cfg, w, ids, cu, dense_shrink_dim=shrink)
         cos = (got * want).sum(-1)
         check("encoder", cos.min() > 1 - 6e-3 and np.isfinite(got).all(), (H, I, L, nq, nkv, d, cfg.rope_type, cfg.qkv_bias, fold, lens, float(1 - cos.min())))
+    # ---- sparse max aggregation, hit-list fusion, shared-prefix encode
+    from lightretriever_amd.score_fuse_utils import fuse_hits
+    BF16_ULP = 2.0 ** -7
+    for r in range(max(1, a.rounds // 4)):
+        lens = [int(x) for x in rng.integers(1, 400, size=int(rng.integers(1, 9)))]
+        T = sum(lens); H = 64 * int(rng.integers(1, 9)); V = int(rng.integers(20, 700))
+        hid = O.round_bf16(rng.standard_normal((T, H)).astype(np.float32)); W = O.round_bf16(rng.standard_normal((V, H)).astype(np.float32) * 0.1)
+        cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32); tm = rng.random(T) < rng.uniform(0.1, 1.0)
+        got = ops.sparse_max_aggregate(bf(hid), bf(W), torch.from_numpy(cu).cuda(), torch.from_numpy(tm.astype(np.uint8)).cuda()).cpu().numpy()
+        want = O.max_aggregate_packed(hid, cu, tm, W, None, bf16=True)
+        empty = want == O.BF16_MIN
+        ok = np.array_equal(got == O.BF16_MIN, empty) and (np.abs(got[~empty] - want[~empty]) <= BF16_ULP * np.abs(want[~empty]) + 1e-6).all()
+        check("maxagg", ok, (lens, H, V))
+        Qf, k1, k2, Nf = int(rng.integers(1, 12)), int(rng.integers(1, 900)), int(rng.integers(1, 900)), 3000
+        sysl = []
+        for kk_ in (k1, k2):
+            ids_ = np.stack([rng.choice(Nf, size=kk_, replace=False) for _ in range(Qf)]).astype(np.int64)
+            sc_ = rng.standard_normal((Qf, kk_)).astype(np.float32)
+            ids_[rng.random((Qf, kk_)) < 0.05] = -1
+            sysl.append((sc_, ids_))
+        method = str(rng.choice(["rrf", "linear"]))
+        fs, fi, fc = fuse_hits([(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()) for x, y in sysl], method=method, k=60, weights=[0.7, 0.3])
+        fs, fi, fc = fs.cpu().numpy(), fi.cpu().numpy(), fc.cpu().numpy()
+        dicts = [{str(q_): {str(int(p_)): float(v_) for p_, v_ in zip(y[q_], x[q_]) if p_ >= 0} for q_ in range(Qf) if (y[q_] >= 0).any()} for x, y in sysl]
+        wantf = O.fuse_scores_rrf(dicts, k=60) if method == "rrf" else O.fuse_scores_linear(dicts, [0.7, 0.3])
+        okf = True
+        for q_ in range(Qf):
+            wq = wantf.get(str(q_), {})
+            gq = {str(int(p_)): float(v_) for p_, v_ in zip(fi[q_, :fc[q_]], fs[q_, :fc[q_]])}
+            okf &= gq == wq
+        check("fuse", okf, (Qf, k1, k2, method))
+    for r in range(max(1, a.rounds // 15)):
+        d = int(rng.choice([64, 128])); nkv = int(rng.choice([1, 2])); grp = int(rng.choice([1, 2, 4])); nq = nkv * grp; H = nq * d
+        cfg = O.EncoderConfig(vocab_size=300, hidden_size=H, num_layers=int(rng.integers(1, 3)), num_q_heads=nq, num_kv_heads=nkv, head_dim=d, intermediate_size=128,
+                              rope_type="default", qkv_bias=bool(rng.random() < 0.5), max_positions=128)
+        w = O.random_weights(cfg, seed=int(rng.integers(0, 1 << 30)), std=0.05)
+        enc = LrxEncoder(EncoderConfig(**asdict(cfg)), {k: torch.from_numpy(v) for k, v in w.items()})
+        P1, S2, n = int(rng.integers(0, 40)), int(rng.integers(1, 4)), int(rng.integers(1, 50))
+        pre = rng.integers(0, 300, size=P1).astype(np.int32); suf = rng.integers(0, 300, size=(n, S2)).astype(np.int32)
+        got = enc.encode_prefixed(torch.from_numpy(pre).cuda(), torch.from_numpy(suf).cuda()).cpu().numpy()
+        full = np.concatenate([np.concatenate([pre, suf[i]]) for i in range(n)]).astype(np.int32)
+        cuf = (np.arange(n + 1) * (P1 + S2)).astype(np.int32)
+        want = enc.encode_packed(torch.from_numpy(full).cuda(), torch.from_numpy(cuf).cuda(), P1 + S2, normalize=False).cpu().numpy()
+        cosv = (got * want).sum(-1) / (np.linalg.norm(got, axis=-1) * np.linalg.norm(want, axis=-1))
+        check("prefixed", cosv.min() > 0.999, (H, d, nq, nkv, P1, S2, n, float(1 - cosv.min())))
     print("fuzz rounds", a.rounds, "failures", fails)
     sys.exit(1 if fails else 0)
 
