@@ -23,6 +23,7 @@
 // Workgroup -> tile map: bijective XCD-chunked remap (blocks b and b+8 share an XCD L2) + 8-m-tile groups walked
 // n-fastest inside an XCD chunk, so the 32 co-resident tiles of an XCD share 8 A panels and 4 B panels.
 #include "lrx_common.h"
+#include <stdlib.h>
 
 #define GBM 256
 #define GBN 256
@@ -443,6 +444,15 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 #endif
 }
 
+// m-tiles per group of the block -> tile map, per epilogue class (measured, see the kernel); LRX_GEMM_GM overrides it for sweeps
+static int gemm_group_m(int epilogue, int K) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("LRX_GEMM_GM"); env = e ? atoi(e) : 0; }
+  if (env > 0) return env;
+  // 1B shapes (K = 2048): gate-up 6, o/down 4, qkv 8; 8B shapes (K = 4096): within 2 % for 2..8, gate-up best at 8 (1596 TFLOP/s)
+  return epilogue == EPI_SWIGLU ? (K >= 4096 ? 8 : 6) : (epilogue == EPI_RESID ? 4 : 8);
+}
+
 extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N,
                                 int32_t K, int32_t epilogue, void* stream) {
   return lrx_gemm_bf16_nt_fused(A, B, C, bias, resid, M, N, K, epilogue, nullptr, nullptr, stream);
@@ -466,7 +476,7 @@ extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, con
   __bf16* c = (__bf16*)C;
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   MaxAggArgs nomx = {nullptr, nullptr, 0};
-  NormArgs nrm = {rscale, ss_part, epilogue == EPI_SWIGLU ? 6 : (epilogue == EPI_RESID ? 4 : 8)};
+  NormArgs nrm = {rscale, ss_part, gemm_group_m(epilogue, K)};
   switch (epilogue) {
     case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm); break;
     case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm); break;

@@ -7,7 +7,8 @@ from lightretriever_amd import ops
 
 def main():
     M = int(os.environ.get("M", 131072))
-    shapes = [("qkv", 3072, 2048, 0), ("o", 2048, 2048, 1), ("gate_up", 16384, 2048, 2), ("down", 2048, 8192, 1)]
+    H, I, QKV = int(os.environ.get("H", 2048)), int(os.environ.get("I", 8192)), int(os.environ.get("QKV", 3072))
+    shapes = [("qkv", QKV, H, 0), ("o", H, H if "QD" not in os.environ else int(os.environ["QD"]), 1), ("gate_up", 2 * I, H, 2), ("down", H, I, 1)]
     if os.environ.get("LRX_GEMM_V1"):
         shapes = [s for s in shapes if s[3] != 2]
     g = torch.Generator(device="cuda").manual_seed(0)
