@@ -146,7 +146,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # LRX_BENCH_FORCE_DIST=1: create the RCCL process group (and run every collective of the N>1 path) even with one rank --
+    # the single-GPU rehearsal of the `torch.distributed.run` launch the driver uses for N = 2, 4, 8
+    distributed = world > 1 or os.environ.get("LRX_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -182,7 +184,7 @@ def main():
             l = lens[i * B:(i + 1) * B]
             cu_i = torch.tensor(np.concatenate([[0], np.cumsum(l)]), dtype=torch.int32, device=dev)
             ids_i = torch.randint(1000, 127000, (int(l.sum()),), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
-            batches.append((ids_i, cu_i, int(l.max()), int(l.sum())))
+            batches.append((ids_i, cu_i, int(l.max()), int(l.sum()), float(sum(cfg.flops_per_doc(int(x)) for x in l)) / B))
 
     # ---- index shard: rows/world rows of L2-normalised N(0,1) fp32 (seed 7); encoded batches overwrite its first rows
     shard_rows = args.index_rows // world
@@ -306,19 +308,23 @@ def main():
 
     # ---- roofline of the dominant kernel: the gate-up SwiGLU GEMM (55% of the model FLOPs)
     gu = gu_timed                      # gate-up launches of the timed region
+    timed = range(args.warmup, args.warmup + args.steps)
+    # FLOPs per document of the timed batches: F(S) for the fixed-length headline, the mean of F(len) over the ragged batches
+    fl_doc = cfg.flops_per_doc(S) if batches is None else sum(batches[i][4] for i in timed) / args.steps
+    m_rows = "%d" % (B * S) if batches is None else "%d..%d" % (min(batches[i][3] for i in timed), max(batches[i][3] for i in timed))
     gemm_all_ms = sum(prof[k_]["ms"] for k_ in ("gemm_store", "gemm_resid", "gemm_swiglu"))
     gemm_all_fl = sum(prof[k_]["flops"] for k_ in ("gemm_store", "gemm_resid", "gemm_swiglu"))
     achieved = gu["flops"] / (gu["ms"] * 1e-3) / 1e12 if gu["ms"] > 0 else 0.0
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-        "traffic": pmc_traffic("k_gemm_bf16_nt<2>") if (args.model == "llama3.2-1b" and B == 256 and S == 512) else None,
-        "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (gate-up projection, M=%d N=%d K=%d)" % (B * S, 2 * cfg.intermediate_size, H),
+        "traffic": pmc_traffic("k_gemm_bf16_nt<2>") if (args.model == "llama3.2-1b" and B == 256 and S == 512 and batches is None) else None,
+        "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (gate-up projection, M=%s N=%d K=%d)" % (m_rows, 2 * cfg.intermediate_size, H),
         "avg_launch_ms": round(gu["ms"] / max(gu["launches"], 1), 4), "launches": gu["launches"],
         "pmc_mfma_busy_frac": pmc_mfma("k_gemm_bf16_nt<2>")[0], "pmc_effective_clock_ghz": pmc_mfma("k_gemm_bf16_nt<2>")[1],
         "all_gemms_tflops": round(gemm_all_fl / (gemm_all_ms * 1e-3) / 1e12, 2) if gemm_all_ms > 0 else None,
         "per_class_ms_per_step": {k_: round(v["ms"] / n_prof, 3) for k_, v in prof.items()},
-        "model_flops_per_doc": cfg.flops_per_doc(S),
-        "end_to_end_tflops": round(docs_per_s / world * cfg.flops_per_doc(S) / 1e12, 2),
+        "model_flops_per_doc": fl_doc,
+        "end_to_end_tflops": round(docs_per_s / world * fl_doc / 1e12, 2),
     }
     line = {
         "metric": "docs embedded/sec (%s dims, seq_len=%d, bf16) [+ queries/sec@top-%d over %d-doc index in `search`]" % (args.model, S, args.topk, args.index_rows),

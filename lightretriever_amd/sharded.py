@@ -6,6 +6,7 @@ across GPUs, per-shard top-k merged on the host) and its RPC fan-out of batches 
 here batch j of the longest-first sorted corpus is owned by rank j % R and its embeddings never leave that rank's HBM."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -45,6 +46,7 @@ def exchange_topk(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.Process
     Payload R*Q*k*8 bytes (640 KB at R=8,Q=100,k=100): latency-bound on xGMI, one collective, no pipelining."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     packed = pack_pairs(D, I)
+    force_collective = force_collective or os.environ.get("LRX_FORCE_COLLECTIVE") == "1"     # one-rank rehearsal of the exchange
     if world == 1 and not (force_collective and dist.is_initialized()):
         return D.unsqueeze(0), I.unsqueeze(0)
     Q = packed.shape[0]
