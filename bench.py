@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--index-rows", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--topk", type=int, default=100)
-    ap.add_argument("--model", default="llama3.2-1b", choices=["llama3.2-1b", "llama3.1-8b", "qwen2.5-1.5b", "qwen2.5-7b"])
+    ap.add_argument("--model", default="llama3.2-1b", choices=["llama3.2-1b", "llama3.2-3b", "llama3.1-8b", "qwen2.5-1.5b", "qwen2.5-3b", "qwen2.5-7b"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mrl-dim", type=int, default=0, help="index / embedding dimension D (dense_shrink_dim, e.g. 256 for BASELINE config 5); 0 = hidden size")
     ap.add_argument("--no-search", action="store_true")
@@ -158,8 +158,8 @@ def main():
     from lightretriever_amd import EncoderConfig, FlatIPIndex, LrxEncoder
     from lightretriever_amd.sharded import ShardedFlatIPIndex
 
-    cfg = {"llama3.2-1b": EncoderConfig.llama32_1b, "llama3.1-8b": EncoderConfig.llama31_8b, "qwen2.5-1.5b": EncoderConfig.qwen25_1_5b,
-           "qwen2.5-7b": EncoderConfig.qwen25_7b}[args.model](args.seq_len)
+    cfg = {"llama3.2-1b": EncoderConfig.llama32_1b, "llama3.2-3b": EncoderConfig.llama32_3b, "llama3.1-8b": EncoderConfig.llama31_8b,
+           "qwen2.5-1.5b": EncoderConfig.qwen25_1_5b, "qwen2.5-3b": EncoderConfig.qwen25_3b, "qwen2.5-7b": EncoderConfig.qwen25_7b}[args.model](args.seq_len)
     if os.environ.get("LRX_FOLD_NORM") is not None:          # dev A/B switch; the default is the library's (folded)
         cfg.fold_norm = os.environ["LRX_FOLD_NORM"] != "0"
     enc = LrxEncoder.random_init(cfg, seed=0, device=dev)

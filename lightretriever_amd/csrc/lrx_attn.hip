@@ -640,15 +640,31 @@ extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens
     LRX_LAUNCH_CHECK();
     return LRX_OK;
   }
-#define LRX_ATTN_CASE(DD, GG) \
-  if (head_dim == DD && grp == GG) return launch_attn<DD, GG>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s);
-  LRX_ATTN_CASE(64, 1) LRX_ATTN_CASE(64, 2) LRX_ATTN_CASE(64, 4) LRX_ATTN_CASE(64, 6) LRX_ATTN_CASE(64, 7) LRX_ATTN_CASE(64, 8)
-  LRX_ATTN_CASE(128, 1) LRX_ATTN_CASE(128, 2) LRX_ATTN_CASE(128, 4)
+  // Tiled kernel: GRP q heads per workgroup, nparts workgroups per kv head (heads beyond the group idle).  head_dim 64 takes up to 8
+  // heads per workgroup; head_dim 128 needs ~190 VGPRs per wave, so at most 4 (more than 8 waves per workgroup would spill): groups
+  // of 5-6 heads run as two workgroups of 3, 7-8 as two of 4 (the K/V tiles are staged twice, from L2), larger groups as ceil(grp/4).
+#define LRX_ATTN_CASE(DD, GG, PARTS) \
+  return launch_attn<DD, GG>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s, PARTS);
+  if (head_dim == 64) {
+    switch (grp) {
+      case 1: LRX_ATTN_CASE(64, 1, 1)
+      case 2: LRX_ATTN_CASE(64, 2, 1)
+      case 3: LRX_ATTN_CASE(64, 3, 1)
+      case 4: LRX_ATTN_CASE(64, 4, 1)
+      case 5: LRX_ATTN_CASE(64, 5, 1)
+      case 6: LRX_ATTN_CASE(64, 6, 1)
+      case 7: LRX_ATTN_CASE(64, 7, 1)
+      case 8: LRX_ATTN_CASE(64, 8, 1)
+      default: LRX_ATTN_CASE(64, 8, (grp + 7) / 8)
+    }
+  }
+  switch (grp) {
+    case 1: LRX_ATTN_CASE(128, 1, 1)
+    case 2: LRX_ATTN_CASE(128, 2, 1)
+    case 3: LRX_ATTN_CASE(128, 3, 1)
+    case 4: LRX_ATTN_CASE(128, 4, 1)
+    case 5: case 6: LRX_ATTN_CASE(128, 3, 2)
+    default: LRX_ATTN_CASE(128, 4, (grp + 3) / 4)
+  }
 #undef LRX_ATTN_CASE
-  // head_dim 128, groups of 6 / 7 / 8 q heads: two workgroups of 3 / 4 / 4 heads per kv head (the K/V tiles are staged twice, from L2)
-  if (head_dim == 128 && grp == 6) return launch_attn<128, 3>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s, 2);
-  if (head_dim == 128 && (grp == 7 || grp == 8))
-    return launch_attn<128, 4>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s, 2);
-  lrx_set_error("attn: GQA group size %d unsupported", grp);
-  return LRX_ERR_INVALID;
 }

@@ -45,9 +45,19 @@ class EncoderConfig:
         return EncoderConfig(128256, 4096, 32, 32, 8, 128, 14336, 1e-5, 500000.0, "llama3", 8.0, 1.0, 4.0, 8192, False, max_positions)
 
     @staticmethod
+    def llama32_3b(max_positions: int = 512) -> "EncoderConfig":
+        """Llama-3.2-3B (backbone of lightretriever-llama3.2-3b): 24 q / 8 kv heads of 128, tied embeddings."""
+        return EncoderConfig(128256, 3072, 28, 24, 8, 128, 8192, 1e-5, 500000.0, "llama3", 32.0, 1.0, 4.0, 8192, False, max_positions)
+
+    @staticmethod
     def qwen25_1_5b(max_positions: int = 512) -> "EncoderConfig":
         """Qwen2.5-1.5B: the backbone of the released lightretriever-qwen2.5-1.5b adapters (scripts/*_infer.ipynb)."""
         return EncoderConfig(151936, 1536, 28, 12, 2, 128, 8960, 1e-6, 1000000.0, "default", 1.0, 1.0, 4.0, 8192, True, max_positions)
+
+    @staticmethod
+    def qwen25_3b(max_positions: int = 512) -> "EncoderConfig":
+        """Qwen2.5-3B (backbone of lightretriever-qwen2.5-3b): 16 q / 2 kv heads of 128 (GQA group 8)."""
+        return EncoderConfig(151936, 2048, 36, 16, 2, 128, 11008, 1e-6, 1000000.0, "default", 1.0, 1.0, 4.0, 8192, True, max_positions)
 
     @staticmethod
     def qwen25_7b(max_positions: int = 512) -> "EncoderConfig":

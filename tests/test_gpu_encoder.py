@@ -169,28 +169,39 @@ def test_full_size_llama32_1b_properties_and_hf_parity():
     assert (1 - cos).max().item() <= COS_TOL, (1 - cos)
 
 
-def test_full_size_qwen25_1_5b_hf_parity():
-    """The released checkpoints' backbone (Qwen2.5-1.5B dims: q/k/v bias, head_dim 128, 12 q / 2 kv heads = GQA group 6, rope theta
-    1e6, vocab 151936): parity with HF transformers Qwen2Model fp32 on the same GPU, tolerance 1e-3 cosine; 8 of the 28 layers keep
-    the test short (every kernel shape of the full model is exercised)."""
+@pytest.mark.parametrize("preset,layers", [("qwen25_1_5b", 8), ("qwen25_3b", 5), ("qwen25_7b", 3), ("llama32_3b", 5), ("llama31_8b", 3)])
+def test_released_backbone_dims_hf_parity(preset, layers):
+    """Every other backbone the reference releases adapters for (README model table), at its real dims: Qwen2.5-1.5B/3B/7B (q/k/v
+    bias, head_dim 128, GQA groups 6/8/7, rope theta 1e6), Llama-3.2-3B and Llama-3.1-8B (llama3 rope, GQA groups 3/4).  Parity with
+    the HF transformers fp32 model on the same GPU, tolerance 1e-3 cosine; a few of the layers keep the test short (every kernel
+    shape of the full model is exercised)."""
     import dataclasses
     from lightretriever_amd import EncoderConfig, LrxEncoder
-    cfg = dataclasses.replace(EncoderConfig.qwen25_1_5b(), num_layers=8)
+    cfg = dataclasses.replace(getattr(EncoderConfig, preset)(), num_layers=layers)
     enc = LrxEncoder.random_init(cfg, seed=3)
     g = torch.Generator().manual_seed(77)
     lens = [512, 300, 64, 1, 129, 511]
-    ids = torch.randint(1000, 150000, (sum(lens),), generator=g, dtype=torch.int64).to(torch.int32).cuda()
+    ids = torch.randint(1000, 127000, (sum(lens),), generator=g, dtype=torch.int64).to(torch.int32).cuda()
     cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32).cuda()
     out = enc.encode_packed(ids, cu, 512)
     assert torch.equal(out, enc.encode_packed(ids, cu, 512))
     assert torch.allclose(out.norm(dim=1), torch.ones(len(lens), device="cuda"), atol=1e-5)
-    from transformers import Qwen2Config, Qwen2Model
-    hf_cfg = Qwen2Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_layers,
-                         num_attention_heads=cfg.num_q_heads, num_key_value_heads=cfg.num_kv_heads, rms_norm_eps=cfg.rms_eps,
-                         max_position_embeddings=32768, rope_parameters={"rope_type": "default", "rope_theta": cfg.rope_theta},
-                         use_sliding_window=False, attn_implementation="sdpa")
-    with torch.device("cuda"):
-        hf = Qwen2Model(hf_cfg).float().eval()
+    common = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_layers,
+                  num_attention_heads=cfg.num_q_heads, num_key_value_heads=cfg.num_kv_heads, rms_norm_eps=cfg.rms_eps, attn_implementation="sdpa")
+    if cfg.qkv_bias:
+        from transformers import Qwen2Config, Qwen2Model
+        hf_cfg = Qwen2Config(max_position_embeddings=32768, rope_parameters={"rope_type": "default", "rope_theta": cfg.rope_theta},
+                             use_sliding_window=False, **common)
+        with torch.device("cuda"):
+            hf = Qwen2Model(hf_cfg).float().eval()
+    else:
+        from transformers import LlamaConfig, LlamaModel
+        hf_cfg = LlamaConfig(head_dim=cfg.head_dim, max_position_embeddings=131072,
+                             rope_parameters={"rope_type": "llama3", "rope_theta": cfg.rope_theta, "factor": cfg.rope_factor,
+                                              "low_freq_factor": cfg.rope_low_freq_factor, "high_freq_factor": cfg.rope_high_freq_factor,
+                                              "original_max_position_embeddings": cfg.rope_original_max_position}, **common)
+        with torch.device("cuda"):
+            hf = LlamaModel(hf_cfg).float().eval()
     missing, unexpected = hf.load_state_dict({k: v.float() for k, v in enc.hf_state_dict().items()}, strict=False)
     assert not unexpected and all("rotary" in m for m in missing), (missing, unexpected)
     refs = []
@@ -199,4 +210,6 @@ def test_full_size_qwen25_1_5b_hf_parity():
             x = ids[cu[b]:cu[b + 1]].long()[None]
             refs.append(torch.nn.functional.normalize(hf(input_ids=x, use_cache=False).last_hidden_state[0, -1], dim=-1))
     cos = (torch.stack(refs) * out).sum(-1)
-    assert (1 - cos).max().item() <= COS_TOL, (1 - cos)
+    assert (1 - cos).max().item() <= COS_TOL, (preset, 1 - cos)
+    del hf, enc
+    torch.cuda.empty_cache()
