@@ -350,6 +350,46 @@ def _as_items(texts) -> list[dict]:
     raise NotImplementedError(f"Unrecognized type {type(texts)}")
 
 
+def _prefetch_batches(coll, items: list, batch_size: int, depth: int = 2):
+    """(start, end, collated batch) in order, collated one worker thread ahead of the consumer: the tokenizer (Rust, releases the
+    GIL) works on batch i+1.. while the caller copies and launches batch i.  The reference gets the same overlap from DataLoader
+    worker processes (exact_search_torchrpc.py:185-200); order is preserved (row i of the output is input i)."""
+    import queue
+    import threading
+    spans = [(s, min(s + batch_size, len(items))) for s in range(0, len(items), batch_size)]
+    if len(spans) <= 1:
+        for s, e in spans:
+            yield s, e, coll(items[s:e])
+        return
+    q: "queue.Queue" = queue.Queue(maxsize=depth)
+    stop = threading.Event()
+
+    def work():
+        try:
+            for s, e in spans:
+                if stop.is_set():
+                    return
+                q.put((s, e, coll(items[s:e])))
+        except BaseException as ex:   # hand the failure to the consumer instead of dying silently
+            q.put(ex)
+
+    th = threading.Thread(target=work, name="lrx-collate", daemon=True)
+    th.start()
+    try:
+        for _ in spans:
+            got = q.get()
+            if isinstance(got, BaseException):
+                raise got
+            yield got
+    finally:
+        stop.set()
+        while th.is_alive():          # unblock a producer waiting on a full queue (consumer stopped early)
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                th.join(0.01)
+
+
 @dataclass
 class LrxExactSearchModel:
     """DRES-style adapter: `encode_queries`, `encode_corpus`, `encode`; mutable `query_prompt`, `corpus_prompt`,
@@ -414,9 +454,8 @@ class LrxExactSearchModel:
         if out is None:
             out = torch.empty(len(items), D, dtype=torch.float32, device=self.model.device)
         sparse_json: list[dict] = []
-        for s in range(0, len(items), batch_size):
-            e = min(s + batch_size, len(items))
-            r = self.model.encode_passage(coll(items[s:e]), out=out[s:e])
+        for s, e, batch in _prefetch_batches(coll, items, batch_size):
+            r = self.model.encode_passage(batch, out=out[s:e])
             if sparse:   # quantised {token id: weight} per document, what call_batch_encode hands to the sparse engine
                 sparse_json.extend(self.model.convert_sparse_reps_to_json(r["sparse_reps"], quantization_factor=100))
         reps = out[:len(items)]

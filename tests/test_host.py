@@ -254,3 +254,31 @@ def test_flat_index_file_layout_and_round_trip(tmp_path):
     assert open(t, encoding="utf-8").readline().rstrip("\r\n") == "beir-docid\tfaiss-docid"
     assert io.load_tsv_to_dict(t) == mapping
     assert io.shard_prefix("my-index") == "my-index" and io.shard_prefix("my-index", 3, 8) == "my-index.rank3-of-8"
+
+
+def test_prefetch_batches_keeps_order_propagates_errors_and_stops_clean():
+    """The collate-ahead worker of encode_corpus: batches arrive in input order, a collator failure surfaces in the consumer,
+    an abandoned iteration leaves no thread behind."""
+    import threading
+    import time
+    from lightretriever_amd.modeling import _prefetch_batches
+
+    def coll(x):
+        time.sleep(0.002)
+        return list(x)
+    items = list(range(103))
+    out = list(_prefetch_batches(coll, items, 10))
+    assert [x for _, _, b in out for x in b] == items and out[-1][:2] == (100, 103) and len(out) == 11
+    assert list(_prefetch_batches(coll, items[:7], 10)) == [(0, 7, items[:7])]          # single batch: no thread
+    g = _prefetch_batches(coll, items, 10)
+    next(g)
+    g.close()
+
+    def bad(x):
+        if x[0] >= 30:
+            raise ValueError("boom")
+        return x
+    with pytest.raises(ValueError, match="boom"):
+        list(_prefetch_batches(bad, items, 10))
+    time.sleep(0.05)
+    assert not [t for t in threading.enumerate() if t.name == "lrx-collate"]
