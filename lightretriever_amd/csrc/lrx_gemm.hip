@@ -93,6 +93,18 @@ extern "C" int lrx_debug_read_gemm_trace(void* dst, size_t bytes) {
 #define G_TRACE(slot)
 #endif
 
+// Diagnostic builds only (tools/gemm_ablate.sh): GEMM_ABL bit 0 = no LDS-DMA inside the K loop, bit 1 = no fragment ds_reads inside
+// the K loop, bit 2 = no barriers inside the K loop, bit 3 = no counted waits, bit 4 = the DMA fetches only K-tiles 0/1 (cache-hot),
+// bit 5 = no B1 request in P2 (4 + 2 DMA instructions per K-tile), bit 6 = no A1 request in P1 (6 + 0),
+// bit 7 = plain VGPR loads instead of LDS-DMA.  Results are garbage (in-bounds); only the time matters.
+#ifndef GEMM_ABL
+#define GEMM_ABL 0
+#endif
+#define ABL_DMA(x)  do { if (!(GEMM_ABL & 1)) { x; } } while (0)
+#define ABL_LDS(x)  do { if (!(GEMM_ABL & 2)) { x } } while (0)
+#define ABL_BAR(x)  do { if (!(GEMM_ABL & 4)) { x; } } while (0)
+#define ABL_WAIT(x) do { if (!(GEMM_ABL & 8)) { x; } } while (0)
+
 template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
@@ -140,11 +152,13 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     pB1[i] = B + (int64_t)min(n0 + 128 + row, N - 1) * K + c * 8;
   }
   char* const dma_dst = smem + wave * 2048;  // + buf*65536 + slot*16384 + i*1024
+#define G_KOFF(KT) ((GEMM_ABL & 16) ? ((KT) & 1) * GBK : (KT) * GBK)   /* bit 4: only K-tiles 0/1 are ever fetched (cache-hot DMA) */
 #define G_ISSUE(P, SLOT, BUF, KT)                                                                                          \
   do {                                                                                                                     \
-    __builtin_amdgcn_global_load_lds((gptr_t)(P[0] + (KT) * GBK), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES), 16, 0, 0);        \
-    __builtin_amdgcn_global_load_lds((gptr_t)(P[1] + (KT) * GBK), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES + 1024), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gptr_t)(P[0] + G_KOFF(KT)), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES), 16, 0, 0);        \
+    __builtin_amdgcn_global_load_lds((gptr_t)(P[1] + G_KOFF(KT)), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES + 1024), 16, 0, 0); \
   } while (0)
+
 
   // ---- fragment read offsets
   const int fr = lane & 15, fq = lane >> 4;
@@ -198,7 +212,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 
   G_BAR();
   G_TRACE(4);
-  if (wr == 1) G_BAR();  // stagger: group 1 runs one barrier behind group 0
+  if (wr == 1) ABL_BAR(G_BAR());  // stagger: group 1 runs one barrier behind group 0
 
   bf16x8 b2[2][2];
 #define G_LDB2(HP)                                                                                   \
@@ -213,34 +227,51 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   // Lifetimes: A0,B0,B1 of K-tile t are read in P1(t) (B fragments stay in registers), A1 in P2(t).  Refill one phase after
   // the last read (stagger-safe): P2(t) issues A0,B0,B1 of t+2, P1(t) issues A1 of t+1 (t >= 1; K-tile 1's comes from the
   // prologue).  Counted waits: vmcnt(8) in both phases = the 2 + 6 youngest DMA instructions stay in flight.
+#if GEMM_ABL & 128
+  // bit 7: the requests of the K loop are plain global_load_dwordx4 into sink registers (the LDS keeps K-tiles 0/1 of the prologue): the issue cost of a VGPR load
+  f32x4 sink0 = {0.f, 0.f, 0.f, 0.f}, sink1 = {0.f, 0.f, 0.f, 0.f};
+#undef G_ISSUE
+#define G_ISSUE(P, SLOT, BUF, KT)                                                                           \
+  do {                                                                                                          \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink0) : "v"(P[0] + G_KOFF(KT)) : "memory");          \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink1) : "v"(P[1] + G_KOFF(KT)) : "memory");          \
+  } while (0)
+#endif
+#if GEMM_ABL & 2
+  { const char* sbuf = smem; G_LDB(0) G_LDB2(1) G_LDA(0) }
+#endif
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     const char* sbuf = smem + cur * 65536;
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
     // P1: quadrants (A0,B0) and (A0,B1)
-    G_LDB(0) G_LDB2(1) G_LDA(0)
-    if (t >= 1 && n1) G_ISSUE(pA1, 1, cur ^ 1, t + 1);          // A1(t+1): its slot (A1 of t-1) was last read in P2(t-1)
-    if (n1 && n2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A1(t) landed
-    G_LSYNC();
+    ABL_LDS(G_LDB(0) G_LDB2(1) G_LDA(0));
+    if (t >= 1 && n1 && !(GEMM_ABL & 64)) ABL_DMA(G_ISSUE(pA1, 1, cur ^ 1, t + 1));          // A1(t+1): its slot (A1 of t-1) was last read in P2(t-1)
+    if (n1 && n2) ABL_WAIT(asm volatile("s_waitcnt vmcnt(8)" ::: "memory")); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A1(t) landed
+    ABL_BAR(G_LSYNC());
     __builtin_amdgcn_s_setprio(1);
     G_MM(0, 0); G_MM2(0, 1);
     __builtin_amdgcn_s_setprio(0);
-    G_BAR();
+    ABL_BAR(G_BAR());
     // P2: quadrants (A1,B1) and (A1,B0)
-    G_LDA(1)
+    ABL_LDS(G_LDA(1));
     if (n2) {
-      G_ISSUE(pA0, 0, cur, t + 2); G_ISSUE(pB0, 2, cur, t + 2); G_ISSUE(pB1, 3, cur, t + 2);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      ABL_DMA(G_ISSUE(pA0, 0, cur, t + 2); G_ISSUE(pB0, 2, cur, t + 2); if (!(GEMM_ABL & 32)) G_ISSUE(pB1, 3, cur, t + 2));
+      ABL_WAIT(asm volatile("s_waitcnt vmcnt(8)" ::: "memory"));
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    G_LSYNC();
+    ABL_BAR(G_LSYNC());
     __builtin_amdgcn_s_setprio(1);
     G_MM2(1, 1); G_MM(1, 0);
     __builtin_amdgcn_s_setprio(0);
-    G_BAR();
+    ABL_BAR(G_BAR());
   }
-  if (wr == 0) G_BAR();
+  if (wr == 0) ABL_BAR(G_BAR());
+#if GEMM_ABL & 128
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" ::"v"(sink0), "v"(sink1));
+#endif
   G_TRACE(1);
 
   // ---- epilogue.  The accumulator layout (lane = 1 row x 4 columns per 16x16 tile) would give 8-byte stores that touch 16

@@ -4,7 +4,7 @@
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/pmc_mfma
+OUT=$R/gpurun_out/pmc_mfma${PMC_TAG:-}
 mkdir -p $OUT
 cd /tmp
 timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -o a -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-search --no-sparse > $OUT/a.log 2>&1 || echo "pass failed"
