@@ -390,6 +390,44 @@ def _prefetch_batches(coll, items: list, batch_size: int, depth: int = 2):
                 th.join(0.01)
 
 
+def _merge_packed(batches: list) -> dict:
+    """Concatenate consecutive packed batches (collator output) into one: ids and masks appended, cu_seqlens re-based."""
+    if len(batches) == 1:
+        return batches[0]
+    out = {"input_ids": torch.cat([b["input_ids"] for b in batches]), "max_seqlen": max(int(b["max_seqlen"]) for b in batches)}
+    cu, base = [batches[0]["cu_seqlens"]], int(batches[0]["cu_seqlens"][-1])
+    for b in batches[1:]:
+        cu.append(b["cu_seqlens"][1:] + base)
+        base += int(b["cu_seqlens"][-1])
+    out["cu_seqlens"] = torch.cat(cu).to(torch.int32)
+    if "sparse_mask" in batches[0]:
+        out["sparse_mask"] = torch.cat([b["sparse_mask"] for b in batches])
+    return out
+
+
+def _token_budget_batches(gen, max_tokens: int, max_docs: int):
+    """Merge consecutive (start, end, packed batch) items while the merged batch stays within `max_tokens` tokens and `max_docs`
+    documents: short documents (the tail of a longest-first sorted corpus) then reach the encoder in batches of the same token
+    count as a batch of full-length ones -- the GEMMs keep their tile count instead of shrinking with the documents.  Outputs are
+    batch-invariant (tests), so the rows are the same as without merging."""
+    pend, tok = [], 0
+    for s, e, b in gen:
+        t = int(b["cu_seqlens"][-1]) if "cu_seqlens" in b else None
+        if t is None or max_tokens <= 0:                      # padded layout or merging off: pass through
+            if pend:
+                yield pend[0][0], pend[-1][1], _merge_packed([x[2] for x in pend])
+                pend, tok = [], 0
+            yield s, e, b
+            continue
+        if pend and (tok + t > max_tokens or (e - pend[0][0]) > max_docs):
+            yield pend[0][0], pend[-1][1], _merge_packed([x[2] for x in pend])
+            pend, tok = [], 0
+        pend.append((s, e, b))
+        tok += t
+    if pend:
+        yield pend[0][0], pend[-1][1], _merge_packed([x[2] for x in pend])
+
+
 @dataclass
 class LrxExactSearchModel:
     """DRES-style adapter: `encode_queries`, `encode_corpus`, `encode`; mutable `query_prompt`, `corpus_prompt`,
@@ -405,6 +443,8 @@ class LrxExactSearchModel:
     corpus_prompt: Optional[str] = None
     encoding_kwargs: dict = field(default_factory=dict)
     token_id_vector_type: str = "sum"          # 'sum' | 'bow' (finetune/arguments.py:203-211): the parameter-free sparse query
+    max_batch_tokens: int = 131072             # encode(): consecutive batches are merged up to this many tokens (0 = off; 256 x 512)
+    max_batch_docs: int = 2048                 # ... and this many documents (bounds the [docs, vocab] sparse activations)
 
     def token_id_reps(self, items: list[dict]) -> list[dict]:
         """Parameter-free sparse query vectors (exact_search_base.py:380-431): raw text with a leading whitespace, no specials,
@@ -454,7 +494,7 @@ class LrxExactSearchModel:
         if out is None:
             out = torch.empty(len(items), D, dtype=torch.float32, device=self.model.device)
         sparse_json: list[dict] = []
-        for s, e, batch in _prefetch_batches(coll, items, batch_size):
+        for s, e, batch in _token_budget_batches(_prefetch_batches(coll, items, batch_size), self.max_batch_tokens, self.max_batch_docs):
             r = self.model.encode_passage(batch, out=out[s:e])
             if sparse:   # quantised {token id: weight} per document, what call_batch_encode hands to the sparse engine
                 sparse_json.extend(self.model.convert_sparse_reps_to_json(r["sparse_reps"], quantization_factor=100))

@@ -253,3 +253,31 @@ def test_index_save_load_round_trip(tmp_path):
     assert got == want
     Dw, Iw = O.flat_ip_topk(q, X, 25)
     assert [list(got["q0"].keys())[j] for j in range(25)] == ["doc/%d" % i for i in Iw[0]]
+
+
+def test_token_budget_batch_merging_leaves_every_row_unchanged():
+    """encode_corpus merges consecutive collated batches up to max_batch_tokens; rows must be bit-identical to one-batch-at-a-time
+    encoding (dense and sparse), whatever the budget cuts."""
+    cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    tok, enc, hm, model = build_stack(cfg_o, w)
+    docs = list(synth_corpus(np.random.default_rng(3), 157).values())
+    model.max_batch_tokens = 0
+    want = model.encode_corpus(docs, batch_size=8)["dense_reps"].clone()
+    for budget, max_docs in [(131072, 2048), (300, 2048), (64, 2048), (100000, 20)]:
+        model.max_batch_tokens, model.max_batch_docs = budget, max_docs
+        got = model.encode_corpus(docs, batch_size=8)["dense_reps"]
+        assert torch.equal(got, want), (budget, max_docs)
+    # merged spans really are larger than one collated batch
+    from lightretriever_amd.modeling import EncodeCollator, _prefetch_batches, _token_budget_batches
+    coll = EncodeCollator(tok, encode_is_query=False, p_max_len=64)
+    spans = [(s, e) for s, e, _ in _token_budget_batches(_prefetch_batches(coll, model.parse_texts(docs), 8), 1000, 2048)]
+    assert spans[0][0] == 0 and spans[-1][1] == len(docs) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert max(e - s for s, e in spans) > 8
+    # sparse branch: the per-token mask travels with the merge
+    from lightretriever_amd.modeling import LrxHybridModel, LrxExactSearchModel
+    hs = LrxHybridModel(enc, normalize=True, pad_token_id=tok.pad_token_id, encode_sparse=True)
+    ms = LrxExactSearchModel(model=hs, tokenizer=tok, q_max_len=32, p_max_len=64, max_batch_tokens=0)
+    a = ms.encode_corpus(docs[:60], batch_size=8)
+    ms.max_batch_tokens = 500
+    b = ms.encode_corpus(docs[:60], batch_size=8)
+    assert torch.equal(a["dense_reps"], b["dense_reps"]) and a["sparse_reps"] == b["sparse_reps"]

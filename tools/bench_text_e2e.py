@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--model", default="llama3.2-1b")
     ap.add_argument("--sparse", action="store_true")
+    ap.add_argument("--words", type=int, default=400, help="words per document (400 -> truncated at 512 tokens; 40 -> short documents)")
+    ap.add_argument("--max-batch-tokens", type=int, default=131072, help="token budget of encode_corpus's batch merging (0 = off)")
     args = ap.parse_args()
     from transformers import PreTrainedTokenizerFast
     from lightretriever_amd import EncoderConfig, LrxEncoder
@@ -33,12 +35,12 @@ def main():
     enc = LrxEncoder.random_init(cfg, seed=0)
     hm = LrxHybridModel(enc, normalize=True, pad_token_id=tok.pad_token_id, encode_sparse=args.sparse) if args.sparse else \
         LrxHybridModel(enc, normalize=True, pad_token_id=tok.pad_token_id)
-    model = LrxExactSearchModel(model=hm, tokenizer=tok, q_max_len=512, p_max_len=512)
+    model = LrxExactSearchModel(model=hm, tokenizer=tok, q_max_len=512, p_max_len=512, max_batch_tokens=args.max_batch_tokens)
 
     rng = np.random.default_rng(0)
     letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
     words = ["".join(rng.choice(letters, size=rng.integers(2, 10))) for _ in range(5000)]
-    docs = [{"title": " ".join(rng.choice(words, size=6)), "text": " ".join(rng.choice(words, size=400))} for _ in range(args.docs)]
+    docs = [{"title": " ".join(rng.choice(words, size=6)), "text": " ".join(rng.choice(words, size=max(1, int(rng.integers(args.words // 2, args.words + 1)))))} for _ in range(args.docs)]
 
     coll = EncodeCollator(tok, encode_is_query=False, p_max_len=512)
     b0 = coll(docs[:args.batch])
