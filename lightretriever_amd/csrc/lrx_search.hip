@@ -232,7 +232,7 @@ __global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, in
 // slices are double-buffered: 48 KiB of LDS per 128-row workgroup -> three workgroups per CU, i.e. 1.5x the HBM bytes in flight of the
 // two-per-CU layout (the shadow filter pass is bound by bytes in flight x latency, not by the matrix pipe or the LDS).
 template <int QT, int NP, int RT, int NST, int WV, bool XB = false, bool QSB = false>
-__global__ void __launch_bounds__(64 * WV, QSB ? 3 : ((NST * (16 * RT * WV * 128 + (((XB ? 2 : NP) * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1))
+__global__ void __launch_bounds__(64 * WV, QSB ? (QT > 8 ? 2 : 3) : ((NST * (16 * RT * WV * 128 + (((XB ? 2 : NP) * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1))
 k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
                        float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate) {
   static_assert(!XB || NP == 1, "the bf16 shadow is a single-product filter");
@@ -461,13 +461,17 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
   const int nblk = (int)(ld / S_ROWS), nblk_ld = (int)((ld / SP_ROWS + 3) & ~3);   // blkmax row stride (sized for the finer blocks)
   dim3 grid((unsigned)nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
-  for (int q0 = 0; q0 < n_queries; q0 += 128) {
-    int nq = n_queries - q0 < 128 ? n_queries - q0 : 128;
+  // queries per pass over the corpus: 128 (8 MFMA tiles); the shadow filter takes up to 256 (16 tiles, 64 KiB of LDS, two workgroups
+  // per CU) -- a large query batch then streams the shadow half as often
+  const bool shadow_pass = qsplit != nullptr && planes == 1 && Xb != nullptr;
+  const int chunk = shadow_pass ? 256 : 128;
+  for (int q0 = 0; q0 < n_queries; q0 += chunk) {
+    int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
     int qt = (nq + 15) / 16;
     const float* qp = q + (int64_t)q0 * dim;
     float* sp = scores + (int64_t)q0 * ld;
     float* bp = blkmax ? blkmax + (int64_t)q0 * nblk_ld : nullptr;
-    if (qsplit != nullptr && planes == 1 && Xb != nullptr) {   // any query count: the shadow pass beats the exact-fp32 kernel from Q = 1
+    if (shadow_pass) {   // any query count: the shadow pass beats the exact-fp32 kernel from Q = 1
       // filter pass over the bf16 shadow of the corpus: half the bytes of the fp32 rows
       int threads = (dim / 64) * 2 * qt * 64;
       hipLaunchKernelGGL(k_pack_queries_xb, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit);
@@ -478,7 +482,8 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
     break;
       // q slices of one or two tiles are small enough for three workgroups per CU even double-buffered; from three tiles on the
       // single-buffered q layout buys the third workgroup (Q = 100: 1.23 -> 1.19 ms)
-      switch (qt) { LRX_SB(1, false) LRX_SB(2, false) LRX_SB(3, SPX_QSB) LRX_SB(4, SPX_QSB) LRX_SB(5, SPX_QSB) LRX_SB(6, SPX_QSB) LRX_SB(7, SPX_QSB) LRX_SB(8, SPX_QSB) }
+      switch (qt) { LRX_SB(1, false) LRX_SB(2, false) LRX_SB(3, SPX_QSB) LRX_SB(4, SPX_QSB) LRX_SB(5, SPX_QSB) LRX_SB(6, SPX_QSB) LRX_SB(7, SPX_QSB) LRX_SB(8, SPX_QSB)
+                   LRX_SB(9, SPX_QSB) LRX_SB(10, SPX_QSB) LRX_SB(11, SPX_QSB) LRX_SB(12, SPX_QSB) LRX_SB(13, SPX_QSB) LRX_SB(14, SPX_QSB) LRX_SB(15, SPX_QSB) LRX_SB(16, SPX_QSB) }
 #undef LRX_SB
       LRX_LAUNCH_CHECK();
       continue;

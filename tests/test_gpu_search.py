@@ -156,7 +156,10 @@ def test_full_size_1m_x_2048_properties():
 
 # ---- two-pass bounded search (bf16 filter + exact rescoring), Q > 32 ---------------------------------------------------
 @pytest.mark.parametrize("N,D,Q,k,scale", [(120000, 256, 100, 100, "unit"), (50000, 128, 64, 10, "mixed"), (9000, 64, 33, 1000, "unit"),
-                                            (30000, 2048, 40, 50, "unit"), (20000, 128, 300, 7, "unit"), (6000, 64, 5, 2048, "mixed")])
+                                            (30000, 2048, 40, 50, "unit"), (20000, 128, 300, 7, "unit"), (6000, 64, 5, 2048, "mixed"),
+                                            # more than 128 queries: the shadow filter takes up to 256 per pass (9..16 MFMA query tiles)
+                                            (25000, 64, 145, 20, "unit"), (25000, 320, 255, 33, "mixed"), (15000, 128, 513, 5, "unit"),
+                                            (12000, 192, 177, 100, "unit")])
 def test_two_pass_equals_six_product_path_and_oracle(N, D, Q, k, scale):
     from lightretriever_amd import FlatIPIndex
     rng = np.random.default_rng(N + D)
