@@ -28,6 +28,7 @@ class FlatIPIndex:
         # bf16 shadow of the rows (round-to-nearest-even), maintained by commit(): the filter pass of the two-pass search streams
         # it instead of the fp32 rows (half the bytes; the exact rescoring still reads fp32).  +50 % index memory; False = no shadow.
         self.shadow_bf16 = True
+        self.max_workspace_bytes = 8 << 30   # search(): cap of the [queries, rows] score workspace; larger query batches are chunked
         self._xb: Optional[torch.Tensor] = None
 
     # -- storage -------------------------------------------------------------------------------------------------
@@ -122,20 +123,29 @@ class FlatIPIndex:
         I = torch.empty(Q, k, dtype=torch.int64, device=self.device)
         if Q == 0:
             return D, I
-        need = int(self.lib.lrx_flat_ip_bounded_workspace_bytes(self.ntotal, self.d, Q, k))
+        # the score workspace is [queries, rows] fp32: large query batches over a large shard go through in chunks of queries that keep
+        # it under max_workspace_bytes (multiples of the 256-query filter pass; results do not depend on the chunking)
+        per_query = max(1, int(self.lib.lrx_flat_ip_bounded_workspace_bytes(self.ntotal, self.d, 2, k))
+                        - int(self.lib.lrx_flat_ip_bounded_workspace_bytes(self.ntotal, self.d, 1, k)))
+        chunk = max(1, min(Q, int(self.max_workspace_bytes) // per_query))
+        if chunk < Q:
+            chunk = chunk // 256 * 256 if chunk >= 256 else (128 if chunk >= 128 else chunk)
+        need = int(self.lib.lrx_flat_ip_bounded_workspace_bytes(self.ntotal, self.d, chunk, k))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
         ldx = self._x.stride(0) if self._x.shape[0] else self.d
-        if self.two_pass:
-            xb = self._xb if (self.shadow_bf16 and self._xb is not None) else None
-            _lib.check(self.lib.lrx_flat_ip_search_bounded(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(xb) if xb is not None else None,
-                                                           xb.stride(0) if xb is not None else 0, _lib.ptr(self._norm_bound), _lib.ptr(q), Q, k,
-                                                           self.id_base, _lib.ptr(D), _lib.ptr(I), _lib.ptr(self._ws), self._ws.numel(),
-                                                           _lib.current_stream()))
-        else:
-            _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(q), Q, k, self.id_base, _lib.ptr(D),
-                                                   _lib.ptr(I), _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))
+        xb = self._xb if (self.two_pass and self.shadow_bf16 and self._xb is not None) else None
+        for s in range(0, Q, chunk):
+            qc, Dc, Ic = q[s:s + chunk], D[s:s + chunk], I[s:s + chunk]
+            if self.two_pass:
+                _lib.check(self.lib.lrx_flat_ip_search_bounded(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(xb) if xb is not None else None,
+                                                               xb.stride(0) if xb is not None else 0, _lib.ptr(self._norm_bound), _lib.ptr(qc),
+                                                               qc.shape[0], k, self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws),
+                                                               self._ws.numel(), _lib.current_stream()))
+            else:
+                _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(qc), qc.shape[0], k, self.id_base,
+                                                       _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))
         return D, I
 
 

@@ -254,3 +254,23 @@ def test_bf16_shadow_filter_gives_the_same_exact_result(Q):
     X2 = X.copy(); X2[:10] = X[100:110] * 3.0
     D2, I2 = a.search(q, k)
     check_against_oracle(D2, I2, q, X2, k)
+
+
+def test_query_chunking_under_a_workspace_cap_changes_nothing():
+    """FlatIPIndex.search keeps the [queries, rows] score workspace under max_workspace_bytes by chunking the queries: same hits."""
+    from lightretriever_amd import FlatIPIndex
+    rng = np.random.default_rng(11)
+    N, D, Q, k = 30000, 128, 700, 10
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32))
+    q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))
+    idx = FlatIPIndex(D, capacity=N)
+    idx.add(X)
+    D0, I0 = idx.search(q, k)
+    ws_full = idx._ws.numel()
+    for cap in (ws_full // 2, ws_full // 5, 40 * N * 4):          # -> chunks of 256, 128, 40-ish queries
+        idx._ws = None
+        idx.max_workspace_bytes = cap
+        D1, I1 = idx.search(q, k)
+        assert idx._ws.numel() < ws_full
+        assert torch.equal(D0, D1) and torch.equal(I0, I1)
+    check_against_oracle(D0, I0, q, X, k)
