@@ -282,3 +282,31 @@ def test_prefetch_batches_keeps_order_propagates_errors_and_stops_clean():
         list(_prefetch_batches(bad, items, 10))
     time.sleep(0.05)
     assert not [t for t in threading.enumerate() if t.name == "lrx-collate"]
+
+
+def test_token_budget_batches_merges_consecutive_packed_batches():
+    """encode_corpus's batch merging on the host side: spans stay consecutive and complete, budgets are respected, cu_seqlens are
+    re-based, padded batches and budget 0 pass through untouched."""
+    import numpy as np
+    import torch
+    from lightretriever_amd.modeling import _token_budget_batches
+
+    def mk(lens, tag, mask=False):
+        b = {"input_ids": torch.arange(sum(lens), dtype=torch.int32) + 1000 * tag,
+             "cu_seqlens": torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32), "max_seqlen": max(lens)}
+        if mask:
+            b["sparse_mask"] = torch.ones(sum(lens), dtype=torch.uint8) * tag
+        return b
+    gen = [(0, 3, mk([5, 4, 3], 0, True)), (3, 6, mk([3, 2, 2], 1, True)), (6, 9, mk([2, 1, 1], 2, True)), (9, 10, mk([1], 3, True))]
+    out = list(_token_budget_batches(iter(gen), 20, 100))
+    assert [(s, e) for s, e, _ in out] == [(0, 6), (6, 10)]
+    b = out[0][2]
+    assert b["cu_seqlens"].tolist() == [0, 5, 9, 12, 15, 17, 19] and b["max_seqlen"] == 5 and b["cu_seqlens"].dtype == torch.int32
+    assert b["input_ids"].tolist() == list(range(12)) + list(range(1000, 1007)) and b["sparse_mask"].tolist() == [0] * 12 + [1] * 7
+    assert [(s, e) for s, e, _ in _token_budget_batches(iter(gen), 0, 100)] == [(0, 3), (3, 6), (6, 9), (9, 10)]      # off
+    assert [(s, e) for s, e, _ in _token_budget_batches(iter(gen), 1000, 6)] == [(0, 6), (6, 10)]                    # document cap
+    assert [(s, e) for s, e, _ in _token_budget_batches(iter(gen), 1000, 1000)] == [(0, 10)]
+    assert [(s, e) for s, e, _ in _token_budget_batches(iter(gen), 3, 1000)] == [(0, 3), (3, 6), (6, 9), (9, 10)]    # nothing fits together
+    padded = [(0, 2, {"input_ids": torch.zeros(2, 4), "attention_mask": torch.ones(2, 4)}), (2, 4, mk([1, 1], 5)), (4, 6, mk([1, 1], 6))]
+    out = list(_token_budget_batches(iter(padded), 100, 100))
+    assert [(s, e) for s, e, _ in out] == [(0, 2), (2, 6)] and "attention_mask" in out[0][2]
