@@ -96,7 +96,7 @@ extern "C" int lrx_debug_read_gemm_trace(void* dst, size_t bytes) {
 // Diagnostic builds only (tools/gemm_ablate.sh): GEMM_ABL bit 0 = no LDS-DMA inside the K loop, bit 1 = no fragment ds_reads inside
 // the K loop, bit 2 = no barriers inside the K loop, bit 3 = no counted waits, bit 4 = the DMA fetches only K-tiles 0/1 (cache-hot),
 // bit 5 = no B1 request in P2 (4 + 2 DMA instructions per K-tile), bit 6 = no A1 request in P1 (6 + 0),
-// bit 7 = plain VGPR loads instead of LDS-DMA.  Results are garbage (in-bounds); only the time matters.
+// bit 7 = plain VGPR loads instead of LDS-DMA, bit 8 = 32x32x16 MFMAs instead of 16x16x32 (same FLOPs, same operand registers).  Results are garbage (in-bounds); only the time matters.
 #ifndef GEMM_ABL
 #define GEMM_ABL 0
 #endif
@@ -224,6 +224,35 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[H][HP][mi][ni] =                        \
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[ni][ks], a[mi][ks], acc[H][HP][mi][ni], 0, 0, 0); \
   } while (0)
+#if GEMM_ABL & 256
+  // bit 8: the same FLOPs issued as v_mfma_f32_32x32x16_bf16 (8 per quadrant) on the same operand registers -- fragment layouts do
+  // not match (garbage results): compares the energy of the two instruction shapes at the power cap
+  f32x16 acc32[2][2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[h][hp][rt][e] = 0.f;
+#undef G_MM
+#undef G_MM2
+#define G_MM32(H, HP, BR)                                                                                       \
+  do {                                                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)           \
+        acc32[H][HP][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BR[ks >> 1][ks & 1], a[2 * rt + (ks >> 1)][ks & 1], acc32[H][HP][rt], 0, 0, 0); \
+  } while (0)
+  // four independent accumulator chains per phase (a 32x32x16 result is ready 16 passes later): both quadrants round-robin
+#define G_MM(H, HP)                                                                                               \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) {           \
+      acc32[H][0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks >> 1][ks & 1], a[2 * rt + (ks >> 1)][ks & 1], acc32[H][0][rt], 0, 0, 0);  \
+      acc32[H][1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2[ks >> 1][ks & 1], a[2 * rt + (ks >> 1)][ks & 1], acc32[H][1][rt], 0, 0, 0); \
+    }                                                                                                             \
+  } while (0)
+#define G_MM2(H, HP) do { } while (0)
+#endif
   // Lifetimes: A0,B0,B1 of K-tile t are read in P1(t) (B fragments stay in registers), A1 in P2(t).  Refill one phase after
   // the last read (stagger-safe): P2(t) issues A0,B0,B1 of t+2, P1(t) issues A1 of t+1 (t >= 1; K-tile 1's comes from the
   // prologue).  Counted waits: vmcnt(8) in both phases = the 2 + 6 youngest DMA instructions stay in flight.
@@ -271,6 +300,18 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 #if GEMM_ABL & 128
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("" ::"v"(sink0), "v"(sink1));
+#endif
+#if GEMM_ABL & 256
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[h][hp][mi][ni][e] += acc32[h][hp][mi >> 1][(mi & 1) * 8 + ni * 4 + e];
 #endif
   G_TRACE(1);
 
