@@ -275,6 +275,24 @@ def main():
                          "fp32_mfma_peak_for_reference": PEAK_F32_MFMA_TFLOPS},
         }
 
+        # the other query counts of SURVEY 8d (Q = 1 and Q = 1000), same flow (EmbeddingBag -> local search -> exchange + merge)
+        other = {}
+        for Qx in (1, 1000):
+            lens_x = torch.randint(8, 33, (Qx,), generator=gq, device=dev)
+            offs_x = (torch.cumsum(lens_x, 0) - lens_x).to(torch.int64)
+            ids_x = torch.randint(1000, 127000, (int(lens_x.sum().item()),), generator=gq, device=dev)
+            sharded.search(ops.embedding_bag_mean(table, ids_x, offs_x, normalize=True), args.topk)
+            barrier_sync(distributed)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sharded.search(ops.embedding_bag_mean(table, ids_x, offs_x, normalize=True), args.topk)
+            barrier_sync(distributed)
+            tx = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            if distributed:
+                dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+            other[str(Qx)] = {"queries_per_s": round(Qx * args.steps / float(tx.item()), 1), "ms_per_pass": round(1e3 * float(tx.item()) / args.steps, 4)}
+        search["other_query_counts"] = other
+
     # ---- dense + sparse document vectors (row N2): same batches through lrx_encode_packed_sparse; not part of `value`
     sparse = None
     if not args.no_sparse and batches is None:
