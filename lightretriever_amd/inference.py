@@ -49,6 +49,41 @@ class InferenceArguments:
     noncontextual_query_embedding: bool = True
     noncontextual_prompt_prefix: Optional[str] = None
     eval_batch_size_embedding_bag: int = 5000
+    # sparse document vectors (finetune/arguments.py:203-290): passages through the LM head, queries as token-id counts
+    hybrid_use_sparse_vector: bool = False
+    hybrid_use_token_id_vector: bool = False
+    token_id_vector_type: str = "sum"
+    sparse_use_max_aggregation: bool = True
+    sparse_use_relu: bool = False
+    sparse_use_log_saturation: bool = False
+    sparse_min_tokens_to_keep: int = 8
+    sparse_top_p_psg: float = 1.0
+    sparse_top_k_psg: int = 0
+    sparse_top_p_qry: float = 1.0                       # (query side is parameter-free here: accepted, unused)
+    sparse_top_k_qry: int = 0
+    normalize: Optional[bool] = None                    # None -> derived from score_function
+    # accepted for CLI compatibility with the reference's argument classes; the options below marked (*) must keep their default
+    hybrid_model_architecture: str = "gpt"              # (*)
+    untie_encoder: bool = False                         # (*)
+    enable_bidirectional_attention: bool = False        # (*)
+    use_sparse_linear_projector: bool = False           # (*)
+    use_sparse_down_projector: bool = False             # (*)
+    use_icu_word_pretokenizer: bool = False             # (*)
+    sparse_remove_stopwords: bool = False               # (*)
+    sparse_pool_from_unique_token_ids: bool = False     # (*)
+    sparse_pool_from_original_input_ids_qry: bool = False   # (*)
+    sparse_pool_from_original_input_ids_psg: bool = False   # (*)
+    sparse_pooling_strategy: Optional[str] = None
+    pad_to_multiple_of: Optional[int] = None
+    max_length: int = 1024                              # reranker only
+    pad_to_max_length: bool = False                     # packed varlen never pads
+    padding: Optional[str] = None
+    anserini_lang: Optional[str] = None                 # sparse engine (out of scope, handed through to `sparse_search`)
+    anserini_vector_type: str = "JsonVectorCollection"
+    anserini_pretokenized: bool = True
+    anserini_impact_search: bool = True
+    anserini_bm25_k1: float = 0.9
+    anserini_bm25_b: float = 0.4
     # rank wiring (env, inference/arguments.py:140-150)
     local_rank: int = -1
     rank: int = -1
@@ -66,12 +101,26 @@ class InferenceArguments:
         if os.getenv("MASTER_PORT"):
             self.master_port = os.environ["MASTER_PORT"]
         self.dtype = torch.bfloat16 if self.bf16 else (torch.float16 if self.fp16 else None)
-        self.normalize = self.score_function == "cos_sim"       # finetune/arguments.py:312-317
+        if self.normalize is None:
+            self.normalize = self.score_function == "cos_sim"   # finetune/arguments.py:312-317
         self.pad_token, self.sep_token = default_special_tokens(self.model_name_or_path, self.pad_token, self.sep_token)
         if self.pooling_strategy != "lasttoken":
             raise NotImplementedError("the MI355X path implements the shipped 'lasttoken' pooling only")
         if self.fp16:
             raise NotImplementedError("bf16 is the compute type of the HIP encoder")
+        # options whose non-default value selects a part of the reference this path does not implement: fail loudly, never silently
+        for name, default in (("hybrid_model_architecture", "gpt"), ("untie_encoder", False), ("enable_bidirectional_attention", False),
+                              ("use_sparse_linear_projector", False), ("use_sparse_down_projector", False), ("use_icu_word_pretokenizer", False),
+                              ("sparse_remove_stopwords", False), ("sparse_pool_from_unique_token_ids", False),
+                              ("sparse_pool_from_original_input_ids_qry", False), ("sparse_pool_from_original_input_ids_psg", False),
+                              ("sparse_use_max_aggregation", True), ("noncontextual_query_embedding", True), ("hybrid_use_dense_vector", False)):
+            if getattr(self, name) != default:
+                raise NotImplementedError(f"--{name}={getattr(self, name)!r}: the MI355X path implements the asymmetric retriever only "
+                                          f"(documents through the LM, queries through the EmbeddingBag / token-id counts)")
+        if self.hybrid_use_sparse_vector and not self.hybrid_use_token_id_vector:
+            raise NotImplementedError("--hybrid_use_sparse_vector without --hybrid_use_token_id_vector asks for query vectors from the LM head; "
+                                      "the query side here is parameter-free (token-id counts)")
+        self.encode_sparse = self.hybrid_use_sparse_vector or self.hybrid_use_token_id_vector   # modeling_hybrid.py:241-245
 
 
 class PytorchRPCExactSearchModel(LrxExactSearchModel):
@@ -87,9 +136,15 @@ class PytorchRPCExactSearchModel(LrxExactSearchModel):
                              add_pad_token=args.add_pad_token, pad_token=args.pad_token, add_sep_token=args.add_sep_token,
                              sep_token=args.sep_token)
         enc = encoder_from_pretrained(args.model_name_or_path, max_positions=max(args.p_max_len, args.q_max_len, 64), device=dev)
-        hm = LrxHybridModel(enc, normalize=args.normalize, dense_shrink_dim=args.dense_shrink_dim, pad_token_id=tok.pad_token_id)
+        hm = LrxHybridModel(enc, normalize=args.normalize, dense_shrink_dim=args.dense_shrink_dim, pad_token_id=tok.pad_token_id,
+                            encode_sparse=args.encode_sparse, sep_token_id=getattr(tok, "sep_token_id", None), add_sep_token=args.add_sep_token,
+                            sparse_use_relu=args.sparse_use_relu, sparse_use_log_saturation=args.sparse_use_log_saturation,
+                            sparse_top_k_psg=args.sparse_top_k_psg, sparse_top_p_psg=args.sparse_top_p_psg,
+                            sparse_min_tokens_to_keep=args.sparse_min_tokens_to_keep)
         super().__init__(model=hm, tokenizer=tok, q_max_len=args.q_max_len, p_max_len=args.p_max_len,
-                         append_prompt_sep=args.append_prompt_sep, eval_batch_size_embedding_bag=args.eval_batch_size_embedding_bag)
+                         append_prompt_sep=args.append_prompt_sep, eval_batch_size_embedding_bag=args.eval_batch_size_embedding_bag,
+                         token_id_vector_type=args.token_id_vector_type)
+        self.encoding_kwargs["anserini_vector_type"] = args.anserini_vector_type      # exact_search_torchrpc.py:100-101
 
     def stop_multi_process_pool(self):  # API parity with the reference (exact_search_torchrpc.py:103-120); nothing to stop
         return None

@@ -281,3 +281,42 @@ def test_token_budget_batch_merging_leaves_every_row_unchanged():
     ms.max_batch_tokens = 500
     b = ms.encode_corpus(docs[:60], batch_size=8)
     assert torch.equal(a["dense_reps"], b["dense_reps"]) and a["sparse_reps"] == b["sparse_reps"]
+
+
+def test_cli_arguments_wire_the_sparse_branch_through_the_reference_entry_point(tmp_path):
+    """The reference's model flags arrive through HfArgumentParser (eval/eval_arguments.py) and select what encode_* returns:
+    --hybrid_use_token_id_vector (+ relu / log saturation) -> corpus: dense rows + quantised sparse JSON from the LM head,
+    queries: EmbeddingBag rows + token-id counts; same vectors as a hand-built LrxHybridModel with those options."""
+    import shutil
+    from transformers import HfArgumentParser, LlamaConfig, LlamaForCausalLM
+    from lightretriever.inference.arguments import InferenceArguments
+    from lightretriever.inference.exact_search_torchrpc import PytorchRPCExactSearchModel
+    from lightretriever_amd.modeling import LrxExactSearchModel, LrxHybridModel
+    tok = tokenizer()
+    torch.manual_seed(4)
+    hf_cfg = LlamaConfig(vocab_size=len(tok), hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                         num_key_value_heads=1, head_dim=64, rms_norm_eps=1e-5, tie_word_embeddings=True,
+                         rope_parameters={"rope_type": "default", "rope_theta": 1e4})
+    ckpt = str(tmp_path / "ckpt")
+    LlamaForCausalLM(hf_cfg).to(torch.bfloat16).save_pretrained(ckpt, safe_serialization=True)
+    for f in os.listdir(os.path.join(GOLDEN, "tok")):
+        shutil.copy(os.path.join(GOLDEN, "tok", f), ckpt)
+    (args,) = HfArgumentParser(InferenceArguments).parse_args_into_dataclasses(
+        ["--model_name_or_path", ckpt, "--q_max_len", "16", "--p_max_len", "48", "--batch_size", "8", "--eval_batch_size_embedding_bag", "128",
+         "--hybrid_use_emb_vector", "--hybrid_use_token_id_vector", "--hybrid_use_sparse_vector", "--sparse_use_relu", "--sparse_use_log_saturation",
+         "--sparse_top_k_psg", "12", "--token_id_vector_type", "bow", "--anserini_vector_type", "JsonVectorCollection"])
+    assert args.encode_sparse and args.normalize
+    model = PytorchRPCExactSearchModel(args)
+    assert model.encoding_kwargs["anserini_vector_type"] == "JsonVectorCollection"
+    docs = list(synth_corpus(np.random.default_rng(9), 21, 3, 40).values())
+    got = model.encode_corpus(docs, batch_size=8)
+    assert set(got) == {"dense_reps", "sparse_reps"} and len(got["sparse_reps"]) == len(docs)
+    assert all(isinstance(k, str) and isinstance(v, int) and v > 0 for d in got["sparse_reps"] for k, v in d.items())
+    assert max(len(d) for d in got["sparse_reps"]) <= 12 + 8                   # top-k 12 (ties kept) on top of min_tokens_to_keep
+    hm = LrxHybridModel(model.model.encoder, normalize=True, pad_token_id=model.tokenizer.pad_token_id, encode_sparse=True,
+                        sep_token_id=getattr(model.tokenizer, "sep_token_id", None), sparse_use_relu=True, sparse_use_log_saturation=True,
+                        sparse_top_k_psg=12)
+    want = LrxExactSearchModel(model=hm, tokenizer=model.tokenizer, q_max_len=16, p_max_len=48).encode_corpus(docs, batch_size=8)
+    assert torch.equal(got["dense_reps"], want["dense_reps"]) and got["sparse_reps"] == want["sparse_reps"]
+    q = model.encode_queries(["capital of france", "dense retrieval retrieval"], batch_size=8)
+    assert set(q) == {"emb_reps", "token_id_reps"} and all(v == 1 for d in q["token_id_reps"] for v in d.values())   # 'bow'

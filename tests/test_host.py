@@ -310,3 +310,26 @@ def test_token_budget_batches_merges_consecutive_packed_batches():
     padded = [(0, 2, {"input_ids": torch.zeros(2, 4), "attention_mask": torch.ones(2, 4)}), (2, 4, mk([1, 1], 5)), (4, 6, mk([1, 1], 6))]
     out = list(_token_budget_batches(iter(padded), 100, 100))
     assert [(s, e) for s, e, _ in out] == [(0, 2), (2, 6)] and "attention_mask" in out[0][2]
+
+
+def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_modes():
+    """lightretriever.inference.arguments.InferenceArguments through HfArgumentParser (how eval/eval_arguments.py builds it): every
+    model flag of the reference's launch scripts parses; options that select parts of the reference this path does not implement
+    raise instead of being ignored."""
+    import pytest
+    from transformers import HfArgumentParser
+    from lightretriever.inference.arguments import InferenceArguments
+    parse = lambda *a: HfArgumentParser(InferenceArguments).parse_args_into_dataclasses(["--model_name_or_path", "meta-llama/Llama-3.2-1B", *a])[0]
+    a = parse("--hybrid_use_emb_vector", "--noncontextual_query_embedding", "--lowercase", "--add_sep_token", "--add_bos_num", "1", "--add_eos_num", "1",
+              "--pooling_strategy", "lasttoken", "--score_function", "cos_sim", "--attn_implementation", "flash_attention_2", "--cumulative_seq",
+              "--liger_kernel", "--bf16", "--batch_size", "256", "--p_max_len", "512", "--q_max_len", "512", "--inference_arch", "PytorchRPCExactSearchModel",
+              "--pad_to_multiple_of", "8", "--anserini_impact_search", "True")
+    assert a.normalize is True and a.encode_sparse is False and a.lowercase and a.add_sep_token
+    assert (a.pad_token, a.sep_token) == ("<|reserved_special_token_0|>", "<|reserved_special_token_1|>")      # llama defaults (arguments.py:286-310)
+    b = parse("--hybrid_use_token_id_vector", "--sparse_use_relu", "--sparse_use_log_saturation", "--score_function", "dot")
+    assert b.encode_sparse and b.normalize is False and b.sparse_use_relu and b.token_id_vector_type == "sum"
+    for bad in (["--untie_encoder"], ["--hybrid_use_dense_vector"], ["--hybrid_use_sparse_vector"], ["--enable_bidirectional_attention"],
+                ["--use_sparse_linear_projector"], ["--sparse_remove_stopwords"], ["--hybrid_model_architecture", "bert"], ["--fp16"],
+                ["--pooling_strategy", "mean"], ["--sparse_use_max_aggregation", "False"], ["--noncontextual_query_embedding", "False"]):
+        with pytest.raises(NotImplementedError):
+            parse(*bad)
