@@ -145,6 +145,8 @@ class PytorchRPCExactSearchModel(LrxExactSearchModel):
                          append_prompt_sep=args.append_prompt_sep, eval_batch_size_embedding_bag=args.eval_batch_size_embedding_bag,
                          token_id_vector_type=args.token_id_vector_type)
         self.encoding_kwargs["anserini_vector_type"] = args.anserini_vector_type      # exact_search_torchrpc.py:100-101
+        from . import rpc_shards
+        rpc_shards.register_worker(self)              # the model remote calls of a driving rank will use (MODEL_REGISTRY of the reference)
 
     def stop_multi_process_pool(self):  # API parity with the reference (exact_search_torchrpc.py:103-120); nothing to stop
         return None

@@ -360,6 +360,13 @@ def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: li
     rank, world = DenseRetrievalFaissSearch._rank_world()
     if world > 1:
         from .sharded import exchange_topk, local_to_global_rows
+    # the reference's own launch (eval/eval_utils.py: torch RPC, only rank 0 drives): shards live on the RPC workers
+    rpc_names = []
+    if world == 1:
+        from . import rpc_shards
+        rpc_names = rpc_shards.rpc_workers()
+        if len(rpc_names) <= 1 or "model" not in rpc_shards._WORKER:
+            rpc_names = []
     for s in range(0, n, searcher.corpus_chunk_size):
         e = min(s + searcher.corpus_chunk_size, n)
         logger.info("Encoding Batch %d/%d...", s // searcher.corpus_chunk_size + 1, -(-n // searcher.corpus_chunk_size))
@@ -368,10 +375,15 @@ def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: li
             # encodes its batches into its own HBM shard whose rows carry their global sorted position
             rows = (local_to_global_rows(e - s, searcher.batch_size, rank, world) + s).tolist()
             searcher._index_in_place([docs[i] for i in rows], rows, dim)
+        elif rpc_names:
+            rpc_shards.index_chunk(rpc_names, docs[s:e], s, dim, searcher.batch_size)   # texts out, nothing back
         else:
             searcher._index_in_place(docs[s:e], list(range(s, e)), dim)   # rows carry their global sorted position
         for j, q in enumerate(qlist):
-            D, I = searcher._retrieve_device(q, top_k)
+            if rpc_names:                             # local top-k of every worker's shard (Q x k pairs each), merged here
+                D, I = merge_topk(*rpc_shards.search_shards(rpc_names, q, top_k, searcher.batch_size))
+            else:
+                D, I = searcher._retrieve_device(q, top_k)
             if world > 1:                             # one all-gather of the packed per-shard lists, merge on every rank
                 Dp, Ip = exchange_topk(D, I)
                 D, I = merge_topk(Dp, Ip)
@@ -380,6 +392,8 @@ def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: li
                 D = torch.where(hit, torch.full_like(D, -FLT_MAX), D)
                 I = torch.where(hit, torch.full_like(I, -1), I)
             run_D[j], run_I[j] = merge_topk(torch.stack([run_D[j], D]), torch.stack([run_I[j], I]))
+        if rpc_names:
+            rpc_shards.clear_shards(rpc_names, searcher.batch_size)
         searcher._clear()
     rev = {i: c for i, c in enumerate(corpus_ids)}
     outs = [_to_result_dict(d, i, query_ids, rev) for d, i in zip(run_D, run_I)]

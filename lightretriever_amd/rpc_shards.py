@@ -1,0 +1,93 @@
+"""Row-sharded search driven from ONE rank over torch RPC -- the launch shape of the reference's own eval driver.
+
+eval/eval_utils.py:launch_eval starts one process per GPU with `rpc.init_rpc(name=f"worker{rank}")`, builds
+`PytorchRPCExactSearchModel(args)` on every rank and then runs the evaluation on rank 0 only; the other ranks sit in
+`rpc.shutdown()` serving calls.  The reference uses that to fan batches out and pull every embedding back to rank 0
+(inference/exact_search_torchrpc.py:122-351).  Here the same launch keeps the corpus where it is encoded: rank 0 sends each
+worker the TEXTS of its batches (batch j of a sorted chunk -> worker j % R), the worker encodes them into a shard in its own
+HBM, later receives the query embeddings (a few hundred KB) and answers with its local top-k (Q x k pairs); rank 0 merges.
+No embedding row ever crosses the RPC transport.  With an initialised `torch.distributed` group the SPMD path of
+`retriever._chunked_dense_search` (RCCL all-gather) is used instead; with neither, everything runs on the calling rank."""
+from __future__ import annotations
+
+import torch
+
+_WORKER: dict = {}      # per-process registry (the reference's MODEL_REGISTRY, exact_search_torchrpc.py:95-96)
+
+
+def register_worker(model) -> None:
+    """Called by PytorchRPCExactSearchModel.__init__ on every rank: the model remote calls will use."""
+    _WORKER["model"] = model
+    _WORKER.pop("searcher", None)
+
+
+def rpc_workers() -> list:
+    """Names of the RPC workers ordered by id ([] when torch RPC is not initialised in this process)."""
+    try:
+        from torch.distributed import rpc
+        if not rpc.api._is_current_rpc_agent_set():
+            return []
+        return [w.name for w in sorted(rpc.api._get_current_rpc_agent().get_worker_infos(), key=lambda w: w.id)]
+    except Exception:   # torch built without RPC
+        return []
+
+
+# ---- executed on the worker (an RPC server thread: the current device must be set explicitly) ------------------------------
+def _searcher(batch_size: int):
+    from .retriever import FlatIPFaissSearch
+    s = _WORKER.get("searcher")
+    if s is None or s.batch_size != batch_size:
+        s = _WORKER["searcher"] = FlatIPFaissSearch(_WORKER["model"], batch_size=batch_size)
+        s.show_progress_bar = False
+    return s
+
+
+def _w_index(docs: list, rows: list, dim: int, batch_size: int) -> int:
+    if "model" not in _WORKER:
+        raise RuntimeError("lrx rpc worker: no model registered in this process (construct PytorchRPCExactSearchModel on every rank)")
+    dev = _WORKER["model"].model.device
+    with torch.cuda.device(dev):
+        _searcher(batch_size)._index_in_place(docs, rows, dim)
+        torch.cuda.synchronize()
+    return len(docs)
+
+
+def _w_search(q_cpu: torch.Tensor, top_k: int, batch_size: int):
+    dev = _WORKER["model"].model.device
+    with torch.cuda.device(dev):
+        D, I = _searcher(batch_size)._retrieve_device(q_cpu.to(dev), top_k)
+        return D.cpu(), I.cpu()
+
+
+def _w_clear(batch_size: int) -> None:
+    s = _WORKER.get("searcher")
+    if s is not None:
+        s._clear()
+
+
+# ---- executed on the driving rank ---------------------------------------------------------------------------------------------
+def index_chunk(workers: list, docs: list, first_row: int, dim: int, batch_size: int) -> None:
+    """Batch j of `docs` (one sorted corpus chunk; global rows first_row ..) -> worker j % R, encoded there into a fresh shard."""
+    from torch.distributed import rpc
+    from .sharded import local_to_global_rows
+    futs = []
+    for r, name in enumerate(workers):
+        rows = local_to_global_rows(len(docs), batch_size, r, len(workers)).tolist()
+        futs.append(rpc.rpc_async(name, _w_index, args=([docs[i] for i in rows], [first_row + i for i in rows], dim, batch_size)))
+    for f in futs:
+        f.wait()
+
+
+def search_shards(workers: list, q: torch.Tensor, top_k: int, batch_size: int):
+    """-> ([R,Q,k] scores, [R,Q,k] global rows) on q's device: every worker's local top-k over the shard it holds."""
+    from torch.distributed import rpc
+    q_cpu = q.detach().cpu()
+    futs = [rpc.rpc_async(name, _w_search, args=(q_cpu, top_k, batch_size)) for name in workers]
+    parts = [f.wait() for f in futs]
+    return torch.stack([p[0] for p in parts]).to(q.device), torch.stack([p[1] for p in parts]).to(q.device)
+
+
+def clear_shards(workers: list, batch_size: int) -> None:
+    from torch.distributed import rpc
+    for f in [rpc.rpc_async(name, _w_clear, args=(batch_size,)) for name in workers]:
+        f.wait()

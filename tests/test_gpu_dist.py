@@ -91,3 +91,64 @@ def test_search_flow_sharded_over_two_ranks_equals_single_process():
             assert list(ret[r][q]) == list(want[q]) or set(ret[r][q]) == set(want[q])
             for pid, sc in want[q].items():
                 assert abs(ret[r][q][pid] - sc) < 1e-6
+
+
+def _rpc_worker(rank, world, port, ret):
+    """One process of the reference's launch shape (eval/eval_utils.py:launch_eval): torch RPC, a model on every rank, only rank 0
+    drives the search; the other rank serves calls inside rpc.shutdown().  Both processes share cuda:0 here."""
+    from torch.distributed import rpc
+    import sys
+    os.environ.setdefault("TP_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_api import build_stack, synth_corpus
+    from helpers import load_model_golden
+    from lightretriever_amd import rpc_shards
+    from lightretriever_amd.retriever import HybridSearch
+    opts = rpc.TensorPipeRpcBackendOptions(init_method=f"tcp://127.0.0.1:{port}", _transports=["shm", "uv"], _channels=["cma", "mpt_uv", "basic"])
+    rpc.init_rpc(name=f"worker{rank}", rank=rank, world_size=world, rpc_backend_options=opts)
+    try:
+        cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+        tok, enc, hm, model = build_stack(cfg_o, w)
+        rpc_shards.register_worker(model)                       # what PytorchRPCExactSearchModel.__init__ does on every rank
+        rpc.api._wait_all_workers(60)
+        if rank == 0:
+            corpus = synth_corpus(np.random.default_rng(0), 150)
+            queries = {"q0": "capital of france", "q1": "dense retrieval models", "q2": "amd instinct memory", "d7": corpus["d7"]["text"]}
+            searcher = HybridSearch(model, batch_size=16, corpus_chunk_size=70)
+            res = searcher.search(corpus, queries, top_k=12, ignore_identical_ids=True)
+            ret["rpc"] = {q: dict(v) for q, v in res.items()}
+            ret["workers"] = rpc_shards.rpc_workers()
+    finally:
+        rpc.shutdown()
+
+
+def test_search_driven_from_rank0_over_rpc_equals_single_process():
+    """The unchanged eval driver's launch: shards on the RPC workers, texts out, per-shard top-k back, merge on rank 0 -> the same
+    hits (ids and scores) as one process holding the whole corpus."""
+    import torch.multiprocessing as mp
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_api import build_stack, synth_corpus
+    from helpers import load_model_golden
+    from lightretriever_amd.retriever import HybridSearch
+    cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    tok, enc, hm, model = build_stack(cfg_o, w)
+    corpus = synth_corpus(np.random.default_rng(0), 150)
+    queries = {"q0": "capital of france", "q1": "dense retrieval models", "q2": "amd instinct memory", "d7": corpus["d7"]["text"]}
+    want = HybridSearch(model, batch_size=16, corpus_chunk_size=70).search(corpus, queries, top_k=12, ignore_identical_ids=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + os.getpid() % 1000
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rpc_worker, args=(r, 2, port, ret)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert ret["workers"] == ["worker0", "worker1"]
+    got = ret["rpc"]
+    assert set(got) == set(want) and "d7" not in got["d7"]
+    for q in want:
+        assert set(got[q]) == set(want[q])
+        for pid, sc in want[q].items():
+            assert abs(got[q][pid] - sc) < 1e-6
