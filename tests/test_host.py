@@ -333,3 +333,16 @@ def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_m
                 ["--pooling_strategy", "mean"], ["--sparse_use_max_aggregation", "False"], ["--noncontextual_query_embedding", "False"]):
         with pytest.raises(NotImplementedError):
             parse(*bad)
+
+
+def test_rpc_shard_mode_is_inactive_without_an_rpc_agent():
+    """retriever._chunked_dense_search only takes the RPC-driven path when torch RPC is initialised and workers registered a model."""
+    from lightretriever_amd import rpc_shards
+    assert rpc_shards.rpc_workers() == []
+    with pytest.raises(RuntimeError, match="no model registered"):
+        saved = rpc_shards._WORKER.pop("model", None)
+        try:
+            rpc_shards._w_index([], [], 8, 4)
+        finally:
+            if saved is not None:
+                rpc_shards._WORKER["model"] = saved
