@@ -346,3 +346,29 @@ def test_rpc_shard_mode_is_inactive_without_an_rpc_agent():
         finally:
             if saved is not None:
                 rpc_shards._WORKER["model"] = saved
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/eval"), reason="reference tree not mounted (GPU box)")
+def test_reference_eval_arguments_build_on_the_import_path_shim():
+    """The reference's own eval/eval_arguments.py (read in place, never copied) subclasses lightretriever.inference.arguments
+    .InferenceArguments: with this repo's import-path shim it must import, parse the flags of eval/call_evaluate_mteb.sh and the model
+    flags of the launch scripts, and run its __post_init__."""
+    import importlib.util
+    from transformers import HfArgumentParser
+    spec = importlib.util.spec_from_file_location("ref_eval_arguments", "/root/reference/eval/eval_arguments.py")
+    mod = importlib.util.module_from_spec(spec)
+    dont = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True          # leave the read-only tree untouched
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.dont_write_bytecode = dont
+    import lightretriever_amd.inference as mine
+    assert issubclass(mod.EvalArguments, mine.InferenceArguments)
+    (a,) = HfArgumentParser(mod.EvalArguments).parse_args_into_dataclasses(
+        ["--model_name_or_path", "results/lightretriever-llama3.2-1b", "--benchmark_name", "BEIR", "--top_k", "1000", "--inference_arch",
+         "PytorchRPCExactSearchModel", "--output_dir", "/tmp/out", "--batch_size", "256", "--corpus_chunk_size", "100000",
+         "--hybrid_use_emb_vector", "--noncontextual_query_embedding", "--lowercase", "--add_sep_token", "--pooling_strategy", "lasttoken",
+         "--score_function", "cos_sim", "--q_max_len", "512", "--p_max_len", "512", "--bf16"])
+    assert a.top_k == 1000 and a.corpus_chunk_size == 100000 and a.normalize is True and a.encode_sparse is False
+    assert a.model_type == "HybridModel" and a.inference_arch == "PytorchRPCExactSearchModel" and max(a.k_values) <= a.top_k
