@@ -70,10 +70,10 @@ def index_chunk(workers: list, docs: list, first_row: int, dim: int, batch_size:
     """Batch j of `docs` (one sorted corpus chunk; global rows first_row ..) -> worker j % R, encoded there into a fresh shard."""
     from torch.distributed import rpc
     from .sharded import local_to_global_rows
-    futs = []
+    futs = []   # timeout=0: a worker's share of a large chunk takes minutes (the RPC default would give up after 60 s)
     for r, name in enumerate(workers):
         rows = local_to_global_rows(len(docs), batch_size, r, len(workers)).tolist()
-        futs.append(rpc.rpc_async(name, _w_index, args=([docs[i] for i in rows], [first_row + i for i in rows], dim, batch_size)))
+        futs.append(rpc.rpc_async(name, _w_index, args=([docs[i] for i in rows], [first_row + i for i in rows], dim, batch_size), timeout=0))
     for f in futs:
         f.wait()
 
@@ -82,12 +82,12 @@ def search_shards(workers: list, q: torch.Tensor, top_k: int, batch_size: int):
     """-> ([R,Q,k] scores, [R,Q,k] global rows) on q's device: every worker's local top-k over the shard it holds."""
     from torch.distributed import rpc
     q_cpu = q.detach().cpu()
-    futs = [rpc.rpc_async(name, _w_search, args=(q_cpu, top_k, batch_size)) for name in workers]
+    futs = [rpc.rpc_async(name, _w_search, args=(q_cpu, top_k, batch_size), timeout=0) for name in workers]
     parts = [f.wait() for f in futs]
     return torch.stack([p[0] for p in parts]).to(q.device), torch.stack([p[1] for p in parts]).to(q.device)
 
 
 def clear_shards(workers: list, batch_size: int) -> None:
     from torch.distributed import rpc
-    for f in [rpc.rpc_async(name, _w_clear, args=(batch_size,)) for name in workers]:
+    for f in [rpc.rpc_async(name, _w_clear, args=(batch_size,), timeout=0) for name in workers]:
         f.wait()
