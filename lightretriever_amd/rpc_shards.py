@@ -42,12 +42,33 @@ def _searcher(batch_size: int):
     return s
 
 
-def _w_index(docs: list, rows: list, dim: int, batch_size: int) -> int:
+def _w_index(docs: list, rows: list, dim: int, batch_size: int, capacity: int, first: bool, last: bool) -> int:
+    """One piece of this worker's share of a corpus chunk: encoded straight into the shard (allocated for `capacity` rows by the first
+    piece); the last piece publishes the shard to the worker's searcher with the rows' global positions as ids."""
     if "model" not in _WORKER:
         raise RuntimeError("lrx rpc worker: no model registered in this process (construct PytorchRPCExactSearchModel on every rank)")
-    dev = _WORKER["model"].model.device
+    from .index import FlatIPIndex
+    from .retriever import FaissIndex
+    model = _WORKER["model"]
+    dev = model.model.device
     with torch.cuda.device(dev):
-        _searcher(batch_size)._index_in_place(docs, rows, dim)
+        s = _searcher(batch_size)
+        if first:
+            s._clear()
+            _WORKER["pending"] = (FlatIPIndex(dim, capacity=capacity, device=dev), [])
+        idx, ids = _WORKER["pending"]
+        if docs:
+            slot = idx.append_slot(len(docs))
+            emb = model.encode_corpus(docs, batch_size=batch_size, show_progress_bar=False, convert_to_tensor=True, out=slot)
+            emb = emb["dense_reps"] if isinstance(emb, dict) else emb
+            if emb.data_ptr() != slot.data_ptr():
+                slot.copy_(emb.to(slot.device))
+            idx.commit(len(docs))
+            ids.extend(rows)
+        if last:
+            s.dim_size = dim
+            s.faiss_index = FaissIndex(idx, ids if ids else None)
+            _WORKER.pop("pending", None)
         torch.cuda.synchronize()
     return len(docs)
 
@@ -66,16 +87,24 @@ def _w_clear(batch_size: int) -> None:
 
 
 # ---- executed on the driving rank ---------------------------------------------------------------------------------------------
+PIECE_DOCS = 32768   # documents per RPC message and worker (tens of MB of text; a 10 M-document chunk must not travel as one pickle)
+
+
 def index_chunk(workers: list, docs: list, first_row: int, dim: int, batch_size: int) -> None:
-    """Batch j of `docs` (one sorted corpus chunk; global rows first_row ..) -> worker j % R, encoded there into a fresh shard."""
+    """Batch j of `docs` (one sorted corpus chunk; global rows first_row ..) -> worker j % R, encoded there into a fresh shard.
+    Every worker's share goes out in pieces of PIECE_DOCS documents, all workers working on their k-th piece at the same time."""
     from torch.distributed import rpc
     from .sharded import local_to_global_rows
-    futs = []   # timeout=0: a worker's share of a large chunk takes minutes (the RPC default would give up after 60 s)
-    for r, name in enumerate(workers):
-        rows = local_to_global_rows(len(docs), batch_size, r, len(workers)).tolist()
-        futs.append(rpc.rpc_async(name, _w_index, args=([docs[i] for i in rows], [first_row + i for i in rows], dim, batch_size), timeout=0))
-    for f in futs:
-        f.wait()
+    shares = [local_to_global_rows(len(docs), batch_size, r, len(workers)).tolist() for r in range(len(workers))]
+    n_pieces = max(1, max(-(-len(sh) // PIECE_DOCS) for sh in shares))
+    for k in range(n_pieces):
+        futs = []   # timeout=0: a piece takes a while to encode (the RPC default would give up after 60 s)
+        for name, sh in zip(workers, shares):
+            part = sh[k * PIECE_DOCS:(k + 1) * PIECE_DOCS]
+            futs.append(rpc.rpc_async(name, _w_index, args=([docs[i] for i in part], [first_row + i for i in part], dim, batch_size, len(sh),
+                                                             k == 0, k == n_pieces - 1), timeout=0))
+        for f in futs:
+            f.wait()
 
 
 def search_shards(workers: list, q: torch.Tensor, top_k: int, batch_size: int):

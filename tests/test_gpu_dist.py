@@ -116,6 +116,7 @@ def _rpc_worker(rank, world, port, ret):
             corpus = synth_corpus(np.random.default_rng(0), 150)
             queries = {"q0": "capital of france", "q1": "dense retrieval models", "q2": "amd instinct memory", "d7": corpus["d7"]["text"]}
             searcher = HybridSearch(model, batch_size=16, corpus_chunk_size=70)
+            rpc_shards.PIECE_DOCS = 20                          # a worker's share of a chunk (~35 documents) travels in two pieces
             res = searcher.search(corpus, queries, top_k=12, ignore_identical_ids=True)
             ret["rpc"] = {q: dict(v) for q, v in res.items()}
             ret["workers"] = rpc_shards.rpc_workers()
