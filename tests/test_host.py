@@ -342,7 +342,7 @@ def test_rpc_shard_mode_is_inactive_without_an_rpc_agent():
     with pytest.raises(RuntimeError, match="no model registered"):
         saved = rpc_shards._WORKER.pop("model", None)
         try:
-            rpc_shards._w_index([], [], 8, 4)
+            rpc_shards._w_index([], [], 8, 4, 0, True, True)
         finally:
             if saved is not None:
                 rpc_shards._WORKER["model"] = saved
