@@ -202,16 +202,17 @@ class FlatIPFaissSearch(DenseRetrievalFaissSearch):
         idx = FlatIPIndex(dim, capacity=len(docs))
         if not docs:                                  # a rank without a batch in this chunk: empty shard, searches return padding
             self.faiss_index = FaissIndex(idx, None)
-            return
+            return None
         slot = idx.append_slot(len(docs))
-        emb = self.model.encode_corpus(docs, batch_size=self.batch_size, show_progress_bar=self.show_progress_bar,
-                                       convert_to_tensor=True, out=slot)
+        enc = emb = self.model.encode_corpus(docs, batch_size=self.batch_size, show_progress_bar=self.show_progress_bar,
+                                             convert_to_tensor=True, out=slot)
         if isinstance(emb, dict):
             emb = emb["dense_reps"]
         if emb.data_ptr() != slot.data_ptr():       # a model that does not support `out=`: one device copy
             slot.copy_(emb.to(slot.device))
         idx.commit(len(docs))
         self.faiss_index = FaissIndex(idx, [self.mapping.get(c, c) for c in corpus_ids])
+        return enc if isinstance(enc, dict) else {"dense_reps": enc}   # what encode_corpus returned (sparse_reps ride along)
 
     def load(self, input_dir: str, prefix: str = "my-index", ext: str = "flat"):
         """faiss_search.py:478-488: id map + index file -> HBM shard of this rank."""
@@ -314,10 +315,22 @@ class HybridSearch:
         results, default = {}, None
         # one corpus pass serves every enabled query representation (they share the document `dense_reps`)
         kinds = [(k, name) for k, name in (("dense_reps", "den"), ("emb_reps", "emb")) if qe.get(k) is not None]
-        multi = _chunked_dense_search(self.dense_search, [qe[k] for k, _ in kinds], query_ids, corpus, top_k, ignore_identical_ids)
+        # sparse half (hybrid_search.py:330-375): every chunk's document vectors go into the engine as they are encoded, the engine is
+        # searched once at the end with the queries' token-id counts, `emb_tok` is the fusion of the two final hit lists
+        use_tok = self.sparse_search is not None and qe.get("token_id_reps") is not None
+        on_chunk = None
+        if use_tok:
+            def on_chunk(chunk_ids, enc):
+                assert enc.get("sparse_reps") is not None, "sparse engine given but encode_corpus returned no sparse_reps"
+                self.sparse_search.index(enc["sparse_reps"], list(chunk_ids))
+        multi = _chunked_dense_search(self.dense_search, [qe[k] for k, _ in kinds], query_ids, corpus, top_k, ignore_identical_ids, on_chunk=on_chunk)
         for (_, name), res in zip(kinds, multi):
             results[name] = res
             default = res
+        if use_tok:
+            results["tok"] = default = self.sparse_search.retrieve_with_emb(query_emb=qe["token_id_reps"], query_ids=query_ids, top_k=top_k)
+            if "emb" in results:
+                results["emb_tok"] = default = self._fuse_results(results["emb"], results["tok"], weights=self.fuse_weights)
         self._clear()
         return results if self.return_all_results else default
 
@@ -342,9 +355,12 @@ def _to_result_dict(scores: torch.Tensor, ids: torch.Tensor, query_ids: list, re
     return out
 
 
-def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: list, corpus, top_k: int, ignore_identical_ids: bool):
+def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: list, corpus, top_k: int, ignore_identical_ids: bool,
+                          on_chunk=None):
     """Chunk loop of faiss_search.py:228-291 / hybrid_search.py:301-358: encode chunk -> index -> retrieve -> merge.
-    `query_embs` may be one tensor or a list of tensors (several query representations scored against the same docs)."""
+    `query_embs` may be one tensor or a list of tensors (several query representations scored against the same docs).
+    `on_chunk(corpus_ids_of_chunk, encode_corpus_result)`: called after each chunk is encoded (the sparse half of
+    HybridSearch.index, hybrid_search.py:330-331); single-process launch only."""
     single = not isinstance(query_embs, (list, tuple))
     qlist = [query_embs] if single else list(query_embs)
     corpus_ids, docs = _sorted_corpus(corpus)
@@ -360,13 +376,15 @@ def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: li
     rank, world = DenseRetrievalFaissSearch._rank_world()
     if world > 1:
         from .sharded import exchange_topk, local_to_global_rows
+        if on_chunk is not None:
+            raise NotImplementedError("a sparse engine needs the chunk's sparse vectors on the calling rank: single-process launch only")
     # the reference's own launch (eval/eval_utils.py: torch RPC, only rank 0 drives): shards live on the RPC workers
     rpc_names = []
     if world == 1:
         from . import rpc_shards
         rpc_names = rpc_shards.rpc_workers()
-        if len(rpc_names) <= 1 or "model" not in rpc_shards._WORKER:
-            rpc_names = []
+        if len(rpc_names) <= 1 or "model" not in rpc_shards._WORKER or on_chunk is not None:
+            rpc_names = []                            # (with a sparse engine the calling rank encodes everything itself)
     for s in range(0, n, searcher.corpus_chunk_size):
         e = min(s + searcher.corpus_chunk_size, n)
         logger.info("Encoding Batch %d/%d...", s // searcher.corpus_chunk_size + 1, -(-n // searcher.corpus_chunk_size))
@@ -378,7 +396,9 @@ def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: li
         elif rpc_names:
             rpc_shards.index_chunk(rpc_names, docs[s:e], s, dim, searcher.batch_size)   # texts out, nothing back
         else:
-            searcher._index_in_place(docs[s:e], list(range(s, e)), dim)   # rows carry their global sorted position
+            enc = searcher._index_in_place(docs[s:e], list(range(s, e)), dim)   # rows carry their global sorted position
+            if on_chunk is not None and enc is not None:
+                on_chunk(corpus_ids[s:e], enc)
         for j, q in enumerate(qlist):
             if rpc_names:                             # local top-k of every worker's shard (Q x k pairs each), merged here
                 D, I = merge_topk(*rpc_shards.search_shards(rpc_names, q, top_k, searcher.batch_size))

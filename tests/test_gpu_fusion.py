@@ -115,3 +115,63 @@ def test_hybrid_search_fuses_dense_and_sparse_hits(method):
     assert res["emb_tok"] == want
     hs._clear()
     assert hs.sparse_search.ids == []
+
+
+class _DictImpactEngine:
+    """Stand-in for the reference's AnseriniSearch (JVM/Lucene, out of scope): exact impact scores = sum_t count_q[t] * weight_d[t]
+    over the documents indexed so far; same interface (index / retrieve_with_emb / _clear)."""
+
+    def __init__(self):
+        self.docs = {}
+
+    def index(self, corpus_emb, corpus_ids):
+        assert len(corpus_emb) == len(corpus_ids)
+        self.docs.update(dict(zip(corpus_ids, corpus_emb)))
+
+    def retrieve_with_emb(self, query_emb, query_ids, top_k, **kw):
+        out = {}
+        for qid, qv in zip(query_ids, query_emb):
+            sc = {pid: float(sum(c * dv.get(t, 0) for t, c in qv.items())) for pid, dv in self.docs.items()}
+            top = sorted(((s, p) for p, s in sc.items() if s > 0), key=lambda x: (-x[0], x[1]))[:top_k]
+            out[qid] = {p: s for s, p in top}
+        return out
+
+    def _clear(self):
+        self.docs = {}
+
+
+def test_hybrid_search_feeds_a_sparse_engine_per_chunk_and_fuses_at_the_end():
+    """hybrid_search.py:301-403 with a sparse engine plugged in: every chunk's quantised document vectors are indexed as the chunk
+    is encoded, `tok` is one retrieval over the whole engine with the queries' token counts, `emb_tok` the fusion of the final `emb`
+    and `tok` lists (not of per-chunk lists)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_api import build_stack, synth_corpus
+    from helpers import load_model_golden
+    from lightretriever_amd.modeling import LrxExactSearchModel, LrxHybridModel
+    from lightretriever_amd.retriever import HybridSearch
+    from lightretriever_amd.score_fuse_utils import fuse_scores_linear
+    cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    tok, enc, hm, _ = build_stack(cfg_o, w)
+    hs = LrxHybridModel(enc, normalize=True, pad_token_id=tok.pad_token_id, encode_sparse=True, sparse_top_k_psg=24)
+    model = LrxExactSearchModel(model=hs, tokenizer=tok, q_max_len=32, p_max_len=64, eval_batch_size_embedding_bag=100)
+    model.query_prompt = "query: "
+    corpus = synth_corpus(np.random.default_rng(2), 60)
+    queries = {"q0": "capital of france paris", "q1": "dense retrieval with large language models", "q2": "amd instinct memory search"}
+    engine = _DictImpactEngine()
+    searcher = HybridSearch(model, batch_size=8, corpus_chunk_size=25, fuse_weights=[0.6, 0.4], return_all_results=True, sparse_search=engine)
+    res = searcher.search(corpus, queries, top_k=10)
+    assert set(res) == {"emb", "tok", "emb_tok"} and engine.docs == {}          # three chunks went in, cleared at the end
+    # the same three lists put together by hand
+    docs = list(corpus.values())
+    enc_all = model.encode_corpus(docs, batch_size=8)
+    ref_engine = _DictImpactEngine()
+    ref_engine.index(enc_all["sparse_reps"], list(corpus))
+    qe = model.encode_queries(list(queries.values()), batch_size=8)
+    tok_want = ref_engine.retrieve_with_emb(qe["token_id_reps"], list(queries), 10)
+    assert res["tok"] == tok_want and all(len(v) > 0 for v in tok_want.values())
+    emb_only = HybridSearch(model, batch_size=8, corpus_chunk_size=25, return_all_results=True).search(corpus, queries, top_k=10)["emb"]
+    assert res["emb"] == emb_only
+    assert res["emb_tok"] == fuse_scores_linear([emb_only, tok_want], weights=[0.6, 0.4])
+    assert HybridSearch(model, batch_size=8, corpus_chunk_size=25, fuse_weights=[0.6, 0.4], sparse_search=_DictImpactEngine()).search(
+        corpus, queries, top_k=10) == res["emb_tok"]                              # default result = the fused list
