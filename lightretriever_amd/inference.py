@@ -148,5 +148,8 @@ class PytorchRPCExactSearchModel(LrxExactSearchModel):
         from . import rpc_shards
         rpc_shards.register_worker(self)              # the model remote calls of a driving rank will use (MODEL_REGISTRY of the reference)
 
+    def empty_cache(self, rank=None):  # exact_search_torchrpc.py:330-335: here it only returns this process's cached allocator blocks
+        torch.cuda.empty_cache()
+
     def stop_multi_process_pool(self):  # API parity with the reference (exact_search_torchrpc.py:103-120); nothing to stop
         return None
