@@ -93,8 +93,8 @@ def _sorted_corpus(corpus):
                     name = c
             if name is None:
                 raise KeyError(f"No id column in corpus dataset {corpus.column_names}")
-            order = sorted(range(len(corpus)), key=lambda i: len(corpus[i]["text"]), reverse=True)
-            rows = [dict(corpus[i]) for i in order]
+            rows = corpus.to_list()                      # one sequential read (row-by-row / permuted access costs ~30-90 us per document)
+            rows.sort(key=lambda r: len(r["text"]), reverse=True)
             return [r[name] for r in rows], rows
     except ImportError:  # pragma: no cover
         pass
