@@ -337,7 +337,7 @@ def _as_items(texts) -> list[dict]:
     try:
         import datasets
         if isinstance(texts, datasets.Dataset):
-            return [dict(r) for r in texts]
+            return texts.to_list()
     except ImportError:  # pragma: no cover
         pass
     if isinstance(texts, list):
