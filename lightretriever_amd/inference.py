@@ -143,7 +143,7 @@ class PytorchRPCExactSearchModel(LrxExactSearchModel):
                             sparse_min_tokens_to_keep=args.sparse_min_tokens_to_keep)
         super().__init__(model=hm, tokenizer=tok, q_max_len=args.q_max_len, p_max_len=args.p_max_len,
                          append_prompt_sep=args.append_prompt_sep, eval_batch_size_embedding_bag=args.eval_batch_size_embedding_bag,
-                         token_id_vector_type=args.token_id_vector_type)
+                         token_id_vector_type=args.token_id_vector_type, noncontextual_prompt_prefix=args.noncontextual_prompt_prefix)
         self.encoding_kwargs["anserini_vector_type"] = args.anserini_vector_type      # exact_search_torchrpc.py:100-101
         from . import rpc_shards
         rpc_shards.register_worker(self)              # the model remote calls of a driving rank will use (MODEL_REGISTRY of the reference)

@@ -443,6 +443,7 @@ class LrxExactSearchModel:
     corpus_prompt: Optional[str] = None
     encoding_kwargs: dict = field(default_factory=dict)
     token_id_vector_type: str = "sum"          # 'sum' | 'bow' (finetune/arguments.py:203-211): the parameter-free sparse query
+    noncontextual_prompt_prefix: Optional[str] = None   # finetune/arguments.py: prepended to the query prompt inside the EmbeddingBag table
     max_batch_tokens: int = 131072             # encode(): consecutive batches are merged up to this many tokens (0 = off; 256 x 512)
     max_batch_docs: int = 2048                 # ... and this many documents (bounds the [docs, vocab] sparse activations)
 
@@ -466,10 +467,14 @@ class LrxExactSearchModel:
         return items
 
     def encode_queries(self, queries, batch_size: int, show_progress_bar: bool = True, convert_to_tensor: bool = True, **kwargs):
-        # the query prompt lives inside the EmbeddingBag table (exact_search_torchrpc.py:139-160): rebuild when it changes
-        if self.model.emb_bag is None or self.model.emb_bag_prompt != self.query_prompt:
-            self.model.construct_embedding_bag(self.tokenizer, prompt=self.query_prompt, batch_size=self.eval_batch_size_embedding_bag)
         items = _as_items(queries)
+        # the query prompt lives inside the EmbeddingBag table (exact_search_torchrpc.py:139-160): the model's query_prompt, else the
+        # `prompt` column of the first query, with noncontextual_prompt_prefix in front; rebuilt when it changes
+        prompt = self.query_prompt or (items[0].get("prompt") if items and isinstance(items[0], dict) else None)
+        if self.noncontextual_prompt_prefix:
+            prompt = self.noncontextual_prompt_prefix + prompt if prompt else self.noncontextual_prompt_prefix
+        if self.model.emb_bag is None or self.model.emb_bag_prompt != prompt:
+            self.model.construct_embedding_bag(self.tokenizer, prompt=prompt, batch_size=self.eval_batch_size_embedding_bag)
         coll = EncodeCollator(self.tokenizer, encode_is_query=True, q_max_len=self.q_max_len, p_max_len=self.p_max_len)
         outs = []
         for s in range(0, len(items), batch_size):

@@ -320,3 +320,24 @@ def test_cli_arguments_wire_the_sparse_branch_through_the_reference_entry_point(
     assert torch.equal(got["dense_reps"], want["dense_reps"]) and got["sparse_reps"] == want["sparse_reps"]
     q = model.encode_queries(["capital of france", "dense retrieval retrieval"], batch_size=8)
     assert set(q) == {"emb_reps", "token_id_reps"} and all(v == 1 for d in q["token_id_reps"] for v in d.values())   # 'bow'
+
+
+def test_embedding_bag_prompt_selection_follows_the_reference():
+    """exact_search_torchrpc.py:139-147: the table's prompt is model.query_prompt, else the `prompt` column of the first query, with
+    noncontextual_prompt_prefix in front; the table is rebuilt only when that string changes."""
+    cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    tok, enc, hm, model = build_stack(cfg_o, w)
+    model.query_prompt = "query: "
+    a = model.encode_queries(["capital of france", "dense retrieval"], batch_size=8)["emb_reps"].clone()
+    table = model.model.emb_bag
+    model.query_prompt = ""                                    # evaluate_mteb.py resets the prompts per task
+    b = model.encode_queries([{"text": "capital of france", "prompt": "query: "}, {"text": "dense retrieval", "prompt": "query: "}], batch_size=8)["emb_reps"]
+    assert model.model.emb_bag_prompt == "query: " and model.model.emb_bag is table and torch.equal(a, b)      # same string: no rebuild
+    c = model.encode_queries(["capital of france", "dense retrieval"], batch_size=8)["emb_reps"]              # no prompt anywhere
+    assert model.model.emb_bag_prompt is None and not torch.equal(a, c)
+    model.noncontextual_prompt_prefix = "Instruct: "
+    model.encode_queries(["capital of france"], batch_size=8)
+    assert model.model.emb_bag_prompt == "Instruct: "
+    model.query_prompt = "query: "
+    model.encode_queries(["capital of france"], batch_size=8)
+    assert model.model.emb_bag_prompt == "Instruct: query: "
