@@ -28,7 +28,7 @@ class FlatIPIndex:
         # bf16 shadow of the rows (round-to-nearest-even), maintained by commit(): the filter pass of the two-pass search streams
         # it instead of the fp32 rows (half the bytes; the exact rescoring still reads fp32).  +50 % index memory; False = no shadow.
         self.shadow_bf16 = True
-        self.max_workspace_bytes = 8 << 30   # search(): cap of the [queries, rows] score workspace; larger query batches are chunked
+        self.max_workspace_bytes = 12 << 30  # search(): cap of the [queries, rows] score workspace; larger query batches are chunked
         self._xb: Optional[torch.Tensor] = None
 
     # -- storage -------------------------------------------------------------------------------------------------
