@@ -341,6 +341,9 @@ def main():
         "pmc_mfma_busy_frac": pmc_mfma("k_gemm_bf16_nt<2>")[0], "pmc_effective_clock_ghz": pmc_mfma("k_gemm_bf16_nt<2>")[1],
         "all_gemms_tflops": round(gemm_all_fl / (gemm_all_ms * 1e-3) / 1e12, 2) if gemm_all_ms > 0 else None,
         "per_class_ms_per_step": {k_: round(v["ms"] / n_prof, 3) for k_, v in prof.items()},
+        # offline measurements that put `frac` in context (not re-measured here; DESIGN.md 5.4, profiles/r01_gemm_ablation.txt, r01_gemm_power.txt)
+        "context": {"package_power_w_during_gemm_loop": "1383-1390 of 1400 (cap)", "shader_clock_ghz_during_gemm_loop": 1.76,
+                    "mfma_only_loop_of_same_kernel_tflops": 1827, "vendor_gemm_same_shape_no_epilogue_tflops": 1471} if args.model == "llama3.2-1b" else None,
         "model_flops_per_doc": fl_doc,
         "end_to_end_tflops": round(docs_per_s / world * fl_doc / 1e12, 2),
     }
