@@ -493,6 +493,15 @@ class LrxExactSearchModel:
                out: Optional[torch.Tensor] = None, **kwargs):
         items = self.parse_texts(sentences, prompt=self.corpus_prompt)
         sparse = self.model.encode_sparse
+        # the reference's own launch (torch RPC, this rank drives, a model registered on every worker): a direct encode call fans the
+        # documents out in contiguous spans and assembles the rows in input order, as PytorchRPCExactSearchModel._encode does
+        # (exact_search_torchrpc.py:185-295).  Search keeps its shards on the workers instead (rpc_shards.index_chunk) and passes
+        # rpc_fanout=False for the pieces a worker encodes itself.
+        if kwargs.pop("rpc_fanout", True) and out is None and len(items) >= 2 * batch_size:
+            from . import rpc_shards
+            names = rpc_shards.rpc_workers()
+            if len(names) > 1 and rpc_shards._WORKER.get("model") is self:
+                return rpc_shards.encode_fanout(names, items, batch_size, convert_to_tensor, self.model.device)
         coll = EncodeCollator(self.tokenizer, encode_is_query=False, q_max_len=self.q_max_len, p_max_len=self.p_max_len, sparse_mask=sparse,
                               sep_token_id=self.model.sep_token_id, add_sep_token=self.model.add_sep_token)
         D = self.model.dense_shrink_dim or self.model.encoder.cfg.hidden_size

@@ -59,7 +59,7 @@ def _w_index(docs: list, rows: list, dim: int, batch_size: int, capacity: int, f
         idx, ids = _WORKER["pending"]
         if docs:
             slot = idx.append_slot(len(docs))
-            emb = model.encode_corpus(docs, batch_size=batch_size, show_progress_bar=False, convert_to_tensor=True, out=slot)
+            emb = model.encode_corpus(docs, batch_size=batch_size, show_progress_bar=False, convert_to_tensor=True, out=slot, rpc_fanout=False)
             emb = emb["dense_reps"] if isinstance(emb, dict) else emb
             if emb.data_ptr() != slot.data_ptr():
                 slot.copy_(emb.to(slot.device))
@@ -71,6 +71,14 @@ def _w_index(docs: list, rows: list, dim: int, batch_size: int, capacity: int, f
             _WORKER.pop("pending", None)
         torch.cuda.synchronize()
     return len(docs)
+
+
+def _w_encode(items: list, batch_size: int) -> dict:
+    """A contiguous span of a direct encode call, encoded on this worker; tensors travel back as CPU tensors (the caller asked for them)."""
+    model = _WORKER["model"]
+    with torch.cuda.device(model.model.device):
+        res = model.encode(items, batch_size=batch_size, show_progress_bar=False, convert_to_tensor=True, rpc_fanout=False)
+        return {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in res.items()}
 
 
 def _w_search(q_cpu: torch.Tensor, top_k: int, batch_size: int):
@@ -120,3 +128,23 @@ def clear_shards(workers: list, batch_size: int) -> None:
     from torch.distributed import rpc
     for f in [rpc.rpc_async(name, _w_clear, args=(batch_size,), timeout=0) for name in workers]:
         f.wait()
+
+
+def encode_fanout(workers: list, items: list, batch_size: int, convert_to_tensor: bool, device) -> dict:
+    """Direct `encode` / `encode_corpus` call on the driving rank: span r of the (already prompt-formatted) items -> worker r, rows
+    assembled in input order (row i of the output is input i)."""
+    from torch.distributed import rpc
+    n, R = len(items), len(workers)
+    per = -(-n // R)
+    per = -(-per // batch_size) * batch_size               # whole batches per worker
+    spans = [(s, min(s + per, n)) for s in range(0, n, per)]
+    futs = [rpc.rpc_async(workers[i], _w_encode, args=(items[s:e], batch_size), timeout=0) for i, (s, e) in enumerate(spans)]
+    parts = [f.wait() for f in futs]
+    out = {}
+    for k in parts[0]:
+        if isinstance(parts[0][k], torch.Tensor):
+            t = torch.cat([p[k] for p in parts], 0)
+            out[k] = t.to(device) if convert_to_tensor else t.numpy()
+        else:
+            out[k] = [x for p in parts for x in p[k]]
+    return out

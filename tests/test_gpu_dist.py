@@ -120,6 +120,12 @@ def _rpc_worker(rank, world, port, ret):
             res = searcher.search(corpus, queries, top_k=12, ignore_identical_ids=True)
             ret["rpc"] = {q: dict(v) for q, v in res.items()}
             ret["workers"] = rpc_shards.rpc_workers()
+            # a direct encode call (MTEB's non-retrieval tasks): spans go to the workers, rows come back in input order
+            model.corpus_prompt = "passage: "                      # set on the driving rank only, like evaluate_mteb.py does
+            docs = list(corpus.values())[:70]
+            enc_out = model.encode_corpus(docs, batch_size=16)
+            ret["enc"] = enc_out["dense_reps"].cpu().numpy()
+            ret["enc_np_type"] = type(model.encode_corpus(docs, batch_size=16, convert_to_tensor=False)["dense_reps"]).__name__
     finally:
         rpc.shutdown()
 
@@ -153,3 +159,6 @@ def test_search_driven_from_rank0_over_rpc_equals_single_process():
         assert set(got[q]) == set(want[q])
         for pid, sc in want[q].items():
             assert abs(got[q][pid] - sc) < 1e-6
+    model.corpus_prompt = "passage: "
+    local = model.encode_corpus(list(corpus.values())[:70], batch_size=16)["dense_reps"].cpu().numpy()
+    assert ret["enc"].shape == local.shape and np.array_equal(ret["enc"], local) and ret["enc_np_type"] == "ndarray"
