@@ -227,6 +227,9 @@ __global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, in
 #ifndef SPX_QSB
 #define SPX_QSB true
 #endif
+#ifndef SPX_AUX
+#define SPX_AUX 2   // cache-policy bits of the corpus-row requests (bit 0 sc0, bit 1 nt, bit 4 sc1): the rows are streamed once -> nt (Q = 1: 0.87 -> 0.79 ms, Q = 100: -1.3 %; sc0 / sc1 alone: no change)
+#endif
 // XB: X is the bf16 shadow of the corpus (half the bytes; k-slices of 64 in natural order, fragments read straight from LDS).
 // QSB: the q k-slice is single-buffered (re-requested after a second barrier per iteration; it comes from L2) so that only the X
 // slices are double-buffered: 48 KiB of LDS per 128-row workgroup -> three workgroups per CU, i.e. 1.5x the HBM bytes in flight of the
@@ -267,7 +270,7 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
     char* sX = smem + st * (QSB ? XT : STAGE);
 #pragma unroll
     for (int i = 0; i < 2 * RT; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + (int64_t)kt * 128), (lptr_t)(sX + (wave * 2 * RT + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + (int64_t)kt * 128), (lptr_t)(sX + (wave * 2 * RT + i) * 1024), 16, 0, SPX_AUX);
   };
   auto stage_q = [&](int st, int kt) {
     char* sQ = QSB ? smem + 2 * XT : smem + st * STAGE + XT;
@@ -727,6 +730,8 @@ k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, in
 // fp32 products, one final rounding to fp32 -- the value every search path reports, so scores do not depend on the path, the query
 // batch size or the shard layout.  Up to 16 row segments of 512 B are requested before the first is consumed (a row of 2048 floats
 // is a single round trip; rescoring is latency-bound gather work).
+// candidate rows are gathered once (random 8-KiB rows): non-temporal loads, k_refine_topk 119 -> 94 us at Q = 100 over 1M x 2048
+#define REF_ROW_LOAD(p) __builtin_nontemporal_load(p)
 __device__ __forceinline__ float exact_dot(const float* __restrict__ x, const float* __restrict__ qrow, int D, int lane) {
   const int sub = lane & 31;
   double acc = 0.0;
@@ -735,7 +740,7 @@ __device__ __forceinline__ float exact_dot(const float* __restrict__ x, const fl
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int i = i0 + u * 128;
-      xv[u] = i < D ? *(const f32x4*)(x + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xv[u] = i < D ? REF_ROW_LOAD((const f32x4*)(x + i)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
