@@ -859,7 +859,9 @@ extern "C" int lrx_debug_read_search_trace(void* dst, size_t bytes) {
 #define S_TRACE(slot)
 #endif
 
+#ifndef REF_SPLIT
 #define REF_SPLIT 4                       // workgroups per query (phase stamps: the exact rescoring is bound by what ONE CU can fetch)
+#endif
 #define REF_PCAND (REF_CAND / REF_SPLIT)  // candidate capacity of one part
 #define REF_PBLK (REF_BLK / REF_SPLIT)
 #define REF_QLDS 8192                     // query rows up to this many floats are staged in LDS by k_refine_topk
