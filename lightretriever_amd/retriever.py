@@ -8,6 +8,10 @@ Design differences, results preserved: corpus embeddings are encoded straight in
 `index.add` copy); the per-chunk (score, pid) heaps of hybrid_search.py:182-205 are a running [Q, top_k] list kept on the
 GPU and merged with lrx_merge_topk, so Python touches O(Q*k) values once at the end instead of once per corpus chunk.
 `ignore_identical_ids` keeps the reference's order of operations (per-chunk top_k first, then the qid == pid hit is dropped).
+Equal scores: inside one chunk (one index) the lower row wins (this build's IndexFlatIP contract); ACROSS
+chunks the reference's heap compares (score, pid) tuples, so at equal scores the LARGER pid survives -- the running list is
+therefore merged on keys that order the documents by descending pid.  Pinned by tests/golden/search_ref.json (outputs of the
+reference's own HybridSearch.search / FlatIPFaissSearch.search).
 """
 from __future__ import annotations
 
@@ -373,6 +377,18 @@ def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: li
     ident = torch.tensor([row_of.get(q, -2) for q in query_ids], dtype=torch.int64, device=device) if ignore_identical_ids else None
     run_D = [torch.full((Q, top_k), -FLT_MAX, dtype=torch.float32, device=device) for _ in qlist]
     run_I = [torch.full((Q, top_k), -1, dtype=torch.int64, device=device) for _ in qlist]
+    # cross-chunk ties (hybrid_search.py:182-205: heapq on (score, pid) tuples keeps the larger pid): the running list carries
+    # key = position of the document in DESCENDING pid order, so the merge's (score desc, key asc) is the heap's order
+    key_of_row = row_of_key = None
+    if n > searcher.corpus_chunk_size:
+        try:
+            order = sorted(range(n), key=corpus_ids.__getitem__, reverse=True)
+        except TypeError:                             # ids of mixed types do not compare (the reference's heap would raise on a tie)
+            order = None
+        if order is not None:
+            row_of_key = torch.tensor(order, dtype=torch.int64, device=device)
+            key_of_row = torch.empty_like(row_of_key)
+            key_of_row[row_of_key] = torch.arange(n, dtype=torch.int64, device=device)
     rank, world = DenseRetrievalFaissSearch._rank_world()
     if world > 1:
         from .sharded import exchange_topk, local_to_global_rows
@@ -411,10 +427,14 @@ def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: li
                 hit = I == ident[:, None]
                 D = torch.where(hit, torch.full_like(D, -FLT_MAX), D)
                 I = torch.where(hit, torch.full_like(I, -1), I)
+            if key_of_row is not None:
+                I = torch.where(I >= 0, key_of_row[I.clamp(min=0)], I)
             run_D[j], run_I[j] = merge_topk(torch.stack([run_D[j], D]), torch.stack([run_I[j], I]))
         if rpc_names:
             rpc_shards.clear_shards(rpc_names, searcher.batch_size)
         searcher._clear()
+    if row_of_key is not None:
+        run_I = [torch.where(i >= 0, row_of_key[i.clamp(min=0)], i) for i in run_I]
     rev = {i: c for i, c in enumerate(corpus_ids)}
     outs = [_to_result_dict(d, i, query_ids, rev) for d, i in zip(run_D, run_I)]
     return outs[0] if single else outs

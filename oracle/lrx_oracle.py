@@ -15,11 +15,21 @@ Parity pin status
   see ``tests/golden/gen_goldens.py``.
 * Flat inner-product search (Faiss ``IndexFlatIP``): **parity unpinned** against Faiss
   itself -- ``faiss`` (pyproject.toml:6, ``faiss>=1.7.4``) is neither vendored in the
-  reference nor installed here, and the reference has no tests.  The restatement follows
+  reference nor installed here, and the reference has no tests.  ``flat_ip_topk`` follows
   the published semantics (exact fp32 inner product, descending top-k, ids = insertion
-  order, ``-1`` ids / ``-inf``... padding when k > ntotal) and the reference's own call
-  sites (retriever/faiss_index.py:27-58, retriever/faiss_search.py:143-173); it is pinned
-  only against ``torch.matmul`` + ``torch.topk`` goldens.
+  order, ``-FLT_MAX`` / ``-1`` padding when k > ntotal = ``CMin<float>::neutral()``); the
+  order of equal scores (lower row first) is THIS BUILD'S contract, not Faiss behaviour
+  (Faiss leaves it unspecified; its strict heap comparison keeps the earlier row at the
+  k-th place, which the rule agrees with).  It is pinned only against ``torch.matmul`` +
+  ``torch.topk`` goldens (``tests/golden/search.npz``).
+* Everything the reference's OWN code does with the index's answers -- ``FaissIndex.build /
+  search`` id mapping (retriever/faiss_index.py:27-58), ``retrieve_with_emb``
+  (retriever/faiss_search.py:143-173), the corpus sort + chunk loop + ``_add_to_heap`` /
+  ``_parse_heap_results`` merge with its (score, pid) tuple order and ``ignore_identical_ids``
+  (retriever/hybrid_search.py:182-205, :234-403; retriever/faiss_search.py:176-291): PINNED by
+  ``tests/golden/search_ref.json``, produced by running those reference functions
+  (``tests/golden/gen_search_goldens.py``; a numpy stand-in supplies the ``faiss`` module
+  they import, which is why Faiss itself stays unpinned).
 
 * Sparse document vectors (row N2: prompt/first/last mask, LM-head max aggregation, relu/log1p, top-k / top-p, quantised
   JSON): PINNED by ``tests/golden/sparse.npz`` / ``sparse_json.json`` (``tests/golden/gen_sparse_goldens.py``, the real
@@ -457,30 +467,61 @@ def sort_corpus_ids_longest_first(corpus: dict) -> list[str]:
 
 
 def add_to_heap(sub_results: dict, heaps: dict, top_k: int, ignore_identical_ids: bool):
-    """hybrid_search.py:182-205: per-query min-heap of (score, pid) capped at top_k."""
+    """hybrid_search.py:182-205: per-query min-heap of (score, pid) capped at top_k.  The heap keeps the top_k LARGEST
+    tuples pushed so far under Python's tuple order, i.e. (score, then pid) -- at equal scores the larger pid survives."""
     for qid, pid_to_score in sub_results.items():
         for pid, score in pid_to_score.items():
             if ignore_identical_ids and qid == pid:
                 continue
+            if qid not in heaps:
+                heaps[qid] = []
             if len(heaps[qid]) < top_k:
                 heapq.heappush(heaps[qid], (score, pid))
             else:
                 heapq.heappushpop(heaps[qid], (score, pid))
 
 
+def faiss_index_search(q: np.ndarray, X: np.ndarray, k: int, passage_ids: Optional[np.ndarray] = None,
+                       reference_padding: bool = False) -> tuple[np.ndarray, np.ndarray]:
+    """FaissIndex.search (retriever/faiss_index.py:27-40): index.search, then rows -> `_passage_ids[rows]`.
+    reference_padding=True restates the reference literally: the numpy lookup turns the -1 padding id of a k > ntotal
+    search into `_passage_ids[-1]`, the LAST passage.  False (the product's contract): padding stays -1."""
+    D, I = flat_ip_topk(q, X, k)
+    if passage_ids is not None:
+        pid = np.asarray(passage_ids, dtype=np.int64)
+        if reference_padding:
+            I = pid[I.reshape(-1)].reshape(I.shape) if len(pid) else I
+        else:
+            I = np.where(I >= 0, pid[np.clip(I, 0, None)], -1) if len(pid) else I
+    return D, I
+
+
+def retrieve_with_emb(q: np.ndarray, query_ids: list, X: np.ndarray, corpus_ids: list, top_k: int,
+                      reference_padding: bool = False) -> dict:
+    """FlatIPFaissSearch.index + retrieve_with_emb (retriever/faiss_search.py:490-504, :143-173): rows -> ids through
+    `rev_mapping`, `float(score)`, `dict(zip(doc_ids, scores))` per query.  With reference_padding the padding entries of a
+    short index arrive as the last document with score -FLT_MAX and, being later in the zip, overwrite its real score."""
+    D, I = faiss_index_search(q, X, top_k, passage_ids=np.arange(len(corpus_ids)), reference_padding=reference_padding)
+    out = {}
+    for qi, qid in enumerate(query_ids):
+        pairs = [(corpus_ids[int(r)], float(sc)) for sc, r in zip(D[qi], I[qi]) if reference_padding or r >= 0]
+        out[qid] = dict(pairs)
+    return out
+
+
 def search_chunks(query_emb: np.ndarray, query_ids: list[str], corpus_emb: np.ndarray, corpus_ids: list[str],
-                  top_k: int, corpus_chunk_size: int, ignore_identical_ids: bool = False) -> dict[str, dict[str, float]]:
+                  top_k: int, corpus_chunk_size: int, ignore_identical_ids: bool = False,
+                  reference_padding: bool = False) -> dict[str, dict[str, float]]:
     """Dense part of HybridSearch.search / DenseRetrievalFaissSearch.search given already-encoded, already
-    length-sorted embeddings: per chunk index -> retrieve_with_emb -> heap merge -> {qid: {pid: score}}."""
+    length-sorted embeddings: per chunk index -> retrieve_with_emb -> heap merge -> {qid: {pid: score}}
+    (hybrid_search.py:301-358, faiss_search.py:228-291).  reference_padding: see retrieve_with_emb (a chunk shorter than
+    top_k makes the reference lose that chunk's last document; the product does not reproduce that)."""
     heaps = {qid: [] for qid in query_ids}
     for s in range(0, len(corpus_ids), corpus_chunk_size):
         e = min(s + corpus_chunk_size, len(corpus_ids))
-        D, I = flat_ip_topk(query_emb, corpus_emb[s:e], top_k)
-        sub = {}
-        for qi, qid in enumerate(query_ids):
-            sub[qid] = {corpus_ids[s + int(r)]: float(sc) for sc, r in zip(D[qi], I[qi]) if r >= 0}
+        sub = retrieve_with_emb(query_emb, query_ids, corpus_emb[s:e], corpus_ids[s:e], top_k, reference_padding)
         add_to_heap(sub, heaps, top_k, ignore_identical_ids)
-    return {qid: {pid: score for score, pid in heaps[qid]} for qid in query_ids}
+    return {qid: {pid: score for score, pid in heaps[qid]} for qid in query_ids}     # _parse_heap_results, hybrid_search.py:347-355
 
 
 # --------------------------------------------------------------------------------------

@@ -38,3 +38,15 @@ def min_cos(a, b):
     a = a / np.linalg.norm(a, axis=-1, keepdims=True)
     b = b / np.linalg.norm(b, axis=-1, keepdims=True)
     return float((a * b).sum(-1).min())
+
+
+def load_search_ref():
+    """tests/golden/search_ref.json (outputs of the reference's own searchers, gen_search_goldens.py) with arrays decoded."""
+    import base64
+    import json
+    fx = json.load(open(os.path.join(GOLDEN, "search_ref.json")))
+    for st in fx["sets"].values():
+        for k in ("X", "emb_reps", "dense_reps"):
+            a = st[k]
+            st[k] = np.frombuffer(base64.b64decode(a["b64"]), dtype=a["dtype"]).reshape(a["shape"]).copy()
+    return fx
