@@ -239,7 +239,6 @@ def main():
         offs = torch.cumsum(lens, 0) - lens
         q_ids = torch.randint(1000, 127000, (int(lens.sum().item()),), generator=gq, device=dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
-        index.refresh_norm_bound()                            # the encode leg wrote its rows straight into committed slots
         q = ops.embedding_bag_mean(table, q_ids, offs.to(torch.int64), normalize=True)
         for _ in range(max(1, args.warmup)):
             sharded.search(q, args.topk)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define LRX_ABI_VERSION 2
+#define LRX_ABI_VERSION 3
 
 enum {
   LRX_OK = 0,
@@ -94,6 +94,14 @@ int lrx_encode_packed(const lrx_encoder_config* cfg, const lrx_encoder_weights* 
                       const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen,
                       float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* The same with `out` = rows of an index shard: the last kernel also writes the rows' bf16 shadow (shadow_out, row stride in
+ * elements; NULL = none) and raises the shard's bounds (row_bounds, see lrx_shard_commit_rows; NULL = none), so the index needs
+ * no second pass over what the encoder just wrote (FaissIndex.build's add, retriever/faiss_index.py:45-58).                     */
+int lrx_encode_packed_shard(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids,
+                            const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen,
+                            float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* shadow_out,
+                            int64_t shadow_row_stride, float* row_bounds, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 /* Same forward, but returns the un-pooled final hidden states (after the final RMSNorm), bf16 [total_tokens, H]:
  * the `last_hidden_state` of lm(...) at finetune/modeling_hybrid.py:260.  Used by EmbeddingBag construction
@@ -243,6 +251,11 @@ int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_s
 int lrx_pool_norm(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                   int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim,
                   int32_t normalize, void* stream);
+/* ... and the shard maintenance fused into it: shadow_out (bf16 rows, RNE copy of what goes to `out`; may be NULL) and row_bounds
+ * (see lrx_shard_commit_rows; may be NULL).                                                                                     */
+int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
+                        int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim,
+                        int32_t normalize, void* shadow_out, int64_t shadow_row_stride, float* row_bounds, void* stream);
 
 /* Query side.  Replaces emb_bag.forward + slice + F.normalize at finetune/modeling_hybrid.py:472-490
  * (torch.nn.EmbeddingBag mode='mean', padding_idx) with inputs from tokenize_nonctx_qry_emb_bag
@@ -264,19 +277,36 @@ int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim,
                        int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids, void* workspace,
                        size_t workspace_bytes, void* stream);
 
-/* Same result as lrx_flat_ip_search (exact top-k, ids ascending among equal scores) for shards whose rows satisfy
- * |x_row| <= *row_norm_bound (DEVICE pointer to one float, e.g. 1 for L2-normalised embeddings), at close to one HBM pass for
- * 32 < Q: a single-product bf16 filter pass bounds every score to +-0.0045 |q| R, the rows inside that band of the k-th filter
- * score are rescored exactly from the fp32 rows (fp64 accumulation, one rounding) and sorted.  Queries whose band overflows the
- * on-chip candidate list are redone by the six-product path (gated on a device flag, no host sync).  Scores returned are the
- * exactly rescored ones.  A bound smaller than the true row norms voids the guarantee.
+/* Same result as lrx_flat_ip_search (exact top-k, ids ascending among equal scores) at close to ONE pass over a bf16 copy of the
+ * shard and without a [queries, rows] score matrix, for shards whose rows satisfy the two bounds in row_bounds (DEVICE pointer to
+ * two floats): row_bounds[0] >= max |x_row| and row_bounds[1] >= max |x_row - bf16(x_row)| (<= 0: unknown, 2^-8 * row_bounds[0] is
+ * used).  lrx_shard_commit_rows / lrx_encode_packed_shard maintain both.  A single-product bf16 filter pass bounds every score to
+ * +- eps(q) = |q - bf16(q)| R + |bf16(q)| E + (D+32) 2^-23 |bf16(q)| R; a strided sample of the shard (every ss-th 128-row block,
+ * scored first) gives a lower bound T' of the k-th largest filter score; the pass over the rest keeps only rows with filter score
+ * >= T' - 2 eps (a per-query candidate list, ~1e-3 of the rows); the rows within 2 eps of the list's k-th score are rescored
+ * exactly from the fp32 rows (fp64 accumulation, one rounding) and sorted.  Queries whose list or band overflows (near-duplicate
+ * corpora) are redone by the six-product path (gated on a device flag, no host sync).  Scores returned are the exactly rescored
+ * ones.  Bounds smaller than the true values void the guarantee.  Small query batches (4 Q < D / 16) and shards below 16 Ki rows
+ * use a score-matrix filter instead (one launch less on the critical path); the result is the same bit for bit.
  * X_bf16 (optional, NULL = convert on the fly): a bf16 copy of X (round-to-nearest-even per element, row stride ldx_bf16
  * elements, multiple of 8; dim % 64 == 0) kept by the caller next to the fp32 rows: the filter pass then streams 2 instead of 4
- * bytes per element (+50 % index memory, ~1.8x queries/s); the error bound and therefore the result are unchanged.          */
+ * bytes per element (+50 % index memory, ~1.8x queries/s); the error bound and therefore the result are unchanged.
+ * Queries are processed in chunks of 256 (128 without X_bf16) over the same workspace, whose size therefore stops growing at
+ * 256 queries: min(Q,128) * rows * 4 bytes for the gated fallback plus Q * 128 KiB of candidate lists.                            */
 size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k);
 int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_bf16, int64_t ldx_bf16,
-                               const float* row_norm_bound, const float* q, int32_t n_queries, int32_t k, int64_t id_base,
+                               const float* row_bounds, const float* q, int32_t n_queries, int32_t k, int64_t id_base,
                                float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream);
+/* Diagnostics / tests: 0 = choose the filter per query chunk (default), 1 = always the score-matrix filter, 2 = the score-free
+ * (candidate-list) filter whenever the shard is large enough for a sample.  Process-global; results do not depend on it.        */
+void lrx_search_set_mode(int32_t mode);
+
+/* Shard maintenance (FaissIndex.build / IndexFlatIP.add, retriever/faiss_index.py:45-58, for rows that were not written by
+ * lrx_encode_packed_shard): one read of n_rows fp32 rows writes their bf16 shadow (RNE; X_bf16 may be NULL) and raises
+ * row_bounds[0] = max |row|, row_bounds[1] = max |row - bf16(row)| (device, two floats, zero-initialised by the caller when the
+ * shard is created; integer atomic max, order-independent).  dim % 4 == 0.                                                      */
+int lrx_shard_commit_rows(const float* X, int64_t ldx, int64_t n_rows, int32_t dim, void* X_bf16, int64_t ldx_bf16,
+                          float* row_bounds, void* stream);
 
 /* Score pass only: scores[Q, ld] fp32 with ld = lrx_flat_ip_score_ld(N); columns >= N hold -FLT_MAX. */
 int64_t lrx_flat_ip_score_ld(int64_t n_rows);

@@ -6,6 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRX_LIB_DEV_VARIANT") or os.path.join(HERE, "liblrx.so")   # env override: tools/ diagnostics only
 LRX_PROF_CLASSES = 8
+ABI_VERSION = 3   # LRX_ABI_VERSION of include/lrx.h
 PROF_CLASS_NAMES = ["gemm_store", "gemm_resid", "gemm_swiglu", "attention", "rmsnorm", "rope", "other", "gemm_maxagg"]
 
 
@@ -37,6 +38,8 @@ SIGNATURES = {
     "lrx_last_error": (C.c_char_p, []),
     "lrx_encode_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I32, _I32]),
     "lrx_encode_packed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),
+    "lrx_encode_packed_shard": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _I64, _P,
+                                       _P, _SZ, _P]),
     "lrx_encode_hidden": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "lrx_encode_prefixed_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I32, _I32, _I32]),
     "lrx_encode_prefixed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _I32, _P, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),
@@ -51,6 +54,9 @@ SIGNATURES = {
     "lrx_hit_union": (_I32, [_P, _P, _I32, _I32, _I64, _P, _P, _P, _P]),
     "lrx_flat_ip_bounded_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "lrx_flat_ip_search_bounded": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _P, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _P]),
+    "lrx_search_set_mode": (None, [_I32]),
+    "lrx_shard_commit_rows": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _P, _P]),
+    "lrx_pool_norm_shard": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P, _I64, _P, _P]),
     "lrx_gemm_bf16_nt_fused": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "lrx_gemm_qkv_rope_fused": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "lrx_row_rscale": (_I32, [_P, _I32, _I32, C.c_float, _P, _P]),
@@ -91,7 +97,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.lrx_abi_version() != 2:
+        if l.lrx_abi_version() != ABI_VERSION:
             raise LrxError("liblrx.so ABI version mismatch")
         _lib = l
     return _lib

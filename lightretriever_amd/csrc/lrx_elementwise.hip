@@ -210,9 +210,13 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// shadow != NULL: the row also goes out as bf16 (RNE) -- the filter pass of the search streams that copy; bounds != NULL: the two
+// shard bounds {max |row|, max |row - bf16(row)|} are raised by integer atomic max on the (non-negative) float patterns: the result
+// does not depend on the order rows arrive in.  This is the index maintenance of FlatIPIndex.commit fused into the row's producer.
 __global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hidden, const __bf16* __restrict__ w,
                                                    const int32_t* __restrict__ cu, int H, float eps, float* __restrict__ out,
-                                                   int64_t out_stride, int out_dim, int normalize) {
+                                                   int64_t out_stride, int out_dim, int normalize, __bf16* __restrict__ shadow,
+                                                   int64_t shadow_stride, float* __restrict__ bounds) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* row = (float*)smem_raw;  // H floats
   float* red = row + H;           // 4 floats
@@ -232,19 +236,45 @@ __global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hi
   n2 = block_sum_256(n2, red);
   float scale = normalize ? 1.0f / fmaxf(sqrtf(n2), 1e-12f) : 1.0f;
   float* o = out + (int64_t)b * out_stride;
-  for (int i = threadIdx.x; i < out_dim; i += 256) o[i] = normalize ? row[i] * scale : row[i];
+  __bf16* ob = shadow ? shadow + (int64_t)b * shadow_stride : nullptr;
+  float r2 = 0.f, e2 = 0.f;
+  for (int i = threadIdx.x; i < out_dim; i += 256) {
+    const float v = normalize ? row[i] * scale : row[i];
+    o[i] = v;
+    const __bf16 h = f2bf(v);
+    if (ob) ob[i] = h;
+    const float d = v - bf2f(h);
+    r2 += v * v;
+    e2 += d * d;
+  }
+  if (bounds != nullptr) {
+    r2 = block_sum_256(r2, red);
+    e2 = block_sum_256(e2, red);
+    if (threadIdx.x == 0) {
+      atomicMax((int*)bounds, __float_as_int(sqrtf(r2) * (1.0f + 1e-6f)));
+      atomicMax((int*)bounds + 1, __float_as_int(sqrtf(e2) * (1.0f + 1e-6f)));
+    }
+  }
+}
+
+extern "C" int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
+                                   int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize,
+                                   void* shadow_out, int64_t shadow_row_stride, float* row_bounds, void* stream) {
+  LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden_size, "pool_norm: out_dim=%d out of range (H=%d)", out_dim, hidden_size);
+  LRX_CHECK_ARG(shadow_out == nullptr || shadow_row_stride >= out_dim, "pool_norm: shadow row stride %lld < out_dim", (long long)shadow_row_stride);
+  if (n_seqs == 0) return LRX_OK;
+  size_t smem = (size_t)(hidden_size + 4) * sizeof(float);
+  hipLaunchKernelGGL(k_pool_norm, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, (const __bf16*)hidden, (const __bf16*)final_norm_w,
+                     cu_seqlens, hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row_stride, row_bounds);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
 }
 
 extern "C" int lrx_pool_norm(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                              int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize,
                              void* stream) {
-  LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden_size, "pool_norm: out_dim=%d out of range (H=%d)", out_dim, hidden_size);
-  if (n_seqs == 0) return LRX_OK;
-  size_t smem = (size_t)(hidden_size + 4) * sizeof(float);
-  hipLaunchKernelGGL(k_pool_norm, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, (const __bf16*)hidden, (const __bf16*)final_norm_w,
-                     cu_seqlens, hidden_size, eps, out, out_row_stride, out_dim, normalize);
-  LRX_LAUNCH_CHECK();
-  return LRX_OK;
+  return lrx_pool_norm_shard(hidden, final_norm_w, cu_seqlens, n_seqs, hidden_size, eps, out, out_row_stride, out_dim, normalize, nullptr, 0,
+                             nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

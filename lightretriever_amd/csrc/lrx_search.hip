@@ -28,6 +28,21 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define S_BK 32          // floats per k-slice (128 B per row)
 #define S_XTILE (S_ROWS * S_BK * 4)
 #define SP_ROWS 128      // corpus rows per workgroup of the split-bf16 kernel
+#define CAND_CAP 16384   // per-query capacity of the filter pass's emitted candidate list (score-free filter)
+
+__device__ __forceinline__ uint32_t f2key(float f) {  // monotone: larger float -> larger key
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(u);
+}
+// (score key, row) packed so that an unsigned sort is (score desc, row asc); rows < 2^32 per shard
+__device__ __forceinline__ unsigned long long sel_pack(uint32_t key, int64_t i) {
+  return ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+}
+__device__ __forceinline__ int64_t sel_row(unsigned long long c) { return (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull)); }
 
 template <int QT>
 __global__ void __launch_bounds__(256, 1)
@@ -234,11 +249,17 @@ __global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, in
 // QSB: the q k-slice is single-buffered (re-requested after a second barrier per iteration; it comes from L2) so that only the X
 // slices are double-buffered: 48 KiB of LDS per 128-row workgroup -> three workgroups per CU, i.e. 1.5x the HBM bytes in flight of the
 // two-per-CU layout (the shadow filter pass is bound by bytes in flight x latency, not by the matrix pipe or the LDS).
-template <int QT, int NP, int RT, int NST, int WV, bool XB = false, bool QSB = false>
+// EMIT (score-free filter): nothing is stored per (query, row); a lane appends (score key, row) to the query's candidate list only when
+// the filter score reaches thr[query] (= a guaranteed lower bound of the k-th largest filter score minus the error band), i.e. for
+// ~1e-3 of the scores.  bmode selects the 16*RT*WV-row blocks a launch covers: 0 = all, 1 = the sample (every ss-th block, results
+// stored compactly at block index blockIdx.x), 2 = all blocks that are not in the sample.
+template <int QT, int NP, int RT, int NST, int WV, bool XB = false, bool QSB = false, bool EMIT = false>
 __global__ void __launch_bounds__(64 * WV, QSB ? (QT > 8 ? 2 : 3) : ((NST * (16 * RT * WV * 128 + (((XB ? 2 : NP) * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1))
 k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
-                       float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate) {
+                       float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate,
+                       int bmode, int ss, const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt) {
   static_assert(!XB || NP == 1, "the bf16 shadow is a single-product filter");
+  static_assert(!EMIT || NP == 1, "the emitting epilogue belongs to the single-product filter");
   const float* X = (const float*)Xv;
   const __bf16* Xb = (const __bf16*)Xv;
   constexpr int RB = 16 * RT * WV;               // corpus rows per workgroup (WV waves x RT 16-row tiles)
@@ -255,7 +276,11 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
   if (gate != nullptr && *gate == 0) return;     // fallback launch of the bounded search: nothing overflowed
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t n0 = (int64_t)blockIdx.x * RB;
+  int64_t blk = blockIdx.x;
+  if (bmode == 1) blk = (int64_t)blockIdx.x * ss;
+  else if (bmode == 2) { const int g = blockIdx.x / (ss - 1); blk = (int64_t)g * ss + 1 + (blockIdx.x - g * (ss - 1)); }
+  const int64_t n0 = blk * RB;                     // corpus rows of this workgroup
+  const int64_t n0s = (int64_t)blockIdx.x * RB;    // where its scores go (compact in sample mode)
 
   const char* px[2 * RT];                        // byte pointers: both element types move 128 B per row per k-slice
 #pragma unroll
@@ -382,6 +407,31 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
       }
     }
   }
+  if constexpr (EMIT) {
+    // D[i = corpus row][j = query]: lane holds query j = fi, rows fq*4 + {0..3}
+#pragma unroll
+    for (int b = 0; b < QT; ++b) {
+      const int qi = b * 16 + fi;
+      const float t = qi < nq ? thr[qi] : FLT_MAX;
+#pragma unroll
+      for (int a = 0; a < RT; ++a) {
+        const int64_t n = n0 + wave * 16 * RT + a * 16 + fq * 4;
+        unsigned int c = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c += (n + e < N && acc[a][b][e] >= t) ? 1u : 0u;
+        if (c && qi < nq) {
+          unsigned int p = atomicAdd(&cnt[qi], c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < N && acc[a][b][e] >= t) {
+              if (p < CAND_CAP) cand[(int64_t)qi * CAND_CAP + p] = sel_pack(f2key(acc[a][b][e]), n + e);
+              ++p;
+            }
+        }
+      }
+    }
+    return;
+  }
   __syncthreads();   // the k loop's last LDS reads are done before the epilogue reuses the buffer
 
   // D[i = corpus row][j = query]: lane holds query j = fi, rows fq*4 + {0..3}.  First the per-(query, 128-row block) maximum,
@@ -441,7 +491,7 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
       const int ql = idx / (RB / 4), c = idx % (RB / 4);
       const int qi = ps * QPT * 16 + ql;
       if (qi < nq)
-        *(f32x4*)(scores + (int64_t)qi * ld + n0 + c * 4) = *(const f32x4*)(smem + ql * SEG + c * 16);
+        *(f32x4*)(scores + (int64_t)qi * ld + n0s + c * 4) = *(const f32x4*)(smem + ql * SEG + c * 16);
     }
   }
 }
@@ -452,58 +502,94 @@ extern "C" int64_t lrx_flat_ip_score_ld(int64_t n_rows) { return lrx_cdiv(n_rows
 #define SPLIT_MIN_QT 3   // Q > 32 -> split-bf16 kernel (fp32-MFMA-bound otherwise); Q <= 32 stays on the exact-fp32 kernel (HBM-bound)
 static size_t split_ws_bytes(int32_t dim) { return (size_t)(dim / 32) * 3 * 8 * 1024; }   // one chunk of <=128 queries
 
-// planes = 3: fp32-grade scores (six bf16 products); planes = 1: one bf16 product, |error| <= FILTER_EPS * |q| * |x| (filter pass
-// of the bounded search); gate != NULL: the whole pass is skipped unless *gate != 0.
+// Which corpus blocks a filter launch covers and what it does with the scores (see k_flat_ip_scores_split)
+struct FilterMode {
+  int bmode = 0;                          // 0 all blocks, 1 sample blocks (compact stores), 2 non-sample blocks
+  int ss = 1;                             // sample stride in blocks
+  int64_t nblocks = -1;                   // workgroups to launch (-1: ld / rows-per-workgroup)
+  const float* thr = nullptr;             // emit mode: per-query threshold
+  unsigned long long* cand = nullptr;     // emit mode: candidate lists [Q, CAND_CAP]
+  unsigned int* cnt = nullptr;            //            and their fill counts
+};
+
+// planes = 3: fp32-grade scores (six bf16 products); planes = 1: one bf16 product (filter pass of the bounded search, error bound
+// query_eps_block); gate != NULL: the whole pass is skipped unless *gate != 0.  One call covers at most one query chunk (128 queries, 256
+// for the shadow filter); `ld` is the row stride of `scores` / rounded row count.
+static int filter_rows_per_wg(bool shadow) { return shadow ? 16 * SPX_RT * SPX_WV : 16 * SPF_RT * SPF_WV; }
+
 static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, float* scores,
                          float* blkmax, __bf16* qsplit, void* stream, int planes = 3, const int* gate = nullptr, const void* Xb = nullptr,
-                         int64_t ldxb = 0) {
+                         int64_t ldxb = 0, int64_t ld = 0, const FilterMode& fm = FilterMode()) {
   LRX_CHECK_ARG(dim > 0 && dim % S_BK == 0, "flat_ip: dim=%d must be a multiple of %d", dim, S_BK);
   LRX_CHECK_ARG(ldx >= dim && ldx % 4 == 0, "flat_ip: ldx=%lld must be >= dim and a multiple of 4", (long long)ldx);
   if (n_rows <= 0 || n_queries <= 0) return LRX_OK;
-  const int64_t ld = lrx_flat_ip_score_ld(n_rows);
-  const int nblk = (int)(ld / S_ROWS), nblk_ld = (int)((ld / SP_ROWS + 3) & ~3);   // blkmax row stride (sized for the finer blocks)
-  dim3 grid((unsigned)nblk), block(256);
+  const int64_t ld_full = lrx_flat_ip_score_ld(n_rows);
+  if (ld == 0) ld = ld_full;
+  const int nblk_ld = (int)((ld / SP_ROWS + 3) & ~3);   // blkmax row stride (128-row blocks)
+  dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
+  const bool emit = fm.cand != nullptr;
   // queries per pass over the corpus: 128 (8 MFMA tiles); the shadow filter takes up to 256 (16 tiles, 64 KiB of LDS, two workgroups
   // per CU) -- a large query batch then streams the shadow half as often
   const bool shadow_pass = qsplit != nullptr && planes == 1 && Xb != nullptr;
   const int chunk = shadow_pass ? 256 : 128;
+  LRX_CHECK_ARG(fm.bmode == 0 || (planes == 1 && qsplit != nullptr && n_queries <= chunk), "flat_ip: sampled filter launch outside the bounded search");
   for (int q0 = 0; q0 < n_queries; q0 += chunk) {
     int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
     int qt = (nq + 15) / 16;
     const float* qp = q + (int64_t)q0 * dim;
-    float* sp = scores + (int64_t)q0 * ld;
+    float* sp = scores ? scores + (int64_t)q0 * ld : nullptr;
     float* bp = blkmax ? blkmax + (int64_t)q0 * nblk_ld : nullptr;
     if (shadow_pass) {   // any query count: the shadow pass beats the exact-fp32 kernel from Q = 1
       // filter pass over the bf16 shadow of the corpus: half the bytes of the fp32 rows
-      int threads = (dim / 64) * 2 * qt * 64;
-      hipLaunchKernelGGL(k_pack_queries_xb, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit);
-#define LRX_SB(QQ, QSB_)                                                                                                                               \
-  case QQ:                                                                                                                                              \
-    hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPX_RT, SPX_NST, SPX_WV, true, QSB_>), dim3((unsigned)(ld / (16 * SPX_RT * SPX_WV))), dim3(64 * SPX_WV), 0, \
-                       s, Xb, n_rows, ldxb, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate);                                                                 \
+      const int64_t nwg = fm.nblocks >= 0 ? fm.nblocks : ld_full / (16 * SPX_RT * SPX_WV);
+      if (nwg == 0) continue;
+      if (fm.bmode != 2) {   // (the main pass of the score-free filter reuses the planes packed for its sample pass)
+        int threads = (dim / 64) * 2 * qt * 64;
+        hipLaunchKernelGGL(k_pack_queries_xb, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit);
+      }
+#define LRX_SB_(QQ, QSB_, EM_)                                                                                                                           \
+    hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPX_RT, SPX_NST, SPX_WV, true, QSB_, EM_>), dim3((unsigned)nwg), dim3(64 * SPX_WV), 0, s, Xb, n_rows, \
+                       ldxb, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.thr, fm.cand, fm.cnt);
+#define LRX_SB(QQ, QSB_)                  \
+  case QQ:                                \
+    if (emit) { LRX_SB_(QQ, QSB_, true) } \
+    else { LRX_SB_(QQ, QSB_, false) }     \
     break;
       // q slices of one or two tiles are small enough for three workgroups per CU even double-buffered; from three tiles on the
       // single-buffered q layout buys the third workgroup (Q = 100: 1.23 -> 1.19 ms)
       switch (qt) { LRX_SB(1, false) LRX_SB(2, false) LRX_SB(3, SPX_QSB) LRX_SB(4, SPX_QSB) LRX_SB(5, SPX_QSB) LRX_SB(6, SPX_QSB) LRX_SB(7, SPX_QSB) LRX_SB(8, SPX_QSB)
                    LRX_SB(9, SPX_QSB) LRX_SB(10, SPX_QSB) LRX_SB(11, SPX_QSB) LRX_SB(12, SPX_QSB) LRX_SB(13, SPX_QSB) LRX_SB(14, SPX_QSB) LRX_SB(15, SPX_QSB) LRX_SB(16, SPX_QSB) }
 #undef LRX_SB
+#undef LRX_SB_
       LRX_LAUNCH_CHECK();
       continue;
     }
     if (qsplit != nullptr && qt >= SPLIT_MIN_QT) {
-      int threads = (dim / 32) * qt * 64;
-      hipLaunchKernelGGL(k_split_queries, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, planes, qsplit, gate);
+      const int rb = planes == 3 ? 128 : 16 * SPF_RT * SPF_WV;
+      const int64_t nwg = fm.nblocks >= 0 ? fm.nblocks : ld_full / rb;
+      if (nwg == 0) continue;
+      if (fm.bmode != 2) {
+        int threads = (dim / 32) * qt * 64;
+        hipLaunchKernelGGL(k_split_queries, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, planes, qsplit, gate);
+      }
+#define LRX_SF_(QQ, EM_)                                                                                                                          \
+    hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPF_RT, SPF_NST, SPF_WV, false, false, EM_>), dim3((unsigned)nwg), dim3(64 * SPF_WV), 0, s, X, n_rows, ldx, \
+                       dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.thr, fm.cand, fm.cnt);
 #define LRX_SS(QQ)                                                                                                                              \
   case QQ:                                                                                                                                      \
-    if (planes == 3) hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 3, 2, 2, 4>), dim3((unsigned)(ld / 128)), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate); \
-    else hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPF_RT, SPF_NST, SPF_WV>), dim3((unsigned)(ld / (16 * SPF_RT * SPF_WV))), dim3(64 * SPF_WV), 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate); \
+    if (planes == 3) hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 3, 2, 2, 4>), dim3((unsigned)nwg), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, 0, 1, (const float*)nullptr, (unsigned long long*)nullptr, (unsigned int*)nullptr); \
+    else if (emit) { LRX_SF_(QQ, true) }                                                                                                        \
+    else { LRX_SF_(QQ, false) }                                                                                                                 \
     break;
       switch (qt) { LRX_SS(3) LRX_SS(4) LRX_SS(5) LRX_SS(6) LRX_SS(7) LRX_SS(8) }
 #undef LRX_SS
+#undef LRX_SF_
       LRX_LAUNCH_CHECK();
       continue;
     }
+    LRX_CHECK_ARG(fm.bmode == 0 && !emit, "flat_ip: the exact-fp32 score kernel has no sampled / emitting mode");
+    dim3 grid((unsigned)(ld_full / S_ROWS));
 #define LRX_SC(QQ) case QQ: hipLaunchKernelGGL(k_flat_ip_scores<QQ>, grid, block, 0, s, X, n_rows, ldx, dim, qp, nq, sp, ld, bp, nblk_ld, gate); break;
     switch (qt) { LRX_SC(1) LRX_SC(2) LRX_SC(3) LRX_SC(4) LRX_SC(5) LRX_SC(6) LRX_SC(7) LRX_SC(8) }
 #undef LRX_SC
@@ -520,14 +606,6 @@ extern "C" int lrx_flat_ip_scores(const float* X, int64_t n_rows, int64_t ldx, i
 // ---------------------------------------------------------------------------------------------------------------
 // top-k select
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t f2key(float f) {  // monotone: larger float -> larger key
-  uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(uint32_t k) {
-  uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-  return __uint_as_float(u);
-}
 
 // sort buf[0..P) descending (P power of two), all threads of the block participate
 __device__ void bitonic_sort_desc(unsigned long long* buf, int P) {
@@ -559,9 +637,44 @@ struct SelShared {
   unsigned int bucket, kk, cnt, ngt, neq;
 };
 
+// One digit of the radix select after the per-wave histograms of that digit are complete: finds the bucket holding the kk-th largest
+// key (suffix sums S(b) = count of keys in buckets >= b, by a wave scan per 64 buckets plus the totals of the higher waves -- a serial
+// walk over 256 LDS entries by one thread cost ~8 us per pass), updates kk to the rank inside the bucket, neq to the bucket's count.
+template <class SH>
+__device__ __forceinline__ unsigned int radix_pick(SH& sh, unsigned int& kk, unsigned int& neq) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  unsigned int cnt_b = 0, suf = 0;
+  if (tid < 256) {
+#pragma unroll
+    for (int w = 0; w < 16; ++w) cnt_b += sh.hist[w][tid];
+    suf = cnt_b;                                   // inclusive suffix within the wave: lanes >= lane
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int up = __shfl_down(suf, o, 64);
+      if ((tid & 63) + o < 64) suf += up;
+    }
+  }
+  __syncthreads();                                 // all per-wave histograms consumed before hist[1] is reused for the wave totals
+  if (tid < 256 && (tid & 63) == 0) sh.hist[1][tid >> 6] = suf;
+  __syncthreads();
+  if (tid < 256) {
+    for (int w = (tid >> 6) + 1; w < 4; ++w) suf += sh.hist[1][w];
+    const unsigned int above = suf - cnt_b;        // keys in strictly higher buckets
+    if (suf >= kk && above < kk) { sh.bucket = tid; sh.kk = kk - above; sh.cnt = cnt_b; }
+  }
+  __syncthreads();
+  const unsigned int bucket = sh.bucket;
+  kk = sh.kk;
+  neq = sh.cnt;
+  __syncthreads();
+  return bucket;
+}
+
 // exact radix select (4 x 8 bit) of the kk-th largest key of row[0..n): returns the key, the number of elements
 // equal to it that belong to the top-kk (need_eq) and how many elements carry that key in total (neq).
-__device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, unsigned int kk, SelShared& sh, unsigned int& need_eq,
+template <class SH>
+__device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, unsigned int kk, SH& sh, unsigned int& need_eq,
                                      unsigned int& neq) {
   const int tid = threadIdx.x, wave = tid >> 6;
   uint32_t prefix = 0, mask = 0;
@@ -581,56 +694,35 @@ __device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, u
       uint32_t key = f2key(row[i]);
       if ((key & mask) == prefix) atomicAdd(&sh.hist[wave][(key >> shift) & 255], 1u);
     }
-    __syncthreads();
-    // bucket holding the kk-th largest key: suffix sums S(b) = count of keys in buckets >= b, by a wave scan per 64 buckets plus the
-    // totals of the higher waves (a serial walk over 256 LDS entries by one thread cost ~8 us per pass)
-    unsigned int cnt_b = 0, suf = 0;
-    if (tid < 256) {
-#pragma unroll
-      for (int w = 0; w < 16; ++w) cnt_b += sh.hist[w][tid];
-      suf = cnt_b;                                   // inclusive suffix within the wave: lanes >= lane
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned int up = __shfl_down(suf, o, 64);
-        if ((tid & 63) + o < 64) suf += up;
-      }
-      if ((tid & 63) == 0) sh.hist[1][tid >> 6] = suf;   // wave total (hist[1] is free: the per-wave histograms were just consumed)
-    }
-    __syncthreads();
-    if (tid < 256) {
-      for (int w = (tid >> 6) + 1; w < 4; ++w) suf += sh.hist[1][w];
-      const unsigned int above = suf - cnt_b;        // keys in strictly higher buckets
-      if (suf >= kk && above < kk) { sh.bucket = tid; sh.kk = kk - above; sh.cnt = cnt_b; }
-    }
-    __syncthreads();
-    prefix |= (uint32_t)sh.bucket << shift;
+    prefix |= (uint32_t)radix_pick(sh, kk, neq) << shift;
     mask |= 0xFFu << shift;
-    kk = sh.kk;
-    neq = sh.cnt;
-    __syncthreads();
   }
   need_eq = kk;
   return prefix;
 }
 
-__device__ __forceinline__ unsigned long long sel_pack(uint32_t key, int64_t i) {
-  return ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+// the same over the score keys (upper halves) of a packed candidate list
+template <class SH>
+__device__ uint32_t radix_select_kth_list(const unsigned long long* __restrict__ list, int n, unsigned int kk, SH& sh) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  uint32_t prefix = 0, mask = 0;
+  unsigned int neq;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 16 * 256; i += SEL_THREADS) (&sh.hist[0][0])[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += SEL_THREADS) {
+      const uint32_t key = (uint32_t)(list[i] >> 32);
+      if ((key & mask) == prefix) atomicAdd(&sh.hist[wave][(key >> shift) & 255], 1u);
+    }
+    prefix |= (uint32_t)radix_pick(sh, kk, neq) << shift;
+    mask |= 0xFFu << shift;
+  }
+  return prefix;
 }
 
-__global__ void __launch_bounds__(SEL_THREADS)
-k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base, const float* __restrict__ blkmax, int nblk,
-              int nblk_ld, float* __restrict__ out_scores, int64_t* __restrict__ out_ids, const int* __restrict__ gate,
-              const int* __restrict__ qflags) {
-  __shared__ SelShared sh;
-  if (gate != nullptr && *gate == 0) return;                 // fallback launch of the bounded search: nothing overflowed
-  if (qflags != nullptr && qflags[blockIdx.x] == 0) return;  // ... or not this query
-  const float* row = scores + (int64_t)blockIdx.x * ld;
-  float* os = out_scores + (int64_t)blockIdx.x * k;
-  int64_t* oi = out_ids + (int64_t)blockIdx.x * k;
+// Exact top-keff of row[0..N) (score desc, row asc) left sorted in sh.cand[0..keff); all SEL_THREADS threads take part.
+__device__ void select_topk_sorted(const float* __restrict__ row, int64_t N, int keff, const float* __restrict__ bm, int nblk, SelShared& sh) {
   const int tid = threadIdx.x;
-  const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
-  for (int i = keff + tid; i < k; i += SEL_THREADS) { os[i] = -FLT_MAX; oi[i] = -1; }
-  if (keff == 0) return;
   int ncand = 0;  // number of valid entries in sh.cand, of which the best keff are the answer
 
   // ---- fast path: threshold = keff-th largest of the per-block maxima (>= keff elements are >= it, so the true top-keff
@@ -640,9 +732,8 @@ k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, in
     for (int64_t i = tid; i < N; i += SEL_THREADS) sh.cand[i] = sel_pack(f2key(row[i]), i);
     ncand = (int)N;
     done = true;
-  } else if (blkmax != nullptr && nblk >= keff) {
+  } else if (bm != nullptr && nblk >= keff) {
     unsigned int ne, nq_;
-    const float* bm = blkmax + (int64_t)blockIdx.x * nblk_ld;
     const uint32_t thr = radix_select_kth(bm, nblk, keff, sh, ne, nq_);
     if (tid == 0) { sh.ngt = 0; sh.neq = 0; }
     __syncthreads();
@@ -719,10 +810,27 @@ k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, in
   __syncthreads();
   for (int i = ncand + tid; i < P; i += SEL_THREADS) sh.cand[i] = 0ull;
   bitonic_sort_desc(sh.cand, P);
+}
+
+__global__ void __launch_bounds__(SEL_THREADS)
+k_topk_select(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base, const float* __restrict__ blkmax, int nblk,
+              int nblk_ld, float* __restrict__ out_scores, int64_t* __restrict__ out_ids, const int* __restrict__ gate,
+              const int* __restrict__ qflags) {
+  __shared__ SelShared sh;
+  if (gate != nullptr && *gate == 0) return;                 // fallback launch of the bounded search: nothing overflowed
+  if (qflags != nullptr && qflags[blockIdx.x] == 0) return;  // ... or not this query
+  const float* row = scores + (int64_t)blockIdx.x * ld;
+  float* os = out_scores + (int64_t)blockIdx.x * k;
+  int64_t* oi = out_ids + (int64_t)blockIdx.x * k;
+  const int tid = threadIdx.x;
+  const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
+  for (int i = keff + tid; i < k; i += SEL_THREADS) { os[i] = -FLT_MAX; oi[i] = -1; }
+  if (keff == 0) return;
+  select_topk_sorted(row, N, keff, blkmax ? blkmax + (int64_t)blockIdx.x * nblk_ld : nullptr, nblk, sh);
   for (int i = tid; i < keff; i += SEL_THREADS) {
-    unsigned long long c = sh.cand[i];
+    const unsigned long long c = sh.cand[i];
     os[i] = key2f((uint32_t)(c >> 32));
-    oi[i] = id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
+    oi[i] = id_base + sel_row(c);
   }
 }
 
@@ -827,82 +935,173 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Bounded two-pass search (Q > 32, rows with a known norm bound R): the same exact top-k at close to one HBM pass.
-//   pass 1  filter: s~ = bf16(q) . bf16(x) with ONE bf16 MFMA product (instead of six), fp32 accumulation.
-//           |s - s~| <= eps = FILTER_EPS * |q| * R, FILTER_EPS = 2^-8 + 2^-18 (two roundings to bf16, unit roundoff 2^-9 each, Cauchy-
-//           Schwarz over the element products) + 2048 * 2^-22 (a generous bound on the fp32 accumulation of <= 2048-term sums per
-//           2^-22-accurate addition) -> 0.0045.  k_topk_select on s~ gives kth~ = k-th largest s~.
-//   pass 2  refine (k_refine_topk, REF_SPLIT workgroups per query, the last one to finish merges): every row of the exact top-k has s~ >= kth~ - 2 eps (its exact score is
-//           >= the k-th largest exact score >= the k-th largest of (s~ - eps)), so all rows with s~ >= kth~ - 2 eps are gathered --
-//           whole 128-row blocks are skipped through the block maxima --, rescored exactly from the fp32 rows (fp64 accumulation,
-//           rounded once to fp32) and sorted (score desc, row asc).  Typical band content at 1M x 2048 normalised rows: ~500 rows.
-//   fallback: a query whose band holds more than REF_CAND rows or REF_BLK blocks (near-duplicate corpora) raises a device flag; the
-//           six-product pass + select are always enqueued behind it, gated on that flag (they return at once when it is 0), and
-//           overwrite only the flagged queries.  No host synchronisation anywhere.
+// Bounded two-pass search (rows with known bounds R >= max |x_row| and E >= max |x_row - bf16(x_row)|): the same exact top-k at close
+// to ONE pass over the bf16 shadow of the shard, without ever writing a [queries, rows] score matrix.
+//   filter  s~ = bf16(q) . bf16(x) with ONE bf16 MFMA product (instead of six), fp32 accumulation.  With q~ = bf16(q), x~ = bf16(x):
+//           s - s~ = (q - q~).x + q~.(x - x~) + (accumulation error), so by Cauchy-Schwarz
+//             |s - s~| <= eps(q) = |q - q~| R + |q~| E + (D + 32) 2^-23 |q~| R          (query_eps_block; |q - q~| and |q~| are computed
+//           from the actual query, E from the actual rows at commit: ~0.0036 |q| R for typical data; the worst case of two roundings
+//           with unit roundoff 2^-8 each is 0.0078 |q| R).
+//   sample  every ss-th 128-row block is scored first, into a small compact matrix; T' = its k-th largest score is a lower bound of
+//           kth~, the k-th largest filter score of the whole shard (k sample rows reach it).
+//   main    all other blocks; the epilogue keeps only rows with s~ >= T' - 2 eps, appended to a per-query candidate list (~1e-3 of the
+//           rows).  Every row of the exact top-k is in the list: its exact score is >= the k-th largest exact score >= the k-th
+//           largest of (s~ - eps), so its s~ >= kth~ - 2 eps >= T' - 2 eps.
+//   refine  kth~ = k-th largest s~ of the list (exact: the list holds every row >= T' - 2 eps), the rows with s~ >= kth~ - 2 eps
+//           are rescored exactly from the fp32 rows (fp64 accumulation, rounded once to fp32) by REF_SPLIT workgroups per query and
+//           sorted (score desc, row asc).  Typical band content at 1M x 2048 normalised rows: ~300 rows.
+//   fallback: a query whose list or band overflows (near-duplicate corpora) raises a device flag; the six-product pass + select +
+//           rescore are always enqueued behind it, gated on that flag (they return at once when it is 0), and overwrite only the
+//           flagged queries.  No host synchronisation anywhere.
+//   Small query batches (score matrix < 1/16 of the shadow bytes) and small shards keep the score-matrix filter: one launch less in
+//   the dependency chain.  Both give the same result -- everything ends in the same exact rescoring of a superset of the top-k.
 // ---------------------------------------------------------------------------------------------------------------
-#define FILTER_EPS 0.0045f
 #define REF_CAND 4096
 #define REF_BLK 8192
-
-#ifdef SEARCH_TRACE
-// diagnostic build only: phase stamps of k_refine_topk (block = query), read back by tools via lrx_debug_read_search_trace
-__device__ long long g_search_trace[8 * 1024];
-extern "C" int lrx_debug_read_search_trace(void* dst, size_t bytes) {
-  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_search_trace), bytes) == hipSuccess ? 0 : 1;
-}
-#define S_TRACE(slot)                                                                                         \
-  do {                                                                                                        \
-    __syncthreads();                                                                                          \
-    if (threadIdx.x == 0 && blockIdx.x < 1024) g_search_trace[8 * blockIdx.x + (slot)] = wall_clock64();      \
-  } while (0)
-#else
-#define S_TRACE(slot)
-#endif
-
 #ifndef REF_SPLIT
 #define REF_SPLIT 4                       // workgroups per query (phase stamps: the exact rescoring is bound by what ONE CU can fetch)
 #endif
 #define REF_PCAND (REF_CAND / REF_SPLIT)  // candidate capacity of one part
 #define REF_PBLK (REF_BLK / REF_SPLIT)
-#define REF_QLDS 8192                     // query rows up to this many floats are staged in LDS by k_refine_topk
+#define REF_QLDS 8192                     // query rows up to this many floats are staged in LDS by the refine kernels
 
-// grid (n_queries, REF_SPLIT): part s of query q owns the 128-row blocks b with b % REF_SPLIT == s: it gathers their rows inside the band,
-// rescores them exactly and publishes the packed (score, row) list (count -1 = the part's lists overflowed); k_refine_merge finishes.
+struct RadixShared {
+  unsigned int hist[16][256];
+  unsigned int bucket, kk, cnt;
+};
+
+// eps(q) of the header comment; all threads of the (<= 1024-thread) block take part, fixed summation order.  Optionally stages the
+// query row in LDS (s_q).  bounds = {R, E}; E <= 0 means "unknown": 2^-8 R (unit roundoff of bf16).
+__device__ float query_eps_block(const float* __restrict__ qglob, int D, const float* __restrict__ bounds, float* s_q, float* s_red /* 32 */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  float a = 0.f, b = 0.f;
+  for (int i = tid; i < D; i += blockDim.x) {
+    const float v = qglob[i];
+    if (s_q != nullptr) s_q[i] = v;
+    const float r = (float)(__bf16)v, d = v - r;
+    a += r * r;
+    b += d * d;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (lane == 0) { s_red[wave] = a; s_red[16 + wave] = b; }
+  __syncthreads();
+  float A = 0.f, B = 0.f;
+  for (int w = 0; w < nw; ++w) { A += s_red[w]; B += s_red[16 + w]; }
+  __syncthreads();
+  const float R = bounds[0], E = bounds[1] > 0.f ? bounds[1] : R * 0.00390625f;
+  const float accum = (float)(D + 32) * 1.1920929e-7f;   // 2^-23 per accumulated term
+  return (sqrtf(B) * R + sqrtf(A) * (E + accum * R * 1.01f)) * 1.0001f + 1e-30f;
+}
+
+// Sample step of the score-free filter (one workgroup per query): kth' = k-th largest of the compact sample scores, thr = kth' - 2 eps,
+// and the sample rows reaching thr open the query's candidate list.  Sample-local row j is corpus row (j / rb) * ss * rb + j % rb.
+__global__ void __launch_bounds__(SEL_THREADS)
+k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, int k, const float* __restrict__ blkmax, int nblk, int nblk_ld,
+                   const float* __restrict__ q, int D, const float* __restrict__ bounds, int rb, int ss, int64_t N, float* __restrict__ thr_out,
+                   float* __restrict__ eps_out, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt) {
+  __shared__ SelShared sh;
+  __shared__ float s_red[32];
+  const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = scores + (int64_t)qi * ld_s;
+  const float* bm = blkmax + (int64_t)qi * nblk_ld;
+  select_topk_sorted(row, Ns, k, bm, nblk, sh);                 // (the plan guarantees >= 2k valid sample rows)
+  const float kth = key2f((uint32_t)(sh.cand[k - 1] >> 32));
+  const float eps = query_eps_block(q + (int64_t)qi * D, D, bounds, nullptr, s_red);
+  const float thr = kth - 2.0f * eps;
+  if (tid == 0) { thr_out[qi] = thr; eps_out[qi] = eps; }
+  unsigned long long* list = cand + (int64_t)qi * CAND_CAP;
+  for (int b = wave; b < nblk; b += SEL_THREADS / 64)
+    if (bm[b] >= thr) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t j = (int64_t)b * SP_ROWS + h * 64 + lane;
+        const float v = row[j];
+        const int64_t g = (j / rb) * ((int64_t)ss * rb) + (j % rb);
+        if (g < N && v >= thr) {
+          const unsigned int p = atomicAdd(&cnt[qi], 1u);
+          if (p < CAND_CAP) list[p] = sel_pack(f2key(v), g);
+        }
+      }
+    }
+}
+
+// exact rescoring of nc candidate rows (s_cand: row numbers): one half-wave per row (fp64 accumulation of the fp32 products, one
+// rounding to fp32); the packed (score, row) pairs go to `mine`
+__device__ __forceinline__ void refine_rescore(const float* __restrict__ X, int64_t ldx, int D, const float* qrow, const unsigned long long* s_cand,
+                                               int nc, unsigned long long* __restrict__ mine) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c0 = wave * 2; c0 < nc; c0 += 32) {
+    const int c = min(c0 + (lane >> 5), nc - 1);
+    const int64_t n = (int64_t)s_cand[c];
+    const float sc = exact_dot(X + n * ldx, qrow, D, lane);
+    if ((lane & 31) == 0 && c0 + (lane >> 5) < nc) mine[c] = sel_pack(f2key(sc), n);
+  }
+}
+
+// Refine step of the score-free filter, grid (n_queries, REF_SPLIT): every part finds kth~ in the query's candidate list (radix
+// select over ~10^3..10^4 L2-resident entries), takes every REF_SPLIT-th entry of the band [kth~ - 2 eps, inf), rescores those rows
+// exactly and publishes the packed (score, row) list (count -1 = list or band overflow); k_refine_merge finishes.
+__global__ void __launch_bounds__(1024)
+k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ q, const unsigned long long* __restrict__ cand,
+              const unsigned int* __restrict__ cnt, const float* __restrict__ eps, int k, unsigned long long* __restrict__ parts,
+              int* __restrict__ part_cnt) {
+  __shared__ RadixShared rs;
+  __shared__ unsigned long long s_cand[REF_PCAND];
+  __shared__ __attribute__((aligned(16))) float s_q[REF_QLDS];   // the query row (every rescoring re-reads it; from global its loads serialise)
+  __shared__ unsigned int s_ncand;
+  const int tid = threadIdx.x;
+  const int qi = blockIdx.x, part = blockIdx.y;
+  const float* qglob = q + (int64_t)qi * D;
+  const float* qrow = D <= REF_QLDS ? s_q : qglob;
+  if (D <= REF_QLDS)
+    for (int i = tid; i < D; i += 1024) s_q[i] = qglob[i];
+  if (tid == 0) s_ncand = 0;
+  const unsigned int n = cnt[qi];
+  bool overflow = n > CAND_CAP || n < (unsigned int)k;      // (n < k cannot happen with a finite threshold: k sample rows reach it)
+  __syncthreads();
+  if (!overflow) {
+    const unsigned long long* list = cand + (int64_t)qi * CAND_CAP;
+    const float kth = key2f(radix_select_kth_list(list, (int)n, (unsigned int)k, rs));
+    const float thr = kth - 2.0f * eps[qi];
+    for (int i = part + REF_SPLIT * tid; i < (int)n; i += REF_SPLIT * 1024) {
+      const unsigned long long e = list[i];
+      if (key2f((uint32_t)(e >> 32)) >= thr) {
+        const unsigned int p = atomicAdd(&s_ncand, 1u);
+        if (p < REF_PCAND) s_cand[p] = (unsigned long long)sel_row(e);
+      }
+    }
+    __syncthreads();
+    overflow = s_ncand > REF_PCAND;
+  }
+  const int nc = overflow ? 0 : (int)s_ncand;
+  refine_rescore(X, ldx, D, qrow, s_cand, nc, parts + ((int64_t)qi * REF_SPLIT + part) * REF_PCAND);
+  if (tid == 0) part_cnt[qi * REF_SPLIT + part] = overflow ? -1 : nc;
+}
+
+// Refine step of the score-matrix filter, grid (n_queries, REF_SPLIT): part s of query q owns the 128-row blocks b with b % REF_SPLIT == s:
+// it gathers their rows inside the band from the score matrix, rescores them exactly and publishes the packed (score, row) list
+// (count -1 = the part's lists overflowed); k_refine_merge finishes.
 __global__ void __launch_bounds__(1024)
 k_refine_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ q, const float* __restrict__ scores, int64_t ld,
-              const float* __restrict__ blkmax, int nblk, int nblk_ld, const float* __restrict__ row_norm_bound, int k, int64_t id_base,
+              const float* __restrict__ blkmax, int nblk, int nblk_ld, const float* __restrict__ bounds, int k, int64_t id_base,
               const float* __restrict__ out_scores, unsigned long long* __restrict__ parts, int* __restrict__ part_cnt) {
   __shared__ unsigned long long s_cand[REF_PCAND];
   __shared__ unsigned int s_blk[REF_PBLK];
-  __shared__ __attribute__((aligned(16))) float s_q[REF_QLDS];   // the query row (every rescoring re-reads it; from global its loads serialise)
-  __shared__ float s_red[16];
+  __shared__ __attribute__((aligned(16))) float s_q[REF_QLDS];
+  __shared__ float s_red[32];
   __shared__ unsigned int s_nblk, s_ncand;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int qi = blockIdx.x, part = blockIdx.y;
   const float* os = out_scores + (int64_t)qi * k;
   const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
   if (tid == 0) { s_nblk = 0; s_ncand = 0; }
   if (keff == 0) return;                      // (outputs already padded by k_topk_select)
-  S_TRACE(0);
-  // |q|
   const float* qglob = q + (int64_t)qi * D;
   const float* qrow = D <= REF_QLDS ? s_q : qglob;
-  float ss = 0.f;
-  for (int i = tid; i < D; i += 1024) {
-    const float v = qglob[i];
-    if (D <= REF_QLDS) s_q[i] = v;
-    ss += v * v;
-  }
-  ss = wave_sum(ss);
-  if (lane == 0) s_red[wave] = ss;
-  __syncthreads();
-  float qn2 = 0.f;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) qn2 += s_red[w];
-  const float band = 2.0f * FILTER_EPS * sqrtf(qn2) * row_norm_bound[0] * 1.0001f + 1e-30f;
+  const float band = 2.0f * query_eps_block(qglob, D, bounds, D <= REF_QLDS ? s_q : nullptr, s_red);
   const float kth = os[keff - 1];             // k-th largest filter score (written by k_topk_select; nobody writes os before the merge)
   const float thr = kth - band;
-  S_TRACE(1);
   // this part's qualifying 128-row blocks
   const float* bm = blkmax + (int64_t)qi * nblk_ld;
   for (int b = part + REF_SPLIT * tid; b < nblk; b += REF_SPLIT * 1024)
@@ -911,7 +1110,6 @@ k_refine_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
       if (p < REF_PBLK) s_blk[p] = (unsigned int)b;
     }
   __syncthreads();
-  S_TRACE(2);
   const unsigned int nb = s_nblk;
   bool overflow = nb > REF_PBLK;
   if (!overflow) {
@@ -936,24 +1134,12 @@ k_refine_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
     __syncthreads();
     overflow = s_ncand > REF_PCAND;
   }
-  S_TRACE(3);
   const int nc = overflow ? 0 : (int)s_ncand;
-#ifdef SEARCH_TRACE
-  if (tid == 0 && blockIdx.x < 1024 && part == 0) { g_search_trace[8 * blockIdx.x + 6] = nc; g_search_trace[8 * blockIdx.x + 7] = nb; }
-#endif
-  // exact rescoring: one half-wave per candidate row (fp64 accumulation of the fp32 products, one rounding to fp32)
-  unsigned long long* mine = parts + ((int64_t)qi * REF_SPLIT + part) * REF_PCAND;
-  for (int c0 = wave * 2; c0 < nc; c0 += 32) {
-    const int c = min(c0 + (lane >> 5), nc - 1);
-    const int64_t n = (int64_t)s_cand[c];
-    const float sc = exact_dot(X + n * ldx, qrow, D, lane);
-    if ((lane & 31) == 0 && c0 + (lane >> 5) < nc) mine[c] = sel_pack(f2key(sc), n);
-  }
+  refine_rescore(X, ldx, D, qrow, s_cand, nc, parts + ((int64_t)qi * REF_SPLIT + part) * REF_PCAND);
   if (tid == 0) part_cnt[qi * REF_SPLIT + part] = overflow ? -1 : nc;
-  S_TRACE(4);
 }
 
-// Merge of the REF_SPLIT published lists of a query (one workgroup per query; the kernel boundary orders it after k_refine_topk --
+// Merge of the REF_SPLIT published lists of a query (one workgroup per query; the kernel boundary orders it after the refine kernel --
 // an in-kernel "last part merges" ticket needed device-scope fences that cost more than this launch): sort, write the top-k; a part
 // that overflowed flags the query for the gated six-product fallback.
 __global__ void __launch_bounds__(1024)
@@ -973,7 +1159,7 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
     any_over |= cnt[p] < 0;
     tot += cnt[p] < 0 ? 0 : cnt[p];
   }
-  if (any_over) {
+  if (any_over || tot < keff) {               // (tot < keff: a non-finite query or threshold -- the exact path sorts it out)
     if (tid == 0) { qflags[qi] = 1; atomicOr(any_flag, 1); }
     return;
   }
@@ -992,61 +1178,212 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
   for (int i = tid; i < keff; i += 1024) {
     const unsigned long long c = s_cand[i];
     os[i] = key2f((uint32_t)(c >> 32));
-    oi[i] = id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
+    oi[i] = id_base + sel_row(c);
   }
 }
 
+// ---- host side: per query chunk (<= 256 queries with the shadow, <= 128 without) one pipeline over one workspace ----------------
+static int g_search_mode = 0;   // 0 = choose per chunk, 1 = always the score-matrix filter, 2 = the score-free filter whenever the shape allows
+extern "C" void lrx_search_set_mode(int32_t mode) { g_search_mode = mode; }
+
+struct BoundedPlan {
+  bool emit;
+  int ss, rb;
+  int64_t ld, nblk, nblk_ld;            // full shard: score row stride, 128-row blocks, blkmax row stride
+  int64_t nsamp_wg, nmain_wg;           // emit: workgroups of the sample / main launch (rb rows each)
+  int64_t ld_s, nblk_s, nblk_ld_s;      // emit: the compact sample matrix
+  size_t off_qsplit, off_ints, off_parts, off_cand, total;   // byte offsets into the workspace (the score region starts at 0)
+};
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow) {
+  BoundedPlan p;
+  memset(&p, 0, sizeof(p));
+  p.rb = filter_rows_per_wg(shadow);
+  p.ld = lrx_flat_ip_score_ld(n_rows);
+  p.nblk = p.ld / SP_ROWS;
+  p.nblk_ld = (p.nblk + 3) & ~(int64_t)3;
+  // sample stride: ~k * ss rows reach the sample's k-th score (plus the band); keep that near CAND_CAP / 8
+  int ss = CAND_CAP / (8 * (k > 0 ? k : 1));
+  ss = ss > 32 ? 32 : (ss < 2 ? 2 : ss);
+  const int64_t nwg = lrx_cdiv(n_rows > 0 ? n_rows : 1, p.rb);
+  while (ss > 2 && (lrx_cdiv(nwg, ss) - 1) * p.rb < 2 * (int64_t)k) ss >>= 1;
+  const int64_t nsamp = lrx_cdiv(nwg, ss);
+  const bool feasible = (nsamp - 1) * p.rb >= 2 * (int64_t)k && nwg - nsamp >= 1 && dim % 4 == 0 && (shadow || nq > 16 * (SPLIT_MIN_QT - 1));
+  p.emit = feasible && g_search_mode != 1 && (g_search_mode == 2 || (n_rows >= 16384 && 64 * (int64_t)nq > dim));
+  p.ss = ss;
+  p.nsamp_wg = nsamp;
+  p.nmain_wg = nwg - nsamp;
+  p.ld_s = lrx_flat_ip_score_ld(nsamp * p.rb);
+  p.nblk_s = nsamp * p.rb / SP_ROWS;
+  p.nblk_ld_s = (p.ld_s / SP_ROWS + 3) & ~(int64_t)3;
+  const size_t fb = (size_t)(nq < 128 ? nq : 128) * (size_t)(p.ld + p.nblk_ld);
+  const size_t prim = p.emit ? (size_t)nq * (size_t)(p.ld_s + p.nblk_ld_s) : (size_t)nq * (size_t)(p.ld + p.nblk_ld);
+  p.off_qsplit = align256((prim > fb ? prim : fb) * sizeof(float));
+  p.off_ints = align256(p.off_qsplit + split_ws_bytes(dim));
+  // ints: flags[nq], any_flag, cnt[nq] (one memset) | part_cnt[nq * REF_SPLIT] | thr[nq] | eps[nq]
+  p.off_parts = align256(p.off_ints + sizeof(int) * ((size_t)nq * (4 + REF_SPLIT) + 1));
+  p.off_cand = align256(p.off_parts + (size_t)nq * REF_CAND * 8);
+  p.total = p.off_cand + (p.emit ? (size_t)nq * CAND_CAP * 8 : 0);
+  return p;
+}
+
 extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
-  const size_t nq = (size_t)(n_queries > 0 ? n_queries : 1);
-  // + flags[Q], any_flag, done[Q], part_cnt[Q, REF_SPLIT], parts[Q, REF_SPLIT, REF_PCAND] u64
-  return lrx_flat_ip_workspace_bytes(n_rows, dim, n_queries, k) + (nq * (2 + REF_SPLIT) + 1) * sizeof(int) + nq * REF_CAND * 8 + 512;
+  // the search walks the queries in chunks of 256 (bf16 shadow) or 128 (fp32 rows), each chunk with its own plan over the same buffer
+  const int32_t nq = n_queries > 0 ? n_queries : 1;
+  size_t need = lrx_flat_ip_workspace_bytes(n_rows, dim, nq < 128 ? nq : 128, k);   // tiny shards / few queries without shadow: plain path in chunks of 128
+  for (int sh = 0; sh < 2; ++sh) {
+    const int chunk = sh ? 256 : 128;
+    const int sizes[2] = {nq < chunk ? nq : chunk, nq > chunk ? nq % chunk : 0};
+    for (int i = 0; i < 2; ++i)
+      if (sizes[i] > 0) {
+        const size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0).total;
+        need = t > need ? t : need;
+      }
+  }
+  return need + 512;
 }
 
 extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_bf16, int64_t ldx_bf16,
-                                          const float* row_norm_bound, const float* q, int32_t n_queries, int32_t k, int64_t id_base,
+                                          const float* row_bounds, const float* q, int32_t n_queries, int32_t k, int64_t id_base,
                                           float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream) {
-  LRX_CHECK_ARG(row_norm_bound != nullptr, "flat_ip_search_bounded: null row_norm_bound (device pointer to max |x_row|)");
-  const int qt_max = ((n_queries < 128 ? n_queries : 128) + 15) / 16;
-  // small query batches are HBM-bound on the exact-fp32 kernel already; tiny shards and wide rows take the plain path too
-  const bool shadow = X_bf16 != nullptr && dim % 64 == 0 && ldx_bf16 >= dim && ldx_bf16 % 8 == 0;
-  if ((qt_max < SPLIT_MIN_QT && !shadow) || n_rows <= REF_CAND || dim % 4 != 0)
-    return lrx_flat_ip_search(X, n_rows, ldx, dim, q, n_queries, k, id_base, out_scores, out_ids, workspace, workspace_bytes, stream);
+  LRX_CHECK_ARG(row_bounds != nullptr, "flat_ip_search_bounded: null row_bounds (device pointer to {max |x_row|, max |x_row - bf16(x_row)|})");
   LRX_CHECK_ARG(k > 0 && k <= SEL_MAXK, "flat_ip_search: k=%d out of range (1..%d)", k, SEL_MAXK);
-  LRX_CHECK_ARG(n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
+  LRX_CHECK_ARG(n_rows >= 0 && n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
+  if (n_queries <= 0) return LRX_OK;
   if (workspace_bytes < lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k)) {
     lrx_set_error("flat_ip_search_bounded: workspace %zu B < required %zu B", workspace_bytes, lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k));
     return LRX_ERR_WORKSPACE;
   }
+  const bool shadow = X_bf16 != nullptr && dim % 64 == 0 && ldx_bf16 >= dim && ldx_bf16 % 8 == 0;
+  const int qt_max = ((n_queries < 128 ? n_queries : 128) + 15) / 16;
+  // tiny shards and odd widths take the plain path; so do small query batches without a shadow (HBM-bound on the exact-fp32 kernel already)
+  if ((qt_max < SPLIT_MIN_QT && !shadow) || n_rows <= REF_CAND || dim % 4 != 0) {
+    for (int q0 = 0; q0 < n_queries; q0 += 128) {
+      const int nq = n_queries - q0 < 128 ? n_queries - q0 : 128;
+      const int rc = lrx_flat_ip_search(X, n_rows, ldx, dim, q + (int64_t)q0 * dim, nq, k, id_base, out_scores + (int64_t)q0 * k, out_ids + (int64_t)q0 * k,
+                                        workspace, workspace_bytes, stream);
+      if (rc != LRX_OK) return rc;
+    }
+    return LRX_OK;
+  }
   hipStream_t s = (hipStream_t)stream;
-  float* scores = (float*)workspace;
-  const int64_t ld = lrx_flat_ip_score_ld(n_rows);
-  float* blkmax = scores + ld * (int64_t)n_queries;
-  const int nblk = (int)(ld / SP_ROWS), nblk_ld = (nblk + 3) & ~3;
-  __bf16* qsplit = (__bf16*)(blkmax + (int64_t)nblk_ld * n_queries);
-  int* flags = (int*)(((uintptr_t)((char*)workspace + lrx_flat_ip_workspace_bytes(n_rows, dim, n_queries, k)) + 255) & ~(uintptr_t)255);
-  int* any_flag = flags + n_queries;
-  int* part_cnt = any_flag + 1 + n_queries;   // (n_queries ints after any_flag are spare)
-  unsigned long long* parts = (unsigned long long*)(((uintptr_t)(part_cnt + (size_t)n_queries * REF_SPLIT) + 15) & ~(uintptr_t)15);
-  LRX_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * (size_t)n_queries + 1), s));     // flags, any_flag, done tickets
-  int rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16);
-  if (rc != LRX_OK) return rc;
-  hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, s, scores, ld, n_rows, k, id_base, blkmax, nblk, nblk_ld, out_scores, out_ids,
-                     (const int*)nullptr, (const int*)nullptr);
-  LRX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_refine_topk, dim3(n_queries, REF_SPLIT), dim3(1024), 0, s, X, n_rows, ldx, dim, q, scores, ld, blkmax, nblk, nblk_ld, row_norm_bound,
-                     k, id_base, (const float*)out_scores, parts, part_cnt);
-  LRX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_refine_merge, dim3(n_queries), dim3(1024), 0, s, (const unsigned long long*)parts, (const int*)part_cnt, n_rows, k, id_base, out_scores,
-                     out_ids, flags, any_flag);
-  LRX_LAUNCH_CHECK();
-  // gated fallback for the flagged queries (returns immediately on the device when nothing overflowed)
-  rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, qsplit, stream, 3, any_flag);
-  if (rc != LRX_OK) return rc;
-  hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, s, scores, ld, n_rows, k, id_base, blkmax, nblk, nblk_ld, out_scores, out_ids,
-                     (const int*)any_flag, (const int*)flags);
-  LRX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_rescore_topk, dim3(n_queries), dim3(1024), 0, s, X, n_rows, ldx, dim, q, k, id_base, out_scores, out_ids, (const int*)any_flag,
-                     (const int*)flags);
+  const int chunk = shadow ? 256 : 128;
+  for (int q0 = 0; q0 < n_queries; q0 += chunk) {
+    const int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
+    const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow);
+    const float* qc = q + (int64_t)q0 * dim;
+    float* osc = out_scores + (int64_t)q0 * k;
+    int64_t* oic = out_ids + (int64_t)q0 * k;
+    char* ws = (char*)workspace;
+    float* scores = (float*)ws;
+    __bf16* qsplit = (__bf16*)(ws + p.off_qsplit);
+    int* flags = (int*)(ws + p.off_ints);
+    int* any_flag = flags + nq;
+    unsigned int* cnt = (unsigned int*)(any_flag + 1);
+    int* part_cnt = (int*)(cnt + nq);
+    float* thr = (float*)(part_cnt + (size_t)nq * REF_SPLIT);
+    float* eps = thr + nq;
+    unsigned long long* parts = (unsigned long long*)(ws + p.off_parts);
+    unsigned long long* cand = (unsigned long long*)(ws + p.off_cand);
+    LRX_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * (size_t)nq + 1), s));     // flags, any_flag, list counts
+    int rc;
+    if (p.emit) {
+      float* blkmax = scores + p.ld_s * (int64_t)nq;
+      FilterMode fs;
+      fs.bmode = 1; fs.ss = p.ss; fs.nblocks = p.nsamp_wg;
+      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld_s, fs);
+      if (rc != LRX_OK) return rc;
+      hipLaunchKernelGGL(k_sample_threshold, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld_s, p.nsamp_wg * p.rb, k, (const float*)blkmax,
+                         (int)p.nblk_s, (int)p.nblk_ld_s, qc, dim, row_bounds, p.rb, p.ss, n_rows, thr, eps, cand, cnt);
+      LRX_LAUNCH_CHECK();
+      FilterMode fm;
+      fm.bmode = 2; fm.ss = p.ss; fm.nblocks = p.nmain_wg; fm.thr = thr; fm.cand = cand; fm.cnt = cnt;
+      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, nullptr, nullptr, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld, fm);
+      if (rc != LRX_OK) return rc;
+      hipLaunchKernelGGL(k_refine_band, dim3(nq, REF_SPLIT), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
+                         (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt);
+      LRX_LAUNCH_CHECK();
+    } else {
+      float* blkmax = scores + p.ld * (int64_t)nq;
+      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16);
+      if (rc != LRX_OK) return rc;
+      hipLaunchKernelGGL(k_topk_select, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax, (int)p.nblk,
+                         (int)p.nblk_ld, osc, oic, (const int*)nullptr, (const int*)nullptr);
+      LRX_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_refine_topk, dim3(nq, REF_SPLIT), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const float*)scores, p.ld, (const float*)blkmax,
+                         (int)p.nblk, (int)p.nblk_ld, row_bounds, k, id_base, (const float*)osc, parts, part_cnt);
+      LRX_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_refine_merge, dim3(nq), dim3(1024), 0, s, (const unsigned long long*)parts, (const int*)part_cnt, n_rows, k, id_base, osc, oic,
+                       flags, any_flag);
+    LRX_LAUNCH_CHECK();
+    // gated fallback for the flagged queries (every kernel returns immediately on the device when nothing overflowed), 128 queries at
+    // a time over the same score region
+    for (int f0 = 0; f0 < nq; f0 += 128) {
+      const int nf = nq - f0 < 128 ? nq - f0 : 128;
+      float* blkmax = scores + p.ld * (int64_t)nf;
+      rc = launch_scores(X, n_rows, ldx, dim, qc + (int64_t)f0 * dim, nf, scores, blkmax, qsplit, stream, 3, any_flag);
+      if (rc != LRX_OK) return rc;
+      hipLaunchKernelGGL(k_topk_select, dim3(nf), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax, (int)p.nblk,
+                         (int)p.nblk_ld, osc + (int64_t)f0 * k, oic + (int64_t)f0 * k, (const int*)any_flag, (const int*)(flags + f0));
+      LRX_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_rescore_topk, dim3(nf), dim3(1024), 0, s, X, n_rows, ldx, dim, qc + (int64_t)f0 * dim, k, id_base, osc + (int64_t)f0 * k,
+                         oic + (int64_t)f0 * k, (const int*)any_flag, (const int*)(flags + f0));
+      LRX_LAUNCH_CHECK();
+    }
+  }
+  return LRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Shard maintenance for rows that did not come from the encoder's last kernel (FlatIPIndex.add, loaded index files): ONE read of the
+// fp32 rows produces the bf16 shadow (RNE) and raises the two bounds {max |row|, max |row - bf16(row)|} (integer atomic max on the
+// non-negative float patterns: order-independent).  A wave walks 16 rows, one atomic pair per 64-row workgroup.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_shard_rows(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int D, __bf16* __restrict__ Xb, int64_t ldxb, float* __restrict__ bounds) {
+  __shared__ float s_r[4], s_e[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float rmax = 0.f, emax = 0.f;
+  for (int j = 0; j < 16; ++j) {
+    const int64_t r = (int64_t)blockIdx.x * 64 + wave * 16 + j;
+    if (r >= n_rows) break;
+    const float* x = X + r * ldx;
+    float r2 = 0.f, e2 = 0.f;
+    for (int i = lane * 4; i < D; i += 256) {
+      const f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + i));
+      bf16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = (__bf16)v[e];
+        const float d = v[e] - (float)h[e];
+        r2 += v[e] * v[e];
+        e2 += d * d;
+      }
+      if (Xb != nullptr) *(bf16x4*)(Xb + r * ldxb + i) = h;
+    }
+    rmax = fmaxf(rmax, wave_sum(r2));
+    emax = fmaxf(emax, wave_sum(e2));
+  }
+  if (lane == 0) { s_r[wave] = rmax; s_e[wave] = emax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rmax = fmaxf(fmaxf(s_r[0], s_r[1]), fmaxf(s_r[2], s_r[3]));
+    emax = fmaxf(fmaxf(s_e[0], s_e[1]), fmaxf(s_e[2], s_e[3]));
+    atomicMax((int*)bounds, __float_as_int(sqrtf(rmax) * (1.0f + 1e-6f)));
+    atomicMax((int*)bounds + 1, __float_as_int(sqrtf(emax) * (1.0f + 1e-6f)));
+  }
+}
+
+extern "C" int lrx_shard_commit_rows(const float* X, int64_t ldx, int64_t n_rows, int32_t dim, void* X_bf16, int64_t ldx_bf16, float* row_bounds,
+                                     void* stream) {
+  LRX_CHECK_ARG(dim > 0 && dim % 4 == 0 && ldx >= dim && ldx % 4 == 0, "shard_commit_rows: dim=%d / ldx=%lld must be multiples of 4", dim, (long long)ldx);
+  LRX_CHECK_ARG(X_bf16 == nullptr || (ldx_bf16 >= dim && ldx_bf16 % 4 == 0), "shard_commit_rows: bad shadow row stride %lld", (long long)ldx_bf16);
+  LRX_CHECK_ARG(row_bounds != nullptr, "shard_commit_rows: null row_bounds");
+  if (n_rows <= 0) return LRX_OK;
+  hipLaunchKernelGGL(k_shard_rows, dim3((unsigned)lrx_cdiv(n_rows, 64)), dim3(256), 0, (hipStream_t)stream, X, ldx, n_rows, dim, (__bf16*)X_bf16, ldx_bf16,
+                     row_bounds);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

@@ -2,11 +2,30 @@
 (retriever/faiss_index.py:20-73: add / search / reset / ntotal), backed by lrx_flat_ip_search."""
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
 
 from . import _lib
+
+
+_SHARDS = weakref.WeakValueDictionary()   # fp32 storage pointer -> FlatIPIndex (lets the encoder recognise a shard slot it writes into)
+
+
+def shard_of(out: torch.Tensor):
+    """(index, first_row) when `out` is a view of whole rows of a live FlatIPIndex's fp32 storage, else None.  LrxEncoder.encode_packed
+    uses it to hand the shard's bf16 shadow rows and bounds to the encoder's last kernel (lrx_encode_packed_shard)."""
+    if not _SHARDS or out.dtype != torch.float32 or out.ndim != 2:
+        return None
+    idx = _SHARDS.get(out.untyped_storage().data_ptr())
+    if idx is None or out.shape[1] != idx.d or out.stride(0) != idx._x.stride(0) or out.stride(1) != 1:
+        return None
+    off = out.data_ptr() - idx._x.data_ptr()
+    row_bytes = idx._x.stride(0) * 4
+    if off < 0 or off % row_bytes:
+        return None
+    return idx, off // row_bytes
 
 
 class FlatIPIndex:
@@ -19,17 +38,34 @@ class FlatIPIndex:
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.ntotal = 0
         self.id_base = id_base  # added to local row numbers (global row of this shard's row 0)
-        self._x = torch.empty(max(capacity, 0), d, dtype=torch.float32, device=self.device)
         self._ws = None
-        # max |row| over the committed rows, kept on the device (no host sync): the error bound of the bf16 filter pass of
-        # lrx_flat_ip_search_bounded scales with it.  two_pass = False forces the six-product path for every search.
-        self._norm_bound = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # {max |row|, max |row - bf16(row)|} over the committed rows, kept on the device (no host sync): the error bound of the bf16
+        # filter pass of lrx_flat_ip_search_bounded is built from them.  two_pass = False forces the six-product path for every search.
+        self._bounds = torch.zeros(2, dtype=torch.float32, device=self.device)
         self.two_pass = True
-        # bf16 shadow of the rows (round-to-nearest-even), maintained by commit(): the filter pass of the two-pass search streams
-        # it instead of the fp32 rows (half the bytes; the exact rescoring still reads fp32).  +50 % index memory; False = no shadow.
+        # bf16 shadow of the rows (round-to-nearest-even): the filter pass of the two-pass search streams it instead of the fp32 rows
+        # (half the bytes; the exact rescoring still reads fp32).  +50 % index memory; False = no shadow.  Shadow rows and bounds are
+        # written by the kernel that produces the fp32 rows (the encoder's last kernel for slots, lrx_shard_commit_rows for add()).
         self.shadow_bf16 = True
-        self.max_workspace_bytes = 12 << 30  # search(): cap of the [queries, rows] score workspace; larger query batches are chunked
+        self.max_workspace_bytes = 12 << 30  # search(): cap of the search workspace; larger query batches are chunked
         self._xb: Optional[torch.Tensor] = None
+        self._fused: list = []               # row intervals whose shadow + bounds the encoder has already written
+        self._x = torch.empty(0, d, dtype=torch.float32, device=self.device)
+        self._set_storage(torch.empty(max(capacity, 0), d, dtype=torch.float32, device=self.device))
+
+    @property
+    def _norm_bound(self) -> torch.Tensor:
+        return self._bounds[:1]
+
+    def _wants_shadow(self) -> bool:
+        return self.shadow_bf16 and self.d % 64 == 0
+
+    def _set_storage(self, x: torch.Tensor):
+        if self._x.numel():
+            _SHARDS.pop(self._x.untyped_storage().data_ptr(), None)
+        self._x = x
+        if x.numel():
+            _SHARDS[x.untyped_storage().data_ptr()] = self
 
     # -- storage -------------------------------------------------------------------------------------------------
     def reserve(self, n_rows: int):
@@ -37,32 +73,56 @@ class FlatIPIndex:
             new = torch.empty(n_rows, self.d, dtype=torch.float32, device=self.device)
             if self.ntotal:
                 new[:self.ntotal].copy_(self._x[:self.ntotal])
-            self._x = new
+            self._set_storage(new)
+        self._ensure_shadow()
 
-    def append_slot(self, n_rows: int) -> torch.Tensor:
-        """Rows [ntotal, ntotal+n) of the shard as a writable view (the encoder writes embeddings straight into it);
-        call commit(n) afterwards."""
-        if self.ntotal + n_rows > self._x.shape[0]:
-            self.reserve(max(self.ntotal + n_rows, int(self._x.shape[0] * 1.5) + 1))
-        return self._x[self.ntotal:self.ntotal + n_rows]
-
-    def _shadow_rows(self, a: int, b: int):
-        if not self.shadow_bf16 or self.d % 64 != 0:
+    def _ensure_shadow(self):
+        if not self._wants_shadow():
             return
         if self._xb is None or self._xb.shape[0] < self._x.shape[0]:
             xb = torch.empty(self._x.shape[0], self.d, dtype=torch.bfloat16, device=self.device)
             if self._xb is not None and self.ntotal:
                 xb[:self.ntotal].copy_(self._xb[:self.ntotal])
             self._xb = xb
-        for s in range(a, b, 262144):
-            e = min(s + 262144, b)
-            self._xb[s:e].copy_(self._x[s:e])          # fp32 -> bf16, round-to-nearest-even
+
+    def append_slot(self, n_rows: int) -> torch.Tensor:
+        """Rows [ntotal, ntotal+n) of the shard as a writable view (the encoder writes embeddings straight into it, together with
+        their shadow rows and the bounds); call commit(n) afterwards."""
+        if self.ntotal + n_rows > self._x.shape[0]:
+            self.reserve(max(self.ntotal + n_rows, int(self._x.shape[0] * 1.5) + 1))
+        self._ensure_shadow()
+        return self._x[self.ntotal:self.ntotal + n_rows]
+
+    def shard_sink(self, row0: int, n_rows: int):
+        """(shadow rows or None, bounds) for rows [row0, row0 + n) and a note that their producer maintains them."""
+        self._ensure_shadow()
+        self._fused.append((row0, row0 + n_rows))
+        xb = self._xb[row0:row0 + n_rows] if (self._wants_shadow() and self._xb is not None) else None
+        return xb, self._bounds
+
+    def _maintain(self, a: int, b: int):
+        """Shadow + bounds of rows [a, b) by lrx_shard_commit_rows (one read of the fp32 rows)."""
+        if b <= a:
+            return
+        self._ensure_shadow()
+        xb = self._xb if self._wants_shadow() else None
+        _lib.check(self.lib.lrx_shard_commit_rows(_lib.ptr(self._x[a:]), self._x.stride(0), b - a, self.d,
+                                                  _lib.ptr(xb[a:]) if xb is not None else None, xb.stride(0) if xb is not None else 0,
+                                                  _lib.ptr(self._bounds), _lib.current_stream()))
 
     def commit(self, n_rows: int):
         if n_rows > 0:
-            new = self._x[self.ntotal:self.ntotal + n_rows]
-            torch.maximum(self._norm_bound, torch.linalg.vector_norm(new, dim=1).max().reshape(1) * (1.0 + 1e-6), out=self._norm_bound)
-            self._shadow_rows(self.ntotal, self.ntotal + n_rows)
+            a, b = self.ntotal, self.ntotal + n_rows
+            # rows the encoder wrote through shard_sink() are done; anything else in [a, b) gets its shadow + bounds now
+            pos = a
+            for s, e in sorted(self._fused):
+                s, e = max(s, a), min(e, b)
+                if e <= pos:
+                    continue
+                self._maintain(pos, min(s, b))
+                pos = max(pos, e)
+            self._maintain(pos, b)
+            self._fused = [(s, e) for s, e in self._fused if e > b]
         self.ntotal += n_rows
 
     def add(self, x):
@@ -76,16 +136,15 @@ class FlatIPIndex:
         self.commit(x.shape[0])
 
     def refresh_norm_bound(self):
-        """Recompute max |row| (and the bf16 shadow) over all committed rows: call after writing into committed rows in place."""
-        self._shadow_rows(0, self.ntotal)
-        self._norm_bound.zero_()
-        for s in range(0, self.ntotal, 262144):
-            e = min(s + 262144, self.ntotal)
-            torch.maximum(self._norm_bound, torch.linalg.vector_norm(self._x[s:e], dim=1).max().reshape(1) * (1.0 + 1e-6), out=self._norm_bound)
+        """Recompute the bounds and the bf16 shadow over all committed rows: needed only after writing into committed rows in place
+        with something other than the encoder (which maintains both itself)."""
+        self._bounds.zero_()
+        self._maintain(0, self.ntotal)
 
     def reset(self):
         self.ntotal = 0
-        self._norm_bound.zero_()
+        self._bounds.zero_()
+        self._fused = []
 
     # -- persistence (faiss.write_index / read_index of an IndexFlatIP, see index_io.py) --------------------------
     def save(self, fname: str, chunk_rows: int = 262144):
@@ -123,14 +182,14 @@ class FlatIPIndex:
         I = torch.empty(Q, k, dtype=torch.int64, device=self.device)
         if Q == 0:
             return D, I
-        # the score workspace is [queries, rows] fp32: large query batches over a large shard go through in chunks of queries that keep
-        # it under max_workspace_bytes (multiples of the 256-query filter pass; results do not depend on the chunking)
-        per_query = max(1, int(self.lib.lrx_flat_ip_bounded_workspace_bytes(self.ntotal, self.d, 2, k))
-                        - int(self.lib.lrx_flat_ip_bounded_workspace_bytes(self.ntotal, self.d, 1, k)))
-        chunk = max(1, min(Q, int(self.max_workspace_bytes) // per_query))
-        if chunk < Q:
-            chunk = chunk // 256 * 256 if chunk >= 256 else (128 if chunk >= 128 else chunk)
-        need = int(self.lib.lrx_flat_ip_bounded_workspace_bytes(self.ntotal, self.d, chunk, k))
+        # the bounded search needs a workspace that stops growing at 256 queries; the six-product path (two_pass = False) a
+        # [queries, rows] fp32 score matrix.  Either way the queries go through in chunks that keep it under max_workspace_bytes
+        # (results do not depend on the chunking).
+        ws_bytes = self.lib.lrx_flat_ip_bounded_workspace_bytes if self.two_pass else self.lib.lrx_flat_ip_workspace_bytes
+        chunk = Q
+        while chunk > 1 and int(ws_bytes(self.ntotal, self.d, chunk, k)) > int(self.max_workspace_bytes):
+            chunk = 256 if chunk > 256 else (128 if chunk > 128 else chunk // 2)
+        need = int(ws_bytes(self.ntotal, self.d, chunk, k))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
@@ -140,7 +199,7 @@ class FlatIPIndex:
             qc, Dc, Ic = q[s:s + chunk], D[s:s + chunk], I[s:s + chunk]
             if self.two_pass:
                 _lib.check(self.lib.lrx_flat_ip_search_bounded(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(xb) if xb is not None else None,
-                                                               xb.stride(0) if xb is not None else 0, _lib.ptr(self._norm_bound), _lib.ptr(qc),
+                                                               xb.stride(0) if xb is not None else 0, _lib.ptr(self._bounds), _lib.ptr(qc),
                                                                qc.shape[0], k, self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws),
                                                                self._ws.numel(), _lib.current_stream()))
             else:

@@ -50,9 +50,16 @@ int main(void) {
   maxn *= 1.000001f;
   CHECK(hipMalloc((void**)&dX, sizeof(float) * N * D)); CHECK(hipMalloc((void**)&dq, sizeof(float) * Q * D));
   CHECK(hipMalloc((void**)&dD, sizeof(float) * Q * k)); CHECK(hipMalloc((void**)&dI, sizeof(long long) * Q * k));
-  CHECK(hipMalloc(&dXb, 2 * (size_t)N * D)); CHECK(hipMalloc((void**)&dbound, 4));
+  CHECK(hipMalloc(&dXb, 2 * (size_t)N * D)); CHECK(hipMalloc((void**)&dbound, 8)); CHECK(hipMemset(dbound, 0, 8));
   CHECK(hipMemcpy(dX, X, sizeof(float) * N * D, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dq, q, sizeof(float) * Q * D, hipMemcpyHostToDevice));
-  CHECK(hipMemcpy(dXb, Xb, 2 * (size_t)N * D, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dbound, &maxn, 4, hipMemcpyHostToDevice));
+  /* shard maintenance on the device: bf16 shadow + the bounds {max |row|, max |row - bf16(row)|}; checked against the host copies */
+  LRX(lrx_shard_commit_rows(dX, D, N, D, dXb, D, dbound, NULL));
+  CHECK(hipDeviceSynchronize());
+  { unsigned short* Xb2 = (unsigned short*)malloc(2 * (size_t)N * D); float hb[2];
+    CHECK(hipMemcpy(Xb2, dXb, 2 * (size_t)N * D, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hb, dbound, 8, hipMemcpyDeviceToHost));
+    if (memcmp(Xb, Xb2, 2 * (size_t)N * D) != 0) { printf("lrx_shard_commit_rows: shadow differs from host RNE\n"); return 5; }
+    if (fabsf(hb[0] / maxn - 1.f) > 1e-5f || !(hb[1] > 0.f && hb[1] < hb[0] / 200.f)) { printf("lrx_shard_commit_rows: bounds %g %g (host max norm %g)\n", hb[0], hb[1], maxn); return 5; }
+    free(Xb2); }
   const size_t wsb = lrx_flat_ip_bounded_workspace_bytes(N, D, Q, k);
   CHECK(hipMalloc(&ws, wsb)); CHECK(hipMemset(ws, 0, wsb));
   float* hD = (float*)malloc(sizeof(float) * Q * k); long long* hI = (long long*)malloc(sizeof(long long) * Q * k);

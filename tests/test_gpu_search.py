@@ -146,8 +146,8 @@ def test_full_size_1m_x_2048_properties():
     assert (kth <= k - 1).all()          # nothing clearly better than the k-th result was missed
     # two-shard merge == whole index
     a, b = FlatIPIndex(D, id_base=0), FlatIPIndex(D, id_base=600_000)
-    a._x, a.ntotal = idx._x[:600_000], 600_000
-    b._x, b.ntotal = idx._x[600_000:], 400_000
+    a._x, a._xb, a._bounds, a.ntotal = idx._x[:600_000], idx._xb[:600_000], idx._bounds, 600_000      # views of the same rows, shadow and bounds
+    b._x, b._xb, b._bounds, b.ntotal = idx._x[600_000:], idx._xb[600_000:], idx._bounds, 400_000
     Da, Ia = a.search(q, k)
     Db, Ib = b.search(q, k)
     Dm, Im = merge_topk(torch.stack([Da, Db]), torch.stack([Ia, Ib]))

@@ -1,0 +1,273 @@
+"""GPU parity of the score-free (candidate-list) filter of lrx_flat_ip_search_bounded, the rigorous per-query error band and the
+shard maintenance fused into the row producers -- against the oracle, against the score-matrix filter (bitwise) and, at the index
+shapes of BASELINE configs 2-5, through size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lrx_oracle as O
+from test_gpu_search import check_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def search_mode():
+    from lightretriever_amd import _lib
+    lib = _lib.lib()
+    yield lib.lrx_search_set_mode
+    lib.lrx_search_set_mode(0)
+
+
+def _index(X, shadow=True, id_base=0, pieces=2):
+    from lightretriever_amd import FlatIPIndex
+    idx = FlatIPIndex(X.shape[1], capacity=X.shape[0], id_base=id_base)
+    idx.shadow_bf16 = shadow
+    step = -(-X.shape[0] // pieces)
+    for s in range(0, X.shape[0], step):
+        idx.add(X[s:s + step])
+    return idx
+
+
+@pytest.mark.parametrize("N,D,Q,k,scale,shadow", [
+    (120000, 256, 100, 100, "unit", True), (50000, 128, 64, 10, "mixed", True), (40000, 64, 33, 1000, "unit", True),
+    (30000, 2048, 40, 50, "unit", True), (70000, 128, 300, 7, "unit", True), (25000, 64, 5, 2048, "mixed", True),
+    (25000, 64, 145, 20, "unit", True), (25000, 320, 255, 33, "mixed", True), (20000, 128, 513, 5, "unit", True),
+    (33000, 4096, 48, 100, "unit", True),                       # the 8B width (BASELINE configs 2-3)
+    (60000, 256, 100, 100, "unit", False), (45000, 128, 128, 10, "mixed", False), (30011, 96, 40, 64, "unit", False),   # fp32 rows converted on the fly
+])
+def test_score_free_filter_equals_score_matrix_filter_bitwise(N, D, Q, k, scale, shadow, search_mode):
+    """Both filters end in the same exact rescoring of a superset of the exact top-k: same ids, same score bits."""
+    rng = np.random.default_rng(N + D + Q)
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32))
+    if scale == "mixed":
+        X *= rng.uniform(0.05, 3.0, size=(N, 1)).astype(np.float32)
+    q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32)) * np.float32(1.7)
+    idx = _index(X, shadow=shadow, id_base=1000)
+    search_mode(2)
+    De, Ie = idx.search(q, k)
+    search_mode(1)
+    Dm, Im = idx.search(q, k)
+    search_mode(0)
+    Da, Ia = idx.search(q, k)
+    assert torch.equal(Ie, Im) and torch.equal(De, Dm)
+    assert torch.equal(Ia, Im) and torch.equal(Da, Dm)
+    check_against_oracle(De, Ie, q, X, k, id_base=1000)
+
+
+def test_workspace_stops_growing_at_256_queries():
+    from lightretriever_amd import _lib
+    lib = _lib.lib()
+    w = [int(lib.lrx_flat_ip_bounded_workspace_bytes(10_000_000, 256, nq, 100)) for nq in (100, 256, 1000, 7000)]
+    assert w[1] == w[2] == w[3] and w[0] <= w[1]
+    assert w[3] < 6 << 30                                        # round 1: 280 GB of [queries, rows] scores for 7000 queries
+    full = 10_000_000 * 100 * 4
+    assert int(lib.lrx_flat_ip_bounded_workspace_bytes(10_000_000, 256, 100, 100)) < 1.1 * full + (64 << 20)
+
+
+def test_adversarial_bf16_rounding_midpoints(search_mode):
+    """bf16 has unit roundoff 2^-8 (8-bit significand).  Rows whose elements all sit just below a rounding midpoint lose
+    0.36 % of their score in the filter; rows with half their elements just above one gain as much and outrank them there although
+    they are worse.  The band is built from the measured |q - bf16(q)| and |x - bf16(x)|, so the exact top-k must survive on both
+    filters and equal the six-product path."""
+    rng = np.random.default_rng(5)
+    N, D, Q, k = 40000, 128, 48, 10
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32)) * np.float32(0.9)
+    w = np.float32(1 + 2.0 ** -8 - 2.0 ** -12)          # rounds DOWN to 1.0            (exact 1.00366)
+    a = np.float32(1 + 2.0 ** -8 + 2.0 ** -12)          # rounds UP   to 1 + 2^-7       (exact 1.00415, filter 1.00781)
+    b = np.float32(1 - 2.0 ** -9 + 2.0 ** -12)          # rounds UP   to 1.0            (exact 0.99829)
+    q = np.abs(O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32)))
+    q[:Q // 2] = w * np.float32(2.0) ** rng.integers(-3, 1, size=(Q // 2, D)).astype(np.float32)   # queries made of understated elements too
+    s = np.float32(0.9 / np.sqrt(D))
+    half = np.arange(D) % 2 == 0
+    for j in range(Q):
+        # block j = the pattern scaled by (1 - j / 1000): block 0 holds every query's exact top-10 (all q > 0, rows parallel to 1)
+        for t in range(12):                               # the true winners: all elements understated, filter score 2.0 (in units of s)
+            X[j * 40 + t] = s * w * np.float32(1 - 1e-4 * t) * np.float32(1 - 1e-3 * j)
+        for t in range(12, 30):                           # decoys: exact 2.00244 < 2.00732, filter 2.00781 > 2.0
+            X[j * 40 + t] = s * np.where(half, a, b).astype(np.float32) * np.float32(1 - 5e-6 * t) * np.float32(1 - 1e-3 * j)
+    Do, Io = O.flat_ip_topk(q, X, k)
+    Xb = torch.from_numpy(X).to(torch.bfloat16).float().numpy()
+    qb = torch.from_numpy(q).to(torch.bfloat16).float().numpy()
+    bf_rank = np.argsort(-(qb.astype(np.float64) @ Xb.astype(np.float64).T), axis=1)[:, :k]
+    assert (np.sort(bf_rank, 1) != np.sort(Io, 1)).any(axis=1).mean() > 0.9     # a bf16-only ranking gets (almost) every query wrong
+    idx = _index(X)
+    res = {}
+    for mode in (1, 2):
+        search_mode(mode)
+        res[mode] = idx.search(q, k)
+    search_mode(0)
+    idx.two_pass = False
+    D6, I6 = idx.search(q, k)
+    for mode in (1, 2):
+        Dg, Ig = res[mode]
+        np.testing.assert_allclose(Dg.cpu().numpy(), Do, atol=3e-6, rtol=2e-6)
+        np.testing.assert_array_equal(Ig.cpu().numpy(), Io)
+        assert torch.equal(Ig, I6)
+        assert (Ig.cpu().numpy() < 12).all()                 # block 0's understated winners, not the overstated decoys
+
+
+def test_candidate_list_overflow_falls_back_per_query(search_mode):
+    """More rows inside T' - 2 eps than a candidate list holds (near-duplicate corpus): those queries must come back from the gated
+    six-product fallback, everything exact."""
+    rng = np.random.default_rng(8)
+    N, D, Q, k = 90000, 128, 48, 20
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32))
+    base = X[123].copy()
+    X[10000:40000] = O.l2_normalize(base[None, :] + 1e-4 * rng.standard_normal((30000, D)).astype(np.float32))   # 30k near-copies > CAND_CAP
+    X[50000:50010] = base
+    q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))
+    q[:5] = O.l2_normalize(base[None, :] + 0.01 * rng.standard_normal((5, D)).astype(np.float32))
+    idx = _index(X)
+    search_mode(2)
+    Dg, Ig = idx.search(q, k)
+    check_against_oracle(Dg, Ig, q, X, k, score_tol=3e-6, max_mismatch=0.12)
+    Do, Io = O.flat_ip_topk(q[5:], X, k)
+    assert (Ig[5:].cpu().numpy() == Io).mean() > 0.999
+    Xd = np.repeat(X[:50], 400, axis=0)                          # 20 000 rows, every vector 400 times: exact ties, lowest row first
+    idx2 = _index(Xd)
+    Dd, Id = idx2.search(q, 8)
+    _, Id_o = O.flat_ip_topk(q, Xd, 8)
+    np.testing.assert_array_equal(Id.cpu().numpy(), Id_o)
+
+
+def test_non_finite_query_does_not_poison_the_batch(search_mode):
+    rng = np.random.default_rng(3)
+    N, D, Q, k = 30000, 64, 40, 5
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32))
+    q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))
+    qn = q.copy()
+    qn[7, 3] = np.inf
+    idx = _index(X)
+    search_mode(2)
+    Dg, Ig = idx.search(qn, k)
+    keep = np.arange(Q) != 7
+    Do, Io = O.flat_ip_topk(q[keep], X, k)
+    np.testing.assert_array_equal(Ig.cpu().numpy()[keep], Io)
+
+
+def test_shard_commit_rows_kernel_shadow_and_bounds():
+    from lightretriever_amd import FlatIPIndex
+    rng = np.random.default_rng(1)
+    N, D = 5003, 192
+    X = (rng.standard_normal((N, D)) * rng.uniform(0.1, 4.0, size=(N, 1))).astype(np.float32)
+    idx = FlatIPIndex(D)
+    idx.add(X[:1000]); idx.add(X[1000:])
+    xb = torch.from_numpy(X).cuda().to(torch.bfloat16)
+    assert torch.equal(idx._xb[:N], xb)
+    R = np.linalg.norm(X.astype(np.float64), axis=1).max()
+    E = np.linalg.norm(X.astype(np.float64) - xb.float().cpu().numpy().astype(np.float64), axis=1).max()
+    b = idx._bounds.cpu().numpy()
+    assert R <= b[0] <= R * (1 + 1e-5) and E * (1 - 1e-6) <= b[1] <= E * (1 + 1e-4)
+    # no torch kernels are needed for maintenance: reset + refresh gives the same state again
+    idx._xb.zero_(); idx._bounds.zero_()
+    idx.refresh_norm_bound()
+    assert torch.equal(idx._xb[:N], xb) and np.array_equal(idx._bounds.cpu().numpy(), b)
+
+
+def test_encoder_writes_shadow_and_bounds_of_the_slot_it_fills():
+    """lrx_encode_packed_shard: rows encoded into a FlatIPIndex slot arrive with their bf16 shadow and the shard bounds -- commit() has
+    nothing left to do (no second pass over the rows), and searching them needs no refresh."""
+    from dataclasses import asdict
+    from lightretriever_amd import EncoderConfig, FlatIPIndex, LrxEncoder
+    cfg_o = O.EncoderConfig(vocab_size=500, hidden_size=256, num_layers=2, num_q_heads=4, num_kv_heads=2, head_dim=64,
+                            intermediate_size=512, rope_type="llama3", rope_original_max_position=64, max_positions=256)
+    w = O.random_weights(cfg_o, seed=1, std=0.04)
+    enc = LrxEncoder(EncoderConfig(**asdict(cfg_o)), {k: torch.from_numpy(v) for k, v in w.items()})
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 120, size=37)
+    ids = torch.from_numpy(rng.integers(0, 500, size=int(lens.sum())).astype(np.int32)).cuda()
+    cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).cuda()
+    idx = FlatIPIndex(256, capacity=64)
+    idx.add(np.zeros((3, 256), np.float32))                      # some rows already there
+    slot = idx.append_slot(37)
+    calls = []
+    orig = idx._maintain
+    idx._maintain = lambda a, b: (calls.append((a, b)), orig(a, b))
+    enc.encode_packed(ids, cu, int(lens.max()), out=slot)
+    idx.commit(37)
+    assert all(b <= a for a, b in calls), f"commit() re-read encoder rows: {calls}"
+    ref = enc.encode_packed(ids, cu, int(lens.max()))
+    assert torch.equal(idx.vectors[3:], ref)
+    assert torch.equal(idx._xb[3:40], ref.to(torch.bfloat16))
+    b = idx._bounds.cpu().numpy()
+    assert 1.0 <= b[0] < 1.00001 and 0 < b[1] < 2.0 ** -8
+    # in-place re-encode of committed rows (what bench.py does) keeps shadow + bounds valid without refresh_norm_bound()
+    enc.encode_packed(ids, cu, int(lens.max()), out=idx._x[3:40])
+    assert torch.equal(idx._xb[3:40], ref.to(torch.bfloat16))
+    # MRL slice narrower than the shard row: not a shard slot, plain output
+    out = enc.encode_packed(ids, cu, int(lens.max()), out_dim=64)
+    assert out.shape == (37, 64)
+
+
+# ---- BASELINE index shapes (configs 2-5): properties that do not need a CPU pass over the whole index -------------------------------
+def _fill_normalised(idx, N, D, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    slot = idx.append_slot(N)
+    step = max(1, (1 << 28) // D)
+    for s in range(0, N, step):
+        e = min(s + step, N)
+        slot[s:e] = torch.nn.functional.normalize(torch.randn(e - s, D, generator=g, device="cuda"), dim=-1)
+    idx.commit(N)
+    return g
+
+
+def _check_properties(idx, q, k, planted, Dg, Ig, chunk):
+    N, D, Q = idx.ntotal, idx.d, q.shape[0]
+    assert (Ig[:len(planted), 0] == planted).all() and torch.allclose(Dg[:len(planted), 0], torch.ones(len(planted), device="cuda"), atol=1e-5)
+    assert (Dg[:, 1:] <= Dg[:, :-1]).all()
+    assert all(len(set(r.tolist())) == k for r in Ig.cpu())
+    rec = torch.einsum("qkd,qd->qk", idx.vectors[Ig.reshape(-1)].view(Q, k, D).double(), q.double()).float()
+    assert torch.allclose(rec, Dg, atol=3e-6)
+    best = torch.full((Q,), -2.0, device="cuda")
+    better = torch.zeros(Q, device="cuda")
+    for s in range(0, N, chunk):
+        sc = q @ idx.vectors[s:s + chunk].T
+        best = torch.maximum(best, sc.max(dim=1).values)
+        better = better + (sc > Dg[:, -1:] + 3e-6).sum(1)
+    assert torch.allclose(best, Dg[:, 0], atol=3e-6)
+    assert (better <= k - 1).all()                                # nothing clearly better than the k-th result was missed
+
+
+@pytest.mark.parametrize("N,D", [(1_000_000, 4096), (10_000_000, 256)], ids=["config2_1Mx4096", "config5_10Mx256_mrl"])
+def test_baseline_index_shapes_properties(N, D, search_mode):
+    from lightretriever_amd import FlatIPIndex, merge_topk
+    Q, k = 100, 100
+    idx = FlatIPIndex(D, capacity=N)
+    g = _fill_normalised(idx, N, D, seed=11)
+    q = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device="cuda"), dim=-1)
+    planted = torch.randint(0, N, (10,), generator=g, device="cuda")
+    q[:10] = idx.vectors[planted]
+    Dg, Ig = idx.search(q, k)
+    _check_properties(idx, q, k, planted, Dg, Ig, chunk=max(1, (1 << 29) // D // 4))
+    search_mode(1)                                                # the score-matrix filter gives the same bits
+    Dm, Im = idx.search(q, k)
+    search_mode(0)
+    assert torch.equal(Im, Ig) and torch.equal(Dm, Dg)
+    # eight-way row shard + merge == whole index (config 4's layout; views of the same rows, no copy)
+    Dp, Ip = [], []
+    for r in range(8):
+        a, b = r * N // 8, (r + 1) * N // 8
+        sh = FlatIPIndex(D, id_base=a)
+        sh._x, sh._xb, sh._bounds, sh.ntotal = idx._x[a:b], idx._xb[a:b], idx._bounds, b - a
+        d, i = sh.search(q, k)
+        Dp.append(d), Ip.append(i)
+    Dm8, Im8 = merge_topk(torch.stack(Dp), torch.stack(Ip))
+    assert torch.equal(Im8, Ig) and torch.equal(Dm8, Dg)
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.get_device_properties(0).total_memory < 270 << 30, reason="needs one 288-GB GPU")
+def test_config3_10m_x_4096_single_gpu_properties():
+    """BASELINE config 3's whole index on ONE GPU: 164 GB of fp32 rows + 82 GB bf16 shadow + < 6 GB of search workspace.  Deselect
+    with -k 'not config3' when the box is short on time: filling the rows takes about a minute."""
+    from lightretriever_amd import FlatIPIndex
+    N, D, Q, k = 10_000_000, 4096, 100, 100
+    idx = FlatIPIndex(D, capacity=N)
+    idx._ensure_shadow()
+    g = _fill_normalised(idx, N, D, seed=13)
+    q = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device="cuda"), dim=-1)
+    planted = torch.randint(0, N, (10,), generator=g, device="cuda")
+    q[:10] = idx.vectors[planted]
+    Dg, Ig = idx.search(q, k)
+    _check_properties(idx, q, k, planted, Dg, Ig, chunk=32768)
+    assert idx._ws.numel() < 6 << 30
