@@ -29,6 +29,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define S_XTILE (S_ROWS * S_BK * 4)
 #define SP_ROWS 128      // corpus rows per workgroup of the split-bf16 kernel
 #define CAND_CAP 16384   // per-query capacity of the filter pass's emitted candidate list (score-free filter)
+#define CNT_STRIDE 64    // list fill counters sit 256 B apart: the reservations of different queries go to different memory channels
 
 __device__ __forceinline__ uint32_t f2key(float f) {  // monotone: larger float -> larger key
   uint32_t u = __float_as_uint(f);
@@ -408,28 +409,45 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
     }
   }
   if constexpr (EMIT) {
-    // D[i = corpus row][j = query]: lane holds query j = fi, rows fq*4 + {0..3}
+    // D[i = corpus row][j = query]: lane holds query j = fi, rows fq*4 + {0..3}.  All list reservations of a wave are issued before
+    // the first one is waited for (the atomics go to the memory side: ~2 us each, but independent).
+    float t[QT];
+    unsigned int c[QT][RT], p[QT][RT];
 #pragma unroll
     for (int b = 0; b < QT; ++b) {
       const int qi = b * 16 + fi;
-      const float t = qi < nq ? thr[qi] : FLT_MAX;
+      t[b] = qi < nq ? thr[qi] : FLT_MAX;
+    }
+#pragma unroll
+    for (int b = 0; b < QT; ++b)
 #pragma unroll
       for (int a = 0; a < RT; ++a) {
         const int64_t n = n0 + wave * 16 * RT + a * 16 + fq * 4;
-        unsigned int c = 0;
+        c[b][a] = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) c += (n + e < N && acc[a][b][e] >= t) ? 1u : 0u;
-        if (c && qi < nq) {
-          unsigned int p = atomicAdd(&cnt[qi], c);
+        for (int e = 0; e < 4; ++e) c[b][a] += (n + e < N && acc[a][b][e] >= t[b]) ? 1u : 0u;
+      }
+#pragma unroll
+    for (int b = 0; b < QT; ++b)
+#pragma unroll
+      for (int a = 0; a < RT; ++a) {
+        p[b][a] = 0;
+        if (c[b][a]) p[b][a] = atomicAdd(&cnt[(b * 16 + fi) * CNT_STRIDE], c[b][a]);
+      }
+#pragma unroll
+    for (int b = 0; b < QT; ++b)
+#pragma unroll
+      for (int a = 0; a < RT; ++a)
+        if (c[b][a]) {
+          const int64_t n = n0 + wave * 16 * RT + a * 16 + fq * 4;
+          unsigned int pp = p[b][a];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (n + e < N && acc[a][b][e] >= t) {
-              if (p < CAND_CAP) cand[(int64_t)qi * CAND_CAP + p] = sel_pack(f2key(acc[a][b][e]), n + e);
-              ++p;
+            if (n + e < N && acc[a][b][e] >= t[b]) {
+              if (pp < CAND_CAP) cand[(int64_t)(b * 16 + fi) * CAND_CAP + pp] = sel_pack(f2key(acc[a][b][e]), n + e);
+              ++pp;
             }
         }
-      }
-    }
     return;
   }
   __syncthreads();   // the k loop's last LDS reads are done before the epilogue reuses the buffer
@@ -953,8 +971,9 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
 //   fallback: a query whose list or band overflows (near-duplicate corpora) raises a device flag; the six-product pass + select +
 //           rescore are always enqueued behind it, gated on that flag (they return at once when it is 0), and overwrite only the
 //           flagged queries.  No host synchronisation anywhere.
-//   Small query batches (score matrix < 1/16 of the shadow bytes) and small shards keep the score-matrix filter: one launch less in
-//   the dependency chain.  Both give the same result -- everything ends in the same exact rescoring of a superset of the top-k.
+//   Very small query batches (Q < max(2, D / 256): the score matrix is < 2 % of the shadow bytes) and shards below 16 Ki rows keep the
+//   score-matrix filter: two launches less in the dependency chain (measured crossover: Q = 1 is 30-100 us faster that way, Q >= 16
+//   4-25 % slower).  Both give the same result -- everything ends in the same exact rescoring of a superset of the top-k.
 // ---------------------------------------------------------------------------------------------------------------
 #define REF_CAND 4096
 #define REF_BLK 8192
@@ -1019,7 +1038,7 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
         const float v = row[j];
         const int64_t g = (j / rb) * ((int64_t)ss * rb) + (j % rb);
         if (g < N && v >= thr) {
-          const unsigned int p = atomicAdd(&cnt[qi], 1u);
+          const unsigned int p = atomicAdd(&cnt[qi * CNT_STRIDE], 1u);
           if (p < CAND_CAP) list[p] = sel_pack(f2key(v), g);
         }
       }
@@ -1057,7 +1076,7 @@ k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
   if (D <= REF_QLDS)
     for (int i = tid; i < D; i += 1024) s_q[i] = qglob[i];
   if (tid == 0) s_ncand = 0;
-  const unsigned int n = cnt[qi];
+  const unsigned int n = cnt[qi * CNT_STRIDE];
   bool overflow = n > CAND_CAP || n < (unsigned int)k;      // (n < k cannot happen with a finite threshold: k sample rows reach it)
   __syncthreads();
   if (!overflow) {
@@ -1196,6 +1215,8 @@ struct BoundedPlan {
 };
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+static size_t ints_before_cnt(int nq) { return ((size_t)nq + 1 + 63) & ~(size_t)63; }
+
 static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow) {
   BoundedPlan p;
   memset(&p, 0, sizeof(p));
@@ -1210,7 +1231,7 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   while (ss > 2 && (lrx_cdiv(nwg, ss) - 1) * p.rb < 2 * (int64_t)k) ss >>= 1;
   const int64_t nsamp = lrx_cdiv(nwg, ss);
   const bool feasible = (nsamp - 1) * p.rb >= 2 * (int64_t)k && nwg - nsamp >= 1 && dim % 4 == 0 && (shadow || nq > 16 * (SPLIT_MIN_QT - 1));
-  p.emit = feasible && g_search_mode != 1 && (g_search_mode == 2 || (n_rows >= 16384 && 64 * (int64_t)nq > dim));
+  p.emit = feasible && g_search_mode != 1 && (g_search_mode == 2 || (n_rows >= 16384 && nq >= 2 && 256 * (int64_t)nq >= dim));
   p.ss = ss;
   p.nsamp_wg = nsamp;
   p.nmain_wg = nwg - nsamp;
@@ -1221,8 +1242,8 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   const size_t prim = p.emit ? (size_t)nq * (size_t)(p.ld_s + p.nblk_ld_s) : (size_t)nq * (size_t)(p.ld + p.nblk_ld);
   p.off_qsplit = align256((prim > fb ? prim : fb) * sizeof(float));
   p.off_ints = align256(p.off_qsplit + split_ws_bytes(dim));
-  // ints: flags[nq], any_flag, cnt[nq] (one memset) | part_cnt[nq * REF_SPLIT] | thr[nq] | eps[nq]
-  p.off_parts = align256(p.off_ints + sizeof(int) * ((size_t)nq * (4 + REF_SPLIT) + 1));
+  // ints: flags[nq], any_flag, pad to 64 ints, cnt[nq * CNT_STRIDE] (one memset) | part_cnt[nq * REF_SPLIT] | thr[nq] | eps[nq]
+  p.off_parts = align256(p.off_ints + sizeof(int) * (ints_before_cnt(nq) + (size_t)nq * (CNT_STRIDE + 2 + REF_SPLIT)));
   p.off_cand = align256(p.off_parts + (size_t)nq * REF_CAND * 8);
   p.total = p.off_cand + (p.emit ? (size_t)nq * CAND_CAP * 8 : 0);
   return p;
@@ -1280,13 +1301,13 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
     __bf16* qsplit = (__bf16*)(ws + p.off_qsplit);
     int* flags = (int*)(ws + p.off_ints);
     int* any_flag = flags + nq;
-    unsigned int* cnt = (unsigned int*)(any_flag + 1);
-    int* part_cnt = (int*)(cnt + nq);
+    unsigned int* cnt = (unsigned int*)(flags + ints_before_cnt(nq));
+    int* part_cnt = (int*)(cnt + (size_t)nq * CNT_STRIDE);
     float* thr = (float*)(part_cnt + (size_t)nq * REF_SPLIT);
     float* eps = thr + nq;
     unsigned long long* parts = (unsigned long long*)(ws + p.off_parts);
     unsigned long long* cand = (unsigned long long*)(ws + p.off_cand);
-    LRX_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (2 * (size_t)nq + 1), s));     // flags, any_flag, list counts
+    LRX_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (ints_before_cnt(nq) + (p.emit ? (size_t)nq * CNT_STRIDE : 0)), s));     // flags, any_flag, list counts
     int rc;
     if (p.emit) {
       float* blkmax = scores + p.ld_s * (int64_t)nq;

@@ -14,6 +14,8 @@ def main():
         e = min(s + 65536, N)
         slot[s:e] = torch.nn.functional.normalize(torch.randn(e - s, D, generator=g, device="cuda"), dim=-1)
     idx.commit(N)
+    if os.environ.get("MODE"):        # 1 = score-matrix filter, 2 = score-free filter (lrx_search_set_mode)
+        idx.lib.lrx_search_set_mode(int(os.environ["MODE"]))
     for Q in [int(x) for x in os.environ.get("QS", "1,16,32,48,100,128").split(",")]:
         q = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device="cuda"), dim=-1)
         for _ in range(2):
@@ -23,6 +25,18 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); idx.search(q, 100); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
         med = statistics.median(ts)
+        if os.environ.get("STATS") and idx._xb is not None and Q >= 4:
+            # what the score-free filter sees for a few queries: rows reaching the sample threshold T' - 2 eps, rows in the final band
+            xb, k, ss = idx._xb[:N], 100, 20
+            nb = (N + 127) // 128
+            samp = torch.arange(0, nb, ss, device="cuda").repeat_interleave(128) * 128 + torch.arange(128, device="cuda").repeat((nb + ss - 1) // ss)
+            samp = samp[samp < N]
+            for qi in range(4):
+                qb = q[qi].to(torch.bfloat16)
+                sc = (xb @ qb).float()
+                eps = float((q[qi] - qb.float()).norm() * idx._bounds[0] + qb.float().norm() * (idx._bounds[1] + (D + 32) * 2.0 ** -23 * idx._bounds[0]))
+                tp = float(sc[samp].topk(k).values[-1]); kth = float(sc.topk(k).values[-1])
+                print(f"   q{qi}: eps {eps:.5f}  T' {tp:.4f} kth~ {kth:.4f}  rows >= T'-2eps {int((sc >= tp - 2 * eps).sum())}  band rows {int((sc >= kth - 2 * eps).sum())}", flush=True)
         bpe = 2 if (idx._xb is not None and idx.two_pass) else 4
         print(f"Q={Q:4d}: {med:.3f} ms  -> {N*D*bpe/med/1e6:.0f} GB/s corpus stream ({bpe} B/element), {Q/med*1e3:.0f} q/s, {2*Q*D*N/med/1e9:.1f} TFLOP/s", flush=True)
 
