@@ -68,8 +68,12 @@ def usable_cores():
 
 
 def cpu_baseline(cfg, seq_len, topk, dim):
-    """The reference's CPU path on this box's host cores, bounded to ~10-30 s: (a) HF transformers LlamaModel (the model
-    code the reference's encode_passage executes) at the real config, bf16, sdpa; (b) flat IP via the oracle port."""
+    """The reference's CPU path on this box's host cores, on a bounded sample (~30 s), as SURVEY.md 8d words it:
+    (a) HF transformers LlamaModel (the model code the reference's encode_passage executes) at the real config, sdpa, batch 8 x
+        seq_len, fp32 AND bf16 -- both reported, the faster one is `value`;
+    (b) flat IP via the oracle port (Faiss is not installed);
+    (c) BASELINE configs[0] end to end on the CPU: 1k documents x 128 tokens + 100 queries -> top-k, from the measured S=128 encode
+        rate of a 16-document sample (the 1k-document encode itself would take minutes) + the measured oracle search over 1000 rows."""
     import numpy as np
     from transformers import LlamaConfig, LlamaModel
     cores = usable_cores()
@@ -81,22 +85,38 @@ def cpu_baseline(cfg, seq_len, topk, dim):
                                           "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192},
                          attn_implementation="sdpa")
     torch.manual_seed(0)
-    # fp32: the GPU box's host (EPYC 9575F) has no AMX-bf16; torch CPU bf16 GEMMs are far slower than fp32 there
     model = LlamaModel(hf_cfg).float().eval()
-    docs = 2
-    ids = torch.randint(1000, 127000, (docs, seq_len))
+
+    def run(ids, budget_s):
+        n_done, t0 = 0, time.perf_counter()
+        with torch.no_grad():
+            while True:
+                h = model(input_ids=ids, use_cache=False).last_hidden_state[:, -1]
+                torch.nn.functional.normalize(h.float(), dim=-1)
+                n_done += ids.shape[0]
+                if time.perf_counter() - t0 > budget_s:
+                    break
+        return n_done, time.perf_counter() - t0
+
+    batch = 8
+    ids = torch.randint(1000, 127000, (batch, seq_len))
     with torch.no_grad():
-        model(input_ids=ids[:1, :32], use_cache=False)  # touch the weights once (page-in), untimed
-    n_done, t0 = 0, time.perf_counter()
+        model(input_ids=ids[:1, :32], use_cache=False)   # touch the weights once (page-in), untimed
+    n32, s32 = run(ids, 6.0)
+    ids128 = torch.randint(1000, 127000, (16, 128))
+    n128, s128 = run(ids128, 1.0)                        # configs[0]'s sequence length
+    # bf16: the GPU box's host (EPYC 9575F) has no AMX; probe one short batch first and shrink the bf16 sample so the leg stays bounded
+    model = model.to(torch.bfloat16)
     with torch.no_grad():
-        while True:
-            h = model(input_ids=ids, use_cache=False).last_hidden_state[:, -1]
-            torch.nn.functional.normalize(h.float(), dim=-1)
-            n_done += docs
-            if time.perf_counter() - t0 > 10.0 or n_done >= 64:
-                break
-    enc_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        model(input_ids=ids[:1, :64], use_cache=False)
+        model(input_ids=ids[:1, :64], use_cache=False)
+        probe = (time.perf_counter() - t0) / 2
+    est_batch_s = probe * batch * seq_len / 64
+    b16 = batch if est_batch_s < 12.0 else max(1, int(batch * 12.0 / est_batch_s))
+    n16, s16 = run(ids[:b16], 0.0)                       # exactly one batch
     del model
+    fp32_rate, bf16_rate = n32 / s32, n16 / s16
     from oracle import lrx_oracle as O
     rng = np.random.default_rng(7)
     n_sample, nq = 50_000, 100
@@ -105,10 +125,19 @@ def cpu_baseline(cfg, seq_len, topk, dim):
     t0 = time.perf_counter()
     O.flat_ip_topk(q, X, topk)
     srch_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.flat_ip_topk(q, X[:1000], min(topk, 1000))
+    srch0_s = time.perf_counter() - t0
+    cfg0_s = 1000 / (n128 / s128) + srch0_s
     return {
-        "value": round(n_done / enc_s, 4), "unit": "docs/s", "cores": cores, "kind": "reference",
+        "value": round(max(fp32_rate, bf16_rate), 4), "unit": "docs/s", "cores": cores, "kind": "reference",
         "sample": f"HF transformers LlamaModel (the third-party forward the reference's encode_passage calls), random-init {cfg.num_layers}L/"
-                  f"H{cfg.hidden_size}, fp32, sdpa, {n_done} docs x {seq_len} tokens in {enc_s:.1f}s on {cores} threads",
+                  f"H{cfg.hidden_size}, sdpa, batch {batch} x {seq_len} tokens on {cores} threads: fp32 {n32} docs in {s32:.1f}s, "
+                  f"bf16 {n16} docs (batch {b16}) in {s16:.1f}s; value = the faster ({'fp32' if fp32_rate >= bf16_rate else 'bf16'})",
+        "fp32_docs_per_s": round(fp32_rate, 4), "bf16_docs_per_s": round(bf16_rate, 4),
+        "config0": {"workload": "BASELINE configs[0]: 1k docs x 128 tokens + 100 queries, CPU only", "seconds_end_to_end": round(cfg0_s, 1),
+                    "sample": f"encode rate at S=128 measured on {n128} docs in {s128:.1f}s (fp32, {n128 / s128:.2f} docs/s) scaled to 1000 docs + "
+                              f"oracle flat_ip_topk of 100 queries over 1000 x {dim} rows measured ({srch0_s * 1e3:.1f} ms)"},
         "search": {"value": round(nq / srch_s, 2), "unit": "queries/s", "kind": "port", "cores": cores,
                    "sample": f"oracle flat_ip_topk (numpy sgemm + lexsort) Q={nq}, k={topk} over {n_sample} x {dim} fp32 rows "
                              f"({srch_s:.2f}s); per-query cost scales linearly with rows",
@@ -120,30 +149,56 @@ def pmc_traffic(kernel_key):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC summary (tools/pmc_traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction); None when no summary is present."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
         return round(d[kernel_key]["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
 
 
+SEARCH_KERNELS = ("k_flat_ip_scores_split<NP=1,emit>", "k_flat_ip_scores_split<NP=1,scores>", "k_sample_threshold", "k_refine_band", "k_refine_merge")
+
+
 def pmc_search_traffic():
-    """filter pass + select + refine of one search (same PMC summary); None when the summary predates the two-pass search."""
-    parts = [pmc_traffic(k) for k in ("k_flat_ip_scores_split<NP=1>", "k_topk_select", "k_refine_topk", "k_refine_merge")]
+    """sample pass + threshold + main (emitting) filter pass + band refine + merge of one search (same PMC summary, per launch)."""
+    parts = [pmc_traffic(k) for k in SEARCH_KERNELS]
     return None if any(p is None for p in parts) else sum(parts)
 
 
 def pmc_mfma(kernel_key):
     """(mfma busy fraction, effective clock GHz) of a kernel from the committed PMC pass (tools/pmc_mfma.sh) or (None, None)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")))[kernel_key]
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_mfma.json")))[kernel_key]
         return d["mfma_busy_frac"], d["effective_clock_GHz"]
     except (OSError, KeyError, ValueError):
         return None, None
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process (before anything in
+    this process touches the GPU) and pass its exit code on.  Under a launcher (WORLD_SIZE set) the world size must equal --gpus."""
+    import subprocess
+    n_dev = torch.cuda.device_count()                     # (does not initialise the GPU on this image)
+    if n_dev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, n_dev))
+        sys.exit(2)
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: launched with WORLD_SIZE=%d but --gpus %d\n" % (world, args.gpus))
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # LRX_BENCH_FORCE_DIST=1: create the RCCL process group (and run every collective of the N>1 path) even with one rank --
@@ -196,6 +251,13 @@ def main():
         slot[s:e] = torch.nn.functional.normalize(torch.randn(e - s, D, generator=gi, device=dev), dim=-1)
     index.commit(shard_rows)
     sharded = ShardedFlatIPIndex(index)
+    # what RCCL itself reports: one all-gather of every rank's shard size (also the first collective: communicator set-up stays out
+    # of the timed regions)
+    rccl_ranks, shard_rows_all = (1, [shard_rows])
+    if distributed:
+        sizes = torch.empty(dist.get_world_size(), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sizes, torch.tensor([index.ntotal], dtype=torch.int64, device=dev))
+        rccl_ranks, shard_rows_all = dist.get_world_size(), sizes.tolist()
 
     def encode_step(i):
         out = index._x[i * B:(i + 1) * B]           # in place into the shard (no host round trip)
@@ -264,12 +326,13 @@ def main():
         search = {
             "metric": "queries/sec @ top-%d over %d-doc fp32 index" % (args.topk, args.index_rows), "value": round(args.queries * args.steps / srch_s, 2),
             "unit": "queries/s", "ms_per_pass": round(1e3 * srch_s / args.steps, 4), "queries": args.queries, "index_rows": args.index_rows,
-            "dim": D, "shard_rows": shard_rows, "scaling": "strong (fixed index row-sharded over ranks)",
+            "dim": D, "shard_rows": shard_rows, "shard_rows_per_rank": shard_rows_all, "rccl_ranks": rccl_ranks,
+            "scaling": "strong (fixed index row-sharded over ranks)",
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (local_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(alg_bytes / (local_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "traffic": pmc_search_traffic() if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100 and D == 2048) else None,
                          "algorithmic_bytes": alg_bytes,
-                         "kernel": "two-pass exact search: k_flat_ip_scores_split<QT,1,..,XB> (single-product filter over the bf16 shadow of the shard, HBM-bound) + k_topk_select + k_refine_topk/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
+                         "kernel": "two-pass exact search without a score matrix: k_flat_ip_scores_split<QT,1,..,XB,EMIT> (single-product filter over the bf16 shadow of the shard, HBM-bound; a strided 1/20 sample first -> k_sample_threshold, then the rest emitting only rows above the threshold) + k_refine_band/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
                          "fp32_equiv_tflops": round(2.0 * args.queries * D * shard_rows / (local_ms * 1e-3) / 1e12, 2),
                          "fp32_mfma_peak_for_reference": PEAK_F32_MFMA_TFLOPS},
         }
@@ -351,6 +414,7 @@ def main():
         "value": round(docs_per_s, 2), "unit": "docs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * enc_s / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights, uniform random token ids, N(0,1) normalised index rows)",
+        "rccl_ranks": rccl_ranks,
         "config": {"workload": ("lightretriever-%s bf16, %d docs/step x seq_len %d per GPU, dense top-%d over %d x %d fp32 index (BASELINE configs[1])"
                                 % (args.model, B, S, args.topk, args.index_rows, D)) if batches is None else
                                ("RAGGED variant (not the headline): lightretriever-%s bf16, %d docs/step, lengths clip(lognormal(5.3,0.6),16,%d) sorted "

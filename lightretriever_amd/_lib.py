@@ -78,6 +78,8 @@ SIGNATURES = {
     "lrx_flat_ip_score_ld": (_I64, [_I64]),
     "lrx_flat_ip_scores": (_I32, [_P, _I64, _I64, _I32, _P, _I32, _P, _P]),
     "lrx_merge_topk": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P, _P]),
+    "lrx_pack_topk": (_I32, [_P, _P, _P, _I64, _I64, _P, _P]),
+    "lrx_merge_topk_packed": (_I32, [_P, _I32, _I32, _I32, _P, _P, _P]),
 }
 
 _lib = None

@@ -1413,9 +1413,11 @@ extern "C" int lrx_shard_commit_rows(const float* X, int64_t ldx, int64_t n_rows
 // merge of R shard-local top-k lists
 // ---------------------------------------------------------------------------------------------------------------
 #define MERGE_MAX 8192
+// in_packed != NULL: the lists arrive as one 64-bit word per hit (fp32 score bits << 32 | row as uint32, row 0xFFFFFFFF = none) --
+// the form that crosses the all-gather (lrx_pack_topk)
 __global__ void __launch_bounds__(1024)
-k_merge_topk(const float* __restrict__ in_scores, const int64_t* __restrict__ in_ids, int R, int Q, int k, float* __restrict__ out_scores,
-             int64_t* __restrict__ out_ids) {
+k_merge_topk(const float* __restrict__ in_scores, const int64_t* __restrict__ in_ids, const unsigned long long* __restrict__ in_packed, int R, int Q,
+             int k, float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned long long* buf = (unsigned long long*)smem_raw;
   const int qi = blockIdx.x, n = R * k;
@@ -1426,8 +1428,13 @@ k_merge_topk(const float* __restrict__ in_scores, const int64_t* __restrict__ in
     if (i < n) {
       int rr = i / k, j = i - rr * k;
       int64_t src = ((int64_t)rr * Q + qi) * k + j;
-      int64_t id = in_ids[src];
-      if (id >= 0) c = ((unsigned long long)f2key(in_scores[src]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+      if (in_packed != nullptr) {
+        const unsigned long long w = in_packed[src];
+        if ((uint32_t)w != 0xFFFFFFFFu) c = ((unsigned long long)f2key(__uint_as_float((uint32_t)(w >> 32))) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)w);
+      } else {
+        int64_t id = in_ids[src];
+        if (id >= 0) c = ((unsigned long long)f2key(in_scores[src]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+      }
     }
     buf[i] = c;
   }
@@ -1436,12 +1443,12 @@ k_merge_topk(const float* __restrict__ in_scores, const int64_t* __restrict__ in
     unsigned long long c = i < P ? buf[i] : 0ull;
     int64_t o = (int64_t)qi * k + i;
     if (c == 0ull) { out_scores[o] = -FLT_MAX; out_ids[o] = -1; }
-    else { out_scores[o] = key2f((uint32_t)(c >> 32)); out_ids[o] = (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull)); }
+    else { out_scores[o] = key2f((uint32_t)(c >> 32)); out_ids[o] = sel_row(c); }
   }
 }
 
-extern "C" int lrx_merge_topk(const float* in_scores, const int64_t* in_ids, int32_t n_parts, int32_t n_queries, int32_t k,
-                              float* out_scores, int64_t* out_ids, void* stream) {
+static int merge_launch(const float* in_scores, const int64_t* in_ids, const unsigned long long* in_packed, int32_t n_parts, int32_t n_queries, int32_t k,
+                        float* out_scores, int64_t* out_ids, void* stream) {
   LRX_CHECK_ARG(n_parts > 0 && k > 0 && (int64_t)n_parts * k <= MERGE_MAX, "merge_topk: parts*k=%lld exceeds %d", (long long)n_parts * k, MERGE_MAX);
   if (n_queries <= 0) return LRX_OK;
   int P = 1;
@@ -1450,8 +1457,38 @@ extern "C" int lrx_merge_topk(const float* in_scores, const int64_t* in_ids, int
   if (smem > 48 * 1024) {
     LRX_HIP(hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   }
-  hipLaunchKernelGGL(k_merge_topk, dim3(n_queries), dim3(1024), smem, (hipStream_t)stream, in_scores, in_ids, n_parts, n_queries, k, out_scores,
-                     out_ids);
+  hipLaunchKernelGGL(k_merge_topk, dim3(n_queries), dim3(1024), smem, (hipStream_t)stream, in_scores, in_ids, in_packed, n_parts, n_queries, k,
+                     out_scores, out_ids);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+extern "C" int lrx_merge_topk(const float* in_scores, const int64_t* in_ids, int32_t n_parts, int32_t n_queries, int32_t k,
+                              float* out_scores, int64_t* out_ids, void* stream) {
+  return merge_launch(in_scores, in_ids, nullptr, n_parts, n_queries, k, out_scores, out_ids, stream);
+}
+
+extern "C" int lrx_merge_topk_packed(const uint64_t* in_packed, int32_t n_parts, int32_t n_queries, int32_t k, float* out_scores, int64_t* out_ids,
+                                     void* stream) {
+  return merge_launch(nullptr, nullptr, (const unsigned long long*)in_packed, n_parts, n_queries, k, out_scores, out_ids, stream);
+}
+
+// (score, id) -> the 64-bit wire word of the exchange; row_map (optional): id = row_map[id - id_base] for id >= 0 (local shard row ->
+// global row of the sorted corpus).  Global rows must fit 32 bits (< 2^32 - 1): checked by the caller that owns the numbering.
+__global__ void k_pack_topk(const float* __restrict__ D, const int64_t* __restrict__ I, const int64_t* __restrict__ row_map, int64_t id_base, int64_t n,
+                            unsigned long long* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t id = I[i];
+  if (id >= 0 && row_map != nullptr) id = row_map[id - id_base];
+  out[i] = ((unsigned long long)__float_as_uint(D[i]) << 32) | (unsigned long long)(id >= 0 ? (uint32_t)id : 0xFFFFFFFFu);
+}
+
+extern "C" int lrx_pack_topk(const float* scores, const int64_t* ids, const int64_t* row_map, int64_t id_base, int64_t n, uint64_t* out_packed,
+                             void* stream) {
+  if (n <= 0) return LRX_OK;
+  hipLaunchKernelGGL(k_pack_topk, dim3((unsigned)lrx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, scores, ids, row_map, id_base, n,
+                     (unsigned long long*)out_packed);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

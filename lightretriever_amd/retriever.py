@@ -391,7 +391,7 @@ def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: li
             key_of_row[row_of_key] = torch.arange(n, dtype=torch.int64, device=device)
     rank, world = DenseRetrievalFaissSearch._rank_world()
     if world > 1:
-        from .sharded import exchange_topk, local_to_global_rows
+        from .sharded import exchange_merge, local_to_global_rows
         if on_chunk is not None:
             raise NotImplementedError("a sparse engine needs the chunk's sparse vectors on the calling rank: single-process launch only")
     # the reference's own launch (eval/eval_utils.py: torch RPC, only rank 0 drives): shards live on the RPC workers
@@ -421,8 +421,7 @@ def _chunked_dense_search(searcher: FlatIPFaissSearch, query_embs, query_ids: li
             else:
                 D, I = searcher._retrieve_device(q, top_k)
             if world > 1:                             # one all-gather of the packed per-shard lists, merge on every rank
-                Dp, Ip = exchange_topk(D, I)
-                D, I = merge_topk(Dp, Ip)
+                D, I = exchange_merge(D, I)
             if ident is not None:                     # drop the qid == pid hit AFTER the per-chunk top_k, like the reference
                 hit = I == ident[:, None]
                 D = torch.where(hit, torch.full_like(D, -FLT_MAX), D)

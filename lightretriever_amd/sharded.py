@@ -29,7 +29,10 @@ def local_to_global_rows(n_docs: int, batch_size: int, rank: int, world: int) ->
 
 
 def pack_pairs(D: torch.Tensor, I: torch.Tensor) -> torch.Tensor:
-    """(score f32, global row i64 < 2^31 or -1) -> one int64 per hit: score bits in the high word, row in the low word."""
+    """(score f32, global row i64 < 2^32 - 1 or -1) -> one int64 per hit: score bits in the high word, row in the low word.  Torch form of
+    lrx_pack_topk for host tensors (tests); raises on rows the 32-bit field cannot carry instead of truncating them."""
+    if I.numel() and int(I.max()) >= 2 ** 32 - 1:
+        raise ValueError("pack_pairs: global row ids must be < 2^32 - 1")
     return (D.contiguous().view(torch.int32).to(torch.int64) << 32) | (I & 0xFFFFFFFF)
 
 
@@ -42,20 +45,47 @@ def unpack_pairs(P: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
 
 def exchange_topk(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
                   force_collective: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
-    """all-gather the packed [Q,k] lists of every rank -> ([R,Q,k] scores, [R,Q,k] global rows) on every rank.
+    """all-gather the packed [Q,k] lists of every rank -> ([R,Q,k] scores, [R,Q,k] global rows) on every rank, UNMERGED (host-side
+    tests and tools; the product path is exchange_merge, which keeps the wire words on the device end to end).
     Payload R*Q*k*8 bytes (640 KB at R=8,Q=100,k=100): latency-bound on xGMI, one collective, no pipelining."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    packed = pack_pairs(D, I)
     force_collective = force_collective or os.environ.get("LRX_FORCE_COLLECTIVE") == "1"     # one-rank rehearsal of the exchange
     if world == 1 and not (force_collective and dist.is_initialized()):
         return D.unsqueeze(0), I.unsqueeze(0)
+    return unpack_pairs(_all_gather_words(pack_pairs(D, I), world, group))
+
+
+def _all_gather_words(packed: torch.Tensor, world: int, group) -> torch.Tensor:
+    """[Q, k] int64 wire words of this rank -> [R, Q, k] on the same device (one all_gather_into_tensor)."""
     Q = packed.shape[0]
     dev = packed.device
     if packed.is_cuda and dist.get_backend(group) == "gloo":      # CPU-side process group (tests, debugging): stage the 8-byte pairs through the host
         packed = packed.cpu()
     out = torch.empty((world * Q,) + tuple(packed.shape[1:]), dtype=torch.int64, device=packed.device)   # concat form: nccl + gloo
     dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
-    return unpack_pairs(out.view((world, Q) + tuple(packed.shape[1:])).to(dev))
+    return out.view((world, Q) + tuple(packed.shape[1:])).to(dev)
+
+
+def exchange_merge(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.ProcessGroup] = None, row_map: Optional[torch.Tensor] = None,
+                   id_base: int = 0, force_collective: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
+    """This shard's device-resident (scores f32 [Q,k], ids i64 [Q,k]) -> the global top-k on every rank:
+    lrx_pack_topk (row map applied, one 64-bit word per hit) -> ONE RCCL all-gather -> lrx_merge_topk_packed.  No torch kernels."""
+    from . import _lib
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    force_collective = force_collective or os.environ.get("LRX_FORCE_COLLECTIVE") == "1"
+    collective = world > 1 or (force_collective and dist.is_initialized())
+    if not collective and row_map is None:
+        return D, I
+    lib = _lib.lib()
+    Q, k = D.shape
+    D, I = D.contiguous(), I.contiguous()
+    words = torch.empty(Q, k, dtype=torch.int64, device=D.device)
+    _lib.check(lib.lrx_pack_topk(_lib.ptr(D), _lib.ptr(I), _lib.ptr(row_map), int(id_base), Q * k, _lib.ptr(words), _lib.current_stream()))
+    allw = _all_gather_words(words, world, group) if collective else words.unsqueeze(0)
+    Dm = torch.empty(Q, k, dtype=torch.float32, device=D.device)
+    Im = torch.empty(Q, k, dtype=torch.int64, device=D.device)
+    _lib.check(lib.lrx_merge_topk_packed(_lib.ptr(allw), allw.shape[0], Q, k, _lib.ptr(Dm), _lib.ptr(Im), _lib.current_stream()))
+    return Dm, Im
 
 
 class ShardedFlatIPIndex:
@@ -64,8 +94,12 @@ class ShardedFlatIPIndex:
 
     def __init__(self, shard, row_map: Optional[torch.Tensor] = None, group=None):
         self.shard = shard
-        self.row_map = row_map
+        self.row_map = None if row_map is None else row_map.to(device=shard.device, dtype=torch.int64).contiguous()
         self.group = group
+        # the wire word carries the global row in 32 bits (0xFFFFFFFF = none)
+        top = int(self.row_map.max()) if (self.row_map is not None and self.row_map.numel()) else shard.id_base + max(shard._x.shape[0], shard.ntotal)
+        if top >= 2 ** 32 - 1:
+            raise ValueError(f"ShardedFlatIPIndex: global row {top} does not fit the 32-bit field of the exchange word")
 
     def search(self, q: torch.Tensor, k: int):
         D, I = self.shard.search(q, k)
@@ -73,11 +107,4 @@ class ShardedFlatIPIndex:
 
     def finish(self, D: torch.Tensor, I: torch.Tensor):
         """local (scores, ids) of this shard -> global top-k on every rank (row map, all-gather, on-device merge)."""
-        from .index import merge_topk
-        if self.row_map is not None:
-            valid = I >= 0
-            I = torch.where(valid, self.row_map[(I - self.shard.id_base).clamp(min=0)], I)
-        Dp, Ip = exchange_topk(D, I, self.group)
-        if Dp.shape[0] == 1:
-            return D, I
-        return merge_topk(Dp, Ip)
+        return exchange_merge(D, I, self.group, row_map=self.row_map, id_base=self.shard.id_base)

@@ -372,3 +372,16 @@ def test_reference_eval_arguments_build_on_the_import_path_shim():
          "--score_function", "cos_sim", "--q_max_len", "512", "--p_max_len", "512", "--bf16"])
     assert a.top_k == 1000 and a.corpus_chunk_size == 100000 and a.normalize is True and a.encode_sparse is False
     assert a.model_type == "HybridModel" and a.inference_arch == "PytorchRPCExactSearchModel" and max(a.k_values) <= a.top_k
+
+
+def test_bench_gpus_flag_is_checked_before_any_gpu_work():
+    """`bench.py --gpus N` must never silently benchmark a different number of GPUs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=2 but --gpus 1" in r.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "--gpus 64 but only" in r.stderr

@@ -5,7 +5,7 @@
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/pmc_r01
+OUT=$R/gpurun_out/pmc_r02
 mkdir -p $OUT
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1 || echo "fetch pass failed"
