@@ -77,6 +77,13 @@ typedef struct lrx_encoder_weights {
   const lrx_layer_weights* layers; /* HOST array of num_layers structs (device pointers inside) */
 } lrx_encoder_weights;
 
+/* What torch.ops.lrx.encode_packed takes as its `weights` argument: the address of one of these (both structs owned, and kept
+ * alive, by whoever built them -- LrxEncoder.handle on the Python side).                                                       */
+typedef struct lrx_encoder_handle {
+  const lrx_encoder_config* cfg;
+  const lrx_encoder_weights* w;
+} lrx_encoder_handle;
+
 /* Workspace (device bytes) needed by lrx_encode_packed for `total_tokens` packed tokens in `n_seqs` sequences. */
 size_t lrx_encode_workspace_bytes(const lrx_encoder_config* cfg, int32_t total_tokens, int32_t n_seqs);
 

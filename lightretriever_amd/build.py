@@ -46,7 +46,34 @@ def build(force: bool = False, verbose: bool = True, defines=(), out: str = None
     return lib_path
 
 
+TORCH_LIB = os.path.join(HERE, "liblrx_torch.so")
+
+
+def build_torch_ops(force: bool = False, verbose: bool = True) -> str:
+    """liblrx_torch.so: the TORCH_LIBRARY(lrx, ...) registration layer over liblrx.so (csrc/lrx_torch.cpp), compiled in-tree against the
+    installed PyTorch-ROCm headers.  Plain host C++ (no device code): the kernels stay in liblrx.so."""
+    src = os.path.join(CSRC, "lrx_torch.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "lrx.h")]
+    if not force and os.path.exists(TORCH_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(TORCH_LIB) for d in deps) and os.path.exists(LIB):
+        return TORCH_LIB
+    build(force=False, verbose=verbose)
+    import torch
+    from torch.utils import cpp_extension as ce
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [hipcc, "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + p for p in ce.include_paths()] + ["-I/opt/rocm/include", src, "-o", TORCH_LIB, "-L" + tlib, "-L" + HERE, "-llrx", "-ltorch", "-ltorch_cpu",
+                                                    "-ltorch_hip", "-lc10", "-lc10_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    if verbose:
+        print("[lrx build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TORCH_LIB
+
+
 if __name__ == "__main__":
     defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
     outs = [a[6:] for a in sys.argv[1:] if a.startswith("--out=")]
     print(build(force="--force" in sys.argv, defines=defs, out=outs[0] if outs else None))
+    if not defs and not outs:
+        print(build_torch_ops(force="--force" in sys.argv))

@@ -249,6 +249,15 @@ class LrxEncoder:
         if not (ids.is_cuda and cu_seqlens.is_cuda and ids.is_contiguous() and cu_seqlens.is_contiguous()):
             raise ValueError("ids and cu_seqlens must be contiguous CUDA tensors")
 
+    @property
+    def handle(self) -> int:
+        """Address of an lrx_encoder_handle {cfg*, weights*} for torch.ops.lrx.encode_packed (valid while this encoder lives)."""
+        if getattr(self, "_handle", None) is None:
+            class _H(C.Structure):
+                _fields_ = [("cfg", C.c_void_p), ("w", C.c_void_p)]
+            self._handle = _H(C.addressof(self._ccfg), C.addressof(self._cw))
+        return C.addressof(self._handle)
+
     def encode_packed(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, out: Optional[torch.Tensor] = None,
                       out_dim: Optional[int] = None, normalize: bool = True) -> torch.Tensor:
         """ids int32 [T], cu_seqlens int32 [B+1] (device).  Writes fp32 [B, out_dim] rows into `out` (e.g. a slice of the

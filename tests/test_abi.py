@@ -48,3 +48,17 @@ def test_graft_entry_build_runs_on_cpu():
     entry = importlib.import_module("__graft_entry__")
     entry.build()
     assert callable(entry.smoke)
+
+
+def test_torch_library_registers_every_op_without_a_gpu():
+    """SURVEY 8b last row: the extension exports torch.ops.lrx.* (TORCH_LIBRARY in csrc/lrx_torch.cpp, built in-tree)."""
+    import torch
+    assert os.path.exists(build.build_torch_ops(verbose=False))
+    from lightretriever_amd import torch_ops
+    for op in torch_ops.OPS:
+        schema = str(getattr(torch.ops.lrx, op).default._schema)
+        assert schema.startswith("lrx::" + op + "(")
+    # host-side argument checks raise RuntimeError (TORCH_CHECK), never crash: CPU tensors have no CUDA kernel registered
+    import pytest
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.lrx.flat_ip_topk(torch.zeros(2, 32), torch.zeros(10, 32), 3)
