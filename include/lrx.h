@@ -158,8 +158,13 @@ int lrx_get_profile(float* ms, double* flops, int32_t* launches);
  * Individual kernels (unit-tested one by one against the oracle; same arithmetic the fused path uses)
  * ---------------------------------------------------------------------------------------------------------- */
 
-/* out[t,:] = table[ids[t],:]  (nn.Embedding inside LlamaModel.forward)  bf16 */
-int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, void* out, void* stream);
+/* out[t,:] = table[ids[t],:]  (nn.Embedding inside LlamaModel.forward)  bf16.  An id outside [0, vocab) never reaches the table: its
+ * row is zero-filled and a device-side counter is raised (lrx_device_error_count).                                               */
+int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, int32_t vocab, void* out,
+                         void* stream);
+/* Number of out-of-range token ids any embedding gather (stand-alone or inside lrx_encode_*) has met since the last reset; -1 if the
+ * read failed.  SYNCHRONISES the device (a blocking copy): call it at a point where the caller waits for results anyway.         */
+int64_t lrx_device_error_count(int32_t reset);
 
 /* LlamaRMSNorm (modeling_llama.py:53-67): y = w * bf16(x * rsqrt(mean(x^2) + eps)); x, w, y bf16; rows x hidden */
 int lrx_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps, void* stream);

@@ -63,7 +63,8 @@ SIGNATURES = {
     "lrx_finalize_rscale": (_I32, [_P, _I32, _I32, _I32, C.c_float, _P, _P]),
     "lrx_set_profiling": (None, [_I32]),
     "lrx_get_profile": (_I32, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
-    "lrx_embedding_gather": (_I32, [_P, _P, _I32, _I32, _P, _P]),
+    "lrx_embedding_gather": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P]),
+    "lrx_device_error_count": (_I64, [_I32]),
     "lrx_rmsnorm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P]),
     "lrx_gemm_bf16_nt": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "lrx_gemm_qkv_rope": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),

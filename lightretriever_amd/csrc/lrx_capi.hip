@@ -137,7 +137,7 @@ static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights
   const int H = c->hidden_size, d = c->head_dim, nq = c->num_q_heads, nkv = c->num_kv_heads, I = c->intermediate_size;
   const int QKV = (nq + 2 * nkv) * d, QD = nq * d;
   int rc;
-  { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, ids, T, H, ws.x, s))) return rc; }
+  { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, ids, T, H, c->vocab_size, ws.x, s))) return rc; }
   { ProfScope p(s, 6, 0); if ((rc = lrx_build_positions(cu, n_seqs, T, ws.pos, s))) return rc; }
   // causal attention flops: sum over sequences is not known on the host without a sync; use the dense upper bound for
   // equal-length batches: n_seqs * S*(S+1)/2 with S = T / n_seqs (exact when all sequences have the same length)
@@ -334,7 +334,7 @@ extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_enco
   if (prefix_len > 0) {
     const int P1 = prefix_len;
     if ((rc = lrx_uniform_layout(pw.cu, ws.pos, 1, P1, 0, s))) return rc;
-    if ((rc = lrx_embedding_gather(w->embed, prefix_ids, P1, H, ws.x, s))) return rc;
+    if ((rc = lrx_embedding_gather(w->embed, prefix_ids, P1, H, c->vocab_size, ws.x, s))) return rc;
     for (int l = 0; l < c->num_layers; ++l) {
       const lrx_layer_weights& L = w->layers[l];
       const void* a_in; const float* rs_in;
@@ -353,7 +353,7 @@ extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_enco
   // ---- pass 2: the suffix tokens of all sequences
   const int T = n_seqs * suffix_len;
   if ((rc = lrx_uniform_layout(pw.cu, ws.pos, n_seqs, suffix_len, prefix_len, s))) return rc;
-  { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, suffix_ids, T, H, ws.x, s))) return rc; }
+  { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, suffix_ids, T, H, c->vocab_size, ws.x, s))) return rc; }
   for (int l = 0; l < c->num_layers; ++l) {
     const lrx_layer_weights& L = w->layers[l];
     const void* a_in; const float* rs_in;

@@ -5,24 +5,47 @@
 // ---------------------------------------------------------------------------------------------------------------
 // embedding gather: one wave per token row
 // ---------------------------------------------------------------------------------------------------------------
+// ids outside [0, vocab) never index the table: the row becomes zeros and a device-side counter is raised (read by
+// lrx_device_error_count; the tokenizer / checkpoint pairing is wrong when that happens -- the host checks len(tokenizer) <= vocab).
+__device__ unsigned int g_bad_token_ids = 0;
+
 __global__ void __launch_bounds__(256) k_embedding_gather(const bf16x8* __restrict__ table, const int32_t* __restrict__ ids,
-                                                          int n_tokens, int chunks /* H/8 */, bf16x8* __restrict__ out) {
+                                                          int n_tokens, int chunks /* H/8 */, int vocab, bf16x8* __restrict__ out) {
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_tokens) return;
   int lane = threadIdx.x & 63;
-  int64_t src = (int64_t)ids[row] * chunks;
+  const int id = ids[row];
   int64_t dst = (int64_t)row * chunks;
+  if (id < 0 || id >= vocab) {
+    if (lane == 0) atomicAdd(&g_bad_token_ids, 1u);
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+    for (int c = lane; c < chunks; c += 64) out[dst + c] = z;
+    return;
+  }
+  int64_t src = (int64_t)id * chunks;
   for (int c = lane; c < chunks; c += 64) out[dst + c] = table[src + c];
 }
 
-extern "C" int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, void* out,
+extern "C" int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, int32_t vocab, void* out,
                                     void* stream) {
-  LRX_CHECK_ARG(hidden % 8 == 0 && n_tokens >= 0, "embedding_gather: hidden %% 8 != 0");
+  LRX_CHECK_ARG(hidden % 8 == 0 && n_tokens >= 0 && vocab > 0, "embedding_gather: hidden %% 8 != 0 or vocab <= 0");
   if (n_tokens == 0) return LRX_OK;
   hipLaunchKernelGGL(k_embedding_gather, dim3(lrx_cdiv(n_tokens, 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16x8*)table, ids, n_tokens, hidden / 8, (bf16x8*)out);
+                     (const bf16x8*)table, ids, n_tokens, hidden / 8, vocab, (bf16x8*)out);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
+}
+
+extern "C" int64_t lrx_device_error_count(int32_t reset) {
+  unsigned int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bad_token_ids), sizeof(v)) != hipSuccess) return -1;
+  if (reset && v) {
+    const unsigned int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bad_token_ids), &z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return (int64_t)v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

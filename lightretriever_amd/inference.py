@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from .loader import default_special_tokens, encoder_from_pretrained, load_tokenizer
+from .loader import default_special_tokens, encoder_from_pretrained, load_model_args, load_tokenizer
 from .modeling import LrxExactSearchModel, LrxHybridModel
 
 
@@ -123,8 +123,27 @@ class InferenceArguments:
         self.encode_sparse = self.hybrid_use_sparse_vector or self.hybrid_use_token_id_vector   # modeling_hybrid.py:241-245
 
 
+def arguments_from_checkpoint(model_name_or_path: str, **overrides) -> "InferenceArguments":
+    """InferenceArguments resumed from the checkpoint's model_args.yaml (EncoderModel._load_model_args,
+    finetune/modeling_encoder.py:635-656): every field this path knows takes the value the retriever was trained with, extra keys
+    are ignored (allow_extra_keys=True in the reference), explicit keyword overrides win."""
+    import dataclasses
+    saved = load_model_args(model_name_or_path)
+    known = {f.name for f in dataclasses.fields(InferenceArguments)}
+    kw = {k: v for k, v in saved.items() if k in known and v is not None}
+    kw.update(overrides)
+    kw["model_name_or_path"] = model_name_or_path
+    return InferenceArguments(**kw)
+
+
 class PytorchRPCExactSearchModel(LrxExactSearchModel):
     """Drop-in for eval/eval_utils.py:179 `PytorchRPCExactSearchModel(args)`."""
+
+    @classmethod
+    def load(cls, model_name_or_path: str, args: Optional[InferenceArguments] = None, **overrides) -> "PytorchRPCExactSearchModel":
+        """HybridModel.load(path, model_args=None) (finetune/modeling_hybrid.py:909-957): without arguments the flags come from the
+        checkpoint's own model_args.yaml."""
+        return cls(args if args is not None else arguments_from_checkpoint(model_name_or_path, **overrides))
 
     def __init__(self, args: InferenceArguments):
         self.args = args
@@ -135,7 +154,8 @@ class PytorchRPCExactSearchModel(LrxExactSearchModel):
                              add_eos_num=args.add_eos_num if args.edit_tokenizer_post_processor else -1,
                              add_pad_token=args.add_pad_token, pad_token=args.pad_token, add_sep_token=args.add_sep_token,
                              sep_token=args.sep_token)
-        enc = encoder_from_pretrained(args.model_name_or_path, max_positions=max(args.p_max_len, args.q_max_len, 64), device=dev)
+        enc = encoder_from_pretrained(args.model_name_or_path, max_positions=max(args.p_max_len, args.q_max_len, 64), device=dev, tokenizer=tok,
+                                      pad_to_multiple_of=getattr(args, "pad_to_multiple_of", None))
         hm = LrxHybridModel(enc, normalize=args.normalize, dense_shrink_dim=args.dense_shrink_dim, pad_token_id=tok.pad_token_id,
                             encode_sparse=args.encode_sparse, sep_token_id=getattr(tok, "sep_token_id", None), add_sep_token=args.add_sep_token,
                             sparse_use_relu=args.sparse_use_relu, sparse_use_log_saturation=args.sparse_use_log_saturation,

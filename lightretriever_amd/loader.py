@@ -15,7 +15,7 @@ from typing import Optional
 
 import torch
 
-from .encoder import EncoderConfig, LrxEncoder, lora_merge
+from .encoder import EncoderConfig, LrxEncoder
 
 
 def _read_safetensors(dirname: str, stem: str = "model") -> dict:
@@ -33,16 +33,98 @@ def _read_safetensors(dirname: str, stem: str = "model") -> dict:
 
 
 def _strip(name: str) -> Optional[str]:
-    """HF causal-LM parameter name -> name relative to the inner model (`model.` prefix dropped); lm_head is unused."""
-    for pre in ("base_model.model.model.", "base_model.model.", "model."):
+    """HF causal-LM parameter name -> name relative to the inner model (`model.` prefix dropped; the CausalLM head keeps its own
+    name `lm_head.*`: the sparse branch projects with it, finetune/modeling_hybrid.py:72-86 get_lm_head)."""
+    for pre in ("base_model.model.", ):
         if name.startswith(pre):
-            return name[len(pre):]
-    return None if name.startswith("lm_head") else name
+            name = name[len(pre):]
+    if name.startswith("lm_head."):
+        return name
+    return name[len("model."):] if name.startswith("model.") else name
 
 
-def load_hf_checkpoint(path: str, max_positions: int = 512) -> tuple[EncoderConfig, dict]:
-    """-> (EncoderConfig, state_dict with names like `layers.0.self_attn.q_proj.weight`), LoRA merged if `path` is an
-    adapter directory."""
+def _lora_scale(acfg: dict, module: str) -> float:
+    """peft's scaling for one target module: lora_alpha / r (alpha / sqrt(r) with use_rslora), r and alpha overridable per module
+    through rank_pattern / alpha_pattern (keys are module-name suffixes or regexes, peft/tuners/lora/model.py)."""
+    import math
+    import re
+
+    def pick(pattern: dict, default):
+        for key, val in (pattern or {}).items():
+            if re.match(rf"(.*\.)?({key})$", module):
+                return val
+        return default
+
+    r = int(pick(acfg.get("rank_pattern"), acfg["r"]))
+    alpha = float(pick(acfg.get("alpha_pattern"), acfg["lora_alpha"]))
+    return alpha / math.sqrt(r) if acfg.get("use_rslora") else alpha / r
+
+
+def merge_lora_adapter(sd: dict, adapter: dict, acfg: dict) -> dict:
+    """peft merge_and_unload on a plain state dict (finetune/modeling_encoder.py:616-625): W += scale * B @ A for every LoRA pair,
+    `modules_to_save` / saved embedding layers replace the base tensor.  Options that change the arithmetic are applied
+    (use_rslora, rank_pattern, alpha_pattern, fan_in_fan_out); anything this merge does not implement raises -- an adapter tensor
+    is never dropped silently."""
+    if acfg.get("use_dora"):
+        raise NotImplementedError("LoRA adapter with use_dora=True (weight-decomposed LoRA) is not supported by this loader")
+    if acfg.get("bias", "none") != "none":
+        raise NotImplementedError(f"LoRA adapter trained with bias={acfg['bias']!r}: bias deltas are not merged by this loader")
+    pairs, unused = {}, []
+    for k, v in adapter.items():
+        k = k.replace(".default.", ".").replace(".default", "")
+        if ".lora_A." in k or ".lora_B." in k:
+            mod, which = (k.split(".lora_A.")[0], "A") if ".lora_A." in k else (k.split(".lora_B.")[0], "B")
+            pairs.setdefault(_strip(mod), {})[which] = v
+        elif ".modules_to_save." in k:                   # a fully trained copy of the module (e.g. embed_tokens / lm_head after adding tokens)
+            name = _strip(k.replace(".modules_to_save.", "."))
+            sd[name] = v
+        elif ".original_module." in k:
+            continue                                     # peft's frozen copy next to modules_to_save
+        elif _strip(k) in sd or _strip(k) in ("lm_head.weight", "embed_tokens.weight"):   # embedding layers saved with the adapter (save_embedding_layers)
+            sd[_strip(k)] = v
+        else:
+            unused.append(k)
+    if unused:
+        raise NotImplementedError(f"adapter tensors this loader cannot merge (lora_embedding_*, DoRA magnitudes, ...): {unused[:5]}"
+                                  f"{' ...' if len(unused) > 5 else ''}")
+    for mod, ab in pairs.items():
+        name = mod + ".weight"
+        if name == "lm_head.weight" and name not in sd:  # LoRA on the head of a tied model: the merged head is its own tensor
+            sd[name] = sd["embed_tokens.weight"].clone()
+        if name not in sd:
+            raise KeyError(f"LoRA target {name} not found in the base model")
+        if "A" not in ab or "B" not in ab:
+            raise KeyError(f"LoRA target {mod}: lora_A / lora_B pair incomplete")
+        delta = ab["B"].float() @ ab["A"].float()
+        if acfg.get("fan_in_fan_out"):
+            delta = delta.T
+        sd[name] = (sd[name].float() + _lora_scale(acfg, mod) * delta).to(sd[name].dtype)
+    return sd
+
+
+def resize_embeddings(cfg: EncoderConfig, sd: dict, n_tokens: int, pad_to_multiple_of: Optional[int] = None) -> None:
+    """resize_emb (utils/data_utils.py:273-281): a tokenizer that gained special tokens needs as many embedding rows.  The reference
+    lets HF draw the new rows at random (mean-resizing); here they are the mean of the existing rows (the centre of that
+    distribution), deterministic.  A no-op for the released checkpoints, whose special tokens pre-exist."""
+    rows = sd["embed_tokens.weight"].shape[0]
+    if n_tokens <= rows:
+        return
+    new_rows = n_tokens if not pad_to_multiple_of else -(-n_tokens // pad_to_multiple_of) * pad_to_multiple_of
+    import logging
+    logging.getLogger(__name__).warning("tokenizer has %d tokens but the checkpoint %d embedding rows: growing to %d (new rows = mean row)",
+                                        n_tokens, rows, new_rows)
+    for name in ("embed_tokens.weight", "lm_head.weight"):
+        if name in sd:
+            w = sd[name]
+            extra = w.float().mean(0, keepdim=True).to(w.dtype).expand(new_rows - rows, -1)
+            sd[name] = torch.cat([w, extra], 0)
+    cfg.vocab_size = new_rows
+
+
+def load_hf_checkpoint(path: str, max_positions: int = 512, n_tokens: Optional[int] = None,
+                       pad_to_multiple_of: Optional[int] = None) -> tuple[EncoderConfig, dict]:
+    """-> (EncoderConfig, state_dict with names like `layers.0.self_attn.q_proj.weight`, plus `lm_head.weight` when the checkpoint
+    has an untied head), LoRA merged if `path` is an adapter directory; embeddings grown to n_tokens (= len(tokenizer)) if needed."""
     adapter_cfg = os.path.join(path, "adapter_config.json")
     if os.path.exists(adapter_cfg):
         acfg = json.load(open(adapter_cfg))
@@ -50,32 +132,50 @@ def load_hf_checkpoint(path: str, max_positions: int = 512) -> tuple[EncoderConf
         if not os.path.isdir(base):
             raise FileNotFoundError(f"LoRA base model {base!r} is not a local directory (no network here)")
         cfg, sd = load_hf_checkpoint(base, max_positions)
-        scale_alpha, r = float(acfg["lora_alpha"]), int(acfg["r"])
-        ad = _read_safetensors(path, "adapter_model")
-        pairs = {}
-        for k, v in ad.items():
-            k = k.replace(".default", "")
-            if ".lora_A." in k or ".lora_B." in k:
-                mod, which = (k.split(".lora_A.")[0], "A") if ".lora_A." in k else (k.split(".lora_B.")[0], "B")
-                pairs.setdefault(_strip(mod), {})[which] = v
-        for mod, ab in pairs.items():
-            name = mod + ".weight"
-            if name not in sd:
-                raise KeyError(f"LoRA target {name} not found in the base model")
-            sd[name] = lora_merge(sd[name], ab["A"], ab["B"], scale_alpha, r)
-        return cfg, sd
-    cfg = EncoderConfig.from_hf_dict(json.load(open(os.path.join(path, "config.json"))), max_positions)
-    sd = {}
-    for k, v in _read_safetensors(path).items():
-        n = _strip(k)
-        if n is not None:
-            sd[n] = v
+        sd = merge_lora_adapter(sd, _read_safetensors(path, "adapter_model"), acfg)
+        cfg.vocab_size = sd["embed_tokens.weight"].shape[0]
+    else:
+        hf = json.load(open(os.path.join(path, "config.json")))
+        cfg = EncoderConfig.from_hf_dict(hf, max_positions)
+        sd = {_strip(k): v for k, v in _read_safetensors(path).items()}
+        if hf.get("tie_word_embeddings", False):
+            sd.pop("lm_head.weight", None)               # tied: the head IS the embedding matrix (LrxEncoder falls back to it)
+        elif "lm_head.weight" not in sd:
+            raise KeyError(f"{path}: config.json says tie_word_embeddings=false but the checkpoint has no lm_head.weight")
+        if sd["embed_tokens.weight"].shape[0] != cfg.vocab_size:
+            raise ValueError(f"{path}: embed_tokens has {sd['embed_tokens.weight'].shape[0]} rows, config.json vocab_size={cfg.vocab_size}")
+    if n_tokens is not None:
+        resize_embeddings(cfg, sd, n_tokens, pad_to_multiple_of)
     return cfg, sd
 
 
-def encoder_from_pretrained(path: str, max_positions: int = 512, device: Optional[torch.device] = None) -> LrxEncoder:
-    cfg, sd = load_hf_checkpoint(path, max_positions)
+def encoder_from_pretrained(path: str, max_positions: int = 512, device: Optional[torch.device] = None, tokenizer=None,
+                            pad_to_multiple_of: Optional[int] = None) -> LrxEncoder:
+    """tokenizer: when given, the embedding matrix is grown to len(tokenizer) like the reference's resize_emb, and the result is
+    checked: every id the tokenizer can produce must have a row."""
+    cfg, sd = load_hf_checkpoint(path, max_positions, n_tokens=len(tokenizer) if tokenizer is not None else None,
+                                 pad_to_multiple_of=pad_to_multiple_of)
+    if tokenizer is not None and len(tokenizer) > cfg.vocab_size:
+        raise ValueError(f"tokenizer has {len(tokenizer)} tokens but the model only {cfg.vocab_size} embedding rows")
     return LrxEncoder(cfg, sd, device)
+
+
+def load_model_args(path: str) -> dict:
+    """model_args.yaml written next to a trained retriever by EncoderModel.save (finetune/modeling_encoder.py:820-822) and read back
+    by EncoderModel._load_model_args (:635-656) when HybridModel.load(path) is called without arguments: the flags the checkpoint
+    was trained with (pooling, normalisation, tokenizer surgery, MRL dims, sparse options ...)."""
+    import yaml
+    f = os.path.join(path, "model_args.yaml")
+    if not os.path.exists(f):
+        raise FileNotFoundError(f"{f} not found: pass the model arguments explicitly")
+
+    class _Loader(yaml.SafeLoader):
+        pass
+    # yaml.dump(model_args.__dict__) tags non-plain values (torch dtypes, tuples, enums); they never matter on this path
+    _Loader.add_multi_constructor("tag:yaml.org,2002:python/", lambda loader, suffix, node: None)
+    d = yaml.load(open(f), Loader=_Loader) or {}
+    d["model_name_or_path"] = path                       # the reference re-points the args at the directory they were loaded from
+    return d
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -447,6 +447,15 @@ class LrxExactSearchModel:
     max_batch_tokens: int = 131072             # encode(): consecutive batches are merged up to this many tokens (0 = off; 256 x 512)
     max_batch_docs: int = 2048                 # ... and this many documents (bounds the [docs, vocab] sparse activations)
 
+    def __post_init__(self):
+        # every id the tokenizer can produce needs an embedding row (the reference grows the matrix with resize_emb,
+        # utils/data_utils.py:273-281; loader.encoder_from_pretrained(tokenizer=...) does the same).  The gather kernel zero-fills and
+        # counts out-of-range ids instead of reading outside the table, but a model that reaches it is misconfigured: fail here.
+        enc = getattr(self.model, "encoder", None)
+        if enc is not None and self.tokenizer is not None and hasattr(self.tokenizer, "__len__") and len(self.tokenizer) > enc.cfg.vocab_size:
+            raise ValueError(f"tokenizer has {len(self.tokenizer)} tokens but the encoder only {enc.cfg.vocab_size} embedding rows "
+                             "(load the encoder with loader.encoder_from_pretrained(..., tokenizer=tokenizer))")
+
     def token_id_reps(self, items: list[dict]) -> list[dict]:
         """Parameter-free sparse query vectors (exact_search_base.py:380-431): raw text with a leading whitespace, no specials,
         {str(token id): count} ('sum') or {str(token id): 1} ('bow')."""

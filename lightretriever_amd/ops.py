@@ -14,7 +14,7 @@ def _s():
 
 def embedding_gather(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     out = torch.empty(ids.numel(), table.shape[1], dtype=torch.bfloat16, device=table.device)
-    _lib.check(_lib.lib().lrx_embedding_gather(_lib.ptr(table), _lib.ptr(ids), ids.numel(), table.shape[1], _lib.ptr(out), _s()))
+    _lib.check(_lib.lib().lrx_embedding_gather(_lib.ptr(table), _lib.ptr(ids), ids.numel(), table.shape[1], table.shape[0], _lib.ptr(out), _s()))
     return out
 
 

@@ -357,3 +357,16 @@ def test_folded_and_unfolded_encoders_agree_and_both_match_fp32():
     assert min_cos(outs[True], outs[False]) > 0.9995
     ref = g["dense_reps"]
     assert min_cos(outs[True], ref) > 0.999 and min_cos(outs[True], ref) >= min_cos(outs[False], ref) - 2e-4
+
+
+def test_embedding_gather_never_reads_outside_the_table():
+    """an out-of-range / negative token id gives a zero row and raises the device-side counter instead of an
+    out-of-bounds HBM read; the fused encoder uses the same kernel."""
+    from lightretriever_amd import _lib, ops
+    lib = _lib.lib()
+    lib.lrx_device_error_count(1)
+    table = torch.randn(50, 64, device="cuda").bfloat16()
+    ids = torch.tensor([0, 49, 50, -1, 7, 1 << 30], dtype=torch.int32, device="cuda")
+    out = ops.embedding_gather(table, ids)
+    assert torch.equal(out[[0, 1, 4]], table[[0, 49, 7]]) and (out[[2, 3, 5]] == 0).all()
+    assert lib.lrx_device_error_count(1) == 3 and lib.lrx_device_error_count(0) == 0

@@ -244,3 +244,39 @@ def test_encode_corpus_and_queries_carry_sparse_vectors():
     assert set(model.encode_queries(["memory search search"], batch_size=1)["token_id_reps"][0].values()) == {1}
     score = lambda qr, pr: sum(v * pr[k] for k, v in qr.items() if k in pr)
     assert score(q["token_id_reps"][0], res["sparse_reps"][1]) >= 0
+
+
+def test_untied_lm_head_matches_reference_golden(tmp_path):
+    """a checkpoint with tie_word_embeddings=false must project the sparse branch with its OWN head, through the
+    loader (safetensors dir -> load_hf_checkpoint -> LrxEncoder.lm_head), not with embed_tokens.  Golden = the reference's
+    HybridModel.encode_passage on the same untied tiny model (tests/golden/gen_sparse_untied_golden.py)."""
+    from safetensors.torch import save_file
+    from lightretriever_amd.loader import encoder_from_pretrained
+    from lightretriever_amd.modeling import LrxHybridModel
+    cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    g = np.load(os.path.join(GOLDEN, "sparse_untied.npz"))
+    head = np.random.default_rng(int(g["head_seed"])).standard_normal((cfg_o.vocab_size, cfg_o.hidden_size)).astype(np.float32) * np.float32(0.05)
+    head = torch.from_numpy(head).to(torch.bfloat16)
+    d = tmp_path / "untied-llama"
+    d.mkdir()
+    sd = {"model." + k: torch.from_numpy(v).to(torch.bfloat16).contiguous() for k, v in w.items()}
+    sd["lm_head.weight"] = head.contiguous()
+    save_file(sd, str(d / "model.safetensors"))
+    json.dump({"model_type": "llama", "vocab_size": cfg_o.vocab_size, "hidden_size": cfg_o.hidden_size, "intermediate_size": cfg_o.intermediate_size,
+               "num_hidden_layers": cfg_o.num_layers, "num_attention_heads": cfg_o.num_q_heads, "num_key_value_heads": cfg_o.num_kv_heads,
+               "head_dim": cfg_o.head_dim, "rms_norm_eps": cfg_o.rms_eps, "tie_word_embeddings": False,
+               "rope_parameters": {"rope_type": "llama3", "rope_theta": cfg_o.rope_theta, "factor": cfg_o.rope_factor, "low_freq_factor": cfg_o.rope_low_freq_factor,
+                                   "high_freq_factor": cfg_o.rope_high_freq_factor, "original_max_position_embeddings": cfg_o.rope_original_max_position}},
+              open(d / "config.json", "w"))
+    enc = encoder_from_pretrained(str(d), max_positions=512)
+    assert enc.lm_head is not None and torch.equal(enc.lm_head.cpu(), head)
+    hm = LrxHybridModel(enc, normalize=True, encode_sparse=True, sep_token_id=int(g["sep_token_id"]), add_sep_token=True, sparse_round_bf16=False,
+                        sparse_use_relu=True, sparse_use_log_saturation=True)
+    out = hm.encode_passage({"input_ids": torch.from_numpy(g["input_ids"]), "attention_mask": torch.from_numpy(g["attention_mask"])})
+    sp = out["sparse_reps"].cpu().numpy()
+    assert np.abs(sp - g["sparse_reps"]).max() < 0.06 and np.abs(sp - g["sparse_reps_autocast"]).max() < 0.06
+    np.testing.assert_array_equal((g["sparse_reps"] > 0).sum(1) == 0, (sp > 0).sum(1) == 0)
+    assert ((sp > 0) == (g["sparse_reps"] > 0)).mean() > 0.985
+    tied = np.load(os.path.join(GOLDEN, "sparse.npz"))["sparse_reps"]
+    assert np.abs(sp - tied).max() > 0.5                           # and it is NOT what the embedding matrix would give
+    assert min_cos(out["dense_reps"].cpu().numpy(), g["dense_reps"]) > 0.998
