@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(HERE, "csrc")
+CSRC = os.environ.get("LRX_CSRC_DIR") or os.path.join(HERE, "csrc")   # env override: tools/ diagnostic variants build from a patched copy
 LIB = os.path.join(HERE, "liblrx.so")
 SOURCES = ["lrx_capi.hip", "lrx_elementwise.hip", "lrx_gemm.hip", "lrx_attn.hip", "lrx_search.hip", "lrx_sparse.hip", "lrx_fuse.hip"]
 

@@ -1,6 +1,8 @@
 // C-ABI glue: error state, the fused encoder forward (launch sequence over the kernels in this directory), profiling.
 #include "lrx_common.h"
 #include <stdarg.h>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -16,7 +18,10 @@ extern "C" int lrx_abi_version(void) { return LRX_ABI_VERSION; }
 // ---------------------------------------------------------------------------------------------------------------
 // profiling (HIP events on the caller's stream)
 // ---------------------------------------------------------------------------------------------------------------
-static bool g_prof = false;
+// Process-wide, guarded by g_prof_mu: the per-batch operator may be called from several host threads (the reference calls it from
+// TensorPipe RPC server threads).  The unprofiled fast path reads one atomic flag and takes no lock.
+static std::mutex g_prof_mu;
+static std::atomic<bool> g_prof{false};
 static uint32_t g_prof_mask = 0xffffffffu;   // classes that get events
 static float g_prof_ms[LRX_PROF_CLASSES];
 static double g_prof_flops[LRX_PROF_CLASSES];
@@ -37,6 +42,8 @@ static hipEvent_t prof_event() {
 struct ProfScope {
   hipStream_t s; int cls; hipEvent_t a = nullptr, b = nullptr;
   ProfScope(hipStream_t s_, int cls_, double flops) : s(s_), cls(cls_) {
+    if (!g_prof.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof || !((g_prof_mask >> cls_) & 1u)) return;
     a = prof_event(); b = prof_event();
     if (a) (void)hipEventRecord(a, s);
@@ -44,7 +51,8 @@ struct ProfScope {
     g_prof_launches[cls] += 1;
   }
   ~ProfScope() {
-    if (!g_prof || !a || !b) return;
+    if (!a || !b) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     (void)hipEventRecord(b, s);
     g_recs.push_back({a, b, cls});
   }
@@ -59,11 +67,13 @@ static void prof_reset() {
 static void prof_begin() {}
 static int prof_end(hipStream_t) { return LRX_OK; }
 extern "C" void lrx_set_profiling(int32_t enabled) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof = enabled != 0;
   g_prof_mask = enabled > 1 ? ((uint32_t)enabled >> 1) : 0xffffffffu;   // 1 = every class, otherwise bit (c + 1) selects class c
   prof_reset();
 }
 extern "C" int lrx_get_profile(float* ms, double* flops, int32_t* launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_recs) {
     float t = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) g_prof_ms[r.cls] += t;

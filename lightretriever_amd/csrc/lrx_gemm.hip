@@ -79,48 +79,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
     G_BAR();                                               \
   } while (0)
 
-#ifdef GEMM_TRACE
-// diagnostic build only (tools/gemm_timeline.py): per-workgroup wall-clock stamps {start, main loop done, end} + hardware id
-__device__ long long g_gemm_trace[8 * 65536];
-extern "C" int lrx_debug_read_gemm_trace(void* dst, size_t bytes) {
-  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_trace), bytes) == hipSuccess ? 0 : 1;
-}
-#define G_TRACE(slot)                                                                                   \
-  do {                                                                                                  \
-    if (threadIdx.x == 0 && blockIdx.x < 65536) g_gemm_trace[8 * blockIdx.x + (slot)] = wall_clock64(); \
-  } while (0)
-#else
-#define G_TRACE(slot)
-#endif
 
-// Diagnostic builds only (tools/gemm_ablate.sh): GEMM_ABL bit 0 = no LDS-DMA inside the K loop, bit 1 = no fragment ds_reads inside
-// the K loop, bit 2 = no barriers inside the K loop, bit 3 = no counted waits, bit 4 = the DMA fetches only K-tiles 0/1 (cache-hot),
-// bit 5 = no B1 request in P2 (4 + 2 DMA instructions per K-tile), bit 6 = no A1 request in P1 (6 + 0),
-// bit 7 = plain VGPR loads instead of LDS-DMA, bit 8 = 32x32x16 MFMAs instead of 16x16x32 (same FLOPs, same operand registers).  Results are garbage (in-bounds); only the time matters.
-#ifndef GEMM_ABL
-#define GEMM_ABL 0
-#endif
-#define ABL_DMA(x)  do { if (!(GEMM_ABL & 1)) { x; } } while (0)
-#define ABL_LDS(x)  do { if (!(GEMM_ABL & 2)) { x } } while (0)
-#define ABL_BAR(x)  do { if (!(GEMM_ABL & 4)) { x; } } while (0)
-#define ABL_WAIT(x) do { if (!(GEMM_ABL & 8)) { x; } } while (0)
 
 template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
                const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope, MaxAggArgs mx, NormArgs nrm) {
   __shared__ __attribute__((aligned(1024))) char smem[8 * HALF_BYTES];  // [buf 0/1][A0 | A1 | B0 | B1]
-
-  G_TRACE(0);
-#ifdef GEMM_TRACE
-  if (threadIdx.x == 0 && blockIdx.x < 65536) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    g_gemm_trace[8 * blockIdx.x + 3] = ((long long)xcc << 32) | hw;
-  }
-#endif
   // ---- workgroup -> tile
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
@@ -152,7 +117,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     pB1[i] = B + (int64_t)min(n0 + 128 + row, N - 1) * K + c * 8;
   }
   char* const dma_dst = smem + wave * 2048;  // + buf*65536 + slot*16384 + i*1024
-#define G_KOFF(KT) ((GEMM_ABL & 16) ? ((KT) & 1) * GBK : (KT) * GBK)   /* bit 4: only K-tiles 0/1 are ever fetched (cache-hot DMA) */
+#define G_KOFF(KT) ((KT) * GBK)
 #define G_ISSUE(P, SLOT, BUF, KT)                                                                                          \
   do {                                                                                                                     \
     __builtin_amdgcn_global_load_lds((gptr_t)(P[0] + G_KOFF(KT)), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES), 16, 0, 0);        \
@@ -211,8 +176,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   }
 
   G_BAR();
-  G_TRACE(4);
-  if (wr == 1) ABL_BAR(G_BAR());  // stagger: group 1 runs one barrier behind group 0
+  if (wr == 1) G_BAR();  // stagger: group 1 runs one barrier behind group 0
 
   bf16x8 b2[2][2];
 #define G_LDB2(HP)                                                                                   \
@@ -224,96 +188,37 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[H][HP][mi][ni] =                        \
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[ni][ks], a[mi][ks], acc[H][HP][mi][ni], 0, 0, 0); \
   } while (0)
-#if GEMM_ABL & 256
-  // bit 8: the same FLOPs issued as v_mfma_f32_32x32x16_bf16 (8 per quadrant) on the same operand registers -- fragment layouts do
-  // not match (garbage results): compares the energy of the two instruction shapes at the power cap
-  f32x16 acc32[2][2][2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int hp = 0; hp < 2; ++hp)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc32[h][hp][rt][e] = 0.f;
-#undef G_MM
-#undef G_MM2
-#define G_MM32(H, HP, BR)                                                                                       \
-  do {                                                                                                          \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)           \
-        acc32[H][HP][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BR[ks >> 1][ks & 1], a[2 * rt + (ks >> 1)][ks & 1], acc32[H][HP][rt], 0, 0, 0); \
-  } while (0)
-  // four independent accumulator chains per phase (a 32x32x16 result is ready 16 passes later): both quadrants round-robin
-#define G_MM(H, HP)                                                                                               \
-  do {                                                                                                            \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) {           \
-      acc32[H][0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks >> 1][ks & 1], a[2 * rt + (ks >> 1)][ks & 1], acc32[H][0][rt], 0, 0, 0);  \
-      acc32[H][1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2[ks >> 1][ks & 1], a[2 * rt + (ks >> 1)][ks & 1], acc32[H][1][rt], 0, 0, 0); \
-    }                                                                                                             \
-  } while (0)
-#define G_MM2(H, HP) do { } while (0)
-#endif
   // Lifetimes: A0,B0,B1 of K-tile t are read in P1(t) (B fragments stay in registers), A1 in P2(t).  Refill one phase after
   // the last read (stagger-safe): P2(t) issues A0,B0,B1 of t+2, P1(t) issues A1 of t+1 (t >= 1; K-tile 1's comes from the
   // prologue).  Counted waits: vmcnt(8) in both phases = the 2 + 6 youngest DMA instructions stay in flight.
-#if GEMM_ABL & 128
-  // bit 7: the requests of the K loop are plain global_load_dwordx4 into sink registers (the LDS keeps K-tiles 0/1 of the prologue): the issue cost of a VGPR load
-  f32x4 sink0 = {0.f, 0.f, 0.f, 0.f}, sink1 = {0.f, 0.f, 0.f, 0.f};
-#undef G_ISSUE
-#define G_ISSUE(P, SLOT, BUF, KT)                                                                           \
-  do {                                                                                                          \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink0) : "v"(P[0] + G_KOFF(KT)) : "memory");          \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink1) : "v"(P[1] + G_KOFF(KT)) : "memory");          \
-  } while (0)
-#endif
-#if GEMM_ABL & 2
-  { const char* sbuf = smem; G_LDB(0) G_LDB2(1) G_LDA(0) }
-#endif
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     const char* sbuf = smem + cur * 65536;
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
     // P1: quadrants (A0,B0) and (A0,B1)
-    ABL_LDS(G_LDB(0) G_LDB2(1) G_LDA(0));
-    if (t >= 1 && n1 && !(GEMM_ABL & 64)) ABL_DMA(G_ISSUE(pA1, 1, cur ^ 1, t + 1));          // A1(t+1): its slot (A1 of t-1) was last read in P2(t-1)
-    if (n1 && n2) ABL_WAIT(asm volatile("s_waitcnt vmcnt(8)" ::: "memory")); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A1(t) landed
-    ABL_BAR(G_LSYNC());
+    G_LDB(0) G_LDB2(1) G_LDA(0)
+    if (t >= 1 && n1) G_ISSUE(pA1, 1, cur ^ 1, t + 1);          // A1(t+1): its slot (A1 of t-1) was last read in P2(t-1)
+    if (n1 && n2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A1(t) landed
+    G_LSYNC();
     __builtin_amdgcn_s_setprio(1);
     G_MM(0, 0); G_MM2(0, 1);
     __builtin_amdgcn_s_setprio(0);
-    ABL_BAR(G_BAR());
+    G_BAR();
     // P2: quadrants (A1,B1) and (A1,B0)
-    ABL_LDS(G_LDA(1));
+    G_LDA(1)
     if (n2) {
-      ABL_DMA(G_ISSUE(pA0, 0, cur, t + 2); G_ISSUE(pB0, 2, cur, t + 2); if (!(GEMM_ABL & 32)) G_ISSUE(pB1, 3, cur, t + 2));
-      ABL_WAIT(asm volatile("s_waitcnt vmcnt(8)" ::: "memory"));
+      G_ISSUE(pA0, 0, cur, t + 2); G_ISSUE(pB0, 2, cur, t + 2); G_ISSUE(pB1, 3, cur, t + 2);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    ABL_BAR(G_LSYNC());
+    G_LSYNC();
     __builtin_amdgcn_s_setprio(1);
     G_MM2(1, 1); G_MM(1, 0);
     __builtin_amdgcn_s_setprio(0);
-    ABL_BAR(G_BAR());
+    G_BAR();
   }
-  if (wr == 0) ABL_BAR(G_BAR());
-#if GEMM_ABL & 128
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("" ::"v"(sink0), "v"(sink1));
-#endif
-#if GEMM_ABL & 256
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int hp = 0; hp < 2; ++hp)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[h][hp][mi][ni][e] += acc32[h][hp][mi >> 1][(mi & 1) * 8 + ni * 4 + e];
-#endif
-  G_TRACE(1);
+  if (wr == 0) G_BAR();
 
   // ---- epilogue.  The accumulator layout (lane = 1 row x 4 columns per 16x16 tile) would give 8-byte stores that touch 16
   //      partial lines per wave instruction (measured: 6-20 us per tile).  Instead the bf16 C tile is staged through the
@@ -372,7 +277,6 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
       }
     }
   __syncthreads();
-  G_TRACE(5);
   if (EPI == EPI_MAXAGG) {
     // Segmented column maximum of the staged bf16 logits tile (utils/max_linear_map.py:8-88 without the [B,S,V] tensor):
     // wave w owns columns [32w, 32w+32); a lane walks rows (lane>>3) + 8*step holding 4 columns.  Rows map to output rows
@@ -508,12 +412,6 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     *(bf16x8*)(C + (int64_t)m * ldc + n) = v;
   }
   }  // it0 batches
-#ifdef GEMM_TRACE
-  G_TRACE(6);
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  G_TRACE(2);
-#endif
 }
 
 // m-tiles per group of the block -> tile map, per epilogue class (measured, see the kernel); LRX_GEMM_GM overrides it for sweeps

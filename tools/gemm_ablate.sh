@@ -5,6 +5,11 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 MASKS="${MASKS:-0 1 2 4 3 12 13 15}"
 if [ "$1" = "build" ]; then
+  # the ablation / trace variants live in tools/exp/gemm_diagnostics.patch, not in the product kernel: build from a patched copy
+  D=$R/lightretriever_amd/build/diag_csrc; rm -rf $D; mkdir -p $D; cp $R/lightretriever_amd/csrc/* $D/
+  patch -s $D/lrx_gemm.hip < $R/tools/exp/gemm_diagnostics.patch || exit 1
+  sed -i 's#"../../include/lrx.h"#"'$R'/include/lrx.h"#' $D/lrx_common.h
+  export LRX_CSRC_DIR=$D
   for m in $MASKS; do python3 -m lightretriever_amd.build -DGEMM_ABL=$m --out=$R/lightretriever_amd/build/liblrx_abl$m.so > /dev/null || exit 1; done
   exit 0
 fi

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-CU timeline of one GEMM launch (diagnostic build: python lightretriever_amd/build.py -DGEMM_TRACE --out=.../liblrx_trace.so,
+"""Per-CU timeline of one GEMM launch (diagnostic build from a csrc copy patched with tools/exp/gemm_diagnostics.patch -- see
+tools/gemm_ablate.sh for the recipe --: LRX_CSRC_DIR=<copy> python lightretriever_amd/build.py -DGEMM_TRACE --out=.../liblrx_trace.so,
 then LRX_LIB_DEV_VARIANT=.../liblrx_trace.so python tools/gemm_timeline.py).  Each workgroup stamps start / main loop done / end and
 its hardware id; this script reports, per epilogue class, tile time, epilogue time, the gap between consecutive workgroups on the
 same CU, and how many CUs are inside their epilogue at the same moment."""
