@@ -32,6 +32,8 @@ struct AttnGeom {
   __device__ static __forceinline__ int xv(int row) { return D == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
 };
 
+#define LAZY_T 8.0f   // exponent head-room of the lazy softmax reference maximum
+
 constexpr int attn_dma_waves(int insts, int nw) {   // largest divisor of insts that is <= nw
   int d = nw < insts ? nw : insts;
   while (insts % d != 0) --d;
@@ -41,72 +43,103 @@ constexpr int attn_dma_waves(int insts, int nw) {   // largest divisor of insts 
 template <int D, int GRP>
 __global__ void __launch_bounds__(128 * GRP)
 k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu, int nqt, int nq, int nkv,
-                     __bf16* __restrict__ out, float scale_log2, int last_tile_only, int nparts) {
+                     __bf16* __restrict__ out, float scale_log2, int last_tile_only, int nparts, int n_seqs, int n_items, int gs) {
   using G = AttnGeom<D>;
   constexpr int NW = 2 * GRP;
   constexpr int KS = D / 16;  // k-steps of the QK^T product
   constexpr int DT = D / 32;  // 32-row tiles of O^T
   // K/V ring: 3 stages with a counted vmcnt (two tiles in flight; a tile's compute, ~0.5 us, is shorter than the load
-  // latency, so one tile of prefetch leaves every barrier waiting on HBM) whenever every wave issues the same number of
-  // LDS-DMA instructions per tile; otherwise 2 stages with a full drain.
+  // latency, so one tile of prefetch leaves every barrier waiting on HBM).
   // The first DW waves (a divisor of the instruction count, e.g. 8 of the 12 waves of a GQA-6 group) issue the LDS-DMA, the same
   // number each, so the counted wait is one immediate for everybody (waves without loads have nothing outstanding).
+  // (Tried: running the workgroup's two halves half a tile apart, two barriers per tile, so that one half's softmax sits beside
+  // the other's MFMAs -- 1.143 -> 1.173 ms at d = 128: the loop is not bound by that pairing, see the ablation in DESIGN.md.)
   constexpr int DW = attn_dma_waves(G::INSTS, NW);
-  constexpr bool RING3 = (3 * 2 * G::TILE_BYTES <= 96 * 1024);
-  constexpr int NST = RING3 ? 3 : 2;
-  constexpr int PER_TILE = RING3 ? 2 * (G::INSTS / DW) : 0;  // LDS-DMA instructions per issuing wave per tile (K + V)
+  constexpr int NST = 3;
+  static_assert(NST * 2 * G::TILE_BYTES <= 96 * 1024, "K/V ring");
+  constexpr int PER_TILE = 2 * (G::INSTS / DW);  // LDS-DMA instructions per issuing wave per tile (K + V)
+  constexpr bool PREFQ = 128 * GRP <= 768;       // 14-16 waves per workgroup have 128 VGPRs each: no room for a second Q fragment set
   __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * G::TILE_BYTES];  // [stage][K|V]
-
-  // GRP = q heads handled by this workgroup; a GQA group of nq/nkv heads is covered by nparts workgroups (head_dim 128 needs ~190
-  // VGPRs per wave: more than 8 waves per workgroup would spill, so groups of 6/7/8 heads are split in two)
-  const int b = last_tile_only ? blockIdx.x : blockIdx.x / nqt;
-  const int hk = blockIdx.y / nparts, part = blockIdx.y - hk * nparts;
-  const int grp_total = nq / nkv;
-  const int s0 = cu[b], len = cu[b + 1] - s0;
-  // last_tile_only: one q tile per sequence, the one holding its last token (all the pooled path needs of the last layer)
-  const int qt = last_tile_only ? ((len - 1) >> 6) : nqt - 1 - (blockIdx.x - b * nqt);  // else: heavy (late) q tiles first
-  const int qtile0 = qt * 64;
-  if (qtile0 >= len) return;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: branches on it stay scalar
   const int r = lane & 31, h = lane >> 5;
-  const int head_in_grp = part * GRP + (wave % GRP);
-  const int hq = hk * grp_total + min(head_in_grp, grp_total - 1);
-  const int q0 = qtile0 + (wave / GRP) * 32;
-  const bool active = q0 < len && head_in_grp < grp_total;
   const int64_t RS = (int64_t)(nq + 2 * nkv) * D;
-  const __bf16* kbase = qkv + (int64_t)s0 * RS + (int64_t)(nq + hk) * D;
-  const __bf16* vbase = kbase + (int64_t)nkv * D;
+  const int grp_total = nq / nkv;
 
-  // ---- Q fragments (B operand): Q[q0 + r][16 ks + 8 h .. +7]
-  bf16x8 qf[KS];
-  {
-    const int qrow = min(q0 + r, len - 1);
-    const __bf16* qp = qkv + ((int64_t)s0 + qrow) * RS + (int64_t)hq * D + h * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-  }
+  // Persistent workgroups: the grid is one workgroup per CU-slot, each walks a list of work items (sequence, kv head[, part], q tile).
+  // (A 96-KiB-LDS workgroup is alone on its CU; with one item per workgroup the CU sat empty a third of the time between a
+  // workgroup's exit and its successor's first instruction -- PMC: 64 workgroups x 18 us of wave lifetime per CU in a 1.85 ms launch.)
+  // The list is built for L2 reuse: the nqt q tiles of one (sequence, kv head) re-read the same K/V tiles (4.5x at S = 512), so they
+  // run at the same time on `gs` workgroups of ONE XCD (blocks b and b + 8 share an XCD: observed dispatch rule, speed only) --
+  // in q-tile-major order over the whole launch every re-read came from HBM and the load + barrier skeleton alone took 0.77 of
+  // the 1.4 ms.  Slot j of a group takes q tiles j, j + gs, ... of its group's current pair, from the long end on even steps and
+  // from the short end on odd ones, so every slot sees the same number of K/V tiles over two steps.
+  // The K/V tiles of all the items of a workgroup form ONE stream through the ring: the prefetch runs two tiles ahead of the
+  // compute across item boundaries (its own walker over the same item list), and the next item's Q fragments are requested during
+  // the current item's last tile -- an item boundary costs no load latency.
+  const int ny = nkv * nparts;
+  const int n_pairs = n_seqs * ny;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int g4 = gs > 0 ? slot / gs : 0, jslot = gs > 0 ? slot % gs : 0, gpx = gs > 0 ? (int)(gridDim.x >> 3) / gs : 1;
+  struct Walk { int step, kq, item; };
+  struct Item { int pair, qt, s0, len; };      // pair < 0: end of the list
+  auto next_item = [&](Walk& w) -> Item {
+    for (;;) {
+      int pair, qt_sel = -1;
+      if (gs > 0) {
+        pair = (w.step * gpx + g4) * 8 + xcd;
+        if (pair >= n_pairs) return Item{-1, 0, 0, 0};
+        const int idx = jslot + w.kq * gs;
+        if (idx >= nqt) { ++w.step; w.kq = 0; continue; }
+        qt_sel = (w.step & 1) ? idx : nqt - 1 - idx;
+        ++w.kq;
+      } else {                         // one item per (pair[, q tile]), round-robin (last-tile mode, odd grids)
+        if (w.item >= n_items) return Item{-1, 0, 0, 0};
+        pair = last_tile_only ? w.item : w.item % n_pairs;
+        if (!last_tile_only) qt_sel = nqt - 1 - w.item / n_pairs;
+        w.item += gridDim.x;
+      }
+      const int b = pair / ny;
+      const int s0 = cu[b], len = cu[b + 1] - s0;
+      // last_tile_only: one q tile per sequence, the one holding its last token (all the pooled path needs of the last layer)
+      const int qt = last_tile_only ? ((len - 1) >> 6) : qt_sel;
+      if (len <= 0 || qt * 64 >= len) continue;
+      return Item{pair, qt, s0, len};
+    }
+  };
 
   // ---- staging: instruction j (0..INSTS-1) of a tile fills LDS bytes [j*1024, j*1024+1024): slot s = j*64 + lane,
   //      row = s / CH, chunk position cs = s % CH, holding logical chunk cs ^ x(row)
-  auto stage = [&](int st, int kt) {
+  auto stage = [&](int st, const Item& it, int kt) {
     char* sK = smem + st * (2 * G::TILE_BYTES);
     char* sV = sK + G::TILE_BYTES;
     if (wave >= DW) return;
-    for (int j = wave; j < G::INSTS; j += DW) {
+    const int hk_ = (it.pair % ny) / nparts;
+    const __bf16* kbase = qkv + (int64_t)it.s0 * RS + (int64_t)(nq + hk_) * D;
+    const __bf16* vbase = kbase + (int64_t)nkv * D;
+#pragma unroll
+    for (int jj = 0; jj < G::INSTS / DW; ++jj) {
+      const int j = wave + jj * DW;
       int s = j * 64 + lane;
       int row = s / G::CH, cs = s % G::CH;
-#if defined(ATTN_EXP) && ATTN_EXP == 1
-      int grow = min(row, len - 1);   // DIAG: always tile 0 (L2-hot), same instruction stream
-#else
-      int grow = min(kt * 64 + row, len - 1);
-#endif
+      int grow = min(kt * 64 + row, it.len - 1);
       const __bf16* kp = kbase + (int64_t)grow * RS + ((cs ^ G::xk(row)) << 3);
       const __bf16* vp = vbase + (int64_t)grow * RS + ((cs ^ G::xv(row)) << 3);
       __builtin_amdgcn_global_load_lds((gptr_t)kp, (lptr_t)(sK + j * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)vp, (lptr_t)(sV + j * 1024), 16, 0, 0);
     }
+  };
+  // prefetch side of the stream
+  Walk wp = {0, 0, (int)blockIdx.x};
+  Item ip = next_item(wp);
+  int ktp = 0, sp_ = 0;                      // next tile of ip to request, ring slot it goes to
+  auto stage_next = [&]() -> bool {
+    if (ip.pair < 0) return false;
+    stage(sp_, ip, ktp);
+    sp_ = sp_ == NST - 1 ? 0 : sp_ + 1;
+    if (++ktp > ip.qt) { ip = next_item(wp); ktp = 0; }
+    return true;
   };
 
   // ---- lane-constant LDS read offsets
@@ -122,6 +155,42 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     for (int dt = 0; dt < DT; ++dt)
       voff[dt] = qd * G::ROW_BYTES + (((dt * 4 + 2 * (g & 1) + (p >> 1)) ^ G::xv(qd)) << 4) + 8 * (p & 1);
   }
+
+  // Q fragments (B operand) of an item for this wave: Q[q0 + r][16 ks + 8 h .. +7]
+  auto load_q = [&](const Item& it, bf16x8 (&dst)[KS]) {
+    const int yy = it.pair % ny;
+    const int hk_ = yy / nparts, part_ = yy - hk_ * nparts;
+    const int hq_ = hk_ * grp_total + min(part_ * GRP + (wave % GRP), grp_total - 1);
+    const int q0_ = it.qt * 64 + (wave / GRP) * 32;
+    const int qrow = min(q0_ + r, it.len - 1);
+    const __bf16* qp = qkv + ((int64_t)it.s0 + qrow) * RS + (int64_t)hq_ * D + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const bf16x8*)(qp + ks * 16);
+  };
+
+  Walk wc = {0, 0, (int)blockIdx.x};
+  Item ic = next_item(wc);
+  if (ic.pair < 0) return;
+  bf16x8 qf[KS], qn[KS];
+  load_q(ic, qf);
+  // prologue: two tiles of the stream in flight, the first one landed
+  const bool t0 = stage_next(), t1 = stage_next();
+  (void)t0;
+  if (t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+
+  while (ic.pair >= 0) {
+  const Item inext = next_item(wc);
+  const int yy = ic.pair % ny;
+  const int hk = yy / nparts, part = yy - hk * nparts;
+  const int s0 = ic.s0, len = ic.len, qt = ic.qt;
+  const int qtile0 = qt * 64;
+  const int head_in_grp = part * GRP + (wave % GRP);
+  const int hq = hk * grp_total + min(head_in_grp, grp_total - 1);
+  const int q0 = qtile0 + (wave / GRP) * 32;
+  const bool active = q0 < len && head_in_grp < grp_total;
 
   f32x16 o[DT];
 #pragma unroll
@@ -171,8 +240,13 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
 #pragma unroll
     for (int t = 3; t < 15; t += 2) mloc = fmaxf(fmaxf(mloc, s[t]), s[t + 1]);
     mloc = xhalf_max(fmaxf(mloc, s[15]));
-    const float mnew = fmaxf(m, mloc);
-    const float alpha = __builtin_amdgcn_exp2f((m - mnew) * scale_log2);
+    // Lazy reference maximum: m moves only when the row maximum has outgrown it by more than LAZY_T in the exponent (a factor
+    // 2^LAZY_T on p); until then p = exp2((s - m) c) <= 2^LAZY_T stays far inside fp32 / bf16 range and alpha is EXACTLY 1, so the
+    // rescaling of the O accumulators (64 multiplies per sub-tile at d = 128, a third of the softmax VALU work) is skipped for
+    // the whole wave almost always after the first tile.  O / l is the same ratio whatever reference the exponentials use.
+    const bool grow = (mloc - m) * scale_log2 > LAZY_T;
+    const float mnew = grow ? mloc : m;
+    const float alpha = grow ? __builtin_amdgcn_exp2f((m - mnew) * scale_log2) : 1.0f;
     m = mnew;
     const float mc = -mnew * scale_log2;
     {
@@ -227,69 +301,59 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
   };
 
   const int nkt = qt + 1;
-  stage(0, 0);
-  if (RING3 && nkt > 1) {
-    stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-
-  int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (RING3) {
-      if (kt + 2 < nkt) stage(cur == 0 ? 2 : cur - 1, kt + 2);   // (cur + 2) % 3
-    } else {
-      if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-    }
-#if defined(ATTN_EXP) && ATTN_EXP == 2
-    if (false) {   // DIAG: loads + barriers only
-#else
+    if (PREFQ && kt == nkt - 1 && inext.pair >= 0) load_q(inext, qn);   // the next item's Q: requested a whole tile before it is used
+    const char* sK = smem + cur * (2 * G::TILE_BYTES);
+    const char* sV = sK + G::TILE_BYTES;
+    // Software pipeline inside the wave: the QK^T MFMAs of BOTH 32-key sub-tiles are issued first (K fragments read in
+    // one batch), so the second product runs on the matrix pipe while the VALU does the first sub-tile's softmax, and
+    // the first P.V runs under the second softmax.
+    const bool two = (kt * 64 + 32 <= q0);   // wave-uniform: second sub-tile not entirely above the diagonal
+    const bool more = stage_next();                              // tile (this + 2) of the stream, whichever item it belongs to
     if (active) {
-#endif
-      const char* sK = smem + cur * (2 * G::TILE_BYTES);
-      const char* sV = sK + G::TILE_BYTES;
-      // Software pipeline inside the wave: the QK^T MFMAs of BOTH 32-key sub-tiles are issued first (K fragments read in
-      // one batch), so the second product runs on the matrix pipe while the VALU does the first sub-tile's softmax, and
-      // the first P.V runs under the second softmax.
-      const bool two = (kt * 64 + 32 <= q0);   // wave-uniform: second sub-tile not entirely above the diagonal
-      f32x16 s0 = qk_product(sK, koff, qf);
-      f32x16 s1;
-      if (two) s1 = qk_product(sK + 32 * G::ROW_BYTES, koff, qf);
-      softmax_pv(s0, sV, kt * 64 == q0);
-      if (two) softmax_pv(s1, sV + 32 * G::ROW_BYTES, kt * 64 + 32 == q0);
+      f32x16 s0_ = qk_product(sK, koff, qf);
+      f32x16 s1_;
+      if (two) s1_ = qk_product(sK + 32 * G::ROW_BYTES, koff, qf);
+      softmax_pv(s0_, sV, kt * 64 == q0);
+      if (two) softmax_pv(s1_, sV + 32 * G::ROW_BYTES, kt * 64 + 32 == q0);
     }
-    if (RING3 && kt + 2 < nkt) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // tile kt+1 landed, tile kt+2 may stay in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");   // the next tile landed, the one after may stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    cur = RING3 ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
+    cur = cur == NST - 1 ? 0 : cur + 1;
   }
-
-  if (!active) return;
-  float ltot;
-  {
-    auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
-    ltot = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+  if (inext.pair >= 0) {
+    if (PREFQ) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];          // (before the stores below: the copy waits for qn only)
+    } else {
+      load_q(inext, qf);
+    }
   }
-  const float inv = 1.0f / ltot;
-  const int q = q0 + r;
-  if (q < len) {
-    __bf16* op = out + ((int64_t)s0 + q) * ((int64_t)nq * D) + (int64_t)hq * D + 4 * h;
+  if (active) {
+    float ltot;
+    {
+      auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+      ltot = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+    }
+    const float inv = 1.0f / ltot;
+    const int q = q0 + r;
+    if (q < len) {
+      __bf16* op = out + ((int64_t)s0 + q) * ((int64_t)nq * D) + (int64_t)hq * D + 4 * h;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 v;
+        for (int g4_ = 0; g4_ < 4; ++g4_) {
+          bf16x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g4 + e] * inv);
-        *(bf16x4*)(op + dt * 32 + 8 * g4) = v;
-      }
+          for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g4_ + e] * inv);
+          *(bf16x4*)(op + dt * 32 + 8 * g4_) = v;
+        }
+    }
   }
+  ic = inext;
+  }  // items
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -409,8 +473,9 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
         auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
         mloc = fmaxf(__uint_as_float(rr[0]), __uint_as_float(rr[1]));
       }
-      const float mnew = fmaxf(m, mloc);
-      const float alpha = __builtin_amdgcn_exp2f((m - mnew) * scale_log2);
+      const bool grow = (mloc - m) * scale_log2 > LAZY_T;     // lazy reference maximum: see k_attn_varlen_causal
+      const float mnew = grow ? mloc : m;
+      const float alpha = grow ? __builtin_amdgcn_exp2f((m - mnew) * scale_log2) : 1.0f;
       m = mnew;
       const float mc = -mnew * scale_log2;
       {
@@ -611,8 +676,29 @@ static int launch_attn(const void* qkv, const int32_t* cu, int n_seqs, int max_s
                        hipStream_t s, int nparts = 1) {
   int nqt = (int)lrx_cdiv(max_seqlen, 64);
   float scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-  hipLaunchKernelGGL((k_attn_varlen_causal<D, GRP>), dim3(last_tile_only ? n_seqs : n_seqs * nqt, nkv * nparts), dim3(128 * GRP), 0, s,
-                     (const __bf16*)qkv, cu, nqt, nq, nkv, (__bf16*)out, scale_log2, last_tile_only, nparts);
+  const int64_t n_items = (int64_t)(last_tile_only ? n_seqs : n_seqs * nqt) * nkv * nparts;
+  LRX_CHECK_ARG(n_items < (1ll << 31), "attn: %lld work items", (long long)n_items);
+  // persistent workgroups, as many as the chip keeps resident at once: the d = 128 ring (96 KiB) and the 256-VGPR budget admit one
+  // per CU; d = 64 workgroups are small enough for more (2-stage 32-KiB rings), so they get a slot count that covers that
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LRX_ERR_HIP;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int per_cu = D == 128 ? 1 : (GRP <= 2 ? 4 : 2);
+  const int64_t slots = (int64_t)n_cu * per_cu;
+  // grouped item list (see the kernel): needs a full grid that splits evenly over the 8 XCDs; gs = slots of one XCD that share a
+  // pair's K/V = the largest power of two <= min(q tiles, slots per XCD)
+  int gs = 0;
+  if (!last_tile_only && n_items >= slots && slots % 8 == 0) {
+    const int spx = (int)(slots / 8);
+    gs = 1;
+    while (gs * 2 <= nqt && gs * 2 <= spx && spx % (gs * 2) == 0) gs *= 2;
+  }
+  hipLaunchKernelGGL((k_attn_varlen_causal<D, GRP>), dim3((unsigned)(n_items < slots ? n_items : slots)), dim3(128 * GRP), 0, s,
+                     (const __bf16*)qkv, cu, nqt, nq, nkv, (__bf16*)out, scale_log2, last_tile_only, nparts, n_seqs, (int)n_items, gs);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

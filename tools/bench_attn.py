@@ -7,7 +7,10 @@ from lightretriever_amd import ops
 
 def main():
     B, S = int(os.environ.get("B", 256)), int(os.environ.get("S", 512))
-    for (nq, nkv, d) in [(32, 8, 64), (32, 8, 128), (12, 2, 128), (28, 4, 128), (12, 2, 64)]:
+    shapes = [(32, 8, 64), (32, 8, 128), (12, 2, 128), (28, 4, 128), (12, 2, 64)]
+    if os.environ.get("SHAPES"):      # e.g. SHAPES=32-8-128,12-2-128
+        shapes = [tuple(int(v) for v in sh.split("-")) for sh in os.environ["SHAPES"].split(",")]
+    for (nq, nkv, d) in shapes:
         T = B * S
         g = torch.Generator(device="cuda").manual_seed(0)
         qkv = torch.randn(T, (nq + 2 * nkv) * d, generator=g, device="cuda").to(torch.bfloat16)
