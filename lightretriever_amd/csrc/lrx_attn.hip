@@ -58,8 +58,13 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
   constexpr int NST = 3;
   static_assert(NST * 2 * G::TILE_BYTES <= 96 * 1024, "K/V ring");
   constexpr int PER_TILE = 2 * (G::INSTS / DW);  // LDS-DMA instructions per issuing wave per tile (K + V)
-  constexpr bool PREFQ = 128 * GRP <= 768;       // 14-16 waves per workgroup have 128 VGPRs each: no room for a second Q fragment set
-  __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * G::TILE_BYTES];  // [stage][K|V]
+  // Per-wave staging block (32 rows x D bf16, private to the wave): the wave's Q rows arrive in it by LDS-DMA (whole 2D-byte row
+  // segments per request instead of 32 rows x 32 B per load instruction) and its O rows leave through it (16 B per lane, whole
+  // row segments per store instruction instead of 32 rows x 16 B).  Ablation at d = 128: the 8-byte-piece stores cost 0.20 ms and
+  // the row-gather Q loads 0.16 ms of a 1.25 ms launch.
+  constexpr int QO_BYTES = 32 * G::ROW_BYTES;
+  constexpr int QINST = QO_BYTES / 1024;         // LDS-DMA instructions per Q block
+  __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * G::TILE_BYTES + NW * QO_BYTES];  // [stage][K|V] | [wave] Q/O block
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: branches on it stay scalar
@@ -88,8 +93,12 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     for (;;) {
       int pair, qt_sel = -1;
       if (gs > 0) {
-        pair = (w.step * gpx + g4) * 8 + xcd;
-        if (pair >= n_pairs) return Item{-1, 0, 0, 0};
+        // v-th (kv head of a sequence, part) of this XCD: the parts of one kv head (they read the same K/V) sit in neighbouring
+        // groups of the same XCD
+        const int v = w.step * gpx + g4;
+        pair = ((v / nparts) * 8 + xcd) * nparts + v % nparts;
+        if ((v / nparts) * 8 >= n_pairs / nparts) return Item{-1, 0, 0, 0};
+        if (pair >= n_pairs) { ++w.step; w.kq = 0; continue; }
         const int idx = jslot + w.kq * gs;
         if (idx >= nqt) { ++w.step; w.kq = 0; continue; }
         qt_sel = (w.step & 1) ? idx : nqt - 1 - idx;
@@ -156,29 +165,42 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
       voff[dt] = qd * G::ROW_BYTES + (((dt * 4 + 2 * (g & 1) + (p >> 1)) ^ G::xv(qd)) << 4) + 8 * (p & 1);
   }
 
-  // Q fragments (B operand) of an item for this wave: Q[q0 + r][16 ks + 8 h .. +7]
-  auto load_q = [&](const Item& it, bf16x8 (&dst)[KS]) {
+  // Q block of an item for this wave: rows q0 .. q0 + 31 of its head, requested into the wave's staging block with the K-tile
+  // swizzle (so the fragment reads are the K row reads: koff); fragments Q[q0 + r][16 ks + 8 h .. +7] (B operand)
+  char* const sW = smem + NST * 2 * G::TILE_BYTES + wave * QO_BYTES;
+  auto request_q = [&](const Item& it) {
     const int yy = it.pair % ny;
     const int hk_ = yy / nparts, part_ = yy - hk_ * nparts;
-    const int hq_ = hk_ * grp_total + min(part_ * GRP + (wave % GRP), grp_total - 1);
+    const int hig = part_ * GRP + (wave % GRP);
     const int q0_ = it.qt * 64 + (wave / GRP) * 32;
-    const int qrow = min(q0_ + r, it.len - 1);
-    const __bf16* qp = qkv + ((int64_t)it.s0 + qrow) * RS + (int64_t)hq_ * D + h * 8;
+    if (q0_ >= it.len || hig >= grp_total) return;           // (an inactive wave of this item: nothing to fetch)
+    const __bf16* qb = qkv + (int64_t)it.s0 * RS + (int64_t)(hk_ * grp_total + hig) * D;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const bf16x8*)(qp + ks * 16);
+    for (int j = 0; j < QINST; ++j) {
+      const int s_ = j * 64 + lane;
+      const int row = s_ / G::CH, cs = s_ % G::CH;
+      const int grow = min(q0_ + row, it.len - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(qb + (int64_t)grow * RS + ((cs ^ G::xk(row)) << 3)), (lptr_t)(sW + j * 1024), 16, 0, 0);
+    }
+  };
+  auto read_q = [&](bf16x8 (&dst)[KS]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const bf16x8*)(sW + koff[ks]);
   };
 
   Walk wc = {0, 0, (int)blockIdx.x};
   Item ic = next_item(wc);
   if (ic.pair < 0) return;
-  bf16x8 qf[KS], qn[KS];
-  load_q(ic, qf);
+  bf16x8 qf[KS];
+  request_q(ic);
   // prologue: two tiles of the stream in flight, the first one landed
   const bool t0 = stage_next(), t1 = stage_next();
   (void)t0;
   if (t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (DW < NW && wave >= DW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // waves without tile requests: the counted wait does not cover their Q block
   __builtin_amdgcn_s_barrier();
+  read_q(qf);                                    // (requested before the first two tiles: landed with the counted wait above)
   int cur = 0;
 
   while (ic.pair >= 0) {
@@ -302,7 +324,7 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
 
   const int nkt = qt + 1;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (PREFQ && kt == nkt - 1 && inext.pair >= 0) load_q(inext, qn);   // the next item's Q: requested a whole tile before it is used
+    if (kt == nkt - 1 && inext.pair >= 0) request_q(inext);     // the next item's Q block: requested a whole tile before it is used
     const char* sK = smem + cur * (2 * G::TILE_BYTES);
     const char* sV = sK + G::TILE_BYTES;
     // Software pipeline inside the wave: the QK^T MFMAs of BOTH 32-key sub-tiles are issued first (K fragments read in
@@ -323,14 +345,10 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     __builtin_amdgcn_s_barrier();
     cur = cur == NST - 1 ? 0 : cur + 1;
   }
-  if (inext.pair >= 0) {
-    if (PREFQ) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];          // (before the stores below: the copy waits for qn only)
-    } else {
-      load_q(inext, qf);
-    }
-  }
+  // the staging block now holds the next item's Q rows (older than the tile the counted wait just covered): fragments out first,
+  // then the block is free for this item's O rows
+  if (DW < NW && wave >= DW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (see the prologue)
+  if (inext.pair >= 0) read_q(qf);
   if (active) {
     float ltot;
     {
@@ -338,18 +356,26 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
       ltot = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
     }
     const float inv = 1.0f / ltot;
-    const int q = q0 + r;
-    if (q < len) {
-      __bf16* op = out + ((int64_t)s0 + q) * ((int64_t)nq * D) + (int64_t)hq * D + 4 * h;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the Q fragment reads are done with the block
+    // O^T accumulators -> bf16 rows in the block: lane (r, h) owns row r, 4 consecutive columns dt*32 + 8*g + 4h; 16-B chunk index
+    // XOR (row mod chunks-per-row) keeps both the 8-byte writes and the 16-byte row reads off each other's banks
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int g4_ = 0; g4_ < 4; ++g4_) {
-          bf16x4 v;
+      for (int g4_ = 0; g4_ < 4; ++g4_) {
+        bf16x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g4_ + e] * inv);
-          *(bf16x4*)(op + dt * 32 + 8 * g4_) = v;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g4_ + e] * inv);
+        *(bf16x4*)(sW + r * G::ROW_BYTES + ((((dt * 4 + g4_) ^ (r & (G::CH - 1))) << 4) | (h << 3))) = v;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // same wave wrote, same wave reads: no barrier
+    __bf16* ob = out + (int64_t)s0 * ((int64_t)nq * D) + (int64_t)hq * D;
+#pragma unroll
+    for (int j = 0; j < QINST; ++j) {
+      const int s_ = j * 64 + lane;
+      const int row = s_ / G::CH, ch = s_ % G::CH;
+      const bf16x8 v = *(const bf16x8*)(sW + row * G::ROW_BYTES + ((ch ^ (row & (G::CH - 1))) << 4));
+      if (q0 + row < len) *(bf16x8*)(ob + (int64_t)(q0 + row) * ((int64_t)nq * D) + ch * 8) = v;
     }
   }
   ic = inext;
