@@ -393,7 +393,7 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
 template <int GRP>
 __global__ void __launch_bounds__(1024)
 k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu, int nq, int nkv, __bf16* __restrict__ out,
-                  float scale_log2) {
+                  float scale_log2, int n_pairs) {
   constexpr int D = 64;
   using G = AttnGeom<D>;
   constexpr int KS = D / 16, DT = D / 32, NG = 16 / GRP;
@@ -402,13 +402,16 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
   char* const sKb = smem;
   char* const sVb = smem + MAXK * G::ROW_BYTES;
 
-  const int b = blockIdx.x, hk = blockIdx.y;
-  const int s0 = cu[b], len = cu[b + 1] - s0;
-  if (len <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int64_t RS = (int64_t)(nq + 2 * nkv) * D;
+  // persistent workgroups (one per CU: 128 KiB of LDS) walk the (sequence, kv head) pairs: a workgroup's successor used to start
+  // ~10 us after its exit (see k_attn_varlen_causal)
+  for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+  const int b = pair / nkv, hk = pair - b * nkv;
+  const int s0 = cu[b], len = cu[b + 1] - s0;
+  if (len <= 0) continue;
   const __bf16* kbase = qkv + (int64_t)s0 * RS + (int64_t)(nq + hk) * D;
   const __bf16* vbase = kbase + (int64_t)nkv * D;
 
@@ -574,6 +577,8 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
         }
     }
   }
+  __syncthreads();     // every wave is done with this pair's K/V before the next pair is staged over it
+  }  // pairs
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -738,16 +743,26 @@ extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens
   if (total_tokens == 0 || n_seqs == 0) return LRX_OK;
   int grp = num_q_heads / num_kv_heads;
   hipStream_t s = (hipStream_t)stream;
-  if (head_dim == 64 && max_seqlen <= 512 && !last_tile_only && (grp == 1 || grp == 2 || grp == 4 || grp == 8)) {
+  static int force_tiled = -1;   // LRX_ATTN_TILED=1: dev switch for A/B runs of the two d = 64 kernels
+  if (force_tiled < 0) { const char* e = getenv("LRX_ATTN_TILED"); force_tiled = e ? atoi(e) : 0; }
+  if (!force_tiled && head_dim == 64 && max_seqlen <= 512 && !last_tile_only && (grp == 1 || grp == 2 || grp == 4 || grp == 8)) {
     const float scale_log2 = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
-    dim3 grid(n_seqs, num_kv_heads), block(1024);
+    static int n_cu64 = 0;
+    if (n_cu64 == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LRX_ERR_HIP;
+      n_cu64 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int n_pairs = n_seqs * num_kv_heads;
+    dim3 grid(n_pairs < n_cu64 ? n_pairs : n_cu64), block(1024);
     const __bf16* in = (const __bf16*)qkv;
     __bf16* o = (__bf16*)out;
     switch (grp) {
-      case 1: hipLaunchKernelGGL(k_attn_resident64<1>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2); break;
-      case 2: hipLaunchKernelGGL(k_attn_resident64<2>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2); break;
-      case 4: hipLaunchKernelGGL(k_attn_resident64<4>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2); break;
-      default: hipLaunchKernelGGL(k_attn_resident64<8>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2); break;
+      case 1: hipLaunchKernelGGL(k_attn_resident64<1>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2, n_pairs); break;
+      case 2: hipLaunchKernelGGL(k_attn_resident64<2>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2, n_pairs); break;
+      case 4: hipLaunchKernelGGL(k_attn_resident64<4>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2, n_pairs); break;
+      default: hipLaunchKernelGGL(k_attn_resident64<8>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2, n_pairs); break;
     }
     LRX_LAUNCH_CHECK();
     return LRX_OK;
