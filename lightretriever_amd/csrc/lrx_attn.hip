@@ -684,6 +684,189 @@ k_attn_prefix(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same on the matrix cores (round 2; P1 <= 64, grp * S2 <= 16 waves at d = 64, 12 at d = 128; other shapes keep the kernel above).  Workgroup = (block of 32 sequences, kv head); wave w =
+// (q head w % grp of the group, suffix position j = w / grp): its 32 query rows are the j-th suffix token of 32 consecutive sequences.
+// The prefix K/V of the kv head (identical for every sequence) sit in LDS once per workgroup, in the K / V tile images of the kernels
+// above: S^T = Kpre . Q^T by MFMA (one q row per lane -> lane-local softmax), O^T += Vpre^T . P^T by MFMA.  Only the <= S2 own keys of
+// a row (different for every row) are VALU work: a 2 x d/2-element dot product per key, split over the two lanes that share the row.
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(D == 64 ? 1024 : 768)     // d = 128 needs ~150 VGPRs: at most 12 waves per workgroup
+k_attn_prefix_mfma(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_kv, int n_seqs, int S2, int P1, int nq, int nkv,
+                   __bf16* __restrict__ out, float scale_log2) {
+  using G = AttnGeom<D>;
+  constexpr int KS = D / 16, DT = D / 32;
+  constexpr int MAXP = 64;                          // prefix keys held in LDS (two 32-key MFMA tiles)
+  __shared__ __attribute__((aligned(1024))) char smem[2 * MAXP * G::ROW_BYTES];   // Kpre image | Vpre image
+  char* const sK = smem;
+  char* const sV = smem + MAXP * G::ROW_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int grp = nq / nkv;
+  const int hk = blockIdx.y, seq0 = blockIdx.x * 32;
+  const int hq = hk * grp + wave % grp, j = wave / grp;
+  const int64_t RS = (int64_t)(nq + 2 * nkv) * D, PS = (int64_t)2 * nkv * D;
+  const int nt = (P1 + 31) >> 5;                    // 32-key prefix tiles (1 or 2)
+
+  // ---- prefix K/V of this kv head -> LDS (rows >= P1: clamped copies, masked below)
+  {
+    const __bf16* kpre = prefix_kv + (int64_t)hk * D;
+    const __bf16* vpre = prefix_kv + (int64_t)(nkv + hk) * D;
+    const int ninst = nt * 32 * G::ROW_BYTES / 1024;
+    for (int jj = wave; jj < ninst; jj += nwaves) {
+      const int s_ = jj * 64 + lane;
+      const int row = s_ / G::CH, cs = s_ % G::CH;
+      const int grow = min(row, P1 - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(kpre + (int64_t)grow * PS + ((cs ^ G::xk(row)) << 3)), (lptr_t)(sK + jj * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vpre + (int64_t)grow * PS + ((cs ^ G::xv(row)) << 3)), (lptr_t)(sV + jj * 1024), 16, 0, 0);
+    }
+  }
+  // ---- this lane's query row and its own suffix keys / values (issued before the wait: they overlap the staging)
+  const int seq = min(seq0 + r, n_seqs - 1);
+  const __bf16* rowq = qkv + ((int64_t)seq * S2 + j) * RS;
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(rowq + (int64_t)hq * D + ks * 16 + h * 8);
+  float so[4];                                      // own-key scores (keys 0..j of the sequence's suffix), raw dot products
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    so[i] = -1e30f;
+    if (i <= j) {
+      const __bf16* kp = qkv + ((int64_t)seq * S2 + i) * RS + (int64_t)(nq + hk) * D + h * 8;
+      float acc = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kv = *(const bf16x8*)(kp + ks * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += bf2f(qf[ks][e]) * bf2f(kv[e]);
+      }
+      auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+      so[i] = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- prefix scores: S^T[key, q] per 32-key tile; reg t of lane (r, h) = key (t&3) + 8(t>>2) + 4h of the tile, query row r
+  f32x16 sc[2];
+  float mloc = -1e30f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t < nt) {
+      bf16x8 kf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(sK + (t * 32 + r) * G::ROW_BYTES + (((2 * ks + h) ^ G::xk(r)) << 4));
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], zero, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int key = t * 32 + (u & 3) + 8 * (u >> 2) + 4 * h;
+        acc[u] = key < P1 ? acc[u] : -1e30f;
+        mloc = fmaxf(mloc, acc[u]);
+      }
+      sc[t] = acc;
+    }
+  }
+  {
+    auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+    mloc = fmaxf(__uint_as_float(rr[0]), __uint_as_float(rr[1]));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mloc = fmaxf(mloc, so[i]);
+  const float mc = -mloc * scale_log2;
+  float l = 0.f;
+  // ---- O^T = Vpre^T . P^T over the prefix tiles
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) o[dt][u] = 0.f;
+  const int g16 = lane >> 4, i16 = lane & 15, qd = i16 >> 2, p4 = i16 & 3;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t < nt) {
+      s16x4 vt[2][DT][2];
+      const uint32_t vb = (uint32_t)(uintptr_t)(lds_char_ptr)(sV + (t * 32 + 4 * h) * G::ROW_BYTES);
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const uint32_t a = vb + sp * 16 * G::ROW_BYTES + qd * G::ROW_BYTES + (((dt * 4 + 2 * (g16 & 1) + (p4 >> 1)) ^ G::xv(qd)) << 4) + 8 * (p4 & 1);
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[sp][dt][0]) : "v"(a));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[sp][dt][1]) : "v"(a), "i"(8 * G::ROW_BYTES));
+        }
+      bf16x8 pf[2];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float pw = __builtin_amdgcn_exp2f(sc[t][u] * scale_log2 + mc);
+        l += pw;
+        pf[u >> 3][u & 7] = f2bf(pw);
+      }
+      if (DT == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]), "+v"(vt[1][0][0]), "+v"(vt[1][0][1]),
+                       "+v"(vt[1][1][0]), "+v"(vt[1][1][1])
+                     :
+                     : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]), "+v"(vt[0][2 % DT][0]), "+v"(vt[0][2 % DT][1]),
+                       "+v"(vt[0][3 % DT][0]), "+v"(vt[0][3 % DT][1]), "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]),
+                       "+v"(vt[1][2 % DT][0]), "+v"(vt[1][2 % DT][1]), "+v"(vt[1][3 % DT][0]), "+v"(vt[1][3 % DT][1])
+                     :
+                     : "memory");
+      }
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          union { struct { s16x4 a, b; } s; bf16x8 v; } u_;
+          u_.s.a = vt[sp][dt][0]; u_.s.b = vt[sp][dt][1];
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u_.v, pf[sp], o[dt], 0, 0, 0);
+        }
+    }
+  }
+  {
+    auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+    l = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);       // both lanes of a row: the row's prefix sum
+  }
+  // ---- own keys: p rounded to bf16 before P.V like everywhere else; lane (r, h) owns output columns dt*32 + 8g + 4h + e
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i <= j) {
+      const float pw = __builtin_amdgcn_exp2f(so[i] * scale_log2 + mc);
+      l += pw;
+      const float pb = bf2f(f2bf(pw));
+      const __bf16* vp = qkv + ((int64_t)seq * S2 + i) * RS + (int64_t)(nq + nkv + hk) * D + 4 * h;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x4 vv = *(const bf16x4*)(vp + dt * 32 + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[dt][4 * g + e] += pb * bf2f(vv[e]);
+        }
+    }
+  }
+  if (seq0 + r < n_seqs) {
+    const float inv = 1.0f / l;
+    __bf16* op = out + ((int64_t)seq * S2 + j) * ((int64_t)nq * D) + (int64_t)hq * D + 4 * h;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g + e] * inv);
+        *(bf16x4*)(op + dt * 32 + 8 * g) = v;
+      }
+  }
+}
+
 extern "C" int lrx_attn_prefix_suffix(const void* qkv, const void* prefix_kv, int32_t n_seqs, int32_t suffix_len, int32_t prefix_len,
                                       int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out, void* stream) {
   LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "attn_prefix: head_dim=%d unsupported", head_dim);
@@ -691,6 +874,19 @@ extern "C" int lrx_attn_prefix_suffix(const void* qkv, const void* prefix_kv, in
   LRX_CHECK_ARG(suffix_len > 0 && prefix_len >= 0, "attn_prefix: bad lengths");
   if (n_seqs == 0) return LRX_OK;
   const float scale = 1.0f / sqrtf((float)head_dim);
+  const int grp_ = num_q_heads / num_kv_heads;
+  if (prefix_len >= 1 && prefix_len <= 64 && suffix_len <= 4 && grp_ * suffix_len <= (head_dim == 64 ? 16 : 12)) {   // matrix-core kernel
+    dim3 g((unsigned)lrx_cdiv(n_seqs, 32), num_kv_heads), b(64 * grp_ * suffix_len);
+    const float sl2 = scale * 1.4426950408889634f;
+    if (head_dim == 64)
+      hipLaunchKernelGGL(k_attn_prefix_mfma<64>, g, b, 0, (hipStream_t)stream, (const __bf16*)qkv, (const __bf16*)prefix_kv, n_seqs, suffix_len,
+                         prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, sl2);
+    else
+      hipLaunchKernelGGL(k_attn_prefix_mfma<128>, g, b, 0, (hipStream_t)stream, (const __bf16*)qkv, (const __bf16*)prefix_kv, n_seqs, suffix_len,
+                         prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, sl2);
+    LRX_LAUNCH_CHECK();
+    return LRX_OK;
+  }
   dim3 grid(n_seqs, num_kv_heads), block(64 * (num_q_heads / num_kv_heads));
   if (head_dim == 64)
     hipLaunchKernelGGL(k_attn_prefix<64>, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (const __bf16*)prefix_kv, n_seqs, suffix_len,

@@ -276,7 +276,11 @@ def test_gemm_qkv_rope_fused_equals_gemm_then_rope(d, nq, nkv, bias):
     assert (diff <= 2.0 ** -7 * want.float().abs() + 1e-6).all()
 
 
-@pytest.mark.parametrize("d,nq,nkv,P1,S2,n", [(64, 4, 2, 9, 2, 37), (64, 32, 8, 22, 2, 5), (128, 8, 1, 3, 3, 11), (64, 2, 2, 0, 2, 4), (128, 4, 4, 40, 1, 3)])
+@pytest.mark.parametrize("d,nq,nkv,P1,S2,n", [(64, 4, 2, 9, 2, 37), (64, 32, 8, 22, 2, 5), (128, 8, 1, 3, 3, 11), (64, 2, 2, 0, 2, 4), (128, 4, 4, 40, 1, 3),
+                                              # round 2: the matrix-core kernel (P1 <= 64): 32-sequence blocks with a ragged tail, two prefix tiles,
+                                              # GQA groups of 6 (Qwen2.5-1.5B) and 4 suffix tokens; and shapes that keep the VALU kernel
+                                              (64, 32, 8, 21, 2, 100), (64, 8, 8, 33, 2, 65), (128, 12, 2, 21, 2, 70), (128, 32, 8, 64, 2, 33), (64, 4, 1, 1, 4, 64),
+                                              (64, 8, 2, 70, 2, 9), (128, 28, 4, 21, 2, 40)])
 def test_attention_prefix_suffix_equals_full_causal(d, nq, nkv, P1, S2, n):
     """Suffix queries over a shared prefix == the suffix rows of full causal attention on [prefix + suffix] per sequence."""
     from lightretriever_amd import ops
