@@ -227,6 +227,20 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   //      read the same way and added to the bf16-rounded product (exactly the reference's bf16 `residual + linear(x)`).
   constexpr int CW = (EPI == EPI_SWIGLU) ? 128 : 256;  // output columns of this tile
   constexpr int CPR = CW / 8;                          // 16-B chunks per staged row
+  constexpr int NIT = (256 * CPR) / 512;
+  bf16x8 rv[EPI == EPI_RESID ? NIT : 1];
+  if (EPI == EPI_RESID) {
+    // all residual loads of this thread are issued before anything is staged: the operand fragments of the K loop are dead, so their
+    // 64 registers hold the 16 loads while the accumulators are converted and written to LDS (the tile's 128 KiB of residual then
+    // arrive under the staging + barrier instead of after them: the timeline showed 6.0 us of a 60 us tile waiting here)
+    const int ldc_ = N, c0_ = n0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = it * 512 + tid;
+      const int m = min(m0 + q / CPR, M - 1), n = min(c0_ + (q % CPR) * 8, ldc_ - 8);
+      rv[it] = *(const bf16x8*)(resid + (int64_t)m * N + n);
+    }
+  }
   // all LDS reads of the K loop are complete (lgkmcnt(0) precedes every barrier; the last barrier was passed by all waves)
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -331,18 +345,6 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   }
   const int ldc = (EPI == EPI_SWIGLU) ? (N >> 1) : N;
   const int c0 = (EPI == EPI_SWIGLU) ? (n0 >> 1) : n0;
-  constexpr int NIT = (256 * CPR) / 512;
-  bf16x8 rv[EPI == EPI_RESID ? NIT : 1];
-  if (EPI == EPI_RESID) {
-    // all residual loads of this thread are issued before the first one is consumed (the accumulators are dead, registers
-    // are free): 16 loads in flight per lane instead of a load -> use chain per chunk
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int q = it * 512 + tid;
-      const int m = min(m0 + q / CPR, M - 1), n = min(c0 + (q % CPR) * 8, N - 8);
-      rv[it] = *(const bf16x8*)(resid + (int64_t)m * N + n);
-    }
-  }
   int rpos[EPI == EPI_ROPE ? NIT : 1];
   if (EPI == EPI_ROPE) {   // positions of this thread's rows, loaded up front (the cos/sin lookups depend on them)
 #pragma unroll

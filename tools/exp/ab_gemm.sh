@@ -1,0 +1,5 @@
+R=${GRAFT_REPO_ROOT:-/root/repo}
+for i in 1 2; do
+echo "== product"; python3 $R/tools/bench_gemm.py 2>&1 | grep -E "^(o|down|qkv|gate)"
+echo "== variant"; LRX_LIB_DEV_VARIANT=$R/lightretriever_amd/build/liblrx_new.so python3 $R/tools/bench_gemm.py 2>&1 | grep -E "^(o|down|qkv|gate)"
+done
