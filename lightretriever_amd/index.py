@@ -192,7 +192,7 @@ class FlatIPIndex:
         need = int(ws_bytes(self.ntotal, self.d, chunk, k))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
-            self._ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         ldx = self._x.stride(0) if self._x.shape[0] else self.d
         xb = self._xb if (self.two_pass and self.shadow_bf16 and self._xb is not None) else None
         for s in range(0, Q, chunk):
