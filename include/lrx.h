@@ -309,7 +309,8 @@ size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t 
 int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_bf16, int64_t ldx_bf16,
                                const float* row_bounds, const float* q, int32_t n_queries, int32_t k, int64_t id_base,
                                float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream);
-/* Diagnostics / tests: 0 = choose the filter per query chunk (default), 1 = always the score-matrix filter, 2 = the score-free
+/* Diagnostics / tests: 0 = choose the filter per query chunk (default), 1 = always the score-matrix filter, 3 = like 2 but never the
+ * GEMM kernel for the main pass, 2 = the score-free
  * (candidate-list) filter whenever the shard is large enough for a sample.  Process-global; results do not depend on it.        */
 void lrx_search_set_mode(int32_t mode);
 

@@ -34,6 +34,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- candidate lists of the score-free search filter (lrx_search.hip; the 256-query filter pass lives in lrx_gemm.hip)
+#define CAND_CAP 16384   // per-query capacity of the filter pass's emitted candidate list (score-free filter)
+#define CNT_STRIDE 64    // list fill counters sit 256 B apart: the reservations of different queries go to different memory channels
+
+__device__ __forceinline__ uint32_t f2key(float f) {  // monotone: larger float -> larger key
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(u);
+}
+// (score key, row) packed so that an unsigned sort is (score desc, row asc); rows < 2^32 per shard
+__device__ __forceinline__ unsigned long long sel_pack(uint32_t key, int64_t i) {
+  return ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+}
+__device__ __forceinline__ int64_t sel_row(unsigned long long c) { return (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull)); }
+
 // host-side error plumbing -----------------------------------------------------------------------------------
 void lrx_set_error(const char* fmt, ...);
 #define LRX_CHECK_ARG(cond, ...)          \
@@ -55,6 +73,11 @@ void lrx_set_error(const char* fmt, ...);
 
 static inline int64_t lrx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// lrx_gemm.hip: the GEMM kernel as the search's filter pass for 129..256 queries: scores = Xb[rows, D] . q16[nq, D]^T (bf16 operands,
+// fp32 accumulation), nothing stored, rows reaching thr[query] appended to the query's candidate list.  Covers the 256-row tiles
+// that are not in the sample (every ss-th tile): n_tiles of them.
+int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles, const float* thr,
+                                unsigned long long* cand, unsigned int* cnt, hipStream_t stream);
 // lrx_gemm.hip: the GEMM kernel with the segmented-maximum epilogue (used by lrx_sparse_max_aggregate)
 int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias, const int32_t* row_seg, float* out, int64_t ldo, int M, int N,
                                   int K, hipStream_t stream);

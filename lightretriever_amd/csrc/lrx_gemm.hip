@@ -23,6 +23,7 @@
 // Workgroup -> tile map: bijective XCD-chunked remap (blocks b and b+8 share an XCD L2) + 8-m-tile groups walked
 // n-fastest inside an XCD chunk, so the 32 co-resident tiles of an XCD share 8 A panels and 4 B panels.
 #include "lrx_common.h"
+#include <float.h>
 #include <stdlib.h>
 
 #define GBM 256
@@ -30,7 +31,7 @@
 #define GBK 64
 #define HALF_BYTES 16384
 
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE = 3, EPI_MAXAGG = 4 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE = 3, EPI_MAXAGG = 4, EPI_EMIT = 5 };
 
 struct RopeArgs {
   const int32_t* positions;  // [M]
@@ -38,6 +39,16 @@ struct RopeArgs {
   const float* sin;
   int rope_cols;             // columns [0, rope_cols) are q|k heads to rotate; the rest (v) is stored as is
   int head_dim;
+};
+
+// Search filter pass (EPI_EMIT): A = bf16 shadow rows of the shard, B = bf16 queries; no C.  A score reaching thr[query] is appended
+// to the query's candidate list (lrx_search.hip).  ss > 0: m-tile t of the launch is the t-th 256-row tile that is NOT in the sample
+// (the sample = every ss-th tile).
+struct EmitArgs {
+  const float* thr;          // [nq]
+  unsigned long long* cand;  // [nq, CAND_CAP]
+  unsigned int* cnt;         // [nq * CNT_STRIDE]
+  int ss;
 };
 
 struct MaxAggArgs {
@@ -84,7 +95,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
-               const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope, MaxAggArgs mx, NormArgs nrm) {
+               const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope, MaxAggArgs mx, NormArgs nrm, EmitArgs em) {
   __shared__ __attribute__((aligned(1024))) char smem[8 * HALF_BYTES];  // [buf 0/1][A0 | A1 | B0 | B1]
   // ---- workgroup -> tile
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -98,7 +109,9 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   const int gsz = min(tiles_m - first_m, GM);
   const int tin = t_lin - group * width;
   const int tm = first_m + tin % gsz, tn = tin / gsz;
-  const int m0 = tm * GBM, n0 = tn * GBN;
+  // (filter pass: the tm-th tile outside the strided sample)
+  const int tmx = (EPI == EPI_EMIT && em.ss > 1) ? (tm / (em.ss - 1)) * em.ss + 1 + tm % (em.ss - 1) : tm;
+  const int m0 = tmx * GBM, n0 = tn * GBN;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,7 +176,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
-      rsv[h][mi] = (EPI != EPI_MAXAGG && EPI != EPI_RESID && nrm.rscale != nullptr) ? nrm.rscale[min(m0 + h * 128 + wr * 64 + mi * 16 + fr, M - 1)] : 1.0f;
+      rsv[h][mi] = (EPI != EPI_MAXAGG && EPI != EPI_RESID && EPI != EPI_EMIT && nrm.rscale != nullptr) ? nrm.rscale[min(m0 + h * 128 + wr * 64 + mi * 16 + fr, M - 1)] : 1.0f;
 
   const int nk = K / GBK;
   // ---- prologue: K-tile 0 landed, K-tile 1 (issued in the steady-state order A0,B0,B1 then A1) stays in flight
@@ -225,6 +238,67 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   //      (now idle) 128 KiB of LDS -- 16-B chunk index XOR (row & 15): conflict-free ds_write_b64 and ds_read_b128 -- and
   //      written row-major, 16 B per lane: every wave instruction moves two full 512-B row segments.  The residual is
   //      read the same way and added to the bf16-rounded product (exactly the reference's bf16 `residual + linear(x)`).
+  if constexpr (EPI == EPI_EMIT) {
+    // ---- search filter epilogue: nothing is stored per (row, query).  Lane (fr, fq) of wave (wr, wc) holds rows h*128 + wr*64 +
+    //      mi*16 + fr and query columns hp*128 + wc*32 + ni*16 + fq*4 + r.  Hits (~5e-3 of the scores) first go to a per-wave list in
+    //      the idle LDS (an LDS atomic per 16x16 sub-tile that has any: ~100 cycles, against ~2 us for a global one, and this
+    //      workgroup has the CU to itself), then the wave reserves the global slots of all its hits with ONE round of atomics.
+    constexpr int WCAP = 512;                                   // hits a wave can park in LDS; more go straight to the global lists
+    unsigned long long* wl = (unsigned long long*)(smem + wave * (WCAP * 12 + 64));
+    unsigned int* wq = (unsigned int*)(wl + WCAP);
+    unsigned int* wn = wq + WCAP;                                // the wave's hit count
+    if (lane == 0) *wn = 0;
+    float t16[2][2][4];
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = hp * 128 + wc * 32 + ni * 16 + fq * 4 + r;
+          t16[hp][ni][r] = col < N ? em.thr[col] : FLT_MAX;
+        }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = (int64_t)m0 + h * 128 + wr * 64 + mi * 16 + fr;
+        const bool mok = m < M;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const f32x4 v = acc[h][hp][mi][ni];
+            unsigned int c = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c += (mok && v[r] >= t16[hp][ni][r]) ? 1u : 0u;
+            if (c) {
+              unsigned int p = atomicAdd(wn, c);                // LDS
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (mok && v[r] >= t16[hp][ni][r]) {
+                  const unsigned int col = hp * 128 + wc * 32 + ni * 16 + fq * 4 + r;
+                  const unsigned long long w = sel_pack(f2key(v[r]), m);
+                  if (p < WCAP) { wl[p] = w; wq[p] = col; }
+                  else {                                        // list full (a tile of near-duplicates): straight to the query's list
+                    const unsigned int gp = atomicAdd(&em.cnt[col * CNT_STRIDE], 1u);
+                    if (gp < CAND_CAP) em.cand[(int64_t)col * CAND_CAP + gp] = w;
+                  }
+                  ++p;
+                }
+            }
+          }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's list is complete (nobody else touches it)
+    const unsigned int total = min(*wn, (unsigned int)WCAP);
+    for (unsigned int i = lane; i < total; i += 64) {
+      const unsigned long long w = wl[i];
+      const unsigned int col = wq[i];
+      const unsigned int gp = atomicAdd(&em.cnt[col * CNT_STRIDE], 1u);
+      if (gp < CAND_CAP) em.cand[(int64_t)col * CAND_CAP + gp] = w;
+    }
+    return;
+  }
   constexpr int CW = (EPI == EPI_SWIGLU) ? 128 : 256;  // output columns of this tile
   constexpr int CPR = CW / 8;                          // 16-B chunks per staged row
   constexpr int NIT = (256 * CPR) / 512;
@@ -450,9 +524,9 @@ extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, con
   MaxAggArgs nomx = {nullptr, nullptr, 0};
   NormArgs nrm = {rscale, ss_part, gemm_group_m(epilogue, K)};
   switch (epilogue) {
-    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm); break;
-    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm); break;
-    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm); break;
+    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0}); break;
+    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0}); break;
+    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0}); break;
   }
   LRX_LAUNCH_CHECK();
   return LRX_OK;
@@ -476,7 +550,7 @@ extern "C" int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C,
   RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)Wqkv,
                      (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{rscale, nullptr, 8});
+                     NormArgs{rscale, nullptr, 8}, EmitArgs{nullptr, nullptr, nullptr, 0});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -494,7 +568,25 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   MaxAggArgs mx = {row_seg, out, ldo};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
-                     (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, LRX_MAXAGG_GM});
+                     (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, LRX_MAXAGG_GM},
+                     EmitArgs{nullptr, nullptr, nullptr, 0});
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// The filter pass of the bounded search for 129..256 queries (lrx_search.hip): the shard's bf16 shadow rows against the bf16 queries
+// on the GEMM kernel -- its 256 x 256 tile stages a query k-slice once per 256 rows and its 4-phase K loop keeps the LDS-DMA ahead of
+// the MFMAs with one workgroup per CU; the 128-row filter kernel re-stages the 32-KiB query slice for every 128 rows and is bound
+// by that L2 -> LDS traffic at 16 query tiles (1.19 ms for 256 queries over 1M x 2048; HBM floor 0.75).
+int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles, const float* thr,
+                                unsigned long long* cand, unsigned int* cnt, hipStream_t stream) {
+  LRX_CHECK_ARG(dim > 0 && dim % GBK == 0 && nq > 0 && nq <= GBN && n_rows < (1ll << 31), "filter_emit: bad shape rows=%lld nq=%d dim=%d",
+                (long long)n_rows, nq, dim);
+  if (n_tiles <= 0) return LRX_OK;
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_EMIT>, dim3((unsigned)n_tiles), dim3(512), 0, stream, (const __bf16*)Xb, (const __bf16*)q16, (__bf16*)nullptr,
+                     (const __bf16*)nullptr, (const __bf16*)nullptr, (int)n_rows, nq, dim, (int)n_tiles, 1, none, MaxAggArgs{nullptr, nullptr, 0},
+                     NormArgs{nullptr, nullptr, 8}, EmitArgs{thr, cand, cnt, ss});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

@@ -28,22 +28,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define S_BK 32          // floats per k-slice (128 B per row)
 #define S_XTILE (S_ROWS * S_BK * 4)
 #define SP_ROWS 128      // corpus rows per workgroup of the split-bf16 kernel
-#define CAND_CAP 16384   // per-query capacity of the filter pass's emitted candidate list (score-free filter)
-#define CNT_STRIDE 64    // list fill counters sit 256 B apart: the reservations of different queries go to different memory channels
-
-__device__ __forceinline__ uint32_t f2key(float f) {  // monotone: larger float -> larger key
-  uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(uint32_t k) {
-  uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-  return __uint_as_float(u);
-}
-// (score key, row) packed so that an unsigned sort is (score desc, row asc); rows < 2^32 per shard
-__device__ __forceinline__ unsigned long long sel_pack(uint32_t key, int64_t i) {
-  return ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-}
-__device__ __forceinline__ int64_t sel_row(unsigned long long c) { return (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull)); }
 
 template <int QT>
 __global__ void __launch_bounds__(256, 1)
@@ -218,6 +202,17 @@ __global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, in
   ((bf16x8*)qs)[(((int64_t)sl * 2 + ks) * QT + qt) * 64 + lane] = h;
 }
 
+// plain bf16 copy of the queries [nq, D] (RNE): the B operand of the 256-query filter pass on the GEMM kernel
+__global__ void k_round_queries(const float* __restrict__ Q, int64_t n, __bf16* __restrict__ q16) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const f32x4 v = *(const f32x4*)(Q + i);
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+  *(bf16x4*)(q16 + i) = o;
+}
+
 // RT = 16-row tiles per wave (rows per workgroup = 64 RT), NST = LDS stages of the k-slice ring.  The six-product kernel runs
 // (RT 2, NST 2, two workgroups per CU: it is bound by the matrix pipe); the single-product filter kernel is HBM-bound and runs the
 // deeper / wider shape selected by SPF_RT / SPF_NST.
@@ -258,7 +253,8 @@ template <int QT, int NP, int RT, int NST, int WV, bool XB = false, bool QSB = f
 __global__ void __launch_bounds__(64 * WV, QSB ? (QT > 8 ? 2 : 3) : ((NST * (16 * RT * WV * 128 + (((XB ? 2 : NP) * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1))
 k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
                        float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate,
-                       int bmode, int ss, const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt) {
+                       int bmode, int ss, int unit, const float* __restrict__ thr, unsigned long long* __restrict__ cand,
+                       unsigned int* __restrict__ cnt) {
   static_assert(!XB || NP == 1, "the bf16 shadow is a single-product filter");
   static_assert(!EMIT || NP == 1, "the emitting epilogue belongs to the single-product filter");
   const float* X = (const float*)Xv;
@@ -277,9 +273,12 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
   if (gate != nullptr && *gate == 0) return;     // fallback launch of the bounded search: nothing overflowed
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int64_t blk = blockIdx.x;
-  if (bmode == 1) blk = (int64_t)blockIdx.x * ss;
-  else if (bmode == 2) { const int g = blockIdx.x / (ss - 1); blk = (int64_t)g * ss + 1 + (blockIdx.x - g * (ss - 1)); }
+  int64_t blk = blockIdx.x;                        // sample units of `unit` consecutive blocks, every ss-th unit is in the sample
+  if (bmode == 1) { const int u = blockIdx.x / unit; blk = (int64_t)u * ss * unit + (blockIdx.x - u * unit); }
+  else if (bmode == 2) {
+    const int u = blockIdx.x / unit, g = u / (ss - 1);
+    blk = ((int64_t)g * ss + 1 + (u - g * (ss - 1))) * unit + (blockIdx.x - u * unit);
+  }
   const int64_t n0 = blk * RB;                     // corpus rows of this workgroup
   const int64_t n0s = (int64_t)blockIdx.x * RB;    // where its scores go (compact in sample mode)
 
@@ -523,7 +522,8 @@ static size_t split_ws_bytes(int32_t dim) { return (size_t)(dim / 32) * 3 * 8 * 
 // Which corpus blocks a filter launch covers and what it does with the scores (see k_flat_ip_scores_split)
 struct FilterMode {
   int bmode = 0;                          // 0 all blocks, 1 sample blocks (compact stores), 2 non-sample blocks
-  int ss = 1;                             // sample stride in blocks
+  int ss = 1;                             // sample stride in units
+  int unit = 1;                           // workgroup blocks per sample unit (2: the 256-query main pass works on 256-row tiles)
   int64_t nblocks = -1;                   // workgroups to launch (-1: ld / rows-per-workgroup)
   const float* thr = nullptr;             // emit mode: per-query threshold
   unsigned long long* cand = nullptr;     // emit mode: candidate lists [Q, CAND_CAP]
@@ -568,7 +568,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
       }
 #define LRX_SB_(QQ, QSB_, EM_)                                                                                                                           \
     hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPX_RT, SPX_NST, SPX_WV, true, QSB_, EM_>), dim3((unsigned)nwg), dim3(64 * SPX_WV), 0, s, Xb, n_rows, \
-                       ldxb, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.thr, fm.cand, fm.cnt);
+                       ldxb, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);
 #define LRX_SB(QQ, QSB_)                  \
   case QQ:                                \
     if (emit) { LRX_SB_(QQ, QSB_, true) } \
@@ -593,10 +593,10 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
       }
 #define LRX_SF_(QQ, EM_)                                                                                                                          \
     hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPF_RT, SPF_NST, SPF_WV, false, false, EM_>), dim3((unsigned)nwg), dim3(64 * SPF_WV), 0, s, X, n_rows, ldx, \
-                       dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.thr, fm.cand, fm.cnt);
+                       dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);
 #define LRX_SS(QQ)                                                                                                                              \
   case QQ:                                                                                                                                      \
-    if (planes == 3) hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 3, 2, 2, 4>), dim3((unsigned)nwg), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, 0, 1, (const float*)nullptr, (unsigned long long*)nullptr, (unsigned int*)nullptr); \
+    if (planes == 3) hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 3, 2, 2, 4>), dim3((unsigned)nwg), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, 0, 1, 1, (const float*)nullptr, (unsigned long long*)nullptr, (unsigned int*)nullptr); \
     else if (emit) { LRX_SF_(QQ, true) }                                                                                                        \
     else { LRX_SF_(QQ, false) }                                                                                                                 \
     break;
@@ -1202,25 +1202,29 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
 }
 
 // ---- host side: per query chunk (<= 256 queries with the shadow, <= 128 without) one pipeline over one workspace ----------------
-static int g_search_mode = 0;   // 0 = choose per chunk, 1 = always the score-matrix filter, 2 = the score-free filter whenever the shape allows
+static int g_search_mode = 0;   // 0 = choose per chunk, 1 = always the score-matrix filter, 2 = the score-free filter whenever the shape allows,
+                                // 3 = like 2 but never the GEMM kernel for the main pass (A/B runs)
 extern "C" void lrx_search_set_mode(int32_t mode) { g_search_mode = mode; }
 
 struct BoundedPlan {
   bool emit;
+  bool gemm;                            // emit: the main pass runs on the GEMM kernel (129..256 queries over a contiguous bf16 shadow)
   int ss, rb;
   int64_t ld, nblk, nblk_ld;            // full shard: score row stride, 128-row blocks, blkmax row stride
   int64_t nsamp_wg, nmain_wg;           // emit: workgroups of the sample / main launch (rb rows each)
   int64_t ld_s, nblk_s, nblk_ld_s;      // emit: the compact sample matrix
-  size_t off_qsplit, off_ints, off_parts, off_cand, total;   // byte offsets into the workspace (the score region starts at 0)
+  size_t off_qsplit, off_q16, off_ints, off_parts, off_cand, total;   // byte offsets into the workspace (the score region starts at 0)
 };
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t ints_before_cnt(int nq) { return ((size_t)nq + 1 + 63) & ~(size_t)63; }
 
-static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow) {
+static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow, bool contiguous_shadow = true) {
   BoundedPlan p;
   memset(&p, 0, sizeof(p));
-  p.rb = filter_rows_per_wg(shadow);
+  // more than 128 queries over a bf16 shadow: the main pass is the GEMM kernel on 256-row tiles (the sample then moves in 256-row units)
+  p.gemm = shadow && contiguous_shadow && nq > 128 && dim >= 1024 && dim % 64 == 0 && n_rows < (1ll << 31) && g_search_mode != 3;   // (D = 256: 4 K-tiles per 256 x 256 tile, 14 % slower than the 128-row kernel)
+  p.rb = p.gemm ? 256 : filter_rows_per_wg(shadow);
   p.ld = lrx_flat_ip_score_ld(n_rows);
   p.nblk = p.ld / SP_ROWS;
   p.nblk_ld = (p.nblk + 3) & ~(int64_t)3;
@@ -1231,7 +1235,8 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   while (ss > 2 && (lrx_cdiv(nwg, ss) - 1) * p.rb < 2 * (int64_t)k) ss >>= 1;
   const int64_t nsamp = lrx_cdiv(nwg, ss);
   const bool feasible = (nsamp - 1) * p.rb >= 2 * (int64_t)k && nwg - nsamp >= 1 && dim % 4 == 0 && (shadow || nq > 16 * (SPLIT_MIN_QT - 1));
-  p.emit = feasible && g_search_mode != 1 && (g_search_mode == 2 || (n_rows >= 16384 && nq >= 2 && 256 * (int64_t)nq >= dim));
+  if (!feasible) p.gemm = false;
+  p.emit = feasible && g_search_mode != 1 && (g_search_mode >= 2 || (n_rows >= 16384 && nq >= 2 && 256 * (int64_t)nq >= dim));
   p.ss = ss;
   p.nsamp_wg = nsamp;
   p.nmain_wg = nwg - nsamp;
@@ -1241,7 +1246,8 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   const size_t fb = (size_t)(nq < 128 ? nq : 128) * (size_t)(p.ld + p.nblk_ld);
   const size_t prim = p.emit ? (size_t)nq * (size_t)(p.ld_s + p.nblk_ld_s) : (size_t)nq * (size_t)(p.ld + p.nblk_ld);
   p.off_qsplit = align256((prim > fb ? prim : fb) * sizeof(float));
-  p.off_ints = align256(p.off_qsplit + split_ws_bytes(dim));
+  p.off_q16 = align256(p.off_qsplit + split_ws_bytes(dim));
+  p.off_ints = align256(p.off_q16 + (size_t)256 * dim * 2);
   // ints: flags[nq], any_flag, pad to 64 ints, cnt[nq * CNT_STRIDE] (one memset) | part_cnt[nq * REF_SPLIT] | thr[nq] | eps[nq]
   p.off_parts = align256(p.off_ints + sizeof(int) * (ints_before_cnt(nq) + (size_t)nq * (CNT_STRIDE + 2 + REF_SPLIT)));
   p.off_cand = align256(p.off_parts + (size_t)nq * REF_CAND * 8);
@@ -1292,7 +1298,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
   const int chunk = shadow ? 256 : 128;
   for (int q0 = 0; q0 < n_queries; q0 += chunk) {
     const int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
-    const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow);
+    const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, ldx_bf16 == dim);
     const float* qc = q + (int64_t)q0 * dim;
     float* osc = out_scores + (int64_t)q0 * k;
     int64_t* oic = out_ids + (int64_t)q0 * k;
@@ -1311,16 +1317,24 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
     int rc;
     if (p.emit) {
       float* blkmax = scores + p.ld_s * (int64_t)nq;
+      const int unit = p.gemm ? 2 : 1;                        // sample units of 256 rows = two blocks of the 128-row filter kernel
       FilterMode fs;
-      fs.bmode = 1; fs.ss = p.ss; fs.nblocks = p.nsamp_wg;
+      fs.bmode = 1; fs.ss = p.ss; fs.unit = unit; fs.nblocks = p.nsamp_wg * unit;
       rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld_s, fs);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_sample_threshold, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld_s, p.nsamp_wg * p.rb, k, (const float*)blkmax,
                          (int)p.nblk_s, (int)p.nblk_ld_s, qc, dim, row_bounds, p.rb, p.ss, n_rows, thr, eps, cand, cnt);
       LRX_LAUNCH_CHECK();
-      FilterMode fm;
-      fm.bmode = 2; fm.ss = p.ss; fm.nblocks = p.nmain_wg; fm.thr = thr; fm.cand = cand; fm.cnt = cnt;
-      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, nullptr, nullptr, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld, fm);
+      if (p.gemm) {
+        __bf16* q16 = (__bf16*)(ws + p.off_q16);
+        hipLaunchKernelGGL(k_round_queries, dim3((unsigned)lrx_cdiv((int64_t)nq * dim, 1024)), dim3(256), 0, s, qc, (int64_t)nq * dim, q16);
+        LRX_LAUNCH_CHECK();
+        rc = lrx_gemm_filter_emit_launch(X_bf16, q16, n_rows, nq, dim, p.ss, p.nmain_wg, thr, cand, cnt, s);
+      } else {
+        FilterMode fm;
+        fm.bmode = 2; fm.ss = p.ss; fm.nblocks = p.nmain_wg; fm.thr = thr; fm.cand = cand; fm.cnt = cnt;
+        rc = launch_scores(X, n_rows, ldx, dim, qc, nq, nullptr, nullptr, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld, fm);
+      }
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_refine_band, dim3(nq, REF_SPLIT), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
                          (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt);

@@ -34,6 +34,8 @@ def _index(X, shadow=True, id_base=0, pieces=2):
     (30000, 2048, 40, 50, "unit", True), (70000, 128, 300, 7, "unit", True), (25000, 64, 5, 2048, "mixed", True),
     (25000, 64, 145, 20, "unit", True), (25000, 320, 255, 33, "mixed", True), (20000, 128, 513, 5, "unit", True),
     (33000, 4096, 48, 100, "unit", True),                       # the 8B width (BASELINE configs 2-3)
+    # 129..256 queries over a wide shard: the main pass runs on the GEMM kernel (256-row tiles, sample in 256-row units)
+    (40000, 1024, 200, 10, "unit", True), (33001, 2048, 300, 5, "mixed", True), (70000, 1024, 256, 100, "unit", True), (20000, 1088, 129, 3, "unit", True),
     (60000, 256, 100, 100, "unit", False), (45000, 128, 128, 10, "mixed", False), (30011, 96, 40, 64, "unit", False),   # fp32 rows converted on the fly
 ])
 def test_score_free_filter_equals_score_matrix_filter_bitwise(N, D, Q, k, scale, shadow, search_mode):
@@ -48,9 +50,12 @@ def test_score_free_filter_equals_score_matrix_filter_bitwise(N, D, Q, k, scale,
     De, Ie = idx.search(q, k)
     search_mode(1)
     Dm, Im = idx.search(q, k)
+    search_mode(3)                                                # score-free, main pass never on the GEMM kernel
+    D3, I3 = idx.search(q, k)
     search_mode(0)
     Da, Ia = idx.search(q, k)
     assert torch.equal(Ie, Im) and torch.equal(De, Dm)
+    assert torch.equal(I3, Im) and torch.equal(D3, Dm)
     assert torch.equal(Ia, Im) and torch.equal(Da, Dm)
     check_against_oracle(De, Ie, q, X, k, id_base=1000)
 
