@@ -325,16 +325,80 @@ extern "C" int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, 
 // EmbeddingBag(mode='mean', padding_idx): one block per bag, thread = column, ids walked in order (same fp32 summation
 // order as the sequential CPU kernel), then slice + optional L2 normalise.
 // ---------------------------------------------------------------------------------------------------------------
+// EB_V4: columns in groups of four per thread (16-B table reads), the bag's ids staged once in LDS, ids outer / columns inner: a
+// thread has all its column groups' loads of several ids in flight (the scalar version re-read the ids and chained one dependent
+// 4-byte load per id per column: 88 us for 100 bags x ~20 ids at D = 2048, 8 % of a search pass).  Per column the rows are still
+// added in id order -> the same fp32 sums bit for bit.
+template <bool EB_V4>
 __global__ void __launch_bounds__(256) k_embedding_bag(const float* __restrict__ table, int vocab, int H, const int64_t* __restrict__ ids,
                                                        int64_t n_ids, const int64_t* __restrict__ offsets, int n_bags, int64_t pad,
                                                        float* __restrict__ out, int64_t out_stride, int out_dim, int normalize) {
   __shared__ float red[4];
+  __shared__ int s_row[256];      // table row of each id of the current chunk, -1 = skipped (padding_idx / out of range)
+  __shared__ int s_cnt[4];
   int b = blockIdx.x;
   int64_t s = offsets[b], e = (b + 1 < n_bags) ? offsets[b + 1] : n_ids;
-  int cnt = 0;
-  for (int64_t i = s; i < e; ++i) cnt += (ids[i] != pad) ? 1 : 0;
   float n2 = 0.f;
   float* o = out + (int64_t)b * out_stride;
+  if (EB_V4) {
+    constexpr int MAXG = 8;                                  // column groups per thread: out_dim <= 8192
+    const int ng = out_dim >> 2;                             // float4 groups in the output row
+    f32x4 acc[MAXG];
+#pragma unroll
+    for (int j = 0; j < MAXG; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+    for (int64_t c0 = s; c0 < e; c0 += 256) {
+      const int nc = (int)min((int64_t)256, e - c0);
+      __syncthreads();
+      int mine = 0;
+      if ((int)threadIdx.x < nc) {
+        const int64_t id = ids[c0 + threadIdx.x];
+        mine = id != pad ? 1 : 0;
+        s_row[threadIdx.x] = (id != pad && id >= 0 && id < vocab) ? (int)id : -1;
+      }
+      // number of non-padding ids of the chunk (the mean's divisor counts them even when out of range, like the scalar kernel)
+      const unsigned long long bal = __ballot(mine);
+      if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(bal);
+      __syncthreads();
+      cnt += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      for (int i = 0; i < nc; ++i) {
+        const int row = s_row[i];
+        if (row < 0) continue;
+        const f32x4* tr = (const f32x4*)(table + (int64_t)row * H);
+#pragma unroll
+        for (int j = 0; j < MAXG; ++j) {
+          const int g = threadIdx.x + 256 * j;
+          if (g < ng) {
+            const f32x4 v = tr[g];
+            acc[j][0] += v[0]; acc[j][1] += v[1]; acc[j][2] += v[2]; acc[j][3] += v[3];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXG; ++j) {
+      const int g = threadIdx.x + 256 * j;
+      if (g < ng) {
+        f32x4 m;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { m[c] = cnt > 0 ? acc[j][c] / (float)cnt : 0.f; n2 += m[c] * m[c]; }
+        acc[j] = m;
+      }
+    }
+    const float scale = normalize ? 1.0f / fmaxf(sqrtf(block_sum_256(n2, red)), 1e-12f) : 1.0f;
+#pragma unroll
+    for (int j = 0; j < MAXG; ++j) {
+      const int g = threadIdx.x + 256 * j;
+      if (g < ng) {
+        f32x4 m = acc[j];
+        if (normalize) { m[0] *= scale; m[1] *= scale; m[2] *= scale; m[3] *= scale; }
+        *(f32x4*)(o + 4 * g) = m;
+      }
+    }
+    return;
+  }
+  int cnt = 0;
+  for (int64_t i = s; i < e; ++i) cnt += (ids[i] != pad) ? 1 : 0;
   // out_dim <= H; each thread owns columns threadIdx.x + 256*j
   for (int c = threadIdx.x; c < out_dim; c += 256) {
     float acc = 0.f;
@@ -357,8 +421,15 @@ extern "C" int lrx_embedding_bag_mean(const float* table, int32_t vocab, int32_t
                                       int32_t out_dim, int32_t normalize, void* stream) {
   LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden, "embedding_bag: out_dim=%d out of range (H=%d)", out_dim, hidden);
   if (n_bags == 0) return LRX_OK;
-  hipLaunchKernelGGL(k_embedding_bag, dim3(n_bags), dim3(256), 0, (hipStream_t)stream, table, vocab, hidden, ids, n_ids, offsets, n_bags,
-                     padding_idx, out, out_row_stride, out_dim, normalize);
+  // 16-B path: rows of the table and of the output 16-B aligned, <= 8 column groups per thread
+  const bool v4 = hidden % 4 == 0 && out_dim % 4 == 0 && out_row_stride % 4 == 0 && out_dim <= 8192 && ((uintptr_t)table & 15) == 0 &&
+                  ((uintptr_t)out & 15) == 0;
+  if (v4)
+    hipLaunchKernelGGL(k_embedding_bag<true>, dim3(n_bags), dim3(256), 0, (hipStream_t)stream, table, vocab, hidden, ids, n_ids, offsets, n_bags,
+                       padding_idx, out, out_row_stride, out_dim, normalize);
+  else
+    hipLaunchKernelGGL(k_embedding_bag<false>, dim3(n_bags), dim3(256), 0, (hipStream_t)stream, table, vocab, hidden, ids, n_ids, offsets, n_bags,
+                       padding_idx, out, out_row_stride, out_dim, normalize);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

@@ -234,6 +234,24 @@ def test_embedding_bag_bit_exact():
     # and against torch.nn.EmbeddingBag itself (the reference's query operator) on the same device
     bag = torch.nn.EmbeddingBag.from_pretrained(tt, padding_idx=pad)
     np.testing.assert_allclose(f32(raw), f32(bag(ti, to)), atol=1e-6)
+    # round 2 kernel: bags longer than one 256-id chunk, the 2048-wide rows of the 1B table, an output width that is not a multiple
+    # of four (scalar path), out-of-range ids counted in the divisor but not summed -- all still the sequential fp32 sums
+    V2, H2 = 500, 2048
+    table2 = rng.standard_normal((V2, H2)).astype(np.float32)
+    lens2 = [600, 1, 257, 0, 32]
+    ids2 = rng.integers(0, V2, size=sum(lens2)).astype(np.int64)
+    ids2[[3, 300, 599, 700]] = pad
+    offs2 = np.concatenate([[0], np.cumsum(lens2)[:-1]]).astype(np.int64)
+    t2, i2, o2 = torch.from_numpy(table2).to(dev()), torch.from_numpy(ids2).to(dev()), torch.from_numpy(offs2).to(dev())
+    np.testing.assert_array_equal(f32(ops.embedding_bag_mean(t2, i2, o2, padding_idx=pad)), O.embedding_bag_mean(table2, ids2, offs2, pad))
+    np.testing.assert_array_equal(f32(ops.embedding_bag_mean(t2, i2, o2, padding_idx=pad, out_dim=250)), O.embedding_bag_mean(table2, ids2, offs2, pad)[:, :250])
+    np.testing.assert_allclose(f32(ops.embedding_bag_mean(t2, i2, o2, padding_idx=pad, out_dim=256, normalize=True)),
+                               O.encode_query_emb(table2, ids2, offs2, pad, dense_shrink_dim=256), atol=1e-6)
+    ids3 = ids2.copy(); ids3[[10, 650]] = V2 + 5          # out of range: skipped in the sum, counted like the scalar kernel does
+    i3 = torch.from_numpy(ids3).to(dev())
+    a4 = f32(ops.embedding_bag_mean(t2, i3, o2, padding_idx=pad))
+    a1 = f32(ops.embedding_bag_mean(t2, i3, o2, padding_idx=pad, out_dim=2047))
+    np.testing.assert_array_equal(a4[:, :2047], a1)
 
 
 def test_attention_last_tile_only_and_gather():
