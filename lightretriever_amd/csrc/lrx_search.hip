@@ -1086,8 +1086,10 @@ k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
     for (int i = part + REF_SPLIT * tid; i < (int)n; i += REF_SPLIT * 1024) {
       const unsigned long long e = list[i];
       if (key2f((uint32_t)(e >> 32)) >= thr) {
-        const unsigned int p = atomicAdd(&s_ncand, 1u);
-        if (p < REF_PCAND) s_cand[p] = (unsigned long long)sel_row(e);
+        const int64_t row = sel_row(e);
+        // never index outside the shard, whatever the list holds: a row that cannot exist sends the query to the exact fallback
+        const unsigned int p = row < N ? atomicAdd(&s_ncand, 1u) : atomicAdd(&s_ncand, (unsigned int)REF_PCAND + 1u);
+        if (p < REF_PCAND) s_cand[p] = (unsigned long long)row;
       }
     }
     __syncthreads();

@@ -276,3 +276,28 @@ def test_config3_10m_x_4096_single_gpu_properties():
     Dg, Ig = idx.search(q, k)
     _check_properties(idx, q, k, planted, Dg, Ig, chunk=32768)
     assert idx._ws.numel() < 6 << 30
+
+
+def test_search_on_a_side_stream_equals_default_stream(search_mode):
+    """The library launches on the stream it is handed (the caller's current HIP stream): a search issued on a non-default stream --
+    what an RPC server thread or a prefetching caller does -- gives the same bits, for both filters."""
+    rng = np.random.default_rng(17)
+    N, D, Q, k = 40000, 256, 150, 20
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32))
+    q = torch.from_numpy(O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))).cuda()
+    idx = _index(X)
+    ref = {}
+    for mode in (1, 2):
+        search_mode(mode)
+        ref[mode] = idx.search(q, k)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for mode in (1, 2):
+            search_mode(mode)
+            for _ in range(3):
+                Ds, Is = idx.search(q, k)
+            side.synchronize()
+            assert torch.equal(Ds, ref[mode][0]) and torch.equal(Is, ref[mode][1])
+    torch.cuda.current_stream().wait_stream(side)
