@@ -96,7 +96,8 @@ class FlatIPIndex:
     def shard_sink(self, row0: int, n_rows: int):
         """(shadow rows or None, bounds) for rows [row0, row0 + n) and a note that their producer maintains them."""
         self._ensure_shadow()
-        self._fused.append((row0, row0 + n_rows))
+        if row0 + n_rows > self.ntotal:               # (rows already committed need no bookkeeping: their producer keeps them valid)
+            self._fused.append((row0, row0 + n_rows))
         xb = self._xb[row0:row0 + n_rows] if (self._wants_shadow() and self._xb is not None) else None
         return xb, self._bounds
 
