@@ -1029,7 +1029,12 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
   const float eps = query_eps_block(q + (int64_t)qi * D, D, bounds, nullptr, s_red);
   const float thr = kth - 2.0f * eps;
   if (tid == 0) { thr_out[qi] = thr; eps_out[qi] = eps; }
+  // this workgroup is the only writer of the query's list until the main pass starts: slots come from an LDS counter (a global
+  // atomic per hit cost ~2 us of round trip per qualifying block and wave: 49 -> 3x us for the kernel), the count is stored once
   unsigned long long* list = cand + (int64_t)qi * CAND_CAP;
+  __shared__ unsigned int s_fill;
+  if (tid == 0) s_fill = 0;
+  __syncthreads();
   for (int b = wave; b < nblk; b += SEL_THREADS / 64)
     if (bm[b] >= thr) {
 #pragma unroll
@@ -1038,11 +1043,13 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
         const float v = row[j];
         const int64_t g = (j / rb) * ((int64_t)ss * rb) + (j % rb);
         if (g < N && v >= thr) {
-          const unsigned int p = atomicAdd(&cnt[qi * CNT_STRIDE], 1u);
+          const unsigned int p = atomicAdd(&s_fill, 1u);
           if (p < CAND_CAP) list[p] = sel_pack(f2key(v), g);
         }
       }
     }
+  __syncthreads();
+  if (tid == 0) cnt[qi * CNT_STRIDE] = s_fill;       // (the chunk's memset zeroed it; nobody else has touched it yet)
 }
 
 // exact rescoring of nc candidate rows (s_cand: row numbers): one half-wave per row (fp64 accumulation of the fp32 products, one
