@@ -233,7 +233,7 @@ int lrx_sparse_compact(const float* reps, int32_t n_rows, int32_t vocab_size, in
  *   method 1 (fuse_scores_linear): param0 * (s - min) / (max - min + param1), min/max over the row's valid entries.
  * Stage 2: the systems' (ids, contributions) concatenated per query in system order [n_queries, n_entries] -> union by id,
  * contributions of one id summed in system order, rows sorted by fused score (descending, lower id first among equals):
- * scores_out f64 / ids_out i64 [n_queries, n_entries] (-inf / -1 beyond counts_out[q]).  k, n_entries <= 2048.             */
+ * scores_out f64 / ids_out i64 [n_queries, n_entries] (-inf / -1 beyond counts_out[q]).  k, n_entries <= 4096.             */
 int lrx_hit_contributions(const double* scores, const int64_t* ids, int32_t n_queries, int32_t k, int64_t row_stride,
                           int32_t method, double param0, double param1, double* contrib_out, int64_t contrib_row_stride,
                           void* stream);

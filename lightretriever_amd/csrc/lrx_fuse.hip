@@ -5,7 +5,7 @@
 //   stage 2  lrx_hit_union:         per query, concatenated lists -> union by document id, summed, sorted by fused score
 #include "lrx_common.h"
 
-#define FUSE_MAX 2048      // entries per workgroup-sorted list (two systems x top-1000 fits)
+#define FUSE_MAX 4096      // entries per workgroup-sorted list: three systems x top-1000 or two x top-2000 (80 KiB of LDS in lrx_hit_union)
 
 template <typename Less, typename Swap>
 __device__ __forceinline__ void bitonic_sort(int n_pow2, Less less, Swap swp) {
@@ -100,10 +100,16 @@ __global__ void __launch_bounds__(1024) k_hit_union(const int64_t* __restrict__ 
   };
   // by document, then by original position = system order (the order the reference accumulates the systems in)
   bitonic_sort(n2, [&](int a, int b) { return s_id[a] < s_id[b] || (s_id[a] == s_id[b] && s_pos[a] < s_pos[b]); }, swp);
-  // heads sum their run (n2 <= 2048 = two rounds of the 1024 threads); two passes so nobody overwrites what a head still reads
-  double tot[2] = {0.0, 0.0};
-  bool hd[2] = {false, false};
-  for (int r = 0, i = tid; i < n2; i += blockDim.x, ++r) {
+  // heads sum their run (n2 <= FUSE_MAX = FUSE_MAX / 1024 rounds of the 1024 threads); two passes so nobody overwrites what a head still reads
+  constexpr int ROUNDS = FUSE_MAX / 1024;
+  double tot[ROUNDS];
+  bool hd[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) { tot[r] = 0.0; hd[r] = false; }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int i = tid + r * 1024;
+    if (i >= n2) break;
     hd[r] = s_id[i] != INV && (i == 0 || s_id[i - 1] != s_id[i]);
     if (hd[r]) {
       double t = 0.0;
@@ -112,7 +118,10 @@ __global__ void __launch_bounds__(1024) k_hit_union(const int64_t* __restrict__ 
     }
   }
   __syncthreads();
-  for (int r = 0, i = tid; i < n2; i += blockDim.x, ++r) {
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int i = tid + r * 1024;
+    if (i >= n2) break;
     if (hd[r]) { s_sc[i] = tot[r]; atomicAdd(&s_cnt, 1); }
     else { s_id[i] = INV; s_sc[i] = -__builtin_inf(); }
   }

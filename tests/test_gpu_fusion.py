@@ -33,14 +33,15 @@ def test_dict_form_equals_reference_bit_for_bit():
         fuse_scores_linear(two, weights=[1.0])
 
 
-@pytest.mark.parametrize("method", ["rrf", "linear"])
-def test_array_form_top1000_lists(method):
-    """Two systems x top-1000 per query (the eval setting): union, sums, ordering and padding against the oracle."""
+@pytest.mark.parametrize("method,n_sys", [("rrf", 2), ("linear", 2), ("rrf", 3), ("linear", 3)])
+def test_array_form_top1000_lists(method, n_sys):
+    """Two systems x top-1000 per query (the eval setting) and three (the reference accepts any number of lists): union, sums,
+    ordering and padding against the oracle."""
     from lightretriever_amd.score_fuse_utils import fuse_hits
     rng = np.random.default_rng(3)
     Q, k, N = 9, 1000, 5000
     sys_np = []
-    for s in range(2):
+    for s in range(n_sys):
         ids = np.stack([rng.choice(N, size=k, replace=False) for _ in range(Q)]).astype(np.int64)
         sc = np.sort(rng.standard_normal((Q, k)).astype(np.float32), axis=1)[:, ::-1].copy()      # sorted hit lists, like a search returns
         ids[2, 700:] = -1                                                                         # a short list (k > hits)
@@ -48,10 +49,10 @@ def test_array_form_top1000_lists(method):
             ids[5, :] = -1                                                                        # a query the second system has nothing for
         sys_np.append((sc, ids))
     sc, ids, cnt = fuse_hits([(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) for a, b in sys_np], method=method, k=60,
-                             weights=[0.7, 0.3])
+                             weights=[0.7, 0.3, 0.2][:n_sys])
     sc, ids, cnt = sc.cpu().numpy(), ids.cpu().numpy(), cnt.cpu().numpy()
     dicts = [{str(q): {str(int(p)): float(v) for p, v in zip(b[q], a[q]) if p >= 0} for q in range(Q) if (b[q] >= 0).any()} for a, b in sys_np]
-    want = O.fuse_scores_rrf(dicts, k=60) if method == "rrf" else O.fuse_scores_linear(dicts, [0.7, 0.3])
+    want = O.fuse_scores_rrf(dicts, k=60) if method == "rrf" else O.fuse_scores_linear(dicts, [0.7, 0.3, 0.2][:n_sys])
     for q in range(Q):
         w = want[str(q)]
         assert cnt[q] == len(w)
@@ -68,7 +69,7 @@ def test_fuse_argument_errors():
     from lightretriever_amd.score_fuse_utils import fuse_hits
     a = (torch.zeros(2, 1500, device="cuda"), torch.zeros(2, 1500, dtype=torch.int64, device="cuda"))
     with pytest.raises(LrxError):
-        fuse_hits([a, a])                       # 3000 entries per query exceed the 2048-entry workgroup sort
+        fuse_hits([a, a, a])                    # 4500 entries per query exceed the 4096-entry workgroup sort
     with pytest.raises(NotImplementedError):
         fuse_hits([a], method="borda")
 
