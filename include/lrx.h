@@ -328,13 +328,13 @@ int lrx_flat_ip_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim,
 
 /* Merge R per-shard result lists (after the RCCL all-gather of [Q,k] pairs; replaces faiss IndexShards' host merge
  * used via index_cpu_to_all_gpus, retriever/faiss_index.py:65-68) : in_scores/in_ids [R, Q, k] -> out [Q, k].
- * Limits: R * k <= 8192 (one LDS-resident bitonic merge per query); ids are carried as 32 bits inside the merge: 0 <= id < 2^32. */
+ * Limits: R * k <= 16384 (one LDS-resident bitonic merge per query); ids are carried as 32 bits inside the merge: 0 <= id < 2^32. */
 int lrx_merge_topk(const float* in_scores, const int64_t* in_ids, int32_t n_parts, int32_t n_queries, int32_t k,
                    float* out_scores, int64_t* out_ids, void* stream);
 /* The exchange form: one 64-bit word per hit (fp32 score bits << 32 | global row as uint32, 0xFFFFFFFF = none), so the
  * all-gather moves a single [Q, k] int64 array per rank.  lrx_pack_topk builds it from a shard's (scores, ids) -- row_map (may be
  * NULL) turns shard-local rows (ids - id_base) into global rows; ids < 0 stay "none"; global rows must be < 2^32 - 1 --
- * lrx_merge_topk_packed merges the gathered [R, Q, k] words (R * k <= 8192) with lrx_merge_topk's ordering rule.               */
+ * lrx_merge_topk_packed merges the gathered [R, Q, k] words (R * k <= 16384) with lrx_merge_topk's ordering rule.               */
 int lrx_pack_topk(const float* scores, const int64_t* ids, const int64_t* row_map, int64_t id_base, int64_t n,
                   uint64_t* out_packed, void* stream);
 int lrx_merge_topk_packed(const uint64_t* in_packed, int32_t n_parts, int32_t n_queries, int32_t k, float* out_scores,

@@ -1435,7 +1435,7 @@ extern "C" int lrx_shard_commit_rows(const float* X, int64_t ldx, int64_t n_rows
 // ---------------------------------------------------------------------------------------------------------------
 // merge of R shard-local top-k lists
 // ---------------------------------------------------------------------------------------------------------------
-#define MERGE_MAX 8192
+#define MERGE_MAX 16384   // R * k: one LDS-resident bitonic merge per query (128 KiB at the maximum: 8 shards x k = 2048)
 // in_packed != NULL: the lists arrive as one 64-bit word per hit (fp32 score bits << 32 | row as uint32, row 0xFFFFFFFF = none) --
 // the form that crosses the all-gather (lrx_pack_topk)
 __global__ void __launch_bounds__(1024)

@@ -111,6 +111,34 @@ def test_merge_topk_matches_oracle_and_single_index():
     np.testing.assert_array_equal(Im_.cpu().numpy(), Io)
 
 
+def test_merge_at_the_widest_supported_exchange():
+    """8 shards x k = 2048 (R * k = 16384, the limit; ADVICE r1: k > 1024 over 8 ranks used to be refused) -- both forms of the merge,
+    and one entry more is refused loudly."""
+    from lightretriever_amd import FlatIPIndex, merge_topk, _lib
+    rng = np.random.default_rng(12)
+    N, Dm, Q, k, R = 40000, 32, 3, 2048, 8
+    X = O.l2_normalize(rng.standard_normal((N, Dm)).astype(np.float32))
+    q = O.l2_normalize(rng.standard_normal((Q, Dm)).astype(np.float32))
+    Dp, Ip = [], []
+    for r in range(R):
+        sh = FlatIPIndex(Dm, id_base=r * N // R)
+        sh.add(X[r * N // R:(r + 1) * N // R])
+        d, i = sh.search(q, k)
+        Dp.append(d), Ip.append(i)
+    Dm_, Im_ = merge_topk(torch.stack(Dp), torch.stack(Ip))
+    Do, Io = O.flat_ip_topk(q, X, k)
+    np.testing.assert_array_equal(Im_.cpu().numpy(), Io)
+    lib = _lib.lib()
+    words = torch.empty(R, Q, k, dtype=torch.int64, device="cuda")
+    for r in range(R):
+        _lib.check(lib.lrx_pack_topk(_lib.ptr(Dp[r]), _lib.ptr(Ip[r]), None, 0, Q * k, _lib.ptr(words[r]), _lib.current_stream()))
+    D2, I2 = torch.empty_like(Dm_), torch.empty_like(Im_)
+    _lib.check(lib.lrx_merge_topk_packed(_lib.ptr(words), R, Q, k, _lib.ptr(D2), _lib.ptr(I2), _lib.current_stream()))
+    assert torch.equal(D2, Dm_) and torch.equal(I2, Im_)
+    with pytest.raises(_lib.LrxError):
+        merge_topk(torch.zeros(9, 1, 2048, device="cuda"), torch.zeros(9, 1, 2048, dtype=torch.int64, device="cuda"))
+
+
 def test_full_size_1m_x_2048_properties():
     """BASELINE config 2 index size.  Properties: sorted, unique ids, every score equals the recomputed dot product, the
     top-1 equals a chunked torch argmax, planted exact matches are found at rank 0, shard-merge equals whole-index."""
