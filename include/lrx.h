@@ -75,6 +75,8 @@ typedef struct lrx_encoder_weights {
   const float* rope_cos;         /* [max_positions, d/2] fp32 (values already rounded to bf16, as HF casts cos/sin) */
   const float* rope_sin;
   const lrx_layer_weights* layers; /* HOST array of num_layers structs (device pointers inside) */
+  const void* rope_cs_bf16;      /* optional (NULL = use the fp32 tables): the same values as bf16, [max_positions, d]: row p = cos(p, 0..d/2-1) |
+                                    sin(p, 0..d/2-1).  The fused QKV+RoPE epilogue then reads 32 B instead of 64 B of table per 8 outputs */
 } lrx_encoder_weights;
 
 /* What torch.ops.lrx.encode_packed takes as its `weights` argument: the address of one of these (both structs owned, and kept

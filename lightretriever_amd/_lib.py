@@ -27,7 +27,7 @@ class LayerWeightsC(C.Structure):
 
 class EncoderWeightsC(C.Structure):
     _fields_ = [("embed", C.c_void_p), ("final_norm", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-                ("layers", C.POINTER(LayerWeightsC))]
+                ("layers", C.POINTER(LayerWeightsC)), ("rope_cs_bf16", C.c_void_p)]
 
 
 _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t

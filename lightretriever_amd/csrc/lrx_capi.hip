@@ -164,7 +164,7 @@ static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights
     const bool last = l == c->num_layers - 1;
     if (!fold) { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
     { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);   // QKV projection with (row scale,) bias + RoPE fused into the epilogue
-      if ((rc = lrx_gemm_qkv_rope_fused(fold ? ws.x : ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv,
+      if ((rc = lrx_gemm_qkv_rope_launch(fold ? ws.x : ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, w->rope_cs_bf16, T, H, nq, nkv,
                                         d, fold ? ws.rsA : nullptr, s))) return rc; }
     if (pooled_tail && last) {
       const int B = n_seqs;
@@ -349,7 +349,7 @@ extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_enco
       const lrx_layer_weights& L = w->layers[l];
       const void* a_in; const float* rs_in;
       if ((rc = pre_norm(c, ws.x, L.ln1, ws.h, P1, ws.rsA, s, &a_in, &rs_in))) return rc;
-      if ((rc = lrx_gemm_qkv_rope_fused(a_in, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, P1, H, nq, nkv, d, rs_in, s))) return rc;
+      if ((rc = lrx_gemm_qkv_rope_launch(a_in, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, w->rope_cs_bf16, P1, H, nq, nkv, d, rs_in, s))) return rc;
       LRX_HIP(hipMemcpy2DAsync(pw.kvcap + (size_t)l * P1 * KVW * 2, (size_t)KVW * 2, ws.qkv + (size_t)QD * 2, (size_t)QKV * 2, (size_t)KVW * 2, P1,
                                hipMemcpyDeviceToDevice, s));
       if (l == c->num_layers - 1) break;   // nothing after the last layer's K/V is needed from the prefix
@@ -369,7 +369,7 @@ extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_enco
     const void* a_in; const float* rs_in;
     { ProfScope p(s, 4, 0); if ((rc = pre_norm(c, ws.x, L.ln1, ws.h, T, ws.rsA, s, &a_in, &rs_in))) return rc; }
     { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);
-      if ((rc = lrx_gemm_qkv_rope_fused(a_in, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, rs_in, s))) return rc; }
+      if ((rc = lrx_gemm_qkv_rope_launch(a_in, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, w->rope_cs_bf16, T, H, nq, nkv, d, rs_in, s))) return rc; }
     { ProfScope p(s, 3, 0);
       if ((rc = lrx_attn_prefix_suffix(ws.qkv, pw.kvcap + (size_t)l * prefix_len * KVW * 2, n_seqs, suffix_len, prefix_len, nq, nkv, d, ws.h, s))) return rc; }
     { ProfScope p(s, 1, 2.0 * T * (double)H * QD); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wo, ws.x, nullptr, ws.x, T, H, QD, 1, s))) return rc; }

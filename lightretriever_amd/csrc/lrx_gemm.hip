@@ -39,6 +39,7 @@ struct RopeArgs {
   const float* sin;
   int rope_cols;             // columns [0, rope_cols) are q|k heads to rotate; the rest (v) is stored as is
   int head_dim;
+  const __bf16* cs16;        // optional: the same table values as bf16, [max_pos, head_dim] = cos | sin per row (half the table bytes)
 };
 
 // Search filter pass (EPI_EMIT): A = bf16 shadow rows of the shard, B = bf16 queries; no C.  A score reaching thr[query] is appended
@@ -437,11 +438,23 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   for (int it0 = 0; it0 < NIT; it0 += RBATCH) {
   f32x4 rcs[EPI == EPI_ROPE ? RBATCH : 1][4];
   if (EPI == EPI_ROPE) {
+    if (rope.cs16 != nullptr) {        // bf16 table rows [cos | sin]: two 16-B loads per 8 outputs instead of four
 #pragma unroll
-    for (int u = 0; u < RBATCH; ++u) {
-      const float* cs = rope.cos + (int64_t)rpos[it0 + u] * rhalf + rj;
-      const float* sn = rope.sin + (int64_t)rpos[it0 + u] * rhalf + rj;
-      rcs[u][0] = *(const f32x4*)cs; rcs[u][1] = *(const f32x4*)(cs + 4); rcs[u][2] = *(const f32x4*)sn; rcs[u][3] = *(const f32x4*)(sn + 4);
+      for (int u = 0; u < RBATCH; ++u) {
+        const __bf16* cs = rope.cs16 + (int64_t)rpos[it0 + u] * rope.head_dim + rj;
+        const bf16x8 c8 = *(const bf16x8*)cs, s8 = *(const bf16x8*)(cs + rhalf);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          rcs[u][0][e] = bf2f(c8[e]); rcs[u][1][e] = bf2f(c8[4 + e]); rcs[u][2][e] = bf2f(s8[e]); rcs[u][3][e] = bf2f(s8[4 + e]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < RBATCH; ++u) {
+        const float* cs = rope.cos + (int64_t)rpos[it0 + u] * rhalf + rj;
+        const float* sn = rope.sin + (int64_t)rpos[it0 + u] * rhalf + rj;
+        rcs[u][0] = *(const f32x4*)cs; rcs[u][1] = *(const f32x4*)(cs + 4); rcs[u][2] = *(const f32x4*)sn; rcs[u][3] = *(const f32x4*)(sn + 4);
+      }
     }
   }
 #pragma unroll
@@ -520,7 +533,7 @@ extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, con
   hipStream_t s = (hipStream_t)stream;
   const __bf16 *a = (const __bf16*)A, *b = (const __bf16*)B, *bi = (const __bf16*)bias, *re = (const __bf16*)resid;
   __bf16* c = (__bf16*)C;
-  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, nullptr};
   MaxAggArgs nomx = {nullptr, nullptr, 0};
   NormArgs nrm = {rscale, ss_part, gemm_group_m(epilogue, K)};
   switch (epilogue) {
@@ -541,13 +554,20 @@ extern "C" int lrx_gemm_qkv_rope(const void* A, const void* Wqkv, void* C, const
 extern "C" int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos,
                                        const float* sin, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
                                        const float* rscale, void* stream) {
+  return lrx_gemm_qkv_rope_launch(A, Wqkv, C, bias, positions, cos, sin, nullptr, M, K, num_q_heads, num_kv_heads, head_dim, rscale, stream);
+}
+
+// (internal) the same with the optional bf16 table of lrx_encoder_weights.rope_cs_bf16
+int lrx_gemm_qkv_rope_launch(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos, const float* sin,
+                             const void* cs16, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, const float* rscale,
+                             void* stream) {
   const int N = (num_q_heads + 2 * num_kv_heads) * head_dim;
   LRX_CHECK_ARG(M >= 0 && K > 0 && K % GBK == 0, "gemm_qkv_rope: bad shape M=%d K=%d", M, K);
   LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "gemm_qkv_rope: head_dim=%d unsupported", head_dim);
   LRX_CHECK_ARG(positions && cos && sin, "gemm_qkv_rope: null rope inputs");
   if (M == 0) return LRX_OK;
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
-  RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim};
+  RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim, (const __bf16*)cs16};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)Wqkv,
                      (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0},
                      NormArgs{rscale, nullptr, 8}, EmitArgs{nullptr, nullptr, nullptr, 0});
@@ -565,7 +585,7 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   LRX_CHECK_ARG(row_seg && out && ldo >= N, "max_aggregate: bad output spec");
   if (M == 0) return LRX_OK;
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
-  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, nullptr};
   MaxAggArgs mx = {row_seg, out, ldo};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
                      (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, LRX_MAXAGG_GM},
@@ -583,7 +603,7 @@ int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows,
   LRX_CHECK_ARG(dim > 0 && dim % GBK == 0 && nq > 0 && nq <= GBN && n_rows < (1ll << 31), "filter_emit: bad shape rows=%lld nq=%d dim=%d",
                 (long long)n_rows, nq, dim);
   if (n_tiles <= 0) return LRX_OK;
-  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, nullptr};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_EMIT>, dim3((unsigned)n_tiles), dim3(512), 0, stream, (const __bf16*)Xb, (const __bf16*)q16, (__bf16*)nullptr,
                      (const __bf16*)nullptr, (const __bf16*)nullptr, (int)n_rows, nq, dim, (int)n_tiles, 1, none, MaxAggArgs{nullptr, nullptr, 0},
                      NormArgs{nullptr, nullptr, 8}, EmitArgs{thr, cand, cnt, ss});

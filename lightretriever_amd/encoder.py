@@ -6,6 +6,8 @@ llama3 scaling), then run HybridModel.encode_passage's dense branch (finetune/mo
 call into liblrx.so on a packed (ids, cu_seqlens) batch."""
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from dataclasses import dataclass
@@ -146,6 +148,8 @@ class LrxEncoder:
         self.final_norm = dev(g("norm.weight"))
         cos, sin = rope_tables(cfg)
         self.rope_cos, self.rope_sin = cos.to(self.device), sin.to(self.device)
+        # the same table as bf16 rows [cos | sin] (the values are bf16-representable already: HF casts cos/sin to the activation dtype)
+        self.rope_cs16 = torch.cat([self.rope_cos, self.rope_sin], 1).to(torch.bfloat16).contiguous()
         self.layers = []
         for i in range(cfg.num_layers):
             p = f"layers.{i}."
@@ -230,7 +234,8 @@ class LrxEncoder:
                                         L["ln2"].data_ptr())
         self._clayers = arr
         self._cw = _lib.EncoderWeightsC(self.embed.data_ptr(), self.final_norm.data_ptr(), self.rope_cos.data_ptr(),
-                                        self.rope_sin.data_ptr(), C.cast(arr, C.POINTER(_lib.LayerWeightsC)))
+                                        self.rope_sin.data_ptr(), C.cast(arr, C.POINTER(_lib.LayerWeightsC)),
+                                        self.rope_cs16.data_ptr() if getattr(self, "use_bf16_rope_table", os.environ.get("LRX_ROPE_FP32_TABLE") != "1") else None)
 
     def workspace_bytes(self, total_tokens: int, n_seqs: int) -> int:
         return int(self.lib.lrx_encode_workspace_bytes(C.byref(self._ccfg), total_tokens, n_seqs))

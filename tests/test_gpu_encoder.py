@@ -213,3 +213,18 @@ def test_released_backbone_dims_hf_parity(preset, layers):
     assert (1 - cos).max().item() <= COS_TOL, (preset, 1 - cos)
     del hf, enc
     torch.cuda.empty_cache()
+
+
+def test_bf16_rope_table_gives_the_same_bits_as_the_fp32_table():
+    """lrx_encoder_weights.rope_cs_bf16 (round 2): the fused QKV + RoPE epilogue reads the cos/sin values as bf16 (they are bf16-representable:
+    HF casts the table to the activation dtype) -- half the table bytes, the same arithmetic, bit-identical embeddings."""
+    cfg_o, w, g, ids, cu, max_len = load_model_golden("llama_small_d64")
+    enc = make_encoder(cfg_o, w)
+    tid, tcu = to_dev(ids, torch.int32), to_dev(cu, torch.int32)
+    assert enc._cw.rope_cs_bf16
+    a = enc.encode_packed(tid, tcu, max_len).clone()
+    enc.use_bf16_rope_table = False
+    enc._build_c_structs()
+    assert not enc._cw.rope_cs_bf16
+    b = enc.encode_packed(tid, tcu, max_len)
+    assert torch.equal(a, b)
