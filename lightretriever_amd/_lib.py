@@ -38,8 +38,8 @@ SIGNATURES = {
     "lrx_last_error": (C.c_char_p, []),
     "lrx_encode_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I32, _I32]),
     "lrx_encode_packed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),
-    "lrx_encode_packed_shard": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _I64, _P,
-                                       _P, _SZ, _P]),
+    "lrx_encode_packed_shard": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _I64, _I64,
+                                       _P, _P, _SZ, _P]),
     "lrx_encode_hidden": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "lrx_encode_prefixed_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I32, _I32, _I32]),
     "lrx_encode_prefixed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _I32, _P, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),
@@ -55,8 +55,8 @@ SIGNATURES = {
     "lrx_flat_ip_bounded_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "lrx_flat_ip_search_bounded": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _P, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _P]),
     "lrx_search_set_mode": (None, [_I32]),
-    "lrx_shard_commit_rows": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _P, _P]),
-    "lrx_pool_norm_shard": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P, _I64, _P, _P]),
+    "lrx_shard_commit_rows": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _I64, _P, _P]),
+    "lrx_pool_norm_shard": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P, _I64, _I64, _P, _P]),
     "lrx_gemm_bf16_nt_fused": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "lrx_gemm_qkv_rope_fused": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "lrx_row_rscale": (_I32, [_P, _I32, _I32, C.c_float, _P, _P]),

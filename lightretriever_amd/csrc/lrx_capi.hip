@@ -213,8 +213,8 @@ static int check_call(const lrx_encoder_config* cfg, const lrx_encoder_weights* 
 
 extern "C" int lrx_encode_packed_shard(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,
                                        int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, float* out, int64_t out_row_stride,
-                                       int32_t out_dim, int32_t normalize, void* shadow_out, int64_t shadow_row_stride, float* row_bounds,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
+                                       int32_t out_dim, int32_t normalize, void* shadow_out, int64_t shadow_row_stride, int64_t shadow_row0,
+                                       float* row_bounds, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_call(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, workspace, workspace_bytes);
   if (rc) return rc;
   LRX_CHECK_ARG(out && out_dim > 0 && out_dim <= cfg->hidden_size && out_row_stride >= out_dim, "encode: bad output spec (dim=%d stride=%lld)",
@@ -226,7 +226,7 @@ extern "C" int lrx_encode_packed_shard(const lrx_encoder_config* cfg, const lrx_
   {
     ProfScope p(s, 6, 0);  // ws.xr holds the compacted last-token rows -> cu_seqlens = NULL
     if ((rc = lrx_pool_norm_shard(ws.xr, w->final_norm, nullptr, n_seqs, cfg->hidden_size, cfg->rms_eps, out, out_row_stride, out_dim, normalize,
-                                  shadow_out, shadow_row_stride, row_bounds, s)))
+                                  shadow_out, shadow_row_stride, shadow_row0, row_bounds, s)))
       return rc;
   }
   return prof_end(s);
@@ -236,7 +236,7 @@ extern "C" int lrx_encode_packed(const lrx_encoder_config* cfg, const lrx_encode
                                  int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, float* out, int64_t out_row_stride,
                                  int32_t out_dim, int32_t normalize, void* workspace, size_t workspace_bytes, void* stream) {
   return lrx_encode_packed_shard(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, out, out_row_stride, out_dim, normalize, nullptr, 0,
-                                 nullptr, workspace, workspace_bytes, stream);
+                                 0, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int lrx_encode_hidden(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,

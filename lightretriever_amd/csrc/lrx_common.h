@@ -76,8 +76,8 @@ static inline int64_t lrx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // lrx_gemm.hip: the GEMM kernel as the search's filter pass for 129..256 queries: scores = Xb[rows, D] . q16[nq, D]^T (bf16 operands,
 // fp32 accumulation), nothing stored, rows reaching thr[query] appended to the query's candidate list.  Covers the 256-row tiles
 // that are not in the sample (every ss-th tile): n_tiles of them.
-int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles, const float* thr,
-                                unsigned long long* cand, unsigned int* cnt, hipStream_t stream);
+int lrx_gemm_filter_emit_launch(const void* Xb, bool xb_tiled, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles,
+                                const float* thr, unsigned long long* cand, unsigned int* cnt, hipStream_t stream);
 // lrx_gemm.hip: fused QKV + RoPE GEMM with the optional bf16 RoPE table (cs16 = lrx_encoder_weights.rope_cs_bf16 or NULL)
 int lrx_gemm_qkv_rope_launch(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos, const float* sin,
                              const void* cs16, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, const float* rscale,

@@ -239,7 +239,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 __global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hidden, const __bf16* __restrict__ w,
                                                    const int32_t* __restrict__ cu, int H, float eps, float* __restrict__ out,
                                                    int64_t out_stride, int out_dim, int normalize, __bf16* __restrict__ shadow,
-                                                   int64_t shadow_stride, float* __restrict__ bounds) {
+                                                   int64_t shadow_stride, int64_t shadow_row0, float* __restrict__ bounds) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* row = (float*)smem_raw;  // H floats
   float* red = row + H;           // 4 floats
@@ -259,13 +259,16 @@ __global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hi
   n2 = block_sum_256(n2, red);
   float scale = normalize ? 1.0f / fmaxf(sqrtf(n2), 1e-12f) : 1.0f;
   float* o = out + (int64_t)b * out_stride;
-  __bf16* ob = shadow ? shadow + (int64_t)b * shadow_stride : nullptr;
+  // shadow row: row-major (stride shadow_stride) or, stride 0, row shadow_row0 + b of the tiled layout [128-row block][64-wide slice][128][64]
+  const int64_t ra = shadow_row0 + b;
+  __bf16* ob = !shadow ? nullptr : (shadow_stride != 0 ? shadow + (int64_t)b * shadow_stride : shadow + ((ra >> 7) * (int64_t)(out_dim / 64)) * 8192 + (ra & 127) * 64);
+  const bool tiled = shadow_stride == 0;
   float r2 = 0.f, e2 = 0.f;
   for (int i = threadIdx.x; i < out_dim; i += 256) {
     const float v = normalize ? row[i] * scale : row[i];
     o[i] = v;
     const __bf16 h = f2bf(v);
-    if (ob) ob[i] = h;
+    if (ob) ob[tiled ? (int64_t)(i >> 6) * 8192 + (i & 63) : i] = h;
     const float d = v - bf2f(h);
     r2 += v * v;
     e2 += d * d;
@@ -282,13 +285,15 @@ __global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hi
 
 extern "C" int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                                    int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize,
-                                   void* shadow_out, int64_t shadow_row_stride, float* row_bounds, void* stream) {
+                                   void* shadow_out, int64_t shadow_row_stride, int64_t shadow_row0, float* row_bounds, void* stream) {
   LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden_size, "pool_norm: out_dim=%d out of range (H=%d)", out_dim, hidden_size);
-  LRX_CHECK_ARG(shadow_out == nullptr || shadow_row_stride >= out_dim, "pool_norm: shadow row stride %lld < out_dim", (long long)shadow_row_stride);
+  LRX_CHECK_ARG(shadow_out == nullptr || shadow_row_stride >= out_dim || (shadow_row_stride == 0 && out_dim % 64 == 0 && shadow_row0 >= 0),
+                "pool_norm: bad shadow layout (row stride %lld, out_dim %d)", (long long)shadow_row_stride, out_dim);
   if (n_seqs == 0) return LRX_OK;
   size_t smem = (size_t)(hidden_size + 4) * sizeof(float);
   hipLaunchKernelGGL(k_pool_norm, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, (const __bf16*)hidden, (const __bf16*)final_norm_w,
-                     cu_seqlens, hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row_stride, row_bounds);
+                     cu_seqlens, hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row_stride, shadow_row0,
+                     row_bounds);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -297,7 +302,7 @@ extern "C" int lrx_pool_norm(const void* hidden, const void* final_norm_w, const
                              int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize,
                              void* stream) {
   return lrx_pool_norm_shard(hidden, final_norm_w, cu_seqlens, n_seqs, hidden_size, eps, out, out_row_stride, out_dim, normalize, nullptr, 0,
-                             nullptr, stream);
+                             0, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -50,6 +50,7 @@ struct EmitArgs {
   unsigned long long* cand;  // [nq, CAND_CAP]
   unsigned int* cnt;         // [nq * CNT_STRIDE]
   int ss;
+  int a_tiled;               // A is the tiled shadow [128-row block][64-wide k-slice][128][64] instead of row-major [M, K]
 };
 
 struct MaxAggArgs {
@@ -125,18 +126,26 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   for (int i = 0; i < 2; ++i) {
     int s = (wave * 2 + i) * 64 + lane;
     int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
-    pA0[i] = A + (int64_t)min(m0 + row, M - 1) * K + c * 8;
-    pA1[i] = A + (int64_t)min(m0 + 128 + row, M - 1) * K + c * 8;
+    if (EPI == EPI_EMIT && em.a_tiled) {
+      const int r0 = min(m0 + row, M - 1), r1 = min(m0 + 128 + row, M - 1);
+      pA0[i] = A + ((int64_t)(r0 >> 7) * (K / 64)) * 8192 + (r0 & 127) * 64 + c * 8;
+      pA1[i] = A + ((int64_t)(r1 >> 7) * (K / 64)) * 8192 + (r1 & 127) * 64 + c * 8;
+    } else {
+      pA0[i] = A + (int64_t)min(m0 + row, M - 1) * K + c * 8;
+      pA1[i] = A + (int64_t)min(m0 + 128 + row, M - 1) * K + c * 8;
+    }
     pB0[i] = B + (int64_t)min(n0 + row, N - 1) * K + c * 8;
     pB1[i] = B + (int64_t)min(n0 + 128 + row, N - 1) * K + c * 8;
   }
   char* const dma_dst = smem + wave * 2048;  // + buf*65536 + slot*16384 + i*1024
 #define G_KOFF(KT) ((KT) * GBK)
-#define G_ISSUE(P, SLOT, BUF, KT)                                                                                          \
+  const int a_ks = (EPI == EPI_EMIT && em.a_tiled) ? 8192 : GBK;   // elements from one K-tile of an A row to the next
+#define G_ISSUE_(P, SLOT, BUF, KOFF)                                                                                       \
   do {                                                                                                                     \
-    __builtin_amdgcn_global_load_lds((gptr_t)(P[0] + G_KOFF(KT)), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES), 16, 0, 0);        \
-    __builtin_amdgcn_global_load_lds((gptr_t)(P[1] + G_KOFF(KT)), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES + 1024), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gptr_t)(P[0] + (KOFF)), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES), 16, 0, 0);        \
+    __builtin_amdgcn_global_load_lds((gptr_t)(P[1] + (KOFF)), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES + 1024), 16, 0, 0); \
   } while (0)
+#define G_ISSUE(P, SLOT, BUF, KT) G_ISSUE_(P, SLOT, BUF, ((SLOT) < 2 ? (int64_t)(KT) * a_ks : (int64_t)G_KOFF(KT)))   /* slots 0/1 = A halves */
 
 
   // ---- fragment read offsets
@@ -537,9 +546,9 @@ extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, con
   MaxAggArgs nomx = {nullptr, nullptr, 0};
   NormArgs nrm = {rscale, ss_part, gemm_group_m(epilogue, K)};
   switch (epilogue) {
-    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0}); break;
-    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0}); break;
-    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0}); break;
+    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0}); break;
+    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0}); break;
+    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0}); break;
   }
   LRX_LAUNCH_CHECK();
   return LRX_OK;
@@ -570,7 +579,7 @@ int lrx_gemm_qkv_rope_launch(const void* A, const void* Wqkv, void* C, const voi
   RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim, (const __bf16*)cs16};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)Wqkv,
                      (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{rscale, nullptr, 8}, EmitArgs{nullptr, nullptr, nullptr, 0});
+                     NormArgs{rscale, nullptr, 8}, EmitArgs{nullptr, nullptr, nullptr, 0, 0});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -589,7 +598,7 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   MaxAggArgs mx = {row_seg, out, ldo};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
                      (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, LRX_MAXAGG_GM},
-                     EmitArgs{nullptr, nullptr, nullptr, 0});
+                     EmitArgs{nullptr, nullptr, nullptr, 0, 0});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -598,15 +607,15 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
 // on the GEMM kernel -- its 256 x 256 tile stages a query k-slice once per 256 rows and its 4-phase K loop keeps the LDS-DMA ahead of
 // the MFMAs with one workgroup per CU; the 128-row filter kernel re-stages the 32-KiB query slice for every 128 rows and is bound
 // by that L2 -> LDS traffic at 16 query tiles (1.19 ms for 256 queries over 1M x 2048; HBM floor 0.75).
-int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles, const float* thr,
-                                unsigned long long* cand, unsigned int* cnt, hipStream_t stream) {
+int lrx_gemm_filter_emit_launch(const void* Xb, bool xb_tiled, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles,
+                                const float* thr, unsigned long long* cand, unsigned int* cnt, hipStream_t stream) {
   LRX_CHECK_ARG(dim > 0 && dim % GBK == 0 && nq > 0 && nq <= GBN && n_rows < (1ll << 31), "filter_emit: bad shape rows=%lld nq=%d dim=%d",
                 (long long)n_rows, nq, dim);
   if (n_tiles <= 0) return LRX_OK;
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, nullptr};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_EMIT>, dim3((unsigned)n_tiles), dim3(512), 0, stream, (const __bf16*)Xb, (const __bf16*)q16, (__bf16*)nullptr,
                      (const __bf16*)nullptr, (const __bf16*)nullptr, (int)n_rows, nq, dim, (int)n_tiles, 1, none, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{nullptr, nullptr, 8}, EmitArgs{thr, cand, cnt, ss});
+                     NormArgs{nullptr, nullptr, 8}, EmitArgs{thr, cand, cnt, ss, xb_tiled ? 1 : 0});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

@@ -128,27 +128,37 @@ std::tuple<at::Tensor, at::Tensor> flat_ip_topk_bounded(const at::Tensor& q, con
   need(x, "x", at::kFloat, 2);
   need(row_bounds, "row_bounds", at::kFloat, 1);
   TORCH_CHECK(q.is_contiguous() && q.size(1) == x.size(1) && row_bounds.numel() == 2, "flat_ip_topk_bounded: q [Q,D] contiguous, x [N,D], row_bounds [2]");
+  bool tiled = false;
   if (x_bf16.has_value()) {
-    need(*x_bf16, "x_bf16", at::kBFloat16, 2);
-    TORCH_CHECK(x_bf16->size(0) >= x.size(0) && x_bf16->size(1) == x.size(1), "flat_ip_topk_bounded: x_bf16 must shadow x");
+    TORCH_CHECK(x_bf16->is_cuda() && x_bf16->scalar_type() == at::kBFloat16, "flat_ip_topk_bounded: x_bf16 must be a bf16 device tensor");
+    tiled = x_bf16->dim() == 1;                     // the tiled layout of include/lrx.h, block 0 row 0 = x row 0
+    TORCH_CHECK(tiled ? (x_bf16->is_contiguous() && x_bf16->numel() >= ((x.size(0) + 127) / 128) * 128 * x.size(1))
+                      : (x_bf16->dim() == 2 && x_bf16->size(0) >= x.size(0) && x_bf16->size(1) == x.size(1) && x_bf16->stride(1) == 1),
+                "flat_ip_topk_bounded: x_bf16 must shadow x (row-major [N, D] or the 1-D tiled layout)");
   }
   at::Tensor d = at::empty({q.size(0), k}, q.options()), i = at::empty({q.size(0), k}, q.options().dtype(at::kLong));
   const size_t wsb = lrx_flat_ip_bounded_workspace_bytes(x.size(0), (int32_t)x.size(1), (int32_t)q.size(0), (int32_t)k);
   at::Tensor ws = bytes((int64_t)wsb, q);
   lrx_check(lrx_flat_ip_search_bounded(x.data_ptr<float>(), x.size(0), x.size(0) ? x.stride(0) : x.size(1), (int32_t)x.size(1),
-                                       x_bf16.has_value() ? x_bf16->data_ptr() : nullptr, x_bf16.has_value() ? x_bf16->stride(0) : 0,
+                                       x_bf16.has_value() ? x_bf16->data_ptr() : nullptr, x_bf16.has_value() ? (tiled ? 0 : x_bf16->stride(0)) : 0,
                                        row_bounds.data_ptr<float>(), q.data_ptr<float>(), (int32_t)q.size(0), (int32_t)k, id_base, d.data_ptr<float>(),
                                        i.data_ptr<int64_t>(), ws.data_ptr(), wsb, cur_stream()),
             "flat_ip_topk_bounded");
   return {d, i};
 }
 
-void shard_commit_rows(const at::Tensor& x, const c10::optional<at::Tensor>& x_bf16, at::Tensor row_bounds) {
+// x_bf16: row-major [>= rows, D] bf16, or 1-D (the tiled layout of include/lrx.h, whole 128-row blocks) with row0 = index of x's first row
+void shard_commit_rows(const at::Tensor& x, const c10::optional<at::Tensor>& x_bf16, at::Tensor row_bounds, int64_t row0) {
   need(x, "x", at::kFloat, 2);
   need(row_bounds, "row_bounds", at::kFloat, 1);
-  if (x_bf16.has_value()) need(*x_bf16, "x_bf16", at::kBFloat16, 2);
+  bool tiled = false;
+  if (x_bf16.has_value()) {
+    TORCH_CHECK(x_bf16->is_cuda() && x_bf16->scalar_type() == at::kBFloat16 && x_bf16->is_contiguous(), "shard_commit_rows: x_bf16 must be contiguous bf16");
+    tiled = x_bf16->dim() == 1;
+    TORCH_CHECK(!tiled || x_bf16->numel() >= ((row0 + x.size(0) + 127) / 128) * 128 * x.size(1), "shard_commit_rows: tiled shadow too small");
+  }
   lrx_check(lrx_shard_commit_rows(x.data_ptr<float>(), x.stride(0), x.size(0), (int32_t)x.size(1), x_bf16.has_value() ? x_bf16->data_ptr() : nullptr,
-                                  x_bf16.has_value() ? x_bf16->stride(0) : 0, row_bounds.data_ptr<float>(), cur_stream()),
+                                  x_bf16.has_value() ? (tiled ? 0 : x_bf16->stride(0)) : 0, row0, row_bounds.data_ptr<float>(), cur_stream()),
             "shard_commit_rows");
 }
 
@@ -175,7 +185,7 @@ TORCH_LIBRARY(lrx, m) {
   m.def("embedding_bag_mean(Tensor table, Tensor ids, Tensor offsets, int padding_idx=-1, int out_dim=0, bool normalize=True) -> Tensor");
   m.def("flat_ip_topk(Tensor q, Tensor x, int k, int id_base=0) -> (Tensor, Tensor)");
   m.def("flat_ip_topk_bounded(Tensor q, Tensor x, Tensor? x_bf16, Tensor row_bounds, int k, int id_base=0) -> (Tensor, Tensor)");
-  m.def("shard_commit_rows(Tensor x, Tensor(a!)? x_bf16, Tensor(b!) row_bounds) -> ()");
+  m.def("shard_commit_rows(Tensor x, Tensor(a!)? x_bf16, Tensor(b!) row_bounds, int row0=0) -> ()");
   m.def("merge_topk(Tensor d_parts, Tensor i_parts) -> (Tensor, Tensor)");
 }
 

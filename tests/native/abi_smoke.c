@@ -53,7 +53,7 @@ int main(void) {
   CHECK(hipMalloc(&dXb, 2 * (size_t)N * D)); CHECK(hipMalloc((void**)&dbound, 8)); CHECK(hipMemset(dbound, 0, 8));
   CHECK(hipMemcpy(dX, X, sizeof(float) * N * D, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dq, q, sizeof(float) * Q * D, hipMemcpyHostToDevice));
   /* shard maintenance on the device: bf16 shadow + the bounds {max |row|, max |row - bf16(row)|}; checked against the host copies */
-  LRX(lrx_shard_commit_rows(dX, D, N, D, dXb, D, dbound, NULL));
+  LRX(lrx_shard_commit_rows(dX, D, N, D, dXb, D, 0, dbound, NULL));
   CHECK(hipDeviceSynchronize());
   { unsigned short* Xb2 = (unsigned short*)malloc(2 * (size_t)N * D); float hb[2];
     CHECK(hipMemcpy(Xb2, dXb, 2 * (size_t)N * D, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hb, dbound, 8, hipMemcpyDeviceToHost));

@@ -173,9 +173,10 @@ def test_full_size_1m_x_2048_properties():
     assert ((arg == Ig[:, 0]) | ((best - Dg[:, 0]).abs() < 3e-6)).all()
     assert (kth <= k - 1).all()          # nothing clearly better than the k-th result was missed
     # two-shard merge == whole index
-    a, b = FlatIPIndex(D, id_base=0), FlatIPIndex(D, id_base=600_000)
-    a._x, a._xb, a._bounds, a.ntotal = idx._x[:600_000], idx._xb[:600_000], idx._bounds, 600_000      # views of the same rows, shadow and bounds
-    b._x, b._xb, b._bounds, b.ntotal = idx._x[600_000:], idx._xb[600_000:], idx._bounds, 400_000
+    cut = 600_064                                         # a multiple of 128: the tiled shadow is shared in whole 128-row blocks
+    a, b = FlatIPIndex(D, id_base=0), FlatIPIndex(D, id_base=cut)
+    a._x, a._xb, a._bounds, a.ntotal = idx._x[:cut], idx._xb[:cut * D], idx._bounds, cut               # views of the same rows, shadow and bounds
+    b._x, b._xb, b._bounds, b.ntotal = idx._x[cut:], idx._xb[cut * D:], idx._bounds, N - cut
     Da, Ia = a.search(q, k)
     Db, Ib = b.search(q, k)
     Dm, Im = merge_topk(torch.stack([Da, Db]), torch.stack([Ia, Ib]))
@@ -267,7 +268,7 @@ def test_bf16_shadow_filter_gives_the_same_exact_result(Q):
     q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))
     a = FlatIPIndex(D, capacity=N)
     a.add(X[:25000]); a.add(X[25000:])
-    assert a._xb is not None and a._xb.dtype == torch.bfloat16 and torch.equal(a._xb[:N], torch.from_numpy(X).cuda().to(torch.bfloat16))
+    assert a._xb is not None and a._xb.dtype == torch.bfloat16 and torch.equal(a.shadow_rows(), torch.from_numpy(X).cuda().to(torch.bfloat16))
     Da, Ia = a.search(q, k)
     b = FlatIPIndex(D, capacity=N)
     b.shadow_bf16 = False

@@ -159,7 +159,7 @@ def test_shard_commit_rows_kernel_shadow_and_bounds():
     idx = FlatIPIndex(D)
     idx.add(X[:1000]); idx.add(X[1000:])
     xb = torch.from_numpy(X).cuda().to(torch.bfloat16)
-    assert torch.equal(idx._xb[:N], xb)
+    assert idx._xb.ndim == 1 and torch.equal(idx.shadow_rows(), xb)            # tiled layout, same values
     R = np.linalg.norm(X.astype(np.float64), axis=1).max()
     E = np.linalg.norm(X.astype(np.float64) - xb.float().cpu().numpy().astype(np.float64), axis=1).max()
     b = idx._bounds.cpu().numpy()
@@ -167,7 +167,13 @@ def test_shard_commit_rows_kernel_shadow_and_bounds():
     # no torch kernels are needed for maintenance: reset + refresh gives the same state again
     idx._xb.zero_(); idx._bounds.zero_()
     idx.refresh_norm_bound()
-    assert torch.equal(idx._xb[:N], xb) and np.array_equal(idx._bounds.cpu().numpy(), b)
+    assert torch.equal(idx.shadow_rows(), xb) and np.array_equal(idx._bounds.cpu().numpy(), b)
+    # the row-major layout of the same index: same shadow values, same bounds
+    idx.shadow_layout = "rows"
+    idx._xb = None
+    idx._bounds.zero_()
+    idx.refresh_norm_bound()
+    assert idx._xb.ndim == 2 and torch.equal(idx._xb[:N], xb) and np.array_equal(idx._bounds.cpu().numpy(), b)
 
 
 def test_encoder_writes_shadow_and_bounds_of_the_slot_it_fills():
@@ -194,12 +200,12 @@ def test_encoder_writes_shadow_and_bounds_of_the_slot_it_fills():
     assert all(b <= a for a, b in calls), f"commit() re-read encoder rows: {calls}"
     ref = enc.encode_packed(ids, cu, int(lens.max()))
     assert torch.equal(idx.vectors[3:], ref)
-    assert torch.equal(idx._xb[3:40], ref.to(torch.bfloat16))
+    assert torch.equal(idx.shadow_rows()[3:40], ref.to(torch.bfloat16))
     b = idx._bounds.cpu().numpy()
     assert 1.0 <= b[0] < 1.00001 and 0 < b[1] < 2.0 ** -8
     # in-place re-encode of committed rows (what bench.py does) keeps shadow + bounds valid without refresh_norm_bound()
     enc.encode_packed(ids, cu, int(lens.max()), out=idx._x[3:40])
-    assert torch.equal(idx._xb[3:40], ref.to(torch.bfloat16))
+    assert torch.equal(idx.shadow_rows()[3:40], ref.to(torch.bfloat16))
     # MRL slice narrower than the shard row: not a shard slot, plain output
     out = enc.encode_packed(ids, cu, int(lens.max()), out_dim=64)
     assert out.shape == (37, 64)
@@ -251,10 +257,11 @@ def test_baseline_index_shapes_properties(N, D, search_mode):
     assert torch.equal(Im, Ig) and torch.equal(Dm, Dg)
     # eight-way row shard + merge == whole index (config 4's layout; views of the same rows, no copy)
     Dp, Ip = [], []
+    cuts = [(r * N // 8) // 128 * 128 for r in range(8)] + [N]       # whole 128-row blocks of the tiled shadow per shard
     for r in range(8):
-        a, b = r * N // 8, (r + 1) * N // 8
+        a, b = cuts[r], cuts[r + 1]
         sh = FlatIPIndex(D, id_base=a)
-        sh._x, sh._xb, sh._bounds, sh.ntotal = idx._x[a:b], idx._xb[a:b], idx._bounds, b - a
+        sh._x, sh._xb, sh._bounds, sh.ntotal = idx._x[a:b], idx._xb[a * D:], idx._bounds, b - a
         d, i = sh.search(q, k)
         Dp.append(d), Ip.append(i)
     Dm8, Im8 = merge_topk(torch.stack(Dp), torch.stack(Ip))
@@ -301,3 +308,27 @@ def test_search_on_a_side_stream_equals_default_stream(search_mode):
             side.synchronize()
             assert torch.equal(Ds, ref[mode][0]) and torch.equal(Is, ref[mode][1])
     torch.cuda.current_stream().wait_stream(side)
+
+
+@pytest.mark.parametrize("N,D,Q,k", [(50000, 128, 100, 10), (33001, 2048, 300, 5), (20011, 64, 1, 50), (70000, 1024, 256, 100), (9000, 192, 40, 7)])
+def test_tiled_and_row_major_shadow_give_the_same_bits(N, D, Q, k, search_mode):
+    """The shadow layout only changes how the filter pass addresses the same bf16 values: hits are bitwise the same, for both filters,
+    for shards that end inside a 128-row block, and for rows that arrive in pieces (add) or through the encoder-slot path."""
+    from lightretriever_amd import FlatIPIndex
+    rng = np.random.default_rng(N + Q)
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32)) * rng.uniform(0.3, 2.0, size=(N, 1)).astype(np.float32)
+    q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))
+    res = {}
+    for layout in ("tiled", "rows"):
+        idx = FlatIPIndex(D, capacity=N // 3)                       # grows twice: the shadow is re-allocated with committed rows in it
+        idx.shadow_layout = layout
+        for s in range(0, N, 7001):
+            idx.add(X[s:s + 7001])
+        assert torch.equal(idx.shadow_rows(), torch.from_numpy(X).cuda().to(torch.bfloat16))
+        for mode in (1, 2):
+            search_mode(mode)
+            res[layout, mode] = idx.search(q, k)
+    search_mode(0)
+    for key in res:
+        assert torch.equal(res[key][0], res["rows", 1][0]) and torch.equal(res[key][1], res["rows", 1][1]), key
+    check_against_oracle(*res["tiled", 2], q, X, k)

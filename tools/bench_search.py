@@ -9,6 +9,8 @@ def main():
     N, D = int(os.environ.get("N", 1_000_000)), int(os.environ.get("D", 2048))
     g = torch.Generator(device="cuda").manual_seed(7)
     idx = FlatIPIndex(D, capacity=N)
+    if os.environ.get("LAYOUT"):      # shadow layout: tiled (default) | rows
+        idx.shadow_layout = os.environ["LAYOUT"]
     slot = idx.append_slot(N)
     for s in range(0, N, 65536):
         e = min(s + 65536, N)
@@ -27,7 +29,7 @@ def main():
         med = statistics.median(ts)
         if os.environ.get("STATS") and idx._xb is not None and Q >= 4:
             # what the score-free filter sees for a few queries: rows reaching the sample threshold T' - 2 eps, rows in the final band
-            xb, k, ss = idx._xb[:N], 100, 20
+            xb, k, ss = idx.shadow_rows(), 100, 20
             nb = (N + 127) // 128
             samp = torch.arange(0, nb, ss, device="cuda").repeat_interleave(128) * 128 + torch.arange(128, device="cuda").repeat((nb + ss - 1) // ss)
             samp = samp[samp < N]
