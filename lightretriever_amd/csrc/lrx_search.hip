@@ -293,7 +293,8 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
     // is then 16 KiB contiguous and every LDS-DMA instruction reads 1 KiB in one piece instead of 8 rows x 128 B
     // (Q = 1: 0.79 -> 0.70 ms, Q = 100: 1.02 -> 0.96 ms over 1M x 2048)
     px[i] = !XB ? (const char*)(X + g * ldx + c * 4)
-                : (ldx == 0 ? (const char*)(Xb + (blk * (int64_t)(D / 64)) * 8192 + (int64_t)row * 64 + c * 8) : (const char*)(Xb + g * ldx + c * 8));
+                : (ldx == 0 ? (const char*)(Xb + (min(blk, (N - 1) >> 7) * (int64_t)(D / 64)) * 8192 + (int64_t)row * 64 + c * 8)
+                            : (const char*)(Xb + g * ldx + c * 8));   // (a launch rounds the row count up to 256: a block past the last one re-reads it, masked below)
   }
   const int64_t kstep_b = (XB && ldx == 0) ? 16384 : 128;   // bytes from one k-slice of a row block to the next
   const __bf16* pq = qs + (int64_t)lane * 8;     // + (kt*QINST + j) * 512 elements

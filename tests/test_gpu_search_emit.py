@@ -310,7 +310,9 @@ def test_search_on_a_side_stream_equals_default_stream(search_mode):
     torch.cuda.current_stream().wait_stream(side)
 
 
-@pytest.mark.parametrize("N,D,Q,k", [(50000, 128, 100, 10), (33001, 2048, 300, 5), (20011, 64, 1, 50), (70000, 1024, 256, 100), (9000, 192, 40, 7)])
+@pytest.mark.parametrize("N,D,Q,k", [(50000, 128, 100, 10), (33001, 2048, 300, 5), (20011, 64, 1, 50), (70000, 1024, 256, 100), (9000, 192, 40, 7),
+                                     # N mod 256 in (0, 128]: a score-matrix launch covers one 128-row block more than the tiled shadow holds
+                                     (4200, 64, 40, 5), (70001, 128, 3, 20)])
 def test_tiled_and_row_major_shadow_give_the_same_bits(N, D, Q, k, search_mode):
     """The shadow layout only changes how the filter pass addresses the same bf16 values: hits are bitwise the same, for both filters,
     for shards that end inside a 128-row block, and for rows that arrive in pieces (add) or through the encoder-slot path."""
