@@ -1280,8 +1280,10 @@ extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t di
     const int sizes[2] = {nq < chunk ? nq : chunk, nq > chunk ? nq % chunk : 0};
     for (int i = 0; i < 2; ++i)
       if (sizes[i] > 0) {
-        const size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0).total;
-        need = t > need ? t : need;
+        for (int contiguous = 0; contiguous < 2; ++contiguous) {       // (a strided row-major shadow keeps the 128-row main pass: other sample geometry)
+          const size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, contiguous != 0).total;
+          need = t > need ? t : need;
+        }
       }
   }
   return need + 512;
@@ -1315,6 +1317,10 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
   for (int q0 = 0; q0 < n_queries; q0 += chunk) {
     const int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
     const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, ldx_bf16 == dim || ldx_bf16 == 0);
+    if (p.total > workspace_bytes) {      // (cannot happen with a workspace sized by lrx_flat_ip_bounded_workspace_bytes under the same filter mode)
+      lrx_set_error("flat_ip_search_bounded: chunk of %d queries needs %zu B of workspace, %zu given", nq, p.total, workspace_bytes);
+      return LRX_ERR_WORKSPACE;
+    }
     const float* qc = q + (int64_t)q0 * dim;
     float* osc = out_scores + (int64_t)q0 * k;
     int64_t* oic = out_ids + (int64_t)q0 * k;
