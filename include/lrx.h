@@ -325,10 +325,13 @@ void lrx_search_set_mode(int32_t mode);
 int lrx_shard_commit_rows(const float* X, int64_t ldx, int64_t n_rows, int32_t dim, void* X_bf16, int64_t ldx_bf16,
                           int64_t shadow_row0, float* row_bounds, void* stream);
 /* Shadow layouts.  ldx_bf16 > 0: row-major, X_bf16 points at the shadow of X's first row, row stride ldx_bf16 elements (multiple of 8).
- * ldx_bf16 == 0: TILED (dim % 64 == 0), X_bf16 = base of an array [ceil(rows / 128)][dim / 64][128][64] bf16 -- element k of row r at
- * ((r / 128) * (dim / 64) + k / 64) * 8192 + (r % 128) * 64 + k % 64 -- allocated for whole 128-row blocks; shadow_row0 = index within
- * that array of X's first row (writers); for lrx_flat_ip_search_bounded the shard's row 0 is row 0 of the array.  The filter pass
- * then reads 1 KiB in one piece per request instead of 8 row pieces of 128 B (Q = 1: -12 %, Q = 100: -6 % per search).           */
+ * ldx_bf16 == 0: TILED (dim % 64 == 0), X_bf16 = base of an array [ceil(rows / 128)][dim / 64] of 16-KiB tiles (128 rows x 64 columns),
+ * each tile fragment-major: [16-row group w = 0..7][k-step ks = 0..1][fq = 0..3][fi = 0..15][8] bf16 holds row 16 w + fi, columns
+ * 32 ks + 8 fq .. + 7 of the tile (the MFMA 16x16x32 operand of one wave), i.e. element k of row r sits at
+ *   ((r / 128) * (dim / 64) + k / 64) * 8192 + ((((r / 16) % 8) * 2 + (k / 32) % 2) * 64 + ((k / 8) % 4) * 16 + r % 16) * 8 + k % 8
+ * -- allocated for whole 128-row blocks; shadow_row0 = index within that array of X's first row (writers); for
+ * lrx_flat_ip_search_bounded the shard's row 0 is row 0 of the array.  A wave of the filter pass then loads its operand with one
+ * coalesced 1-KiB request straight into registers (no LDS staging of the corpus side).                                          */
 
 /* Score pass only: scores[Q, ld] fp32 with ld = lrx_flat_ip_score_ld(N); columns >= N hold -FLT_MAX. */
 int64_t lrx_flat_ip_score_ld(int64_t n_rows);

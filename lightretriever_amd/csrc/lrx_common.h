@@ -52,6 +52,13 @@ __device__ __forceinline__ unsigned long long sel_pack(uint32_t key, int64_t i) 
 }
 __device__ __forceinline__ int64_t sel_row(unsigned long long c) { return (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull)); }
 
+// ---- the tiled bf16 shadow of an index shard (include/lrx.h, lrx_shard_commit_rows): [128-row block][64-wide k-slice] tiles of 16 KiB, each tile
+// FRAGMENT-MAJOR: [16-row group w = 0..7][k-step ks = 0..1][lane = fq*16 + fi][8], the MFMA 16x16x32 A operand of rows 16w + fi, k = 32 ks + 8 fq .. + 7,
+// so that a wave of the filter pass loads its fragment with one coalesced 1-KiB request.  Element (row r, column k), D % 64 == 0:
+__host__ __device__ __forceinline__ int64_t lrx_shadow_off(int64_t r, int k, int D) {
+  return ((r >> 7) * (int64_t)(D / 64) + (k >> 6)) * 8192 + ((((r >> 4) & 7) * 2 + ((k >> 5) & 1)) * 64 + ((k >> 3) & 3) * 16 + (r & 15)) * 8 + (k & 7);
+}
+
 // host-side error plumbing -----------------------------------------------------------------------------------
 void lrx_set_error(const char* fmt, ...);
 #define LRX_CHECK_ARG(cond, ...)          \

@@ -259,16 +259,16 @@ __global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hi
   n2 = block_sum_256(n2, red);
   float scale = normalize ? 1.0f / fmaxf(sqrtf(n2), 1e-12f) : 1.0f;
   float* o = out + (int64_t)b * out_stride;
-  // shadow row: row-major (stride shadow_stride) or, stride 0, row shadow_row0 + b of the tiled layout [128-row block][64-wide slice][128][64]
+  // shadow row: row-major (stride shadow_stride) or, stride 0, row shadow_row0 + b of the tiled layout (lrx_shadow_off)
   const int64_t ra = shadow_row0 + b;
-  __bf16* ob = !shadow ? nullptr : (shadow_stride != 0 ? shadow + (int64_t)b * shadow_stride : shadow + ((ra >> 7) * (int64_t)(out_dim / 64)) * 8192 + (ra & 127) * 64);
   const bool tiled = shadow_stride == 0;
+  __bf16* ob = !shadow ? nullptr : (tiled ? shadow : shadow + (int64_t)b * shadow_stride);
   float r2 = 0.f, e2 = 0.f;
   for (int i = threadIdx.x; i < out_dim; i += 256) {
     const float v = normalize ? row[i] * scale : row[i];
     o[i] = v;
     const __bf16 h = f2bf(v);
-    if (ob) ob[tiled ? (int64_t)(i >> 6) * 8192 + (i & 63) : i] = h;
+    if (ob) ob[tiled ? lrx_shadow_off(ra, i, out_dim) : (int64_t)i] = h;
     const float d = v - bf2f(h);
     r2 += v * v;
     e2 += d * d;

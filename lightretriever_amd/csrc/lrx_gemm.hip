@@ -50,7 +50,7 @@ struct EmitArgs {
   unsigned long long* cand;  // [nq, CAND_CAP]
   unsigned int* cnt;         // [nq * CNT_STRIDE]
   int ss;
-  int a_tiled;               // A is the tiled shadow [128-row block][64-wide k-slice][128][64] instead of row-major [M, K]
+  int a_tiled;               // A is the tiled shadow (lrx_shadow_off) instead of row-major [M, K]
 };
 
 struct MaxAggArgs {
@@ -127,9 +127,12 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     int s = (wave * 2 + i) * 64 + lane;
     int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
     if (EPI == EPI_EMIT && em.a_tiled) {
-      const int r0 = min(m0 + row, M - 1), r1 = min(m0 + 128 + row, M - 1);
-      pA0[i] = A + ((int64_t)(r0 >> 7) * (K / 64)) * 8192 + (r0 & 127) * 64 + c * 8;
-      pA1[i] = A + ((int64_t)(r1 >> 7) * (K / 64)) * 8192 + (r1 & 127) * 64 + c * 8;
+      // tiled shadow: a half-tile (128 rows x 64) IS one 16-KiB fragment-major tile of the source -> copied linearly, 1 KiB per request
+      // (the LDS image is then fragment-major too: laneoffA below); blocks past the last one re-read it, masked in the epilogue
+      const int64_t lastb = (int64_t)(M - 1) >> 7;
+      const int64_t b0 = min((int64_t)(m0 >> 7), lastb), b1 = min((int64_t)(m0 >> 7) + 1, lastb);
+      pA0[i] = A + (b0 * (K / 64)) * 8192 + s * 8;
+      pA1[i] = A + (b1 * (K / 64)) * 8192 + s * 8;
     } else {
       pA0[i] = A + (int64_t)min(m0 + row, M - 1) * K + c * 8;
       pA1[i] = A + (int64_t)min(m0 + 128 + row, M - 1) * K + c * 8;
@@ -154,6 +157,9 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   int laneoff[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) laneoff[ks] = fr * 128 + (((ks * 4 + fq) ^ xs) << 4);
+  int laneoffA[2];               // A-side fragment offsets: the swizzled row image, or (tiled shadow) the fragment-major tile [16-row group][ks][lane]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) laneoffA[ks] = (EPI == EPI_EMIT && em.a_tiled) ? ks * 1024 + lane * 16 : laneoff[ks];
   const int a_off = (wr * 64) * 128, b_off = 2 * HALF_BYTES + (wc * 32) * 128;
 
   f32x4 acc[2][2][4][2];
@@ -169,7 +175,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 
 #define G_LDA(H)                                                                                     \
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)  \
-      a[mi][ks] = *(const bf16x8*)(sbuf + (H) * HALF_BYTES + a_off + mi * 2048 + laneoff[ks]);
+      a[mi][ks] = *(const bf16x8*)(sbuf + (H) * HALF_BYTES + a_off + mi * 2048 + laneoffA[ks]);
 #define G_LDB(HP)                                                                                    \
   _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)  \
       b[ni][ks] = *(const bf16x8*)(sbuf + (HP) * HALF_BYTES + b_off + ni * 2048 + laneoff[ks]);

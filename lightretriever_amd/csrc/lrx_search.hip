@@ -257,7 +257,6 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
                        unsigned int* __restrict__ cnt) {
   static_assert(!XB || NP == 1, "the bf16 shadow is a single-product filter");
   static_assert(!EMIT || NP == 1, "the emitting epilogue belongs to the single-product filter");
-  static_assert(!XB || 16 * RT * WV == 128, "the tiled shadow is addressed in 128-row blocks");
   const float* X = (const float*)Xv;
   const __bf16* Xb = (const __bf16*)Xv;
   constexpr int RB = 16 * RT * WV;               // corpus rows per workgroup (WV waves x RT 16-row tiles)
@@ -289,14 +288,10 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
     int s = (wave * 2 * RT + i) * 64 + lane;
     int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
     int64_t g = min(n0 + row, N - 1);
-    // bf16 shadow: row-major (row stride ldx) or, ldx == 0, TILED [128-row block][64-wide k-slice][128 rows][64]: a workgroup's k-slice
-    // is then 16 KiB contiguous and every LDS-DMA instruction reads 1 KiB in one piece instead of 8 rows x 128 B
-    // (Q = 1: 0.79 -> 0.70 ms, Q = 100: 1.02 -> 0.96 ms over 1M x 2048)
-    px[i] = !XB ? (const char*)(X + g * ldx + c * 4)
-                : (ldx == 0 ? (const char*)(Xb + (min(blk, (N - 1) >> 7) * (int64_t)(D / 64)) * 8192 + (int64_t)row * 64 + c * 8)
-                            : (const char*)(Xb + g * ldx + c * 8));   // (a launch rounds the row count up to 256: a block past the last one re-reads it, masked below)
+    // (row-major bf16 shadow here; the tiled shadow has its own kernels, k_filter_xreg / k_filter_xreg_emit)
+    px[i] = !XB ? (const char*)(X + g * ldx + c * 4) : (const char*)(Xb + g * ldx + c * 8);
   }
-  const int64_t kstep_b = (XB && ldx == 0) ? 16384 : 128;   // bytes from one k-slice of a row block to the next
+  constexpr int64_t kstep_b = 128;                 // bytes from one k-slice of a row to the next
   const __bf16* pq = qs + (int64_t)lane * 8;     // + (kt*QINST + j) * 512 elements
   auto stage_x = [&](int st, int kt) {
     char* sX = smem + st * (QSB ? XT : STAGE);
@@ -521,6 +516,389 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Shadow filter with the corpus fragments streamed through REGISTERS (tiled shadow only).  A corpus element is used by exactly one
+// wave, so staging X in LDS buys nothing but a barrier-coupled two-stage ring (16 KiB in flight per workgroup, 48 KiB per CU: the
+// pass ran at bytes-in-flight x latency = 5.3 TB/s).  Here the 16-KiB tile of a (128-row block, k-slice) is stored FRAGMENT-MAJOR --
+// [wave 0..7][k-step 0..1][lane][8 bf16], lane (fi, fq) = row 16 wave + fi, k = 32 ks + 8 fq .. + 7, the MFMA 16x16x32 A operand --
+// so a wave's fragment is one 1-KiB coalesced global_load_dwordx4 and its prefetch ring is PF k-slices deep in VGPRs (8 per slice).
+// Only the q k-slice, which all eight waves share, goes through LDS: a ninth PRODUCER wave requests it one slice ahead by LDS-DMA
+// (its own in-order vmcnt, so the consumers' counted waits see nothing but their X loads); one barrier per k-slice.
+// ---------------------------------------------------------------------------------------------------------------
+template <int QT, int PF, bool EMIT>
+__global__ void __launch_bounds__(576, QT > 8 ? 1 : 2)
+k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, float* __restrict__ scores, int64_t ld,
+              float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate, int bmode, int ss, int unit,
+              const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt) {
+  constexpr int WV = 8, RB = 128;
+  constexpr int QINST = 2 * QT;                    // 1-KiB LDS-DMA instructions per q slice
+  constexpr int QBYTES = QINST * 1024;
+  constexpr int SEG = RB * 4 + 16;                 // epilogue staging: one query's 128 scores + pad
+  constexpr int QB = QT > 8 ? 2 : 4;               // q ring: the producer runs QB-1 slices ahead
+  static_assert((QB - 2) * QINST <= 63, "vmcnt immediate");
+  constexpr int LDS_BYTES = QB * QBYTES > 16 * SEG ? QB * QBYTES : 16 * SEG;
+  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+  if (gate != nullptr && *gate == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t blk = blockIdx.x;
+  if (bmode == 1) { const int u = blockIdx.x / unit; blk = (int64_t)u * ss * unit + (blockIdx.x - u * unit); }
+  else if (bmode == 2) {
+    const int u = blockIdx.x / unit, g = u / (ss - 1);
+    blk = ((int64_t)g * ss + 1 + (u - g * (ss - 1))) * unit + (blockIdx.x - u * unit);
+  }
+  const int64_t n0 = blk * RB;
+  const int64_t n0s = (int64_t)blockIdx.x * RB;
+  const int nk = D / 64;
+  const int fi = lane & 15, fq = lane >> 4;
+
+  f32x4 acc[QT];
+#pragma unroll
+  for (int b = 0; b < QT; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (wave == WV) {
+    // ---- producer: q slice kt+1 requested while the consumers work on kt
+    const __bf16* pq = qs + (int64_t)lane * 8;
+    auto stage_q = [&](int kt) {
+      char* sQ = smem + (kt % QB) * QBYTES;
+#pragma unroll
+      for (int j = 0; j < QINST; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(pq + ((int64_t)kt * QINST + j) * 512), (lptr_t)(sQ + j * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p < QB - 1; ++p)
+      if (p < nk) stage_q(p);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + QB - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QB - 2) * QINST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                // q(kt) is in LDS; every consumer has finished slice kt-1 -> its buffer is free
+      if (kt + QB - 1 < nk) stage_q(kt + QB - 1);
+    }
+  } else {
+    // ---- consumers: wave w owns rows 16w .. 16w+15 of the block
+    const bf16x8* px = (const bf16x8*)(Xb + (min(blk, (N - 1) >> 7) * (int64_t)(D / 64)) * 8192 + wave * 1024) + lane;   // + kt*1024 (+64: k-step 1)
+    bf16x8 xf[PF][2];
+    auto step = [&](int u, int kt, bool fetch) __attribute__((always_inline)) {
+      if (fetch) {
+        xf[(u + PF - 1) % PF][0] = __builtin_nontemporal_load(px + (int64_t)(kt + PF - 1) * 1024);
+        xf[(u + PF - 1) % PF][1] = __builtin_nontemporal_load(px + (int64_t)(kt + PF - 1) * 1024 + 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* sQ = smem + (kt % QB) * QBYTES + lane * 16;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int b = 0; b < QT; ++b) {
+          const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][ks], qf, acc[b], 0, 0, 0);
+        }
+    };
+    // steady state: every step of the trip prefetches (no guard -> the compiler's counted vmcnt keeps PF-1 slices in flight);
+    // the last trips re-check per step
+    int kt0 = 0;
+    if (2 * PF - 2 < nk) {
+#pragma unroll
+      for (int p = 0; p < PF - 1; ++p) {
+        xf[p][0] = __builtin_nontemporal_load(px + (int64_t)p * 1024);
+        xf[p][1] = __builtin_nontemporal_load(px + (int64_t)p * 1024 + 64);
+        __builtin_amdgcn_sched_barrier(0);           // issue order = ring order: the counted waits of the loop rely on it
+      }
+      for (; kt0 + 2 * PF - 2 < nk; kt0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) step(u, kt0 + u, true);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PF - 1; ++p)
+        if (p < nk) {
+          xf[p][0] = __builtin_nontemporal_load(px + (int64_t)p * 1024);
+          xf[p][1] = __builtin_nontemporal_load(px + (int64_t)p * 1024 + 64);
+        }
+    }
+    for (; kt0 < nk; kt0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        if (kt0 + u < nk) step(u, kt0 + u, kt0 + u + PF - 1 < nk);
+    }
+  }
+  if constexpr (EMIT) {
+    if (wave == WV) return;
+    float t[QT];
+    unsigned int c[QT], p[QT];
+#pragma unroll
+    for (int b = 0; b < QT; ++b) {
+      const int qi = b * 16 + fi;
+      t[b] = qi < nq ? thr[qi] : FLT_MAX;
+    }
+    const int64_t n = n0 + wave * 16 + fq * 4;
+#pragma unroll
+    for (int b = 0; b < QT; ++b) {
+      c[b] = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[b] += (n + e < N && acc[b][e] >= t[b]) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < QT; ++b) {
+      p[b] = 0;
+      if (c[b]) p[b] = atomicAdd(&cnt[(b * 16 + fi) * CNT_STRIDE], c[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < QT; ++b)
+      if (c[b]) {
+        unsigned int pp = p[b];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < N && acc[b][e] >= t[b]) {
+            if (pp < CAND_CAP) cand[(int64_t)(b * 16 + fi) * CAND_CAP + pp] = sel_pack(f2key(acc[b][e]), n + e);
+            ++pp;
+          }
+      }
+    return;
+  }
+  __syncthreads();   // all nine waves: the q buffers are dead, the epilogue reuses them
+  float* wmax = (float*)smem;  // [8 waves][QT*16]
+  if (wave < WV) {
+#pragma unroll
+    for (int b = 0; b < QT; ++b) {
+      const int qi = b * 16 + fi;
+      float mx = -FLT_MAX;
+      const int64_t n = n0 + wave * 16 + fq * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= N) acc[b][e] = -FLT_MAX;
+        mx = fmaxf(mx, acc[b][e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (fq == 0) wmax[wave * (QT * 16) + qi] = mx;
+    }
+  }
+  __syncthreads();
+  if (blkmax != nullptr) {
+    for (int t = tid; t < QT * 16; t += 576)
+      if (t < nq) {
+        float mx = -FLT_MAX;
+#pragma unroll
+        for (int w = 0; w < WV; ++w) mx = fmaxf(mx, wmax[w * (QT * 16) + t]);
+        blkmax[(int64_t)t * nblk_ld + blockIdx.x] = mx;
+      }
+  }
+  constexpr int QPT = (LDS_BYTES / SEG / 16) < QT ? (LDS_BYTES / SEG / 16) : QT;   // q-tiles staged per pass
+  static_assert(QPT >= 1, "epilogue staging does not fit");
+  constexpr int NPASS = (QT + QPT - 1) / QPT;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    __syncthreads();
+    if (wave < WV) {
+#pragma unroll
+      for (int b = 0; b < QT; ++b)
+        if (b / QPT == ps) *(f32x4*)(smem + ((b - ps * QPT) * 16 + fi) * SEG + (wave * 16 + fq * 4) * 4) = acc[b];
+    }
+    __syncthreads();
+    const int nqt = (QT - ps * QPT) < QPT ? (QT - ps * QPT) : QPT;
+    for (int idx = tid; idx < nqt * 16 * (RB / 4); idx += 576) {
+      const int ql = idx / (RB / 4), c = idx % (RB / 4);
+      const int qi = ps * QPT * 16 + ql;
+      if (qi < nq) *(f32x4*)(scores + (int64_t)qi * ld + n0s + c * 4) = *(const f32x4*)(smem + ql * SEG + c * 16);
+    }
+  }
+}
+
+// The main pass of the score-free filter as PERSISTENT workgroups: with one 128-row block per workgroup every block paid the latency of
+// its first loads and of its list reservations (memory-side atomics, ~2 us) with nothing of its own in flight -- 11 % of the pass.
+// Here a workgroup walks blocks blockIdx.x, + gridDim.x, ...: the X ring and the q producer run straight across block boundaries,
+// the thresholds stay in registers, and hits (~1e-3 of the scores) are parked in a per-wave LDS list that is written to the queries'
+// candidate lists once, at the end (or when it fills up).  RT = blocks worked on at a time (the q slice is read from LDS once for both).
+// Requires D / 64 to be a multiple of PF (the ring phase is the same at every block start); other shapes use k_filter_xreg<.., EMIT>.
+template <int QT, int PF, int RT>
+__global__ void __launch_bounds__(576, (QT > 8 || RT > 1) ? 3 : 5)   // (second argument: waves per SIMD -> two workgroups of nine waves per CU need five)
+k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, int nblocks, int bmode, int ss,
+                   int unit, const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt) {
+  constexpr int WV = 8;
+  constexpr int QINST = 2 * QT;
+  constexpr int QBYTES = QINST * 1024;
+  constexpr int QB = QT > 8 ? 3 : 4;               // q ring: the producer runs QB-1 slices ahead
+  static_assert((QB - 2) * QINST <= 63, "vmcnt immediate");
+  constexpr int WCAP = 320;                        // hits a wave parks in LDS
+  constexpr int WL_BYTES = WCAP * 12 + 16;
+  __shared__ __attribute__((aligned(1024))) char smem[QB * QBYTES + WV * WL_BYTES + QT * 16 * 4];
+  float* sthr = (float*)(smem + QB * QBYTES + WV * WL_BYTES);   // the thresholds (LDS: they are needed once per block, not per k-step)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < QT * 16; i += 576) sthr[i] = i < nq ? thr[i] : FLT_MAX;
+  __syncthreads();
+  const int G = gridDim.x * RT;                                                  // blocks in flight over the grid
+  const int nmine = (nblocks - (int)blockIdx.x * RT + G - 1) / G;               // groups of RT blocks this workgroup walks (>= 1)
+  const int nk = D / 64;
+  const int64_t total = (int64_t)nmine * nk;                                     // k-steps of this workgroup
+  const bool qres = nk <= QB;                      // the whole q fits the ring (D <= 256): staged once, no barrier per k-step
+
+  if (wave == WV) {
+    // ---- producer: the q slices, cyclically, QB-1 steps ahead
+    const __bf16* pq = qs + (int64_t)lane * 8;
+    int hs = 0, hb = 0;                            // head: slice and ring buffer
+    auto stage_next = [&]() {
+      char* sQ = smem + hb * QBYTES;
+#pragma unroll
+      for (int j = 0; j < QINST; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(pq + ((int64_t)hs * QINST + j) * 512), (lptr_t)(sQ + j * 1024), 16, 0, 0);
+      hs = hs + 1 == nk ? 0 : hs + 1;
+      hb = hb + 1 == QB ? 0 : hb + 1;
+    };
+    if (qres) {
+      for (int p = 0; p < nk; ++p) stage_next();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      return;
+    }
+#pragma unroll
+    for (int p = 0; p < QB - 1; ++p)
+      if (p < total) stage_next();
+    for (int64_t g = 0; g < total; ++g) {
+      if (g + QB - 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QB - 2) * QINST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                // q(g) is in LDS; the consumers are done with step g-1 -> its buffer is free
+      if (g + QB - 1 < total) stage_next();
+    }
+    return;
+  }
+
+  // ---- consumers: wave w owns rows 16w .. 16w+15 of each of the RT blocks in work
+  const int fi = lane & 15, fq = lane >> 4;
+  unsigned long long* wl = (unsigned long long*)(smem + QB * QBYTES + wave * WL_BYTES);
+  unsigned int* wq = (unsigned int*)(wl + WCAP);
+  unsigned int* wn = wq + WCAP;
+  if (lane == 0) *wn = 0;
+  auto blk_of = [&](int i) -> int {                // launch index -> 128-row block (see k_flat_ip_scores_split); all < 2^25
+    if (bmode != 2) return i;
+    const unsigned int u = (unsigned int)i / (unsigned int)unit, g = u / (unsigned int)(ss - 1);
+    return (int)((g * ss + 1 + (u - g * (ss - 1))) * unit + ((unsigned int)i - u * unit));
+  };
+  const int last_blk = (int)((N - 1) >> 7);
+  auto base_of = [&](int i) -> const bf16x8* {
+    const int b = min(blk_of(min(i, nblocks - 1)), last_blk);
+    return (const bf16x8*)(Xb + ((int64_t)b * (D / 64)) * 8192 + wave * 1024) + lane;
+  };
+  auto flush = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned int tot = min(*wn, (unsigned int)WCAP);
+    for (unsigned int i = lane; i < tot; i += 64) {
+      const unsigned long long w = wl[i];
+      const unsigned int col = wq[i];
+      const unsigned int gp = atomicAdd(&cnt[col * CNT_STRIDE], 1u);
+      if (gp < CAND_CAP) cand[(int64_t)col * CAND_CAP + gp] = w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *wn = 0;
+  };
+
+  f32x4 acc[RT][QT];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prefetch head
+  int pf_j = 0, pf_kt = 0;
+  const bf16x8* pfp[RT];
+#pragma unroll
+  for (int a = 0; a < RT; ++a) pfp[a] = base_of((int)blockIdx.x * RT + a);
+  bf16x8 xf[PF][RT][2];
+  auto fetch = [&](int slot) {
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+      xf[slot][a][0] = __builtin_nontemporal_load(pfp[a]);
+      xf[slot][a][1] = __builtin_nontemporal_load(pfp[a] + 64);
+    }
+    if (++pf_kt == nk) {                          // next group of blocks (past the end: the last group again -- loaded, never used)
+      pf_kt = 0;
+      pf_j = min(pf_j + 1, nmine - 1);
+#pragma unroll
+      for (int a = 0; a < RT; ++a) pfp[a] = base_of((pf_j * (int)gridDim.x + (int)blockIdx.x) * RT + a);
+    } else {
+#pragma unroll
+      for (int a = 0; a < RT; ++a) pfp[a] += 1024;
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < PF - 1; ++p) {
+    fetch(p);
+    __builtin_amdgcn_sched_barrier(0);             // issue order = ring order: the counted waits of the loop rely on it
+  }
+  int qb = 0;
+  const int qper = qres ? nk : QB;                 // slice of step g sits in ring buffer g % qper
+  unsigned int ovf = 0;
+  if (qres) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                  // the whole q has landed
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int j = 0; j < nmine; ++j) {
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        fetch((u + PF - 1) % PF);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!qres) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sQ = smem + qb * QBYTES + lane * 16;
+        qb = qb + 1 == qper ? 0 : qb + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int b = 0; b < QT; ++b) {
+            const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
+#pragma unroll
+            for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][a][ks], qf, acc[a][b], 0, 0, 0);
+          }
+      }
+    }
+    // ---- block epilogue: D[i = corpus row][j = query]: lane holds query fi of tile b, rows fq*4 + {0..3}.  LDS only: a wave tile with
+    //      more hits than the list holds (near-duplicate rows) pushes the query's counter past CAND_CAP instead -> flagged, redone by the fallback
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+      const int li = (j * (int)gridDim.x + (int)blockIdx.x) * RT + a;
+      const int64_t n64 = (int64_t)blk_of(li) * 128 + wave * 16 + fq * 4;
+      const unsigned int n = (unsigned int)n64;
+      const int valid = li < nblocks ? (int)max((int64_t)0, min((int64_t)4, N - n64)) : 0;
+#pragma unroll
+      for (int b = 0; b < QT; ++b) {
+        const f32x4 v = acc[a][b];
+        acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float tb = sthr[b * 16 + fi];
+        unsigned int c = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c += (e < valid && v[e] >= tb) ? 1u : 0u;
+        if (c) {
+          unsigned int p = atomicAdd(wn, c);        // LDS
+          const unsigned int col = b * 16 + fi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < valid && v[e] >= tb) {
+              if (p < WCAP) { wl[p] = sel_pack(f2key(v[e]), n + e); wq[p] = col; }
+              else ovf |= 1u << b;
+              ++p;
+            }
+        }
+      }
+    }
+    if (__builtin_expect(ovf != 0, 0)) {
+      for (int b = 0; b < QT; ++b)
+        if ((ovf >> b) & 1u) {
+          unsigned int col = b * 16 + fi;
+          asm volatile("" : "+v"(col));             // (keeps the address arithmetic inside this cold branch)
+          __hip_atomic_fetch_add(&cnt[col * CNT_STRIDE], (unsigned int)CAND_CAP + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      ovf = 0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (*wn > WCAP - 96) flush();                  // (wave-uniform: one LDS word)
+  }
+  flush();
+}
+
 extern "C" int64_t lrx_flat_ip_score_ld(int64_t n_rows) { return lrx_cdiv(n_rows > 0 ? n_rows : 1, S_ROWS) * S_ROWS; }
 
 #define SPLIT_MIN_QT 3   // Q > 32 -> split-bf16 kernel (fp32-MFMA-bound otherwise); Q <= 32 stays on the exact-fp32 kernel (HBM-bound)
@@ -540,6 +918,16 @@ struct FilterMode {
 // planes = 3: fp32-grade scores (six bf16 products); planes = 1: one bf16 product (filter pass of the bounded search, error bound
 // query_eps_block); gate != NULL: the whole pass is skipped unless *gate != 0.  One call covers at most one query chunk (128 queries, 256
 // for the shadow filter); `ld` is the row stride of `scores` / rounded row count.
+static int lrx_cu_count() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n_cu;
+}
+
 static int filter_rows_per_wg(bool shadow) { return shadow ? 16 * SPX_RT * SPX_WV : 16 * SPF_RT * SPF_WV; }
 
 static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, float* scores,
@@ -573,7 +961,36 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
         int threads = (dim / 64) * 2 * qt * 64;
         hipLaunchKernelGGL(k_pack_queries_xb, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit);
       }
-#define LRX_SB_(QQ, QSB_, EM_)                                                                                                                           \
+      if (ldxb == 0) {
+        // tiled shadow: corpus fragments through registers.  Main pass of the score-free filter: persistent workgroups, one per CU
+        // (D / 64 a multiple of the ring depth); everything else: one workgroup per 128-row block
+        constexpr int XPF = 4;
+        const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31);
+        const int n_cu = lrx_cu_count();
+#define LRX_XP(QQ, RT_)                                                                                                                     \
+  {                                                                                                                                         \
+    const int64_t groups = (nwg + RT_ - 1) / RT_;                                                                                           \
+    hipLaunchKernelGGL((k_filter_xreg_emit<QQ, XPF, RT_>), dim3((unsigned)(groups < n_cu ? groups : n_cu)), dim3(576), 0, s, (const __bf16*)Xb, n_rows, \
+                       dim, qsplit, nq, (int)nwg, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);                                      \
+  }
+#define LRX_XN(QQ, EM_)                                                                                                                     \
+  hipLaunchKernelGGL((k_filter_xreg<QQ, XPF, EM_>), dim3((unsigned)nwg), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
+                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);
+#define LRX_XR(QQ, RT_)                        \
+  case QQ:                                     \
+    if (persistent) LRX_XP(QQ, RT_)            \
+    else if (emit) { LRX_XN(QQ, true) }        \
+    else { LRX_XN(QQ, false) }                 \
+    break;
+        switch (qt) { LRX_XR(1, 2) LRX_XR(2, 2) LRX_XR(3, 2) LRX_XR(4, 2) LRX_XR(5, 2) LRX_XR(6, 2) LRX_XR(7, 2) LRX_XR(8, 1)
+                     LRX_XR(9, 1) LRX_XR(10, 1) LRX_XR(11, 1) LRX_XR(12, 1) LRX_XR(13, 1) LRX_XR(14, 1) LRX_XR(15, 1) LRX_XR(16, 1) }
+#undef LRX_XR
+#undef LRX_XN
+#undef LRX_XP
+        LRX_LAUNCH_CHECK();
+        continue;
+      }
+#define LRX_SB_(QQ, QSB_, EM_)                                                                                                                         \
     hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPX_RT, SPX_NST, SPX_WV, true, QSB_, EM_>), dim3((unsigned)nwg), dim3(64 * SPX_WV), 0, s, Xb, n_rows, \
                        ldxb, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);
 #define LRX_SB(QQ, QSB_)                  \
@@ -1423,7 +1840,7 @@ k_shard_rows(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int D, __
         if (ldxb != 0) *(bf16x4*)(Xb + r * ldxb + i) = h;
         else {                                              // tiled shadow: Xb = its base, this row is row0 + r of it
           const int64_t ra = row0 + r;
-          *(bf16x4*)(Xb + ((ra >> 7) * (int64_t)(D / 64) + (i >> 6)) * 8192 + (ra & 127) * 64 + (i & 63)) = h;
+          *(bf16x4*)(Xb + lrx_shadow_off(ra, i, D)) = h;      // (i % 4 == 0: four consecutive k of one 8-element fragment piece)
         }
       }
     }

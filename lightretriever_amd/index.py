@@ -47,7 +47,8 @@ class FlatIPIndex:
         # (half the bytes; the exact rescoring still reads fp32).  +50 % index memory; False = no shadow.  Shadow rows and bounds are
         # written by the kernel that produces the fp32 rows (the encoder's last kernel for slots, lrx_shard_commit_rows for add()).
         self.shadow_bf16 = True
-        # "tiled": [128-row block][64-wide k-slice][128][64] bf16 (include/lrx.h): every request of the filter pass reads 1 KiB in one piece
+        # "tiled": [128-row block][64-wide k-slice] tiles of 16 KiB, fragment-major inside (include/lrx.h): a wave of the filter pass loads
+        # its MFMA operand with one coalesced 1-KiB request, straight into registers
         # (Q = 1: -12 %, Q = 100: -6 % per search); "rows": plain row-major [capacity, d].  Same hits either way.
         self.shadow_layout = "tiled"
         self.max_workspace_bytes = 12 << 30  # search(): cap of the search workspace; larger query batches are chunked
@@ -116,7 +117,9 @@ class FlatIPIndex:
         if self._xb.ndim == 2:
             return self._xb[:n]
         nb = -(-n // 128)
-        return self._xb[:nb * 128 * self.d].view(nb, self.d // 64, 128, 64).permute(0, 2, 1, 3).reshape(nb * 128, self.d)[:n]
+        # tile = [16-row group w][k-step ks][fq][fi][8]  ->  row 128 b + 16 w + fi, column 64 s + 32 ks + 8 fq + j
+        t = self._xb[:nb * 128 * self.d].view(nb, self.d // 64, 8, 2, 4, 16, 8)          # b, s, w, ks, fq, fi, j
+        return t.permute(0, 2, 5, 1, 3, 4, 6).reshape(nb * 128, self.d)[:n]
 
     def append_slot(self, n_rows: int) -> torch.Tensor:
         """Rows [ntotal, ntotal+n) of the shard as a writable view (the encoder writes embeddings straight into it, together with

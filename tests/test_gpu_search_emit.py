@@ -37,6 +37,10 @@ def _index(X, shadow=True, id_base=0, pieces=2):
     # 129..256 queries over a wide shard: the main pass runs on the GEMM kernel (256-row tiles, sample in 256-row units)
     (40000, 1024, 200, 10, "unit", True), (33001, 2048, 300, 5, "mixed", True), (70000, 1024, 256, 100, "unit", True), (20000, 1088, 129, 3, "unit", True),
     (60000, 256, 100, 100, "unit", False), (45000, 128, 128, 10, "mixed", False), (30011, 96, 40, 64, "unit", False),   # fp32 rows converted on the fly
+    # the register-streaming filter kernels of the tiled shadow: persistent main pass (D/64 % 4 == 0: 512, 768; whole q resident in LDS at
+    # 256), one-workgroup-per-block form otherwise (192 = 3 slices), odd block counts for the two-blocks-at-a-time walk, 9..16 query tiles
+    (50001, 512, 100, 20, "unit", True), (30000, 768, 17, 5, "mixed", True), (40000, 192, 60, 10, "unit", True), (90000, 256, 200, 10, "unit", True),
+    (16512, 256, 2, 3, "unit", True), (16640, 1024, 128, 100, "mixed", True),
 ])
 def test_score_free_filter_equals_score_matrix_filter_bitwise(N, D, Q, k, scale, shadow, search_mode):
     """Both filters end in the same exact rescoring of a superset of the exact top-k: same ids, same score bits."""
@@ -58,6 +62,22 @@ def test_score_free_filter_equals_score_matrix_filter_bitwise(N, D, Q, k, scale,
     assert torch.equal(I3, Im) and torch.equal(D3, Dm)
     assert torch.equal(Ia, Im) and torch.equal(Da, Dm)
     check_against_oracle(De, Ie, q, X, k, id_base=1000)
+
+
+def test_tiled_shadow_layout_is_the_documented_one():
+    """include/lrx.h: element k of row r of the tiled shadow sits at
+    ((r/128)(D/64) + k/64) 8192 + ((((r/16)%8) 2 + (k/32)%2) 64 + ((k/8)%4) 16 + r%16) 8 + k%8."""
+    rng = np.random.default_rng(9)
+    N, D = 1000, 192
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    idx = _index(X, pieces=3)
+    assert idx._xb.ndim == 1
+    flat = idx._xb.view(torch.int16).cpu().numpy()
+    want = torch.from_numpy(X).to(torch.bfloat16).view(torch.int16).numpy()
+    r = rng.integers(0, N, size=4000)
+    k = rng.integers(0, D, size=4000)
+    off = ((r // 128) * (D // 64) + k // 64) * 8192 + ((((r // 16) % 8) * 2 + (k // 32) % 2) * 64 + ((k // 8) % 4) * 16 + r % 16) * 8 + k % 8
+    assert np.array_equal(flat[off], want[r, k])
 
 
 def test_workspace_stops_growing_at_256_queries():
