@@ -846,13 +846,14 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
         const char* sQ = smem + qb * QBYTES + lane * 16;
         qb = qb + 1 == qper ? 0 : qb + 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
           for (int b = 0; b < QT; ++b) {
             const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
 #pragma unroll
             for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][a][ks], qf, acc[a][b], 0, 0, 0);
           }
+        }
       }
     }
     // ---- block epilogue: D[i = corpus row][j = query]: lane holds query fi of tile b, rows fq*4 + {0..3}.  LDS only: a wave tile with
@@ -965,16 +966,19 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
         // tiled shadow: corpus fragments through registers.  Main pass of the score-free filter: persistent workgroups, one per CU
         // (D / 64 a multiple of the ring depth); everything else: one workgroup per 128-row block
         constexpr int XPF = 4;
+#ifndef XPF_S
+#define XPF_S 8
+#endif
         const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31);
         const int n_cu = lrx_cu_count();
 #define LRX_XP(QQ, RT_)                                                                                                                     \
   {                                                                                                                                         \
     const int64_t groups = (nwg + RT_ - 1) / RT_;                                                                                           \
-    hipLaunchKernelGGL((k_filter_xreg_emit<QQ, XPF, RT_>), dim3((unsigned)(groups < n_cu ? groups : n_cu)), dim3(576), 0, s, (const __bf16*)Xb, n_rows, \
+    hipLaunchKernelGGL((k_filter_xreg_emit<QQ, (QQ == 8 ? 2 : XPF), RT_>), dim3((unsigned)(groups < n_cu ? groups : n_cu)), dim3(576), 0, s, (const __bf16*)Xb, n_rows, \
                        dim, qsplit, nq, (int)nwg, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);                                      \
   }
 #define LRX_XN(QQ, EM_)                                                                                                                     \
-  hipLaunchKernelGGL((k_filter_xreg<QQ, XPF, EM_>), dim3((unsigned)nwg), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
+  hipLaunchKernelGGL((k_filter_xreg<QQ, (EM_ ? XPF : XPF_S), EM_>), dim3((unsigned)nwg), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
                      nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);
 #define LRX_XR(QQ, RT_)                        \
   case QQ:                                     \
@@ -982,7 +986,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
     else if (emit) { LRX_XN(QQ, true) }        \
     else { LRX_XN(QQ, false) }                 \
     break;
-        switch (qt) { LRX_XR(1, 2) LRX_XR(2, 2) LRX_XR(3, 2) LRX_XR(4, 2) LRX_XR(5, 2) LRX_XR(6, 2) LRX_XR(7, 2) LRX_XR(8, 1)
+        switch (qt) { LRX_XR(1, 2) LRX_XR(2, 2) LRX_XR(3, 2) LRX_XR(4, 2) LRX_XR(5, 2) LRX_XR(6, 2) LRX_XR(7, 2) LRX_XR(8, 2)
                      LRX_XR(9, 1) LRX_XR(10, 1) LRX_XR(11, 1) LRX_XR(12, 1) LRX_XR(13, 1) LRX_XR(14, 1) LRX_XR(15, 1) LRX_XR(16, 1) }
 #undef LRX_XR
 #undef LRX_XN
@@ -1477,7 +1481,9 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
 }
 
 // exact rescoring of nc candidate rows (s_cand: row numbers): one half-wave per row (fp64 accumulation of the fp32 products, one
-// rounding to fp32); the packed (score, row) pairs go to `mine`
+// rounding to fp32); the packed (score, row) pairs go to `mine`.  (A version that streams the rows as 1024-float chunks through two
+// register buffers, the next chunk requested before the current one is accumulated, changed nothing: the step is bound by the chip's
+// random 8-KiB gather rate, 0.30 GB in ~58 us = 5.2 TB/s at Q = 100, 5.8 TB/s at Q = 256.)
 __device__ __forceinline__ void refine_rescore(const float* __restrict__ X, int64_t ldx, int D, const float* qrow, const unsigned long long* s_cand,
                                                int nc, unsigned long long* __restrict__ mine) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1495,13 +1501,14 @@ __device__ __forceinline__ void refine_rescore(const float* __restrict__ X, int6
 __global__ void __launch_bounds__(1024)
 k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ q, const unsigned long long* __restrict__ cand,
               const unsigned int* __restrict__ cnt, const float* __restrict__ eps, int k, unsigned long long* __restrict__ parts,
-              int* __restrict__ part_cnt) {
+              int* __restrict__ part_cnt, int nsplit) {
   __shared__ RadixShared rs;
-  __shared__ unsigned long long s_cand[REF_PCAND];
+  __shared__ unsigned long long s_cand[REF_CAND];           // (a part holds REF_CAND / nsplit of them)
   __shared__ __attribute__((aligned(16))) float s_q[REF_QLDS];   // the query row (every rescoring re-reads it; from global its loads serialise)
   __shared__ unsigned int s_ncand;
   const int tid = threadIdx.x;
   const int qi = blockIdx.x, part = blockIdx.y;
+  const unsigned int pcand = REF_CAND / nsplit;             // candidate capacity of one part
   const float* qglob = q + (int64_t)qi * D;
   const float* qrow = D <= REF_QLDS ? s_q : qglob;
   if (D <= REF_QLDS)
@@ -1514,21 +1521,21 @@ k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
     const unsigned long long* list = cand + (int64_t)qi * CAND_CAP;
     const float kth = key2f(radix_select_kth_list(list, (int)n, (unsigned int)k, rs));
     const float thr = kth - 2.0f * eps[qi];
-    for (int i = part + REF_SPLIT * tid; i < (int)n; i += REF_SPLIT * 1024) {
+    for (int i = part + nsplit * tid; i < (int)n; i += nsplit * 1024) {
       const unsigned long long e = list[i];
       if (key2f((uint32_t)(e >> 32)) >= thr) {
         const int64_t row = sel_row(e);
         // never index outside the shard, whatever the list holds: a row that cannot exist sends the query to the exact fallback
-        const unsigned int p = row < N ? atomicAdd(&s_ncand, 1u) : atomicAdd(&s_ncand, (unsigned int)REF_PCAND + 1u);
-        if (p < REF_PCAND) s_cand[p] = (unsigned long long)row;
+        const unsigned int p = row < N ? atomicAdd(&s_ncand, 1u) : atomicAdd(&s_ncand, (unsigned int)REF_CAND + 1u);
+        if (p < pcand) s_cand[p] = (unsigned long long)row;
       }
     }
     __syncthreads();
-    overflow = s_ncand > REF_PCAND;
+    overflow = s_ncand > pcand;
   }
   const int nc = overflow ? 0 : (int)s_ncand;
-  refine_rescore(X, ldx, D, qrow, s_cand, nc, parts + ((int64_t)qi * REF_SPLIT + part) * REF_PCAND);
-  if (tid == 0) part_cnt[qi * REF_SPLIT + part] = overflow ? -1 : nc;
+  refine_rescore(X, ldx, D, qrow, s_cand, nc, parts + ((int64_t)qi * nsplit + part) * pcand);
+  if (tid == 0) part_cnt[qi * nsplit + part] = overflow ? -1 : nc;
 }
 
 // Refine step of the score-matrix filter, grid (n_queries, REF_SPLIT): part s of query q owns the 128-row blocks b with b % REF_SPLIT == s:
@@ -1596,18 +1603,19 @@ k_refine_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
 // that overflowed flags the query for the gated six-product fallback.
 __global__ void __launch_bounds__(1024)
 k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restrict__ part_cnt, int64_t N, int k, int64_t id_base,
-               float* __restrict__ out_scores, int64_t* __restrict__ out_ids, int* __restrict__ qflags, int* __restrict__ any_flag) {
+               float* __restrict__ out_scores, int64_t* __restrict__ out_ids, int* __restrict__ qflags, int* __restrict__ any_flag, int nsplit) {
   __shared__ unsigned long long s_cand[REF_CAND];
   const int tid = threadIdx.x, qi = blockIdx.x;
+  const int pcand = REF_CAND / nsplit;
   float* os = out_scores + (int64_t)qi * k;
   int64_t* oi = out_ids + (int64_t)qi * k;
   const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
   if (keff == 0) return;
-  int cnt[REF_SPLIT], tot = 0;
+  int cnt[REF_SPLIT], tot = 0;                 // nsplit <= REF_SPLIT
   bool any_over = false;
 #pragma unroll
   for (int p = 0; p < REF_SPLIT; ++p) {
-    cnt[p] = part_cnt[qi * REF_SPLIT + p];
+    cnt[p] = p < nsplit ? part_cnt[qi * nsplit + p] : 0;
     any_over |= cnt[p] < 0;
     tot += cnt[p] < 0 ? 0 : cnt[p];
   }
@@ -1618,7 +1626,7 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
   int base = 0;
 #pragma unroll
   for (int p = 0; p < REF_SPLIT; ++p) {
-    const unsigned long long* src = parts + ((int64_t)qi * REF_SPLIT + p) * REF_PCAND;
+    const unsigned long long* src = parts + ((int64_t)qi * nsplit + p) * pcand;
     for (int i = tid; i < cnt[p]; i += 1024) s_cand[base + i] = src[i];
     base += cnt[p];
   }
@@ -1754,6 +1762,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
     unsigned long long* cand = (unsigned long long*)(ws + p.off_cand);
     LRX_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (ints_before_cnt(nq) + (p.emit ? (size_t)nq * CNT_STRIDE : 0)), s));     // flags, any_flag, list counts
     int rc;
+    int nsplit = REF_SPLIT;                   // parts per query of the refine step
     if (p.emit) {
       float* blkmax = scores + p.ld_s * (int64_t)nq;
       const int unit = p.gemm ? 2 : 1;                        // sample units of 256 rows = two blocks of the 128-row filter kernel
@@ -1775,8 +1784,11 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
         rc = launch_scores(X, n_rows, ldx, dim, qc, nq, nullptr, nullptr, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld, fm);
       }
       if (rc != LRX_OK) return rc;
-      hipLaunchKernelGGL(k_refine_band, dim3(nq, REF_SPLIT), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
-                         (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt);
+      // parts per query: the 1024-thread workgroups of the refine step run one per CU, so REF_SPLIT x nq of them beyond the CU count take
+      // a second round of ~40 us each (Q = 100: 400 workgroups, 82 us) -- fewer, larger parts then finish sooner
+      nsplit = (int64_t)nq * REF_SPLIT <= lrx_cu_count() ? REF_SPLIT : ((int64_t)nq * 2 <= lrx_cu_count() ? 2 : 1);
+      hipLaunchKernelGGL(k_refine_band, dim3(nq, nsplit), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
+                         (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt, nsplit);
       LRX_LAUNCH_CHECK();
     } else {
       float* blkmax = scores + p.ld * (int64_t)nq;
@@ -1790,7 +1802,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       LRX_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_refine_merge, dim3(nq), dim3(1024), 0, s, (const unsigned long long*)parts, (const int*)part_cnt, n_rows, k, id_base, osc, oic,
-                       flags, any_flag);
+                       flags, any_flag, nsplit);
     LRX_LAUNCH_CHECK();
     // gated fallback for the flagged queries (every kernel returns immediately on the device when nothing overflowed), 128 queries at
     // a time over the same score region
