@@ -721,7 +721,12 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
   constexpr int QBYTES = QINST * 1024;
   constexpr int QB = QT > 8 ? 3 : 4;               // q ring: the producer runs QB-1 slices ahead
   static_assert((QB - 2) * QINST <= 63, "vmcnt immediate");
-  constexpr int WCAP = 320;                        // hits a wave parks in LDS
+  // hits a wave parks in LDS: as many as the 160 KiB of the CU allow next to the q ring (one workgroup per CU).  A pass emits ~5 000 hits per
+  // query, i.e. 2.4 x queries per wave: with 320 entries most waves of a 100-query pass had to flush once in mid-pass (one memory-side atomic
+  // per hit, the wave waits, the workgroup waits for it at the next barrier): 630 us against 580 us for the same pass with hardly any hits
+  constexpr int WCAP_FIT = ((160 * 1024 - QB * QBYTES - QT * 64 - 1024) / (WV * 12)) / 64 * 64;
+  constexpr int WCAP = WCAP_FIT > 1024 ? 1024 : WCAP_FIT;
+  static_assert(WCAP >= 256, "hit lists do not fit next to the q ring");
   constexpr int WL_BYTES = WCAP * 12 + 16;
   __shared__ __attribute__((aligned(1024))) char smem[QB * QBYTES + WV * WL_BYTES + QT * 16 * 4];
   float* sthr = (float*)(smem + QB * QBYTES + WV * WL_BYTES);   // the thresholds (LDS: they are needed once per block, not per k-step)
@@ -729,8 +734,10 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < QT * 16; i += 576) sthr[i] = i < nq ? thr[i] : FLT_MAX;
   __syncthreads();
-  const int G = gridDim.x * RT;                                                  // blocks in flight over the grid
-  const int nmine = (nblocks - (int)blockIdx.x * RT + G - 1) / G;               // groups of RT blocks this workgroup walks (>= 1)
+  // this workgroup's blocks: launch indices blockIdx.x + i * gridDim.x, i < nbw (the counts differ by at most one block over the grid),
+  // walked RT at a time; an odd one out at the end is worked on with its own block in the second slot (cache hits, result dropped)
+  const int nbw = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int nmine = (nbw + RT - 1) / RT;                                         // steps of RT blocks (>= 1)
   const int nk = D / 64;
   const int64_t total = (int64_t)nmine * nk;                                     // k-steps of this workgroup
   const bool qres = nk <= QB;                      // the whole q fits the ring (D <= 256): staged once, no barrier per k-step
@@ -751,17 +758,19 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
       for (int p = 0; p < nk; ++p) stage_next();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      return;
+    } else {
+#pragma unroll
+      for (int p = 0; p < QB - 1; ++p)
+        if (p < total) stage_next();
+      for (int64_t g = 0; g < total; ++g) {
+        if (g + QB - 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QB - 2) * QINST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // q(g) is in LDS; the consumers are done with step g-1 -> its buffer is free
+        if (g + QB - 1 < total) stage_next();
+      }
     }
 #pragma unroll
-    for (int p = 0; p < QB - 1; ++p)
-      if (p < total) stage_next();
-    for (int64_t g = 0; g < total; ++g) {
-      if (g + QB - 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QB - 2) * QINST) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                // q(g) is in LDS; the consumers are done with step g-1 -> its buffer is free
-      if (g + QB - 1 < total) stage_next();
-    }
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_barrier();   // the four barriers of the consumers' final flush
     return;
   }
 
@@ -769,29 +778,28 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
   const int fi = lane & 15, fq = lane >> 4;
   unsigned long long* wl = (unsigned long long*)(smem + QB * QBYTES + wave * WL_BYTES);
   unsigned int* wq = (unsigned int*)(wl + WCAP);
-  unsigned int* wn = wq + WCAP;
-  if (lane == 0) *wn = 0;
   auto blk_of = [&](int i) -> int {                // launch index -> 128-row block (see k_flat_ip_scores_split); all < 2^25
     if (bmode != 2) return i;
     const unsigned int u = (unsigned int)i / (unsigned int)unit, g = u / (unsigned int)(ss - 1);
     return (int)((g * ss + 1 + (u - g * (ss - 1))) * unit + ((unsigned int)i - u * unit));
   };
   const int last_blk = (int)((N - 1) >> 7);
+  auto li_of = [&](int j, int a) -> int { return (int)blockIdx.x + min(j * RT + a, nbw - 1) * (int)gridDim.x; };   // launch index of slot a in step j
   auto base_of = [&](int i) -> const bf16x8* {
-    const int b = min(blk_of(min(i, nblocks - 1)), last_blk);
+    const int b = min(blk_of(i), last_blk);
     return (const bf16x8*)(Xb + ((int64_t)b * (D / 64)) * 8192 + wave * 1024) + lane;
   };
-  auto flush = [&]() {
+  unsigned int wcnt = 0;                           // entries in this wave's list (wave-uniform)
+  auto flush = [&]() {                             // mid-pass, by the wave alone: one reservation per hit
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned int tot = min(*wn, (unsigned int)WCAP);
+    const unsigned int tot = min(wcnt, (unsigned int)WCAP);
     for (unsigned int i = lane; i < tot; i += 64) {
       const unsigned long long w = wl[i];
       const unsigned int col = wq[i];
       const unsigned int gp = atomicAdd(&cnt[col * CNT_STRIDE], 1u);
       if (gp < CAND_CAP) cand[(int64_t)col * CAND_CAP + gp] = w;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) *wn = 0;
+    wcnt = 0;
   };
 
   f32x4 acc[RT][QT];
@@ -804,7 +812,7 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
   int pf_j = 0, pf_kt = 0;
   const bf16x8* pfp[RT];
 #pragma unroll
-  for (int a = 0; a < RT; ++a) pfp[a] = base_of((int)blockIdx.x * RT + a);
+  for (int a = 0; a < RT; ++a) pfp[a] = base_of(li_of(0, a));
   bf16x8 xf[PF][RT][2];
   auto fetch = [&](int slot) {
 #pragma unroll
@@ -816,7 +824,7 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
       pf_kt = 0;
       pf_j = min(pf_j + 1, nmine - 1);
 #pragma unroll
-      for (int a = 0; a < RT; ++a) pfp[a] = base_of((pf_j * (int)gridDim.x + (int)blockIdx.x) * RT + a);
+      for (int a = 0; a < RT; ++a) pfp[a] = base_of(li_of(pf_j, a));
     } else {
 #pragma unroll
       for (int a = 0; a < RT; ++a) pfp[a] += 1024;
@@ -860,28 +868,29 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
     //      more hits than the list holds (near-duplicate rows) pushes the query's counter past CAND_CAP instead -> flagged, redone by the fallback
 #pragma unroll
     for (int a = 0; a < RT; ++a) {
-      const int li = (j * (int)gridDim.x + (int)blockIdx.x) * RT + a;
-      const int64_t n64 = (int64_t)blk_of(li) * 128 + wave * 16 + fq * 4;
+      const int64_t n64 = (int64_t)blk_of(li_of(j, a)) * 128 + wave * 16 + fq * 4;
       const unsigned int n = (unsigned int)n64;
-      const int valid = li < nblocks ? (int)max((int64_t)0, min((int64_t)4, N - n64)) : 0;
+      const int valid = j * RT + a < nbw ? (int)max((int64_t)0, min((int64_t)4, N - n64)) : 0;
 #pragma unroll
       for (int b = 0; b < QT; ++b) {
         const f32x4 v = acc[a][b];
         acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float tb = sthr[b * 16 + fi];
-        unsigned int c = 0;
+        const unsigned int col = b * 16 + fi;
+        // the list is private to the wave: slots by ballot + lane prefix, the fill count in a scalar (an LDS atomic per tile with a hit --
+        // nearly every tile at ~17 hits per step -- was a serial ~120-cycle round trip each)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) c += (e < valid && v[e] >= tb) ? 1u : 0u;
-        if (c) {
-          unsigned int p = atomicAdd(wn, c);        // LDS
-          const unsigned int col = b * 16 + fi;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < valid && v[e] >= tb) {
-              if (p < WCAP) { wl[p] = sel_pack(f2key(v[e]), n + e); wq[p] = col; }
+        for (int e = 0; e < 4; ++e) {
+          const bool h = e < valid && v[e] >= tb;
+          const unsigned long long m = __ballot(h);
+          if (m) {
+            const unsigned int pos = wcnt + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+            if (h) {
+              if (pos < WCAP) { wl[pos] = sel_pack(f2key(v[e]), n + e); wq[pos] = col; }
               else ovf |= 1u << b;
-              ++p;
             }
+            wcnt += (unsigned int)__popcll(m);
+          }
         }
       }
     }
@@ -894,10 +903,33 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
         }
       ovf = 0;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (*wn > WCAP - 96) flush();                  // (wave-uniform: one LDS word)
+    if (wcnt > WCAP - 96) flush();                 // (wave-uniform)
   }
-  flush();
+  // ---- final flush, by the workgroup: one list reservation per (workgroup, query) instead of one per hit.  The ~5e5 hits of a pass would
+  //      otherwise reach the ~100 list counters at the same time, at the end of the pass, and the memory-side atomics of one address
+  //      serialise (k = 100: 50 us of tail; with k = 1, i.e. hardly any hits, the same pass took 580 instead of 630 us).
+  unsigned int* qcnt = (unsigned int*)smem;        // [QT*16] hits per query, then the running offset (the q ring is dead)
+  unsigned int* qbase = qcnt + QT * 16;            // [QT*16] first slot of this workgroup in the query's list
+  __builtin_amdgcn_s_barrier();                    // every wave is out of the k loop: nobody reads the q ring any more
+  for (int i = tid; i < QT * 16; i += 512) qcnt[i] = 0;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const unsigned int tot = min(wcnt, (unsigned int)WCAP);
+  for (unsigned int i = lane; i < tot; i += 64) atomicAdd(&qcnt[wq[i]], 1u);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int i = tid; i < QT * 16; i += 512) {
+    const unsigned int c = qcnt[i];
+    if (c) qbase[i] = atomicAdd(&cnt[i * CNT_STRIDE], c);
+    qcnt[i] = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (unsigned int i = lane; i < tot; i += 64) {
+    const unsigned int col = wq[i];
+    const unsigned int slot = qbase[col] + atomicAdd(&qcnt[col], 1u);
+    if (slot < CAND_CAP) cand[(int64_t)col * CAND_CAP + slot] = wl[i];
+  }
 }
 
 extern "C" int64_t lrx_flat_ip_score_ld(int64_t n_rows) { return lrx_cdiv(n_rows > 0 ? n_rows : 1, S_ROWS) * S_ROWS; }

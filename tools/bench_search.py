@@ -18,18 +18,19 @@ def main():
     idx.commit(N)
     if os.environ.get("MODE"):        # 1 = score-matrix filter, 2 = score-free filter (lrx_search_set_mode)
         idx.lib.lrx_search_set_mode(int(os.environ["MODE"]))
+    K = int(os.environ.get("K", 100))
     for Q in [int(x) for x in os.environ.get("QS", "1,16,32,48,100,128").split(",")]:
         q = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device="cuda"), dim=-1)
         for _ in range(2):
-            idx.search(q, 100)
+            idx.search(q, K)
         ts = []
         for _ in range(8):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); idx.search(q, 100); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+            e0.record(); idx.search(q, K); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
         med = statistics.median(ts)
         if os.environ.get("STATS") and idx._xb is not None and Q >= 4:
             # what the score-free filter sees for a few queries: rows reaching the sample threshold T' - 2 eps, rows in the final band
-            xb, k, ss = idx.shadow_rows(), 100, 20
+            xb, k, ss = idx.shadow_rows(), K, 20
             nb = (N + 127) // 128
             samp = torch.arange(0, nb, ss, device="cuda").repeat_interleave(128) * 128 + torch.arange(128, device="cuda").repeat((nb + ss - 1) // ss)
             samp = samp[samp < N]
