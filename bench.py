@@ -160,7 +160,7 @@ def pmc_traffic(kernel_key):
         return None
 
 
-SEARCH_KERNELS = ("k_flat_ip_scores_split<NP=1,emit>", "k_flat_ip_scores_split<NP=1,scores>", "k_sample_threshold", "k_refine_band", "k_refine_merge")
+SEARCH_KERNELS = ("k_filter_xreg<emit>", "k_filter_xreg<scores>", "k_sample_threshold", "k_refine_band", "k_refine_merge")
 
 
 def pmc_search_traffic():
@@ -344,7 +344,7 @@ def main():
                          "frac": round(alg_bytes / (local_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "traffic": pmc_search_traffic() if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100 and D == 2048) else None,
                          "algorithmic_bytes": alg_bytes,
-                         "kernel": "two-pass exact search without a score matrix: k_flat_ip_scores_split<QT,1,..,XB,EMIT> (single-product filter over the bf16 shadow of the shard, HBM-bound; a strided 1/20 sample first -> k_sample_threshold, then the rest emitting only rows above the threshold) + k_refine_band/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
+                         "kernel": "two-pass exact search without a score matrix: k_filter_xreg / k_filter_xreg_emit (single-product filter over the tiled bf16 shadow of the shard, corpus fragments streamed through registers, HBM-bound; a strided 1/20 sample first -> k_sample_threshold, then persistent workgroups over the rest, emitting only rows above the threshold) + k_refine_band/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
                          "fp32_equiv_tflops": round(2.0 * args.queries * D * shard_rows / (local_ms * 1e-3) / 1e12, 2),
                          "fp32_mfma_peak_for_reference": PEAK_F32_MFMA_TFLOPS},
         }

@@ -15,6 +15,12 @@ def load(d, counter):
 import re
 
 def short(name):
+    # the tiled-shadow filter kernels: persistent emitting main pass / one-workgroup-per-block form (emit or score stores)
+    if "k_filter_xreg_emit<" in name:
+        return "k_filter_xreg<emit>"
+    m = re.search(r"k_filter_xreg<(\d+), (\d+), (true|false)>", name)
+    if m:
+        return "k_filter_xreg<%s>" % ("emit" if m.group(3) == "true" else "scores")
     m = re.search(r"k_flat_ip_scores_split<(\d+), (\d+)([^>]*)>", name)
     if m:
         # NP=1: filter pass (emit = the score-free main pass, scores = its sample pass / the score-matrix filter), NP=3: six-product

@@ -20,11 +20,11 @@ python3 $R/tools/pmc_summary.py $OUT/srch > $OUT/srch_summary.json
 python3 - <<PY
 import json
 a = json.load(open("$OUT/enc_summary.json")); b = json.load(open("$OUT/srch_summary.json"))
-keep = ("k_flat_ip", "k_sample_threshold", "k_refine", "k_topk_select", "k_rescore", "k_shard_rows")
+keep = ("k_flat_ip", "k_filter_xreg", "k_sample_threshold", "k_refine", "k_topk_select", "k_rescore", "k_shard_rows")
 out = {k: v for k, v in a.items() if not k.startswith(keep)}
 out.update({k: v for k, v in b.items() if k.startswith(keep)})
 out["_workloads"] = {"encode": "bench.py --steps 2 --warmup 1 --no-search (llama3.2-1b dims, 256 x 512 tokens)", "search": "tools/bench_search.py QS=100, 1M x 2048, k=100"}
 json.dump(out, open("$OUT/summary.json", "w"), indent=1)
-for k in ("k_gemm_bf16_nt<2>", "k_flat_ip_scores_split<NP=1,emit>", "k_flat_ip_scores_split<NP=1,scores>", "k_sample_threshold", "k_refine_band", "k_refine_merge"):
+for k in ("k_gemm_bf16_nt<2>", "k_filter_xreg<emit>", "k_filter_xreg<scores>", "k_sample_threshold", "k_refine_band", "k_refine_merge"):
     if k in out: print(k, round(out[k]["hbm_bytes_per_launch"] / 1e6, 1), "MB per launch")
 PY
