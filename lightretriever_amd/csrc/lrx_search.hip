@@ -525,11 +525,14 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
 // Only the q k-slice, which all eight waves share, goes through LDS: a ninth PRODUCER wave requests it one slice ahead by LDS-DMA
 // (its own in-order vmcnt, so the consumers' counted waits see nothing but their X loads); one barrier per k-slice.
 // ---------------------------------------------------------------------------------------------------------------
-template <int QT, int PF, bool EMIT>
+template <int QT, int PF, bool EMIT, int RT = 1>
 __global__ void __launch_bounds__(576, QT > 8 ? 1 : 2)
 k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, float* __restrict__ scores, int64_t ld,
               float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate, int bmode, int ss, int unit,
-              const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt) {
+              const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, int nlaunch) {
+  // RT = blocks per workgroup (launch indices RT * blockIdx.x + a < nlaunch): with two, the q slice is fetched once per 256 rows -- the
+  // sample pass of a 100-query search had 391 workgroups on 256 CUs, one or two per CU (56 -> 52 us; Q = 128: 61 -> 50 us)
+  static_assert(RT == 1 || !EMIT, "the emitting epilogue works on one block");
   constexpr int WV = 8, RB = 128;
   constexpr int QINST = 2 * QT;                    // 1-KiB LDS-DMA instructions per q slice
   constexpr int QBYTES = QINST * 1024;
@@ -541,20 +544,27 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
   if (gate != nullptr && *gate == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int64_t blk = blockIdx.x;
-  if (bmode == 1) { const int u = blockIdx.x / unit; blk = (int64_t)u * ss * unit + (blockIdx.x - u * unit); }
-  else if (bmode == 2) {
-    const int u = blockIdx.x / unit, g = u / (ss - 1);
-    blk = ((int64_t)g * ss + 1 + (u - g * (ss - 1))) * unit + (blockIdx.x - u * unit);
+  int64_t blks[RT], lis[RT];                       // corpus block and launch index (= where the scores go: compact in sample mode) per slot
+#pragma unroll
+  for (int a = 0; a < RT; ++a) {
+    const int li = min((int)blockIdx.x * RT + a, nlaunch - 1);   // (an odd one out: the last block again, nothing stored)
+    int64_t blk = li;
+    if (bmode == 1) { const int u = li / unit; blk = (int64_t)u * ss * unit + (li - u * unit); }
+    else if (bmode == 2) {
+      const int u = li / unit, g = u / (ss - 1);
+      blk = ((int64_t)g * ss + 1 + (u - g * (ss - 1))) * unit + (li - u * unit);
+    }
+    blks[a] = blk;
+    lis[a] = li;
   }
-  const int64_t n0 = blk * RB;
-  const int64_t n0s = (int64_t)blockIdx.x * RB;
   const int nk = D / 64;
   const int fi = lane & 15, fq = lane >> 4;
 
-  f32x4 acc[QT];
+  f32x4 acc[RT][QT];
 #pragma unroll
-  for (int b = 0; b < QT; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (wave == WV) {
     // ---- producer: q slice kt+1 requested while the consumers work on kt
@@ -575,14 +585,20 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
       if (kt + QB - 1 < nk) stage_q(kt + QB - 1);
     }
   } else {
-    // ---- consumers: wave w owns rows 16w .. 16w+15 of the block
-    const bf16x8* px = (const bf16x8*)(Xb + (min(blk, (N - 1) >> 7) * (int64_t)(D / 64)) * 8192 + wave * 1024) + lane;   // + kt*1024 (+64: k-step 1)
-    bf16x8 xf[PF][2];
-    auto step = [&](int u, int kt, bool fetch) __attribute__((always_inline)) {
-      if (fetch) {
-        xf[(u + PF - 1) % PF][0] = __builtin_nontemporal_load(px + (int64_t)(kt + PF - 1) * 1024);
-        xf[(u + PF - 1) % PF][1] = __builtin_nontemporal_load(px + (int64_t)(kt + PF - 1) * 1024 + 64);
+    // ---- consumers: wave w owns rows 16w .. 16w+15 of each block
+    const bf16x8* px[RT];                          // + kt*1024 (+64: k-step 1)
+#pragma unroll
+    for (int a = 0; a < RT; ++a) px[a] = (const bf16x8*)(Xb + (min(blks[a], (N - 1) >> 7) * (int64_t)(D / 64)) * 8192 + wave * 1024) + lane;
+    bf16x8 xf[PF][RT][2];
+    auto load = [&](int slot, int kt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int a = 0; a < RT; ++a) {
+        xf[slot][a][0] = __builtin_nontemporal_load(px[a] + (int64_t)kt * 1024);
+        xf[slot][a][1] = __builtin_nontemporal_load(px[a] + (int64_t)kt * 1024 + 64);
       }
+    };
+    auto step = [&](int u, int kt, bool fetch) __attribute__((always_inline)) {
+      if (fetch) load((u + PF - 1) % PF, kt + PF - 1);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -592,7 +608,8 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
 #pragma unroll
         for (int b = 0; b < QT; ++b) {
           const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
-          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][ks], qf, acc[b], 0, 0, 0);
+#pragma unroll
+          for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][a][ks], qf, acc[a][b], 0, 0, 0);
         }
     };
     // steady state: every step of the trip prefetches (no guard -> the compiler's counted vmcnt keeps PF-1 slices in flight);
@@ -601,8 +618,7 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
     if (2 * PF - 2 < nk) {
 #pragma unroll
       for (int p = 0; p < PF - 1; ++p) {
-        xf[p][0] = __builtin_nontemporal_load(px + (int64_t)p * 1024);
-        xf[p][1] = __builtin_nontemporal_load(px + (int64_t)p * 1024 + 64);
+        load(p, p);
         __builtin_amdgcn_sched_barrier(0);           // issue order = ring order: the counted waits of the loop rely on it
       }
       for (; kt0 + 2 * PF - 2 < nk; kt0 += PF) {
@@ -612,10 +628,7 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
     } else {
 #pragma unroll
       for (int p = 0; p < PF - 1; ++p)
-        if (p < nk) {
-          xf[p][0] = __builtin_nontemporal_load(px + (int64_t)p * 1024);
-          xf[p][1] = __builtin_nontemporal_load(px + (int64_t)p * 1024 + 64);
-        }
+        if (p < nk) load(p, p);
     }
     for (; kt0 < nk; kt0 += PF) {
 #pragma unroll
@@ -632,12 +645,12 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
       const int qi = b * 16 + fi;
       t[b] = qi < nq ? thr[qi] : FLT_MAX;
     }
-    const int64_t n = n0 + wave * 16 + fq * 4;
+    const int64_t n = blks[0] * RB + wave * 16 + fq * 4;
 #pragma unroll
     for (int b = 0; b < QT; ++b) {
       c[b] = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) c[b] += (n + e < N && acc[b][e] >= t[b]) ? 1u : 0u;
+      for (int e = 0; e < 4; ++e) c[b] += (n + e < N && acc[0][b][e] >= t[b]) ? 1u : 0u;
     }
 #pragma unroll
     for (int b = 0; b < QT; ++b) {
@@ -650,58 +663,63 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
         unsigned int pp = p[b];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (n + e < N && acc[b][e] >= t[b]) {
-            if (pp < CAND_CAP) cand[(int64_t)(b * 16 + fi) * CAND_CAP + pp] = sel_pack(f2key(acc[b][e]), n + e);
+          if (n + e < N && acc[0][b][e] >= t[b]) {
+            if (pp < CAND_CAP) cand[(int64_t)(b * 16 + fi) * CAND_CAP + pp] = sel_pack(f2key(acc[0][b][e]), n + e);
             ++pp;
           }
       }
     return;
   }
-  __syncthreads();   // all nine waves: the q buffers are dead, the epilogue reuses them
   float* wmax = (float*)smem;  // [8 waves][QT*16]
-  if (wave < WV) {
-#pragma unroll
-    for (int b = 0; b < QT; ++b) {
-      const int qi = b * 16 + fi;
-      float mx = -FLT_MAX;
-      const int64_t n = n0 + wave * 16 + fq * 4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e >= N) acc[b][e] = -FLT_MAX;
-        mx = fmaxf(mx, acc[b][e]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      if (fq == 0) wmax[wave * (QT * 16) + qi] = mx;
-    }
-  }
-  __syncthreads();
-  if (blkmax != nullptr) {
-    for (int t = tid; t < QT * 16; t += 576)
-      if (t < nq) {
-        float mx = -FLT_MAX;
-#pragma unroll
-        for (int w = 0; w < WV; ++w) mx = fmaxf(mx, wmax[w * (QT * 16) + t]);
-        blkmax[(int64_t)t * nblk_ld + blockIdx.x] = mx;
-      }
-  }
   constexpr int QPT = (LDS_BYTES / SEG / 16) < QT ? (LDS_BYTES / SEG / 16) : QT;   // q-tiles staged per pass
   static_assert(QPT >= 1, "epilogue staging does not fit");
   constexpr int NPASS = (QT + QPT - 1) / QPT;
 #pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    __syncthreads();
+  for (int a = 0; a < RT; ++a) {
+    if (a > 0 && (int)blockIdx.x * RT + a >= nlaunch) break;     // (uniform)
+    const int64_t n0 = blks[a] * RB, n0s = lis[a] * RB;
+    __syncthreads();   // all nine waves: the q buffers (or the previous block's staging) are dead, the epilogue reuses them
     if (wave < WV) {
 #pragma unroll
-      for (int b = 0; b < QT; ++b)
-        if (b / QPT == ps) *(f32x4*)(smem + ((b - ps * QPT) * 16 + fi) * SEG + (wave * 16 + fq * 4) * 4) = acc[b];
+      for (int b = 0; b < QT; ++b) {
+        const int qi = b * 16 + fi;
+        float mx = -FLT_MAX;
+        const int64_t n = n0 + wave * 16 + fq * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= N) acc[a][b][e] = -FLT_MAX;
+          mx = fmaxf(mx, acc[a][b][e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (fq == 0) wmax[wave * (QT * 16) + qi] = mx;
+      }
     }
     __syncthreads();
-    const int nqt = (QT - ps * QPT) < QPT ? (QT - ps * QPT) : QPT;
-    for (int idx = tid; idx < nqt * 16 * (RB / 4); idx += 576) {
-      const int ql = idx / (RB / 4), c = idx % (RB / 4);
-      const int qi = ps * QPT * 16 + ql;
-      if (qi < nq) *(f32x4*)(scores + (int64_t)qi * ld + n0s + c * 4) = *(const f32x4*)(smem + ql * SEG + c * 16);
+    if (blkmax != nullptr) {
+      for (int t = tid; t < QT * 16; t += 576)
+        if (t < nq) {
+          float mx = -FLT_MAX;
+#pragma unroll
+          for (int w = 0; w < WV; ++w) mx = fmaxf(mx, wmax[w * (QT * 16) + t]);
+          blkmax[(int64_t)t * nblk_ld + lis[a]] = mx;
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      __syncthreads();
+      if (wave < WV) {
+#pragma unroll
+        for (int b = 0; b < QT; ++b)
+          if (b / QPT == ps) *(f32x4*)(smem + ((b - ps * QPT) * 16 + fi) * SEG + (wave * 16 + fq * 4) * 4) = acc[a][b];
+      }
+      __syncthreads();
+      const int nqt = (QT - ps * QPT) < QPT ? (QT - ps * QPT) : QPT;
+      for (int idx = tid; idx < nqt * 16 * (RB / 4); idx += 576) {
+        const int ql = idx / (RB / 4), c = idx % (RB / 4);
+        const int qi = ps * QPT * 16 + ql;
+        if (qi < nq) *(f32x4*)(scores + (int64_t)qi * ld + n0s + c * 4) = *(const f32x4*)(smem + ql * SEG + c * 16);
+      }
     }
   }
 }
@@ -1003,6 +1021,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
 #endif
         const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31);
         const int n_cu = lrx_cu_count();
+        const bool two_blocks = !emit && fm.bmode == 1 && nwg < (1ll << 31);
 #define LRX_XP(QQ, RT_)                                                                                                                     \
   {                                                                                                                                         \
     const int64_t groups = (nwg + RT_ - 1) / RT_;                                                                                           \
@@ -1011,17 +1030,22 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
   }
 #define LRX_XN(QQ, EM_)                                                                                                                     \
   hipLaunchKernelGGL((k_filter_xreg<QQ, (EM_ ? XPF : XPF_S), EM_>), dim3((unsigned)nwg), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
-                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);
-#define LRX_XR(QQ, RT_)                        \
-  case QQ:                                     \
-    if (persistent) LRX_XP(QQ, RT_)            \
-    else if (emit) { LRX_XN(QQ, true) }        \
-    else { LRX_XN(QQ, false) }                 \
+                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg);
+#define LRX_XN2(QQ)   /* sample pass: two blocks per workgroup */                                                                           \
+  hipLaunchKernelGGL((k_filter_xreg<QQ, XPF, false, 2>), dim3((unsigned)((nwg + 1) / 2)), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
+                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg);
+#define LRX_XR(QQ, RT_)                                  \
+  case QQ:                                               \
+    if (persistent) LRX_XP(QQ, RT_)                      \
+    else if (emit) { LRX_XN(QQ, true) }                  \
+    else if (two_blocks && QQ <= 8) { LRX_XN2(QQ <= 8 ? QQ : 1) } \
+    else { LRX_XN(QQ, false) }                           \
     break;
         switch (qt) { LRX_XR(1, 2) LRX_XR(2, 2) LRX_XR(3, 2) LRX_XR(4, 2) LRX_XR(5, 2) LRX_XR(6, 2) LRX_XR(7, 2) LRX_XR(8, 2)
                      LRX_XR(9, 1) LRX_XR(10, 1) LRX_XR(11, 1) LRX_XR(12, 1) LRX_XR(13, 1) LRX_XR(14, 1) LRX_XR(15, 1) LRX_XR(16, 1) }
 #undef LRX_XR
 #undef LRX_XN
+#undef LRX_XN2
 #undef LRX_XP
         LRX_LAUNCH_CHECK();
         continue;
