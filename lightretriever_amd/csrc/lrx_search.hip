@@ -1017,7 +1017,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
         // (D / 64 a multiple of the ring depth); everything else: one workgroup per 128-row block
         constexpr int XPF = 4;
 #ifndef XPF_S
-#define XPF_S 8
+#define XPF_S 4   // ring depth of the one-workgroup-per-block form (8: no faster at D = 2048, 13 % slower at 10M x 256, Q = 1)
 #endif
         const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31);
         const int n_cu = lrx_cu_count();
