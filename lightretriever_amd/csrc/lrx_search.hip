@@ -529,7 +529,7 @@ template <int QT, int PF, bool EMIT, int RT = 1>
 __global__ void __launch_bounds__(576, QT > 8 ? 1 : 2)
 k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, float* __restrict__ scores, int64_t ld,
               float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate, int bmode, int ss, int unit,
-              const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, int nlaunch) {
+              const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, int nlaunch, int gmax) {
   // RT = blocks per workgroup (launch indices RT * blockIdx.x + a < nlaunch): with two, the q slice is fetched once per 256 rows -- the
   // sample pass of a 100-query search had 391 workgroups on 256 CUs, one or two per CU (56 -> 52 us; Q = 128: 61 -> 50 us)
   static_assert(RT == 1 || !EMIT, "the emitting epilogue works on one block");
@@ -696,7 +696,12 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
       }
     }
     __syncthreads();
-    if (blkmax != nullptr) {
+    if (blkmax != nullptr && gmax) {             // maxima of the eight 16-row groups: [query][8 * block + wave], row stride 8 * nblk_ld
+      for (int t = tid; t < QT * 16 * WV; t += 576) {
+        const int qi = t >> 3, w = t & 7;
+        if (qi < nq) blkmax[(int64_t)qi * (8 * (int64_t)nblk_ld) + lis[a] * 8 + w] = wmax[w * (QT * 16) + qi];
+      }
+    } else if (blkmax != nullptr) {
       for (int t = tid; t < QT * 16; t += 576)
         if (t < nq) {
           float mx = -FLT_MAX;
@@ -964,6 +969,8 @@ struct FilterMode {
   const float* thr = nullptr;             // emit mode: per-query threshold
   unsigned long long* cand = nullptr;     // emit mode: candidate lists [Q, CAND_CAP]
   unsigned int* cnt = nullptr;            //            and their fill counts
+  bool group_max = false;                 // tiled-shadow kernels, score stores: `blkmax` receives the maxima of the 16-row wave groups
+                                          // (8 per block, row stride 8 x nblk_ld) instead of one maximum per 128-row block
 };
 
 // planes = 3: fp32-grade scores (six bf16 products); planes = 1: one bf16 product (filter pass of the bounded search, error bound
@@ -1030,10 +1037,10 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
   }
 #define LRX_XN(QQ, EM_)                                                                                                                     \
   hipLaunchKernelGGL((k_filter_xreg<QQ, (EM_ ? XPF : XPF_S), EM_>), dim3((unsigned)nwg), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
-                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg);
+                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg, fm.group_max ? 1 : 0);
 #define LRX_XN2(QQ)   /* sample pass: two blocks per workgroup */                                                                           \
   hipLaunchKernelGGL((k_filter_xreg<QQ, XPF, false, 2>), dim3((unsigned)((nwg + 1) / 2)), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
-                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg);
+                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg, fm.group_max ? 1 : 0);
 #define LRX_XR(QQ, RT_)                                  \
   case QQ:                                               \
     if (persistent) LRX_XP(QQ, RT_)                      \
@@ -1497,19 +1504,33 @@ __device__ float query_eps_block(const float* __restrict__ qglob, int D, const f
   return (sqrtf(B) * R + sqrtf(A) * (E + accum * R * 1.01f)) * 1.0001f + 1e-30f;
 }
 
-// Sample step of the score-free filter (one workgroup per query): kth' = k-th largest of the compact sample scores, thr = kth' - 2 eps,
-// and the sample rows reaching thr open the query's candidate list.  Sample-local row j is corpus row (j / rb) * ss * rb + j % rb.
+// Sample step of the score-free filter (one workgroup per query): T' = a lower bound of the k-th largest filter score of the shard taken from
+// the compact sample scores, thr = T' - 2 eps, and the sample rows reaching thr open the query's candidate list.  Sample-local row j is
+// corpus row (j / rb) * ss * rb + j % rb.  gsz = rows per entry of `blkmax`:
+//   128: T' = the k-th largest sample score (select_topk_sorted over the block maxima + the qualifying blocks);
+//   16 (register-streaming kernels: maxima of the 16-row wave groups, row stride 8 * nblk_ld): T' = the k-th largest GROUP maximum -- k
+//       different rows reach it, so it is a lower bound too, and with ~30 groups per wanted row it is the ~(1.02 k)-th score: one radix
+//       select over nblk * 8 values instead of select + gather + sort over the scores (40 -> 15 us at 1M x 2048, k = 100; 78 -> 41 us at 10M x 256).
 __global__ void __launch_bounds__(SEL_THREADS)
 k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, int k, const float* __restrict__ blkmax, int nblk, int nblk_ld,
                    const float* __restrict__ q, int D, const float* __restrict__ bounds, int rb, int ss, int64_t N, float* __restrict__ thr_out,
-                   float* __restrict__ eps_out, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt) {
+                   float* __restrict__ eps_out, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, int gsz) {
   __shared__ SelShared sh;
   __shared__ float s_red[32];
   const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = scores + (int64_t)qi * ld_s;
-  const float* bm = blkmax + (int64_t)qi * nblk_ld;
-  select_topk_sorted(row, Ns, k, bm, nblk, sh);                 // (the plan guarantees >= 2k valid sample rows)
-  const float kth = key2f((uint32_t)(sh.cand[k - 1] >> 32));
+  const int ng = gsz == 16 ? nblk * 8 : nblk;                    // entries of this query's maxima
+  const float* bm = blkmax + (int64_t)qi * (gsz == 16 ? 8 * (int64_t)nblk_ld : (int64_t)nblk_ld);
+  float kth;
+  if (gsz == 16 && ng >= k) {
+    unsigned int ne, nq_;
+    kth = key2f(radix_select_kth(bm, ng, (unsigned int)k, sh, ne, nq_));
+  } else {
+    // (group maxima: fewer than k groups -- a shard of a few thousand rows -- fall back to the scores themselves, without block pruning)
+    select_topk_sorted(row, Ns, k, gsz == 16 ? nullptr : bm, gsz == 16 ? 0 : nblk, sh);   // (the plan guarantees >= 2k valid sample rows)
+    kth = key2f((uint32_t)(sh.cand[k - 1] >> 32));
+  }
+  __syncthreads();
   const float eps = query_eps_block(q + (int64_t)qi * D, D, bounds, nullptr, s_red);
   const float thr = kth - 2.0f * eps;
   if (tid == 0) { thr_out[qi] = thr; eps_out[qi] = eps; }
@@ -1517,13 +1538,23 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
   // atomic per hit cost ~2 us of round trip per qualifying block and wave: 49 -> 3x us for the kernel), the count is stored once
   unsigned long long* list = cand + (int64_t)qi * CAND_CAP;
   __shared__ unsigned int s_fill;
-  if (tid == 0) s_fill = 0;
+  if (tid == 0) { s_fill = 0; sh.neq = 0; }
   __syncthreads();
-  for (int b = wave; b < nblk; b += SEL_THREADS / 64)
-    if (bm[b] >= thr) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int64_t j = (int64_t)b * SP_ROWS + h * 64 + lane;
+  if (gsz == 16) {
+    // qualifying 16-row groups first (all threads), then their rows, 16 lanes per group
+    unsigned int* glist = (unsigned int*)sh.eqs;                 // 2 * SEL_EQCAP entries
+    for (int g = tid; g < ng; g += SEL_THREADS)
+      if (bm[g] >= thr) {
+        const unsigned int p = atomicAdd(&sh.neq, 1u);
+        if (p < 2 * SEL_EQCAP) glist[p] = (unsigned int)g;
+      }
+    __syncthreads();
+    const unsigned int ngl = sh.neq;
+    if (ngl > 2 * SEL_EQCAP) {                                   // (near-duplicate rows: more groups than any list would hold -> exact fallback)
+      if (tid == 0) s_fill = CAND_CAP + 1;
+    } else {
+      for (unsigned int idx = tid; idx < ngl * 16; idx += SEL_THREADS) {
+        const int64_t j = (int64_t)glist[idx >> 4] * 16 + (idx & 15);
         const float v = row[j];
         const int64_t g = (j / rb) * ((int64_t)ss * rb) + (j % rb);
         if (g < N && v >= thr) {
@@ -1532,6 +1563,21 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
         }
       }
     }
+  } else {
+    for (int b = wave; b < nblk; b += SEL_THREADS / 64)
+      if (bm[b] >= thr) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int64_t j = (int64_t)b * SP_ROWS + h * 64 + lane;
+          const float v = row[j];
+          const int64_t g = (j / rb) * ((int64_t)ss * rb) + (j % rb);
+          if (g < N && v >= thr) {
+            const unsigned int p = atomicAdd(&s_fill, 1u);
+            if (p < CAND_CAP) list[p] = sel_pack(f2key(v), g);
+          }
+        }
+      }
+  }
   __syncthreads();
   if (tid == 0) cnt[qi * CNT_STRIDE] = s_fill;       // (the chunk's memset zeroed it; nobody else has touched it yet)
 }
@@ -1741,7 +1787,7 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   p.nblk_s = nsamp * p.rb / SP_ROWS;
   p.nblk_ld_s = (p.ld_s / SP_ROWS + 3) & ~(int64_t)3;
   const size_t fb = (size_t)(nq < 128 ? nq : 128) * (size_t)(p.ld + p.nblk_ld);
-  const size_t prim = p.emit ? (size_t)nq * (size_t)(p.ld_s + p.nblk_ld_s) : (size_t)nq * (size_t)(p.ld + p.nblk_ld);
+  const size_t prim = p.emit ? (size_t)nq * (size_t)(p.ld_s + 8 * p.nblk_ld_s) : (size_t)nq * (size_t)(p.ld + p.nblk_ld);   // (sample: group maxima, 8 per block)
   p.off_qsplit = align256((prim > fb ? prim : fb) * sizeof(float));
   p.off_q16 = align256(p.off_qsplit + split_ws_bytes(dim));
   p.off_ints = align256(p.off_q16 + (size_t)256 * dim * 2);
@@ -1824,10 +1870,11 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       const int unit = p.gemm ? 2 : 1;                        // sample units of 256 rows = two blocks of the 128-row filter kernel
       FilterMode fs;
       fs.bmode = 1; fs.ss = p.ss; fs.unit = unit; fs.nblocks = p.nsamp_wg * unit;
+      fs.group_max = shadow && ldx_bf16 == 0;                 // the register-streaming kernels hand over the maxima of their 16-row wave groups
       rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld_s, fs);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_sample_threshold, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld_s, p.nsamp_wg * p.rb, k, (const float*)blkmax,
-                         (int)p.nblk_s, (int)p.nblk_ld_s, qc, dim, row_bounds, p.rb, p.ss, n_rows, thr, eps, cand, cnt);
+                         (int)p.nblk_s, (int)p.nblk_ld_s, qc, dim, row_bounds, p.rb, p.ss, n_rows, thr, eps, cand, cnt, fs.group_max ? 16 : 128);
       LRX_LAUNCH_CHECK();
       if (p.gemm) {
         __bf16* q16 = (__bf16*)(ws + p.off_q16);
