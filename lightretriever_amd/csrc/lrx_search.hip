@@ -1729,15 +1729,15 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
 #pragma unroll
   for (int p = 0; p < REF_SPLIT; ++p) {
     const unsigned long long* src = parts + ((int64_t)qi * nsplit + p) * pcand;
-    for (int i = tid; i < cnt[p]; i += 1024) s_cand[base + i] = src[i];
+    for (int i = tid; i < cnt[p]; i += blockDim.x) s_cand[base + i] = src[i];
     base += cnt[p];
   }
   int P = 1;
   while (P < tot) P <<= 1;
   __syncthreads();
-  for (int i = tot + tid; i < P; i += 1024) s_cand[i] = 0ull;
+  for (int i = tot + tid; i < P; i += blockDim.x) s_cand[i] = 0ull;
   bitonic_sort_desc(s_cand, P);
-  for (int i = tid; i < keff; i += 1024) {
+  for (int i = tid; i < keff; i += blockDim.x) {
     const unsigned long long c = s_cand[i];
     os[i] = key2f((uint32_t)(c >> 32));
     oi[i] = id_base + sel_row(c);
@@ -1904,6 +1904,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
                          (int)p.nblk, (int)p.nblk_ld, row_bounds, k, id_base, (const float*)osc, parts, part_cnt);
       LRX_LAUNCH_CHECK();
     }
+    // (1024 threads: with 256 the sort of the typical 300-500 band rows took 20 instead of 14 us)
     hipLaunchKernelGGL(k_refine_merge, dim3(nq), dim3(1024), 0, s, (const unsigned long long*)parts, (const int*)part_cnt, n_rows, k, id_base, osc, oic,
                        flags, any_flag, nsplit);
     LRX_LAUNCH_CHECK();
