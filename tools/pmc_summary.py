@@ -18,7 +18,7 @@ def short(name):
     # the tiled-shadow filter kernels: persistent emitting main pass / one-workgroup-per-block form (emit or score stores)
     if "k_filter_xreg_emit<" in name:
         return "k_filter_xreg<emit>"
-    m = re.search(r"k_filter_xreg<(\d+), (\d+), (true|false)>", name)
+    m = re.search(r"k_filter_xreg<(\d+), (\d+), (true|false)(, \d+)?>", name)
     if m:
         return "k_filter_xreg<%s>" % ("emit" if m.group(3) == "true" else "scores")
     m = re.search(r"k_flat_ip_scores_split<(\d+), (\d+)([^>]*)>", name)
