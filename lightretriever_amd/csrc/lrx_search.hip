@@ -188,8 +188,11 @@ __global__ void k_split_queries(const float* __restrict__ Q, int nq, int D, int 
 
 // bf16-shadow filter: natural k order, 64-wide slices.  qs layout: [D/64 slices][2 k-steps][QT][64 lanes][8] bf16, lane (fi = query in
 // tile, fq) of k-step ks holds k = slice*64 + ks*32 + fq*8 .. +7 (the MFMA 16x16x32 operand layout).
-__global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, int QT, __bf16* __restrict__ qs) {
+// zero / nzero: ints cleared on the way (the flags and list counters of a bounded search: this is the first kernel of its chain, so the
+// clear needs no launch of its own)
+__global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, int QT, __bf16* __restrict__ qs, int* __restrict__ zero, int nzero) {
   int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = gid; i < nzero; i += gridDim.x * blockDim.x) zero[i] = 0;
   int lane = gid & 63, rest = gid >> 6;
   int qt = rest % QT, r2 = rest / QT;
   int ks = r2 & 1, sl = r2 >> 1;
@@ -969,6 +972,8 @@ struct FilterMode {
   const float* thr = nullptr;             // emit mode: per-query threshold
   unsigned long long* cand = nullptr;     // emit mode: candidate lists [Q, CAND_CAP]
   unsigned int* cnt = nullptr;            //            and their fill counts
+  int* zero = nullptr;                    // shadow filter: ints the query-packing kernel clears on the way (first launch of a bounded search)
+  int nzero = 0;
   bool group_max = false;                 // tiled-shadow kernels, score stores: `blkmax` receives the maxima of the 16-row wave groups
                                           // (8 per block, row stride 8 x nblk_ld) instead of one maximum per 128-row block
 };
@@ -1017,7 +1022,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
       if (nwg == 0) continue;
       if (fm.bmode != 2) {   // (the main pass of the score-free filter reuses the planes packed for its sample pass)
         int threads = (dim / 64) * 2 * qt * 64;
-        hipLaunchKernelGGL(k_pack_queries_xb, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit);
+        hipLaunchKernelGGL(k_pack_queries_xb, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit, fm.zero, fm.nzero);
       }
       if (ldxb == 0) {
         // tiled shadow: corpus fragments through registers.  Main pass of the score-free filter: persistent workgroups, one per CU
@@ -1879,7 +1884,10 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
     float* eps = thr + nq;
     unsigned long long* parts = (unsigned long long*)(ws + p.off_parts);
     unsigned long long* cand = (unsigned long long*)(ws + p.off_cand);
-    LRX_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (ints_before_cnt(nq) + (p.emit ? (size_t)nq * CNT_STRIDE : 0)), s));     // flags, any_flag, list counts
+    // flags, any_flag, list counts start at zero: cleared by the query-packing kernel of the first filter launch when there is one
+    const size_t nclear = ints_before_cnt(nq) + (p.emit ? (size_t)nq * CNT_STRIDE : 0);
+    const bool clear_in_pack = shadow && nclear < (1u << 30);
+    if (!clear_in_pack) LRX_HIP(hipMemsetAsync(flags, 0, sizeof(int) * nclear, s));
     int rc;
     int nsplit = REF_SPLIT;                   // parts per query of the refine step
     if (p.emit) {
@@ -1888,6 +1896,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       FilterMode fs;
       fs.bmode = 1; fs.ss = p.ss; fs.unit = unit; fs.nblocks = p.nsamp_wg * unit;
       fs.group_max = shadow && ldx_bf16 == 0;                 // the register-streaming kernels hand over the maxima of their 16-row wave groups
+      if (clear_in_pack) { fs.zero = flags; fs.nzero = (int)nclear; }
       rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld_s, fs);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_sample_threshold, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld_s, p.nsamp_wg * p.rb, k, (const float*)blkmax,
@@ -1912,7 +1921,9 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       LRX_LAUNCH_CHECK();
     } else {
       float* blkmax = scores + p.ld * (int64_t)nq;
-      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16);
+      FilterMode fa;
+      if (clear_in_pack) { fa.zero = flags; fa.nzero = (int)nclear; }
+      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, 0, fa);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_topk_select, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax, (int)p.nblk,
                          (int)p.nblk_ld, osc, oic, (const int*)nullptr, (const int*)nullptr);
