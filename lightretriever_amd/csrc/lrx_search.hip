@@ -12,7 +12,7 @@
 //     elements), LDS bitonic sort on (score desc, row asc).  Fallback when the gather overflows (heavy ties) or the
 //     index is small: exact 4 x 8-bit radix select of the k-th largest score + gather of everything strictly greater
 //     plus the lowest-row-id ties.  Deterministic output regardless of atomics order on both paths.
-//  2b. Every path ends with exact rescoring of the selected rows (k_rescore_topk / k_refine_topk: fp64 accumulation, one rounding
+//  2b. Every path ends with exact rescoring of the selected rows (k_topk_select_rescore / k_refine_topk: fp64 accumulation, one rounding
 //     to fp32), so the reported scores do not depend on the path, the query batch size or the shard layout.  For Q > 32 and rows
 //     with a known norm bound the search is two-pass (lrx_flat_ip_search_bounded): a single-product bf16 FILTER pass
 //     (k_flat_ip_scores_split<QT, 1, ..>, HBM-bound) + exact refinement of the rows inside a rigorous error band, with the
@@ -1379,35 +1379,43 @@ __device__ __forceinline__ float exact_dot(const float* __restrict__ x, const fl
   return (float)acc;
 }
 
-// Final step of the plain path: the k selected rows of each query are rescored with exact_dot and re-sorted (score desc, id asc).
-__global__ void __launch_bounds__(1024)
-k_rescore_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ q, int k, int64_t id_base,
-               float* __restrict__ out_scores, int64_t* __restrict__ out_ids, const int* __restrict__ gate, const int* __restrict__ qflags) {
-  __shared__ unsigned long long s_c[SEL_MAXK];
-  if (gate != nullptr && *gate == 0) return;
-  if (qflags != nullptr && qflags[blockIdx.x] == 0) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Select + final step of the plain path in one launch: the k selected rows of each query are rescored with exact_dot and re-sorted (score
+// desc, id asc).  (Two kernels until round 2; the gated fallback of the bounded search runs the same pair, and every launch that returns
+// at once still costs ~4.5 us of its chain.)  The selected rows stay in LDS between the two steps.
+__global__ void __launch_bounds__(SEL_THREADS)
+k_topk_select_rescore(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base, const float* __restrict__ blkmax, int nblk,
+                      int nblk_ld, const float* __restrict__ X, int64_t ldx, int D, const float* __restrict__ q, float* __restrict__ out_scores,
+                      int64_t* __restrict__ out_ids, const int* __restrict__ gate, const int* __restrict__ qflags) {
+  __shared__ SelShared sh;
+  if (gate != nullptr && *gate == 0) return;                 // fallback launch of the bounded search: nothing overflowed
+  if (qflags != nullptr && qflags[blockIdx.x] == 0) return;  // ... or not this query
+  const float* row = scores + (int64_t)blockIdx.x * ld;
   float* os = out_scores + (int64_t)blockIdx.x * k;
   int64_t* oi = out_ids + (int64_t)blockIdx.x * k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
+  for (int i = keff + tid; i < k; i += SEL_THREADS) { os[i] = -FLT_MAX; oi[i] = -1; }
   if (keff == 0) return;
+  select_topk_sorted(row, N, keff, blkmax ? blkmax + (int64_t)blockIdx.x * nblk_ld : nullptr, nblk, sh);   // sh.cand[0..keff): the selection
+  unsigned long long* s_c = sh.eqs;                          // SEL_EQCAP == SEL_MAXK entries, idle after the select
+  static_assert(SEL_EQCAP >= SEL_MAXK, "rescoring buffer");
   const float* qrow = q + (int64_t)blockIdx.x * D;
-  for (int c0 = wave * 2; c0 < keff; c0 += 32) {           // two rows per wave (one per half-wave)
+  for (int c0 = wave * 2; c0 < keff; c0 += 32) {             // two rows per wave (one per half-wave)
     const int c = min(c0 + (lane >> 5), keff - 1);
-    int64_t n = oi[c] - id_base;
-    n = n < 0 ? 0 : (n >= N ? N - 1 : n);          // never index outside the shard, whatever the select stage handed over
+    int64_t n = sel_row(sh.cand[c]);
+    n = n < 0 ? 0 : (n >= N ? N - 1 : n);
     const float sc = exact_dot(X + n * ldx, qrow, D, lane);
     if ((lane & 31) == 0 && c0 + (lane >> 5) < keff) s_c[c] = sel_pack(f2key(sc), n);
   }
   __syncthreads();
   int P = 1;
   while (P < keff) P <<= 1;
-  for (int i = keff + tid; i < P; i += 1024) s_c[i] = 0ull;
+  for (int i = keff + tid; i < P; i += SEL_THREADS) s_c[i] = 0ull;
   bitonic_sort_desc(s_c, P);
-  for (int i = tid; i < keff; i += 1024) {
+  for (int i = tid; i < keff; i += SEL_THREADS) {
     const unsigned long long c = s_c[i];
     os[i] = key2f((uint32_t)(c >> 32));
-    oi[i] = id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
+    oi[i] = id_base + sel_row(c);
   }
 }
 
@@ -1437,14 +1445,14 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
     int rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, qsplit, stream);
     if (rc != LRX_OK) return rc;
   }
-  hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, scores, ld, n_rows, k, id_base, blkmax, nblk,
-                     nblk_ld, out_scores, out_ids, (const int*)nullptr, (const int*)nullptr);
-  LRX_LAUNCH_CHECK();
   if (n_rows > 0 && dim % 4 == 0) {
-    hipLaunchKernelGGL(k_rescore_topk, dim3(n_queries), dim3(1024), 0, (hipStream_t)stream, X, n_rows, ldx, dim, q, k, id_base, out_scores, out_ids,
-                       (const int*)nullptr, (const int*)nullptr);
-    LRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_topk_select_rescore, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, (const float*)scores, ld, n_rows, k, id_base,
+                       (const float*)blkmax, nblk, nblk_ld, X, ldx, dim, q, out_scores, out_ids, (const int*)nullptr, (const int*)nullptr);
+  } else {
+    hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, scores, ld, n_rows, k, id_base, blkmax, nblk,
+                       nblk_ld, out_scores, out_ids, (const int*)nullptr, (const int*)nullptr);
   }
+  LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
 
@@ -1943,11 +1951,9 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       float* blkmax = scores + p.ld * (int64_t)nf;
       rc = launch_scores(X, n_rows, ldx, dim, qc + (int64_t)f0 * dim, nf, scores, blkmax, qsplit, stream, 3, any_flag);
       if (rc != LRX_OK) return rc;
-      hipLaunchKernelGGL(k_topk_select, dim3(nf), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax, (int)p.nblk,
-                         (int)p.nblk_ld, osc + (int64_t)f0 * k, oic + (int64_t)f0 * k, (const int*)any_flag, (const int*)(flags + f0));
-      LRX_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_rescore_topk, dim3(nf), dim3(1024), 0, s, X, n_rows, ldx, dim, qc + (int64_t)f0 * dim, k, id_base, osc + (int64_t)f0 * k,
-                         oic + (int64_t)f0 * k, (const int*)any_flag, (const int*)(flags + f0));
+      hipLaunchKernelGGL(k_topk_select_rescore, dim3(nf), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax,
+                         (int)p.nblk, (int)p.nblk_ld, X, ldx, dim, qc + (int64_t)f0 * dim, osc + (int64_t)f0 * k, oic + (int64_t)f0 * k,
+                         (const int*)any_flag, (const int*)(flags + f0));
       LRX_LAUNCH_CHECK();
     }
   }
