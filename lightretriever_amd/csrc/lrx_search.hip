@@ -160,9 +160,7 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
 }
 
 // qs layout: [D/32 slices][NP planes][QT][64 lanes][8] bf16   (NP = 3: hi/mid/lo, NP = 1: hi only)
-__global__ void k_split_queries(const float* __restrict__ Q, int nq, int D, int QT, int NP, __bf16* __restrict__ qs, const int* __restrict__ gate) {
-  if (gate != nullptr && *gate == 0) return;
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void split_queries_body(const float* __restrict__ Q, int nq, int D, int QT, int NP, __bf16* __restrict__ qs, int gid) {
   int lane = gid & 63, rest = gid >> 6;
   int qt = rest % QT, kt = rest / QT;
   if (kt >= D / 32) return;
@@ -185,14 +183,35 @@ __global__ void k_split_queries(const float* __restrict__ Q, int nq, int D, int 
     out[base + 2 * (int64_t)QT * 64] = l;
   }
 }
+__global__ void k_split_queries(const float* __restrict__ Q, int nq, int D, int QT, int NP, __bf16* __restrict__ qs, const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
+  split_queries_body(Q, nq, D, QT, NP, qs, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Planes of the gated six-product fallback of a bounded search, written ahead of time by extra workgroups of the query-packing kernel (the
+// first launch of the chain) instead of by a launch of their own behind the gate: groups of <= 128 queries, qs3 + g * stride each.
+struct PreSplit {
+  __bf16* qs3 = nullptr;
+  int64_t stride = 0;                     // elements between the groups' plane sets
+  int ngroups = 0, nb_xb = 0;             // nb_xb: workgroups of the packing proper
+  int nf[2] = {0, 0}, qt[2] = {0, 0}, blocks[2] = {0, 0};
+};
 
 // bf16-shadow filter: natural k order, 64-wide slices.  qs layout: [D/64 slices][2 k-steps][QT][64 lanes][8] bf16, lane (fi = query in
 // tile, fq) of k-step ks holds k = slice*64 + ks*32 + fq*8 .. +7 (the MFMA 16x16x32 operand layout).
 // zero / nzero: ints cleared on the way (the flags and list counters of a bounded search: this is the first kernel of its chain, so the
 // clear needs no launch of its own)
-__global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, int QT, __bf16* __restrict__ qs, int* __restrict__ zero, int nzero) {
+__global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, int QT, __bf16* __restrict__ qs, int* __restrict__ zero, int nzero,
+                                  PreSplit ps) {
+  if (ps.ngroups > 0 && (int)blockIdx.x >= ps.nb_xb) {
+    int b = (int)blockIdx.x - ps.nb_xb, g = 0;
+    if (b >= ps.blocks[0]) { b -= ps.blocks[0]; g = 1; }
+    split_queries_body(Q + (int64_t)g * 128 * D, ps.nf[g], D, ps.qt[g], 3, ps.qs3 + g * ps.stride, b * blockDim.x + threadIdx.x);
+    return;
+  }
+  const int nb = ps.ngroups > 0 ? ps.nb_xb : (int)gridDim.x;
   int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int i = gid; i < nzero; i += gridDim.x * blockDim.x) zero[i] = 0;
+  for (int i = gid; i < nzero; i += nb * blockDim.x) zero[i] = 0;
   int lane = gid & 63, rest = gid >> 6;
   int qt = rest % QT, r2 = rest / QT;
   int ks = r2 & 1, sl = r2 >> 1;
@@ -974,6 +993,8 @@ struct FilterMode {
   unsigned int* cnt = nullptr;            //            and their fill counts
   int* zero = nullptr;                    // shadow filter: ints the query-packing kernel clears on the way (first launch of a bounded search)
   int nzero = 0;
+  PreSplit presplit;                      // shadow filter: fallback planes the packing kernel writes on the way (ngroups > 0)
+  bool planes_ready = false;              // six-product pass: `qsplit` already holds the planes (see PreSplit)
   bool group_max = false;                 // tiled-shadow kernels, score stores: `blkmax` receives the maxima of the 16-row wave groups
                                           // (8 per block, row stride 8 x nblk_ld) instead of one maximum per 128-row block
 };
@@ -1022,7 +1043,10 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
       if (nwg == 0) continue;
       if (fm.bmode != 2) {   // (the main pass of the score-free filter reuses the planes packed for its sample pass)
         int threads = (dim / 64) * 2 * qt * 64;
-        hipLaunchKernelGGL(k_pack_queries_xb, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, qsplit, fm.zero, fm.nzero);
+        PreSplit ps = fm.presplit;
+        ps.nb_xb = (threads + 255) / 256;
+        hipLaunchKernelGGL(k_pack_queries_xb, dim3(ps.nb_xb + (ps.ngroups > 0 ? ps.blocks[0] + ps.blocks[1] : 0)), dim3(256), 0, s, qp, nq, dim, qt, qsplit,
+                           fm.zero, fm.nzero, ps);
       }
       if (ldxb == 0) {
         // tiled shadow: corpus fragments through registers.  Main pass of the score-free filter: persistent workgroups, one per CU
@@ -1083,7 +1107,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
       const int rb = planes == 3 ? 128 : 16 * SPF_RT * SPF_WV;
       const int64_t nwg = fm.nblocks >= 0 ? fm.nblocks : ld_full / rb;
       if (nwg == 0) continue;
-      if (fm.bmode != 2) {
+      if (fm.bmode != 2 && !fm.planes_ready) {
         int threads = (dim / 32) * qt * 64;
         hipLaunchKernelGGL(k_split_queries, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, planes, qsplit, gate);
       }
@@ -1786,7 +1810,7 @@ struct BoundedPlan {
   int64_t ld, nblk, nblk_ld;            // full shard: score row stride, 128-row blocks, blkmax row stride
   int64_t nsamp_wg, nmain_wg;           // emit: workgroups of the sample / main launch (rb rows each)
   int64_t ld_s, nblk_s, nblk_ld_s;      // emit: the compact sample matrix
-  size_t off_qsplit, off_q16, off_ints, off_parts, off_cand, total;   // byte offsets into the workspace (the score region starts at 0)
+  size_t off_qsplit, off_q16, off_qs3, off_ints, off_parts, off_cand, total;   // byte offsets into the workspace (the score region starts at 0)
 };
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -1820,7 +1844,8 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   const size_t prim = p.emit ? (size_t)nq * (size_t)(p.ld_s + 8 * p.nblk_ld_s) : (size_t)nq * (size_t)(p.ld + p.nblk_ld);   // (sample: group maxima, 8 per block)
   p.off_qsplit = align256((prim > fb ? prim : fb) * sizeof(float));
   p.off_q16 = align256(p.off_qsplit + split_ws_bytes(dim));
-  p.off_ints = align256(p.off_q16 + (size_t)256 * dim * 2);
+  p.off_qs3 = align256(p.off_q16 + (size_t)256 * dim * 2);          // planes of the gated fallback, two groups of <= 128 queries
+  p.off_ints = align256(p.off_qs3 + 2 * split_ws_bytes(dim));
   // ints: flags[nq], any_flag, pad to 64 ints, cnt[nq * CNT_STRIDE] (one memset) | part_cnt[nq * REF_SPLIT] | thr[nq] | eps[nq]
   p.off_parts = align256(p.off_ints + sizeof(int) * (ints_before_cnt(nq) + (size_t)nq * (CNT_STRIDE + 2 + REF_SPLIT)));
   p.off_cand = align256(p.off_parts + (size_t)nq * REF_CAND * 8);
@@ -1896,6 +1921,22 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
     const size_t nclear = ints_before_cnt(nq) + (p.emit ? (size_t)nq * CNT_STRIDE : 0);
     const bool clear_in_pack = shadow && nclear < (1u << 30);
     if (!clear_in_pack) LRX_HIP(hipMemsetAsync(flags, 0, sizeof(int) * nclear, s));
+    // ... and so are the hi/mid/lo query planes of the gated six-product fallback (groups of <= 128 queries; <= 32 queries run the
+    // exact-fp32 kernel, which needs none)
+    PreSplit presplit;
+    __bf16* qs3 = (__bf16*)(ws + p.off_qs3);
+    if (shadow) {
+      presplit.qs3 = qs3;
+      presplit.stride = (int64_t)(split_ws_bytes(dim) / sizeof(__bf16));
+      for (int f0 = 0, g = 0; f0 < nq; f0 += 128, ++g) {
+        const int nf = nq - f0 < 128 ? nq - f0 : 128, qtf = (nf + 15) / 16;
+        presplit.nf[g] = nf;
+        presplit.qt[g] = qtf;
+        presplit.blocks[g] = qtf >= SPLIT_MIN_QT ? ((dim / 32) * qtf * 64 + 255) / 256 : 0;
+        presplit.ngroups = g + 1;
+      }
+      if (presplit.blocks[0] + presplit.blocks[1] == 0) presplit.ngroups = 0;
+    }
     int rc;
     int nsplit = REF_SPLIT;                   // parts per query of the refine step
     if (p.emit) {
@@ -1905,6 +1946,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       fs.bmode = 1; fs.ss = p.ss; fs.unit = unit; fs.nblocks = p.nsamp_wg * unit;
       fs.group_max = shadow && ldx_bf16 == 0;                 // the register-streaming kernels hand over the maxima of their 16-row wave groups
       if (clear_in_pack) { fs.zero = flags; fs.nzero = (int)nclear; }
+      fs.presplit = presplit;
       rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld_s, fs);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_sample_threshold, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld_s, p.nsamp_wg * p.rb, k, (const float*)blkmax,
@@ -1931,6 +1973,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       float* blkmax = scores + p.ld * (int64_t)nq;
       FilterMode fa;
       if (clear_in_pack) { fa.zero = flags; fa.nzero = (int)nclear; }
+      fa.presplit = presplit;
       rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, 0, fa);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_topk_select, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax, (int)p.nblk,
@@ -1949,7 +1992,10 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
     for (int f0 = 0; f0 < nq; f0 += 128) {
       const int nf = nq - f0 < 128 ? nq - f0 : 128;
       float* blkmax = scores + p.ld * (int64_t)nf;
-      rc = launch_scores(X, n_rows, ldx, dim, qc + (int64_t)f0 * dim, nf, scores, blkmax, qsplit, stream, 3, any_flag);
+      FilterMode ff;
+      ff.planes_ready = presplit.ngroups > 0;                 // written by the packing kernel at the head of the chain
+      rc = launch_scores(X, n_rows, ldx, dim, qc + (int64_t)f0 * dim, nf, scores, blkmax, ff.planes_ready ? qs3 + (f0 / 128) * presplit.stride : qsplit, stream, 3,
+                         any_flag, nullptr, 0, 0, ff);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_topk_select_rescore, dim3(nf), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax,
                          (int)p.nblk, (int)p.nblk_ld, X, ldx, dim, qc + (int64_t)f0 * dim, osc + (int64_t)f0 * k, oic + (int64_t)f0 * k,

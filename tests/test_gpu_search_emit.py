@@ -154,6 +154,16 @@ def test_candidate_list_overflow_falls_back_per_query(search_mode):
     Dd, Id = idx2.search(q, 8)
     _, Id_o = O.flat_ip_topk(q, Xd, 8)
     np.testing.assert_array_equal(Id.cpu().numpy(), Id_o)
+    # more than 128 flagged queries: two groups of the gated fallback, each with its own pre-split query planes (written by the
+    # packing kernel at the head of the chain), the second one short enough for the exact-fp32 kernel (no planes)
+    q2 = O.l2_normalize(rng.standard_normal((150, D)).astype(np.float32))
+    _, I2 = idx2.search(q2, 8)
+    _, I2_o = O.flat_ip_topk(q2, Xd, 8)
+    np.testing.assert_array_equal(I2.cpu().numpy(), I2_o)
+    q3 = O.l2_normalize(rng.standard_normal((230, D)).astype(np.float32))       # both groups on the six-product kernel
+    _, I3 = idx2.search(q3, 8)
+    _, I3_o = O.flat_ip_topk(q3, Xd, 8)
+    np.testing.assert_array_equal(I3.cpu().numpy(), I3_o)
 
 
 def test_non_finite_query_does_not_poison_the_batch(search_mode):
