@@ -203,7 +203,8 @@ def test_shard_commit_rows_kernel_shadow_and_bounds():
     idx._xb = None
     idx._bounds.zero_()
     idx.refresh_norm_bound()
-    assert idx._xb.ndim == 2 and torch.equal(idx._xb[:N], xb) and np.array_equal(idx._bounds.cpu().numpy(), b)
+    # (bounds: the two layouts have their own kernels, i.e. summation orders -- equal to fp32 rounding)
+    assert idx._xb.ndim == 2 and torch.equal(idx._xb[:N], xb) and np.allclose(idx._bounds.cpu().numpy(), b, rtol=2e-6, atol=0)
 
 
 def test_encoder_writes_shadow_and_bounds_of_the_slot_it_fills():
