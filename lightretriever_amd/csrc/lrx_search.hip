@@ -1499,9 +1499,8 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
 //   fallback: a query whose list or band overflows (near-duplicate corpora) raises a device flag; the six-product pass + select +
 //           rescore are always enqueued behind it, gated on that flag (they return at once when it is 0), and overwrite only the
 //           flagged queries.  No host synchronisation anywhere.
-//   Very small query batches (Q < max(2, D / 256): the score matrix is < 2 % of the shadow bytes) and shards below 16 Ki rows keep the
-//   score-matrix filter: two launches less in the dependency chain (measured crossover: Q = 1 is 30-100 us faster that way, Q >= 16
-//   4-25 % slower).  Both give the same result -- everything ends in the same exact rescoring of a superset of the top-k.
+//   Shards below 16 Ki rows keep the score-matrix filter (two launches less in the dependency chain).  Both give the same result --
+//   everything ends in the same exact rescoring of a superset of the top-k.
 // ---------------------------------------------------------------------------------------------------------------
 #define REF_CAND 4096
 #define REF_BLK 8192
@@ -1833,7 +1832,9 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   const int64_t nsamp = lrx_cdiv(nwg, ss);
   const bool feasible = (nsamp - 1) * p.rb >= 2 * (int64_t)k && nwg - nsamp >= 1 && dim % 4 == 0 && (shadow || nq > 16 * (SPLIT_MIN_QT - 1));
   if (!feasible) p.gemm = false;
-  p.emit = feasible && g_search_mode != 1 && (g_search_mode >= 2 || (n_rows >= 16384 && nq >= 2 && 256 * (int64_t)nq >= dim));
+  // (until the register-streaming kernels and the group-maxima threshold step, batches of Q < max(2, D / 256) queries were faster on the
+  // score-matrix filter; now the score-free chain is as fast at Q = 1 over 1M x 2048 (0.69 ms both) and faster at 10M x 256 (0.85 vs 1.03 ms))
+  p.emit = feasible && g_search_mode != 1 && (g_search_mode >= 2 || n_rows >= 16384);
   p.ss = ss;
   p.nsamp_wg = nsamp;
   p.nmain_wg = nwg - nsamp;
