@@ -41,6 +41,9 @@ def _index(X, shadow=True, id_base=0, pieces=2):
     # 256), one-workgroup-per-block form otherwise (192 = 3 slices), odd block counts for the two-blocks-at-a-time walk, 9..16 query tiles
     (50001, 512, 100, 20, "unit", True), (30000, 768, 17, 5, "mixed", True), (40000, 192, 60, 10, "unit", True), (90000, 256, 200, 10, "unit", True),
     (16512, 256, 2, 3, "unit", True), (16640, 1024, 128, 100, "mixed", True),
+    # many hits per wave without any list overflowing (256 queries x ~3000 rows above the threshold over ~600 waves): the per-wave LDS hit
+    # lists of the persistent pass fill up and are flushed in mid-pass
+    (20000, 256, 256, 1000, "unit", True), (24000, 512, 128, 2000, "mixed", True),
 ])
 def test_score_free_filter_equals_score_matrix_filter_bitwise(N, D, Q, k, scale, shadow, search_mode):
     """Both filters end in the same exact rescoring of a superset of the exact top-k: same ids, same score bits."""
