@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(64 * WV, QSB ? (QT > 8 ? 2 : 3) : ((NST * (16 
 k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
                        float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate,
                        int bmode, int ss, int unit, const float* __restrict__ thr, unsigned long long* __restrict__ cand,
-                       unsigned int* __restrict__ cnt) {
+                       unsigned int* __restrict__ cnt, int64_t nbx) {
   static_assert(!XB || NP == 1, "the bf16 shadow is a single-product filter");
   static_assert(!EMIT || NP == 1, "the emitting epilogue belongs to the single-product filter");
   const float* X = (const float*)Xv;
@@ -295,14 +295,18 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
   if (gate != nullptr && *gate == 0) return;     // fallback launch of the bounded search: nothing overflowed
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int64_t blk = blockIdx.x;                        // sample units of `unit` consecutive blocks, every ss-th unit is in the sample
-  if (bmode == 1) { const int u = blockIdx.x / unit; blk = (int64_t)u * ss * unit + (blockIdx.x - u * unit); }
+  // nbx = blocks of the launch; a grid smaller than that walks them (the gated fallback launch of the bounded search is capped: its
+  // workgroups return at once when nothing overflowed, and 78 k of them over a 10M-row shard still cost 19 us)
+  for (int64_t bx = blockIdx.x; bx < nbx; bx += gridDim.x) {
+  if (bx != (int64_t)blockIdx.x) __syncthreads();   // the previous block's LDS is dead
+  int64_t blk = bx;                                // sample units of `unit` consecutive blocks, every ss-th unit is in the sample
+  if (bmode == 1) { const int u = (int)(bx / unit); blk = (int64_t)u * ss * unit + (bx - (int64_t)u * unit); }
   else if (bmode == 2) {
-    const int u = blockIdx.x / unit, g = u / (ss - 1);
-    blk = ((int64_t)g * ss + 1 + (u - g * (ss - 1))) * unit + (blockIdx.x - u * unit);
+    const int u = (int)(bx / unit), g = u / (ss - 1);
+    blk = ((int64_t)g * ss + 1 + (u - g * (ss - 1))) * unit + (bx - (int64_t)u * unit);
   }
   const int64_t n0 = blk * RB;                     // corpus rows of this workgroup
-  const int64_t n0s = (int64_t)blockIdx.x * RB;    // where its scores go (compact in sample mode)
+  const int64_t n0s = bx * RB;    // where its scores go (compact in sample mode)
 
   const char* px[2 * RT];                        // byte pointers: both element types move 128 B per row per k-slice
 #pragma unroll
@@ -471,7 +475,7 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
               ++pp;
             }
         }
-    return;
+    continue;
   }
   __syncthreads();   // the k loop's last LDS reads are done before the epilogue reuses the buffer
 
@@ -504,7 +508,7 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
         float mx = -FLT_MAX;
 #pragma unroll
         for (int w = 0; w < WPG; ++w) mx = fmaxf(mx, wmax[(grp * WPG + w) * (QT * 16) + qi]);
-        blkmax[(int64_t)qi * nblk_ld + (int64_t)blockIdx.x * (RB / 128) + grp] = mx;
+        blkmax[(int64_t)qi * nblk_ld + bx * (RB / 128) + grp] = mx;
       }
     }
   }
@@ -535,6 +539,7 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
         *(f32x4*)(scores + (int64_t)qi * ld + n0s + c * 4) = *(const f32x4*)(smem + ql * SEG + c * 16);
     }
   }
+  }   // blocks of this workgroup
 }
 
 
@@ -1088,7 +1093,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
       }
 #define LRX_SB_(QQ, QSB_, EM_)                                                                                                                         \
     hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPX_RT, SPX_NST, SPX_WV, true, QSB_, EM_>), dim3((unsigned)nwg), dim3(64 * SPX_WV), 0, s, Xb, n_rows, \
-                       ldxb, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);
+                       ldxb, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int64_t)nwg);
 #define LRX_SB(QQ, QSB_)                  \
   case QQ:                                \
     if (emit) { LRX_SB_(QQ, QSB_, true) } \
@@ -1106,6 +1111,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
     if (qsplit != nullptr && qt >= SPLIT_MIN_QT) {
       const int rb = planes == 3 ? 128 : 16 * SPF_RT * SPF_WV;
       const int64_t nwg = fm.nblocks >= 0 ? fm.nblocks : ld_full / rb;
+      const int64_t gated_cap = 8 * (int64_t)lrx_cu_count();   // grid of a gated (normally idle) six-product launch
       if (nwg == 0) continue;
       if (fm.bmode != 2 && !fm.planes_ready) {
         int threads = (dim / 32) * qt * 64;
@@ -1113,10 +1119,10 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
       }
 #define LRX_SF_(QQ, EM_)                                                                                                                          \
     hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPF_RT, SPF_NST, SPF_WV, false, false, EM_>), dim3((unsigned)nwg), dim3(64 * SPF_WV), 0, s, X, n_rows, ldx, \
-                       dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);
+                       dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int64_t)nwg);
 #define LRX_SS(QQ)                                                                                                                              \
   case QQ:                                                                                                                                      \
-    if (planes == 3) hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 3, 2, 2, 4>), dim3((unsigned)nwg), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, 0, 1, 1, (const float*)nullptr, (unsigned long long*)nullptr, (unsigned int*)nullptr); \
+    if (planes == 3) hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 3, 2, 2, 4>), dim3((unsigned)(gate != nullptr && nwg > gated_cap ? gated_cap : nwg)), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, 0, 1, 1, (const float*)nullptr, (unsigned long long*)nullptr, (unsigned int*)nullptr, (int64_t)nwg); \
     else if (emit) { LRX_SF_(QQ, true) }                                                                                                        \
     else { LRX_SF_(QQ, false) }                                                                                                                 \
     break;

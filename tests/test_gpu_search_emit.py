@@ -163,6 +163,12 @@ def test_candidate_list_overflow_falls_back_per_query(search_mode):
     _, I2 = idx2.search(q2, 8)
     _, I2_o = O.flat_ip_topk(q2, Xd, 8)
     np.testing.assert_array_equal(I2.cpu().numpy(), I2_o)
+    # a shard with more 128-row blocks than the grid cap of the gated six-product launch (8 x CUs): its workgroups walk several blocks
+    Xw = np.repeat(X[:50], 6000, axis=0)                         # 300 000 rows = 2344 blocks, every vector 6000 times
+    idxw = _index(Xw, pieces=3)
+    _, Iw = idxw.search(q, 8)
+    _, Iw_o = O.flat_ip_topk(q, Xw, 8)
+    np.testing.assert_array_equal(Iw.cpu().numpy(), Iw_o)
     q3 = O.l2_normalize(rng.standard_normal((230, D)).astype(np.float32))       # both groups on the six-product kernel
     _, I3 = idx2.search(q3, 8)
     _, I3_o = O.flat_ip_topk(q3, Xd, 8)
