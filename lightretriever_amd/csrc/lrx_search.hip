@@ -475,7 +475,7 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
               ++pp;
             }
         }
-    continue;
+    return;          // (EMIT implies NP == 1: one block per workgroup)
   }
   __syncthreads();   // the k loop's last LDS reads are done before the epilogue reuses the buffer
 
@@ -539,6 +539,8 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
         *(f32x4*)(scores + (int64_t)qi * ld + n0s + c * 4) = *(const f32x4*)(smem + ql * SEG + c * 16);
     }
   }
+  if constexpr (NP != 3) break;   // only the six-product (fallback) instantiations are ever launched with fewer workgroups than blocks;
+                                  // as a real loop the single-product kernels went from 60 to 107 VGPRs (two workgroups per CU instead of three)
   }   // blocks of this workgroup
 }
 
@@ -1821,7 +1823,7 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t ints_before_cnt(int nq) { return ((size_t)nq + 1 + 63) & ~(size_t)63; }
 
-static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow, bool contiguous_shadow = true) {
+static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow, bool contiguous_shadow = true, bool tiled_shadow = true) {
   BoundedPlan p;
   memset(&p, 0, sizeof(p));
   // more than 128 queries over a bf16 shadow: the main pass is the GEMM kernel on 256-row tiles (the sample then moves in 256-row units)
@@ -1840,7 +1842,9 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   if (!feasible) p.gemm = false;
   // (until the register-streaming kernels and the group-maxima threshold step, batches of Q < max(2, D / 256) queries were faster on the
   // score-matrix filter; now the score-free chain is as fast at Q = 1 over 1M x 2048 (0.69 ms both) and faster at 10M x 256 (0.85 vs 1.03 ms))
-  p.emit = feasible && g_search_mode != 1 && (g_search_mode >= 2 || n_rows >= 16384);
+  // A row-major shadow (LDS-staged filter kernels) keeps the old crossover: Q = 1 over 1M x 2048 0.79-0.82 ms that way, 0.87 score-free.
+  const bool small_batch = !(shadow && tiled_shadow) && !(nq >= 2 && 256 * (int64_t)nq >= dim);
+  p.emit = feasible && g_search_mode != 1 && (g_search_mode >= 2 || (n_rows >= 16384 && !small_batch));
   p.ss = ss;
   p.nsamp_wg = nsamp;
   p.nmain_wg = nwg - nsamp;
@@ -1869,10 +1873,11 @@ extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t di
     const int sizes[2] = {nq < chunk ? nq : chunk, nq > chunk ? nq % chunk : 0};
     for (int i = 0; i < 2; ++i)
       if (sizes[i] > 0) {
-        for (int contiguous = 0; contiguous < 2; ++contiguous) {       // (a strided row-major shadow keeps the 128-row main pass: other sample geometry)
-          const size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, contiguous != 0).total;
-          need = t > need ? t : need;
-        }
+        for (int contiguous = 0; contiguous < 2; ++contiguous)         // (a strided row-major shadow keeps the 128-row main pass: other sample geometry)
+          for (int tiled = 0; tiled < 2; ++tiled) {                    // (a row-major shadow keeps the score-matrix filter for very small batches)
+            const size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, contiguous != 0, tiled != 0).total;
+            need = t > need ? t : need;
+          }
       }
   }
   return need + 512;
@@ -1905,7 +1910,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
   const int chunk = shadow ? 256 : 128;
   for (int q0 = 0; q0 < n_queries; q0 += chunk) {
     const int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
-    const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, ldx_bf16 == dim || ldx_bf16 == 0);
+    const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, ldx_bf16 == dim || ldx_bf16 == 0, ldx_bf16 == 0);
     if (p.total > workspace_bytes) {      // (cannot happen with a workspace sized by lrx_flat_ip_bounded_workspace_bytes under the same filter mode)
       lrx_set_error("flat_ip_search_bounded: chunk of %d queries needs %zu B of workspace, %zu given", nq, p.total, workspace_bytes);
       return LRX_ERR_WORKSPACE;
