@@ -984,6 +984,176 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
   }
 }
 
+// The sample pass of a LARGE shard as persistent workgroups (same walk as k_filter_xreg_emit, score stores instead of hit lists): with one
+// or two blocks per workgroup a 10M x 256 shard launched ~2000 workgroups that each fetched the whole q and paid their own load latency
+// (120 us for 5 % of the rows).  Here the q ring and the X ring run across block boundaries (D <= 256: q is fetched once per workgroup),
+// the scores of a block leave through a staging region of their own, and the producer wave takes part in the 2 RT barriers of every
+// block step's epilogue.  QT <= 8, D / 64 a multiple of PF.
+template <int QT, int PF, int RT>
+__global__ void __launch_bounds__(576, 3)
+k_filter_xreg_store(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, float* __restrict__ scores, int64_t ld,
+                    float* __restrict__ gmax, int nblk_ld, int nblocks, int bmode, int ss, int unit) {
+  static_assert(QT <= 8, "staging sized for eight query tiles");
+  constexpr int WV = 8, RB = 128;
+  constexpr int QINST = 2 * QT;
+  constexpr int QBYTES = QINST * 1024;
+  constexpr int QB = 4;
+  static_assert((QB - 2) * QINST <= 63, "vmcnt immediate");
+  constexpr int SEG = RB * 4 + 16;                 // staging: one query's 128 scores + pad
+  __shared__ __attribute__((aligned(1024))) char smem[QB * QBYTES + QT * 16 * SEG];
+  char* stg = smem + QB * QBYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbw = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // this workgroup's blocks: blockIdx.x + i * gridDim.x
+  const int nmine = (nbw + RT - 1) / RT;                                               // steps of RT blocks
+  const int nk = D / 64;
+  const int64_t total = (int64_t)nmine * nk;
+  const bool qres = nk <= QB;
+
+  if (wave == WV) {
+    // ---- producer: the q slices, cyclically, QB-1 steps ahead; joins the barriers of the block epilogues
+    const __bf16* pq = qs + (int64_t)lane * 8;
+    int hs = 0, hb = 0;
+    auto stage_next = [&]() {
+      char* sQ = smem + hb * QBYTES;
+#pragma unroll
+      for (int j = 0; j < QINST; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(pq + ((int64_t)hs * QINST + j) * 512), (lptr_t)(sQ + j * 1024), 16, 0, 0);
+      hs = hs + 1 == nk ? 0 : hs + 1;
+      hb = hb + 1 == QB ? 0 : hb + 1;
+    };
+    if (qres) {
+      for (int p = 0; p < nk; ++p) stage_next();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+#pragma unroll
+      for (int p = 0; p < QB - 1; ++p)
+        if (p < total) stage_next();
+    }
+    int64_t g = 0;
+    for (int j = 0; j < nmine; ++j) {
+      if (!qres)
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+          if (g + QB - 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QB - 2) * QINST) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (g + QB - 1 < total) stage_next();
+        }
+#pragma unroll
+      for (int a = 0; a < RT; ++a)
+        if (j * RT + a < nbw) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+    }
+    return;
+  }
+
+  // ---- consumers
+  const int fi = lane & 15, fq = lane >> 4;
+  auto blk_of = [&](int i) -> int {                // launch index -> 128-row block
+    if (bmode == 1) { const unsigned int u = (unsigned int)i / (unsigned int)unit; return (int)(u * ss * unit + ((unsigned int)i - u * unit)); }
+    if (bmode != 2) return i;
+    const unsigned int u = (unsigned int)i / (unsigned int)unit, g = u / (unsigned int)(ss - 1);
+    return (int)((g * ss + 1 + (u - g * (ss - 1))) * unit + ((unsigned int)i - u * unit));
+  };
+  const int last_blk = (int)((N - 1) >> 7);
+  auto li_of = [&](int j, int a) -> int { return (int)blockIdx.x + min(j * RT + a, nbw - 1) * (int)gridDim.x; };
+  auto base_of = [&](int i) -> const bf16x8* {
+    const int b = min(blk_of(i), last_blk);
+    return (const bf16x8*)(Xb + ((int64_t)b * (D / 64)) * 8192 + wave * 1024) + lane;
+  };
+  f32x4 acc[RT][QT];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int pf_j = 0, pf_kt = 0;
+  const bf16x8* pfp[RT];
+#pragma unroll
+  for (int a = 0; a < RT; ++a) pfp[a] = base_of(li_of(0, a));
+  bf16x8 xf[PF][RT][2];
+  auto fetch = [&](int slot) {
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+      xf[slot][a][0] = __builtin_nontemporal_load(pfp[a]);
+      xf[slot][a][1] = __builtin_nontemporal_load(pfp[a] + 64);
+    }
+    if (++pf_kt == nk) {
+      pf_kt = 0;
+      pf_j = min(pf_j + 1, nmine - 1);
+#pragma unroll
+      for (int a = 0; a < RT; ++a) pfp[a] = base_of(li_of(pf_j, a));
+    } else {
+#pragma unroll
+      for (int a = 0; a < RT; ++a) pfp[a] += 1024;
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < PF - 1; ++p) {
+    fetch(p);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  int qb = 0;
+  const int qper = qres ? nk : QB;
+  if (qres) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                  // the whole q has landed
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int j = 0; j < nmine; ++j) {
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        fetch((u + PF - 1) % PF);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!qres) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sQ = smem + qb * QBYTES + lane * 16;
+        qb = qb + 1 == qper ? 0 : qb + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int b = 0; b < QT; ++b) {
+            const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
+#pragma unroll
+            for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][a][ks], qf, acc[a][b], 0, 0, 0);
+          }
+      }
+    }
+    // ---- block epilogue: the wave groups' maxima straight from registers, the scores through the staging region
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+      if (j * RT + a >= nbw) break;                // (uniform over the workgroup, producer included)
+      const int li = li_of(j, a);
+      const int64_t n0 = (int64_t)blk_of(li) * RB, n = n0 + wave * 16 + fq * 4;
+#pragma unroll
+      for (int b = 0; b < QT; ++b) {
+        float mx = -FLT_MAX;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= N) acc[a][b][e] = -FLT_MAX;
+          mx = fmaxf(mx, acc[a][b][e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const int qi = b * 16 + fi;
+        if (fq == 0 && qi < nq) gmax[(int64_t)qi * (8 * (int64_t)nblk_ld) + (int64_t)li * 8 + wave] = mx;
+      }
+      __builtin_amdgcn_s_barrier();                // the previous block's scores have left the staging region
+#pragma unroll
+      for (int b = 0; b < QT; ++b) {
+        *(f32x4*)(stg + (b * 16 + fi) * SEG + (wave * 16 + fq * 4) * 4) = acc[a][b];
+        acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                // staged
+      for (int idx = tid; idx < QT * 16 * (RB / 4); idx += 512) {
+        const int ql = idx / (RB / 4), c = idx % (RB / 4);
+        if (ql < nq) __builtin_nontemporal_store(*(const f32x4*)(stg + ql * SEG + c * 16), (f32x4*)(scores + (int64_t)ql * ld + (int64_t)li * RB + c * 4));
+      }
+    }
+  }
+}
+
 extern "C" int64_t lrx_flat_ip_score_ld(int64_t n_rows) { return lrx_cdiv(n_rows > 0 ? n_rows : 1, S_ROWS) * S_ROWS; }
 
 #define SPLIT_MIN_QT 3   // Q > 32 -> split-bf16 kernel (fp32-MFMA-bound otherwise); Q <= 32 stays on the exact-fp32 kernel (HBM-bound)
@@ -1065,6 +1235,9 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
         const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31);
         const int n_cu = lrx_cu_count();
         const bool two_blocks = !emit && fm.bmode == 1 && nwg < (1ll << 31);
+        // sample pass of a large shard (more than two block pairs per CU): persistent workgroups
+        const bool persistent_store = two_blocks && fm.group_max && gate == nullptr && sp != nullptr && bp != nullptr && qt <= 8 && (dim / 64) % XPF == 0 &&
+                                      (nwg + 1) / 2 > 2 * (int64_t)n_cu;
 #define LRX_XP(QQ, RT_)                                                                                                                     \
   {                                                                                                                                         \
     const int64_t groups = (nwg + RT_ - 1) / RT_;                                                                                           \
@@ -1077,10 +1250,14 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
 #define LRX_XN2(QQ)   /* sample pass: two blocks per workgroup */                                                                           \
   hipLaunchKernelGGL((k_filter_xreg<QQ, XPF, false, 2>), dim3((unsigned)((nwg + 1) / 2)), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
                      nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg, fm.group_max ? 1 : 0);
+#define LRX_XS(QQ)   /* sample pass of a large shard: persistent, two blocks at a time (one from seven query tiles on: registers) */                                                  \
+  hipLaunchKernelGGL((k_filter_xreg_store<(QQ), XPF, ((QQ) <= 6 ? 2 : 1)>), dim3((unsigned)n_cu), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
+                     nblk_ld, (int)nwg, fm.bmode, fm.ss, fm.unit);
 #define LRX_XR(QQ, RT_)                                  \
   case QQ:                                               \
     if (persistent) LRX_XP(QQ, RT_)                      \
     else if (emit) { LRX_XN(QQ, true) }                  \
+    else if (persistent_store && QQ <= 8) { LRX_XS(QQ <= 8 ? QQ : 1) } \
     else if (two_blocks && QQ <= 8) { LRX_XN2(QQ <= 8 ? QQ : 1) } \
     else { LRX_XN(QQ, false) }                           \
     break;
@@ -1089,6 +1266,7 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
 #undef LRX_XR
 #undef LRX_XN
 #undef LRX_XN2
+#undef LRX_XS
 #undef LRX_XP
         LRX_LAUNCH_CHECK();
         continue;

@@ -44,6 +44,9 @@ def _index(X, shadow=True, id_base=0, pieces=2):
     # many hits per wave without any list overflowing (256 queries x ~3000 rows above the threshold over ~600 waves): the per-wave LDS hit
     # lists of the persistent pass fill up and are flushed in mid-pass
     (20000, 256, 256, 1000, "unit", True), (24000, 512, 128, 2000, "mixed", True),
+    # more than two sample block pairs per CU: the sample pass runs as persistent workgroups (k_filter_xreg_store), with the whole q
+    # resident in LDS (D = 256) and with a cycling q ring (D = 512), two blocks at a time and one (seven query tiles)
+    (300000, 256, 20, 1000, "unit", True), (300001, 512, 100, 1000, "mixed", True),
 ])
 def test_score_free_filter_equals_score_matrix_filter_bitwise(N, D, Q, k, scale, shadow, search_mode):
     """Both filters end in the same exact rescoring of a superset of the exact top-k: same ids, same score bits."""
