@@ -47,6 +47,7 @@ def _index(X, shadow=True, id_base=0, pieces=2):
     # more than two sample block pairs per CU: the sample pass runs as persistent workgroups (k_filter_xreg_store), with the whole q
     # resident in LDS (D = 256) and with a cycling q ring (D = 512), two blocks at a time and one (seven query tiles)
     (300000, 256, 20, 1000, "unit", True), (300001, 512, 100, 1000, "mixed", True),
+    (120000, 256, 30, 1, "unit", True), (200000, 128, 9, 3, "mixed", True),      # samples of >= 8 k blocks: threshold from the block maxima
 ])
 def test_score_free_filter_equals_score_matrix_filter_bitwise(N, D, Q, k, scale, shadow, search_mode):
     """Both filters end in the same exact rescoring of a superset of the exact top-k: same ids, same score bits."""
