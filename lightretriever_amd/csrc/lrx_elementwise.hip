@@ -334,7 +334,10 @@ extern "C" int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, 
 // thread has all its column groups' loads of several ids in flight (the scalar version re-read the ids and chained one dependent
 // 4-byte load per id per column: 88 us for 100 bags x ~20 ids at D = 2048, 8 % of a search pass).  Per column the rows are still
 // added in id order -> the same fp32 sums bit for bit.
-template <bool EB_V4>
+// EB_V4 = float4 column groups per thread (1, 2, 4, 8; 0 = scalar path).  The rows of a bag are summed in id order (the bits of
+// torch.nn.EmbeddingBag), but their loads do not depend on each other: 8 / EB_V4 rows are requested before the first is added (one row
+// at a time, a 20-token bag over H = 2048 took 21 us of serial load latency).
+template <int EB_V4>
 __global__ void __launch_bounds__(256) k_embedding_bag(const float* __restrict__ table, int vocab, int H, const int64_t* __restrict__ ids,
                                                        int64_t n_ids, const int64_t* __restrict__ offsets, int n_bags, int64_t pad,
                                                        float* __restrict__ out, int64_t out_stride, int out_dim, int normalize) {
@@ -346,7 +349,8 @@ __global__ void __launch_bounds__(256) k_embedding_bag(const float* __restrict__
   float n2 = 0.f;
   float* o = out + (int64_t)b * out_stride;
   if (EB_V4) {
-    constexpr int MAXG = 8;                                  // column groups per thread: out_dim <= 8192
+    constexpr int MAXG = EB_V4 > 0 ? EB_V4 : 1;              // column groups per thread: out_dim <= 1024 * MAXG
+    constexpr int UR = 8 / MAXG;                             // rows in flight
     const int ng = out_dim >> 2;                             // float4 groups in the output row
     f32x4 acc[MAXG];
 #pragma unroll
@@ -366,18 +370,28 @@ __global__ void __launch_bounds__(256) k_embedding_bag(const float* __restrict__
       if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(bal);
       __syncthreads();
       cnt += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-      for (int i = 0; i < nc; ++i) {
-        const int row = s_row[i];
-        if (row < 0) continue;
-        const f32x4* tr = (const f32x4*)(table + (int64_t)row * H);
+      for (int i0 = 0; i0 < nc; i0 += UR) {
+        int rows[UR];
+        f32x4 v[UR][MAXG];
 #pragma unroll
-        for (int j = 0; j < MAXG; ++j) {
-          const int g = threadIdx.x + 256 * j;
-          if (g < ng) {
-            const f32x4 v = tr[g];
-            acc[j][0] += v[0]; acc[j][1] += v[1]; acc[j][2] += v[2]; acc[j][3] += v[3];
+        for (int u = 0; u < UR; ++u) {
+          rows[u] = i0 + u < nc ? s_row[i0 + u] : -1;
+          const f32x4* tr = (const f32x4*)(table + (int64_t)(rows[u] < 0 ? 0 : rows[u]) * H);
+#pragma unroll
+          for (int j = 0; j < MAXG; ++j) {
+            const int g = threadIdx.x + 256 * j;
+            v[u][j] = (rows[u] >= 0 && g < ng) ? tr[g] : f32x4{0.f, 0.f, 0.f, 0.f};
           }
         }
+#pragma unroll
+        for (int u = 0; u < UR; ++u)
+          if (rows[u] >= 0) {                                  // (uniform; a skipped row adds nothing, not even + 0)
+#pragma unroll
+            for (int j = 0; j < MAXG; ++j) {
+              const int g = threadIdx.x + 256 * j;
+              if (g < ng) { acc[j][0] += v[u][j][0]; acc[j][1] += v[u][j][1]; acc[j][2] += v[u][j][2]; acc[j][3] += v[u][j][3]; }
+            }
+          }
       }
     }
 #pragma unroll
@@ -429,12 +443,15 @@ extern "C" int lrx_embedding_bag_mean(const float* table, int32_t vocab, int32_t
   // 16-B path: rows of the table and of the output 16-B aligned, <= 8 column groups per thread
   const bool v4 = hidden % 4 == 0 && out_dim % 4 == 0 && out_row_stride % 4 == 0 && out_dim <= 8192 && ((uintptr_t)table & 15) == 0 &&
                   ((uintptr_t)out & 15) == 0;
-  if (v4)
-    hipLaunchKernelGGL(k_embedding_bag<true>, dim3(n_bags), dim3(256), 0, (hipStream_t)stream, table, vocab, hidden, ids, n_ids, offsets, n_bags,
-                       padding_idx, out, out_row_stride, out_dim, normalize);
-  else
-    hipLaunchKernelGGL(k_embedding_bag<false>, dim3(n_bags), dim3(256), 0, (hipStream_t)stream, table, vocab, hidden, ids, n_ids, offsets, n_bags,
-                       padding_idx, out, out_row_stride, out_dim, normalize);
+#define LRX_EB(NJ)                                                                                                                          \
+  hipLaunchKernelGGL(k_embedding_bag<NJ>, dim3(n_bags), dim3(256), 0, (hipStream_t)stream, table, vocab, hidden, ids, n_ids, offsets, n_bags, \
+                     padding_idx, out, out_row_stride, out_dim, normalize)
+  if (!v4) LRX_EB(0);
+  else if (out_dim <= 1024) LRX_EB(1);
+  else if (out_dim <= 2048) LRX_EB(2);
+  else if (out_dim <= 4096) LRX_EB(4);
+  else LRX_EB(8);
+#undef LRX_EB
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
