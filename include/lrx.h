@@ -301,8 +301,9 @@ int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim,
  * >= T' - 2 eps (a per-query candidate list, ~1e-3 of the rows); the rows within 2 eps of the list's k-th score are rescored
  * exactly from the fp32 rows (fp64 accumulation, one rounding) and sorted.  Queries whose list or band overflows (near-duplicate
  * corpora) are redone by the six-product path (gated on a device flag, no host sync).  Scores returned are the exactly rescored
- * ones.  Bounds smaller than the true values void the guarantee.  Very small query batches (Q < max(2, D / 256)) and shards below 16 Ki
- * rows use a score-matrix filter instead (two launches less on the critical path); the result is the same bit for bit.
+ * ones.  Bounds smaller than the true values void the guarantee.  Shards below 16 Ki rows (and, without a tiled shadow, very small
+ * query batches: Q < max(2, D / 256)) use a score-matrix filter instead (two launches less on the critical path); the result is the
+ * same bit for bit.
  * X_bf16 (optional, NULL = convert on the fly): a bf16 copy of X (round-to-nearest-even per element; row-major with row stride
  * ldx_bf16 elements, multiple of 8, or tiled with ldx_bf16 = 0 -- layouts at lrx_shard_commit_rows; dim % 64 == 0) kept by the caller
  * next to the fp32 rows: the filter pass then streams 2 instead of 4
