@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Stress of the persistent filter kernels on shards with many blocks per workgroup: random query counts / k, the score-free chain against the
+score-matrix filter bit for bit (both end in the same exact rescoring).  usage: python tools/exp/search_stress.py [rounds] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from lightretriever_amd import FlatIPIndex
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+fails = 0
+for (N, D) in [(1_000_000, 256), (600_000, 512), (3_000_001, 256), (400_000, 1024)]:
+    g = torch.Generator(device="cuda").manual_seed(N + D)
+    idx = FlatIPIndex(D, capacity=N)
+    slot = idx.append_slot(N)
+    for s in range(0, N, 1 << 18):
+        e = min(s + (1 << 18), N)
+        slot[s:e] = torch.nn.functional.normalize(torch.randn(e - s, D, generator=g, device="cuda"), dim=-1) * (0.5 + torch.rand(e - s, 1, generator=g, device="cuda"))
+    idx.commit(N)
+    for r in range(rounds):
+        Q = int(rng.choice([1, 2, 7, 16, 33, 64, 100, 113, 128, 129, 200, 256, 300])); k = int(rng.choice([1, 10, 100, 500, 1000, 2048]))
+        q = torch.randn(Q, D, generator=g, device="cuda")
+        idx.lib.lrx_search_set_mode(int(rng.choice([0, 2, 3])))
+        D2, I2 = idx.search(q, k)
+        idx.lib.lrx_search_set_mode(1)
+        D1, I1 = idx.search(q, k)
+        idx.lib.lrx_search_set_mode(0)
+        if not (torch.equal(D1, D2) and torch.equal(I1, I2)):
+            fails += 1
+            print("DIFFERENT", (N, D, Q, k), flush=True)
+    print((N, D), "done", flush=True)
+    del idx
+print("stress failures", fails)
+sys.exit(1 if fails else 0)
