@@ -1606,21 +1606,26 @@ k_topk_select_rescore(const float* __restrict__ scores, int64_t ld, int64_t N, i
   const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
   for (int i = keff + tid; i < k; i += SEL_THREADS) { os[i] = -FLT_MAX; oi[i] = -1; }
   if (keff == 0) return;
-  select_topk_sorted(row, N, keff, blkmax ? blkmax + (int64_t)blockIdx.x * nblk_ld : nullptr, nblk, sh);   // sh.cand[0..keff): the selection
-  unsigned long long* s_c = sh.eqs;                          // SEL_EQCAP == SEL_MAXK entries, idle after the select
-  static_assert(SEL_EQCAP >= SEL_MAXK, "rescoring buffer");
+  // The matrix scores carry fp32 accumulation noise (~1e-6 relative): at a near-tie between the k-th and the (k+1)-th row the selection by
+  // them can pick the other row.  So SEL_MARGIN more rows are selected, all of them rescored exactly, and the best keff of those returned
+  // (seen in a stress run at k = 2048: exact scores 2.9917817 vs 2.9917798, the lower one returned).
+  constexpr int SEL_MARGIN = 64;
+  static_assert(SEL_MAXK + SEL_MARGIN <= SEL_CAND, "selection with margin");
+  const int ksel = (int)(N < (int64_t)(keff + SEL_MARGIN) ? N : (int64_t)(keff + SEL_MARGIN));
+  select_topk_sorted(row, N, ksel, blkmax ? blkmax + (int64_t)blockIdx.x * nblk_ld : nullptr, nblk, sh);   // sh.cand[0..ksel): the selection
+  unsigned long long* s_c = sh.cand;                         // rescored in place: entry c is read and written by the same half-wave
   const float* qrow = q + (int64_t)blockIdx.x * D;
-  for (int c0 = wave * 2; c0 < keff; c0 += 32) {             // two rows per wave (one per half-wave)
-    const int c = min(c0 + (lane >> 5), keff - 1);
+  for (int c0 = wave * 2; c0 < ksel; c0 += 32) {             // two rows per wave (one per half-wave)
+    const int c = min(c0 + (lane >> 5), ksel - 1);
     int64_t n = sel_row(sh.cand[c]);
     n = n < 0 ? 0 : (n >= N ? N - 1 : n);
     const float sc = exact_dot(X + n * ldx, qrow, D, lane);
-    if ((lane & 31) == 0 && c0 + (lane >> 5) < keff) s_c[c] = sel_pack(f2key(sc), n);
+    if ((lane & 31) == 0 && c0 + (lane >> 5) < ksel) s_c[c] = sel_pack(f2key(sc), n);
   }
   __syncthreads();
   int P = 1;
-  while (P < keff) P <<= 1;
-  for (int i = keff + tid; i < P; i += SEL_THREADS) s_c[i] = 0ull;
+  while (P < ksel) P <<= 1;
+  for (int i = ksel + tid; i < P; i += SEL_THREADS) s_c[i] = 0ull;
   bitonic_sort_desc(s_c, P);
   for (int i = tid; i < keff; i += SEL_THREADS) {
     const unsigned long long c = s_c[i];
