@@ -9,7 +9,7 @@ from lightretriever_amd import FlatIPIndex
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 fails = 0
-for (N, D) in [(1_000_000, 256), (600_000, 512), (3_000_001, 256), (400_000, 1024)]:
+for (N, D) in [(1_000_000, 256), (600_000, 512), (3_000_001, 256), (400_000, 1024), (500_000, 2048), (250_000, 4096), (700_000, 192), (900_000, 64)]:
     g = torch.Generator(device="cuda").manual_seed(N + D)
     idx = FlatIPIndex(D, capacity=N)
     slot = idx.append_slot(N)
