@@ -76,6 +76,27 @@ def main():
             qi, ri = np.nonzero(mism)
             ok = np.abs(np.einsum("ij,ij->i", qq[qi], X[Ig[qi, ri]]) - Do[qi, ri]).max() < 5e-5
         check("search", ok, (N_, D, Q, kk, float(mism.mean())))
+    # ---- EmbeddingBag lookup (bits of the sequential fp32 sum) and the shard merge
+    from lightretriever_amd.index import merge_topk
+    for r in range(a.rounds):
+        V = int(rng.integers(5, 400)); H = 4 * int(rng.integers(1, 600)) if rng.random() < 0.8 else int(rng.integers(1, 300)); nb = int(rng.integers(1, 40))
+        table = rng.standard_normal((V, H)).astype(np.float32)
+        lens = rng.integers(0, 300 if rng.random() < 0.1 else 24, size=nb)
+        ids = rng.integers(0, V, size=int(lens.sum())).astype(np.int64)
+        pad = int(rng.integers(0, V)) if rng.random() < 0.5 else None
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        od = H if rng.random() < 0.6 else max(1, (H // 2) & ~3) if H >= 8 else H
+        got = ops.embedding_bag_mean(torch.from_numpy(table).cuda(), torch.from_numpy(ids).cuda(), torch.from_numpy(offs).cuda(), padding_idx=pad, out_dim=od).cpu().numpy()
+        want = O.embedding_bag_mean(table, ids, offs, pad)[:, :od]
+        check("embedding_bag", np.array_equal(got, want), (V, H, nb, od, pad))
+        R, Qm, km = int(rng.integers(1, 9)), int(rng.integers(1, 20)), int(rng.integers(1, 300))
+        Dp = rng.standard_normal((R, Qm, km)).astype(np.float32); Dp[rng.random(Dp.shape) < 0.1] = np.float32(0.25)      # ties
+        Ip = np.stack([np.stack([rng.choice(100000, size=km, replace=False) for _ in range(Qm)]) for _ in range(R)]).astype(np.int64)
+        Ip[rng.random(Ip.shape) < 0.05] = -1
+        Dp = -np.sort(-Dp, axis=2)
+        gD, gI = merge_topk(torch.from_numpy(Dp).cuda(), torch.from_numpy(Ip).cuda())
+        wD, wI = O.merge_topk(list(Dp), list(Ip), km)
+        check("merge_topk", np.array_equal(gI.cpu().numpy(), wI) and np.array_equal(gD.cpu().numpy()[wI >= 0], wD[wI >= 0]), (R, Qm, km))
     # ---- encoder end to end vs the oracle (small random architectures)
     from dataclasses import asdict
     from lightretriever_amd import EncoderConfig, LrxEncoder
