@@ -3,7 +3,8 @@
 // the power cap?  Both shapes as MOCK kernels with the instruction mix of the real 256 x 256 x 64 K loop -- per K-tile 64 KiB of LDS-DMA
 // from an L2-resident source into a 2-stage 128-KiB ring, the fragment reads of random bf16 data, 512 MFMA 16x16x32 per workgroup, the
 // barriers and counted vmcnt waits of a stage hand-over -- but no tile addressing, no epilogue, garbage results: only the rate matters.
-// It is an optimistic bound for the 4-wave shape (the compiler is free to interleave reads and MFMAs in straight-line code).
+// Compiler-scheduled straight-line code, two barriers per K-tile: not the product's staggered 4-phase schedule (which is ~15 % faster than the
+// 8-wave mock) -- the question is how far apart the two SHAPES are.
 // build: hipcc --offload-arch=gfx950 -O3 tools/exp/gemm_mock.hip -o tools/exp/gemm_mock
 #include <hip/hip_runtime.h>
 #include <stdio.h>
