@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mrl-dim", type=int, default=0, help="index / embedding dimension D (dense_shrink_dim, e.g. 256 for BASELINE config 5); 0 = hidden size")
     ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the extra single-GPU legs (BASELINE configs 2-4, 8-way shard, top_k = 1000)")
     ap.add_argument("--no-sparse", action="store_true", help="skip the dense+sparse document-vector leg (SURVEY 8f N2)")
     ap.add_argument("--ragged", action="store_true",
                     help="document lengths ~ clip(lognormal(5.3, 0.6), 16, seq_len), sorted longest first (mirrors hybrid_search.py:273-276) "
@@ -150,11 +151,27 @@ def cpu_baseline(cfg, seq_len, topk, dim):
     }
 
 
+PMC_SUMMARY = os.environ.get("LRX_PMC_SUMMARY", "profiles/r02_pmc_summary.json")   # offline rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+PMC_MFMA = os.environ.get("LRX_PMC_MFMA", "profiles/r02_pmc_mfma.json")
+
+
+def git_blob_sha(rel_path):
+    """git's blob id of a committed file, computed from its bytes (sha1 of "blob <len>\\0" + content): ties an offline number quoted in
+    the JSON line to the exact profile file it was read from (`git cat-file -p <id>` shows it)."""
+    import hashlib
+    try:
+        data = open(os.path.join(ROOT, rel_path), "rb").read()
+    except OSError:
+        return None
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def pmc_traffic(kernel_key):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC summary (tools/pmc_traffic.sh: separate
-    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction); None when no summary is present."""
+    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction); None when no summary is present.  NOT measured by this run:
+    `offline_profile` next to it names the file and its git blob id."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        d = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
         return round(d[kernel_key]["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
@@ -172,10 +189,143 @@ def pmc_search_traffic():
 def pmc_mfma(kernel_key):
     """(mfma busy fraction, effective clock GHz) of a kernel from the committed PMC pass (tools/pmc_mfma.sh) or (None, None)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_mfma.json")))[kernel_key]
+        d = json.load(open(os.path.join(ROOT, PMC_MFMA)))[kernel_key]
         return d["mfma_busy_frac"], d["effective_clock_GHz"]
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def hbm_roofline(n_rows, dim, nq, k, ms, shadow=True):
+    alg = n_rows * dim * (2 if shadow else 4) + nq * dim * 4 + nq * k * 12
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": alg,
+            "traffic": None}
+
+
+def time_search(fn, passes, warm=2):
+    """HIP events (torch's current stream = the stream liblrx launches on) around each of `passes` calls -> (mean ms, median ms)."""
+    for _ in range(warm):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * passes)]
+    for i in range(passes):
+        ev[2 * i].record()
+        fn()
+        ev[2 * i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(passes))
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def synthetic_index(n_rows, dim, dev, seed):
+    from lightretriever_amd import FlatIPIndex
+    idx = FlatIPIndex(dim, capacity=n_rows, device=dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    slot = idx.append_slot(n_rows)
+    step = max(1, (1 << 27) // dim)
+    for s0 in range(0, n_rows, step):
+        e = min(s0 + step, n_rows)
+        slot[s0:e] = torch.nn.functional.normalize(torch.randn(e - s0, dim, generator=g, device=dev), dim=-1)
+    idx.commit(n_rows)
+    return idx, g
+
+
+def search_leg(n_rows, dim, nq, k, dev, passes, index=None, seed=21):
+    own = index is None
+    g = torch.Generator(device=dev).manual_seed(seed + nq)
+    if own:
+        index, _ = synthetic_index(n_rows, dim, dev, seed)
+    q = torch.nn.functional.normalize(torch.randn(nq, dim, generator=g, device=dev), dim=-1)
+    mean_ms, med_ms = time_search(lambda: index.search(q, k), passes)
+    out = {"workload": "exact top-%d of %d queries over %d x %d fp32 rows (+ tiled bf16 shadow), one GPU, HIP events around lrx_flat_ip_search_bounded"
+                       % (k, nq, n_rows, dim),
+           "ms": round(mean_ms, 4), "ms_median": round(med_ms, 4), "passes": passes, "queries_per_s": round(nq / (mean_ms * 1e-3), 1),
+           "roofline": hbm_roofline(n_rows, dim, nq, k, mean_ms)}
+    if own:
+        del index
+        torch.cuda.empty_cache()
+    return out
+
+
+def extra_legs(args, dev, headline_index):
+    """What VERDICT r2 asked to put in front of the driver next to the (unchanged) headline, N = 1 only: BASELINE configs 2-4 on one GPU
+    (8B encode at batch 128; 1M x 4096 and 10M x 256 search), the shard an 8-GPU run of the headline search really scans (125 000 x 2048
+    rows + pack -> all-gather -> merge on a 1-rank RCCL group), and the reference's default operating point top_k = 1000 over
+    CORPUS_CHUNK_SIZE = 100 000 (eval/call_evaluate_mteb.sh:9-10) and over the 1M index."""
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    legs = {}
+    # ---- top_k = 1000 (the reference's default), Q = 100 and 1000, over the headline index and over one 100k-row chunk
+    k1000 = {}
+    if headline_index is not None and headline_index.d == 2048 and headline_index.ntotal == 1_000_000:
+        for Qx, passes in ((100, 20), (1000, 5)):
+            k1000["1Mx2048_Q%d" % Qx] = search_leg(1_000_000, 2048, Qx, 1000, dev, passes, index=headline_index)
+        k100 = search_leg(1_000_000, 2048, 100, 100, dev, 20, index=headline_index)
+        k1000["1Mx2048_Q100_k100_same_harness_ms"] = k100["ms"]
+        k1000["k1000_over_k100_time_ratio_Q100"] = round(k1000["1Mx2048_Q100"]["ms"] / k100["ms"], 3)
+    idx100k, _ = synthetic_index(100_000, 2048, dev, 31)
+    for Qx, passes in ((100, 20), (1000, 5)):
+        k1000["100kx2048_Q%d" % Qx] = search_leg(100_000, 2048, Qx, 1000, dev, passes, index=idx100k)
+    del idx100k
+    legs["top_k_1000"] = k1000
+    # ---- the per-rank shard of the 8-GPU headline search: 125 000 x 2048, Q = 100, k = 100, + the exchange on a 1-rank RCCL group
+    from lightretriever_amd.sharded import exchange_merge
+    sh, g = synthetic_index(125_000, 2048, dev, 41)
+    q = torch.nn.functional.normalize(torch.randn(100, 2048, generator=g, device=dev), dim=-1)
+    local_ms, local_med = time_search(lambda: sh.search(q, 100), 40)
+    rccl = "not initialised"
+    try:
+        if not dist.is_initialized():
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        exchange_merge(*sh.search(q, 100), force_collective=True, id_base=0)       # communicator set-up outside the timing
+        rccl = "1-rank RCCL all_gather_into_tensor"
+        full_ms, full_med = time_search(lambda: exchange_merge(*sh.search(q, 100), force_collective=True, id_base=0), 40)
+    except Exception as e:  # noqa: BLE001  (the local time stands on its own; say why the exchange is missing)
+        rccl = "unavailable: %r" % (e,)
+        full_ms = full_med = None
+    legs["search_per_shard_8way"] = {
+        "workload": "what ONE rank of an 8-GPU run of the headline search does: exact top-100 of 100 queries over its 125 000 x 2048 shard, then "
+                    "lrx_pack_topk -> all-gather of [Q,k] words -> lrx_merge_topk_packed", "local_search_ms": round(local_ms, 4),
+        "local_search_ms_median": round(local_med, 4), "with_exchange_ms": None if full_ms is None else round(full_ms, 4),
+        "with_exchange_ms_median": None if full_med is None else round(full_med, 4), "exchange": rccl,
+        "roofline": hbm_roofline(125_000, 2048, 100, 100, local_ms)}
+    del sh
+    torch.cuda.empty_cache()
+    # ---- BASELINE configs[2] / configs[3] index shape (8B width) and configs[4] (MRL 256, 10M rows) on one GPU
+    legs["config2_search_1Mx4096"] = search_leg(1_000_000, 4096, 100, 100, dev, 20, seed=51)
+    legs["config4_search_10Mx256"] = search_leg(10_000_000, 256, 100, 100, dev, 20, seed=61)
+    # ---- BASELINE configs[2]: Llama-3.1-8B dims, 128 documents x seq_len per step
+    cfg8 = EncoderConfig.llama31_8b(args.seq_len)
+    enc8 = LrxEncoder.random_init(cfg8, seed=0, device=dev)
+    B8, S = 128, args.seq_len
+    g8 = torch.Generator(device=dev).manual_seed(77)
+    ids8 = torch.randint(1000, 127000, (3, B8 * S), generator=g8, device=dev, dtype=torch.int64).to(torch.int32)
+    cu8 = (torch.arange(B8 + 1, device=dev, dtype=torch.int64) * S).to(torch.int32)
+    out8 = torch.empty(B8, cfg8.hidden_size, device=dev)
+    enc8.encode_packed(ids8[0], cu8, S, out=out8)
+    enc8.lib.lrx_set_profiling(1 << 3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in (1, 2):
+        enc8.encode_packed(ids8[i], cu8, S, out=out8)
+    torch.cuda.synchronize()
+    t8 = time.perf_counter() - t0
+    gu8 = enc8.get_profile()["gemm_swiglu"]
+    enc8.set_profiling(False)
+    tf8 = gu8["flops"] / (gu8["ms"] * 1e-3) / 1e12 if gu8["ms"] > 0 else 0.0
+    legs["config2_encode_llama31_8b"] = {
+        "workload": "lightretriever-llama3.1-8b dims bf16, %d docs/step x seq_len %d, 2 timed steps after 1 warm-up (BASELINE configs[2] encoder)" % (B8, S),
+        "docs_per_s": round(2 * B8 / t8, 2), "ms_per_step": round(1e3 * t8 / 2, 2),
+        "end_to_end_tflops": round(2 * B8 / t8 * cfg8.flops_per_doc(S) / 1e12, 1),
+        "roofline": {"bound": "mfma", "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (M=%d N=%d K=%d)" % (B8 * S, 2 * cfg8.intermediate_size, cfg8.hidden_size),
+                     "achieved": round(tf8, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf8 / PEAK_BF16_TFLOPS, 4),
+                     "avg_launch_ms": round(gu8["ms"] / max(gu8["launches"], 1), 4), "launches": gu8["launches"], "traffic": None}}
+    del enc8, out8, ids8
+    torch.cuda.empty_cache()
+    return legs
 
 
 def launch_ranks(args):
@@ -346,7 +496,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (local_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(alg_bytes / (local_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "traffic": pmc_search_traffic() if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100 and D == 2048) else None,
-                         "algorithmic_bytes": alg_bytes,
+                         "algorithmic_bytes": alg_bytes, "traffic_source": {"file": PMC_SUMMARY, "git_blob": git_blob_sha(PMC_SUMMARY), "note": "offline rocprofv3 --pmc passes, not measured by this run"},
                          "kernel": "two-pass exact search without a score matrix: k_filter_xreg / k_filter_xreg_emit (single-product filter over the tiled bf16 shadow of the shard, corpus fragments streamed through registers, HBM-bound; a strided 1/20 sample first -> k_sample_threshold, then persistent workgroups over the rest, emitting only rows above the threshold) + k_refine_band/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
                          "fp32_equiv_tflops": round(2.0 * args.queries * D * shard_rows / (local_ms * 1e-3) / 1e12, 2),
                          "fp32_mfma_peak_for_reference": PEAK_F32_MFMA_TFLOPS},
@@ -414,15 +564,25 @@ def main():
         "traffic": pmc_traffic("k_gemm_bf16_nt<2>") if (args.model == "llama3.2-1b" and B == 256 and S == 512 and batches is None) else None,
         "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (gate-up projection, M=%s N=%d K=%d)" % (m_rows, 2 * cfg.intermediate_size, H),
         "avg_launch_ms": round(gu["ms"] / max(gu["launches"], 1), 4), "launches": gu["launches"],
-        "pmc_mfma_busy_frac": pmc_mfma("k_gemm_bf16_nt<2>")[0], "pmc_effective_clock_ghz": pmc_mfma("k_gemm_bf16_nt<2>")[1],
         "all_gemms_tflops": round(gemm_all_fl / (gemm_all_ms * 1e-3) / 1e12, 2) if gemm_all_ms > 0 else None,
         "per_class_ms_per_step": {k_: round(v["ms"] / n_prof, 3) for k_, v in prof.items()},
-        # offline measurements that put `frac` in context (not re-measured here; DESIGN.md 5.4, profiles/r01_gemm_ablation.txt, r01_gemm_power.txt)
-        "context": {"package_power_w_during_gemm_loop": "1383-1390 of 1400 (cap)", "shader_clock_ghz_during_gemm_loop": 1.76,
-                    "mfma_only_loop_of_same_kernel_tflops": 1827, "vendor_gemm_same_shape_no_epilogue_tflops": 1471} if args.model == "llama3.2-1b" else None,
+        # NOT measured by this run (PMC counters cannot be read from inside the timed process): numbers of committed rocprofv3 --pmc passes,
+        # each with the git blob id of the file it was read from; `traffic` above comes from pmc_summary
+        "offline_profile": {"pmc_summary": {"file": PMC_SUMMARY, "git_blob": git_blob_sha(PMC_SUMMARY)},
+                            "pmc_mfma": {"file": PMC_MFMA, "git_blob": git_blob_sha(PMC_MFMA), "mfma_busy_frac": pmc_mfma("k_gemm_bf16_nt<2>")[0],
+                                         "effective_clock_ghz": pmc_mfma("k_gemm_bf16_nt<2>")[1]},
+                            "gemm_power": {"file": "profiles/r01_gemm_power.txt", "git_blob": git_blob_sha("profiles/r01_gemm_power.txt"),
+                                           "package_power_w_during_gemm_loop": "1383-1390 of 1400 (cap)", "shader_clock_ghz_during_gemm_loop": 1.76},
+                            "gemm_ablation": {"file": "profiles/r01_gemm_ablation.txt", "git_blob": git_blob_sha("profiles/r01_gemm_ablation.txt"),
+                                              "mfma_only_loop_of_same_kernel_tflops": 1827, "vendor_gemm_same_shape_no_epilogue_tflops": 1471}}
+                           if args.model == "llama3.2-1b" else None,
         "model_flops_per_doc": fl_doc,
         "end_to_end_tflops": round(docs_per_s / world * fl_doc / 1e12, 2),
     }
+    # (end_to_end_tflops counts the algorithmic F(S) per document; the final layer's O-projection / MLP run on the B pooled rows only, so the
+    # FLOPs actually executed are lower: `executed_tflops` = the sum over the profiled kernel classes / the profiled steps' time share)
+    ex_fl = sum(v["flops"] for v in prof.values()) / max(n_prof, 1)
+    roofline["executed_tflops"] = round(ex_fl / (enc_s / args.steps) / 1e12, 2)
     line = {
         "metric": "docs embedded/sec (%s dims, seq_len=%d, bf16) [+ queries/sec@top-%d over %d-doc index in `search`]" % (args.model, S, args.topk, args.index_rows),
         "value": round(docs_per_s, 2), "unit": "docs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -438,6 +598,11 @@ def main():
         "search": search,
         "sparse": sparse,
     }
+    if world == 1 and not args.no_configs and not args.no_search and batches is None:
+        try:
+            line["configs"] = extra_legs(args, dev, index if (D == 2048 and args.index_rows == 1_000_000) else None)
+        except Exception as e:  # noqa: BLE001  (additional legs: never take the headline line down with them)
+            line["configs"] = {"failed": "%r" % (e,)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             cb = cpu_baseline(cfg, S, args.topk, D)
@@ -447,7 +612,7 @@ def main():
         except Exception as e:  # noqa: BLE001  (the baseline is a reported number, never the product path)
             line["cpu_baseline"] = {"value": None, "unit": "docs/s", "cores": usable_cores(), "kind": "reference", "sample": "failed: %r" % (e,)}
     print(json.dumps(line), flush=True)
-    if distributed:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

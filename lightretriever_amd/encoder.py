@@ -236,6 +236,7 @@ class LrxEncoder:
         self._cw = _lib.EncoderWeightsC(self.embed.data_ptr(), self.final_norm.data_ptr(), self.rope_cos.data_ptr(),
                                         self.rope_sin.data_ptr(), C.cast(arr, C.POINTER(_lib.LayerWeightsC)),
                                         self.rope_cs16.data_ptr() if getattr(self, "use_bf16_rope_table", os.environ.get("LRX_ROPE_FP32_TABLE") != "1") else None)
+        self._handle = None        # (a handle built before this call points at the structs just replaced)
 
     def workspace_bytes(self, total_tokens: int, n_seqs: int) -> int:
         return int(self.lib.lrx_encode_workspace_bytes(C.byref(self._ccfg), total_tokens, n_seqs))

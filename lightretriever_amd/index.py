@@ -94,20 +94,23 @@ class FlatIPIndex:
                 if self._xb is not None and self._xb.ndim == 1 and self.ntotal:
                     n_old = min(self._xb.numel(), -(-self.ntotal // 128) * 128 * self.d)   # the blocks that hold committed rows
                     xb[:n_old].copy_(self._xb[:n_old])
-                elif self._xb is not None and self.ntotal:
+                elif self.ntotal:
+                    # no same-layout shadow to copy (layout switched, or shadow_bf16 turned on after rows were added): rebuild the
+                    # committed rows from the fp32 rows; the bounds too when there was no shadow at all (E was never measured)
+                    had = self._xb is not None
                     self._xb = xb
-                    self._maintain(0, self.ntotal, bounds=False)       # layout switched: rebuild from the fp32 rows
+                    self._maintain(0, self.ntotal, bounds=not had)
                     return
                 self._xb = xb
         elif self._xb is None or self._xb.ndim != 2 or self._xb.shape[0] < cap:
             xb = torch.empty(cap, self.d, dtype=torch.bfloat16, device=self.device)
             old = self._xb
             self._xb = xb
-            if old is not None and self.ntotal:
-                if old.ndim == 2:
+            if self.ntotal:
+                if old is not None and old.ndim == 2:
                     xb[:self.ntotal].copy_(old[:self.ntotal])
-                else:
-                    self._maintain(0, self.ntotal, bounds=False)
+                else:                                                   # other layout, or no shadow so far: rebuild from the fp32 rows
+                    self._maintain(0, self.ntotal, bounds=old is None)
 
     def shadow_rows(self, n: Optional[int] = None) -> torch.Tensor:
         """The shadow as a row-major [n, d] bf16 tensor (a copy when the layout is tiled): tests and tools."""
@@ -127,7 +130,11 @@ class FlatIPIndex:
         if self.ntotal + n_rows > self._x.shape[0]:
             self.reserve(max(self.ntotal + n_rows, int(self._x.shape[0] * 1.5) + 1))
         self._ensure_shadow()
-        return self._x[self.ntotal:self.ntotal + n_rows]
+        # whoever receives these rows may write them with anything: an earlier encoder write into them no longer vouches for
+        # their shadow / bounds (commit() maintains whatever is not re-recorded by shard_sink() after this point)
+        a, b = self.ntotal, self.ntotal + n_rows
+        self._fused = [iv for s, e in self._fused for iv in ((s, min(e, a)), (max(s, b), e)) if iv[1] > iv[0]]
+        return self._x[a:b]
 
     def shard_sink(self, row0: int, n_rows: int):
         """(shadow pointer tensor or None, shadow row stride [0 = tiled], first shadow row, bounds) for rows [row0, row0 + n) and a note
@@ -166,7 +173,9 @@ class FlatIPIndex:
                 self._maintain(pos, min(s, b))
                 pos = max(pos, e)
             self._maintain(pos, b)
-            self._fused = [(s, e) for s, e in self._fused if e > b]
+        # an interval vouches for ONE commit: rows beyond b that are handed out again (append_slot) or written by something else are
+        # maintained by the commit that covers them
+        self._fused = []
         self.ntotal += n_rows
 
     def add(self, x):

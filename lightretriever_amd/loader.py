@@ -138,7 +138,13 @@ def load_hf_checkpoint(path: str, max_positions: int = 512, n_tokens: Optional[i
         hf = json.load(open(os.path.join(path, "config.json")))
         cfg = EncoderConfig.from_hf_dict(hf, max_positions)
         sd = {_strip(k): v for k, v in _read_safetensors(path).items()}
-        if hf.get("tie_word_embeddings", False):
+        # HF's to_diff_dict leaves `tie_word_embeddings` out of config.json when it equals the class default (tied for PretrainedConfig
+        # and the Gemma-style configs), so an ABSENT key says nothing: then the checkpoint decides -- no lm_head.weight = tied.  Only an
+        # explicit `false` with the tensor missing is an error.
+        tie = hf.get("tie_word_embeddings")
+        if tie is None:
+            tie = "lm_head.weight" not in sd
+        if tie:
             sd.pop("lm_head.weight", None)               # tied: the head IS the embedding matrix (LrxEncoder falls back to it)
         elif "lm_head.weight" not in sd:
             raise KeyError(f"{path}: config.json says tie_word_embeddings=false but the checkpoint has no lm_head.weight")

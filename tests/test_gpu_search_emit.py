@@ -255,6 +255,58 @@ def test_encoder_writes_shadow_and_bounds_of_the_slot_it_fills():
     assert out.shape == (37, 64)
 
 
+def test_rows_rewritten_after_a_partial_commit_get_fresh_shadow_and_bounds():
+    """encode 100 rows into a slot, commit only 60, then add() other rows -- they land in rows 60.. that the encoder had
+    vouched for.  The encoder's interval must not survive: the next commit maintains them, and the search equals the oracle."""
+    from dataclasses import asdict
+    from lightretriever_amd import EncoderConfig, FlatIPIndex, LrxEncoder
+    cfg_o = O.EncoderConfig(vocab_size=500, hidden_size=256, num_layers=2, num_q_heads=4, num_kv_heads=2, head_dim=64,
+                            intermediate_size=512, rope_type="llama3", rope_original_max_position=64, max_positions=256)
+    w = O.random_weights(cfg_o, seed=1, std=0.04)
+    enc = LrxEncoder(EncoderConfig(**asdict(cfg_o)), {k: torch.from_numpy(v) for k, v in w.items()})
+    rng = np.random.default_rng(4)
+    lens = rng.integers(1, 60, size=100)
+    ids = torch.from_numpy(rng.integers(0, 500, size=int(lens.sum())).astype(np.int32)).cuda()
+    cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).cuda()
+    idx = FlatIPIndex(256, capacity=40000)
+    enc.encode_packed(ids, cu, int(lens.max()), out=idx.append_slot(100))
+    idx.commit(60)
+    assert idx._fused == []
+    extra = (O.l2_normalize(rng.standard_normal((30000, 256)).astype(np.float32)) * np.float32(3.0))   # larger norms: stale bounds would be too small
+    idx.add(extra)
+    X = np.concatenate([idx.vectors[:60].cpu().numpy(), extra])
+    assert torch.equal(idx.shadow_rows(), torch.from_numpy(X).cuda().to(torch.bfloat16))
+    assert idx._bounds[0].item() >= 3.0 * (1 - 1e-6)
+    q = O.l2_normalize(rng.standard_normal((40, 256)).astype(np.float32))
+    Dg, Ig = idx.search(q, 10)
+    check_against_oracle(Dg, Ig, q, X, 10)
+    # the same rows handed out twice before a commit: the second receiver's rows are maintained by the commit
+    idx2 = FlatIPIndex(256, capacity=40000)
+    enc.encode_packed(ids, cu, int(lens.max()), out=idx2.append_slot(100))
+    idx2.append_slot(30000).copy_(torch.from_numpy(extra))
+    idx2.commit(30000)
+    assert torch.equal(idx2.shadow_rows(), torch.from_numpy(extra).cuda().to(torch.bfloat16))
+    check_against_oracle(*idx2.search(q, 10), q, extra, 10)
+
+
+@pytest.mark.parametrize("layout", ["tiled", "rows"])
+def test_shadow_switched_on_after_rows_were_added_is_built_from_the_rows(layout):
+    """shadow_bf16 = True on an index that already holds rows must not leave their shadow uninitialised."""
+    from lightretriever_amd import FlatIPIndex
+    rng = np.random.default_rng(12)
+    X = O.l2_normalize(rng.standard_normal((30000, 128)).astype(np.float32))
+    idx = FlatIPIndex(128, capacity=40000)
+    idx.shadow_bf16 = False
+    idx.shadow_layout = layout
+    idx.add(X[:20000])
+    assert idx._xb is None
+    idx.shadow_bf16 = True
+    idx.add(X[20000:])
+    assert torch.equal(idx.shadow_rows(), torch.from_numpy(X).cuda().to(torch.bfloat16))
+    q = O.l2_normalize(rng.standard_normal((50, 128)).astype(np.float32))
+    check_against_oracle(*idx.search(q, 10), q, X, 10)
+
+
 # ---- BASELINE index shapes (configs 2-5): properties that do not need a CPU pass over the whole index -------------------------------
 def _fill_normalised(idx, N, D, seed):
     g = torch.Generator(device="cuda").manual_seed(seed)

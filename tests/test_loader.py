@@ -142,6 +142,17 @@ def test_untied_lm_head_is_kept_and_tied_head_is_not_duplicated(tmp_path):
     json.dump(json.load(open(os.path.join(d, "config.json"))), open(bad / "config.json", "w"))
     with pytest.raises(KeyError, match="lm_head"):
         load_hf_checkpoint(str(bad))
+    # config.json WITHOUT the key (HF's to_diff_dict drops values equal to the class default): the checkpoint decides --
+    # no lm_head.weight = tied, a separate head stays
+    for src, name, has_head in ((str(bad), "nokey_tied", False), (d, "nokey_untied", True)):
+        nk = tmp_path / name
+        nk.mkdir()
+        c = json.load(open(os.path.join(src, "config.json")))
+        c.pop("tie_word_embeddings")
+        json.dump(c, open(nk / "config.json", "w"))
+        st.save_file({k: v.contiguous() for k, v in st.load_file(os.path.join(src, "model.safetensors")).items()}, str(nk / "model.safetensors"))
+        _, sdn = load_hf_checkpoint(str(nk))
+        assert ("lm_head.weight" in sdn) == has_head
 
 
 def _adapter(tmp_path, base, tensors, **cfg):
