@@ -166,7 +166,57 @@ def run_case(name, X, Qs, qids, corpus, text_row, top_k, chunk, ignore):
     return out
 
 
+def persist_goldens():
+    """Row f-N4 (index persistence): the `.tsv` id map exactly as the reference's own save_dict_to_tsv writes it
+    (retriever/faiss_search.py:28-33: csv.writer, tab delimiter, QUOTE_MINIMAL, header row from mapping_tsv_keys :63), read back by
+    its load_tsv_to_dict (:35-43), and the file name / id order DenseRetrievalFaissSearch.save and ._load derive (:99-123).  The ids
+    carry everything the csv dialect treats specially: tabs, double quotes, commas, leading / trailing blanks, non-ASCII, an
+    embedded line feed, the empty string.  Bytes are stored base64; nothing of the reference's source is."""
+    import base64
+    import tempfile
+    from lightretriever.retriever import faiss_search as ref_fs
+    ids = ["doc-0", "with\ttab", 'say "hi"', "comma,inside", " lead", "trail ", "\u00fcml\u00e4ut-\u6587\u66f8", "multi\nline", "", "quote\"and\ttab", "123", "d9", "d10"]
+    mapping = {pid: i for i, pid in enumerate(ids)}
+    out = {"generator": "tests/golden/gen_search_goldens.py:persist_goldens", "ids": ids}
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "m.tsv")
+        ref_fs.save_dict_to_tsv(mapping, f, keys=["beir-docid", "faiss-docid"])
+        out["tsv_with_header_b64"] = base64.b64encode(open(f, "rb").read()).decode()
+        back = ref_fs.load_tsv_to_dict(f, header=True)
+        out["loaded_with_header"] = [[k, v] for k, v in back.items()]
+        ref_fs.save_dict_to_tsv(mapping, f)                                     # keys=[] -> no header row
+        out["tsv_no_header_b64"] = base64.b64encode(open(f, "rb").read()).decode()
+        out["loaded_no_header"] = [[k, v] for k, v in ref_fs.load_tsv_to_dict(f, header=False).items()]
+
+        # DenseRetrievalFaissSearch.save / ._load around a recording index object (the .faiss bytes themselves are Faiss's: unpinnable here)
+        class RecordingIndex:
+            def __init__(self):
+                self.saved = []
+
+            def save(self, fname):
+                self.saved.append(os.path.basename(fname))
+                open(fname, "wb").write(b"x")
+
+        fs = FlatIPFaissSearch(model=None, batch_size=8, show_progress_bar=False)
+        fs.mapping = {pid: i for i, pid in enumerate(ids[:6])}
+        fs.faiss_index = RecordingIndex()
+        ref_fs.DenseRetrievalFaissSearch.save(fs, td, "my-index", "flat")
+        out["save_files"] = sorted(os.listdir(td))
+        out["save_index_file"] = fs.faiss_index.saved
+        out["save_tsv_b64"] = base64.b64encode(open(os.path.join(td, "my-index.flat.tsv"), "rb").read()).decode()
+        fs2 = FlatIPFaissSearch(model=None, batch_size=8, show_progress_bar=False)
+        path, passage_ids = ref_fs.DenseRetrievalFaissSearch._load(fs2, td, "my-index", "flat")
+        out["load_faiss_path_basename"] = os.path.basename(path)
+        out["load_passage_ids"] = passage_ids
+        out["load_mapping"] = [[k, v] for k, v in fs2.mapping.items()]
+        out["load_rev_mapping"] = [[k, v] for k, v in fs2.rev_mapping.items()]
+    with open(os.path.join(HERE, "persist_ref.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print(f"wrote persist_ref.json: {len(ids)} ids, {os.path.getsize(os.path.join(HERE, 'persist_ref.json'))} bytes")
+
+
 def main():
+    persist_goldens()
     rng = np.random.default_rng(20260203)
     fx = {"generator": "tests/golden/gen_search_goldens.py", "faiss": "numpy stand-in (pins nothing about Faiss)", "sets": {}}
 

@@ -256,6 +256,82 @@ def test_flat_index_file_layout_and_round_trip(tmp_path):
     assert io.shard_prefix("my-index") == "my-index" and io.shard_prefix("my-index", 3, 8) == "my-index.rank3-of-8"
 
 
+def test_id_map_tsv_is_byte_equal_to_the_reference_written_file(tmp_path):
+    """Row f-N4 pinned to the reference: tests/golden/persist_ref.json holds the bytes the reference's own save_dict_to_tsv wrote
+    (retriever/faiss_search.py:28-33) for ids with tabs, quotes, commas, blanks, non-ASCII, an embedded line feed and the empty string,
+    what its load_tsv_to_dict (:35-43) read back, and what DenseRetrievalFaissSearch.save / ._load (:99-123) name and return
+    (tests/golden/gen_search_goldens.py:persist_goldens).  index_io must write the same bytes and read the reference's file the same way."""
+    import base64
+    import json
+    from lightretriever_amd import index_io as io
+    from lightretriever_amd.retriever import FlatIPFaissSearch
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "persist_ref.json")))
+    ids = fx["ids"]
+    mapping = {pid: i for i, pid in enumerate(ids)}
+    for key, keys, header in (("tsv_with_header_b64", io.MAPPING_TSV_KEYS, True), ("tsv_no_header_b64", None, False)):
+        want = base64.b64decode(fx[key])
+        f = str(tmp_path / (key + ".tsv"))
+        io.save_dict_to_tsv(mapping, f, keys=keys)
+        assert open(f, "rb").read() == want, key                           # byte for byte what the reference writes
+        ref_file = str(tmp_path / (key + ".ref.tsv"))
+        open(ref_file, "wb").write(want)
+        got = io.load_tsv_to_dict(ref_file, header=header)                  # the reference's file through this build's reader
+        want_loaded = fx["loaded_with_header" if header else "loaded_no_header"]
+        assert [[k, v] for k, v in got.items()] == want_loaded              # same keys, same order, same ints as the reference's reader
+    # the reference's reader does not restore an embedded "\n" differently from this one, and every id survives the round trip
+    assert [k for k, _ in fx["loaded_with_header"]] == ids
+
+    class RecordingIndex:
+        saved = []
+
+        def save(self, fname):
+            self.saved.append(os.path.basename(fname))
+            open(fname, "wb").write(b"x")
+
+    fs = FlatIPFaissSearch.__new__(FlatIPFaissSearch)
+    fs.mapping, fs.faiss_index = {pid: i for i, pid in enumerate(ids[:6])}, RecordingIndex()
+    out_dir = tmp_path / "saved"
+    FlatIPFaissSearch.__mro__[1].save(fs, str(out_dir), "my-index", "flat")  # DenseRetrievalFaissSearch.save (faiss_search.py:111-123)
+    assert sorted(os.listdir(out_dir)) == [n for n in fx["save_files"] if n != "m.tsv"]
+    assert fs.faiss_index.saved == fx["save_index_file"]
+    assert open(out_dir / "my-index.flat.tsv", "rb").read() == base64.b64decode(fx["save_tsv_b64"])
+    fs2 = FlatIPFaissSearch.__new__(FlatIPFaissSearch)
+    path, passage_ids = FlatIPFaissSearch.__mro__[1]._load(fs2, str(out_dir), "my-index", "flat")
+    assert os.path.basename(path) == fx["load_faiss_path_basename"] and passage_ids == fx["load_passage_ids"]
+    assert [[k, v] for k, v in fs2.mapping.items()] == fx["load_mapping"] and [[k, v] for k, v in fs2.rev_mapping.items()] == fx["load_rev_mapping"]
+
+
+def test_flat_index_header_hand_derived_from_the_faiss_source():
+    """The `.faiss` bytes for d = 64, ntotal = 3, written out by hand from Faiss's published serialiser -- NO Faiss build has verified
+    this (faiss is neither in the reference tree nor in the image).  faiss/impl/index_write.cpp (v1.7.3 .. 1.8): write_index(), IndexFlat
+    branch: `uint32_t h = fourcc("IxFI")` for METRIC_INNER_PRODUCT, WRITE1(h); write_index_header(): WRITE1(idx->d) [int, 4 B],
+    WRITE1(idx->ntotal) [idx_t = int64], `idx_t dummy = 1 << 20; WRITE1(dummy); WRITE1(dummy);`, WRITE1(idx->is_trained) [bool, 1 B],
+    WRITE1(idx->metric_type) [enum MetricType, 4 B; METRIC_INNER_PRODUCT = 0; metric_arg only when metric_type > 1]; then
+    WRITEXBVECTOR(idxf->codes) (faiss/impl/io_macros.h): `size_t size = vec.size() / 4` [8 B, the float count] followed by the bytes.
+    fourcc() (faiss/impl/io.cpp) packs the four characters little-endian, i.e. the file starts with the text "IxFI"."""
+    from lightretriever_amd import index_io as io
+    import tempfile
+    x = np.arange(3 * 64, dtype=np.float32).reshape(3, 64) / 8
+    want = bytes.fromhex(
+        "49784649"            # 'I' 'x' 'F' 'I'
+        "40000000"            # d = 64
+        "0300000000000000"    # ntotal = 3
+        "0000100000000000"    # dummy = 1 << 20
+        "0000100000000000"    # dummy = 1 << 20
+        "01"                  # is_trained
+        "00000000"            # metric_type = METRIC_INNER_PRODUCT
+        "c000000000000000"    # 192 floats follow
+    )
+    assert len(want) == 45
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "h.flat.faiss")
+        io.write_flat_ip(f, [x], 64, 3)
+        raw = open(f, "rb").read()
+    assert raw[:45] == want
+    assert raw[45:45 + 16] == bytes.fromhex("00000000" "0000003e" "0000803e" "0000c03e")      # 0, 1/8, 2/8, 3/8 as little-endian fp32
+    assert len(raw) == 45 + 3 * 64 * 4
+
+
 def test_prefetch_batches_keeps_order_propagates_errors_and_stops_clean():
     """The collate-ahead worker of encode_corpus: batches arrive in input order, a collator failure surfaces in the consumer,
     an abandoned iteration leaves no thread behind."""
