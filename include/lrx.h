@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define LRX_ABI_VERSION 3
+#define LRX_ABI_VERSION 4
 
 enum {
   LRX_OK = 0,
@@ -51,14 +51,23 @@ typedef struct lrx_encoder_config {
                                  activations: the row statistic rsqrt(mean(x^2)+eps) is applied to the GEMM's fp32 accumulator and the
                                  residual GEMMs emit the sum of squares of the rows they write.  Same function; the two bf16 roundings of
                                  the normalised activations disappear (closer to the fp32 model).  ln1 / ln2 are ignored.            */
+  int32_t precise_stream;     /* 1 (needs norm_folded = 0 and the ORIGINAL wqkv / wgu): the residual stream is kept in fp32; every residual GEMM
+                                 adds into it with one rounding (to fp32) and also writes the next projection's bf16 operand bf16(x * gamma_next)
+                                 -- the norm weight rides on the activation, the weights stay exact, the row statistic is applied to the consumer's
+                                 accumulator as with norm_folded.  For deep backbones: at 32 layers the bf16 stream + folded weights spend ~1.1e-3
+                                 of the 1e-3 cosine budget against the fp32 model (tools/exp/rounding_budget.py); +6 B / element of traffic
+                                 per residual GEMM (~3 % of an 8B step).  LrxEncoder switches it on from 20 layers.                   */
 } lrx_encoder_config;
 
 /* Per-layer weights, bf16, nn.Linear layout [out, in] row-major (K contiguous).
- *   wqkv  [(nq + 2 nkv) * d, H]   rows = q_proj | k_proj | v_proj concatenated
+ *   wqkv  [(nq + 2 nkv) * d, H]   rows = q_proj | k_proj | v_proj concatenated, the d rows of every q and k head in ROTARY-PAIR order:
+ *                                 physical row 32 g + 16 i + t of a head = logical row i * d/2 + 16 g + t  (g < d/32, i < 2, t < 16), so that
+ *                                 the fused QKV epilogue finds x_j and x_{j + d/2} in one lane and rotates on the fp32 accumulators; q and k
+ *                                 leave the projection in the same order (q . k is invariant), v rows are in logical order
  *   wo    [H, nq * d]
  *   wgu   [2 * I, H]              gate/up interleaved in 16-row groups: rows [32j,32j+16) = gate[16j..], [32j+16,32j+32) = up[16j..]
  *   wdown [H, I]
- *   ln1, ln2 [H] bf16 (input_layernorm, post_attention_layernorm); bqkv [(nq+2nkv)*d] bf16 or NULL            */
+ *   ln1, ln2 [H] bf16 (input_layernorm, post_attention_layernorm); bqkv [(nq+2nkv)*d] bf16 (same row order as wqkv) or NULL */
 typedef struct lrx_layer_weights {
   const void* wqkv;
   const void* bqkv;
@@ -72,11 +81,9 @@ typedef struct lrx_layer_weights {
 typedef struct lrx_encoder_weights {
   const void* embed;             /* [V, H] bf16 */
   const void* final_norm;        /* [H] bf16 */
-  const float* rope_cos;         /* [max_positions, d/2] fp32 (values already rounded to bf16, as HF casts cos/sin) */
+  const float* rope_cos;         /* [max_positions, d/2] fp32: cos(position * inv_freq), the values LlamaRotaryEmbedding computes in fp32 */
   const float* rope_sin;
   const lrx_layer_weights* layers; /* HOST array of num_layers structs (device pointers inside) */
-  const void* rope_cs_bf16;      /* optional (NULL = use the fp32 tables): the same values as bf16, [max_positions, d]: row p = cos(p, 0..d/2-1) |
-                                    sin(p, 0..d/2-1).  The fused QKV+RoPE epilogue then reads 32 B instead of 64 B of table per 8 outputs */
 } lrx_encoder_weights;
 
 /* What torch.ops.lrx.encode_packed takes as its `weights` argument: the address of one of these (both structs owned, and kept
@@ -179,8 +186,9 @@ int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, co
                      int32_t N, int32_t K, int32_t epilogue, void* stream);
 
 /* Fused QKV projection + rotary embedding: C[M, (nq+2nkv)*d] = A[M,K] * Wqkv^T (+ bias), then apply_rotary_pos_emb
- * (modeling_llama.py:130-160) to the q and k column blocks in the epilogue; v columns are stored unrotated.
- * Equivalent to lrx_gemm_bf16_nt(epilogue 0) followed by lrx_rope_inplace, without the extra pass over qkv.        */
+ * (modeling_llama.py:130-160) on the q and k column blocks, on the fp32 accumulators with the fp32 cos/sin table (one rounding); v columns
+ * are stored unrotated.  Wqkv / bias rows of the q and k heads in rotary-pair order (lrx_layer_weights); C is FP16 (saturating at
+ * +-65504; 11 significant bits for both operands of q . k), q and k columns in the same pair order.                                */
 int lrx_gemm_qkv_rope(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions,
                       const float* cos, const float* sin, int32_t M, int32_t K, int32_t num_q_heads,
                       int32_t num_kv_heads, int32_t head_dim, void* stream);
@@ -188,13 +196,9 @@ int lrx_gemm_qkv_rope(const void* A, const void* Wqkv, void* C, const void* bias
 /* positions[t] = t - cu_seqlens[seq(t)] */
 int lrx_build_positions(const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t* positions, void* stream);
 
-/* In-place rotary embedding (apply_rotary_pos_emb, modeling_llama.py:130-160, half-split pairing) on the q and k
- * column blocks of the fused qkv activation [T, (nq + 2 nkv) * d] bf16.                                          */
-int lrx_rope_inplace(void* qkv, const int32_t* positions, const float* cos, const float* sin, int32_t total_tokens,
-                     int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* stream);
-
 /* Varlen causal GQA attention (flash_attention_2 varlen call the reference requires for packing,
  * utils/nested_input.py:137-146): out[T, nq*d] bf16 = softmax(q k^T / sqrt(d), causal within each sequence) v.
+ * qkv [T, (nq + 2 nkv) * d] FP16 as lrx_gemm_qkv_rope writes it (probabilities are rounded to fp16 too; fp32 accumulation).
  * last_tile_only != 0: only the 64-row q tile that holds each sequence's LAST token is computed (other rows of `out`
  * are left untouched) -- all the pooled path needs from the final layer.                                          */
 int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens,
@@ -203,7 +207,7 @@ int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens, int32_t n
 
 /* Attention of suffix queries over a shared prefix: qkv [n_seqs*suffix_len, (nq+2nkv)*d] (RoPE applied), prefix_kv
  * [prefix_len, 2*nkv*d] (k block | v block of one layer, RoPE applied); query j of a sequence sees the prefix keys and its own
- * suffix keys 0..j.  out [n_seqs*suffix_len, nq*d] bf16.                                                                      */
+ * suffix keys 0..j.  qkv and prefix_kv FP16 (lrx_gemm_qkv_rope output), out [n_seqs*suffix_len, nq*d] bf16.                    */
 int lrx_attn_prefix_suffix(const void* qkv, const void* prefix_kv, int32_t n_seqs, int32_t suffix_len, int32_t prefix_len,
                            int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out, void* stream);
 
@@ -250,6 +254,15 @@ int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, const void* bi
 int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions,
                             const float* cos, const float* sin, int32_t M, int32_t K, int32_t num_q_heads,
                             int32_t num_kv_heads, int32_t head_dim, const float* rscale, void* stream);
+/* Precise residual stream (lrx_encoder_config.precise_stream).  x32[M, N] (fp32, in place) += A[M, K] * B[N, K]^T; a16_out (bf16 [M, N],
+ * may be NULL) = bf16(x32 * gamma[n]) (gamma bf16 [N], NULL = 1): the next projection's operand; ss_part as above, from the fp32 row.   */
+int lrx_gemm_bf16_nt_resid32(const void* A, const void* B, float* x32, void* a16_out, const void* gamma, int32_t M, int32_t N,
+                             int32_t K, float* ss_part, void* stream);
+/* ... its start: x32[t, :] = table[ids[t], :], a16[t, :] = bf16(x32 * gamma), rscale_out[t] = rsqrt(mean(x32^2) + eps)              */
+int lrx_embed_stream32(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, int32_t vocab, const void* gamma,
+                       float* x32, void* a16, float* rscale_out, float eps, void* stream);
+/* ... and its end: y bf16 = w * x32 * rsqrt(mean(x32^2) + eps), one rounding                                                         */
+int lrx_rmsnorm_f32(const float* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps, void* stream);
 /* rscale_out[r] = rsqrt(mean(x[r,:]^2) + eps) for bf16 rows (LlamaRMSNorm's statistic, modeling_llama.py:53-67) */
 int lrx_row_rscale(const void* x, int32_t rows, int32_t hidden_size, float eps, float* rscale_out, void* stream);
 /* rscale_out[r] = rsqrt(sum_p ss_part[p, r] / hidden_size + eps), partials added in index order */
@@ -266,11 +279,11 @@ int lrx_pool_norm(const void* hidden, const void* final_norm_w, const int32_t* c
                   int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim,
                   int32_t normalize, void* stream);
 /* ... and the shard maintenance fused into it: shadow_out (bf16 rows, RNE copy of what goes to `out`; may be NULL) and row_bounds
- * (see lrx_shard_commit_rows; may be NULL).                                                                                     */
+ * (see lrx_shard_commit_rows; may be NULL).  hidden_f32 != 0: `hidden` holds fp32 rows (precise_stream), the norm runs in fp32.   */
 int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                         int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim,
                         int32_t normalize, void* shadow_out, int64_t shadow_row_stride, int64_t shadow_row0, float* row_bounds,
-                        void* stream);
+                        int32_t hidden_f32, void* stream);
 
 /* Query side.  Replaces emb_bag.forward + slice + F.normalize at finetune/modeling_hybrid.py:472-490
  * (torch.nn.EmbeddingBag mode='mean', padding_idx) with inputs from tokenize_nonctx_qry_emb_bag

@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRX_LIB_DEV_VARIANT") or os.path.join(HERE, "liblrx.so")   # env override: tools/ diagnostics only
 LRX_PROF_CLASSES = 8
-ABI_VERSION = 3   # LRX_ABI_VERSION of include/lrx.h
+ABI_VERSION = 4   # LRX_ABI_VERSION of include/lrx.h
 PROF_CLASS_NAMES = ["gemm_store", "gemm_resid", "gemm_swiglu", "attention", "rmsnorm", "rope", "other", "gemm_maxagg"]
 
 
@@ -17,7 +17,7 @@ class LrxError(RuntimeError):
 class EncoderConfigC(C.Structure):
     _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_q_heads", C.c_int32),
                 ("num_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("intermediate_size", C.c_int32), ("rms_eps", C.c_float),
-                ("qkv_bias", C.c_int32), ("max_positions", C.c_int32), ("norm_folded", C.c_int32)]
+                ("qkv_bias", C.c_int32), ("max_positions", C.c_int32), ("norm_folded", C.c_int32), ("precise_stream", C.c_int32)]
 
 
 class LayerWeightsC(C.Structure):
@@ -27,7 +27,7 @@ class LayerWeightsC(C.Structure):
 
 class EncoderWeightsC(C.Structure):
     _fields_ = [("embed", C.c_void_p), ("final_norm", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-                ("layers", C.POINTER(LayerWeightsC)), ("rope_cs_bf16", C.c_void_p)]
+                ("layers", C.POINTER(LayerWeightsC))]
 
 
 _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -56,7 +56,10 @@ SIGNATURES = {
     "lrx_flat_ip_search_bounded": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _P, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _P]),
     "lrx_search_set_mode": (None, [_I32]),
     "lrx_shard_commit_rows": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _I64, _P, _P]),
-    "lrx_pool_norm_shard": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P, _I64, _I64, _P, _P]),
+    "lrx_pool_norm_shard": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P, _I64, _I64, _P, _I32, _P]),
+    "lrx_gemm_bf16_nt_resid32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
+    "lrx_embed_stream32": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _F, _P]),
+    "lrx_rmsnorm_f32": (_I32, [_P, _P, _P, _I32, _I32, _F, _P]),
     "lrx_gemm_bf16_nt_fused": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "lrx_gemm_qkv_rope_fused": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "lrx_row_rscale": (_I32, [_P, _I32, _I32, C.c_float, _P, _P]),
@@ -69,7 +72,6 @@ SIGNATURES = {
     "lrx_gemm_bf16_nt": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "lrx_gemm_qkv_rope": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "lrx_build_positions": (_I32, [_P, _I32, _I32, _P, _P]),
-    "lrx_rope_inplace": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "lrx_attn_varlen_causal": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "lrx_gather_last_rows": (_I32, [_P, _P, _I32, _I32, _P, _P]),
     "lrx_pool_norm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P]),

@@ -1,4 +1,4 @@
-// Varlen causal GQA attention forward for packed sequences (S <= max_positions), gfx950 MFMA 32x32x16 bf16.
+// Varlen causal GQA attention forward for packed sequences (S <= max_positions), gfx950 MFMA 32x32x16; q, k, v, P in fp16 (see attn_mfma), output bf16.
 //
 // Work item = (sequence, 64-row q tile, kv head).  Workgroup = 2*GRP waves: wave w handles q head (kvh*GRP + w%GRP)
 // and the 32-row half (w / GRP) of the q tile, so the K/V tile staged in LDS is shared by all GRP q heads of the group.
@@ -7,7 +7,7 @@
 //   S^T[key, q] = K . Q^T      (A = K rows from LDS via ds_read_b128, B = Q fragments kept in registers)
 //     -> the score column of one q row lives in ONE lane (16 regs) + its lane^32 partner: row max / row sum are
 //        15 VALU ops + one cross-half shuffle, no LDS.
-//   P^T (bf16) is exactly the B-operand layout of the next MFMA (accumulator tile as operand), so
+//   P^T (fp16) is exactly the B-operand layout of the next MFMA (accumulator tile as operand), so
 //   O^T[d, q] += V^T . P^T     (A = V^T fragments read from the row-major V tile with ds_read_b64_tr_b16)
 //   online softmax state (m, l) is one scalar per lane.
 //
@@ -19,6 +19,18 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+// q, k, v and the softmax probabilities are FP16 (round 3): 11 significant bits instead of bf16's 8 on both MFMA operands of QK^T and
+// P.V.  tools/exp/rounding_budget.py: at the 32-layer Llama-3.1-8B dims the bf16 roundings of q|k|v were the largest single share of
+// 1 - cos against the fp32 model (9e-4 of 2.4e-3 with the double rounding around RoPE).  The fused QKV + RoPE epilogue writes fp16
+// (saturating at +-65504), the 16-bit containers below stay typed bf16x8 (LDS-DMA, swizzles and transposing reads move bits) and are
+// re-interpreted at the MFMA; the attention OUTPUT stays bf16 (it is the bf16 A operand of the O-projection GEMM).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ f32x16 attn_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ __bf16 attn_cvt(float v) { return __builtin_bit_cast(__bf16, (_Float16)v); }      // fp16 bits in the 16-bit container
+__device__ __forceinline__ float attn_f(__bf16 v) { return (float)__builtin_bit_cast(_Float16, v); }
 typedef __attribute__((address_space(3))) const char* lds_char_ptr;
 
 template <int D>
@@ -226,9 +238,9 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kt_base + koff_[ks]);
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // inline-constant C operand
-    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf_[0], zero, 0, 0, 0);
+    f32x16 acc = attn_mfma(kf[0], qf_[0], zero);
 #pragma unroll
-    for (int ks = 1; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf_[ks], acc, 0, 0, 0);
+    for (int ks = 1; ks < KS; ++ks) acc = attn_mfma(kf[ks], qf_[ks], acc);
     return acc;
   };
   // lane <-> lane^32 exchange on the VALU (v_permlane32_swap) instead of an LDS round trip (ds_bpermute)
@@ -296,7 +308,7 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) pf[sp][jj] = f2bf(s[8 * sp + jj]);
+      for (int jj = 0; jj < 8; ++jj) pf[sp][jj] = attn_cvt(s[8 * sp + jj]);
     // ---- O^T += V^T P^T
     if (DT == 2) {
       asm volatile("s_waitcnt lgkmcnt(0)"
@@ -318,7 +330,7 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
       for (int dt = 0; dt < DT; ++dt) {
         union { struct { s16x4 a, b; } s; bf16x8 v; } u;
         u.s.a = vt[sp][dt][0]; u.s.b = vt[sp][dt][1];
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pf[sp], o[dt], 0, 0, 0);
+        o[dt] = attn_mfma(u.v, pf[sp], o[dt]);
       }
   };
 
@@ -469,9 +481,9 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kt_base + koff[ks]);
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], zero, 0, 0, 0);
+      f32x16 acc = attn_mfma(kf[0], qf[0], zero);
 #pragma unroll
-      for (int ks = 1; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], acc, 0, 0, 0);
+      for (int ks = 1; ks < KS; ++ks) acc = attn_mfma(kf[ks], qf[ks], acc);
       return acc;
     };
 
@@ -532,7 +544,7 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) pf[sp][jj] = f2bf(sc[8 * sp + jj]);
+        for (int jj = 0; jj < 8; ++jj) pf[sp][jj] = attn_cvt(sc[8 * sp + jj]);
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]), "+v"(vt[1][0][0]), "+v"(vt[1][0][1]),
                      "+v"(vt[1][1][0]), "+v"(vt[1][1][1])
@@ -544,7 +556,7 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
         for (int dt = 0; dt < DT; ++dt) {
           union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
           uu.s.a = vt[sp][dt][0]; uu.s.b = vt[sp][dt][1];
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uu.v, pf[sp], o[dt], 0, 0, 0);
+          o[dt] = attn_mfma(uu.v, pf[sp], o[dt]);
         }
     };
     // two named score accumulators ping-pong (no register copies): product u+1 is issued before softmax u
@@ -610,7 +622,7 @@ k_attn_prefix(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_
     for (int jj = 0; jj < nj; ++jj)
 #pragma unroll
       for (int e = 0; e < E; ++e)
-        q_lds[wave][jj][lane * E + e] = bf2f(qkv[((int64_t)seq * S2 + j0 + jj) * RS + (int64_t)hq * D + lane * E + e]) * scale;
+        q_lds[wave][jj][lane * E + e] = attn_f(qkv[((int64_t)seq * S2 + j0 + jj) * RS + (int64_t)hq * D + lane * E + e]) * scale;
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same-wave LDS writes visible to the reads below
     float m[JB], l[JB], o[JB][E];
 #pragma unroll
@@ -632,7 +644,7 @@ k_attn_prefix(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_
           const bf16x8 kv = *(const bf16x8*)(kp + e8 * 8);
           float kf[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) kf[i] = bf2f(kv[i]);
+          for (int i = 0; i < 8; ++i) kf[i] = attn_f(kv[i]);
 #pragma unroll
           for (int jj = 0; jj < JB; ++jj) {
             if (jj < nj) {
@@ -651,7 +663,7 @@ k_attn_prefix(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_
         alpha[jj] = __expf(m[jj] - mn);
         const float pw = vis ? __expf(s_ - mn) : 0.f;
         l[jj] = l[jj] * alpha[jj] + wave_sum(pw);
-        pr[jj] = bf2f(f2bf(pw));                           // P is rounded to bf16 before P.V like the tiled kernels
+        pr[jj] = attn_f(attn_cvt(pw));                      // P is rounded to fp16 before P.V like the tiled kernels
         m[jj] = mn;
 #pragma unroll
         for (int e = 0; e < E; ++e) o[jj][e] *= alpha[jj];
@@ -663,7 +675,7 @@ k_attn_prefix(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_
         const __bf16* vp = key_u < P1 ? vpre + (int64_t)key_u * PS : vsuf + (int64_t)(key_u - P1) * RS;
         float vf[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) vf[e] = bf2f(vp[lane * E + e]);
+        for (int e = 0; e < E; ++e) vf[e] = attn_f(vp[lane * E + e]);
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {
           const float pk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[jj]), kk));
@@ -740,7 +752,7 @@ k_attn_prefix_mfma(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pr
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kv = *(const bf16x8*)(kp + ks * 16);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc += bf2f(qf[ks][e]) * bf2f(kv[e]);
+        for (int e = 0; e < 8; ++e) acc += attn_f(qf[ks][e]) * attn_f(kv[e]);
       }
       auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
       so[i] = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
@@ -759,9 +771,9 @@ k_attn_prefix_mfma(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pr
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(sK + (t * 32 + r) * G::ROW_BYTES + (((2 * ks + h) ^ G::xk(r)) << 4));
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], zero, 0, 0, 0);
+      f32x16 acc = attn_mfma(kf[0], qf[0], zero);
 #pragma unroll
-      for (int ks = 1; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], acc, 0, 0, 0);
+      for (int ks = 1; ks < KS; ++ks) acc = attn_mfma(kf[ks], qf[ks], acc);
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int key = t * 32 + (u & 3) + 8 * (u >> 2) + 4 * h;
@@ -804,7 +816,7 @@ k_attn_prefix_mfma(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pr
       for (int u = 0; u < 16; ++u) {
         const float pw = __builtin_amdgcn_exp2f(sc[t][u] * scale_log2 + mc);
         l += pw;
-        pf[u >> 3][u & 7] = f2bf(pw);
+        pf[u >> 3][u & 7] = attn_cvt(pw);
       }
       if (DT == 2) {
         asm volatile("s_waitcnt lgkmcnt(0)"
@@ -826,7 +838,7 @@ k_attn_prefix_mfma(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pr
         for (int dt = 0; dt < DT; ++dt) {
           union { struct { s16x4 a, b; } s; bf16x8 v; } u_;
           u_.s.a = vt[sp][dt][0]; u_.s.b = vt[sp][dt][1];
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u_.v, pf[sp], o[dt], 0, 0, 0);
+          o[dt] = attn_mfma(u_.v, pf[sp], o[dt]);
         }
     }
   }
@@ -840,7 +852,7 @@ k_attn_prefix_mfma(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pr
     if (i <= j) {
       const float pw = __builtin_amdgcn_exp2f(so[i] * scale_log2 + mc);
       l += pw;
-      const float pb = bf2f(f2bf(pw));
+      const float pb = attn_f(attn_cvt(pw));
       const __bf16* vp = qkv + ((int64_t)seq * S2 + i) * RS + (int64_t)(nq + nkv + hk) * D + 4 * h;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
@@ -848,7 +860,7 @@ k_attn_prefix_mfma(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pr
         for (int g = 0; g < 4; ++g) {
           const bf16x4 vv = *(const bf16x4*)(vp + dt * 32 + 8 * g);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[dt][4 * g + e] += pb * bf2f(vv[e]);
+          for (int e = 0; e < 4; ++e) o[dt][4 * g + e] += pb * attn_f(vv[e]);
         }
     }
   }

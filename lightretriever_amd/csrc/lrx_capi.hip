@@ -95,8 +95,9 @@ extern "C" int lrx_get_profile(float* ms, double* flops, int32_t* launches) {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct EncWs {
-  char *x, *h, *qkv, *act;
+  char *x, *h, *qkv, *act;    // x: the bf16 residual stream, or (precise_stream) the bf16 A operand bf16(x32 * gamma_next) of the next projection
   char *xr, *ar, *hr, *actr;  // compact [n_seqs, .] buffers of the pooled tail of the final layer
+  float *x32, *xr32;          // precise_stream: the fp32 residual stream (and its pooled-tail rows)
   int32_t* pos;
   float *rsA, *rsB, *ssp;     // folded RMSNorm: row scales for the two norms of a layer, per-n-tile sum-of-squares partials
   size_t total;
@@ -119,6 +120,11 @@ static EncWs carve(const lrx_encoder_config* c, int64_t T, int64_t B, char* base
   w.ar = base + off; off += align_up((size_t)B * HM * 2, 1024);
   w.hr = base + off; off += align_up((size_t)B * H * 2, 1024);
   w.actr = base + off; off += align_up((size_t)B * I * 2, 1024);
+  w.x32 = w.xr32 = nullptr;
+  if (c->precise_stream) {
+    w.x32 = (float*)(base + off); off += align_up((size_t)T * H * 4, 1024);
+    w.xr32 = (float*)(base + off); off += align_up((size_t)B * H * 4, 1024);
+  }
   w.total = off;
   return w;
 }
@@ -136,62 +142,100 @@ static int check_cfg(const lrx_encoder_config* c) {
   LRX_CHECK_ARG(c->head_dim == 64 || c->head_dim == 128, "encode: head_dim=%d unsupported", c->head_dim);
   LRX_CHECK_ARG(c->num_kv_heads > 0 && c->num_q_heads % c->num_kv_heads == 0, "encode: bad head counts %d/%d", c->num_q_heads, c->num_kv_heads);
   LRX_CHECK_ARG(c->num_layers > 0 && c->vocab_size > 0 && c->max_positions > 0, "encode: bad config");
+  LRX_CHECK_ARG(!(c->precise_stream && c->norm_folded), "encode: precise_stream keeps the norm weight on the activation operand -- pass the unfolded weights (norm_folded = 0)");
   return LRX_OK;
 }
 
-// runs embedding + all layers; leaves the residual stream (before the final norm) in ws.x -- or, with pooled_tail, only
-// the n_seqs last-token rows of it, compacted, in ws.xr: after the final layer's attention nothing but those rows
-// reaches the pooled output, so its O-projection and MLP run on [n_seqs, H] instead of [T, H] (bit-identical rows).
-static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu, int n_seqs,
-                          int T, int max_seqlen, EncWs& ws, bool pooled_tail, hipStream_t s) {
+// What differs between the callers of the layer loop: the attention step (varlen causal over the batch; the same restricted to each sequence's
+// last q tile; suffix queries over a captured prefix) and an optional hook between the QKV projection and the attention (the shared-prefix
+// pass copies K|V out there; returning 1 stops the loop: nothing after the last layer's K/V is needed from the prefix).
+struct LayerHooks {
+  // attention of layer l over ws.qkv -> ws.h; last_tile: only each sequence's last 64-row q tile is needed
+  int (*attn)(void* ctx, int l, bool last_tile, hipStream_t s);
+  int (*after_qkv)(void* ctx, int l, hipStream_t s);   // may be NULL
+  void* ctx;
+  double attn_flops;            // per layer, for the profile
+};
+
+// Embedding + all layers over T packed tokens.  Leaves the residual stream BEFORE the final norm in ws.x (bf16) or ws.x32 (precise_stream) --
+// or, with tail_cu != NULL, only the n_tail last-token rows of it, compacted, in ws.xr / ws.xr32: after the final layer's attention nothing
+// but those rows reaches the pooled output, so its O-projection and MLP run on [n_tail, H] instead of [T, H] (bit-identical rows).
+//   norm_folded:    RMSNorm weights pre-multiplied into wqkv / wgu; the row statistic travels as a [T] fp32 scale that the consuming GEMM
+//                   applies to its fp32 accumulator, the residual GEMMs emit the sum of squares of the rows they produce.
+//   precise_stream: the residual stream is fp32 (x32), every residual GEMM also writes the next projection's bf16 A operand
+//                   bf16(x32 * gamma_next) into ws.x; weights exact, row scale on the accumulator as above.  tools/exp/rounding_budget.py:
+//                   at 32 layers the bf16 stream + folded weights cost ~1.1e-3 of the 1e-3 cosine budget against the fp32 model.
+//   neither:        HF's bf16 arithmetic (normalised activations materialised by lrx_rmsnorm).
+static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w, const int32_t* ids, int T, EncWs& ws, const LayerHooks& hk,
+                      const int32_t* tail_cu, int n_tail, hipStream_t s) {
   const int H = c->hidden_size, d = c->head_dim, nq = c->num_q_heads, nkv = c->num_kv_heads, I = c->intermediate_size;
   const int QKV = (nq + 2 * nkv) * d, QD = nq * d;
+  const bool fold = c->norm_folded != 0, precise = c->precise_stream != 0;
+  const bool scaled = fold || precise;                 // the consumer GEMM multiplies its accumulator rows by rsqrt(mean(x^2) + eps)
+  const int NP = (H + 255) / 256;                      // n-tiles of a residual GEMM (N = H)
   int rc;
-  { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, ids, T, H, c->vocab_size, ws.x, s))) return rc; }
+  if (precise) { ProfScope p(s, 6, 0); if ((rc = lrx_embed_stream32(w->embed, ids, T, H, c->vocab_size, w->layers[0].ln1, ws.x32, ws.x, ws.rsA, c->rms_eps, s))) return rc; }
+  else {
+    { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, ids, T, H, c->vocab_size, ws.x, s))) return rc; }
+    if (fold) { ProfScope p(s, 4, 0); if ((rc = lrx_row_rscale(ws.x, T, H, c->rms_eps, ws.rsA, s))) return rc; }
+  }
+  // residual GEMM: stream += A . W^T over `rows` rows (+ what the next consumer needs: the bf16 operand in precise mode, the sum of squares)
+  auto resid = [&](const void* A, const void* W, char* xb, float* x32, const void* gamma_next, bool want_next, int rows, int N, int K) -> int {
+    ProfScope p(s, 1, 2.0 * rows * (double)N * K);
+    if (precise) return lrx_gemm_bf16_nt_resid32(A, W, x32, want_next ? xb : nullptr, want_next ? gamma_next : nullptr, rows, N, K, want_next ? ws.ssp : nullptr, s);
+    return lrx_gemm_bf16_nt_fused(A, W, xb, nullptr, xb, rows, N, K, 1, nullptr, (fold && want_next) ? ws.ssp : nullptr, s);
+  };
+  for (int l = 0; l < c->num_layers; ++l) {
+    const lrx_layer_weights& L = w->layers[l];
+    const bool last = l == c->num_layers - 1;
+    if (!scaled) { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
+    { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);   // QKV projection with (row scale,) bias + RoPE fused into the epilogue
+      if ((rc = lrx_gemm_qkv_rope_fused(scaled ? ws.x : ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d,
+                                        scaled ? ws.rsA : nullptr, s))) return rc; }
+    if (hk.after_qkv) { rc = hk.after_qkv(hk.ctx, l, s); if (rc == 1) break; if (rc) return rc; }
+    if (tail_cu != nullptr && last) {
+      const int B = n_tail;
+      const double S = (double)T / (double)(B > 0 ? B : 1);
+      { ProfScope p(s, 3, hk.attn_flops * 64.0 / (S > 64.0 ? S : 64.0)); if ((rc = hk.attn(hk.ctx, l, true, s))) return rc; }
+      { ProfScope p(s, 6, 0); if ((rc = lrx_gather_last_rows(ws.h, tail_cu, B, QD, ws.ar, s))) return rc; }
+      { ProfScope p(s, 6, 0);
+        if ((rc = precise ? lrx_gather_last_rows(ws.x32, tail_cu, B, 2 * H, ws.xr32, s) : lrx_gather_last_rows(ws.x, tail_cu, B, H, ws.xr, s))) return rc; }
+      if ((rc = resid(ws.ar, L.wo, ws.xr, ws.xr32, L.ln2, true, B, H, QD))) return rc;
+      if (scaled) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, B, H, c->rms_eps, ws.rsB, s))) return rc; }
+      else { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.xr, L.ln2, ws.hr, B, H, c->rms_eps, s))) return rc; }
+      { ProfScope p(s, 2, 2.0 * B * (double)(2 * I) * H);
+        if ((rc = lrx_gemm_bf16_nt_fused(scaled ? ws.xr : ws.hr, L.wgu, ws.actr, nullptr, nullptr, B, 2 * I, H, 2, scaled ? ws.rsB : nullptr, nullptr, s))) return rc; }
+      if ((rc = resid(ws.actr, L.wdown, ws.xr, ws.xr32, nullptr, false, B, H, I))) return rc;
+      break;
+    }
+    { ProfScope p(s, 3, hk.attn_flops); if ((rc = hk.attn(hk.ctx, l, false, s))) return rc; }
+    if ((rc = resid(ws.h, L.wo, ws.x, ws.x32, L.ln2, true, T, H, QD))) return rc;
+    if (scaled) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, T, H, c->rms_eps, ws.rsB, s))) return rc; }
+    else { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, T, H, c->rms_eps, s))) return rc; }
+    { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H);
+      if ((rc = lrx_gemm_bf16_nt_fused(scaled ? ws.x : ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, scaled ? ws.rsB : nullptr, nullptr, s))) return rc; }
+    if ((rc = resid(ws.act, L.wdown, ws.x, ws.x32, last ? nullptr : w->layers[l + 1].ln1, !last, T, H, I))) return rc;
+    if (scaled && !last) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, T, H, c->rms_eps, ws.rsA, s))) return rc; }
+  }
+  return LRX_OK;
+}
+
+// the batch callers: varlen causal attention over (cu, n_seqs)
+struct BatchAttn { const lrx_encoder_config* c; EncWs* ws; const int32_t* cu; int n_seqs, T, max_seqlen; };
+static int batch_attn(void* ctx, int, bool last_tile, hipStream_t s) {
+  const BatchAttn& a = *(const BatchAttn*)ctx;
+  return lrx_attn_varlen_causal(a.ws->qkv, a.cu, a.n_seqs, a.T, a.max_seqlen, a.c->num_q_heads, a.c->num_kv_heads, a.c->head_dim, a.ws->h, last_tile ? 1 : 0, s);
+}
+static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu, int n_seqs,
+                          int T, int max_seqlen, EncWs& ws, bool pooled_tail, hipStream_t s) {
+  int rc;
   { ProfScope p(s, 6, 0); if ((rc = lrx_build_positions(cu, n_seqs, T, ws.pos, s))) return rc; }
   // causal attention flops: sum over sequences is not known on the host without a sync; use the dense upper bound for
   // equal-length batches: n_seqs * S*(S+1)/2 with S = T / n_seqs (exact when all sequences have the same length)
   const double S = (double)T / (double)(n_seqs > 0 ? n_seqs : 1);
-  const double attn_flops = 2.0 * 2.0 * d * nq * (double)n_seqs * (S * (S + 1.0) / 2.0);
-  // norm_folded: the RMSNorm weights are pre-multiplied into wqkv / wgu; the row statistic travels as a [T] fp32 scale that the
-  // consuming GEMM applies to its fp32 accumulator, and the residual GEMMs emit the sum of squares of the rows they produce
-  // (per n-tile partials, summed in fixed order) -- the normalised activations are never written or re-read.
-  const bool fold = c->norm_folded != 0;
-  const int NP = (H + 255) / 256;   // n-tiles of a residual GEMM (N = H)
-  if (fold) { ProfScope p(s, 4, 0); if ((rc = lrx_row_rscale(ws.x, T, H, c->rms_eps, ws.rsA, s))) return rc; }
-  for (int l = 0; l < c->num_layers; ++l) {
-    const lrx_layer_weights& L = w->layers[l];
-    const bool last = l == c->num_layers - 1;
-    if (!fold) { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
-    { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);   // QKV projection with (row scale,) bias + RoPE fused into the epilogue
-      if ((rc = lrx_gemm_qkv_rope_launch(fold ? ws.x : ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, w->rope_cs_bf16, T, H, nq, nkv,
-                                        d, fold ? ws.rsA : nullptr, s))) return rc; }
-    if (pooled_tail && last) {
-      const int B = n_seqs;
-      { ProfScope p(s, 3, attn_flops * 64.0 / (S > 64.0 ? S : 64.0)); if ((rc = lrx_attn_varlen_causal(ws.qkv, cu, n_seqs, T, max_seqlen, nq, nkv, d, ws.h, 1, s))) return rc; }
-      { ProfScope p(s, 6, 0); if ((rc = lrx_gather_last_rows(ws.h, cu, B, QD, ws.ar, s))) return rc; }
-      { ProfScope p(s, 6, 0); if ((rc = lrx_gather_last_rows(ws.x, cu, B, H, ws.xr, s))) return rc; }
-      { ProfScope p(s, 1, 2.0 * B * (double)H * QD);
-        if ((rc = lrx_gemm_bf16_nt_fused(ws.ar, L.wo, ws.xr, nullptr, ws.xr, B, H, QD, 1, nullptr, fold ? ws.ssp : nullptr, s))) return rc; }
-      if (fold) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, B, H, c->rms_eps, ws.rsB, s))) return rc; }
-      else { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.xr, L.ln2, ws.hr, B, H, c->rms_eps, s))) return rc; }
-      { ProfScope p(s, 2, 2.0 * B * (double)(2 * I) * H);
-        if ((rc = lrx_gemm_bf16_nt_fused(fold ? ws.xr : ws.hr, L.wgu, ws.actr, nullptr, nullptr, B, 2 * I, H, 2, fold ? ws.rsB : nullptr, nullptr, s))) return rc; }
-      { ProfScope p(s, 1, 2.0 * B * (double)H * I); if ((rc = lrx_gemm_bf16_nt(ws.actr, L.wdown, ws.xr, nullptr, ws.xr, B, H, I, 1, s))) return rc; }
-      break;
-    }
-    { ProfScope p(s, 3, attn_flops); if ((rc = lrx_attn_varlen_causal(ws.qkv, cu, n_seqs, T, max_seqlen, nq, nkv, d, ws.h, 0, s))) return rc; }
-    { ProfScope p(s, 1, 2.0 * T * (double)H * QD);
-      if ((rc = lrx_gemm_bf16_nt_fused(ws.h, L.wo, ws.x, nullptr, ws.x, T, H, QD, 1, nullptr, fold ? ws.ssp : nullptr, s))) return rc; }
-    if (fold) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, T, H, c->rms_eps, ws.rsB, s))) return rc; }
-    else { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, T, H, c->rms_eps, s))) return rc; }
-    { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H);
-      if ((rc = lrx_gemm_bf16_nt_fused(fold ? ws.x : ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, fold ? ws.rsB : nullptr, nullptr, s))) return rc; }
-    { ProfScope p(s, 1, 2.0 * T * (double)H * I);
-      if ((rc = lrx_gemm_bf16_nt_fused(ws.act, L.wdown, ws.x, nullptr, ws.x, T, H, I, 1, nullptr, (fold && !last) ? ws.ssp : nullptr, s))) return rc; }
-    if (fold && !last) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, T, H, c->rms_eps, ws.rsA, s))) return rc; }
-  }
-  return LRX_OK;
+  BatchAttn ba = {c, &ws, cu, n_seqs, T, max_seqlen};
+  LayerHooks hk = {batch_attn, nullptr, &ba, 2.0 * 2.0 * c->head_dim * c->num_q_heads * (double)n_seqs * (S * (S + 1.0) / 2.0)};
+  return run_layers(c, w, ids, T, ws, hk, pooled_tail ? cu : nullptr, n_seqs, s);
 }
 
 static int check_call(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu, int n_seqs, int T,
@@ -211,6 +255,13 @@ static int check_call(const lrx_encoder_config* cfg, const lrx_encoder_weights* 
   return LRX_OK;
 }
 
+// final RMSNorm of all T rows of the stream -> bf16 (last_hidden_state)
+static int final_norm_rows(const lrx_encoder_config* c, const lrx_encoder_weights* w, EncWs& ws, int T, void* out, hipStream_t s) {
+  ProfScope p(s, 4, 0);
+  if (c->precise_stream) return lrx_rmsnorm_f32(ws.x32, w->final_norm, out, T, c->hidden_size, c->rms_eps, s);
+  return lrx_rmsnorm(ws.x, w->final_norm, out, T, c->hidden_size, c->rms_eps, s);
+}
+
 extern "C" int lrx_encode_packed_shard(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,
                                        int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, float* out, int64_t out_row_stride,
                                        int32_t out_dim, int32_t normalize, void* shadow_out, int64_t shadow_row_stride, int64_t shadow_row0,
@@ -224,9 +275,10 @@ extern "C" int lrx_encode_packed_shard(const lrx_encoder_config* cfg, const lrx_
   prof_begin();
   if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, true, s))) return rc;
   {
-    ProfScope p(s, 6, 0);  // ws.xr holds the compacted last-token rows -> cu_seqlens = NULL
-    if ((rc = lrx_pool_norm_shard(ws.xr, w->final_norm, nullptr, n_seqs, cfg->hidden_size, cfg->rms_eps, out, out_row_stride, out_dim, normalize,
-                                  shadow_out, shadow_row_stride, shadow_row0, row_bounds, s)))
+    ProfScope p(s, 6, 0);  // ws.xr / ws.xr32 holds the compacted last-token rows -> cu_seqlens = NULL
+    const bool pr = cfg->precise_stream != 0;
+    if ((rc = lrx_pool_norm_shard(pr ? (const void*)ws.xr32 : (const void*)ws.xr, w->final_norm, nullptr, n_seqs, cfg->hidden_size, cfg->rms_eps, out,
+                                  out_row_stride, out_dim, normalize, shadow_out, shadow_row_stride, shadow_row0, row_bounds, pr ? 1 : 0, s)))
       return rc;
   }
   return prof_end(s);
@@ -249,10 +301,7 @@ extern "C" int lrx_encode_hidden(const lrx_encoder_config* cfg, const lrx_encode
   EncWs ws = carve(cfg, total_tokens, n_seqs, (char*)workspace);
   prof_begin();
   if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, false, s))) return rc;
-  {
-    ProfScope p(s, 4, 0);
-    if ((rc = lrx_rmsnorm(ws.x, w->final_norm, hidden_out_bf16, total_tokens, cfg->hidden_size, cfg->rms_eps, s))) return rc;
-  }
+  if ((rc = final_norm_rows(cfg, w, ws, total_tokens, hidden_out_bf16, s))) return rc;
   return prof_end(s);
 }
 
@@ -270,14 +319,16 @@ extern "C" int lrx_encode_packed_sparse(const lrx_encoder_config* cfg, const lrx
   LRX_CHECK_ARG(!dense_out || (dense_dim > 0 && dense_dim <= cfg->hidden_size && dense_row_stride >= dense_dim), "encode_sparse: bad dense output spec");
   hipStream_t s = (hipStream_t)stream;
   const int H = cfg->hidden_size, V = cfg->vocab_size;
+  const bool pr = cfg->precise_stream != 0;
   EncWs ws = carve(cfg, total_tokens, n_seqs, (char*)workspace);
   prof_begin();
   if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, false, s))) return rc;
   if (dense_out) {
     ProfScope p(s, 6, 0);
-    if ((rc = lrx_pool_norm(ws.x, w->final_norm, cu_seqlens, n_seqs, H, cfg->rms_eps, dense_out, dense_row_stride, dense_dim, normalize, s))) return rc;
+    if ((rc = lrx_pool_norm_shard(pr ? (const void*)ws.x32 : (const void*)ws.x, w->final_norm, cu_seqlens, n_seqs, H, cfg->rms_eps, dense_out, dense_row_stride,
+                                  dense_dim, normalize, nullptr, 0, 0, nullptr, pr ? 1 : 0, s))) return rc;
   }
-  { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, w->final_norm, ws.h, total_tokens, H, cfg->rms_eps, s))) return rc; }
+  if ((rc = final_norm_rows(cfg, w, ws, total_tokens, ws.h, s))) return rc;
   { ProfScope p(s, 7, 2.0 * total_tokens * (double)V * H);   // positions are dead after the layers: ws.pos holds the row -> sequence map
     if ((rc = lrx_sparse_max_aggregate(ws.h, lm_head ? lm_head : w->embed, lm_head_bias, cu_seqlens, tok_mask, n_seqs, total_tokens, H, V, sparse_out,
                                        sparse_row_stride, ws.pos, s))) return rc; }
@@ -290,20 +341,9 @@ extern "C" int lrx_encode_packed_sparse(const lrx_encoder_config* cfg, const lrx
 // Shared-prefix encode (EmbeddingBag construction): n_seqs sequences = prefix (same for all) + suffix_len own tokens.
 // The prefix runs ONCE through the encoder while its per-layer K/V (post-RoPE) are captured; then only the
 // n_seqs * suffix_len suffix tokens are pushed through the layers, attending to the captured prefix K/V plus their own
-// suffix keys.  Same result as encoding every [prefix + suffix] sequence in full, (P + S2) / S2 times fewer FLOPs.
+// suffix keys.  Same result as encoding every [prefix + suffix] sequence in full, (P + S2) / S2 times fewer FLOPs.  Both passes
+// run the layer loop of the batch path (run_layers) with their own attention step.
 // ---------------------------------------------------------------------------------------------------------------
-// Pre-GEMM norm of the simple paths: with folded norm weights only the row scale is computed (the GEMM applies it), otherwise the
-// normalised rows are written to h.  Returns the GEMM's A operand and row-scale pointer.
-static int pre_norm(const lrx_encoder_config* c, const void* x, const void* ln, void* h, int rows, float* rs, hipStream_t s, const void** a_out,
-                    const float** rs_out) {
-  if (c->norm_folded) {
-    *a_out = x; *rs_out = rs;
-    return lrx_row_rscale(x, rows, c->hidden_size, c->rms_eps, rs, s);
-  }
-  *a_out = h; *rs_out = nullptr;
-  return lrx_rmsnorm(x, ln, h, rows, c->hidden_size, c->rms_eps, s);
-}
-
 struct PrefWs { EncWs e; char* kvcap; int32_t* cu; size_t total; };
 static PrefWs carve_prefixed(const lrx_encoder_config* c, int64_t P1, int64_t n_seqs, int64_t S2, char* base) {
   const int64_t T = (n_seqs * S2 > P1 ? n_seqs * S2 : P1);
@@ -318,6 +358,25 @@ static PrefWs carve_prefixed(const lrx_encoder_config* c, int64_t P1, int64_t n_
 extern "C" size_t lrx_encode_prefixed_workspace_bytes(const lrx_encoder_config* cfg, int32_t prefix_len, int32_t n_seqs, int32_t suffix_len) {
   if (!cfg) return 0;
   return carve_prefixed(cfg, prefix_len, n_seqs, suffix_len, nullptr).total;
+}
+
+struct PrefCtx { const lrx_encoder_config* c; PrefWs* pw; int P1, n_seqs, S2; };
+static int prefix_capture(void* ctx, int l, hipStream_t s) {          // K|V (post-RoPE) of the prefix tokens of layer l -> the capture buffer
+  const PrefCtx& a = *(const PrefCtx*)ctx;
+  const int d = a.c->head_dim, nq = a.c->num_q_heads, nkv = a.c->num_kv_heads;
+  const size_t KVW = (size_t)2 * nkv * d, QKV = (size_t)(nq + 2 * nkv) * d, QD = (size_t)nq * d;
+  LRX_HIP(hipMemcpy2DAsync(a.pw->kvcap + (size_t)l * a.P1 * KVW * 2, KVW * 2, a.pw->e.qkv + QD * 2, QKV * 2, KVW * 2, a.P1, hipMemcpyDeviceToDevice, s));
+  return l == a.c->num_layers - 1 ? 1 : 0;                             // nothing after the last layer's K/V is needed from the prefix
+}
+static int prefix_attn(void* ctx, int, bool, hipStream_t s) {
+  const PrefCtx& a = *(const PrefCtx*)ctx;
+  return lrx_attn_varlen_causal(a.pw->e.qkv, a.pw->cu, 1, a.P1, a.P1, a.c->num_q_heads, a.c->num_kv_heads, a.c->head_dim, a.pw->e.h, 0, s);
+}
+static int suffix_attn(void* ctx, int l, bool, hipStream_t s) {
+  const PrefCtx& a = *(const PrefCtx*)ctx;
+  const size_t KVW = (size_t)2 * a.c->num_kv_heads * a.c->head_dim;
+  return lrx_attn_prefix_suffix(a.pw->e.qkv, a.pw->kvcap + (size_t)l * a.P1 * KVW * 2, a.n_seqs, a.S2, a.P1, a.c->num_q_heads, a.c->num_kv_heads, a.c->head_dim,
+                                a.pw->e.h, s);
 }
 
 extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* prefix_ids, int32_t prefix_len,
@@ -337,48 +396,22 @@ extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_enco
   const lrx_encoder_config* c = cfg;
   PrefWs pw = carve_prefixed(c, prefix_len, n_seqs, suffix_len, (char*)workspace);
   EncWs& ws = pw.e;
-  const int H = c->hidden_size, d = c->head_dim, nq = c->num_q_heads, nkv = c->num_kv_heads, I = c->intermediate_size;
-  const int QKV = (nq + 2 * nkv) * d, QD = nq * d, KVW = 2 * nkv * d;
+  PrefCtx pc = {c, &pw, prefix_len, n_seqs, suffix_len};
   prof_begin();
   // ---- pass 1: the prefix alone (one sequence), capturing K|V of every layer
   if (prefix_len > 0) {
-    const int P1 = prefix_len;
-    if ((rc = lrx_uniform_layout(pw.cu, ws.pos, 1, P1, 0, s))) return rc;
-    if ((rc = lrx_embedding_gather(w->embed, prefix_ids, P1, H, c->vocab_size, ws.x, s))) return rc;
-    for (int l = 0; l < c->num_layers; ++l) {
-      const lrx_layer_weights& L = w->layers[l];
-      const void* a_in; const float* rs_in;
-      if ((rc = pre_norm(c, ws.x, L.ln1, ws.h, P1, ws.rsA, s, &a_in, &rs_in))) return rc;
-      if ((rc = lrx_gemm_qkv_rope_launch(a_in, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, w->rope_cs_bf16, P1, H, nq, nkv, d, rs_in, s))) return rc;
-      LRX_HIP(hipMemcpy2DAsync(pw.kvcap + (size_t)l * P1 * KVW * 2, (size_t)KVW * 2, ws.qkv + (size_t)QD * 2, (size_t)QKV * 2, (size_t)KVW * 2, P1,
-                               hipMemcpyDeviceToDevice, s));
-      if (l == c->num_layers - 1) break;   // nothing after the last layer's K/V is needed from the prefix
-      if ((rc = lrx_attn_varlen_causal(ws.qkv, pw.cu, 1, P1, P1, nq, nkv, d, ws.h, 0, s))) return rc;
-      if ((rc = lrx_gemm_bf16_nt(ws.h, L.wo, ws.x, nullptr, ws.x, P1, H, QD, 1, s))) return rc;
-      if ((rc = pre_norm(c, ws.x, L.ln2, ws.h, P1, ws.rsB, s, &a_in, &rs_in))) return rc;
-      if ((rc = lrx_gemm_bf16_nt_fused(a_in, L.wgu, ws.act, nullptr, nullptr, P1, 2 * I, H, 2, rs_in, nullptr, s))) return rc;
-      if ((rc = lrx_gemm_bf16_nt(ws.act, L.wdown, ws.x, nullptr, ws.x, P1, H, I, 1, s))) return rc;
-    }
+    if ((rc = lrx_uniform_layout(pw.cu, ws.pos, 1, prefix_len, 0, s))) return rc;
+    LayerHooks hk = {prefix_attn, prefix_capture, &pc, 0.0};
+    if ((rc = run_layers(c, w, prefix_ids, prefix_len, ws, hk, nullptr, 0, s))) return rc;
   }
   // ---- pass 2: the suffix tokens of all sequences
   const int T = n_seqs * suffix_len;
   if ((rc = lrx_uniform_layout(pw.cu, ws.pos, n_seqs, suffix_len, prefix_len, s))) return rc;
-  { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, suffix_ids, T, H, c->vocab_size, ws.x, s))) return rc; }
-  for (int l = 0; l < c->num_layers; ++l) {
-    const lrx_layer_weights& L = w->layers[l];
-    const void* a_in; const float* rs_in;
-    { ProfScope p(s, 4, 0); if ((rc = pre_norm(c, ws.x, L.ln1, ws.h, T, ws.rsA, s, &a_in, &rs_in))) return rc; }
-    { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);
-      if ((rc = lrx_gemm_qkv_rope_launch(a_in, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, w->rope_cs_bf16, T, H, nq, nkv, d, rs_in, s))) return rc; }
-    { ProfScope p(s, 3, 0);
-      if ((rc = lrx_attn_prefix_suffix(ws.qkv, pw.kvcap + (size_t)l * prefix_len * KVW * 2, n_seqs, suffix_len, prefix_len, nq, nkv, d, ws.h, s))) return rc; }
-    { ProfScope p(s, 1, 2.0 * T * (double)H * QD); if ((rc = lrx_gemm_bf16_nt(ws.h, L.wo, ws.x, nullptr, ws.x, T, H, QD, 1, s))) return rc; }
-    { ProfScope p(s, 4, 0); if ((rc = pre_norm(c, ws.x, L.ln2, ws.h, T, ws.rsB, s, &a_in, &rs_in))) return rc; }
-    { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H);
-      if ((rc = lrx_gemm_bf16_nt_fused(a_in, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, rs_in, nullptr, s))) return rc; }
-    { ProfScope p(s, 1, 2.0 * T * (double)H * I); if ((rc = lrx_gemm_bf16_nt(ws.act, L.wdown, ws.x, nullptr, ws.x, T, H, I, 1, s))) return rc; }
-  }
+  LayerHooks hk = {suffix_attn, nullptr, &pc, 0.0};
+  if ((rc = run_layers(c, w, suffix_ids, T, ws, hk, nullptr, 0, s))) return rc;
   { ProfScope p(s, 6, 0);
-    if ((rc = lrx_pool_norm(ws.x, w->final_norm, pw.cu, n_seqs, H, c->rms_eps, out, out_row_stride, out_dim, normalize, s))) return rc; }
+    const bool pr = c->precise_stream != 0;
+    if ((rc = lrx_pool_norm_shard(pr ? (const void*)ws.x32 : (const void*)ws.x, w->final_norm, pw.cu, n_seqs, c->hidden_size, c->rms_eps, out, out_row_stride,
+                                  out_dim, normalize, nullptr, 0, 0, nullptr, pr ? 1 : 0, s))) return rc; }
   return prof_end(s);
 }

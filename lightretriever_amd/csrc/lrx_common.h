@@ -85,10 +85,6 @@ static inline int64_t lrx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // that are not in the sample (every ss-th tile): n_tiles of them.
 int lrx_gemm_filter_emit_launch(const void* Xb, bool xb_tiled, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles,
                                 const float* thr, unsigned long long* cand, unsigned int* cnt, hipStream_t stream);
-// lrx_gemm.hip: fused QKV + RoPE GEMM with the optional bf16 RoPE table (cs16 = lrx_encoder_weights.rope_cs_bf16 or NULL)
-int lrx_gemm_qkv_rope_launch(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos, const float* sin,
-                             const void* cs16, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, const float* rscale,
-                             void* stream);
 // lrx_gemm.hip: the GEMM kernel with the segmented-maximum epilogue (used by lrx_sparse_max_aggregate)
 int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias, const int32_t* row_seg, float* out, int64_t ldo, int M, int N,
                                   int K, hipStream_t stream);

@@ -38,6 +38,50 @@ extern "C" int lrx_embedding_gather(const void* table, const int32_t* ids, int32
   return LRX_OK;
 }
 
+// Precise residual stream (lrx_encoder_config.precise_stream): the embedding row becomes the fp32 stream x32, the first projection's bf16 A
+// operand a16 = bf16(x * gamma) (gamma = layer 0's input_layernorm weight: the norm weight rides on the operand, the weights stay exact) and
+// the row statistic rs = rsqrt(mean(x^2) + eps).  One wave per token.
+__global__ void __launch_bounds__(256) k_embed_stream32(const bf16x8* __restrict__ table, const int32_t* __restrict__ ids, int n_tokens, int chunks,
+                                                        int vocab, const bf16x8* __restrict__ gamma, float* __restrict__ x32, bf16x8* __restrict__ a16,
+                                                        float* __restrict__ rs, float inv_h, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_tokens) return;
+  const int lane = threadIdx.x & 63;
+  const int id = ids[row];
+  const bool bad = id < 0 || id >= vocab;
+  if (bad && lane == 0) atomicAdd(&g_bad_token_ids, 1u);
+  const int64_t src = (int64_t)(bad ? 0 : id) * chunks, dst = (int64_t)row * chunks;
+  float ss = 0.f;
+  for (int c = lane; c < chunks; c += 64) {
+    bf16x8 v = table[src + c];
+    const bf16x8 g = gamma[c];
+    bf16x8 a;
+    f32x4 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = bad ? 0.f : bf2f(v[j]);
+      ss += f * f;
+      a[j] = f2bf(f * bf2f(g[j]));
+      if (j < 4) lo[j] = f; else hi[j - 4] = f;
+    }
+    *(f32x4*)(x32 + (dst + c) * 8) = lo;
+    *(f32x4*)(x32 + (dst + c) * 8 + 4) = hi;
+    a16[dst + c] = a;
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) rs[row] = rsqrtf(ss * inv_h + eps);
+}
+
+extern "C" int lrx_embed_stream32(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, int32_t vocab, const void* gamma,
+                                  float* x32, void* a16, float* rscale_out, float eps, void* stream) {
+  LRX_CHECK_ARG(hidden % 8 == 0 && n_tokens >= 0 && vocab > 0 && gamma && x32 && a16 && rscale_out, "embed_stream32: bad operand");
+  if (n_tokens == 0) return LRX_OK;
+  hipLaunchKernelGGL(k_embed_stream32, dim3(lrx_cdiv(n_tokens, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)table, ids, n_tokens, hidden / 8,
+                     vocab, (const bf16x8*)gamma, x32, (bf16x8*)a16, rscale_out, 1.0f / (float)hidden, eps);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
 extern "C" int64_t lrx_device_error_count(int32_t reset) {
   unsigned int v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bad_token_ids), sizeof(v)) != hipSuccess) return -1;
@@ -90,6 +134,39 @@ extern "C" int lrx_rmsnorm(const void* x, const void* w, void* y, int32_t rows, 
   if (rows == 0) return LRX_OK;
   hipLaunchKernelGGL(k_rmsnorm, dim3(lrx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, (const bf16x8*)w,
                      (bf16x8*)y, rows, hidden / 8, 1.0f / (float)hidden, eps);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// The same statistic on an fp32 row (the precise residual stream), ONE rounding: y = bf16(w * x * rsqrt(mean(x^2) + eps)).
+__global__ void __launch_bounds__(256) k_rmsnorm_f32(const float* __restrict__ x, const __bf16* __restrict__ w, __bf16* __restrict__ y, int rows, int H,
+                                                     float inv_h, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + (int64_t)row * H;
+  float ss = 0.f;
+  for (int i = lane * 4; i < H; i += 256) {
+    const f32x4 v = *(const f32x4*)(xr + i);
+    ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss * inv_h + eps);
+  for (int i = lane * 4; i < H; i += 256) {
+    const f32x4 v = *(const f32x4*)(xr + i);
+    const bf16x4 wv = *(const bf16x4*)(w + i);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(wv[e]) * (v[e] * rstd));
+    *(bf16x4*)(y + (int64_t)row * H + i) = o;
+  }
+}
+
+extern "C" int lrx_rmsnorm_f32(const float* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps, void* stream) {
+  LRX_CHECK_ARG(hidden % 4 == 0 && x && w && y, "rmsnorm_f32: bad operand (hidden=%d)", hidden);
+  if (rows == 0) return LRX_OK;
+  hipLaunchKernelGGL(k_rmsnorm_f32, dim3(lrx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, (const __bf16*)w, (__bf16*)y, rows, hidden,
+                     1.0f / (float)hidden, eps);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -177,50 +254,6 @@ extern "C" int lrx_uniform_layout(int32_t* cu_seqlens, int32_t* positions, int32
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// RoPE in place on the q | k column blocks of qkv [T, (nq + 2nkv) * d].  One thread = 8 elements of the first half of a
-// head and the 8 paired elements of the second half.  cos/sin are the bf16-rounded table values (HF casts them to the
-// activation dtype); the rotation itself is done in fp32 and rounded once.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_rope(bf16x8* __restrict__ qkv, const int32_t* __restrict__ pos, const float* __restrict__ cosT,
-                                              const float* __restrict__ sinT, int total, int rot_heads /* nq + nkv */, int row_chunks,
-                                              int half_chunks /* d/16 */) {
-  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int per_tok = rot_heads * half_chunks;
-  int64_t t = gid / per_tok;
-  if (t >= total) return;
-  int rem = (int)(gid - t * per_tok);
-  int head = rem / half_chunks, c = rem - head * half_chunks;
-  int p = pos[t];
-  int64_t base = t * row_chunks + (int64_t)head * (2 * half_chunks);
-  bf16x8 x1 = qkv[base + c], x2 = qkv[base + half_chunks + c];
-  const float* cs = cosT + (int64_t)p * (half_chunks * 8) + c * 8;
-  const float* sn = sinT + (int64_t)p * (half_chunks * 8) + c * 8;
-  bf16x8 o1, o2;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float a = bf2f(x1[j]), b = bf2f(x2[j]), cc = cs[j], ss = sn[j];
-    o1[j] = f2bf(a * cc - b * ss);
-    o2[j] = f2bf(b * cc + a * ss);
-  }
-  qkv[base + c] = o1;
-  qkv[base + half_chunks + c] = o2;
-}
-
-extern "C" int lrx_rope_inplace(void* qkv, const int32_t* positions, const float* cos, const float* sin, int32_t total_tokens,
-                                int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* stream) {
-  LRX_CHECK_ARG(head_dim % 16 == 0, "rope: head_dim %% 16 != 0");
-  if (total_tokens == 0) return LRX_OK;
-  int rot_heads = num_q_heads + num_kv_heads;
-  int row_chunks = (num_q_heads + 2 * num_kv_heads) * head_dim / 8;
-  int half_chunks = head_dim / 16;
-  int64_t threads = (int64_t)total_tokens * rot_heads * half_chunks;
-  hipLaunchKernelGGL(k_rope, dim3(lrx_cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, (bf16x8*)qkv, positions, cos, sin,
-                     total_tokens, rot_heads, row_chunks, half_chunks);
-  LRX_LAUNCH_CHECK();
-  return LRX_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // last-token pool + final RMSNorm (on the pooled rows only) + MRL slice + L2 normalise -> fp32 row.
 // One 256-thread block per sequence.  Row cached in LDS as fp32.
 // ---------------------------------------------------------------------------------------------------------------
@@ -236,7 +269,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // shadow != NULL: the row also goes out as bf16 (RNE) -- the filter pass of the search streams that copy; bounds != NULL: the two
 // shard bounds {max |row|, max |row - bf16(row)|} are raised by integer atomic max on the (non-negative) float patterns: the result
 // does not depend on the order rows arrive in.  This is the index maintenance of FlatIPIndex.commit fused into the row's producer.
-__global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hidden, const __bf16* __restrict__ w,
+// F32: `hidden` holds fp32 rows (the precise residual stream): the final norm then runs in fp32 without the two bf16 roundings of HF's
+// bf16 LlamaRMSNorm (the reference for the 1e-3 bound is the fp32 model).
+template <bool F32>
+__global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidden_v, const __bf16* __restrict__ w,
                                                    const int32_t* __restrict__ cu, int H, float eps, float* __restrict__ out,
                                                    int64_t out_stride, int out_dim, int normalize, __bf16* __restrict__ shadow,
                                                    int64_t shadow_stride, int64_t shadow_row0, float* __restrict__ bounds) {
@@ -245,14 +281,18 @@ __global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hi
   float* red = row + H;           // 4 floats
   int b = blockIdx.x;
   int64_t t = cu ? (int64_t)cu[b + 1] - 1 : (int64_t)b;
-  const __bf16* x = hidden + t * H;
   float ss = 0.f;
-  for (int i = threadIdx.x; i < H; i += 256) { float f = bf2f(x[i]); row[i] = f; ss += f * f; }
+  for (int i = threadIdx.x; i < H; i += 256) {
+    const float f = F32 ? ((const float*)hidden_v)[t * H + i] : bf2f(((const __bf16*)hidden_v)[t * H + i]);
+    row[i] = f;
+    ss += f * f;
+  }
   ss = block_sum_256(ss, red);
   float rstd = rsqrtf(ss / (float)H + eps);
   float n2 = 0.f;
   for (int i = threadIdx.x; i < out_dim; i += 256) {
-    float y = bf2f(f2bf(bf2f(w[i]) * bf2f(f2bf(row[i] * rstd))));  // HF LlamaRMSNorm rounding order, bf16 result
+    float y = F32 ? bf2f(w[i]) * (row[i] * rstd)
+                  : bf2f(f2bf(bf2f(w[i]) * bf2f(f2bf(row[i] * rstd))));  // HF LlamaRMSNorm rounding order, bf16 result
     row[i] = y;
     n2 += y * y;
   }
@@ -285,15 +325,19 @@ __global__ void __launch_bounds__(256) k_pool_norm(const __bf16* __restrict__ hi
 
 extern "C" int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                                    int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize,
-                                   void* shadow_out, int64_t shadow_row_stride, int64_t shadow_row0, float* row_bounds, void* stream) {
+                                   void* shadow_out, int64_t shadow_row_stride, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32,
+                                   void* stream) {
   LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden_size, "pool_norm: out_dim=%d out of range (H=%d)", out_dim, hidden_size);
   LRX_CHECK_ARG(shadow_out == nullptr || shadow_row_stride >= out_dim || (shadow_row_stride == 0 && out_dim % 64 == 0 && shadow_row0 >= 0),
                 "pool_norm: bad shadow layout (row stride %lld, out_dim %d)", (long long)shadow_row_stride, out_dim);
   if (n_seqs == 0) return LRX_OK;
   size_t smem = (size_t)(hidden_size + 4) * sizeof(float);
-  hipLaunchKernelGGL(k_pool_norm, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, (const __bf16*)hidden, (const __bf16*)final_norm_w,
-                     cu_seqlens, hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row_stride, shadow_row0,
-                     row_bounds);
+  if (hidden_f32)
+    hipLaunchKernelGGL(k_pool_norm<true>, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, hidden, (const __bf16*)final_norm_w, cu_seqlens,
+                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row_stride, shadow_row0, row_bounds);
+  else
+    hipLaunchKernelGGL(k_pool_norm<false>, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, hidden, (const __bf16*)final_norm_w, cu_seqlens,
+                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row_stride, shadow_row0, row_bounds);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -302,7 +346,7 @@ extern "C" int lrx_pool_norm(const void* hidden, const void* final_norm_w, const
                              int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize,
                              void* stream) {
   return lrx_pool_norm_shard(hidden, final_norm_w, cu_seqlens, n_seqs, hidden_size, eps, out, out_row_stride, out_dim, normalize, nullptr, 0,
-                             0, nullptr, stream);
+                             0, nullptr, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -31,16 +31,24 @@
 #define GBK 64
 #define HALF_BYTES 16384
 
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE = 3, EPI_MAXAGG = 4, EPI_EMIT = 5 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE = 3, EPI_MAXAGG = 4, EPI_EMIT = 5, EPI_RESID32 = 6 };
 
+// Fused QKV epilogue (EPI_ROPE, round 3): the rows of the q and k heads of Wqkv arrive in ROTARY-PAIR order (include/lrx.h: physical
+// column 32 g + 16 i + t of a head = logical column i d/2 + 16 g + t), so the two accumulators a lane holds for a 16 x 32 block -- columns
+// t and 16 + t of the block -- ARE a rotary pair (x_j, x_{j + d/2}): the rotation runs on the fp32 accumulators with the fp32 cos/sin
+// table, one rounding, no partner read from the staged tile, and the result is stored as FP16 in the same pair order (q . k does not
+// care about a permutation of the head dimension common to both).  v columns: plain fp16 store.
 struct RopeArgs {
   const int32_t* positions;  // [M]
-  const float* cos;          // [max_pos, d/2]
+  const float* cos;          // [max_pos, d/2] fp32
   const float* sin;
   int rope_cols;             // columns [0, rope_cols) are q|k heads to rotate; the rest (v) is stored as is
   int head_dim;
-  const __bf16* cs16;        // optional: the same table values as bf16, [max_pos, head_dim] = cos | sin per row (half the table bytes)
 };
+
+__device__ __forceinline__ __bf16 f2h_bits(float v) {   // fp16 (saturating) in the kernel's 16-bit container type
+  return __builtin_bit_cast(__bf16, (_Float16)fminf(fmaxf(v, -65504.f), 65504.f));
+}
 
 // Search filter pass (EPI_EMIT): A = bf16 shadow rows of the shard, B = bf16 queries; no C.  A score reaching thr[query] is appended
 // to the query's candidate list (lrx_search.hip).  ss > 0: m-tile t of the launch is the t-th 256-row tile that is NOT in the sample
@@ -194,6 +202,12 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     for (int mi = 0; mi < 4; ++mi)
       rsv[h][mi] = (EPI != EPI_MAXAGG && EPI != EPI_RESID && EPI != EPI_EMIT && nrm.rscale != nullptr) ? nrm.rscale[min(m0 + h * 128 + wr * 64 + mi * 16 + fr, M - 1)] : 1.0f;
 
+  int rposv[2][4];             // EPI_ROPE: positions of this lane's 8 rows (the table lookups of the epilogue depend on them)
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) rposv[h][mi] = EPI == EPI_ROPE ? rope.positions[min(m0 + h * 128 + wr * 64 + mi * 16 + fr, M - 1)] : 0;
+
   const int nk = K / GBK;
   // ---- prologue: K-tile 0 landed, K-tile 1 (issued in the steady-state order A0,B0,B1 then A1) stays in flight
   G_ISSUE(pA0, 0, 0, 0); G_ISSUE(pB1, 3, 0, 0); G_ISSUE(pA1, 1, 0, 0); G_ISSUE(pB0, 2, 0, 0);
@@ -315,6 +329,73 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     }
     return;
   }
+  if constexpr (EPI == EPI_RESID32) {
+    // ---- precise residual stream: x32[m, n] += acc (fp32 in, fp32 out, ONE rounding: to fp32), a16[m, n] = bf16(x32 * gamma[n]) = the
+    //      next projection's bf16 A operand (the RMSNorm weight rides on the operand, the weights stay exact; the row scale is applied to
+    //      the consumer's accumulator as in the folded path), ss_part = sum of squares of the fp32 row.  `resid` = x32 (in/out), C = a16
+    //      (may be NULL), `bias` = gamma (bf16 [N], NULL = 1).  The fp32 tile is staged through LDS in two 128-row passes (128 KiB each):
+    //      16-B chunk index XOR ((row & 15) << 2) keeps the accumulator-layout writes and the row-major reads conflict-free; one wave
+    //      instruction of the read-out covers one whole 1-KiB row segment (x32 read + write) and 512 B of a16.
+    float* x32 = (float*)resid;
+    const int nq4 = n0 + lane * 4;                       // this lane's four columns in every read-out iteration
+    const bool nin = nq4 < N;
+    float gm[4] = {1.f, 1.f, 1.f, 1.f};
+    if (bias != nullptr && nin) {
+      const bf16x4 g4 = *(const bf16x4*)(bias + nq4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gm[e] = bf2f(g4[e]);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f32x4 rv[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int m = m0 + p * 128 + it * 8 + wave;
+        rv[it] = (m < M && nin) ? *(const f32x4*)(x32 + (int64_t)m * N + nq4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (p) __syncthreads();                            // the previous pass has been read out
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const int row = wr * 64 + mi * 16 + fr, chunk = hp * 32 + wc * 8 + ni * 4 + fq;
+            *(f32x4*)(smem + row * 1024 + ((chunk ^ ((row & 15) << 2)) << 4)) = acc[p][hp][mi][ni];
+          }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 8 + wave, m = m0 + p * 128 + row;
+        f32x4 v = *(const f32x4*)(smem + row * 1024 + ((lane ^ ((row & 15) << 2)) << 4));
+        const bool inb = m < M && nin;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rv[it][e];
+        if (inb) {
+          *(f32x4*)(x32 + (int64_t)m * N + nq4) = v;
+          if (C != nullptr) {
+            bf16x4 a4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a4[e] = f2bf(v[e] * gm[e]);
+            *(bf16x4*)(C + (int64_t)m * N + nq4) = a4;
+          }
+        }
+        if (nrm.ss_part != nullptr) {
+          // sum of squares of the row's 256 columns: fixed order inside the lane, then a fixed DPP tree over the wave (rotations
+          // inside the 16-lane rows, row_bcast:15 / :31 across them): lane 63 holds the total, the same bits in every run
+          float ssq = inb ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.f;
+          ssq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssq), 0x128, 0xF, 0xF, true));   // row_ror:8
+          ssq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssq), 0x124, 0xF, 0xF, true));   // row_ror:4
+          ssq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssq), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+          ssq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssq), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+          ssq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssq), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+          ssq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssq), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+          if (lane == 63 && m < M) nrm.ss_part[(int64_t)tn * M + m] = ssq;
+        }
+      }
+    }
+    return;
+  }
   constexpr int CW = (EPI == EPI_SWIGLU) ? 128 : 256;  // output columns of this tile
   constexpr int CPR = CW / 8;                          // 16-B chunks per staged row
   constexpr int NIT = (256 * CPR) / 512;
@@ -353,16 +434,46 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
           }
           const int col = hp * 64 + wc * 16 + fq * 4;  // within the 128-column output tile
           *(bf16x4*)(smem + row * (CW * 2) + ((((col >> 3) ^ (row & 15)) << 4) | ((col & 4) << 1))) = o;
+        } else if (EPI == EPI_ROPE) {
+          // the lane's rotary pair of this 32-column block: x1 = block columns fq*4 + r (logical j), x2 = 16 + fq*4 + r (logical j + d/2)
+          const int cb = hp * 128 + wc * 32;                       // block's first column inside the tile
+          const bool rot = n0 + cb < rope.rope_cols;               // (wave-uniform: q|k blocks rotate, v blocks do not)
+          f32x4 x1 = acc[h][hp][mi][0], x2 = acc[h][hp][mi][1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { x1[r] *= rs; x2[r] *= rs; }
+          if (bias != nullptr) {
+            const int nb = min(n0 + cb + fq * 4, N - 20);
+            const bf16x4 b1 = *(const bf16x4*)(bias + nb), b2 = *(const bf16x4*)(bias + nb + 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x1[r] += bf2f(b1[r]); x2[r] += bf2f(b2[r]); }
+          }
+          if (rot) {
+            const int rhalf = rope.head_dim >> 1;
+            const int j = (((n0 + cb) % rope.head_dim) >> 5) * 16 + fq * 4;
+            const f32x4 cc = *(const f32x4*)(rope.cos + (int64_t)rposv[h][mi] * rhalf + j), sn = *(const f32x4*)(rope.sin + (int64_t)rposv[h][mi] * rhalf + j);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a = x1[r], b = x2[r];
+              x1[r] = a * cc[r] - b * sn[r];
+              x2[r] = b * cc[r] + a * sn[r];
+            }
+          }
+          bf16x4 o1, o2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { o1[r] = f2h_bits(x1[r]); o2[r] = f2h_bits(x2[r]); }
+          const int c1 = cb + fq * 4, c2 = c1 + 16;
+          *(bf16x4*)(smem + row * (CW * 2) + ((((c1 >> 3) ^ (row & 15)) << 4) | ((c1 & 4) << 1))) = o1;
+          *(bf16x4*)(smem + row * (CW * 2) + ((((c2 >> 3) ^ (row & 15)) << 4) | ((c2 & 4) << 1))) = o2;
         } else {
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             const int col = hp * 128 + wc * 32 + ni * 16 + fq * 4;
             f32x4 v = acc[h][hp][mi][ni];
-            if (EPI == EPI_STORE || EPI == EPI_ROPE) {
+            if (EPI == EPI_STORE) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] *= rs;
             }
-            if ((EPI == EPI_STORE || EPI == EPI_ROPE) && bias != nullptr) {
+            if (EPI == EPI_STORE && bias != nullptr) {
               const int n = min(n0 + col, N - 4);
               bf16x4 bv = *(const bf16x4*)(bias + n);
 #pragma unroll
@@ -435,46 +546,9 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   }
   const int ldc = (EPI == EPI_SWIGLU) ? (N >> 1) : N;
   const int c0 = (EPI == EPI_SWIGLU) ? (n0 >> 1) : n0;
-  int rpos[EPI == EPI_ROPE ? NIT : 1];
-  if (EPI == EPI_ROPE) {   // positions of this thread's rows, loaded up front (the cos/sin lookups depend on them)
+  {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) rpos[it] = rope.positions[min(m0 + (it * 512 + tid) / CPR, M - 1)];
-  }
-  // RoPE: this thread's column chunk (hence its rotary pair and table offset j) is the same in every iteration; the cos/sin rows of
-  // eight iterations are requested together before the first is used (one dependent L2 round trip per iteration cost 6.6 us per tile)
-  constexpr int RBATCH = (EPI == EPI_ROPE) ? 8 : NIT;
-  const int rn = c0 + (tid % CPR) * 8;
-  const bool rot = EPI == EPI_ROPE && rn < rope.rope_cols;
-  const int rhalf = rope.head_dim >> 1;
-  const int rwithin = rn % rope.head_dim;
-  const bool rfirst = rwithin < rhalf;
-  const int rj = rot ? (rfirst ? rwithin : rwithin - rhalf) : 0;
-#pragma unroll
-  for (int it0 = 0; it0 < NIT; it0 += RBATCH) {
-  f32x4 rcs[EPI == EPI_ROPE ? RBATCH : 1][4];
-  if (EPI == EPI_ROPE) {
-    if (rope.cs16 != nullptr) {        // bf16 table rows [cos | sin]: two 16-B loads per 8 outputs instead of four
-#pragma unroll
-      for (int u = 0; u < RBATCH; ++u) {
-        const __bf16* cs = rope.cs16 + (int64_t)rpos[it0 + u] * rope.head_dim + rj;
-        const bf16x8 c8 = *(const bf16x8*)cs, s8 = *(const bf16x8*)(cs + rhalf);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          rcs[u][0][e] = bf2f(c8[e]); rcs[u][1][e] = bf2f(c8[4 + e]); rcs[u][2][e] = bf2f(s8[e]); rcs[u][3][e] = bf2f(s8[4 + e]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < RBATCH; ++u) {
-        const float* cs = rope.cos + (int64_t)rpos[it0 + u] * rhalf + rj;
-        const float* sn = rope.sin + (int64_t)rpos[it0 + u] * rhalf + rj;
-        rcs[u][0] = *(const f32x4*)cs; rcs[u][1] = *(const f32x4*)(cs + 4); rcs[u][2] = *(const f32x4*)sn; rcs[u][3] = *(const f32x4*)(sn + 4);
-      }
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < RBATCH; ++u) {
-    const int it = it0 + u;
+  for (int it = 0; it < NIT; ++it) {
     const int q = it * 512 + tid;
     const int row = q / CPR, ch = q % CPR;
     const int m = m0 + row, n = c0 + ch * 8;
@@ -501,21 +575,9 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
         if (!inb) continue;
       }
     }
-    if (EPI == EPI_ROPE && rot) {
-      // rotary embedding on the staged bf16 q|k values (same arithmetic as k_rope): the rotate_half partner sits half a
-      // head away in the same staged row (heads never straddle a 256-column tile: head_dim divides 256)
-      const int pch = ch + (rfirst ? (rhalf >> 3) : -(rhalf >> 3));
-      bf16x8 pv = *(const bf16x8*)(smem + row * (CW * 2) + ((pch ^ (row & 15)) << 4));
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float a = bf2f(v[e]), b = bf2f(pv[e]);
-        const float cc = e < 4 ? rcs[u][0][e & 3] : rcs[u][1][e & 3], ss = e < 4 ? rcs[u][2][e & 3] : rcs[u][3][e & 3];
-        v[e] = f2bf(rfirst ? a * cc - b * ss : a * cc + b * ss);
-      }
-    }
     *(bf16x8*)(C + (int64_t)m * ldc + n) = v;
   }
-  }  // it0 batches
+  }
 }
 
 // m-tiles per group of the block -> tile map, per epilogue class (measured, see the kernel); LRX_GEMM_GM overrides it for sweeps
@@ -548,7 +610,7 @@ extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, con
   hipStream_t s = (hipStream_t)stream;
   const __bf16 *a = (const __bf16*)A, *b = (const __bf16*)B, *bi = (const __bf16*)bias, *re = (const __bf16*)resid;
   __bf16* c = (__bf16*)C;
-  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, nullptr};
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   MaxAggArgs nomx = {nullptr, nullptr, 0};
   NormArgs nrm = {rscale, ss_part, gemm_group_m(epilogue, K)};
   switch (epilogue) {
@@ -569,23 +631,33 @@ extern "C" int lrx_gemm_qkv_rope(const void* A, const void* Wqkv, void* C, const
 extern "C" int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos,
                                        const float* sin, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
                                        const float* rscale, void* stream) {
-  return lrx_gemm_qkv_rope_launch(A, Wqkv, C, bias, positions, cos, sin, nullptr, M, K, num_q_heads, num_kv_heads, head_dim, rscale, stream);
-}
-
-// (internal) the same with the optional bf16 table of lrx_encoder_weights.rope_cs_bf16
-int lrx_gemm_qkv_rope_launch(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos, const float* sin,
-                             const void* cs16, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, const float* rscale,
-                             void* stream) {
   const int N = (num_q_heads + 2 * num_kv_heads) * head_dim;
   LRX_CHECK_ARG(M >= 0 && K > 0 && K % GBK == 0, "gemm_qkv_rope: bad shape M=%d K=%d", M, K);
   LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "gemm_qkv_rope: head_dim=%d unsupported", head_dim);
   LRX_CHECK_ARG(positions && cos && sin, "gemm_qkv_rope: null rope inputs");
   if (M == 0) return LRX_OK;
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
-  RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim, (const __bf16*)cs16};
+  RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)Wqkv,
                      (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0},
                      NormArgs{rscale, nullptr, 8}, EmitArgs{nullptr, nullptr, nullptr, 0, 0});
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// x32[M, N] (fp32, in place) += A[M, K] . B[N, K]^T; a16_out[M, N] (bf16, optional) = bf16(x32 * gamma[n]) (gamma bf16 [N], NULL = 1);
+// ss_part (optional) [ceil(N / 256), M]: sum of squares of the new fp32 row per 256-column tile.  The precise residual stream of deep
+// backbones (lrx_encoder_config.precise_stream).
+extern "C" int lrx_gemm_bf16_nt_resid32(const void* A, const void* B, float* x32, void* a16_out, const void* gamma, int32_t M, int32_t N, int32_t K,
+                                        float* ss_part, void* stream) {
+  LRX_CHECK_ARG(M >= 0 && N > 0 && K > 0 && K % GBK == 0 && N % 8 == 0, "gemm_resid32: bad shape M=%d N=%d K=%d", M, N, K);
+  LRX_CHECK_ARG(x32 != nullptr, "gemm_resid32: null residual stream");
+  if (M == 0) return LRX_OK;
+  int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID32>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)B,
+                     (__bf16*)a16_out, (const __bf16*)gamma, (const __bf16*)x32, M, N, K, tiles_m, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
+                     NormArgs{nullptr, ss_part, gemm_group_m(EPI_RESID, K)}, EmitArgs{nullptr, nullptr, nullptr, 0, 0});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -600,7 +672,7 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   LRX_CHECK_ARG(row_seg && out && ldo >= N, "max_aggregate: bad output spec");
   if (M == 0) return LRX_OK;
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
-  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, nullptr};
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   MaxAggArgs mx = {row_seg, out, ldo};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
                      (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, LRX_MAXAGG_GM},
@@ -618,7 +690,7 @@ int lrx_gemm_filter_emit_launch(const void* Xb, bool xb_tiled, const void* q16, 
   LRX_CHECK_ARG(dim > 0 && dim % GBK == 0 && nq > 0 && nq <= GBN && n_rows < (1ll << 31), "filter_emit: bad shape rows=%lld nq=%d dim=%d",
                 (long long)n_rows, nq, dim);
   if (n_tiles <= 0) return LRX_OK;
-  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, nullptr};
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_EMIT>, dim3((unsigned)n_tiles), dim3(512), 0, stream, (const __bf16*)Xb, (const __bf16*)q16, (__bf16*)nullptr,
                      (const __bf16*)nullptr, (const __bf16*)nullptr, (int)n_rows, nq, dim, (int)n_tiles, 1, none, MaxAggArgs{nullptr, nullptr, 0},
                      NormArgs{nullptr, nullptr, 8}, EmitArgs{thr, cand, cnt, ss, xb_tiled ? 1 : 0});

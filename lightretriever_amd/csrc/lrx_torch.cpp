@@ -3,6 +3,7 @@
 // (Python RuntimeError).  Every op forwards to exactly one lrx_* entry point of liblrx.so; no arithmetic lives here.
 // Built by lightretriever_amd/build.py into lightretriever_amd/liblrx_torch.so (next to liblrx.so, rpath $ORIGIN).
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -10,6 +11,9 @@
 
 namespace {
 
+// every op first makes the device of its first tensor current (getCurrentHIPStream() belongs to the CURRENT device, which need
+// not be the tensors' device) and then takes that device's current stream
+using DevGuard = c10::hip::OptionalHIPGuardMasqueradingAsCUDA;
 void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
 
 void lrx_check(int rc, const char* what) { TORCH_CHECK(rc == LRX_OK, what, ": liblrx error ", rc, ": ", lrx_last_error()); }
@@ -25,8 +29,12 @@ at::Tensor bytes(int64_t n, const at::Tensor& like) { return at::empty({n}, like
 
 // ---- encoder ---------------------------------------------------------------------------------------------------------------------
 // weights: the address of an lrx_encoder_handle {cfg*, weights*} kept alive by its owner (LrxEncoder.handle)
+// shadow / row_bounds (optional): `out` = rows [shadow_row0, ...) of an index shard -- the last kernel also writes their tiled shadow rows and
+// raises the shard's bounds (lrx_encode_packed_shard), like the ctypes path does for a live FlatIPIndex slot.  Without them a caller that
+// encodes into committed shard rows must run shard_commit_rows afterwards.
 void encode_packed(const at::Tensor& ids, const at::Tensor& cu_seqlens, int64_t max_seqlen, int64_t weights, at::Tensor out, int64_t mrl_dim,
-                   bool normalize) {
+                   bool normalize, const c10::optional<at::Tensor>& shadow, int64_t shadow_row0, const c10::optional<at::Tensor>& row_bounds) {
+  DevGuard guard(ids.device());
   need(ids, "ids", at::kInt, 1);
   need(cu_seqlens, "cu_seqlens", at::kInt, 1);
   need(out, "out", at::kFloat, 2);
@@ -37,13 +45,28 @@ void encode_packed(const at::Tensor& ids, const at::Tensor& cu_seqlens, int64_t 
   TORCH_CHECK(out.size(0) >= B && out.size(1) >= D, "encode_packed: out must be fp32 [>= n_seqs, >= mrl_dim]");
   const size_t need_b = lrx_encode_workspace_bytes(h->cfg, (int32_t)T, (int32_t)B);
   at::Tensor ws = bytes((int64_t)need_b, ids);
-  lrx_check(lrx_encode_packed(h->cfg, h->w, ids.data_ptr<int32_t>(), cu_seqlens.data_ptr<int32_t>(), (int32_t)B, (int32_t)T, (int32_t)max_seqlen,
-                              out.data_ptr<float>(), out.stride(0), (int32_t)D, normalize ? 1 : 0, ws.data_ptr(), need_b, cur_stream()),
+  void* sh = nullptr;
+  if (shadow.has_value()) {
+    TORCH_CHECK(shadow->is_cuda() && shadow->dim() == 1 && shadow->is_contiguous() && shadow->element_size() == 2 && D % 64 == 0 && D == out.size(1) &&
+                    shadow_row0 >= 0 && shadow->numel() >= ((shadow_row0 + B + 127) / 128) * 128 * D,
+                "encode_packed: shadow must be the shard's 1-D tiled 16-bit shadow (include/lrx.h), out its full-width rows from shadow_row0 on");
+    sh = shadow->data_ptr();
+  }
+  float* rb = nullptr;
+  if (row_bounds.has_value()) {
+    need(*row_bounds, "row_bounds", at::kFloat, 1);
+    TORCH_CHECK(row_bounds->numel() == 2, "encode_packed: row_bounds [2]");
+    rb = row_bounds->data_ptr<float>();
+  }
+  lrx_check(lrx_encode_packed_shard(h->cfg, h->w, ids.data_ptr<int32_t>(), cu_seqlens.data_ptr<int32_t>(), (int32_t)B, (int32_t)T, (int32_t)max_seqlen,
+                                    out.data_ptr<float>(), out.stride(0), (int32_t)D, normalize ? 1 : 0, sh, 0, shadow_row0, rb, ws.data_ptr(), need_b,
+                                    cur_stream()),
             "encode_packed");
 }
 
 // ---- unit kernels -------------------------------------------------------------------------------------------------------------------
 at::Tensor rmsnorm(const at::Tensor& x, const at::Tensor& w, double eps) {
+  DevGuard guard(x.device());
   need(x, "x", at::kBFloat16, 2);
   need(w, "w", at::kBFloat16, 1);
   TORCH_CHECK(x.is_contiguous() && w.numel() == x.size(1), "rmsnorm: x [rows, H] contiguous, w [H]");
@@ -54,6 +77,7 @@ at::Tensor rmsnorm(const at::Tensor& x, const at::Tensor& w, double eps) {
 
 at::Tensor rope_qkv_gemm(const at::Tensor& a, const at::Tensor& wqkv, const c10::optional<at::Tensor>& bias, const at::Tensor& positions,
                          const at::Tensor& cos, const at::Tensor& sin, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim) {
+  DevGuard guard(a.device());
   need(a, "a", at::kBFloat16, 2);
   need(wqkv, "wqkv", at::kBFloat16, 2);
   need(positions, "positions", at::kInt, 1);
@@ -61,7 +85,7 @@ at::Tensor rope_qkv_gemm(const at::Tensor& a, const at::Tensor& wqkv, const c10:
   need(sin, "sin", at::kFloat, 2);
   TORCH_CHECK(a.is_contiguous() && wqkv.is_contiguous() && wqkv.size(1) == a.size(1), "rope_qkv_gemm: a [M,K], wqkv [N,K] contiguous");
   TORCH_CHECK(wqkv.size(0) == (num_q_heads + 2 * num_kv_heads) * head_dim, "rope_qkv_gemm: wqkv rows != (nq + 2 nkv) * d");
-  at::Tensor c = at::empty({a.size(0), wqkv.size(0)}, a.options());
+  at::Tensor c = at::empty({a.size(0), wqkv.size(0)}, a.options().dtype(at::kHalf));   // fp16, q | k columns in rotary-pair order (include/lrx.h)
   lrx_check(lrx_gemm_qkv_rope(a.data_ptr(), wqkv.data_ptr(), c.data_ptr(), bias.has_value() ? bias->data_ptr() : nullptr, positions.data_ptr<int32_t>(),
                               cos.data_ptr<float>(), sin.data_ptr<float>(), (int32_t)a.size(0), (int32_t)a.size(1), (int32_t)num_q_heads,
                               (int32_t)num_kv_heads, (int32_t)head_dim, cur_stream()),
@@ -71,10 +95,11 @@ at::Tensor rope_qkv_gemm(const at::Tensor& a, const at::Tensor& wqkv, const c10:
 
 at::Tensor attn_varlen(const at::Tensor& qkv, const at::Tensor& cu_seqlens, int64_t max_seqlen, int64_t num_q_heads, int64_t num_kv_heads,
                        int64_t head_dim) {
-  need(qkv, "qkv", at::kBFloat16, 2);
+  DevGuard guard(qkv.device());
+  need(qkv, "qkv", at::kHalf, 2);
   need(cu_seqlens, "cu_seqlens", at::kInt, 1);
   TORCH_CHECK(qkv.is_contiguous() && qkv.size(1) == (num_q_heads + 2 * num_kv_heads) * head_dim, "attn_varlen: qkv [T, (nq + 2 nkv) * d] contiguous");
-  at::Tensor out = at::empty({qkv.size(0), num_q_heads * head_dim}, qkv.options());
+  at::Tensor out = at::empty({qkv.size(0), num_q_heads * head_dim}, qkv.options().dtype(at::kBFloat16));
   lrx_check(lrx_attn_varlen_causal(qkv.data_ptr(), cu_seqlens.data_ptr<int32_t>(), (int32_t)cu_seqlens.numel() - 1, (int32_t)qkv.size(0),
                                    (int32_t)max_seqlen, (int32_t)num_q_heads, (int32_t)num_kv_heads, (int32_t)head_dim, out.data_ptr(), 0, cur_stream()),
             "attn_varlen");
@@ -82,6 +107,7 @@ at::Tensor attn_varlen(const at::Tensor& qkv, const at::Tensor& cu_seqlens, int6
 }
 
 at::Tensor swiglu_gemm(const at::Tensor& a, const at::Tensor& wgu) {
+  DevGuard guard(a.device());
   need(a, "a", at::kBFloat16, 2);
   need(wgu, "wgu", at::kBFloat16, 2);
   TORCH_CHECK(a.is_contiguous() && wgu.is_contiguous() && wgu.size(1) == a.size(1) && wgu.size(0) % 2 == 0, "swiglu_gemm: a [M,K], wgu [2I,K] contiguous");
@@ -95,6 +121,7 @@ at::Tensor swiglu_gemm(const at::Tensor& a, const at::Tensor& wgu) {
 // ---- query side -------------------------------------------------------------------------------------------------------------------
 at::Tensor embedding_bag_mean(const at::Tensor& table, const at::Tensor& ids, const at::Tensor& offsets, int64_t padding_idx, int64_t out_dim,
                               bool normalize) {
+  DevGuard guard(table.device());
   need(table, "table", at::kFloat, 2);
   need(ids, "ids", at::kLong, 1);
   need(offsets, "offsets", at::kLong, 1);
@@ -110,6 +137,7 @@ at::Tensor embedding_bag_mean(const at::Tensor& table, const at::Tensor& ids, co
 
 // ---- index ----------------------------------------------------------------------------------------------------------------------
 std::tuple<at::Tensor, at::Tensor> flat_ip_topk(const at::Tensor& q, const at::Tensor& x, int64_t k, int64_t id_base) {
+  DevGuard guard(q.device());
   need(q, "q", at::kFloat, 2);
   need(x, "x", at::kFloat, 2);
   TORCH_CHECK(q.is_contiguous() && q.size(1) == x.size(1), "flat_ip_topk: q [Q,D] contiguous, x [N,D]");
@@ -124,6 +152,7 @@ std::tuple<at::Tensor, at::Tensor> flat_ip_topk(const at::Tensor& q, const at::T
 
 std::tuple<at::Tensor, at::Tensor> flat_ip_topk_bounded(const at::Tensor& q, const at::Tensor& x, const c10::optional<at::Tensor>& x_bf16,
                                                         const at::Tensor& row_bounds, int64_t k, int64_t id_base) {
+  DevGuard guard(q.device());
   need(q, "q", at::kFloat, 2);
   need(x, "x", at::kFloat, 2);
   need(row_bounds, "row_bounds", at::kFloat, 1);
@@ -149,6 +178,7 @@ std::tuple<at::Tensor, at::Tensor> flat_ip_topk_bounded(const at::Tensor& q, con
 
 // x_bf16: row-major [>= rows, D] bf16, or 1-D (the tiled layout of include/lrx.h, whole 128-row blocks) with row0 = index of x's first row
 void shard_commit_rows(const at::Tensor& x, const c10::optional<at::Tensor>& x_bf16, at::Tensor row_bounds, int64_t row0) {
+  DevGuard guard(x.device());
   need(x, "x", at::kFloat, 2);
   need(row_bounds, "row_bounds", at::kFloat, 1);
   bool tiled = false;
@@ -163,6 +193,7 @@ void shard_commit_rows(const at::Tensor& x, const c10::optional<at::Tensor>& x_b
 }
 
 std::tuple<at::Tensor, at::Tensor> merge_topk(const at::Tensor& d_parts, const at::Tensor& i_parts) {
+  DevGuard guard(d_parts.device());
   need(d_parts, "d_parts", at::kFloat, 3);
   need(i_parts, "i_parts", at::kLong, 3);
   TORCH_CHECK(d_parts.is_contiguous() && i_parts.is_contiguous() && d_parts.sizes() == i_parts.sizes(), "merge_topk: [R,Q,k] contiguous pairs");
@@ -177,7 +208,8 @@ std::tuple<at::Tensor, at::Tensor> merge_topk(const at::Tensor& d_parts, const a
 }  // namespace
 
 TORCH_LIBRARY(lrx, m) {
-  m.def("encode_packed(Tensor ids, Tensor cu_seqlens, int max_seqlen, int weights, Tensor(a!) out, int mrl_dim=0, bool normalize=True) -> ()");
+  m.def("encode_packed(Tensor ids, Tensor cu_seqlens, int max_seqlen, int weights, Tensor(a!) out, int mrl_dim=0, bool normalize=True, "
+        "Tensor(b!)? shadow=None, int shadow_row0=0, Tensor(c!)? row_bounds=None) -> ()");
   m.def("rmsnorm(Tensor x, Tensor w, float eps) -> Tensor");
   m.def("rope_qkv_gemm(Tensor a, Tensor wqkv, Tensor? bias, Tensor positions, Tensor cos, Tensor sin, int num_q_heads, int num_kv_heads, int head_dim) -> Tensor");
   m.def("attn_varlen(Tensor qkv, Tensor cu_seqlens, int max_seqlen, int num_q_heads, int num_kv_heads, int head_dim) -> Tensor");

@@ -18,6 +18,9 @@ import torch
 from . import _lib
 
 
+PRECISE_FROM_LAYERS = 20    # measured (tests/test_gpu_encoder.py::test_full_depth_hf_parity): 16 layers keep 1 - cos < 4e-4 on the bf16 stream
+
+
 @dataclass
 class EncoderConfig:
     vocab_size: int
@@ -37,6 +40,12 @@ class EncoderConfig:
     qkv_bias: bool = False
     max_positions: int = 512
     fold_norm: bool = True      # RMSNorm weights folded into the next projection at load time (lrx_encoder_config.norm_folded)
+    # fp32 residual stream + exact weights, the norm weight on the bf16 activation operand (lrx_encoder_config.precise_stream): None = from
+    # PRECISE_FROM_LAYERS layers on (deep backbones spend the 1e-3 cosine budget on the bf16 stream and the folded weights otherwise)
+    precise_stream: Optional[bool] = None
+
+    def use_precise_stream(self) -> bool:
+        return self.num_layers >= PRECISE_FROM_LAYERS if self.precise_stream is None else bool(self.precise_stream)
 
     @staticmethod
     def llama32_1b(max_positions: int = 512) -> "EncoderConfig":
@@ -91,7 +100,8 @@ class EncoderConfig:
 
 
 def rope_tables(cfg: EncoderConfig) -> tuple[torch.Tensor, torch.Tensor]:
-    """cos/sin [max_positions, d/2] fp32, values rounded to bf16 (HF casts cos/sin to the activation dtype)."""
+    """cos/sin [max_positions, d/2] fp32 as LlamaRotaryEmbedding computes them (fp32 position * inv_freq; default and llama3 scaling).  HF's
+    bf16 run rounds them to bf16 afterwards; the fused QKV epilogue rotates the fp32 accumulators with the fp32 values (round 3)."""
     d = cfg.head_dim
     inv = 1.0 / (torch.tensor(cfg.rope_theta, dtype=torch.float32) ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
     if cfg.rope_type == "llama3":
@@ -107,7 +117,7 @@ def rope_tables(cfg: EncoderConfig) -> tuple[torch.Tensor, torch.Tensor]:
         raise NotImplementedError(f"rope_type {cfg.rope_type}")
     pos = torch.arange(cfg.max_positions, dtype=torch.float32)
     freqs = pos[:, None] * inv[None, :].float()
-    return freqs.cos().to(torch.bfloat16).float().contiguous(), freqs.sin().to(torch.bfloat16).float().contiguous()
+    return freqs.cos().contiguous(), freqs.sin().contiguous()
 
 
 def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
@@ -148,8 +158,9 @@ class LrxEncoder:
         self.final_norm = dev(g("norm.weight"))
         cos, sin = rope_tables(cfg)
         self.rope_cos, self.rope_sin = cos.to(self.device), sin.to(self.device)
-        # the same table as bf16 rows [cos | sin] (the values are bf16-representable already: HF casts cos/sin to the activation dtype)
-        self.rope_cs16 = torch.cat([self.rope_cos, self.rope_sin], 1).to(torch.bfloat16).contiguous()
+        from .ops import rotary_pair_order
+        perm = rotary_pair_order(cfg.num_q_heads, cfg.num_kv_heads, cfg.head_dim).to(self.device)
+        self.precise = cfg.use_precise_stream()
         self.layers = []
         for i in range(cfg.num_layers):
             p = f"layers.{i}."
@@ -162,11 +173,14 @@ class LrxEncoder:
                 wgu=dev(interleave_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"))),
                 wdown=dev(g(p + "mlp.down_proj.weight")), ln1=dev(g(p + "input_layernorm.weight")),
                 ln2=dev(g(p + "post_attention_layernorm.weight"))))
-        if cfg.fold_norm:
-            # W' = W diag(gamma): fp32 product, one rounding to bf16.  The originals stay (hf_state_dict, inspection); the C structs get W'.
-            for L in self.layers:
-                L["wqkv_f"] = (L["wqkv"].float() * L["ln1"].float()[None, :]).to(bf).contiguous()
-                L["wgu_f"] = (L["wgu"].float() * L["ln2"].float()[None, :]).to(bf).contiguous()
+        # What the C structs get (the logical-order originals stay for hf_state_dict / inspection): wqkv / bqkv with the q and k heads' rows in
+        # rotary-pair order; with the folded norm (and no precise stream) W' = W diag(gamma): fp32 product, one rounding to bf16.
+        fold = cfg.fold_norm and not self.precise
+        for L in self.layers:
+            wq = L["wqkv"].float() * L["ln1"].float()[None, :] if fold else L["wqkv"]
+            L["wqkv_c"] = wq[perm].to(bf).contiguous()
+            L["bqkv_c"] = L["bqkv"][perm].contiguous() if L["bqkv"] is not None else None
+            L["wgu_c"] = (L["wgu"].float() * L["ln2"].float()[None, :]).to(bf).contiguous() if fold else L["wgu"]
         # LM head for the sparse branch: tied to the embedding unless the checkpoint carries its own (`lm_head.weight`)
         self.lm_head = dev(g("lm_head.weight")) if "lm_head.weight" in state_dict else None
         self._build_c_structs()
@@ -225,17 +239,16 @@ class LrxEncoder:
     def _build_c_structs(self):
         c = self.cfg
         self._ccfg = _lib.EncoderConfigC(c.vocab_size, c.hidden_size, c.num_layers, c.num_q_heads, c.num_kv_heads, c.head_dim,
-                                         c.intermediate_size, c.rms_eps, int(c.qkv_bias), c.max_positions, int(c.fold_norm))
+                                         c.intermediate_size, c.rms_eps, int(c.qkv_bias), c.max_positions, int(c.fold_norm and not self.precise),
+                                         int(self.precise))
         arr = (_lib.LayerWeightsC * c.num_layers)()
-        fq, fg = ("wqkv_f", "wgu_f") if c.fold_norm else ("wqkv", "wgu")
         for i, L in enumerate(self.layers):
-            arr[i] = _lib.LayerWeightsC(L[fq].data_ptr(), L["bqkv"].data_ptr() if L["bqkv"] is not None else None,
-                                        L["wo"].data_ptr(), L[fg].data_ptr(), L["wdown"].data_ptr(), L["ln1"].data_ptr(),
+            arr[i] = _lib.LayerWeightsC(L["wqkv_c"].data_ptr(), L["bqkv_c"].data_ptr() if L["bqkv_c"] is not None else None,
+                                        L["wo"].data_ptr(), L["wgu_c"].data_ptr(), L["wdown"].data_ptr(), L["ln1"].data_ptr(),
                                         L["ln2"].data_ptr())
         self._clayers = arr
         self._cw = _lib.EncoderWeightsC(self.embed.data_ptr(), self.final_norm.data_ptr(), self.rope_cos.data_ptr(),
-                                        self.rope_sin.data_ptr(), C.cast(arr, C.POINTER(_lib.LayerWeightsC)),
-                                        self.rope_cs16.data_ptr() if getattr(self, "use_bf16_rope_table", os.environ.get("LRX_ROPE_FP32_TABLE") != "1") else None)
+                                        self.rope_sin.data_ptr(), C.cast(arr, C.POINTER(_lib.LayerWeightsC)))
         self._handle = None        # (a handle built before this call points at the structs just replaced)
 
     def workspace_bytes(self, total_tokens: int, n_seqs: int) -> int:

@@ -59,13 +59,52 @@ def finalize_rscale(ss_part: torch.Tensor, hidden_size: int, eps: float) -> torc
     return out
 
 
+def rotary_pair_order(nq: int, nkv: int, d: int) -> torch.Tensor:
+    """Row permutation of the fused qkv projection (include/lrx.h, lrx_layer_weights.wqkv): physical row 32 g + 16 i + t of every q and k head
+    = logical row i * d/2 + 16 g + t; v rows stay in place.  `W_physical = W_logical[perm]`; the same index applies to the bias and, read
+    the other way (`x_logical[..., perm] = x_physical`), to the q | k columns the fused kernel writes."""
+    t = torch.arange(d)
+    g, i, r = t // 32, (t % 32) // 16, t % 16
+    head = i * (d // 2) + 16 * g + r
+    rot = torch.cat([h * d + head for h in range(nq + nkv)])
+    return torch.cat([rot, torch.arange((nq + nkv) * d, (nq + 2 * nkv) * d)])
+
+
 def gemm_qkv_rope(A: torch.Tensor, Wqkv: torch.Tensor, positions: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, nq: int, nkv: int,
-                  d: int, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  d: int, bias: Optional[torch.Tensor] = None, rscale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Wqkv / bias rows in rotary-pair order (rotary_pair_order); -> fp16 [M, (nq+2nkv)d], q | k columns in the same order."""
     M, K = A.shape
-    out = torch.empty(M, (nq + 2 * nkv) * d, dtype=torch.bfloat16, device=A.device)
-    _lib.check(_lib.lib().lrx_gemm_qkv_rope(_lib.ptr(A), _lib.ptr(Wqkv), _lib.ptr(out), _lib.ptr(bias), _lib.ptr(positions), _lib.ptr(cos),
-                                            _lib.ptr(sin), M, K, nq, nkv, d, _s()))
+    out = torch.empty(M, (nq + 2 * nkv) * d, dtype=torch.float16, device=A.device)
+    _lib.check(_lib.lib().lrx_gemm_qkv_rope_fused(_lib.ptr(A), _lib.ptr(Wqkv), _lib.ptr(out), _lib.ptr(bias), _lib.ptr(positions), _lib.ptr(cos),
+                                                  _lib.ptr(sin), M, K, nq, nkv, d, _lib.ptr(rscale), _s()))
     return out
+
+
+def gemm_resid32(A: torch.Tensor, B: torch.Tensor, x32: torch.Tensor, gamma: Optional[torch.Tensor] = None, want_a16: bool = True, want_ss: bool = False):
+    """lrx_gemm_bf16_nt_resid32: x32 (fp32 [M,N], in place) += A . B^T -> (a16 bf16 [M,N] = bf16(x32 * gamma) or None, ss_part or None)."""
+    M, K = A.shape
+    N = B.shape[0]
+    a16 = torch.empty(M, N, dtype=torch.bfloat16, device=A.device) if want_a16 else None
+    ss = torch.full(((N + 255) // 256, M), float("nan"), dtype=torch.float32, device=A.device) if want_ss else None
+    _lib.check(_lib.lib().lrx_gemm_bf16_nt_resid32(_lib.ptr(A), _lib.ptr(B), _lib.ptr(x32), _lib.ptr(a16), _lib.ptr(gamma), M, N, K, _lib.ptr(ss), _s()))
+    return a16, ss
+
+
+def embed_stream32(table: torch.Tensor, ids: torch.Tensor, gamma: torch.Tensor, eps: float):
+    """lrx_embed_stream32 -> (x32 fp32 [T,H], a16 bf16 [T,H], rscale fp32 [T])."""
+    T, H = ids.numel(), table.shape[1]
+    x32 = torch.empty(T, H, dtype=torch.float32, device=table.device)
+    a16 = torch.empty(T, H, dtype=torch.bfloat16, device=table.device)
+    rs = torch.empty(T, dtype=torch.float32, device=table.device)
+    _lib.check(_lib.lib().lrx_embed_stream32(_lib.ptr(table), _lib.ptr(ids), T, H, table.shape[0], _lib.ptr(gamma), _lib.ptr(x32), _lib.ptr(a16), _lib.ptr(rs),
+                                             float(eps), _s()))
+    return x32, a16, rs
+
+
+def rmsnorm_f32(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().lrx_rmsnorm_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), x.shape[0], x.shape[1], float(eps), _s()))
+    return y
 
 
 def build_positions(cu_seqlens: torch.Tensor, total_tokens: int) -> torch.Tensor:
@@ -74,13 +113,10 @@ def build_positions(cu_seqlens: torch.Tensor, total_tokens: int) -> torch.Tensor
     return pos
 
 
-def rope_inplace(qkv: torch.Tensor, positions: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, nq: int, nkv: int, d: int):
-    _lib.check(_lib.lib().lrx_rope_inplace(_lib.ptr(qkv), _lib.ptr(positions), _lib.ptr(cos), _lib.ptr(sin), qkv.shape[0], nq, nkv, d, _s()))
-    return qkv
-
-
 def attn_varlen_causal(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, nq: int, nkv: int, d: int,
                        last_tile_only: bool = False) -> torch.Tensor:
+    if qkv.dtype != torch.float16:
+        raise TypeError("attn_varlen_causal: qkv must be fp16 (the fused QKV + RoPE projection writes fp16)")
     T = qkv.shape[0]
     out = (torch.zeros if last_tile_only else torch.empty)(T, nq * d, dtype=torch.bfloat16, device=qkv.device)
     _lib.check(_lib.lib().lrx_attn_varlen_causal(_lib.ptr(qkv), _lib.ptr(cu_seqlens), cu_seqlens.numel() - 1, T, max_seqlen, nq, nkv, d,
@@ -89,7 +125,9 @@ def attn_varlen_causal(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: 
 
 
 def attn_prefix_suffix(qkv: torch.Tensor, prefix_kv: torch.Tensor, n_seqs: int, suffix_len: int, nq: int, nkv: int, d: int) -> torch.Tensor:
-    """qkv [n_seqs*suffix_len, (nq+2nkv)d] bf16, prefix_kv [P1, 2*nkv*d] bf16 (k | v) -> [n_seqs*suffix_len, nq*d] bf16."""
+    """qkv [n_seqs*suffix_len, (nq+2nkv)d] fp16, prefix_kv [P1, 2*nkv*d] fp16 (k | v) -> [n_seqs*suffix_len, nq*d] bf16."""
+    if qkv.dtype != torch.float16 or prefix_kv.dtype != torch.float16:
+        raise TypeError("attn_prefix_suffix: qkv and prefix_kv must be fp16")
     if qkv.shape != (n_seqs * suffix_len, (nq + 2 * nkv) * d) or prefix_kv.shape[1:] != (2 * nkv * d,):
         raise ValueError("attn_prefix_suffix: operand shapes do not match the head layout")
     out = torch.empty(n_seqs * suffix_len, nq * d, dtype=torch.bfloat16, device=qkv.device)
@@ -114,10 +152,12 @@ def gather_last_rows(src: torch.Tensor, cu_seqlens: torch.Tensor) -> torch.Tenso
 
 def pool_norm(hidden: torch.Tensor, w: torch.Tensor, cu_seqlens: torch.Tensor, eps: float, out_dim: Optional[int] = None,
               normalize: bool = True) -> torch.Tensor:
+    """hidden bf16 [T,H] (HF's bf16 norm arithmetic) or fp32 [T,H] (the precise stream: fp32 norm)."""
     B, H = cu_seqlens.numel() - 1, hidden.shape[1]
     D = out_dim or H
     out = torch.empty(B, D, dtype=torch.float32, device=hidden.device)
-    _lib.check(_lib.lib().lrx_pool_norm(_lib.ptr(hidden), _lib.ptr(w), _lib.ptr(cu_seqlens), B, H, eps, _lib.ptr(out), D, D, int(normalize), _s()))
+    _lib.check(_lib.lib().lrx_pool_norm_shard(_lib.ptr(hidden), _lib.ptr(w), _lib.ptr(cu_seqlens), B, H, eps, _lib.ptr(out), D, D, int(normalize), None, 0, 0,
+                                              None, int(hidden.dtype == torch.float32), _s()))
     return out
 
 

@@ -283,18 +283,3 @@ def test_full_depth_hf_parity(preset):
         with open(os.path.join(out_dir, "full_depth_parity.jsonl"), "a") as f:
             f.write(json.dumps({"preset": preset, "layers": cfg.num_layers, **m}) + "\n")
     assert max(m.values()) <= COS_TOL, (preset, m)
-
-
-def test_bf16_rope_table_gives_the_same_bits_as_the_fp32_table():
-    """lrx_encoder_weights.rope_cs_bf16 (round 2): the fused QKV + RoPE epilogue reads the cos/sin values as bf16 (they are bf16-representable:
-    HF casts the table to the activation dtype) -- half the table bytes, the same arithmetic, bit-identical embeddings."""
-    cfg_o, w, g, ids, cu, max_len = load_model_golden("llama_small_d64")
-    enc = make_encoder(cfg_o, w)
-    tid, tcu = to_dev(ids, torch.int32), to_dev(cu, torch.int32)
-    assert enc._cw.rope_cs_bf16
-    a = enc.encode_packed(tid, tcu, max_len).clone()
-    enc.use_bf16_rope_table = False
-    enc._build_c_structs()
-    assert not enc._cw.rope_cs_bf16
-    b = enc.encode_packed(tid, tcu, max_len)
-    assert torch.equal(a, b)

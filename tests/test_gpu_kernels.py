@@ -16,6 +16,11 @@ def bf16_t(a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev()).to(torch.bfloat16).contiguous()
 
 
+def f16_t(a: np.ndarray) -> torch.Tensor:
+    """q | k | v activations are fp16 since round 3 (the fused QKV + RoPE projection writes fp16)"""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev()).to(torch.float16).contiguous()
+
+
 def f32(t: torch.Tensor) -> np.ndarray:
     return t.float().cpu().numpy()
 
@@ -112,28 +117,16 @@ def test_positions_match_packing_oracle():
     np.testing.assert_array_equal(got.cpu().numpy(), pos)
 
 
-@pytest.mark.parametrize("d,nq,nkv,rope_type", [(64, 4, 2, "llama3"), (128, 2, 1, "default"), (64, 32, 8, "llama3")])
-def test_rope(d, nq, nkv, rope_type):
-    from lightretriever_amd import ops, rope_tables, EncoderConfig
-    rng = np.random.default_rng(d)
-    T = 77
-    ocfg = O.EncoderConfig(100, nq * d, 1, nq, nkv, d, 64, rope_type=rope_type, rope_original_max_position=64, max_positions=128)
-    cfg = EncoderConfig(100, nq * d, 1, nq, nkv, d, 64, rope_type=rope_type, rope_original_max_position=64, max_positions=128)
+@pytest.mark.parametrize("d,rope_type", [(64, "llama3"), (128, "default"), (128, "llama3")])
+def test_rope_table_is_the_fp32_table_of_the_hf_restatement(d, rope_type):
+    """cos/sin are fp32 (LlamaRotaryEmbedding's fp32 values; HF's bf16 run rounds them afterwards, the kernels do not)."""
+    from lightretriever_amd import rope_tables, EncoderConfig
+    ocfg = O.EncoderConfig(100, 4 * d, 1, 4, 2, d, 64, rope_type=rope_type, rope_original_max_position=64, max_positions=512)
+    cfg = EncoderConfig(100, 4 * d, 1, 4, 2, d, 64, rope_type=rope_type, rope_original_max_position=64, max_positions=512)
     cos, sin = rope_tables(cfg)
-    oc, osn = O.rope_table(ocfg, 128)
-    np.testing.assert_allclose(cos.numpy(), O.round_bf16(oc), atol=2 ** -8)   # table itself vs the HF restatement
-    np.testing.assert_allclose(sin.numpy(), O.round_bf16(osn), atol=2 ** -8)
-    qkv = rnd(rng, T, (nq + 2 * nkv) * d)
-    pos = rng.integers(0, 128, size=T).astype(np.int32)
-    t = bf16_t(qkv)
-    ops.rope_inplace(t, torch.from_numpy(pos).to(dev()), cos.to(dev()), sin.to(dev()), nq, nkv, d)
-    got = f32(t)
-    c, s = cos.numpy()[pos], sin.numpy()[pos]
-    want = qkv.copy()
-    rot = O.apply_rope(qkv[:, :(nq + nkv) * d].reshape(T, nq + nkv, d), c, s).reshape(T, -1)
-    want[:, :(nq + nkv) * d] = rot
-    bf16_ulp_close(got, O.round_bf16(want), ulps=1.01, atol=1e-6)
-    np.testing.assert_array_equal(got[:, (nq + nkv) * d:], qkv[:, (nq + nkv) * d:])  # v untouched
+    oc, osn = O.rope_table(ocfg, 512)
+    np.testing.assert_allclose(cos.numpy(), oc, atol=5e-6)
+    np.testing.assert_allclose(sin.numpy(), osn, atol=5e-6)
 
 
 def attn_oracle(qkv, cu, nq, nkv, d):
@@ -181,7 +174,7 @@ def test_attention_varlen_causal(d, nq, nkv, lens):
     qkv = rnd(rng, T, (nq + 2 * nkv) * d)
     qkv[:, :nq * d] *= 2.0  # peaky softmax
     cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    got = ops.attn_varlen_causal(bf16_t(qkv), torch.from_numpy(cu).to(dev()), max(lens), nq, nkv, d)
+    got = ops.attn_varlen_causal(f16_t(qkv), torch.from_numpy(cu).to(dev()), max(lens), nq, nkv, d)
     want = attn_oracle(qkv, cu, nq, nkv, d)
     np.testing.assert_allclose(f32(got), want, atol=2e-2, rtol=2e-2)
     # rows are convex combinations of v: a tighter relative check on the row norms catches scale errors
@@ -196,7 +189,7 @@ def test_attention_forced_max_jump():
     qkv = rnd(rng, L, (nq + 2 * nkv) * d, scale=0.3)
     qkv[100, nq * d:nq * d + d] = O.round_bf16(qkv[150, :d] * 40)  # key 100 (kv head 0) aligned with q row 150 of head 0
     cu = np.array([0, L], np.int32)
-    got = ops.attn_varlen_causal(bf16_t(qkv), torch.from_numpy(cu).to(dev()), L, nq, nkv, d)
+    got = ops.attn_varlen_causal(f16_t(qkv), torch.from_numpy(cu).to(dev()), L, nq, nkv, d)
     np.testing.assert_allclose(f32(got), attn_oracle(qkv, cu, nq, nkv, d), atol=2e-2, rtol=2e-2)
 
 
@@ -261,7 +254,7 @@ def test_attention_last_tile_only_and_gather():
     rng = np.random.default_rng(21)
     d, nq, nkv, lens = 64, 8, 2, [1, 64, 65, 200, 512, 129]
     T = sum(lens)
-    qkv = bf16_t(rnd(rng, T, (nq + 2 * nkv) * d))
+    qkv = f16_t(rnd(rng, T, (nq + 2 * nkv) * d))
     cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev())
     full = ops.attn_varlen_causal(qkv, cu, max(lens), nq, nkv, d)
     last = ops.attn_varlen_causal(qkv, cu, max(lens), nq, nkv, d, last_tile_only=True)
@@ -275,8 +268,10 @@ def test_attention_last_tile_only_and_gather():
         assert (last[cu_h[b]:cu_h[b] + t0] == 0).all()
 
 
-@pytest.mark.parametrize("d,nq,nkv,bias", [(64, 4, 2, False), (128, 2, 1, True), (64, 32, 8, False)])
-def test_gemm_qkv_rope_fused_equals_gemm_then_rope(d, nq, nkv, bias):
+@pytest.mark.parametrize("d,nq,nkv,bias,scaled", [(64, 4, 2, False, False), (128, 2, 1, True, True), (64, 32, 8, False, True), (128, 6, 2, True, False)])
+def test_gemm_qkv_rope_fused_equals_fp32_projection_then_rope(d, nq, nkv, bias, scaled):
+    """lrx_gemm_qkv_rope_fused (round 3): weights / bias in rotary-pair order, rotation on the fp32 accumulators with the fp32 table, fp16
+    out in pair order == fp32 x W^T (* row scale) + b, apply_rotary_pos_emb (modeling_llama.py:130-160) in fp32, ONE rounding to fp16."""
     from lightretriever_amd import ops, rope_tables, EncoderConfig
     rng = np.random.default_rng(d + nq)
     T, K = 333, 256
@@ -286,12 +281,26 @@ def test_gemm_qkv_rope_fused_equals_gemm_then_rope(d, nq, nkv, bias):
     cos, sin = cos.to(dev()), sin.to(dev())
     A, W = bf16_t(rnd(rng, T, K)), bf16_t(rnd(rng, N, K, scale=0.05))
     b = bf16_t(rnd(rng, N)) if bias else None
+    rs = torch.from_numpy(rng.uniform(0.2, 3.0, size=T).astype(np.float32)).to(dev()) if scaled else None
     pos = torch.from_numpy(rng.integers(0, 128, size=T).astype(np.int32)).to(dev())
-    want = ops.rope_inplace(ops.gemm_bf16_nt(A, W, bias=b), pos, cos, sin, nq, nkv, d)
-    got = ops.gemm_qkv_rope(A, W, pos, cos, sin, nq, nkv, d, bias=b)
-    diff = (got.float() - want.float()).abs()
-    assert (got == want).float().mean() > 0.999          # identical arithmetic up to fma contraction in the last bit
-    assert (diff <= 2.0 ** -7 * want.float().abs() + 1e-6).all()
+    t = A.double() @ W.double().T
+    if scaled:
+        t = t * rs.double()[:, None]
+    if bias:
+        t = t + b.double()
+    qk = t[:, :(nq + nkv) * d].reshape(T, nq + nkv, d)
+    c, s_ = cos[pos.long()].double()[:, None, :], sin[pos.long()].double()[:, None, :]
+    x1, x2 = qk[..., :d // 2], qk[..., d // 2:]
+    want = torch.cat([torch.cat([x1 * c - x2 * s_, x2 * c + x1 * s_], -1).reshape(T, -1), t[:, (nq + nkv) * d:]], 1).float()
+    perm = ops.rotary_pair_order(nq, nkv, d).to(dev())
+    got_p = ops.gemm_qkv_rope(A, W[perm].contiguous(), pos, cos, sin, nq, nkv, d, bias=b[perm].contiguous() if bias else None, rscale=rs)
+    assert got_p.dtype == torch.float16
+    got = torch.empty_like(got_p)
+    got[:, perm] = got_p                                                    # back to the logical column order
+    diff = (got.float() - want).abs()
+    assert (diff <= 2.0 ** -10 * want.abs() + 2e-4).all(), diff.max()        # one fp16 rounding (+ fp32 accumulation order)
+    assert (got == want.to(torch.float16)).float().mean() > 0.99
+    assert torch.equal(perm[(nq + nkv) * d:], torch.arange((nq + nkv) * d, N, device=perm.device))    # v columns stay in place
 
 
 @pytest.mark.parametrize("d,nq,nkv,P1,S2,n", [(64, 4, 2, 9, 2, 37), (64, 32, 8, 22, 2, 5), (128, 8, 1, 3, 3, 11), (64, 2, 2, 0, 2, 4), (128, 4, 4, 40, 1, 3),
@@ -308,7 +317,7 @@ def test_attention_prefix_suffix_equals_full_causal(d, nq, nkv, P1, S2, n):
     suf = rnd(rng, n * S2, W)
     suf[:, :nq * d] *= 2.0
     prefix_kv = np.ascontiguousarray(pre[:, nq * d:])
-    got = f32(ops.attn_prefix_suffix(bf16_t(suf), bf16_t(prefix_kv).reshape(P1, 2 * nkv * d), n, S2, nq, nkv, d))
+    got = f32(ops.attn_prefix_suffix(f16_t(suf), f16_t(prefix_kv).reshape(P1, 2 * nkv * d), n, S2, nq, nkv, d))
     L = P1 + S2
     full = np.concatenate([np.concatenate([pre, suf[i * S2:(i + 1) * S2]]) for i in range(n)])
     cu = (np.arange(n + 1) * L).astype(np.int32)
@@ -362,6 +371,79 @@ def test_folded_norm_gemms_equal_norm_then_gemm(M, H, I):
     np.testing.assert_allclose(f32(ops.finalize_rscale(ss, H, eps)), 1.0 / np.sqrt(f32(want_ss) / H + eps), rtol=3e-6)
     out2, ss2 = ops.gemm_bf16_nt_fused(bf16_t(act), bf16_t(Wd), resid=bf16_t(x), epilogue=1, want_ss=True)
     assert torch.equal(ss, ss2) and torch.equal(out, out2)                                         # no atomics: bitwise repeatable
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 2048, 2048), (131, 64, 512), (513, 1536, 8960 // 64 * 64)])
+def test_precise_stream_residual_gemm(M, N, K):
+    """lrx_gemm_bf16_nt_resid32 (round 3): x32 += A . B^T with one rounding to fp32, a16 = bf16(x32 * gamma), ss_part from the fp32 row."""
+    from lightretriever_amd import ops
+    rng = np.random.default_rng(M + N)
+    A, B = rnd(rng, M, K), rnd(rng, N, K, scale=0.05)
+    x0 = (rng.standard_normal((M, N)) * 3).astype(np.float32)
+    gamma = O.round_bf16(1.0 + 0.3 * rng.standard_normal(N).astype(np.float32))
+    x32 = torch.from_numpy(x0.copy()).cuda()
+    a16, ss = ops.gemm_resid32(bf16_t(A), bf16_t(B), x32, gamma=bf16_t(gamma), want_ss=True)
+    want = x0.astype(np.float64) + A.astype(np.float64) @ B.astype(np.float64).T
+    np.testing.assert_allclose(f32(x32), want, rtol=3e-6, atol=1e-5)
+    wa = torch.from_numpy((f32(x32) * gamma[None, :]).astype(np.float32)).to(torch.bfloat16)
+    assert (a16.cpu() == wa).float().mean() > 0.999 and bf16_ulp_close(f32(a16), wa.float().numpy(), ulps=1.01) is None
+    np.testing.assert_allclose(f32(ss.sum(0)), (f32(x32).astype(np.float64) ** 2).sum(1), rtol=3e-6)
+    # repeatable bit for bit (no atomics), and without the optional outputs
+    x32b = torch.from_numpy(x0.copy()).cuda()
+    a16b, ssb = ops.gemm_resid32(bf16_t(A), bf16_t(B), x32b, gamma=bf16_t(gamma), want_ss=True)
+    assert torch.equal(x32, x32b) and torch.equal(a16, a16b) and torch.equal(ss, ssb)
+    x32c = torch.from_numpy(x0.copy()).cuda()
+    a_none, ss_none = ops.gemm_resid32(bf16_t(A), bf16_t(B), x32c, want_a16=False)
+    assert a_none is None and ss_none is None and torch.equal(x32c, x32)
+
+
+def test_precise_stream_embedding_and_final_norm():
+    from lightretriever_amd import _lib, ops
+    rng = np.random.default_rng(2)
+    V, H, eps = 90, 320, 1e-5
+    table = bf16_t(rnd(rng, V, H))
+    gamma = bf16_t(O.round_bf16(1.0 + 0.2 * rng.standard_normal(H).astype(np.float32)))
+    ids = torch.tensor([3, 89, 0, 17, 90, -2], dtype=torch.int32, device="cuda")
+    _lib.lib().lrx_device_error_count(1)
+    x32, a16, rs = ops.embed_stream32(table, ids, gamma, eps)
+    good = [0, 1, 2, 3]
+    assert torch.equal(x32[good], table[ids[good].long()].float()) and (x32[4:] == 0).all()
+    assert torch.equal(a16[good], (table[ids[good].long()].float() * gamma.float()).to(torch.bfloat16))
+    np.testing.assert_allclose(f32(rs)[good], 1.0 / np.sqrt((f32(x32)[good].astype(np.float64) ** 2).mean(1) + eps), rtol=2e-6)
+    assert _lib.lib().lrx_device_error_count(1) == 2
+    x = torch.from_numpy((rng.standard_normal((37, H)) * 5).astype(np.float32)).cuda()
+    y = ops.rmsnorm_f32(x, gamma, eps)
+    want = (x.double() * torch.rsqrt(x.double().pow(2).mean(1, keepdim=True) + eps) * gamma.double()).float()
+    assert bf16_ulp_close(f32(y), f32(want.to(torch.bfloat16)), ulps=1.01) is None
+    cu = torch.tensor([0, 10, 11, 37], dtype=torch.int32, device="cuda")
+    p32 = ops.pool_norm(x, gamma, cu, eps)                                   # fp32 rows: fp32 norm, no bf16 rounding inside
+    wantp = torch.nn.functional.normalize(want.double()[cu[1:].long() - 1] * 0 + (x.double() * torch.rsqrt(x.double().pow(2).mean(1, keepdim=True) + eps)
+                                                                                  * gamma.double())[cu[1:].long() - 1], dim=-1)
+    np.testing.assert_allclose(f32(p32), wantp.float().cpu().numpy(), atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["llama_small_d64", "llama_small_d128", "qwen2_tiny"])
+def test_precise_stream_encoder_is_closer_to_fp32_than_the_bf16_stream(name):
+    """The same checkpoint through the bf16-stream pipeline and the precise one (fp32 stream, exact weights, norm weight on the operand):
+    both inside the reference's bf16 band; the precise one closer to the fp32 golden; encode_hidden / prefixed follow the same mode."""
+    from dataclasses import asdict, replace
+    from helpers import load_model_golden, min_cos
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    cfg_o, w, g, ids, cu, max_len = load_model_golden(name)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    tid, tcu = torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda()
+    out, hid = {}, {}
+    for precise in (False, True):
+        enc = LrxEncoder(replace(EncoderConfig(**asdict(cfg_o)), precise_stream=precise), sd)
+        assert enc._ccfg.precise_stream == int(precise) and enc._ccfg.norm_folded == int(not precise)
+        out[precise] = enc.encode_packed(tid, tcu, max_len).cpu().numpy()
+        hid[precise] = enc.encode_hidden(tid, tcu, max_len).float()
+        pooled = torch.nn.functional.normalize(hid[precise][tcu[1:].long() - 1], dim=-1).cpu().numpy()
+        assert min_cos(pooled, out[precise]) > 1 - 2e-5                      # pooled tail == pooling the full forward (bf16 hidden output)
+    ref = g["dense_reps"]
+    e_fast, e_prec = 1 - min_cos(out[False], ref), 1 - min_cos(out[True], ref)
+    assert e_prec <= max(1e-4, 0.8 * e_fast), (e_prec, e_fast)
+    assert min_cos(out[True], out[False]) > 0.999
 
 
 def test_folded_and_unfolded_encoders_agree_and_both_match_fp32():
