@@ -241,8 +241,9 @@ FULL_DEPTH_MARGINS = {}     # preset -> {variant: max (1 - cos)}; printed by the
 def test_full_depth_hf_parity(preset):
     """every released backbone at its REAL depth (32 / 28 / 28 / 36 / 28 layers; BASELINE configs 2-4 are the 32-layer
     Llama-3.1-8B), random-init at the real config, documents of 512 / 1 / 129 / ... tokens, against the HF transformers fp32 model on the
-    same GPU (the forward finetune/modeling_hybrid.py:248-278 runs): 1 - cos <= 1e-3 for the full embedding, for the MRL slice
-    out_dim = 256 (BASELINE config 5) and with the HF rounding order (fold_norm = False)."""
+    same GPU (the forward finetune/modeling_hybrid.py:248-278 runs): 1 - cos <= 1e-3 for the full embedding and for the MRL slice
+    out_dim = 256 (BASELINE config 5).  Round 3: with the bf16 residual stream of round 2 the 32-layer model was at 2.4e-3 -- deep
+    backbones now run the precise stream (fp32 stream, exact weights; fp32 RoPE and fp16 q|k|v for every model)."""
     import dataclasses
     from lightretriever_amd import EncoderConfig, LrxEncoder
     cfg = getattr(EncoderConfig, preset)()
@@ -264,16 +265,18 @@ def test_full_depth_hf_parity(preset):
     h = torch.stack(hs)
     ref, ref256 = torch.nn.functional.normalize(h, dim=-1), torch.nn.functional.normalize(h[:, :256], dim=-1)
     m = {}
+    assert enc.precise                                                   # >= 20 layers: fp32 residual stream, exact weights (encoder.PRECISE_FROM_LAYERS)
     out = enc.encode_packed(ids, cu, 512)
     assert torch.equal(out, enc.encode_packed(ids, cu, 512))
-    m["folded"] = (1 - (ref * out).sum(-1)).max().item()
-    m["folded_mrl256"] = (1 - (ref256 * enc.encode_packed(ids, cu, 512, out_dim=256)).sum(-1)).max().item()
+    per_doc = (1 - (ref * out).sum(-1)).tolist()
+    m["precise"] = max(per_doc)
+    m["precise_mrl256"] = (1 - (ref256 * enc.encode_packed(ids, cu, 512, out_dim=256)).sum(-1)).max().item()
     del enc
     torch.cuda.empty_cache()
-    enc_u = LrxEncoder(dataclasses.replace(cfg, fold_norm=False), sd)
-    m["hf_order"] = (1 - (ref * enc_u.encode_packed(ids, cu, 512)).sum(-1)).max().item()
-    m["hf_order_mrl256"] = (1 - (ref256 * enc_u.encode_packed(ids, cu, 512, out_dim=256)).sum(-1)).max().item()
-    del enc_u, sd
+    # for the record (not asserted): the bf16 residual stream with folded norm weights -- the 16-layer headline configuration -- at this depth
+    enc_b = LrxEncoder(dataclasses.replace(cfg, precise_stream=False), sd)
+    m["bf16_stream_folded"] = (1 - (ref * enc_b.encode_packed(ids, cu, 512)).sum(-1)).max().item()
+    del enc_b, sd
     torch.cuda.empty_cache()
     FULL_DEPTH_MARGINS[preset] = m
     print("full-depth parity %s (%d layers): %s" % (preset, cfg.num_layers, {k: "%.2e" % v for k, v in m.items()}))
@@ -282,4 +285,4 @@ def test_full_depth_hf_parity(preset):
     if os.path.isdir(out_dir):                                   # (the margins DESIGN.md section 3 quotes come from this file)
         with open(os.path.join(out_dir, "full_depth_parity.jsonl"), "a") as f:
             f.write(json.dumps({"preset": preset, "layers": cfg.num_layers, **m}) + "\n")
-    assert max(m.values()) <= COS_TOL, (preset, m)
+    assert max(m["precise"], m["precise_mrl256"]) <= COS_TOL, (preset, m, per_doc)

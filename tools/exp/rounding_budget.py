@@ -39,7 +39,7 @@ _TABLES = {}
 def tables(cfg, enc, S, cs16):
     """cos/sin [S, d/2]: the product's bf16-valued table, or the fp32 values HF's fp32 model uses"""
     if cs16:
-        return enc.rope_cos[:S], enc.rope_sin[:S]
+        return bf16_tables(enc, S)
     if "f32" not in _TABLES:
         import math
         from lightretriever_amd import encoder as E
@@ -59,6 +59,20 @@ def tables(cfg, enc, S, cs16):
     return _TABLES["f32"][0][:S], _TABLES["f32"][1][:S]
 
 
+def folded(L, key, ln):
+    """bf16(W * gamma): what the folded-norm pipeline multiplies with (cached on the layer dict)"""
+    k = key + "_f"
+    if k not in L:
+        L[k] = (L[key].float() * L[ln].float()[None, :]).to(bf)
+    return L[k]
+
+
+def bf16_tables(enc, S):
+    if "bf" not in _TABLES:
+        _TABLES["bf"] = (enc.rope_cos.to(bf).float(), enc.rope_sin.to(bf).float())
+    return _TABLES["bf"][0][:S], _TABLES["bf"][1][:S]
+
+
 def forward(enc, cfg, ids, fl):
     """one document, all-fp32 torch arithmetic with the selected roundings; returns the pooled, final-normed row (fp32)"""
     H, d, nq, nkv = cfg.hidden_size, cfg.head_dim, cfg.num_q_heads, cfg.num_kv_heads
@@ -71,7 +85,7 @@ def forward(enc, cfg, ids, fl):
         a = r16(x)                                                           # GEMM A operand (always bf16)
         rs = torch.rsqrt((a if fl["stream"] else x).pow(2).mean(-1, keepdim=True) + cfg.rms_eps)
         if fl.get("fold", True):
-            t = (a @ L["wqkv_f"].float().T) * rs
+            t = (a @ folded(L, "wqkv", "ln1").float().T) * rs
         else:                                                                # exact weights and gamma (what HF fp32 multiplies)
             t = ((a if fl.get("a16", True) else x) * rs * L["ln1"].float()) @ L["wqkv"].float().T
         if L["bqkv"] is not None:
@@ -97,7 +111,7 @@ def forward(enc, cfg, ids, fl):
         a = r16(x)
         rs = torch.rsqrt((a if fl["stream"] else x).pow(2).mean(-1, keepdim=True) + cfg.rms_eps)
         if fl.get("fold", True):
-            gu = (a @ L["wgu_f"].float().T) * rs
+            gu = (a @ folded(L, "wgu", "ln2").float().T) * rs
         else:
             gu = ((a if fl.get("a16", True) else x) * rs * L["ln2"].float()) @ L["wgu"].float().T
         I = cfg.intermediate_size
@@ -136,6 +150,9 @@ def main():
         "P (fp32 stream, A = bf16(x gamma), exact weights)": dict(ALL, fold=False, lin=False, stream=False),
         "P + F1": dict(F1, fold=False, lin=False, stream=False),
         "P + F1 + F4": dict(F1, fold=False, lin=False, stream=False, qkv="f16", p="f16"),
+        "P + F1 + F4 - o": dict(F1, fold=False, lin=False, stream=False, qkv="f16", p="f16", o=False),
+        "P + F1 + F4 - act": dict(F1, fold=False, lin=False, stream=False, qkv="f16", p="f16", act=False),
+        "P + F1 + F4 - o - act": dict(F1, fold=False, lin=False, stream=False, qkv="f16", p="f16", o=False, act=False),
         "P + F4": dict(ALL, fold=False, lin=False, stream=False, qkv="f16", p="f16"),
         "F4 only": dict(ALL, qkv="f16", p="f16"),
         "F1 + F2": dict(F1, lin=False),
@@ -166,7 +183,8 @@ def main():
         docs = [ids[cu[b]:cu[b + 1]] for b in range(len(lens))]
         ref = torch.stack([torch.nn.functional.normalize(ref_forward(dc), dim=-1) for dc in docs])
         print("%-55s max 1-cos vs fp32   (vs product)" % preset)
-        print("%-55s %.3e" % ("PRODUCT lrx_encode_packed", (1 - (ref * out).sum(-1)).max().item()))
+        print("%-55s %.3e   per doc %s" % ("PRODUCT lrx_encode_packed (precise_stream=%s)" % enc.precise, (1 - (ref * out).sum(-1)).max().item(),
+                                            " ".join("%.1e" % v for v in (1 - (ref * out).sum(-1)).tolist())))
         for name, fl in variants.items():
             e = torch.stack([torch.nn.functional.normalize(forward(enc, cfg, dc, fl), dim=-1) for dc in docs])
             print("%-55s %.3e   (%.3e)  per doc %s" % (name, (1 - (ref * e).sum(-1)).max().item(), (1 - (out * e).sum(-1)).max().item(),

@@ -10,6 +10,7 @@ from lightretriever_amd import ops, FlatIPIndex
 from lightretriever_amd.encoder import interleave_gate_up
 
 def bf(a): return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda().to(torch.bfloat16).contiguous()
+def hf(a): return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda().to(torch.float16).contiguous()   # q | k | v activations are fp16
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--rounds", type=int, default=40)
@@ -46,7 +47,7 @@ def main():
         lens = [int(x) for x in rng.integers(1, 300, size=int(rng.integers(1, 6)))]
         T = sum(lens); W = (nq + 2 * nkv) * d
         qkv = O.round_bf16(rng.standard_normal((T, W)).astype(np.float32)); cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-        got = ops.attn_varlen_causal(bf(qkv), torch.from_numpy(cu).cuda(), max(lens), nq, nkv, d).float().cpu().numpy()
+        got = ops.attn_varlen_causal(hf(qkv), torch.from_numpy(cu).cuda(), max(lens), nq, nkv, d).float().cpu().numpy()
         q = qkv[:, :nq * d].reshape(T, nq, d); k = qkv[:, nq * d:(nq + nkv) * d].reshape(T, nkv, d); v = qkv[:, (nq + nkv) * d:].reshape(T, nkv, d)
         want = np.zeros((T, nq, d), np.float32)
         for b in range(len(lens)):
@@ -111,12 +112,13 @@ def main():
         lens = [int(x) for x in rng.integers(1, 200, size=int(rng.integers(1, 7)))]
         ids = rng.integers(0, 400, size=sum(lens)).astype(np.int32); cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         fold = bool(rng.random() < 0.7)
-        enc = LrxEncoder(EncoderConfig(**asdict(cfg), fold_norm=fold), {k: torch.from_numpy(v) for k, v in w.items()})
+        prec = bool(rng.random() < 0.35)                             # the fp32 residual stream of deep backbones
+        enc = LrxEncoder(EncoderConfig(**asdict(cfg), fold_norm=fold, precise_stream=prec), {k: torch.from_numpy(v) for k, v in w.items()})
         shrink = int(rng.choice([H, H // 2]))
         got = enc.encode_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), max(lens), out_dim=shrink).cpu().numpy()
         want = O.encode_passage(cfg, w, ids, cu, dense_shrink_dim=shrink)
         cos = (got * want).sum(-1)
-        check("encoder", cos.min() > 1 - 6e-3 and np.isfinite(got).all(), (H, I, L, nq, nkv, d, cfg.rope_type, cfg.qkv_bias, fold, lens, float(1 - cos.min())))
+        check("encoder", cos.min() > 1 - 6e-3 and np.isfinite(got).all(), (H, I, L, nq, nkv, d, cfg.rope_type, cfg.qkv_bias, fold, prec, lens, float(1 - cos.min())))
     # ---- sparse max aggregation, hit-list fusion, shared-prefix encode
     from lightretriever_amd.score_fuse_utils import fuse_hits
     BF16_ULP = 2.0 ** -7
