@@ -110,14 +110,14 @@ int lrx_encode_packed(const lrx_encoder_config* cfg, const lrx_encoder_weights* 
                       const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen,
                       float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* workspace,
                       size_t workspace_bytes, void* stream);
-/* The same with `out` = rows of an index shard: the last kernel also writes the rows' bf16 shadow (shadow_out + shadow_row_stride + shadow_row0: see the
- * shadow layouts at lrx_shard_commit_rows; NULL = none) and raises the shard's bounds (row_bounds, see lrx_shard_commit_rows; NULL = none), so the index needs
- * no second pass over what the encoder just wrote (FaissIndex.build's add, retriever/faiss_index.py:45-58).                     */
+/* The same with `out` = rows of an index shard: the last kernel also writes the rows' fp16 shadow (shadow_out = base of the shard's tiled
+ * shadow, `out` row b = its row shadow_row0 + b: layout at lrx_shard_commit_rows; NULL = none; needs out_dim % 64 == 0) and raises the shard's
+ * bounds (row_bounds, see lrx_shard_commit_rows; NULL = none), so the index needs no second pass over what the encoder just wrote
+ * (FaissIndex.build's add, retriever/faiss_index.py:45-58).                                                                       */
 int lrx_encode_packed_shard(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids,
                             const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen,
                             float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* shadow_out,
-                            int64_t shadow_row_stride, int64_t shadow_row0, float* row_bounds, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            int64_t shadow_row0, float* row_bounds, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same forward, but returns the un-pooled final hidden states (after the final RMSNorm), bf16 [total_tokens, H]:
  * the `last_hidden_state` of lm(...) at finetune/modeling_hybrid.py:260.  Used by EmbeddingBag construction
@@ -278,12 +278,12 @@ int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_s
 int lrx_pool_norm(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                   int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim,
                   int32_t normalize, void* stream);
-/* ... and the shard maintenance fused into it: shadow_out (bf16 rows, RNE copy of what goes to `out`; may be NULL) and row_bounds
- * (see lrx_shard_commit_rows; may be NULL).  hidden_f32 != 0: `hidden` holds fp32 rows (precise_stream), the norm runs in fp32.   */
+/* ... and the shard maintenance fused into it: shadow_out (the shard's tiled fp16 shadow, row b of `out` = its row shadow_row0 + b; may be
+ * NULL) and row_bounds (see lrx_shard_commit_rows; may be NULL).  hidden_f32 != 0: `hidden` holds fp32 rows (precise_stream), the norm
+ * runs in fp32.                                                                                                                     */
 int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                         int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim,
-                        int32_t normalize, void* shadow_out, int64_t shadow_row_stride, int64_t shadow_row0, float* row_bounds,
-                        int32_t hidden_f32, void* stream);
+                        int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream);
 
 /* Query side.  Replaces emb_bag.forward + slice + F.normalize at finetune/modeling_hybrid.py:472-490
  * (torch.nn.EmbeddingBag mode='mean', padding_idx) with inputs from tokenize_nonctx_qry_emb_bag
@@ -298,54 +298,63 @@ int lrx_embedding_bag_mean(const float* table, int32_t vocab, int32_t hidden, co
  * FaissIndex.search (retriever/faiss_index.py:27-40): exact fp32 scores, descending top-k, ids = row numbers
  * (+ id_base, so shards can return global rows), ties broken by lower row id, id -1 / score -FLT_MAX when k > N.
  *   X [N, D] fp32 row-major (row stride ldx floats), q [Q, D] fp32, D % 32 == 0, k <= 2048.
+ * Memory: a shard that keeps the fp16 shadow below holds 6 bytes per element (fp32 rows + shadow: 1.5x the rows alone) -- BASELINE
+ * config 3 (10M x 4096) on ONE 288-GB GPU is 164 + 82 GB + < 6 GB of workspace; row-sharded over 8 GPUs 31 GB each.
  * ---------------------------------------------------------------------------------------------------------- */
 size_t lrx_flat_ip_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k);
 
-int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries,
-                       int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids, void* workspace,
+/* One pass over the fp32 rows (six bf16 products = fp32-grade scores; the exact-fp32 MFMA for <= 32 queries) into a [Q, N] score
+ * matrix, selection, exact rescoring (fp64 accumulation, one rounding).  The selection is rigorous: every row whose matrix score lies
+ * within 2 eps6(q) = 2 (6 D + 8) 2^-23 |q| R of the k-th largest is rescored before the best k are returned (R = row_bounds[0] >=
+ * max |x_row|).  row_bounds: DEVICE pointer to the shard's two bounds (lrx_shard_commit_rows) or NULL = not known: the rows are then
+ * read once more to measure R.                                                                                                       */
+int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* row_bounds, const float* q,
+                       int32_t n_queries, int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids, void* workspace,
                        size_t workspace_bytes, void* stream);
 
-/* Same result as lrx_flat_ip_search (exact top-k, ids ascending among equal scores) at close to ONE pass over a bf16 copy of the
+/* Same result as lrx_flat_ip_search (exact top-k, ids ascending among equal scores) at close to ONE pass over a 2-byte copy of the
  * shard and without a [queries, rows] score matrix, for shards whose rows satisfy the two bounds in row_bounds (DEVICE pointer to
- * two floats): row_bounds[0] >= max |x_row| and row_bounds[1] >= max |x_row - bf16(x_row)| (<= 0: unknown, 2^-8 * row_bounds[0] is
- * used).  lrx_shard_commit_rows / lrx_encode_packed_shard maintain both.  A single-product bf16 filter pass bounds every score to
- * +- eps(q) = |q - bf16(q)| R + |bf16(q)| E + (D+32) 2^-23 |bf16(q)| R; a strided sample of the shard (every ss-th 128-row block,
- * scored first) gives a lower bound T' of the k-th largest filter score; the pass over the rest keeps only rows with filter score
- * >= T' - 2 eps (a per-query candidate list, ~1e-3 of the rows); the rows within 2 eps of the list's k-th score are rescored
- * exactly from the fp32 rows (fp64 accumulation, one rounding) and sorted.  Queries whose list or band overflows (near-duplicate
- * corpora) are redone by the six-product path (gated on a device flag, no host sync).  Scores returned are the exactly rescored
- * ones.  Bounds smaller than the true values void the guarantee.  Shards below 16 Ki rows (and, without a tiled shadow, very small
- * query batches: Q < max(2, D / 256)) use a score-matrix filter instead (two launches less on the critical path); the result is the
- * same bit for bit.
- * X_bf16 (optional, NULL = convert on the fly): a bf16 copy of X (round-to-nearest-even per element; row-major with row stride
- * ldx_bf16 elements, multiple of 8, or tiled with ldx_bf16 = 0 -- layouts at lrx_shard_commit_rows; dim % 64 == 0) kept by the caller
- * next to the fp32 rows: the filter pass then streams 2 instead of 4
- * bytes per element (+50 % index memory, ~1.8x queries/s); the error bound and therefore the result are unchanged.
- * Queries are processed in chunks of 256 (128 without X_bf16) over the same workspace, whose size therefore stops growing at
- * 256 queries: min(Q,128) * rows * 4 bytes for the gated fallback plus Q * 128 KiB of candidate lists.                            */
+ * two floats): row_bounds[0] >= max |x_row| and row_bounds[1] >= max |x_row - fp16(x_row)| (<= 0: unknown, 2^-11 * row_bounds[0] is
+ * used).  lrx_shard_commit_rows / lrx_encode_packed_shard maintain both.  A single-product FP16 filter pass (fp16(q) . fp16(x), fp32
+ * accumulation) bounds every score to +- eps(q) = |q - fp16(q)| R + |fp16(q)| E + (D+32) 2^-23 |fp16(q)| R (~7e-4 |q| R on normalised
+ * rows; the bf16 filter of round 2 had 3.7e-3); a strided sample of the shard (every ss-th 128-row block, scored first) gives a lower
+ * bound T' of the k-th largest filter score; the pass over the rest keeps only rows with filter score >= T' - 2 eps (a per-query
+ * candidate list, ~1e-3 of the rows; capacity 64 k rounded up to a power of two, at least 16 Ki); the rows within 2 eps of the list's
+ * k-th score are rescored exactly from the fp32 rows (fp64 accumulation, one rounding) and sorted.  Queries whose list or band
+ * overflows (near-duplicate corpora, rows outside fp16's range) are redone by the six-product path (gated on a device flag, no host
+ * sync).  Scores returned are the exactly rescored ones.  Bounds smaller than the true values void the guarantee.
+ * X_shadow (optional, NULL = convert the fp32 rows on the fly: half the queries/s): the shard's TILED FP16 SHADOW kept by the caller
+ * next to the fp32 rows -- round-to-nearest-even per element, saturating at +-65504; dim % 64 == 0; layout at lrx_shard_commit_rows;
+ * row 0 of the array is the shard's row 0.
+ * flags: LRX_SEARCH_FILTER_* below (A/B runs and tests; the result does not depend on it).  Per call -- there is no process-wide
+ * search state, calls from several host threads (the reference's RPC server threads) do not interact.
+ * Queries are processed in chunks of 256 (128 without X_shadow) over the same workspace, whose size therefore stops growing at
+ * 256 queries: min(Q,128) * rows * 4 bytes for the gated fallback plus Q candidate lists.                                          */
+enum {
+  LRX_SEARCH_FILTER_AUTO = 0,            /* score-free filter from 16 Ki rows on, score-matrix filter below                         */
+  LRX_SEARCH_FILTER_MATRIX = 1,          /* always the score-matrix filter                                                           */
+  LRX_SEARCH_FILTER_SCORE_FREE = 2,      /* the score-free (candidate-list) filter whenever the shard is large enough for a sample   */
+  LRX_SEARCH_FILTER_SCORE_FREE_NO_GEMM = 3 /* like 2, but chunks of 129..256 queries never take the GEMM kernel for the main pass   */
+};
 size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k);
-int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_bf16, int64_t ldx_bf16,
-                               const float* row_bounds, const float* q, int32_t n_queries, int32_t k, int64_t id_base,
-                               float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream);
-/* Diagnostics / tests: 0 = choose the filter per query chunk (default), 1 = always the score-matrix filter, 3 = like 2 but never the
- * GEMM kernel for the main pass, 2 = the score-free
- * (candidate-list) filter whenever the shard is large enough for a sample.  Process-global; results do not depend on it.        */
-void lrx_search_set_mode(int32_t mode);
+int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_shadow, const float* row_bounds,
+                               const float* q, int32_t n_queries, int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids,
+                               void* workspace, size_t workspace_bytes, int32_t flags, void* stream);
 
 /* Shard maintenance (FaissIndex.build / IndexFlatIP.add, retriever/faiss_index.py:45-58, for rows that were not written by
- * lrx_encode_packed_shard): one read of n_rows fp32 rows writes their bf16 shadow (RNE; X_bf16 may be NULL) and raises
- * row_bounds[0] = max |row|, row_bounds[1] = max |row - bf16(row)| (device, two floats, zero-initialised by the caller when the
+ * lrx_encode_packed_shard): one read of n_rows fp32 rows writes their fp16 shadow (X_shadow may be NULL: bounds only) and raises
+ * row_bounds[0] = max |row|, row_bounds[1] = max |row - fp16(row)| (device, two floats, zero-initialised by the caller when the
  * shard is created; integer atomic max, order-independent).  dim % 4 == 0.                                                      */
-int lrx_shard_commit_rows(const float* X, int64_t ldx, int64_t n_rows, int32_t dim, void* X_bf16, int64_t ldx_bf16,
-                          int64_t shadow_row0, float* row_bounds, void* stream);
-/* Shadow layouts.  ldx_bf16 > 0: row-major, X_bf16 points at the shadow of X's first row, row stride ldx_bf16 elements (multiple of 8).
- * ldx_bf16 == 0: TILED (dim % 64 == 0), X_bf16 = base of an array [ceil(rows / 128)][dim / 64] of 16-KiB tiles (128 rows x 64 columns),
- * each tile fragment-major: [16-row group w = 0..7][k-step ks = 0..1][fq = 0..3][fi = 0..15][8] bf16 holds row 16 w + fi, columns
+int lrx_shard_commit_rows(const float* X, int64_t ldx, int64_t n_rows, int32_t dim, void* X_shadow, int64_t shadow_row0,
+                          float* row_bounds, void* stream);
+/* The shadow layout (dim % 64 == 0): X_shadow = base of an array [ceil(rows / 128)][dim / 64] of 16-KiB tiles (128 rows x 64 columns),
+ * each tile fragment-major: [16-row group w = 0..7][k-step ks = 0..1][fq = 0..3][fi = 0..15][8] fp16 holds row 16 w + fi, columns
  * 32 ks + 8 fq .. + 7 of the tile (the MFMA 16x16x32 operand of one wave), i.e. element k of row r sits at
  *   ((r / 128) * (dim / 64) + k / 64) * 8192 + ((((r / 16) % 8) * 2 + (k / 32) % 2) * 64 + ((k / 8) % 4) * 16 + r % 16) * 8 + k % 8
  * -- allocated for whole 128-row blocks; shadow_row0 = index within that array of X's first row (writers); for
- * lrx_flat_ip_search_bounded the shard's row 0 is row 0 of the array.  A wave of the filter pass then loads its operand with one
- * coalesced 1-KiB request straight into registers (no LDS staging of the corpus side).                                          */
+ * lrx_flat_ip_search_bounded the shard's row 0 is row 0 of the array.  A wave of the filter pass loads its operand with one
+ * coalesced 1-KiB request straight into registers (no LDS staging of the corpus side).  (Round 2 also accepted a row-major bf16
+ * shadow; it is gone: the tiled layout was faster at every shape and fp16 gives the narrower band.)                               */
 
 /* Score pass only: scores[Q, ld] fp32 with ld = lrx_flat_ip_score_ld(N); columns >= N hold -FLT_MAX. */
 int64_t lrx_flat_ip_score_ld(int64_t n_rows);

@@ -7,6 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRX_LIB_DEV_VARIANT") or os.path.join(HERE, "liblrx.so")   # env override: tools/ diagnostics only
 LRX_PROF_CLASSES = 8
 ABI_VERSION = 4   # LRX_ABI_VERSION of include/lrx.h
+# lrx_flat_ip_search_bounded flags (LRX_SEARCH_FILTER_*): A/B runs and tests; the hits do not depend on them
+SEARCH_FILTER_AUTO, SEARCH_FILTER_MATRIX, SEARCH_FILTER_SCORE_FREE, SEARCH_FILTER_SCORE_FREE_NO_GEMM = 0, 1, 2, 3
 PROF_CLASS_NAMES = ["gemm_store", "gemm_resid", "gemm_swiglu", "attention", "rmsnorm", "rope", "other", "gemm_maxagg"]
 
 
@@ -38,7 +40,7 @@ SIGNATURES = {
     "lrx_last_error": (C.c_char_p, []),
     "lrx_encode_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I32, _I32]),
     "lrx_encode_packed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),
-    "lrx_encode_packed_shard": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _I64, _I64,
+    "lrx_encode_packed_shard": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _I64,
                                        _P, _P, _SZ, _P]),
     "lrx_encode_hidden": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "lrx_encode_prefixed_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I32, _I32, _I32]),
@@ -53,10 +55,9 @@ SIGNATURES = {
     "lrx_hit_contributions": (_I32, [_P, _P, _I32, _I32, _I64, _I32, C.c_double, C.c_double, _P, _I64, _P]),
     "lrx_hit_union": (_I32, [_P, _P, _I32, _I32, _I64, _P, _P, _P, _P]),
     "lrx_flat_ip_bounded_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
-    "lrx_flat_ip_search_bounded": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _P, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _P]),
-    "lrx_search_set_mode": (None, [_I32]),
-    "lrx_shard_commit_rows": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _I64, _P, _P]),
-    "lrx_pool_norm_shard": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P, _I64, _I64, _P, _I32, _P]),
+    "lrx_flat_ip_search_bounded": (_I32, [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _I32, _P]),
+    "lrx_shard_commit_rows": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _P, _P]),
+    "lrx_pool_norm_shard": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P]),
     "lrx_gemm_bf16_nt_resid32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "lrx_embed_stream32": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _F, _P]),
     "lrx_rmsnorm_f32": (_I32, [_P, _P, _P, _I32, _I32, _F, _P]),
@@ -77,7 +78,7 @@ SIGNATURES = {
     "lrx_pool_norm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P]),
     "lrx_embedding_bag_mean": (_I32, [_P, _I32, _I32, _P, _I64, _P, _I32, _I64, _P, _I64, _I32, _I32, _P]),
     "lrx_flat_ip_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
-    "lrx_flat_ip_search": (_I32, [_P, _I64, _I64, _I32, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _P]),
+    "lrx_flat_ip_search": (_I32, [_P, _I64, _I64, _I32, _P, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _P]),
     "lrx_flat_ip_score_ld": (_I64, [_I64]),
     "lrx_flat_ip_scores": (_I32, [_P, _I64, _I64, _I32, _P, _I32, _P, _P]),
     "lrx_merge_topk": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P, _P]),

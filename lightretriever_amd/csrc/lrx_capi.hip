@@ -264,8 +264,8 @@ static int final_norm_rows(const lrx_encoder_config* c, const lrx_encoder_weight
 
 extern "C" int lrx_encode_packed_shard(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,
                                        int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, float* out, int64_t out_row_stride,
-                                       int32_t out_dim, int32_t normalize, void* shadow_out, int64_t shadow_row_stride, int64_t shadow_row0,
-                                       float* row_bounds, void* workspace, size_t workspace_bytes, void* stream) {
+                                       int32_t out_dim, int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   int rc = check_call(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, workspace, workspace_bytes);
   if (rc) return rc;
   LRX_CHECK_ARG(out && out_dim > 0 && out_dim <= cfg->hidden_size && out_row_stride >= out_dim, "encode: bad output spec (dim=%d stride=%lld)",
@@ -278,7 +278,7 @@ extern "C" int lrx_encode_packed_shard(const lrx_encoder_config* cfg, const lrx_
     ProfScope p(s, 6, 0);  // ws.xr / ws.xr32 holds the compacted last-token rows -> cu_seqlens = NULL
     const bool pr = cfg->precise_stream != 0;
     if ((rc = lrx_pool_norm_shard(pr ? (const void*)ws.xr32 : (const void*)ws.xr, w->final_norm, nullptr, n_seqs, cfg->hidden_size, cfg->rms_eps, out,
-                                  out_row_stride, out_dim, normalize, shadow_out, shadow_row_stride, shadow_row0, row_bounds, pr ? 1 : 0, s)))
+                                  out_row_stride, out_dim, normalize, shadow_out, shadow_row0, row_bounds, pr ? 1 : 0, s)))
       return rc;
   }
   return prof_end(s);
@@ -288,7 +288,7 @@ extern "C" int lrx_encode_packed(const lrx_encoder_config* cfg, const lrx_encode
                                  int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, float* out, int64_t out_row_stride,
                                  int32_t out_dim, int32_t normalize, void* workspace, size_t workspace_bytes, void* stream) {
   return lrx_encode_packed_shard(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, out, out_row_stride, out_dim, normalize, nullptr, 0,
-                                 0, nullptr, workspace, workspace_bytes, stream);
+                                 nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int lrx_encode_hidden(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,
@@ -326,7 +326,7 @@ extern "C" int lrx_encode_packed_sparse(const lrx_encoder_config* cfg, const lrx
   if (dense_out) {
     ProfScope p(s, 6, 0);
     if ((rc = lrx_pool_norm_shard(pr ? (const void*)ws.x32 : (const void*)ws.x, w->final_norm, cu_seqlens, n_seqs, H, cfg->rms_eps, dense_out, dense_row_stride,
-                                  dense_dim, normalize, nullptr, 0, 0, nullptr, pr ? 1 : 0, s))) return rc;
+                                  dense_dim, normalize, nullptr, 0, nullptr, pr ? 1 : 0, s))) return rc;
   }
   if ((rc = final_norm_rows(cfg, w, ws, total_tokens, ws.h, s))) return rc;
   { ProfScope p(s, 7, 2.0 * total_tokens * (double)V * H);   // positions are dead after the layers: ws.pos holds the row -> sequence map
@@ -412,6 +412,6 @@ extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_enco
   { ProfScope p(s, 6, 0);
     const bool pr = c->precise_stream != 0;
     if ((rc = lrx_pool_norm_shard(pr ? (const void*)ws.x32 : (const void*)ws.x, w->final_norm, pw.cu, n_seqs, c->hidden_size, c->rms_eps, out, out_row_stride,
-                                  out_dim, normalize, nullptr, 0, 0, nullptr, pr ? 1 : 0, s))) return rc; }
+                                  out_dim, normalize, nullptr, 0, nullptr, pr ? 1 : 0, s))) return rc; }
   return prof_end(s);
 }

@@ -35,7 +35,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- candidate lists of the score-free search filter (lrx_search.hip; the 256-query filter pass lives in lrx_gemm.hip)
-#define CAND_CAP 16384   // per-query capacity of the filter pass's emitted candidate list (score-free filter)
+#define CAND_CAP_MIN 16384   // smallest per-query capacity of the filter pass's candidate list (score-free filter); grows with k (lrx_search.hip: plan_chunk)
 #define CNT_STRIDE 64    // list fill counters sit 256 B apart: the reservations of different queries go to different memory channels
 
 __device__ __forceinline__ uint32_t f2key(float f) {  // monotone: larger float -> larger key
@@ -52,7 +52,7 @@ __device__ __forceinline__ unsigned long long sel_pack(uint32_t key, int64_t i) 
 }
 __device__ __forceinline__ int64_t sel_row(unsigned long long c) { return (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull)); }
 
-// ---- the tiled bf16 shadow of an index shard (include/lrx.h, lrx_shard_commit_rows): [128-row block][64-wide k-slice] tiles of 16 KiB, each tile
+// ---- the tiled fp16 shadow of an index shard (include/lrx.h, lrx_shard_commit_rows): [128-row block][64-wide k-slice] tiles of 16 KiB, each tile
 // FRAGMENT-MAJOR: [16-row group w = 0..7][k-step ks = 0..1][lane = fq*16 + fi][8], the MFMA 16x16x32 A operand of rows 16w + fi, k = 32 ks + 8 fq .. + 7,
 // so that a wave of the filter pass loads its fragment with one coalesced 1-KiB request.  Element (row r, column k), D % 64 == 0:
 __host__ __device__ __forceinline__ int64_t lrx_shadow_off(int64_t r, int k, int D) {
@@ -83,8 +83,8 @@ static inline int64_t lrx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // lrx_gemm.hip: the GEMM kernel as the search's filter pass for 129..256 queries: scores = Xb[rows, D] . q16[nq, D]^T (bf16 operands,
 // fp32 accumulation), nothing stored, rows reaching thr[query] appended to the query's candidate list.  Covers the 256-row tiles
 // that are not in the sample (every ss-th tile): n_tiles of them.
-int lrx_gemm_filter_emit_launch(const void* Xb, bool xb_tiled, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles,
-                                const float* thr, unsigned long long* cand, unsigned int* cnt, hipStream_t stream);
+int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles,
+                                const float* thr, unsigned long long* cand, unsigned int* cnt, unsigned int cap, hipStream_t stream);
 // lrx_gemm.hip: the GEMM kernel with the segmented-maximum epilogue (used by lrx_sparse_max_aggregate)
 int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias, const int32_t* row_seg, float* out, int64_t ldo, int M, int N,
                                   int K, hipStream_t stream);

@@ -266,16 +266,17 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// shadow != NULL: the row also goes out as bf16 (RNE) -- the filter pass of the search streams that copy; bounds != NULL: the two
-// shard bounds {max |row|, max |row - bf16(row)|} are raised by integer atomic max on the (non-negative) float patterns: the result
-// does not depend on the order rows arrive in.  This is the index maintenance of FlatIPIndex.commit fused into the row's producer.
+// shadow != NULL: the row also goes out as fp16 (RNE, saturating) into the shard's tiled shadow -- the filter pass of the search streams that
+// copy; bounds != NULL: the two shard bounds {max |row|, max |row - fp16(row)|} are raised by integer atomic max on the (non-negative) float
+// patterns: the result does not depend on the order rows arrive in.  This is the index maintenance of FlatIPIndex.commit fused into the
+// row's producer.
 // F32: `hidden` holds fp32 rows (the precise residual stream): the final norm then runs in fp32 without the two bf16 roundings of HF's
 // bf16 LlamaRMSNorm (the reference for the 1e-3 bound is the fp32 model).
 template <bool F32>
 __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidden_v, const __bf16* __restrict__ w,
                                                    const int32_t* __restrict__ cu, int H, float eps, float* __restrict__ out,
                                                    int64_t out_stride, int out_dim, int normalize, __bf16* __restrict__ shadow,
-                                                   int64_t shadow_stride, int64_t shadow_row0, float* __restrict__ bounds) {
+                                                   int64_t shadow_row0, float* __restrict__ bounds) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* row = (float*)smem_raw;  // H floats
   float* red = row + H;           // 4 floats
@@ -299,17 +300,15 @@ __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidd
   n2 = block_sum_256(n2, red);
   float scale = normalize ? 1.0f / fmaxf(sqrtf(n2), 1e-12f) : 1.0f;
   float* o = out + (int64_t)b * out_stride;
-  // shadow row: row-major (stride shadow_stride) or, stride 0, row shadow_row0 + b of the tiled layout (lrx_shadow_off)
+  // shadow row: row shadow_row0 + b of the tiled layout (lrx_shadow_off)
   const int64_t ra = shadow_row0 + b;
-  const bool tiled = shadow_stride == 0;
-  __bf16* ob = !shadow ? nullptr : (tiled ? shadow : shadow + (int64_t)b * shadow_stride);
   float r2 = 0.f, e2 = 0.f;
   for (int i = threadIdx.x; i < out_dim; i += 256) {
     const float v = normalize ? row[i] * scale : row[i];
     o[i] = v;
-    const __bf16 h = f2bf(v);
-    if (ob) ob[tiled ? lrx_shadow_off(ra, i, out_dim) : (int64_t)i] = h;
-    const float d = v - bf2f(h);
+    const _Float16 h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+    if (shadow) shadow[lrx_shadow_off(ra, i, out_dim)] = __builtin_bit_cast(__bf16, h);
+    const float d = v - (float)h;
     r2 += v * v;
     e2 += d * d;
   }
@@ -325,19 +324,17 @@ __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidd
 
 extern "C" int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                                    int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize,
-                                   void* shadow_out, int64_t shadow_row_stride, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32,
-                                   void* stream) {
+                                   void* shadow_out, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream) {
   LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden_size, "pool_norm: out_dim=%d out of range (H=%d)", out_dim, hidden_size);
-  LRX_CHECK_ARG(shadow_out == nullptr || shadow_row_stride >= out_dim || (shadow_row_stride == 0 && out_dim % 64 == 0 && shadow_row0 >= 0),
-                "pool_norm: bad shadow layout (row stride %lld, out_dim %d)", (long long)shadow_row_stride, out_dim);
+  LRX_CHECK_ARG(shadow_out == nullptr || (out_dim % 64 == 0 && shadow_row0 >= 0), "pool_norm: the tiled shadow needs out_dim %% 64 == 0 (out_dim %d)", out_dim);
   if (n_seqs == 0) return LRX_OK;
   size_t smem = (size_t)(hidden_size + 4) * sizeof(float);
   if (hidden_f32)
     hipLaunchKernelGGL(k_pool_norm<true>, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, hidden, (const __bf16*)final_norm_w, cu_seqlens,
-                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row_stride, shadow_row0, row_bounds);
+                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row0, row_bounds);
   else
     hipLaunchKernelGGL(k_pool_norm<false>, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, hidden, (const __bf16*)final_norm_w, cu_seqlens,
-                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row_stride, shadow_row0, row_bounds);
+                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row0, row_bounds);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -346,7 +343,7 @@ extern "C" int lrx_pool_norm(const void* hidden, const void* final_norm_w, const
                              int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize,
                              void* stream) {
   return lrx_pool_norm_shard(hidden, final_norm_w, cu_seqlens, n_seqs, hidden_size, eps, out, out_row_stride, out_dim, normalize, nullptr, 0,
-                             0, nullptr, 0, stream);
+                             nullptr, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -50,15 +50,15 @@ __device__ __forceinline__ __bf16 f2h_bits(float v) {   // fp16 (saturating) in 
   return __builtin_bit_cast(__bf16, (_Float16)fminf(fmaxf(v, -65504.f), 65504.f));
 }
 
-// Search filter pass (EPI_EMIT): A = bf16 shadow rows of the shard, B = bf16 queries; no C.  A score reaching thr[query] is appended
+// Search filter pass (EPI_EMIT): A = the shard's tiled FP16 shadow (lrx_shadow_off), B = fp16 queries (f16 MFMA); no C.  A score reaching thr[query] is appended
 // to the query's candidate list (lrx_search.hip).  ss > 0: m-tile t of the launch is the t-th 256-row tile that is NOT in the sample
 // (the sample = every ss-th tile).
 struct EmitArgs {
   const float* thr;          // [nq]
-  unsigned long long* cand;  // [nq, CAND_CAP]
+  unsigned long long* cand;  // [nq, cap]
   unsigned int* cnt;         // [nq * CNT_STRIDE]
   int ss;
-  int a_tiled;               // A is the tiled shadow (lrx_shadow_off) instead of row-major [M, K]
+  unsigned int cap;          // capacity of one candidate list
 };
 
 struct MaxAggArgs {
@@ -102,6 +102,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 
 
+// bf16 x bf16 for the encoder GEMMs; the search filter's instantiation multiplies fp16 operands (same containers, same data movement)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <int EPI>
+__device__ __forceinline__ f32x4 gemm_mfma(bf16x8 x, bf16x8 y, f32x4 c) {
+  if constexpr (EPI == EPI_EMIT) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+}
+
 template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
@@ -134,7 +142,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   for (int i = 0; i < 2; ++i) {
     int s = (wave * 2 + i) * 64 + lane;
     int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
-    if (EPI == EPI_EMIT && em.a_tiled) {
+    if (EPI == EPI_EMIT) {
       // tiled shadow: a half-tile (128 rows x 64) IS one 16-KiB fragment-major tile of the source -> copied linearly, 1 KiB per request
       // (the LDS image is then fragment-major too: laneoffA below); blocks past the last one re-read it, masked in the epilogue
       const int64_t lastb = (int64_t)(M - 1) >> 7;
@@ -150,7 +158,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   }
   char* const dma_dst = smem + wave * 2048;  // + buf*65536 + slot*16384 + i*1024
 #define G_KOFF(KT) ((KT) * GBK)
-  const int a_ks = (EPI == EPI_EMIT && em.a_tiled) ? 8192 : GBK;   // elements from one K-tile of an A row to the next
+  const int a_ks = (EPI == EPI_EMIT) ? 8192 : GBK;   // elements from one K-tile of an A row to the next
 #define G_ISSUE_(P, SLOT, BUF, KOFF)                                                                                       \
   do {                                                                                                                     \
     __builtin_amdgcn_global_load_lds((gptr_t)(P[0] + (KOFF)), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES), 16, 0, 0);        \
@@ -167,7 +175,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   for (int ks = 0; ks < 2; ++ks) laneoff[ks] = fr * 128 + (((ks * 4 + fq) ^ xs) << 4);
   int laneoffA[2];               // A-side fragment offsets: the swizzled row image, or (tiled shadow) the fragment-major tile [16-row group][ks][lane]
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) laneoffA[ks] = (EPI == EPI_EMIT && em.a_tiled) ? ks * 1024 + lane * 16 : laneoff[ks];
+  for (int ks = 0; ks < 2; ++ks) laneoffA[ks] = (EPI == EPI_EMIT) ? ks * 1024 + lane * 16 : laneoff[ks];
   const int a_off = (wr * 64) * 128, b_off = 2 * HALF_BYTES + (wc * 32) * 128;
 
   f32x4 acc[2][2][4][2];
@@ -191,7 +199,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   do {                                                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[H][HP][mi][ni] =                        \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][ks], a[mi][ks], acc[H][HP][mi][ni], 0, 0, 0); \
+            gemm_mfma<EPI>(b[ni][ks], a[mi][ks], acc[H][HP][mi][ni]); \
   } while (0)
 
   // folded RMSNorm: this lane's 8 row scales, requested now so they have long arrived when the epilogue multiplies
@@ -229,7 +237,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   do {                                                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[H][HP][mi][ni] =                        \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[ni][ks], a[mi][ks], acc[H][HP][mi][ni], 0, 0, 0); \
+            gemm_mfma<EPI>(b2[ni][ks], a[mi][ks], acc[H][HP][mi][ni]); \
   } while (0)
   // Lifetimes: A0,B0,B1 of K-tile t are read in P1(t) (B fragments stay in registers), A1 in P2(t).  Refill one phase after
   // the last read (stagger-safe): P2(t) issues A0,B0,B1 of t+2, P1(t) issues A1 of t+1 (t >= 1; K-tile 1's comes from the
@@ -312,7 +320,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
                   if (p < WCAP) { wl[p] = w; wq[p] = col; }
                   else {                                        // list full (a tile of near-duplicates): straight to the query's list
                     const unsigned int gp = atomicAdd(&em.cnt[col * CNT_STRIDE], 1u);
-                    if (gp < CAND_CAP) em.cand[(int64_t)col * CAND_CAP + gp] = w;
+                    if (gp < em.cap) em.cand[(int64_t)col * em.cap + gp] = w;
                   }
                   ++p;
                 }
@@ -325,7 +333,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
       const unsigned long long w = wl[i];
       const unsigned int col = wq[i];
       const unsigned int gp = atomicAdd(&em.cnt[col * CNT_STRIDE], 1u);
-      if (gp < CAND_CAP) em.cand[(int64_t)col * CAND_CAP + gp] = w;
+      if (gp < em.cap) em.cand[(int64_t)col * em.cap + gp] = w;
     }
     return;
   }
@@ -614,9 +622,9 @@ extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, con
   MaxAggArgs nomx = {nullptr, nullptr, 0};
   NormArgs nrm = {rscale, ss_part, gemm_group_m(epilogue, K)};
   switch (epilogue) {
-    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0}); break;
-    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0}); break;
-    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0}); break;
+    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u}); break;
+    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u}); break;
+    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u}); break;
   }
   LRX_LAUNCH_CHECK();
   return LRX_OK;
@@ -640,7 +648,7 @@ extern "C" int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C,
   RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)Wqkv,
                      (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{rscale, nullptr, 8}, EmitArgs{nullptr, nullptr, nullptr, 0, 0});
+                     NormArgs{rscale, nullptr, 8}, EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -657,7 +665,7 @@ extern "C" int lrx_gemm_bf16_nt_resid32(const void* A, const void* B, float* x32
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID32>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)B,
                      (__bf16*)a16_out, (const __bf16*)gamma, (const __bf16*)x32, M, N, K, tiles_m, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{nullptr, ss_part, gemm_group_m(EPI_RESID, K)}, EmitArgs{nullptr, nullptr, nullptr, 0, 0});
+                     NormArgs{nullptr, ss_part, gemm_group_m(EPI_RESID, K)}, EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -676,24 +684,24 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   MaxAggArgs mx = {row_seg, out, ldo};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
                      (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, LRX_MAXAGG_GM},
-                     EmitArgs{nullptr, nullptr, nullptr, 0, 0});
+                     EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
 
-// The filter pass of the bounded search for 129..256 queries (lrx_search.hip): the shard's bf16 shadow rows against the bf16 queries
+// The filter pass of the bounded search for 129..256 queries (lrx_search.hip): the shard's tiled fp16 shadow against the fp16 queries
 // on the GEMM kernel -- its 256 x 256 tile stages a query k-slice once per 256 rows and its 4-phase K loop keeps the LDS-DMA ahead of
 // the MFMAs with one workgroup per CU; the 128-row filter kernel re-stages the 32-KiB query slice for every 128 rows and is bound
 // by that L2 -> LDS traffic at 16 query tiles (1.19 ms for 256 queries over 1M x 2048; HBM floor 0.75).
-int lrx_gemm_filter_emit_launch(const void* Xb, bool xb_tiled, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles,
-                                const float* thr, unsigned long long* cand, unsigned int* cnt, hipStream_t stream) {
+int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles,
+                                const float* thr, unsigned long long* cand, unsigned int* cnt, unsigned int cap, hipStream_t stream) {
   LRX_CHECK_ARG(dim > 0 && dim % GBK == 0 && nq > 0 && nq <= GBN && n_rows < (1ll << 31), "filter_emit: bad shape rows=%lld nq=%d dim=%d",
                 (long long)n_rows, nq, dim);
   if (n_tiles <= 0) return LRX_OK;
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_EMIT>, dim3((unsigned)n_tiles), dim3(512), 0, stream, (const __bf16*)Xb, (const __bf16*)q16, (__bf16*)nullptr,
                      (const __bf16*)nullptr, (const __bf16*)nullptr, (int)n_rows, nq, dim, (int)n_tiles, 1, none, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{nullptr, nullptr, 8}, EmitArgs{thr, cand, cnt, ss, xb_tiled ? 1 : 0});
+                     NormArgs{nullptr, nullptr, 8}, EmitArgs{thr, cand, cnt, ss, cap});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

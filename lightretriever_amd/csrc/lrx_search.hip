@@ -24,6 +24,18 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// The single-product FILTER of the bounded search runs in FP16 since round 3 (shadow rows, query planes, MFMA 16x16x32 f16): 11
+// significant bits instead of bf16's 8 make the rigorous error band ~5x narrower (|x - fp16(x)| <= 2^-11 |x| element-wise), i.e. ~5x
+// fewer band rows to rescore and half the candidate-list entries.  16-bit containers stay typed bf16x8 (they are moved, not computed
+// on); conversions saturate at +-65504 so a value outside fp16's range shows up as a large measured rounding error E (-> huge band ->
+// exact fallback), never as inf / NaN.  The six-product exact path keeps its bf16 hi/mid/lo split (exact for any fp32 value).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ f32x4 mfma_f16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ _Float16 f2h_sat(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
+__device__ __forceinline__ __bf16 f2h_bits(float v) { return __builtin_bit_cast(__bf16, f2h_sat(v)); }
+
 #define S_ROWS 256       // corpus rows per workgroup
 #define S_BK 32          // floats per k-slice (128 B per row)
 #define S_XTILE (S_ROWS * S_BK * 4)
@@ -159,7 +171,7 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)r2;
 }
 
-// qs layout: [D/32 slices][NP planes][QT][64 lanes][8] bf16   (NP = 3: hi/mid/lo, NP = 1: hi only)
+// qs layout: [D/32 slices][NP planes][QT][64 lanes][8] 16-bit   (NP = 3: bf16 hi/mid/lo, NP = 1: fp16(q))
 __device__ __forceinline__ void split_queries_body(const float* __restrict__ Q, int nq, int D, int QT, int NP, __bf16* __restrict__ qs, int gid) {
   int lane = gid & 63, rest = gid >> 6;
   int qt = rest % QT, kt = rest / QT;
@@ -173,7 +185,7 @@ __device__ __forceinline__ void split_queries_body(const float* __restrict__ Q, 
     float v = row < nq ? Q[(int64_t)row * D + k] : 0.f;
     __bf16 a, b, c;
     split3(v, a, b, c);
-    h[j] = a; m[j] = b; l[j] = c;
+    h[j] = NP == 1 ? f2h_bits(v) : a; m[j] = b; l[j] = c;      // one plane = the fp16 filter operand; three = the exact bf16 split
   }
   int64_t base = (((int64_t)kt * NP) * QT + qt) * 64 + lane;
   bf16x8* out = (bf16x8*)qs;
@@ -197,7 +209,7 @@ struct PreSplit {
   int nf[2] = {0, 0}, qt[2] = {0, 0}, blocks[2] = {0, 0};
 };
 
-// bf16-shadow filter: natural k order, 64-wide slices.  qs layout: [D/64 slices][2 k-steps][QT][64 lanes][8] bf16, lane (fi = query in
+// shadow filter: natural k order, 64-wide slices, fp16.  qs layout: [D/64 slices][2 k-steps][QT][64 lanes][8] fp16, lane (fi = query in
 // tile, fq) of k-step ks holds k = slice*64 + ks*32 + fq*8 .. +7 (the MFMA 16x16x32 operand layout).
 // zero / nzero: ints cleared on the way (the flags and list counters of a bounded search: this is the first kernel of its chain, so the
 // clear needs no launch of its own)
@@ -220,24 +232,24 @@ __global__ void k_pack_queries_xb(const float* __restrict__ Q, int nq, int D, in
   int row = qt * 16 + fi;
   bf16x8 h;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) h[j] = (__bf16)(row < nq ? Q[(int64_t)row * D + sl * 64 + ks * 32 + fq * 8 + j] : 0.f);
+  for (int j = 0; j < 8; ++j) h[j] = f2h_bits(row < nq ? Q[(int64_t)row * D + sl * 64 + ks * 32 + fq * 8 + j] : 0.f);
   ((bf16x8*)qs)[(((int64_t)sl * 2 + ks) * QT + qt) * 64 + lane] = h;
 }
 
-// plain bf16 copy of the queries [nq, D] (RNE): the B operand of the 256-query filter pass on the GEMM kernel
+// plain fp16 copy of the queries [nq, D] (RNE, saturating): the B operand of the 256-query filter pass on the GEMM kernel
 __global__ void k_round_queries(const float* __restrict__ Q, int64_t n, __bf16* __restrict__ q16) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   const f32x4 v = *(const f32x4*)(Q + i);
   bf16x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+  for (int e = 0; e < 4; ++e) o[e] = f2h_bits(v[e]);
   *(bf16x4*)(q16 + i) = o;
 }
 
-// RT = 16-row tiles per wave (rows per workgroup = 64 RT), NST = LDS stages of the k-slice ring.  The six-product kernel runs
-// (RT 2, NST 2, two workgroups per CU: it is bound by the matrix pipe); the single-product filter kernel is HBM-bound and runs the
-// deeper / wider shape selected by SPF_RT / SPF_NST.
+// RT = 16-row tiles per wave (rows per workgroup = 16 RT WV), NST = LDS stages of the k-slice ring.  The six-product kernel runs
+// (RT 2, NST 2, 4 waves, two workgroups per CU: it is bound by the matrix pipe); the single-product filter over fp32 rows (a shard without
+// a shadow: rows converted to fp16 in registers) is HBM-bound and runs the deeper / wider shape selected by SPF_RT / SPF_NST.
 #ifndef SPF_RT
 #define SPF_RT 2
 #endif
@@ -247,50 +259,26 @@ __global__ void k_round_queries(const float* __restrict__ Q, int64_t n, __bf16* 
 #ifndef SPF_WV
 #define SPF_WV 8
 #endif
-// shape of the bf16-shadow filter kernel (its q slice is twice as large per stage: 128-row workgroups keep two per CU)
-#ifndef SPX_RT
-#define SPX_RT 1
-#endif
-#ifndef SPX_NST
-#define SPX_NST 2
-#endif
-#ifndef SPX_WV
-#define SPX_WV 8
-#endif
-#ifndef SPX_QSB
-#define SPX_QSB true
-#endif
-#ifndef SPX_AUX
-#define SPX_AUX 2   // cache-policy bits of the corpus-row requests (bit 0 sc0, bit 1 nt, bit 4 sc1): the rows are streamed once -> nt (Q = 1: 0.87 -> 0.79 ms, Q = 100: -1.3 %; sc0 / sc1 alone: no change)
-#endif
-// XB: X is the bf16 shadow of the corpus (half the bytes; k-slices of 64 in natural order, fragments read straight from LDS).
-// QSB: the q k-slice is single-buffered (re-requested after a second barrier per iteration; it comes from L2) so that only the X
-// slices are double-buffered: 48 KiB of LDS per 128-row workgroup -> three workgroups per CU, i.e. 1.5x the HBM bytes in flight of the
-// two-per-CU layout (the shadow filter pass is bound by bytes in flight x latency, not by the matrix pipe or the LDS).
 // EMIT (score-free filter): nothing is stored per (query, row); a lane appends (score key, row) to the query's candidate list only when
 // the filter score reaches thr[query] (= a guaranteed lower bound of the k-th largest filter score minus the error band), i.e. for
 // ~1e-3 of the scores.  bmode selects the 16*RT*WV-row blocks a launch covers: 0 = all, 1 = the sample (every ss-th block, results
-// stored compactly at block index blockIdx.x), 2 = all blocks that are not in the sample.
-template <int QT, int NP, int RT, int NST, int WV, bool XB = false, bool QSB = false, bool EMIT = false>
-__global__ void __launch_bounds__(64 * WV, QSB ? (QT > 8 ? 2 : 3) : ((NST * (16 * RT * WV * 128 + (((XB ? 2 : NP) * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1))
-k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
+// stored compactly at block index blockIdx.x), 2 = all blocks that are not in the sample.  cap = capacity of a candidate list.
+template <int QT, int NP, int RT, int NST, int WV, bool EMIT = false>
+__global__ void __launch_bounds__(64 * WV, ((NST * (16 * RT * WV * 128 + ((NP * QT + WV - 1) / WV) * WV * 1024) <= 81920) ? 2 : 1))
+k_flat_ip_scores_split(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const __bf16* __restrict__ qs, int nq,
                        float* __restrict__ scores, int64_t ld, float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate,
                        int bmode, int ss, int unit, const float* __restrict__ thr, unsigned long long* __restrict__ cand,
-                       unsigned int* __restrict__ cnt, int64_t nbx) {
-  static_assert(!XB || NP == 1, "the bf16 shadow is a single-product filter");
+                       unsigned int* __restrict__ cnt, int64_t nbx, unsigned int cap) {
   static_assert(!EMIT || NP == 1, "the emitting epilogue belongs to the single-product filter");
-  const float* X = (const float*)Xv;
-  const __bf16* Xb = (const __bf16*)Xv;
   constexpr int RB = 16 * RT * WV;               // corpus rows per workgroup (WV waves x RT 16-row tiles)
-  constexpr int QINST = (XB ? 2 : NP) * QT;      // 1-KiB LDS-DMA instructions per q slice
+  constexpr int QINST = NP * QT;                 // 1-KiB LDS-DMA instructions per q slice
   constexpr int QI4 = (QINST + WV - 1) / WV;     // ... per wave (the last ones re-load the final plane into padding: equal counts per wave)
   constexpr int QBYTES = QI4 * WV * 1024;
   constexpr int XT = RB * S_BK * 4;              // X k-slice: RB rows x 128 B
   constexpr int STAGE = XT + QBYTES;
   constexpr int CW = 2 * RT + QI4;               // DMA instructions per wave per stage
   static_assert((NST - 1) * CW <= 63, "vmcnt immediate");
-  static_assert(!QSB || (XB && NST == 2), "single-buffered q: shadow filter with two X stages");
-  constexpr int LDS_BYTES = QSB ? (2 * XT + QBYTES) : NST * STAGE;
+  constexpr int LDS_BYTES = NST * STAGE;
   __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
   if (gate != nullptr && *gate == 0) return;     // fallback launch of the bounded search: nothing overflowed
   const int tid = threadIdx.x, lane = tid & 63;
@@ -308,25 +296,21 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
   const int64_t n0 = blk * RB;                     // corpus rows of this workgroup
   const int64_t n0s = bx * RB;    // where its scores go (compact in sample mode)
 
-  const char* px[2 * RT];                        // byte pointers: both element types move 128 B per row per k-slice
+  const float* px[2 * RT];
 #pragma unroll
   for (int i = 0; i < 2 * RT; ++i) {
     int s = (wave * 2 * RT + i) * 64 + lane;
     int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
     int64_t g = min(n0 + row, N - 1);
-    // (row-major bf16 shadow here; the tiled shadow has its own kernels, k_filter_xreg / k_filter_xreg_emit)
-    px[i] = !XB ? (const char*)(X + g * ldx + c * 4) : (const char*)(Xb + g * ldx + c * 8);
+    px[i] = X + g * ldx + c * 4;
   }
-  constexpr int64_t kstep_b = 128;                 // bytes from one k-slice of a row to the next
   const __bf16* pq = qs + (int64_t)lane * 8;     // + (kt*QINST + j) * 512 elements
-  auto stage_x = [&](int st, int kt) {
-    char* sX = smem + st * (QSB ? XT : STAGE);
+  auto stage = [&](int st, int kt) {
+    char* sX = smem + st * STAGE;
 #pragma unroll
     for (int i = 0; i < 2 * RT; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + (int64_t)kt * kstep_b), (lptr_t)(sX + (wave * 2 * RT + i) * 1024), 16, 0, SPX_AUX);
-  };
-  auto stage_q = [&](int st, int kt) {
-    char* sQ = QSB ? smem + 2 * XT : smem + st * STAGE + XT;
+      __builtin_amdgcn_global_load_lds((gptr_t)(px[i] + (int64_t)kt * S_BK), (lptr_t)(sX + (wave * 2 * RT + i) * 1024), 16, 0, 2 /* nt: streamed once */);
+    char* sQ = sX + XT;
 #pragma unroll
     for (int jj = 0; jj < QI4; ++jj) {
       const int j = wave + WV * jj;
@@ -334,7 +318,6 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
       __builtin_amdgcn_global_load_lds((gptr_t)(pq + ((int64_t)kt * QINST + jsrc) * 512), (lptr_t)(sQ + j * 1024), 16, 0, 0);
     }
   };
-  auto stage = [&](int st, int kt) { stage_x(st, kt); stage_q(st, kt); };
 
   const int fi = lane & 15, fq = lane >> 4;
   const int xs = fi >> 1;
@@ -347,52 +330,19 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
 #pragma unroll
     for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = XB ? D / 64 : D / S_BK;
-  if (QSB) {
-    stage_x(0, 0); stage_q(0, 0);
-    if (nk > 1) stage_x(1, 1);
-  } else {
+  const int nk = D / S_BK;
 #pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
-      if (st < nk) stage(st, st);
-  }
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nk) stage(st, st);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt % NST;
-    if (QSB) {
-      // in flight at most the X slice of kt+1 (issued last): X(kt) and q(kt) have landed
-      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    } else {
     // stage kt has landed when at most the (NST-2) younger stages' instructions of this wave are outstanding
     if (NST > 2 && kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * CW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // everyone's part of stage kt is in LDS; slot (kt-1) % NST is free
     if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST, kt + NST - 1);
-    }
-    const char* sX = smem + cur * (QSB ? XT : STAGE) + (wave * 16 * RT) * 128;
-    const char* sQ = (QSB ? smem + 2 * XT : smem + cur * STAGE + XT) + lane * 16;
-    if (XB) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 xf[RT];
-#pragma unroll
-        for (int a = 0; a < RT; ++a) xf[a] = *(const bf16x8*)(sX + a * 2048 + fi * 128 + (((ks * 4 + fq) ^ xs) << 4));
-#pragma unroll
-        for (int b = 0; b < QT; ++b) {
-          const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
-#pragma unroll
-          for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], qf, acc[a][b], 0, 0, 0);
-        }
-      }
-      if (QSB && kt + 1 < nk) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // every wave has read q(kt) and X slot cur: both may be overwritten
-        stage_q(0, kt + 1);
-        if (kt + 2 < nk) stage_x(cur, kt + 2);             // issued after q: stays in flight across the next wait
-      }
-      continue;
-    }
+    const char* sX = smem + cur * STAGE + (wave * 16 * RT) * 128;
+    const char* sQ = smem + cur * STAGE + XT + lane * 16;
     bf16x8 xh[RT], xm[NP == 3 ? RT : 1], xl[NP == 3 ? RT : 1];
 #pragma unroll
     for (int a = 0; a < RT; ++a) {
@@ -406,9 +356,9 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
           xh[a][j] = h; xm[a][j] = m; xl[a][j] = l;
           split3(v1[j], h, m, l);
           xh[a][4 + j] = h; xm[a][4 + j] = m; xl[a][4 + j] = l;
-        } else {
-          xh[a][j] = (__bf16)v0[j];
-          xh[a][4 + j] = (__bf16)v1[j];
+        } else {                                           // the filter operand: fp16(x), like a shadow row would hold
+          xh[a][j] = f2h_bits(v0[j]);
+          xh[a][4 + j] = f2h_bits(v1[j]);
         }
       }
     }
@@ -431,7 +381,7 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
         }
       } else {
 #pragma unroll
-        for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], qh, acc[a][b], 0, 0, 0);
+        for (int a = 0; a < RT; ++a) acc[a][b] = mfma_f16(xh[a], qh, acc[a][b]);
       }
     }
   }
@@ -471,7 +421,7 @@ k_flat_ip_scores_split(const void* __restrict__ Xv, int64_t N, int64_t ldx, int 
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (n + e < N && acc[a][b][e] >= t[b]) {
-              if (pp < CAND_CAP) cand[(int64_t)(b * 16 + fi) * CAND_CAP + pp] = sel_pack(f2key(acc[a][b][e]), n + e);
+              if (pp < cap) cand[(int64_t)(b * 16 + fi) * cap + pp] = sel_pack(f2key(acc[a][b][e]), n + e);
               ++pp;
             }
         }
@@ -558,7 +508,8 @@ template <int QT, int PF, bool EMIT, int RT = 1>
 __global__ void __launch_bounds__(576, QT > 8 ? 1 : 2)
 k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, float* __restrict__ scores, int64_t ld,
               float* __restrict__ blkmax, int nblk_ld, const int* __restrict__ gate, int bmode, int ss, int unit,
-              const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, int nlaunch, int gmax) {
+              const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, int nlaunch, int gmax,
+              unsigned int cap) {
   // RT = blocks per workgroup (launch indices RT * blockIdx.x + a < nlaunch): with two, the q slice is fetched once per 256 rows -- the
   // sample pass of a 100-query search had 391 workgroups on 256 CUs, one or two per CU (56 -> 52 us; Q = 128: 61 -> 50 us)
   static_assert(RT == 1 || !EMIT, "the emitting epilogue works on one block");
@@ -638,7 +589,7 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
         for (int b = 0; b < QT; ++b) {
           const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
 #pragma unroll
-          for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][a][ks], qf, acc[a][b], 0, 0, 0);
+          for (int a = 0; a < RT; ++a) acc[a][b] = mfma_f16(xf[u][a][ks], qf, acc[a][b]);
         }
     };
     // steady state: every step of the trip prefetches (no guard -> the compiler's counted vmcnt keeps PF-1 slices in flight);
@@ -693,7 +644,7 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (n + e < N && acc[0][b][e] >= t[b]) {
-            if (pp < CAND_CAP) cand[(int64_t)(b * 16 + fi) * CAND_CAP + pp] = sel_pack(f2key(acc[0][b][e]), n + e);
+            if (pp < cap) cand[(int64_t)(b * 16 + fi) * cap + pp] = sel_pack(f2key(acc[0][b][e]), n + e);
             ++pp;
           }
       }
@@ -767,7 +718,7 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
 template <int QT, int PF, int RT>
 __global__ void __launch_bounds__(576, (QT > 8 || RT > 1) ? 3 : 5)   // (second argument: waves per SIMD -> two workgroups of nine waves per CU need five)
 k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, int nblocks, int bmode, int ss,
-                   int unit, const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt) {
+                   int unit, const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, unsigned int cap) {
   constexpr int WV = 8;
   constexpr int QINST = 2 * QT;
   constexpr int QBYTES = QINST * 1024;
@@ -849,7 +800,7 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
       const unsigned long long w = wl[i];
       const unsigned int col = wq[i];
       const unsigned int gp = atomicAdd(&cnt[col * CNT_STRIDE], 1u);
-      if (gp < CAND_CAP) cand[(int64_t)col * CAND_CAP + gp] = w;
+      if (gp < cap) cand[(int64_t)col * cap + gp] = w;
     }
     wcnt = 0;
   };
@@ -911,13 +862,13 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
           for (int b = 0; b < QT; ++b) {
             const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
 #pragma unroll
-            for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][a][ks], qf, acc[a][b], 0, 0, 0);
+            for (int a = 0; a < RT; ++a) acc[a][b] = mfma_f16(xf[u][a][ks], qf, acc[a][b]);
           }
         }
       }
     }
     // ---- block epilogue: D[i = corpus row][j = query]: lane holds query fi of tile b, rows fq*4 + {0..3}.  LDS only: a wave tile with
-    //      more hits than the list holds (near-duplicate rows) pushes the query's counter past CAND_CAP instead -> flagged, redone by the fallback
+    //      more hits than the list holds (near-duplicate rows) pushes the query's counter past the list capacity instead -> flagged, redone by the fallback
 #pragma unroll
     for (int a = 0; a < RT; ++a) {
       const int64_t n64 = (int64_t)blk_of(li_of(j, a)) * 128 + wave * 16 + fq * 4;
@@ -951,7 +902,7 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
         if ((ovf >> b) & 1u) {
           unsigned int col = b * 16 + fi;
           asm volatile("" : "+v"(col));             // (keeps the address arithmetic inside this cold branch)
-          __hip_atomic_fetch_add(&cnt[col * CNT_STRIDE], (unsigned int)CAND_CAP + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(&cnt[col * CNT_STRIDE], cap + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       ovf = 0;
     }
@@ -980,7 +931,7 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
   for (unsigned int i = lane; i < tot; i += 64) {
     const unsigned int col = wq[i];
     const unsigned int slot = qbase[col] + atomicAdd(&qcnt[col], 1u);
-    if (slot < CAND_CAP) cand[(int64_t)col * CAND_CAP + slot] = wl[i];
+    if (slot < cap) cand[(int64_t)col * cap + slot] = wl[i];
   }
 }
 
@@ -1115,7 +1066,7 @@ k_filter_xreg_store(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf1
           for (int b = 0; b < QT; ++b) {
             const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
 #pragma unroll
-            for (int a = 0; a < RT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][a][ks], qf, acc[a][b], 0, 0, 0);
+            for (int a = 0; a < RT; ++a) acc[a][b] = mfma_f16(xf[u][a][ks], qf, acc[a][b]);
           }
       }
     }
@@ -1166,19 +1117,20 @@ struct FilterMode {
   int unit = 1;                           // workgroup blocks per sample unit (2: the 256-query main pass works on 256-row tiles)
   int64_t nblocks = -1;                   // workgroups to launch (-1: ld / rows-per-workgroup)
   const float* thr = nullptr;             // emit mode: per-query threshold
-  unsigned long long* cand = nullptr;     // emit mode: candidate lists [Q, CAND_CAP]
+  unsigned long long* cand = nullptr;     // emit mode: candidate lists [Q, cap]
   unsigned int* cnt = nullptr;            //            and their fill counts
+  unsigned int cap = CAND_CAP_MIN;        //            capacity of one list
   int* zero = nullptr;                    // shadow filter: ints the query-packing kernel clears on the way (first launch of a bounded search)
   int nzero = 0;
   PreSplit presplit;                      // shadow filter: fallback planes the packing kernel writes on the way (ngroups > 0)
   bool planes_ready = false;              // six-product pass: `qsplit` already holds the planes (see PreSplit)
-  bool group_max = false;                 // tiled-shadow kernels, score stores: `blkmax` receives the maxima of the 16-row wave groups
+  bool group_max = false;                 // shadow kernels, score stores: `blkmax` receives the maxima of the 16-row wave groups
                                           // (8 per block, row stride 8 x nblk_ld) instead of one maximum per 128-row block
 };
 
-// planes = 3: fp32-grade scores (six bf16 products); planes = 1: one bf16 product (filter pass of the bounded search, error bound
+// planes = 3: fp32-grade scores (six bf16 products); planes = 1: one fp16 product (filter pass of the bounded search, error bound
 // query_eps_block); gate != NULL: the whole pass is skipped unless *gate != 0.  One call covers at most one query chunk (128 queries, 256
-// for the shadow filter); `ld` is the row stride of `scores` / rounded row count.
+// for the shadow filter); `ld` is the row stride of `scores` / rounded row count.  Xs = the shard's tiled fp16 shadow (planes == 1) or NULL.
 static int lrx_cu_count() {
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -1189,11 +1141,11 @@ static int lrx_cu_count() {
   return n_cu;
 }
 
-static int filter_rows_per_wg(bool shadow) { return shadow ? 16 * SPX_RT * SPX_WV : 16 * SPF_RT * SPF_WV; }
+static int filter_rows_per_wg(bool shadow) { return shadow ? 128 : 16 * SPF_RT * SPF_WV; }
 
 static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, float* scores,
-                         float* blkmax, __bf16* qsplit, void* stream, int planes = 3, const int* gate = nullptr, const void* Xb = nullptr,
-                         int64_t ldxb = 0, int64_t ld = 0, const FilterMode& fm = FilterMode()) {
+                         float* blkmax, __bf16* qsplit, void* stream, int planes = 3, const int* gate = nullptr, const void* Xs = nullptr,
+                         int64_t ld = 0, const FilterMode& fm = FilterMode()) {
   LRX_CHECK_ARG(dim > 0 && dim % S_BK == 0, "flat_ip: dim=%d must be a multiple of %d", dim, S_BK);
   LRX_CHECK_ARG(ldx >= dim && ldx % 4 == 0, "flat_ip: ldx=%lld must be >= dim and a multiple of 4", (long long)ldx);
   if (n_rows <= 0 || n_queries <= 0) return LRX_OK;
@@ -1203,9 +1155,9 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
   dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool emit = fm.cand != nullptr;
-  // queries per pass over the corpus: 128 (8 MFMA tiles); the shadow filter takes up to 256 (16 tiles, 64 KiB of LDS, two workgroups
-  // per CU) -- a large query batch then streams the shadow half as often
-  const bool shadow_pass = qsplit != nullptr && planes == 1 && Xb != nullptr;
+  // queries per pass over the corpus: 128 (8 MFMA tiles); the shadow filter takes up to 256 (16 tiles) -- a large query batch then
+  // streams the shadow half as often
+  const bool shadow_pass = qsplit != nullptr && planes == 1 && Xs != nullptr;
   const int chunk = shadow_pass ? 256 : 128;
   LRX_CHECK_ARG(fm.bmode == 0 || (planes == 1 && qsplit != nullptr && n_queries <= chunk), "flat_ip: sampled filter launch outside the bounded search");
   for (int q0 = 0; q0 < n_queries; q0 += chunk) {
@@ -1215,8 +1167,8 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
     float* sp = scores ? scores + (int64_t)q0 * ld : nullptr;
     float* bp = blkmax ? blkmax + (int64_t)q0 * nblk_ld : nullptr;
     if (shadow_pass) {   // any query count: the shadow pass beats the exact-fp32 kernel from Q = 1
-      // filter pass over the bf16 shadow of the corpus: half the bytes of the fp32 rows
-      const int64_t nwg = fm.nblocks >= 0 ? fm.nblocks : ld_full / (16 * SPX_RT * SPX_WV);
+      // filter pass over the fp16 shadow of the corpus: half the bytes of the fp32 rows, fragments streamed through registers
+      const int64_t nwg = fm.nblocks >= 0 ? fm.nblocks : ld_full / 128;
       if (nwg == 0) continue;
       if (fm.bmode != 2) {   // (the main pass of the score-free filter reuses the planes packed for its sample pass)
         int threads = (dim / 64) * 2 * qt * 64;
@@ -1225,33 +1177,32 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
         hipLaunchKernelGGL(k_pack_queries_xb, dim3(ps.nb_xb + (ps.ngroups > 0 ? ps.blocks[0] + ps.blocks[1] : 0)), dim3(256), 0, s, qp, nq, dim, qt, qsplit,
                            fm.zero, fm.nzero, ps);
       }
-      if (ldxb == 0) {
-        // tiled shadow: corpus fragments through registers.  Main pass of the score-free filter: persistent workgroups, one per CU
-        // (D / 64 a multiple of the ring depth); everything else: one workgroup per 128-row block
-        constexpr int XPF = 4;
+      // Main pass of the score-free filter: persistent workgroups, one per CU (D / 64 a multiple of the ring depth); everything
+      // else: one workgroup per 128-row block
+      constexpr int XPF = 4;
 #ifndef XPF_S
 #define XPF_S 4   // ring depth of the one-workgroup-per-block form (8: no faster at D = 2048, 13 % slower at 10M x 256, Q = 1)
 #endif
-        const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31);
-        const int n_cu = lrx_cu_count();
-        const bool two_blocks = !emit && fm.bmode == 1 && nwg < (1ll << 31);
-        // sample pass of a large shard (more than two block pairs per CU): persistent workgroups
-        const bool persistent_store = two_blocks && fm.group_max && gate == nullptr && sp != nullptr && bp != nullptr && qt <= 8 && (dim / 64) % XPF == 0 &&
-                                      (nwg + 1) / 2 > 2 * (int64_t)n_cu;
+      const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31);
+      const int n_cu = lrx_cu_count();
+      const bool two_blocks = !emit && fm.bmode == 1 && nwg < (1ll << 31);
+      // sample pass of a large shard (more than two block pairs per CU): persistent workgroups
+      const bool persistent_store = two_blocks && fm.group_max && gate == nullptr && sp != nullptr && bp != nullptr && qt <= 8 && (dim / 64) % XPF == 0 &&
+                                    (nwg + 1) / 2 > 2 * (int64_t)n_cu;
 #define LRX_XP(QQ, RT_)                                                                                                                     \
   {                                                                                                                                         \
     const int64_t groups = (nwg + RT_ - 1) / RT_;                                                                                           \
-    hipLaunchKernelGGL((k_filter_xreg_emit<QQ, (QQ == 8 ? 2 : XPF), RT_>), dim3((unsigned)(groups < n_cu ? groups : n_cu)), dim3(576), 0, s, (const __bf16*)Xb, n_rows, \
-                       dim, qsplit, nq, (int)nwg, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt);                                      \
+    hipLaunchKernelGGL((k_filter_xreg_emit<QQ, (QQ == 8 ? 2 : XPF), RT_>), dim3((unsigned)(groups < n_cu ? groups : n_cu)), dim3(576), 0, s, (const __bf16*)Xs, n_rows, \
+                       dim, qsplit, nq, (int)nwg, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, fm.cap);                              \
   }
 #define LRX_XN(QQ, EM_)                                                                                                                     \
-  hipLaunchKernelGGL((k_filter_xreg<QQ, (EM_ ? XPF : XPF_S), EM_>), dim3((unsigned)nwg), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
-                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg, fm.group_max ? 1 : 0);
+  hipLaunchKernelGGL((k_filter_xreg<QQ, (EM_ ? XPF : XPF_S), EM_>), dim3((unsigned)nwg), dim3(576), 0, s, (const __bf16*)Xs, n_rows, dim, qsplit, nq, sp, ld, bp, \
+                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg, fm.group_max ? 1 : 0, fm.cap);
 #define LRX_XN2(QQ)   /* sample pass: two blocks per workgroup */                                                                           \
-  hipLaunchKernelGGL((k_filter_xreg<QQ, XPF, false, 2>), dim3((unsigned)((nwg + 1) / 2)), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
-                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg, fm.group_max ? 1 : 0);
+  hipLaunchKernelGGL((k_filter_xreg<QQ, XPF, false, 2>), dim3((unsigned)((nwg + 1) / 2)), dim3(576), 0, s, (const __bf16*)Xs, n_rows, dim, qsplit, nq, sp, ld, bp, \
+                     nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int)nwg, fm.group_max ? 1 : 0, fm.cap);
 #define LRX_XS(QQ)   /* sample pass of a large shard: persistent, two blocks at a time (one from seven query tiles on: registers) */                                                  \
-  hipLaunchKernelGGL((k_filter_xreg_store<(QQ), XPF, ((QQ) <= 6 ? 2 : 1)>), dim3((unsigned)n_cu), dim3(576), 0, s, (const __bf16*)Xb, n_rows, dim, qsplit, nq, sp, ld, bp, \
+  hipLaunchKernelGGL((k_filter_xreg_store<(QQ), XPF, ((QQ) <= 6 ? 2 : 1)>), dim3((unsigned)n_cu), dim3(576), 0, s, (const __bf16*)Xs, n_rows, dim, qsplit, nq, sp, ld, bp, \
                      nblk_ld, (int)nwg, fm.bmode, fm.ss, fm.unit);
 #define LRX_XR(QQ, RT_)                                  \
   case QQ:                                               \
@@ -1261,30 +1212,13 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
     else if (two_blocks && QQ <= 8) { LRX_XN2(QQ <= 8 ? QQ : 1) } \
     else { LRX_XN(QQ, false) }                           \
     break;
-        switch (qt) { LRX_XR(1, 2) LRX_XR(2, 2) LRX_XR(3, 2) LRX_XR(4, 2) LRX_XR(5, 2) LRX_XR(6, 2) LRX_XR(7, 2) LRX_XR(8, 2)
-                     LRX_XR(9, 1) LRX_XR(10, 1) LRX_XR(11, 1) LRX_XR(12, 1) LRX_XR(13, 1) LRX_XR(14, 1) LRX_XR(15, 1) LRX_XR(16, 1) }
+      switch (qt) { LRX_XR(1, 2) LRX_XR(2, 2) LRX_XR(3, 2) LRX_XR(4, 2) LRX_XR(5, 2) LRX_XR(6, 2) LRX_XR(7, 2) LRX_XR(8, 2)
+                   LRX_XR(9, 1) LRX_XR(10, 1) LRX_XR(11, 1) LRX_XR(12, 1) LRX_XR(13, 1) LRX_XR(14, 1) LRX_XR(15, 1) LRX_XR(16, 1) }
 #undef LRX_XR
 #undef LRX_XN
 #undef LRX_XN2
 #undef LRX_XS
 #undef LRX_XP
-        LRX_LAUNCH_CHECK();
-        continue;
-      }
-#define LRX_SB_(QQ, QSB_, EM_)                                                                                                                         \
-    hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPX_RT, SPX_NST, SPX_WV, true, QSB_, EM_>), dim3((unsigned)nwg), dim3(64 * SPX_WV), 0, s, Xb, n_rows, \
-                       ldxb, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int64_t)nwg);
-#define LRX_SB(QQ, QSB_)                  \
-  case QQ:                                \
-    if (emit) { LRX_SB_(QQ, QSB_, true) } \
-    else { LRX_SB_(QQ, QSB_, false) }     \
-    break;
-      // q slices of one or two tiles are small enough for three workgroups per CU even double-buffered; from three tiles on the
-      // single-buffered q layout buys the third workgroup (Q = 100: 1.23 -> 1.19 ms)
-      switch (qt) { LRX_SB(1, false) LRX_SB(2, false) LRX_SB(3, SPX_QSB) LRX_SB(4, SPX_QSB) LRX_SB(5, SPX_QSB) LRX_SB(6, SPX_QSB) LRX_SB(7, SPX_QSB) LRX_SB(8, SPX_QSB)
-                   LRX_SB(9, SPX_QSB) LRX_SB(10, SPX_QSB) LRX_SB(11, SPX_QSB) LRX_SB(12, SPX_QSB) LRX_SB(13, SPX_QSB) LRX_SB(14, SPX_QSB) LRX_SB(15, SPX_QSB) LRX_SB(16, SPX_QSB) }
-#undef LRX_SB
-#undef LRX_SB_
       LRX_LAUNCH_CHECK();
       continue;
     }
@@ -1298,11 +1232,11 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
         hipLaunchKernelGGL(k_split_queries, dim3((threads + 255) / 256), dim3(256), 0, s, qp, nq, dim, qt, planes, qsplit, gate);
       }
 #define LRX_SF_(QQ, EM_)                                                                                                                          \
-    hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPF_RT, SPF_NST, SPF_WV, false, false, EM_>), dim3((unsigned)nwg), dim3(64 * SPF_WV), 0, s, X, n_rows, ldx, \
-                       dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int64_t)nwg);
+    hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 1, SPF_RT, SPF_NST, SPF_WV, EM_>), dim3((unsigned)nwg), dim3(64 * SPF_WV), 0, s, X, n_rows, ldx, \
+                       dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, fm.bmode, fm.ss, fm.unit, fm.thr, fm.cand, fm.cnt, (int64_t)nwg, fm.cap);
 #define LRX_SS(QQ)                                                                                                                              \
   case QQ:                                                                                                                                      \
-    if (planes == 3) hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 3, 2, 2, 4>), dim3((unsigned)(gate != nullptr && nwg > gated_cap ? gated_cap : nwg)), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, 0, 1, 1, (const float*)nullptr, (unsigned long long*)nullptr, (unsigned int*)nullptr, (int64_t)nwg); \
+    if (planes == 3) hipLaunchKernelGGL((k_flat_ip_scores_split<QQ, 3, 2, 2, 4>), dim3((unsigned)(gate != nullptr && nwg > gated_cap ? gated_cap : nwg)), block, 0, s, X, n_rows, ldx, dim, qsplit, nq, sp, ld, bp, nblk_ld, gate, 0, 1, 1, (const float*)nullptr, (unsigned long long*)nullptr, (unsigned int*)nullptr, (int64_t)nwg, 0u); \
     else if (emit) { LRX_SF_(QQ, true) }                                                                                                        \
     else { LRX_SF_(QQ, false) }                                                                                                                 \
     break;
@@ -1589,14 +1523,32 @@ __device__ __forceinline__ float exact_dot(const float* __restrict__ x, const fl
   return (float)acc;
 }
 
-// Select + final step of the plain path in one launch: the k selected rows of each query are rescored with exact_dot and re-sorted (score
-// desc, id asc).  (Two kernels until round 2; the gated fallback of the bounded search runs the same pair, and every launch that returns
-// at once still costs ~4.5 us of its chain.)  The selected rows stay in LDS between the two steps.
+// Select + final step of the plain path (and of the gated fallback of the bounded search) in one launch, RIGOROUS since round 3: the
+// matrix scores s6 (six bf16 products, or the fp32 fma chain for <= 32 queries) differ from the exact inner product s by at most
+//     eps6(q) = (6 D + 8) 2^-23 |q| R            R >= max |x_row|  (bounds[0])
+// (dropped product terms mid*lo, lo*mid, lo*lo <= 2^-23 sum |q_i x_i|; at most 6 D fp32 accumulation steps, each within 2^-23 of a
+// partial sum that is itself <= (1 + 2^-7) |q| |x|; Cauchy-Schwarz).  Every row of the exact top-k has s >= S_k >= kth6 - eps6 (k rows
+// have s6 >= kth6), hence s6 >= kth6 - 2 eps6: ALL rows at or above that threshold are rescored exactly (fp64 accumulation, one rounding)
+// and the best k of them returned.  Usually that is k + a few rows; a near-duplicate cluster with more than SEL_CAND rows inside the band
+// takes the streaming form (the score row walked in 2048-row windows, a running exact top-k in LDS): slow (~ms per such query) but exact
+// for any cluster size.  (Round 2 selected k + 64 rows by score: a heuristic that a stress run had already caught once.)
+__device__ __forceinline__ float block_sum_1024(float v, float* red /* 16 */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += red[w];
+  return t;
+}
+
 __global__ void __launch_bounds__(SEL_THREADS)
 k_topk_select_rescore(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base, const float* __restrict__ blkmax, int nblk,
                       int nblk_ld, const float* __restrict__ X, int64_t ldx, int D, const float* __restrict__ q, float* __restrict__ out_scores,
-                      int64_t* __restrict__ out_ids, const int* __restrict__ gate, const int* __restrict__ qflags) {
+                      int64_t* __restrict__ out_ids, const int* __restrict__ gate, const int* __restrict__ qflags, const float* __restrict__ bounds) {
   __shared__ SelShared sh;
+  __shared__ float s_red[16];
   if (gate != nullptr && *gate == 0) return;                 // fallback launch of the bounded search: nothing overflowed
   if (qflags != nullptr && qflags[blockIdx.x] == 0) return;  // ... or not this query
   const float* row = scores + (int64_t)blockIdx.x * ld;
@@ -1606,27 +1558,101 @@ k_topk_select_rescore(const float* __restrict__ scores, int64_t ld, int64_t N, i
   const int keff = (int)(N < (int64_t)k ? N : (int64_t)k);
   for (int i = keff + tid; i < k; i += SEL_THREADS) { os[i] = -FLT_MAX; oi[i] = -1; }
   if (keff == 0) return;
-  // The matrix scores carry fp32 accumulation noise (~1e-6 relative): at a near-tie between the k-th and the (k+1)-th row the selection by
-  // them can pick the other row.  So SEL_MARGIN more rows are selected, all of them rescored exactly, and the best keff of those returned
-  // (seen in a stress run at k = 2048: exact scores 2.9917817 vs 2.9917798, the lower one returned).
-  constexpr int SEL_MARGIN = 64;
-  static_assert(SEL_MAXK + SEL_MARGIN <= SEL_CAND, "selection with margin");
-  const int ksel = (int)(N < (int64_t)(keff + SEL_MARGIN) ? N : (int64_t)(keff + SEL_MARGIN));
-  select_topk_sorted(row, N, ksel, blkmax ? blkmax + (int64_t)blockIdx.x * nblk_ld : nullptr, nblk, sh);   // sh.cand[0..ksel): the selection
-  unsigned long long* s_c = sh.cand;                         // rescored in place: entry c is read and written by the same half-wave
   const float* qrow = q + (int64_t)blockIdx.x * D;
-  for (int c0 = wave * 2; c0 < ksel; c0 += 32) {             // two rows per wave (one per half-wave)
-    const int c = min(c0 + (lane >> 5), ksel - 1);
-    int64_t n = sel_row(sh.cand[c]);
-    n = n < 0 ? 0 : (n >= N ? N - 1 : n);
-    const float sc = exact_dot(X + n * ldx, qrow, D, lane);
-    if ((lane & 31) == 0 && c0 + (lane >> 5) < ksel) s_c[c] = sel_pack(f2key(sc), n);
+  const float* bm = blkmax ? blkmax + (int64_t)blockIdx.x * nblk_ld : nullptr;
+  float q2 = 0.f;
+  for (int i = tid; i < D; i += SEL_THREADS) { const float v = qrow[i]; q2 += v * v; }
+  q2 = block_sum_1024(q2, s_red);
+  const float eps6 = (float)(6 * D + 8) * 1.1920929e-7f * sqrtf(q2) * bounds[0] * 1.01f;
+  select_topk_sorted(row, N, keff, bm, nblk, sh);            // sh.cand[0..keff): the top-keff by matrix score, sorted
+  const float kth6 = key2f((uint32_t)(sh.cand[keff - 1] >> 32));
+  const float thr = kth6 - 2.0f * eps6;                      // (a non-finite query gives a NaN threshold: nothing qualifies below, the selection above stands)
+  __syncthreads();
+  unsigned long long* s_c = sh.cand;
+  auto rescore = [&](unsigned long long* list, int n) {      // exact scores of list[0..n) in place: entry c is read and written by the same half-wave
+    for (int c0 = wave * 2; c0 < n; c0 += 32) {
+      const int c = min(c0 + (lane >> 5), n - 1);
+      int64_t r = sel_row(list[c]);
+      r = r < 0 ? 0 : (r >= N ? N - 1 : r);
+      const float sc = exact_dot(X + r * ldx, qrow, D, lane);
+      if ((lane & 31) == 0 && c0 + (lane >> 5) < n) list[c] = sel_pack(f2key(sc), r);
+    }
+  };
+  // ---- every row with s6 >= thr: the qualifying 128-row blocks first (block maxima), then their rows
+  unsigned int* blist = (unsigned int*)sh.eqs;               // 2 * SEL_EQCAP entries
+  bool overflow = false;
+  if (!(thr == thr)) {                                       // NaN band (non-finite query or bound): keep the score selection
+    if (tid == 0) sh.ngt = (unsigned int)keff;
+  } else if (N <= SEL_CAND || bm == nullptr) {
+    if (tid == 0) sh.ngt = 0;
+    __syncthreads();
+    overflow = N > SEL_CAND;                                 // (no block maxima on a large row: straight to the streaming form)
+    if (!overflow)
+      for (int64_t i = tid; i < N; i += SEL_THREADS) {
+        const float v = row[i];
+        if (v >= thr) s_c[atomicAdd(&sh.ngt, 1u)] = sel_pack(f2key(v), i);
+      }
+  } else {
+    if (tid == 0) { sh.ngt = 0; sh.neq = 0; }
+    __syncthreads();
+    for (int b = tid; b < nblk; b += SEL_THREADS)
+      if (bm[b] >= thr) {
+        const unsigned int p = atomicAdd(&sh.neq, 1u);
+        if (p < 2 * SEL_EQCAP) blist[p] = (unsigned int)b;
+      }
+    __syncthreads();
+    const unsigned int nb = sh.neq;
+    overflow = nb > 2 * SEL_EQCAP;
+    if (!overflow) {
+      for (unsigned int idx = tid; idx < nb * SP_ROWS; idx += SEL_THREADS) {
+        const int64_t i = (int64_t)blist[idx >> 7] * SP_ROWS + (idx & (SP_ROWS - 1));
+        if (i < N) {
+          const float v = row[i];
+          if (v >= thr) {
+            const unsigned int p = atomicAdd(&sh.ngt, 1u);
+            if (p < SEL_CAND) s_c[p] = sel_pack(f2key(v), i);
+          }
+        }
+      }
+    }
   }
   __syncthreads();
-  int P = 1;
-  while (P < ksel) P <<= 1;
-  for (int i = ksel + tid; i < P; i += SEL_THREADS) s_c[i] = 0ull;
-  bitonic_sort_desc(s_c, P);
+  overflow = overflow || sh.ngt > SEL_CAND;
+  __syncthreads();
+  if (!overflow) {
+    const int n = (int)sh.ngt;                               // >= keff: the keff selected rows are among them
+    rescore(s_c, n);
+    __syncthreads();
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int i = n + tid; i < P; i += SEL_THREADS) s_c[i] = 0ull;
+    bitonic_sort_desc(s_c, P);
+  } else {
+    // ---- streaming form: best[0..2048) = running exact top (sorted, 0-padded), chunk[0..2048) = the band rows of the current window
+    unsigned long long* best = s_c;
+    unsigned long long* chunk = s_c + SEL_MAXK;
+    for (int i = tid; i < SEL_MAXK; i += SEL_THREADS) best[i] = 0ull;
+    for (int64_t w0 = 0; w0 < N; w0 += SEL_MAXK) {
+      if (tid == 0) sh.ngt = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < SEL_MAXK / SEL_THREADS; ++j) {
+        const int64_t i = w0 + tid + j * SEL_THREADS;
+        if (i < N) {
+          const float v = row[i];
+          if (v >= thr) chunk[atomicAdd(&sh.ngt, 1u)] = sel_pack(f2key(v), i);
+        }
+      }
+      __syncthreads();
+      const int n = (int)sh.ngt;                             // (wave-uniform for everybody: read after the barrier)
+      if (n == 0) continue;
+      rescore(chunk, n);
+      __syncthreads();
+      for (int i = n + tid; i < SEL_MAXK; i += SEL_THREADS) chunk[i] = 0ull;
+      bitonic_sort_desc(best, 2 * SEL_MAXK);                 // merge: the best SEL_MAXK (>= keff) of best + chunk stay in front
+      __syncthreads();
+    }
+  }
   for (int i = tid; i < keff; i += SEL_THREADS) {
     const unsigned long long c = s_c[i];
     os[i] = key2f((uint32_t)(c >> 32));
@@ -1637,12 +1663,15 @@ k_topk_select_rescore(const float* __restrict__ scores, int64_t ld, int64_t N, i
 extern "C" size_t lrx_flat_ip_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
   (void)k;
   const size_t ld = (size_t)lrx_flat_ip_score_ld(n_rows), nq = (size_t)(n_queries > 0 ? n_queries : 1);
-  // scores [Q, ld] + per-block maxima [Q, ~ld/256] + split-bf16 query planes of one 128-query chunk
-  return (ld * nq + ((ld / SP_ROWS + 3) & ~(size_t)3) * nq) * sizeof(float) + split_ws_bytes(dim);
+  // scores [Q, ld] + per-block maxima [Q, ~ld/256] + split-bf16 query planes of one 128-query chunk + the two row bounds of a caller
+  // that does not know them
+  return (ld * nq + ((ld / SP_ROWS + 3) & ~(size_t)3) * nq) * sizeof(float) + split_ws_bytes(dim) + 256;
 }
 
-extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, int32_t k,
-                                  int64_t id_base, float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes,
+static int shard_bounds_launch(const float* X, int64_t ldx, int64_t n_rows, int32_t dim, float* row_bounds, hipStream_t s);
+
+extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* row_bounds, const float* q, int32_t n_queries,
+                                  int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes,
                                   void* stream) {
   LRX_CHECK_ARG(k > 0 && k <= SEL_MAXK, "flat_ip_search: k=%d out of range (1..%d)", k, SEL_MAXK);
   LRX_CHECK_ARG(n_rows >= 0 && n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
@@ -1654,15 +1683,23 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
   float* scores = (float*)workspace;
   const int64_t ld = lrx_flat_ip_score_ld(n_rows);
   float* blkmax = scores + ld * (int64_t)n_queries;
-    const int nblk = (int)(ld / SP_ROWS), nblk_ld = (nblk + 3) & ~3;   // block maxima at 128-row granularity on both paths
+  const int nblk = (int)(ld / SP_ROWS), nblk_ld = (nblk + 3) & ~3;   // block maxima at 128-row granularity on both paths
+  __bf16* qsplit = (__bf16*)(blkmax + (int64_t)nblk_ld * n_queries);
   if (n_rows > 0) {
-    __bf16* qsplit = (__bf16*)(blkmax + (int64_t)nblk_ld * n_queries);
     int rc = launch_scores(X, n_rows, ldx, dim, q, n_queries, scores, blkmax, qsplit, stream);
     if (rc != LRX_OK) return rc;
   }
   if (n_rows > 0 && dim % 4 == 0) {
+    // the band of the final selection needs max |row|: a caller that keeps the shard's bounds passes them; otherwise one more read of the rows
+    if (row_bounds == nullptr) {
+      float* wb = (float*)((char*)qsplit + split_ws_bytes(dim));
+      LRX_HIP(hipMemsetAsync(wb, 0, 2 * sizeof(float), (hipStream_t)stream));
+      int rc = shard_bounds_launch(X, ldx, n_rows, dim, wb, (hipStream_t)stream);
+      if (rc != LRX_OK) return rc;
+      row_bounds = wb;
+    }
     hipLaunchKernelGGL(k_topk_select_rescore, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, (const float*)scores, ld, n_rows, k, id_base,
-                       (const float*)blkmax, nblk, nblk_ld, X, ldx, dim, q, out_scores, out_ids, (const int*)nullptr, (const int*)nullptr);
+                       (const float*)blkmax, nblk, nblk_ld, X, ldx, dim, q, out_scores, out_ids, (const int*)nullptr, (const int*)nullptr, row_bounds);
   } else {
     hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, scores, ld, n_rows, k, id_base, blkmax, nblk,
                        nblk_ld, out_scores, out_ids, (const int*)nullptr, (const int*)nullptr);
@@ -1708,14 +1745,14 @@ struct RadixShared {
 };
 
 // eps(q) of the header comment; all threads of the (<= 1024-thread) block take part, fixed summation order.  Optionally stages the
-// query row in LDS (s_q).  bounds = {R, E}; E <= 0 means "unknown": 2^-8 R (unit roundoff of bf16).
+// query row in LDS (s_q).  bounds = {R, E}; E <= 0 means "unknown": 2^-11 R (unit roundoff of fp16).
 __device__ float query_eps_block(const float* __restrict__ qglob, int D, const float* __restrict__ bounds, float* s_q, float* s_red /* 32 */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   float a = 0.f, b = 0.f;
   for (int i = tid; i < D; i += blockDim.x) {
     const float v = qglob[i];
     if (s_q != nullptr) s_q[i] = v;
-    const float r = (float)(__bf16)v, d = v - r;
+    const float r = (float)f2h_sat(v), d = v - r;
     a += r * r;
     b += d * d;
   }
@@ -1726,7 +1763,7 @@ __device__ float query_eps_block(const float* __restrict__ qglob, int D, const f
   float A = 0.f, B = 0.f;
   for (int w = 0; w < nw; ++w) { A += s_red[w]; B += s_red[16 + w]; }
   __syncthreads();
-  const float R = bounds[0], E = bounds[1] > 0.f ? bounds[1] : R * 0.00390625f;
+  const float R = bounds[0], E = bounds[1] > 0.f ? bounds[1] : R * 0.00048828125f;   // unknown E: fp16's unit roundoff 2^-11 (rows inside fp16's normal range)
   const float accum = (float)(D + 32) * 1.1920929e-7f;   // 2^-23 per accumulated term
   return (sqrtf(B) * R + sqrtf(A) * (E + accum * R * 1.01f)) * 1.0001f + 1e-30f;
 }
@@ -1741,7 +1778,7 @@ __device__ float query_eps_block(const float* __restrict__ qglob, int D, const f
 __global__ void __launch_bounds__(SEL_THREADS)
 k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, int k, const float* __restrict__ blkmax, int nblk, int nblk_ld,
                    const float* __restrict__ q, int D, const float* __restrict__ bounds, int rb, int ss, int64_t N, float* __restrict__ thr_out,
-                   float* __restrict__ eps_out, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, int gsz) {
+                   float* __restrict__ eps_out, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, int gsz, unsigned int cap) {
   __shared__ SelShared sh;
   __shared__ float s_red[32];
   const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1775,7 +1812,7 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
   if (tid == 0) { thr_out[qi] = thr; eps_out[qi] = eps; }
   // this workgroup is the only writer of the query's list until the main pass starts: slots come from an LDS counter (a global
   // atomic per hit cost ~2 us of round trip per qualifying block and wave: 49 -> 3x us for the kernel), the count is stored once
-  unsigned long long* list = cand + (int64_t)qi * CAND_CAP;
+  unsigned long long* list = cand + (int64_t)qi * cap;
   __shared__ unsigned int s_fill;
   if (tid == 0) { s_fill = 0; sh.neq = 0; }
   __syncthreads();
@@ -1790,7 +1827,7 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
     __syncthreads();
     const unsigned int ngl = sh.neq;
     if (ngl > 2 * SEL_EQCAP) {                                   // (near-duplicate rows: more groups than any list would hold -> exact fallback)
-      if (tid == 0) s_fill = CAND_CAP + 1;
+      if (tid == 0) s_fill = cap + 1;
     } else {
       for (unsigned int idx = tid; idx < ngl * 16; idx += SEL_THREADS) {
         const int64_t j = (int64_t)glist[idx >> 4] * 16 + (idx & 15);
@@ -1798,7 +1835,7 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
         const int64_t g = (j / rb) * ((int64_t)ss * rb) + (j % rb);
         if (g < N && v >= thr) {
           const unsigned int p = atomicAdd(&s_fill, 1u);
-          if (p < CAND_CAP) list[p] = sel_pack(f2key(v), g);
+          if (p < cap) list[p] = sel_pack(f2key(v), g);
         }
       }
     }
@@ -1812,7 +1849,7 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
           const int64_t g = (j / rb) * ((int64_t)ss * rb) + (j % rb);
           if (g < N && v >= thr) {
             const unsigned int p = atomicAdd(&s_fill, 1u);
-            if (p < CAND_CAP) list[p] = sel_pack(f2key(v), g);
+            if (p < cap) list[p] = sel_pack(f2key(v), g);
           }
         }
       }
@@ -1842,7 +1879,7 @@ __device__ __forceinline__ void refine_rescore(const float* __restrict__ X, int6
 __global__ void __launch_bounds__(1024)
 k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ q, const unsigned long long* __restrict__ cand,
               const unsigned int* __restrict__ cnt, const float* __restrict__ eps, int k, unsigned long long* __restrict__ parts,
-              int* __restrict__ part_cnt, int nsplit) {
+              int* __restrict__ part_cnt, int nsplit, unsigned int cap) {
   __shared__ RadixShared rs;
   __shared__ unsigned long long s_cand[REF_CAND];           // (a part holds REF_CAND / nsplit of them)
   __shared__ __attribute__((aligned(16))) float s_q[REF_QLDS];   // the query row (every rescoring re-reads it; from global its loads serialise)
@@ -1856,10 +1893,10 @@ k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
     for (int i = tid; i < D; i += 1024) s_q[i] = qglob[i];
   if (tid == 0) s_ncand = 0;
   const unsigned int n = cnt[qi * CNT_STRIDE];
-  bool overflow = n > CAND_CAP || n < (unsigned int)k;      // (n < k cannot happen with a finite threshold: k sample rows reach it)
+  bool overflow = n > cap || n < (unsigned int)k;      // (n < k cannot happen with a finite threshold: k sample rows reach it)
   __syncthreads();
   if (!overflow) {
-    const unsigned long long* list = cand + (int64_t)qi * CAND_CAP;
+    const unsigned long long* list = cand + (int64_t)qi * cap;
     const float kth = key2f(radix_select_kth_list(list, (int)n, (unsigned int)k, rs));
     const float thr = kth - 2.0f * eps[qi];
     for (int i = part + nsplit * tid; i < (int)n; i += nsplit * 1024) {
@@ -2001,14 +2038,13 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
 }
 
 // ---- host side: per query chunk (<= 256 queries with the shadow, <= 128 without) one pipeline over one workspace ----------------
-static int g_search_mode = 0;   // 0 = choose per chunk, 1 = always the score-matrix filter, 2 = the score-free filter whenever the shape allows,
-                                // 3 = like 2 but never the GEMM kernel for the main pass (A/B runs)
-extern "C" void lrx_search_set_mode(int32_t mode) { g_search_mode = mode; }
-
+// flags & 3 (lrx.h LRX_SEARCH_FILTER_*): 0 = choose the filter per chunk, 1 = always the score-matrix filter, 2 = the score-free filter
+// whenever the shape allows, 3 = like 2 but never the GEMM kernel for the main pass (A/B runs).  Per call: no process-wide state.
 struct BoundedPlan {
   bool emit;
-  bool gemm;                            // emit: the main pass runs on the GEMM kernel (129..256 queries over a contiguous bf16 shadow)
+  bool gemm;                            // emit: the main pass runs on the GEMM kernel (129..256 queries over the tiled shadow)
   int ss, rb;
+  unsigned int cap;                     // emit: capacity of one candidate list
   int64_t ld, nblk, nblk_ld;            // full shard: score row stride, 128-row blocks, blkmax row stride
   int64_t nsamp_wg, nmain_wg;           // emit: workgroups of the sample / main launch (rb rows each)
   int64_t ld_s, nblk_s, nblk_ld_s;      // emit: the compact sample matrix
@@ -2018,28 +2054,35 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t ints_before_cnt(int nq) { return ((size_t)nq + 1 + 63) & ~(size_t)63; }
 
-static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow, bool contiguous_shadow = true, bool tiled_shadow = true) {
+// Candidate-list capacity and sample stride for top-k: ~k * ss rows reach the sample's k-th score, the fp16 band adds ~30 % -- the list
+// should end up around a third full (a list that overflows sends its query to the exact fallback).  k <= 256: 16 Ki entries and ss = 20
+// (1/20 of the shard goes through the sample pass); larger k: the capacity grows with k (64 k, a power of two) so that the stride stays
+// at 20 -- round 2 kept 16 Ki entries for every k, which at the reference's default top_k = 1000 meant ss = 2: half of the shard went
+// through the sample pass and its [Q, N/2] score matrix.
+static unsigned int cand_cap_for(int32_t k) {
+  unsigned int cap = CAND_CAP_MIN;
+  while (cap < 64u * (unsigned int)(k > 0 ? k : 1)) cap <<= 1;
+  return cap;
+}
+
+static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow, int mode) {
   BoundedPlan p;
   memset(&p, 0, sizeof(p));
-  // more than 128 queries over a bf16 shadow: the main pass is the GEMM kernel on 256-row tiles (the sample then moves in 256-row units)
-  p.gemm = shadow && contiguous_shadow && nq > 128 && dim >= 1024 && dim % 64 == 0 && n_rows < (1ll << 31) && g_search_mode != 3;   // (D = 256: 4 K-tiles per 256 x 256 tile, 14 % slower than the 128-row kernel)
+  // more than 128 queries over the shadow: the main pass is the GEMM kernel on 256-row tiles (the sample then moves in 256-row units)
+  p.gemm = shadow && nq > 128 && dim >= 1024 && dim % 64 == 0 && n_rows < (1ll << 31) && mode != 3;   // (D = 256: 4 K-tiles per 256 x 256 tile, 14 % slower than the 128-row kernel)
   p.rb = p.gemm ? 256 : filter_rows_per_wg(shadow);
   p.ld = lrx_flat_ip_score_ld(n_rows);
   p.nblk = p.ld / SP_ROWS;
   p.nblk_ld = (p.nblk + 3) & ~(int64_t)3;
-  // sample stride: ~k * ss rows reach the sample's k-th score (plus the band); keep that near CAND_CAP / 8
-  int ss = CAND_CAP / (8 * (k > 0 ? k : 1));
-  ss = ss > 32 ? 32 : (ss < 2 ? 2 : ss);
+  p.cap = cand_cap_for(k);
+  int ss = (int)(p.cap / (3u * (unsigned int)(k > 0 ? k : 1)));
+  ss = ss > 20 ? 20 : (ss < 2 ? 2 : ss);
   const int64_t nwg = lrx_cdiv(n_rows > 0 ? n_rows : 1, p.rb);
   while (ss > 2 && (lrx_cdiv(nwg, ss) - 1) * p.rb < 2 * (int64_t)k) ss >>= 1;
   const int64_t nsamp = lrx_cdiv(nwg, ss);
   const bool feasible = (nsamp - 1) * p.rb >= 2 * (int64_t)k && nwg - nsamp >= 1 && dim % 4 == 0 && (shadow || nq > 16 * (SPLIT_MIN_QT - 1));
   if (!feasible) p.gemm = false;
-  // (until the register-streaming kernels and the group-maxima threshold step, batches of Q < max(2, D / 256) queries were faster on the
-  // score-matrix filter; now the score-free chain is as fast at Q = 1 over 1M x 2048 (0.69 ms both) and faster at 10M x 256 (0.85 vs 1.03 ms))
-  // A row-major shadow (LDS-staged filter kernels) keeps the old crossover: Q = 1 over 1M x 2048 0.79-0.82 ms that way, 0.87 score-free.
-  const bool small_batch = !(shadow && tiled_shadow) && !(nq >= 2 && 256 * (int64_t)nq >= dim);
-  p.emit = feasible && g_search_mode != 1 && (g_search_mode >= 2 || (n_rows >= 16384 && !small_batch));
+  p.emit = feasible && mode != 1 && (mode >= 2 || n_rows >= 16384);
   p.ss = ss;
   p.nsamp_wg = nsamp;
   p.nmain_wg = nwg - nsamp;
@@ -2055,48 +2098,49 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   // ints: flags[nq], any_flag, pad to 64 ints, cnt[nq * CNT_STRIDE] (one memset) | part_cnt[nq * REF_SPLIT] | thr[nq] | eps[nq]
   p.off_parts = align256(p.off_ints + sizeof(int) * (ints_before_cnt(nq) + (size_t)nq * (CNT_STRIDE + 2 + REF_SPLIT)));
   p.off_cand = align256(p.off_parts + (size_t)nq * REF_CAND * 8);
-  p.total = p.off_cand + (p.emit ? (size_t)nq * CAND_CAP * 8 : 0);
+  p.total = p.off_cand + (p.emit ? (size_t)nq * p.cap * 8 : 0);
   return p;
 }
 
 extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
-  // the search walks the queries in chunks of 256 (bf16 shadow) or 128 (fp32 rows), each chunk with its own plan over the same buffer
+  // the search walks the queries in chunks of 256 (shadow) or 128 (fp32 rows), each chunk with its own plan over the same buffer; the
+  // size covers every filter choice (flags), so a workspace sized here serves any call on that shard shape
   const int32_t nq = n_queries > 0 ? n_queries : 1;
   size_t need = lrx_flat_ip_workspace_bytes(n_rows, dim, nq < 128 ? nq : 128, k);   // tiny shards / few queries without shadow: plain path in chunks of 128
   for (int sh = 0; sh < 2; ++sh) {
     const int chunk = sh ? 256 : 128;
     const int sizes[2] = {nq < chunk ? nq : chunk, nq > chunk ? nq % chunk : 0};
     for (int i = 0; i < 2; ++i)
-      if (sizes[i] > 0) {
-        for (int contiguous = 0; contiguous < 2; ++contiguous)         // (a strided row-major shadow keeps the 128-row main pass: other sample geometry)
-          for (int tiled = 0; tiled < 2; ++tiled) {                    // (a row-major shadow keeps the score-matrix filter for very small batches)
-            const size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, contiguous != 0, tiled != 0).total;
-            need = t > need ? t : need;
-          }
-      }
+      if (sizes[i] > 0)
+        for (int mode = 1; mode <= 3; ++mode) {
+          const size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, mode).total;
+          need = t > need ? t : need;
+        }
   }
   return need + 512;
 }
 
-extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_bf16, int64_t ldx_bf16,
-                                          const float* row_bounds, const float* q, int32_t n_queries, int32_t k, int64_t id_base,
-                                          float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream) {
-  LRX_CHECK_ARG(row_bounds != nullptr, "flat_ip_search_bounded: null row_bounds (device pointer to {max |x_row|, max |x_row - bf16(x_row)|})");
+extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_shadow, const float* row_bounds,
+                                          const float* q, int32_t n_queries, int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids,
+                                          void* workspace, size_t workspace_bytes, int32_t flags, void* stream) {
+  LRX_CHECK_ARG(row_bounds != nullptr, "flat_ip_search_bounded: null row_bounds (device pointer to {max |x_row|, max |x_row - fp16(x_row)|})");
   LRX_CHECK_ARG(k > 0 && k <= SEL_MAXK, "flat_ip_search: k=%d out of range (1..%d)", k, SEL_MAXK);
   LRX_CHECK_ARG(n_rows >= 0 && n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
+  LRX_CHECK_ARG((flags & ~3) == 0, "flat_ip_search_bounded: unknown flags 0x%x", flags);
   if (n_queries <= 0) return LRX_OK;
   if (workspace_bytes < lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k)) {
     lrx_set_error("flat_ip_search_bounded: workspace %zu B < required %zu B", workspace_bytes, lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k));
     return LRX_ERR_WORKSPACE;
   }
-  const bool shadow = X_bf16 != nullptr && dim % 64 == 0 && ((ldx_bf16 >= dim && ldx_bf16 % 8 == 0) || ldx_bf16 == 0);   // 0 = tiled layout
+  const int mode = flags & 3;
+  const bool shadow = X_shadow != nullptr && dim % 64 == 0;
   const int qt_max = ((n_queries < 128 ? n_queries : 128) + 15) / 16;
   // tiny shards and odd widths take the plain path; so do small query batches without a shadow (HBM-bound on the exact-fp32 kernel already)
   if ((qt_max < SPLIT_MIN_QT && !shadow) || n_rows <= REF_CAND || dim % 4 != 0) {
     for (int q0 = 0; q0 < n_queries; q0 += 128) {
       const int nq = n_queries - q0 < 128 ? n_queries - q0 : 128;
-      const int rc = lrx_flat_ip_search(X, n_rows, ldx, dim, q + (int64_t)q0 * dim, nq, k, id_base, out_scores + (int64_t)q0 * k, out_ids + (int64_t)q0 * k,
-                                        workspace, workspace_bytes, stream);
+      const int rc = lrx_flat_ip_search(X, n_rows, ldx, dim, row_bounds, q + (int64_t)q0 * dim, nq, k, id_base, out_scores + (int64_t)q0 * k,
+                                        out_ids + (int64_t)q0 * k, workspace, workspace_bytes, stream);
       if (rc != LRX_OK) return rc;
     }
     return LRX_OK;
@@ -2105,8 +2149,8 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
   const int chunk = shadow ? 256 : 128;
   for (int q0 = 0; q0 < n_queries; q0 += chunk) {
     const int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
-    const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, ldx_bf16 == dim || ldx_bf16 == 0, ldx_bf16 == 0);
-    if (p.total > workspace_bytes) {      // (cannot happen with a workspace sized by lrx_flat_ip_bounded_workspace_bytes under the same filter mode)
+    const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, mode);
+    if (p.total > workspace_bytes) {      // (cannot happen with a workspace sized by lrx_flat_ip_bounded_workspace_bytes)
       lrx_set_error("flat_ip_search_bounded: chunk of %d queries needs %zu B of workspace, %zu given", nq, p.total, workspace_bytes);
       return LRX_ERR_WORKSPACE;
     }
@@ -2116,9 +2160,9 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
     char* ws = (char*)workspace;
     float* scores = (float*)ws;
     __bf16* qsplit = (__bf16*)(ws + p.off_qsplit);
-    int* flags = (int*)(ws + p.off_ints);
-    int* any_flag = flags + nq;
-    unsigned int* cnt = (unsigned int*)(flags + ints_before_cnt(nq));
+    int* flg = (int*)(ws + p.off_ints);
+    int* any_flag = flg + nq;
+    unsigned int* cnt = (unsigned int*)(flg + ints_before_cnt(nq));
     int* part_cnt = (int*)(cnt + (size_t)nq * CNT_STRIDE);
     float* thr = (float*)(part_cnt + (size_t)nq * REF_SPLIT);
     float* eps = thr + nq;
@@ -2127,7 +2171,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
     // flags, any_flag, list counts start at zero: cleared by the query-packing kernel of the first filter launch when there is one
     const size_t nclear = ints_before_cnt(nq) + (p.emit ? (size_t)nq * CNT_STRIDE : 0);
     const bool clear_in_pack = shadow && nclear < (1u << 30);
-    if (!clear_in_pack) LRX_HIP(hipMemsetAsync(flags, 0, sizeof(int) * nclear, s));
+    if (!clear_in_pack) LRX_HIP(hipMemsetAsync(flg, 0, sizeof(int) * nclear, s));
     // ... and so are the hi/mid/lo query planes of the gated six-product fallback (groups of <= 128 queries; <= 32 queries run the
     // exact-fp32 kernel, which needs none)
     PreSplit presplit;
@@ -2151,37 +2195,37 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       const int unit = p.gemm ? 2 : 1;                        // sample units of 256 rows = two blocks of the 128-row filter kernel
       FilterMode fs;
       fs.bmode = 1; fs.ss = p.ss; fs.unit = unit; fs.nblocks = p.nsamp_wg * unit;
-      fs.group_max = shadow && ldx_bf16 == 0;                 // the register-streaming kernels hand over the maxima of their 16-row wave groups
-      if (clear_in_pack) { fs.zero = flags; fs.nzero = (int)nclear; }
+      fs.group_max = shadow;                                  // the register-streaming kernels hand over the maxima of their 16-row wave groups
+      if (clear_in_pack) { fs.zero = flg; fs.nzero = (int)nclear; }
       fs.presplit = presplit;
-      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld_s, fs);
+      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_shadow : nullptr, p.ld_s, fs);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_sample_threshold, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld_s, p.nsamp_wg * p.rb, k, (const float*)blkmax,
-                         (int)p.nblk_s, (int)p.nblk_ld_s, qc, dim, row_bounds, p.rb, p.ss, n_rows, thr, eps, cand, cnt, fs.group_max ? 16 : 128);
+                         (int)p.nblk_s, (int)p.nblk_ld_s, qc, dim, row_bounds, p.rb, p.ss, n_rows, thr, eps, cand, cnt, fs.group_max ? 16 : 128, p.cap);
       LRX_LAUNCH_CHECK();
       if (p.gemm) {
         __bf16* q16 = (__bf16*)(ws + p.off_q16);
         hipLaunchKernelGGL(k_round_queries, dim3((unsigned)lrx_cdiv((int64_t)nq * dim, 1024)), dim3(256), 0, s, qc, (int64_t)nq * dim, q16);
         LRX_LAUNCH_CHECK();
-        rc = lrx_gemm_filter_emit_launch(X_bf16, ldx_bf16 == 0, q16, n_rows, nq, dim, p.ss, p.nmain_wg, thr, cand, cnt, s);
+        rc = lrx_gemm_filter_emit_launch(X_shadow, q16, n_rows, nq, dim, p.ss, p.nmain_wg, thr, cand, cnt, p.cap, s);
       } else {
         FilterMode fm;
-        fm.bmode = 2; fm.ss = p.ss; fm.nblocks = p.nmain_wg; fm.thr = thr; fm.cand = cand; fm.cnt = cnt;
-        rc = launch_scores(X, n_rows, ldx, dim, qc, nq, nullptr, nullptr, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, p.ld, fm);
+        fm.bmode = 2; fm.ss = p.ss; fm.nblocks = p.nmain_wg; fm.thr = thr; fm.cand = cand; fm.cnt = cnt; fm.cap = p.cap;
+        rc = launch_scores(X, n_rows, ldx, dim, qc, nq, nullptr, nullptr, qsplit, stream, 1, nullptr, shadow ? X_shadow : nullptr, p.ld, fm);
       }
       if (rc != LRX_OK) return rc;
       // parts per query: the 1024-thread workgroups of the refine step run one per CU, so REF_SPLIT x nq of them beyond the CU count take
       // a second round of ~40 us each (Q = 100: 400 workgroups, 82 us) -- fewer, larger parts then finish sooner
       nsplit = (int64_t)nq * REF_SPLIT <= lrx_cu_count() ? REF_SPLIT : ((int64_t)nq * 2 <= lrx_cu_count() ? 2 : 1);
       hipLaunchKernelGGL(k_refine_band, dim3(nq, nsplit), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
-                         (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt, nsplit);
+                         (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt, nsplit, p.cap);
       LRX_LAUNCH_CHECK();
     } else {
       float* blkmax = scores + p.ld * (int64_t)nq;
       FilterMode fa;
-      if (clear_in_pack) { fa.zero = flags; fa.nzero = (int)nclear; }
+      if (clear_in_pack) { fa.zero = flg; fa.nzero = (int)nclear; }
       fa.presplit = presplit;
-      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_bf16 : nullptr, ldx_bf16, 0, fa);
+      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_shadow : nullptr, 0, fa);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_topk_select, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax, (int)p.nblk,
                          (int)p.nblk_ld, osc, oic, (const int*)nullptr, (const int*)nullptr);
@@ -2192,7 +2236,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
     }
     // (1024 threads: with 256 the sort of the typical 300-500 band rows took 20 instead of 14 us)
     hipLaunchKernelGGL(k_refine_merge, dim3(nq), dim3(1024), 0, s, (const unsigned long long*)parts, (const int*)part_cnt, n_rows, k, id_base, osc, oic,
-                       flags, any_flag, nsplit);
+                       flg, any_flag, nsplit);
     LRX_LAUNCH_CHECK();
     // gated fallback for the flagged queries (every kernel returns immediately on the device when nothing overflowed), 128 queries at
     // a time over the same score region
@@ -2202,11 +2246,11 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       FilterMode ff;
       ff.planes_ready = presplit.ngroups > 0;                 // written by the packing kernel at the head of the chain
       rc = launch_scores(X, n_rows, ldx, dim, qc + (int64_t)f0 * dim, nf, scores, blkmax, ff.planes_ready ? qs3 + (f0 / 128) * presplit.stride : qsplit, stream, 3,
-                         any_flag, nullptr, 0, 0, ff);
+                         any_flag, nullptr, 0, ff);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_topk_select_rescore, dim3(nf), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax,
                          (int)p.nblk, (int)p.nblk_ld, X, ldx, dim, qc + (int64_t)f0 * dim, osc + (int64_t)f0 * k, oic + (int64_t)f0 * k,
-                         (const int*)any_flag, (const int*)(flags + f0));
+                         (const int*)any_flag, (const int*)(flg + f0), row_bounds);
       LRX_LAUNCH_CHECK();
     }
   }
@@ -2215,12 +2259,13 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
 
 // ---------------------------------------------------------------------------------------------------------------
 // Shard maintenance for rows that did not come from the encoder's last kernel (FlatIPIndex.add, loaded index files): ONE read of the
-// fp32 rows produces the bf16 shadow (RNE) and raises the two bounds {max |row|, max |row - bf16(row)|} (integer atomic max on the
-// non-negative float patterns: order-independent).  A wave walks 16 rows, one atomic pair per 64-row workgroup.
+// fp32 rows produces the fp16 shadow (RNE, saturating) and raises the two bounds {max |row|, max |row - fp16(row)|} (integer atomic max on
+// the non-negative float patterns: order-independent).
 // ---------------------------------------------------------------------------------------------------------------
+// bounds only (a shard without a shadow, or a plain search that was not given its bounds): a wave walks 16 rows, one atomic pair per
+// 64-row workgroup
 __global__ void __launch_bounds__(256)
-k_shard_rows(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int D, __bf16* __restrict__ Xb, int64_t ldxb, int64_t row0,
-             float* __restrict__ bounds) {
+k_shard_bounds(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int D, float* __restrict__ bounds) {
   __shared__ float s_r[4], s_e[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float rmax = 0.f, emax = 0.f;
@@ -2231,20 +2276,11 @@ k_shard_rows(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int D, __
     float r2 = 0.f, e2 = 0.f;
     for (int i = lane * 4; i < D; i += 256) {
       const f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + i));
-      bf16x4 h;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        h[e] = (__bf16)v[e];
-        const float d = v[e] - (float)h[e];
+        const float d = v[e] - (float)f2h_sat(v[e]);
         r2 += v[e] * v[e];
         e2 += d * d;
-      }
-      if (Xb != nullptr) {
-        if (ldxb != 0) *(bf16x4*)(Xb + r * ldxb + i) = h;
-        else {                                              // tiled shadow: Xb = its base, this row is row0 + r of it
-          const int64_t ra = row0 + r;
-          *(bf16x4*)(Xb + lrx_shadow_off(ra, i, D)) = h;      // (i % 4 == 0: four consecutive k of one 8-element fragment piece)
-        }
       }
     }
     rmax = fmaxf(rmax, wave_sum(r2));
@@ -2259,10 +2295,15 @@ k_shard_rows(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int D, __
     atomicMax((int*)bounds + 1, __float_as_int(sqrtf(emax) * (1.0f + 1e-6f)));
   }
 }
+static int shard_bounds_launch(const float* X, int64_t ldx, int64_t n_rows, int32_t dim, float* row_bounds, hipStream_t s) {
+  if (n_rows <= 0) return LRX_OK;
+  hipLaunchKernelGGL(k_shard_bounds, dim3((unsigned)lrx_cdiv(n_rows, 64)), dim3(256), 0, s, X, ldx, n_rows, dim, row_bounds);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
 
-// The same for the TILED shadow: a wave owns a 16-row group of the tile grid, lane (fi, fq) reads row fi's 8 floats of k-step
-// (slice, ks, fq) -- four lanes cover one 128-B line of the row -- and writes its 16-B piece of the fragment-major tile: 1 KiB contiguous
-// per wave instruction (the row-at-a-time walk above scattered 8-byte pieces 256 B apart over the tile: 4.8 instead of 2.5 ms per 1M x 2048).
+// Shadow + bounds: a wave owns a 16-row group of the tile grid, lane (fi, fq) reads row fi's 8 floats of k-step (slice, ks, fq) -- four
+// lanes cover one 128-B line of the row -- and writes its 16-B piece of the fragment-major tile: 1 KiB contiguous per wave instruction.
 __global__ void __launch_bounds__(256)
 k_shard_rows_tiled(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int D, __bf16* __restrict__ Xb, int64_t row0, float* __restrict__ bounds) {
   __shared__ float s_r[4], s_e[4];
@@ -2289,8 +2330,9 @@ k_shard_rows_tiled(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float f = v[u][e >> 2][e & 3];
-          h[e] = (__bf16)f;
-          const float d = f - (float)h[e];
+          const _Float16 hh = f2h_sat(f);
+          h[e] = __builtin_bit_cast(__bf16, hh);
+          const float d = f - (float)hh;
           r2 += f * f;
           e2 += d * d;
         }
@@ -2310,21 +2352,15 @@ k_shard_rows_tiled(const float* __restrict__ X, int64_t ldx, int64_t n_rows, int
   }
 }
 
-extern "C" int lrx_shard_commit_rows(const float* X, int64_t ldx, int64_t n_rows, int32_t dim, void* X_bf16, int64_t ldx_bf16, int64_t shadow_row0,
-                                     float* row_bounds, void* stream) {
+extern "C" int lrx_shard_commit_rows(const float* X, int64_t ldx, int64_t n_rows, int32_t dim, void* X_shadow, int64_t shadow_row0, float* row_bounds,
+                                     void* stream) {
   LRX_CHECK_ARG(dim > 0 && dim % 4 == 0 && ldx >= dim && ldx % 4 == 0, "shard_commit_rows: dim=%d / ldx=%lld must be multiples of 4", dim, (long long)ldx);
-  LRX_CHECK_ARG(X_bf16 == nullptr || (ldx_bf16 >= dim && ldx_bf16 % 4 == 0) || (ldx_bf16 == 0 && dim % 64 == 0 && shadow_row0 >= 0),
-                "shard_commit_rows: bad shadow layout (row stride %lld, dim %d)", (long long)ldx_bf16, dim);
+  LRX_CHECK_ARG(X_shadow == nullptr || (dim % 64 == 0 && shadow_row0 >= 0), "shard_commit_rows: the tiled shadow needs dim %% 64 == 0 (dim %d) and row0 >= 0", dim);
   LRX_CHECK_ARG(row_bounds != nullptr, "shard_commit_rows: null row_bounds");
   if (n_rows <= 0) return LRX_OK;
-  if (X_bf16 != nullptr && ldx_bf16 == 0) {
-    const int64_t groups = ((shadow_row0 + n_rows + 15) >> 4) - (shadow_row0 >> 4);
-    hipLaunchKernelGGL(k_shard_rows_tiled, dim3((unsigned)lrx_cdiv(groups, 4)), dim3(256), 0, (hipStream_t)stream, X, ldx, n_rows, dim, (__bf16*)X_bf16,
-                       shadow_row0, row_bounds);
-    LRX_LAUNCH_CHECK();
-    return LRX_OK;
-  }
-  hipLaunchKernelGGL(k_shard_rows, dim3((unsigned)lrx_cdiv(n_rows, 64)), dim3(256), 0, (hipStream_t)stream, X, ldx, n_rows, dim, (__bf16*)X_bf16, ldx_bf16,
+  if (X_shadow == nullptr) return shard_bounds_launch(X, ldx, n_rows, dim, row_bounds, (hipStream_t)stream);
+  const int64_t groups = ((shadow_row0 + n_rows + 15) >> 4) - (shadow_row0 >> 4);
+  hipLaunchKernelGGL(k_shard_rows_tiled, dim3((unsigned)lrx_cdiv(groups, 4)), dim3(256), 0, (hipStream_t)stream, X, ldx, n_rows, dim, (__bf16*)X_shadow,
                      shadow_row0, row_bounds);
   LRX_LAUNCH_CHECK();
   return LRX_OK;

@@ -59,7 +59,7 @@ void encode_packed(const at::Tensor& ids, const at::Tensor& cu_seqlens, int64_t 
     rb = row_bounds->data_ptr<float>();
   }
   lrx_check(lrx_encode_packed_shard(h->cfg, h->w, ids.data_ptr<int32_t>(), cu_seqlens.data_ptr<int32_t>(), (int32_t)B, (int32_t)T, (int32_t)max_seqlen,
-                                    out.data_ptr<float>(), out.stride(0), (int32_t)D, normalize ? 1 : 0, sh, 0, shadow_row0, rb, ws.data_ptr(), need_b,
+                                    out.data_ptr<float>(), out.stride(0), (int32_t)D, normalize ? 1 : 0, sh, shadow_row0, rb, ws.data_ptr(), need_b,
                                     cur_stream()),
             "encode_packed");
 }
@@ -136,7 +136,8 @@ at::Tensor embedding_bag_mean(const at::Tensor& table, const at::Tensor& ids, co
 }
 
 // ---- index ----------------------------------------------------------------------------------------------------------------------
-std::tuple<at::Tensor, at::Tensor> flat_ip_topk(const at::Tensor& q, const at::Tensor& x, int64_t k, int64_t id_base) {
+std::tuple<at::Tensor, at::Tensor> flat_ip_topk(const at::Tensor& q, const at::Tensor& x, int64_t k, int64_t id_base,
+                                                const c10::optional<at::Tensor>& row_bounds) {
   DevGuard guard(q.device());
   need(q, "q", at::kFloat, 2);
   need(x, "x", at::kFloat, 2);
@@ -144,51 +145,54 @@ std::tuple<at::Tensor, at::Tensor> flat_ip_topk(const at::Tensor& q, const at::T
   at::Tensor d = at::empty({q.size(0), k}, q.options()), i = at::empty({q.size(0), k}, q.options().dtype(at::kLong));
   const size_t wsb = lrx_flat_ip_workspace_bytes(x.size(0), (int32_t)x.size(1), (int32_t)q.size(0), (int32_t)k);
   at::Tensor ws = bytes((int64_t)wsb, q);
-  lrx_check(lrx_flat_ip_search(x.data_ptr<float>(), x.size(0), x.size(0) ? x.stride(0) : x.size(1), (int32_t)x.size(1), q.data_ptr<float>(), (int32_t)q.size(0),
-                               (int32_t)k, id_base, d.data_ptr<float>(), i.data_ptr<int64_t>(), ws.data_ptr(), wsb, cur_stream()),
+  const float* rb = nullptr;
+  if (row_bounds.has_value()) {
+    need(*row_bounds, "row_bounds", at::kFloat, 1);
+    TORCH_CHECK(row_bounds->numel() == 2, "flat_ip_topk: row_bounds [2]");
+    rb = row_bounds->data_ptr<float>();
+  }
+  lrx_check(lrx_flat_ip_search(x.data_ptr<float>(), x.size(0), x.size(0) ? x.stride(0) : x.size(1), (int32_t)x.size(1), rb, q.data_ptr<float>(),
+                               (int32_t)q.size(0), (int32_t)k, id_base, d.data_ptr<float>(), i.data_ptr<int64_t>(), ws.data_ptr(), wsb, cur_stream()),
             "flat_ip_topk");
   return {d, i};
 }
 
-std::tuple<at::Tensor, at::Tensor> flat_ip_topk_bounded(const at::Tensor& q, const at::Tensor& x, const c10::optional<at::Tensor>& x_bf16,
-                                                        const at::Tensor& row_bounds, int64_t k, int64_t id_base) {
+// x_shadow: the shard's 1-D tiled fp16 shadow (include/lrx.h), block 0 row 0 = x row 0; flags: LRX_SEARCH_FILTER_*
+std::tuple<at::Tensor, at::Tensor> flat_ip_topk_bounded(const at::Tensor& q, const at::Tensor& x, const c10::optional<at::Tensor>& x_shadow,
+                                                        const at::Tensor& row_bounds, int64_t k, int64_t id_base, int64_t flags) {
   DevGuard guard(q.device());
   need(q, "q", at::kFloat, 2);
   need(x, "x", at::kFloat, 2);
   need(row_bounds, "row_bounds", at::kFloat, 1);
   TORCH_CHECK(q.is_contiguous() && q.size(1) == x.size(1) && row_bounds.numel() == 2, "flat_ip_topk_bounded: q [Q,D] contiguous, x [N,D], row_bounds [2]");
-  bool tiled = false;
-  if (x_bf16.has_value()) {
-    TORCH_CHECK(x_bf16->is_cuda() && x_bf16->scalar_type() == at::kBFloat16, "flat_ip_topk_bounded: x_bf16 must be a bf16 device tensor");
-    tiled = x_bf16->dim() == 1;                     // the tiled layout of include/lrx.h, block 0 row 0 = x row 0
-    TORCH_CHECK(tiled ? (x_bf16->is_contiguous() && x_bf16->numel() >= ((x.size(0) + 127) / 128) * 128 * x.size(1))
-                      : (x_bf16->dim() == 2 && x_bf16->size(0) >= x.size(0) && x_bf16->size(1) == x.size(1) && x_bf16->stride(1) == 1),
-                "flat_ip_topk_bounded: x_bf16 must shadow x (row-major [N, D] or the 1-D tiled layout)");
+  if (x_shadow.has_value()) {
+    TORCH_CHECK(x_shadow->is_cuda() && x_shadow->scalar_type() == at::kHalf && x_shadow->dim() == 1 && x_shadow->is_contiguous() &&
+                    x_shadow->numel() >= ((x.size(0) + 127) / 128) * 128 * x.size(1),
+                "flat_ip_topk_bounded: x_shadow must be the 1-D tiled fp16 shadow of x (whole 128-row blocks)");
   }
   at::Tensor d = at::empty({q.size(0), k}, q.options()), i = at::empty({q.size(0), k}, q.options().dtype(at::kLong));
   const size_t wsb = lrx_flat_ip_bounded_workspace_bytes(x.size(0), (int32_t)x.size(1), (int32_t)q.size(0), (int32_t)k);
   at::Tensor ws = bytes((int64_t)wsb, q);
   lrx_check(lrx_flat_ip_search_bounded(x.data_ptr<float>(), x.size(0), x.size(0) ? x.stride(0) : x.size(1), (int32_t)x.size(1),
-                                       x_bf16.has_value() ? x_bf16->data_ptr() : nullptr, x_bf16.has_value() ? (tiled ? 0 : x_bf16->stride(0)) : 0,
-                                       row_bounds.data_ptr<float>(), q.data_ptr<float>(), (int32_t)q.size(0), (int32_t)k, id_base, d.data_ptr<float>(),
-                                       i.data_ptr<int64_t>(), ws.data_ptr(), wsb, cur_stream()),
+                                       x_shadow.has_value() ? x_shadow->data_ptr() : nullptr, row_bounds.data_ptr<float>(), q.data_ptr<float>(),
+                                       (int32_t)q.size(0), (int32_t)k, id_base, d.data_ptr<float>(), i.data_ptr<int64_t>(), ws.data_ptr(), wsb, (int32_t)flags,
+                                       cur_stream()),
             "flat_ip_topk_bounded");
   return {d, i};
 }
 
-// x_bf16: row-major [>= rows, D] bf16, or 1-D (the tiled layout of include/lrx.h, whole 128-row blocks) with row0 = index of x's first row
-void shard_commit_rows(const at::Tensor& x, const c10::optional<at::Tensor>& x_bf16, at::Tensor row_bounds, int64_t row0) {
+// x_shadow: 1-D tiled fp16 shadow (whole 128-row blocks) with row0 = index of x's first row in it, or None (bounds only)
+void shard_commit_rows(const at::Tensor& x, const c10::optional<at::Tensor>& x_shadow, at::Tensor row_bounds, int64_t row0) {
   DevGuard guard(x.device());
   need(x, "x", at::kFloat, 2);
   need(row_bounds, "row_bounds", at::kFloat, 1);
-  bool tiled = false;
-  if (x_bf16.has_value()) {
-    TORCH_CHECK(x_bf16->is_cuda() && x_bf16->scalar_type() == at::kBFloat16 && x_bf16->is_contiguous(), "shard_commit_rows: x_bf16 must be contiguous bf16");
-    tiled = x_bf16->dim() == 1;
-    TORCH_CHECK(!tiled || x_bf16->numel() >= ((row0 + x.size(0) + 127) / 128) * 128 * x.size(1), "shard_commit_rows: tiled shadow too small");
+  if (x_shadow.has_value()) {
+    TORCH_CHECK(x_shadow->is_cuda() && x_shadow->scalar_type() == at::kHalf && x_shadow->is_contiguous() && x_shadow->dim() == 1 &&
+                    x_shadow->numel() >= ((row0 + x.size(0) + 127) / 128) * 128 * x.size(1),
+                "shard_commit_rows: x_shadow must be the 1-D tiled fp16 shadow, large enough for rows row0 .. row0 + n");
   }
-  lrx_check(lrx_shard_commit_rows(x.data_ptr<float>(), x.stride(0), x.size(0), (int32_t)x.size(1), x_bf16.has_value() ? x_bf16->data_ptr() : nullptr,
-                                  x_bf16.has_value() ? (tiled ? 0 : x_bf16->stride(0)) : 0, row0, row_bounds.data_ptr<float>(), cur_stream()),
+  lrx_check(lrx_shard_commit_rows(x.data_ptr<float>(), x.stride(0), x.size(0), (int32_t)x.size(1), x_shadow.has_value() ? x_shadow->data_ptr() : nullptr, row0,
+                                  row_bounds.data_ptr<float>(), cur_stream()),
             "shard_commit_rows");
 }
 
@@ -215,9 +219,9 @@ TORCH_LIBRARY(lrx, m) {
   m.def("attn_varlen(Tensor qkv, Tensor cu_seqlens, int max_seqlen, int num_q_heads, int num_kv_heads, int head_dim) -> Tensor");
   m.def("swiglu_gemm(Tensor a, Tensor wgu) -> Tensor");
   m.def("embedding_bag_mean(Tensor table, Tensor ids, Tensor offsets, int padding_idx=-1, int out_dim=0, bool normalize=True) -> Tensor");
-  m.def("flat_ip_topk(Tensor q, Tensor x, int k, int id_base=0) -> (Tensor, Tensor)");
-  m.def("flat_ip_topk_bounded(Tensor q, Tensor x, Tensor? x_bf16, Tensor row_bounds, int k, int id_base=0) -> (Tensor, Tensor)");
-  m.def("shard_commit_rows(Tensor x, Tensor(a!)? x_bf16, Tensor(b!) row_bounds, int row0=0) -> ()");
+  m.def("flat_ip_topk(Tensor q, Tensor x, int k, int id_base=0, Tensor? row_bounds=None) -> (Tensor, Tensor)");
+  m.def("flat_ip_topk_bounded(Tensor q, Tensor x, Tensor? x_shadow, Tensor row_bounds, int k, int id_base=0, int flags=0) -> (Tensor, Tensor)");
+  m.def("shard_commit_rows(Tensor x, Tensor(a!)? x_shadow, Tensor(b!) row_bounds, int row0=0) -> ()");
   m.def("merge_topk(Tensor d_parts, Tensor i_parts) -> (Tensor, Tensor)");
 }
 

@@ -289,13 +289,13 @@ class LrxEncoder:
         if out.dtype != torch.float32 or out.shape[0] < B or out.shape[1] < D or out.stride(1) != 1:
             raise ValueError("out must be fp32 [>=B, >=out_dim] with unit inner stride")
         ws = self._workspace(T, B)
-        # rows of a live index shard: the last kernel also writes their bf16 shadow and raises the shard's bounds (no second pass)
+        # rows of a live index shard: the last kernel also writes their fp16 shadow and raises the shard's bounds (no second pass)
         from .index import shard_of
         hit = shard_of(out) if D == out.shape[1] else None
-        shadow, sstride, srow0, bounds = hit[0].shard_sink(hit[1], B) if hit is not None else (None, 0, 0, None)
+        shadow, srow0, bounds = hit[0].shard_sink(hit[1], B) if hit is not None else (None, 0, None)
         _lib.check(self.lib.lrx_encode_packed_shard(C.byref(self._ccfg), C.byref(self._cw), _lib.ptr(ids), _lib.ptr(cu_seqlens), B, T,
                                                     int(max_seqlen), _lib.ptr(out), out.stride(0), D, int(normalize), _lib.ptr(shadow),
-                                                    int(sstride), int(srow0), _lib.ptr(bounds), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+                                                    int(srow0), _lib.ptr(bounds), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
         return out[:B, :D]
 
     def encode_hidden(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int) -> torch.Tensor:

@@ -29,6 +29,10 @@ def shard_of(out: torch.Tensor):
 
 
 class FlatIPIndex:
+    # lrx_flat_ip_search_bounded flags (_lib.SEARCH_FILTER_*): which filter the bounded search runs.  A class-level default that tests and A/B
+    # tools override (per index or for all); the hits do not depend on it.  (Round 2 had a process-global switch inside the library.)
+    search_flags = _lib.SEARCH_FILTER_AUTO
+
     def __init__(self, d: int, capacity: int = 0, device: Optional[torch.device] = None, id_base: int = 0):
         _lib.require_gpu()
         if d % 32 != 0:
@@ -39,18 +43,16 @@ class FlatIPIndex:
         self.ntotal = 0
         self.id_base = id_base  # added to local row numbers (global row of this shard's row 0)
         self._ws = None
-        # {max |row|, max |row - bf16(row)|} over the committed rows, kept on the device (no host sync): the error bound of the bf16
+        # {max |row|, max |row - fp16(row)|} over the committed rows, kept on the device (no host sync): the error bound of the fp16
         # filter pass of lrx_flat_ip_search_bounded is built from them.  two_pass = False forces the six-product path for every search.
         self._bounds = torch.zeros(2, dtype=torch.float32, device=self.device)
         self.two_pass = True
-        # bf16 shadow of the rows (round-to-nearest-even): the filter pass of the two-pass search streams it instead of the fp32 rows
-        # (half the bytes; the exact rescoring still reads fp32).  +50 % index memory; False = no shadow.  Shadow rows and bounds are
+        # fp16 shadow of the rows (round-to-nearest-even, saturating): the filter pass of the two-pass search streams it instead of the fp32
+        # rows (half the bytes; the exact rescoring still reads fp32).  +50 % index memory; False = no shadow.  Shadow rows and bounds are
         # written by the kernel that produces the fp32 rows (the encoder's last kernel for slots, lrx_shard_commit_rows for add()).
-        self.shadow_bf16 = True
-        # "tiled": [128-row block][64-wide k-slice] tiles of 16 KiB, fragment-major inside (include/lrx.h): a wave of the filter pass loads
-        # its MFMA operand with one coalesced 1-KiB request, straight into registers
-        # (Q = 1: -12 %, Q = 100: -6 % per search); "rows": plain row-major [capacity, d].  Same hits either way.
-        self.shadow_layout = "tiled"
+        # Layout: [128-row block][64-wide k-slice] tiles of 16 KiB, fragment-major inside (include/lrx.h): a wave of the filter pass loads
+        # its MFMA operand with one coalesced 1-KiB request, straight into registers.
+        self.shadow_f16 = True
         self.max_workspace_bytes = 12 << 30  # search(): cap of the search workspace; larger query batches are chunked
         self._xb: Optional[torch.Tensor] = None
         self._fused: list = []               # row intervals whose shadow + bounds the encoder has already written
@@ -62,7 +64,7 @@ class FlatIPIndex:
         return self._bounds[:1]
 
     def _wants_shadow(self) -> bool:
-        return self.shadow_bf16 and self.d % 64 == 0
+        return self.shadow_f16 and self.d % 64 == 0
 
     def _set_storage(self, x: torch.Tensor):
         if self._x.numel():
@@ -80,45 +82,28 @@ class FlatIPIndex:
             self._set_storage(new)
         self._ensure_shadow()
 
-    def _tiled(self) -> bool:
-        return self.shadow_layout == "tiled"
-
     def _ensure_shadow(self):
         if not self._wants_shadow():
             return
         cap = self._x.shape[0]
-        if self._tiled():
-            need = -(-cap // 128) * 128 * self.d                       # whole 128-row blocks, flat
-            if self._xb is None or self._xb.ndim != 1 or self._xb.numel() < need:
-                xb = torch.empty(need, dtype=torch.bfloat16, device=self.device)   # (padding rows of the last block are masked by the kernels)
-                if self._xb is not None and self._xb.ndim == 1 and self.ntotal:
-                    n_old = min(self._xb.numel(), -(-self.ntotal // 128) * 128 * self.d)   # the blocks that hold committed rows
-                    xb[:n_old].copy_(self._xb[:n_old])
-                elif self.ntotal:
-                    # no same-layout shadow to copy (layout switched, or shadow_bf16 turned on after rows were added): rebuild the
-                    # committed rows from the fp32 rows; the bounds too when there was no shadow at all (E was never measured)
-                    had = self._xb is not None
-                    self._xb = xb
-                    self._maintain(0, self.ntotal, bounds=not had)
-                    return
+        need = -(-cap // 128) * 128 * self.d                           # whole 128-row blocks, flat
+        if self._xb is None or self._xb.numel() < need:
+            xb = torch.empty(need, dtype=torch.float16, device=self.device)   # (padding rows of the last block are masked by the kernels)
+            if self._xb is not None and self.ntotal:
+                n_old = min(self._xb.numel(), -(-self.ntotal // 128) * 128 * self.d)   # the blocks that hold committed rows
+                xb[:n_old].copy_(self._xb[:n_old])
                 self._xb = xb
-        elif self._xb is None or self._xb.ndim != 2 or self._xb.shape[0] < cap:
-            xb = torch.empty(cap, self.d, dtype=torch.bfloat16, device=self.device)
-            old = self._xb
-            self._xb = xb
-            if self.ntotal:
-                if old is not None and old.ndim == 2:
-                    xb[:self.ntotal].copy_(old[:self.ntotal])
-                else:                                                   # other layout, or no shadow so far: rebuild from the fp32 rows
-                    self._maintain(0, self.ntotal, bounds=old is None)
+            else:
+                # no shadow so far (shadow_f16 switched on after rows were added): build the committed rows' shadow from the fp32 rows
+                self._xb = xb
+                if self.ntotal:
+                    self._maintain(0, self.ntotal)
 
     def shadow_rows(self, n: Optional[int] = None) -> torch.Tensor:
-        """The shadow as a row-major [n, d] bf16 tensor (a copy when the layout is tiled): tests and tools."""
+        """The shadow as a row-major [n, d] fp16 tensor (a copy: the stored layout is tiled): tests and tools."""
         n = self.ntotal if n is None else n
         if self._xb is None:
-            raise ValueError("this index keeps no bf16 shadow")
-        if self._xb.ndim == 2:
-            return self._xb[:n]
+            raise ValueError("this index keeps no fp16 shadow")
         nb = -(-n // 128)
         # tile = [16-row group w][k-step ks][fq][fi][8]  ->  row 128 b + 16 w + fi, column 64 s + 32 ks + 8 fq + j
         t = self._xb[:nb * 128 * self.d].view(nb, self.d // 64, 8, 2, 4, 16, 8)          # b, s, w, ks, fq, fi, j
@@ -137,29 +122,22 @@ class FlatIPIndex:
         return self._x[a:b]
 
     def shard_sink(self, row0: int, n_rows: int):
-        """(shadow pointer tensor or None, shadow row stride [0 = tiled], first shadow row, bounds) for rows [row0, row0 + n) and a note
-        that their producer maintains them."""
+        """(tiled shadow tensor or None, first shadow row, bounds) for rows [row0, row0 + n) and a note that their producer maintains them."""
         self._ensure_shadow()
         if row0 + n_rows > self.ntotal:               # (rows already committed need no bookkeeping: their producer keeps them valid)
             self._fused.append((row0, row0 + n_rows))
         if not (self._wants_shadow() and self._xb is not None):
-            return None, 0, 0, self._bounds
-        if self._tiled():
-            return self._xb, 0, row0, self._bounds
-        return self._xb[row0:row0 + n_rows], self._xb.stride(0), 0, self._bounds
+            return None, 0, self._bounds
+        return self._xb, row0, self._bounds
 
-    def _maintain(self, a: int, b: int, bounds: bool = True):
+    def _maintain(self, a: int, b: int):
         """Shadow + bounds of rows [a, b) by lrx_shard_commit_rows (one read of the fp32 rows)."""
         if b <= a:
             return
         self._ensure_shadow()
         xb = self._xb if self._wants_shadow() else None
-        tiled = xb is not None and xb.ndim == 1
-        tgt = self._bounds if bounds else torch.zeros_like(self._bounds)
-        _lib.check(self.lib.lrx_shard_commit_rows(_lib.ptr(self._x[a:]), self._x.stride(0), b - a, self.d,
-                                                  _lib.ptr(xb if tiled else xb[a:]) if xb is not None else None,
-                                                  (0 if tiled else xb.stride(0)) if xb is not None else 0, a if tiled else 0,
-                                                  _lib.ptr(tgt), _lib.current_stream()))
+        _lib.check(self.lib.lrx_shard_commit_rows(_lib.ptr(self._x[a:]), self._x.stride(0), b - a, self.d, _lib.ptr(xb), a, _lib.ptr(self._bounds),
+                                                  _lib.current_stream()))
 
     def commit(self, n_rows: int):
         if n_rows > 0:
@@ -189,7 +167,7 @@ class FlatIPIndex:
         self.commit(x.shape[0])
 
     def refresh_norm_bound(self):
-        """Recompute the bounds and the bf16 shadow over all committed rows: needed only after writing into committed rows in place
+        """Recompute the bounds and the fp16 shadow over all committed rows: needed only after writing into committed rows in place
         with something other than the encoder (which maintains both itself)."""
         self._bounds.zero_()
         self._maintain(0, self.ntotal)
@@ -247,18 +225,16 @@ class FlatIPIndex:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         ldx = self._x.stride(0) if self._x.shape[0] else self.d
-        xb = self._xb if (self.two_pass and self.shadow_bf16 and self._xb is not None) else None
-        ldxb = 0 if (xb is not None and xb.ndim == 1) else (xb.stride(0) if xb is not None else 0)
+        xb = self._xb if (self.two_pass and self.shadow_f16 and self._xb is not None) else None
         for s in range(0, Q, chunk):
             qc, Dc, Ic = q[s:s + chunk], D[s:s + chunk], I[s:s + chunk]
             if self.two_pass:
-                _lib.check(self.lib.lrx_flat_ip_search_bounded(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(xb) if xb is not None else None,
-                                                               ldxb, _lib.ptr(self._bounds), _lib.ptr(qc),
+                _lib.check(self.lib.lrx_flat_ip_search_bounded(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(xb), _lib.ptr(self._bounds), _lib.ptr(qc),
                                                                qc.shape[0], k, self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws),
-                                                               self._ws.numel(), _lib.current_stream()))
+                                                               self._ws.numel(), int(self.search_flags), _lib.current_stream()))
             else:
-                _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(qc), qc.shape[0], k, self.id_base,
-                                                       _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))
+                _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(self._bounds), _lib.ptr(qc), qc.shape[0], k,
+                                                       self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))
         return D, I
 
 

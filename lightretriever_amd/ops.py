@@ -156,7 +156,7 @@ def pool_norm(hidden: torch.Tensor, w: torch.Tensor, cu_seqlens: torch.Tensor, e
     B, H = cu_seqlens.numel() - 1, hidden.shape[1]
     D = out_dim or H
     out = torch.empty(B, D, dtype=torch.float32, device=hidden.device)
-    _lib.check(_lib.lib().lrx_pool_norm_shard(_lib.ptr(hidden), _lib.ptr(w), _lib.ptr(cu_seqlens), B, H, eps, _lib.ptr(out), D, D, int(normalize), None, 0, 0,
+    _lib.check(_lib.lib().lrx_pool_norm_shard(_lib.ptr(hidden), _lib.ptr(w), _lib.ptr(cu_seqlens), B, H, eps, _lib.ptr(out), D, D, int(normalize), None, 0,
                                               None, int(hidden.dtype == torch.float32), _s()))
     return out
 

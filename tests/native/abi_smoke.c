@@ -15,6 +15,30 @@
 static unsigned long long rng_state = 88172645463325252ull;
 static float frand(void) { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (float)((rng_state >> 11) & 0xFFFFFF) / 8388608.0f - 1.0f; }
 
+/* fp32 -> fp16 bits, round to nearest even, saturating at +-65504 (what the shadow holds; include/lrx.h) */
+static unsigned short f32_to_f16(float f) {
+  if (f > 65504.f) f = 65504.f;
+  if (f < -65504.f) f = -65504.f;
+  unsigned u; memcpy(&u, &f, 4);
+  const unsigned sign = (u >> 16) & 0x8000u;
+  const int e = (int)((u >> 23) & 0xFF) - 127 + 15;
+  unsigned m = u & 0x7FFFFFu;
+  if (e >= 31) return (unsigned short)(sign | 0x7BFFu);
+  if (e <= 0) {                                  /* subnormal half (or zero) */
+    if (e < -10) return (unsigned short)sign;
+    m |= 0x800000u;
+    const int sh = 14 - e;                       /* 24-bit significand -> 10 bits + exponent offset */
+    unsigned h = m >> sh;
+    const unsigned rem = m & ((1u << sh) - 1u), halfway = 1u << (sh - 1);
+    if (rem > halfway || (rem == halfway && (h & 1u))) ++h;
+    return (unsigned short)(sign | h);
+  }
+  unsigned h = ((unsigned)e << 10) | (m >> 13);
+  const unsigned rem = m & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;      /* carries into the exponent correctly; cannot pass 0x7BFF after the clamp */
+  return (unsigned short)(sign | h);
+}
+
 static int check_topk(const float* X, const float* q, int N, int D, int Q, int k, const float* Dg, const long long* Ig, const char* what) {
   double* sc = (double*)malloc(sizeof(double) * N);
   int bad = 0;
@@ -43,38 +67,42 @@ int main(void) {
   float maxn = 0.f;
   for (int n = 0; n < N; ++n) { double s = 0; for (int d = 0; d < D; ++d) { X[n * D + d] = frand(); s += X[n * D + d] * X[n * D + d]; } if (sqrt(s) > maxn) maxn = (float)sqrt(s); }
   for (int i = 0; i < Q * D; ++i) q[i] = frand();
-  /* bf16 shadow (round to nearest even) made on the host */
-  unsigned short* Xb = (unsigned short*)malloc(2 * (size_t)N * D);
-  for (size_t i = 0; i < (size_t)N * D; ++i) { unsigned u; memcpy(&u, &X[i], 4); u += 0x7FFFu + ((u >> 16) & 1u); Xb[i] = (unsigned short)(u >> 16); }
+  /* the tiled fp16 shadow (round to nearest even; layout formula of include/lrx.h) made on the host */
+  const size_t NSH = ((size_t)(N + 127) / 128) * 128 * D;
+  unsigned short* Xb = (unsigned short*)calloc(NSH, 2);
+  for (int r = 0; r < N; ++r)
+    for (int c = 0; c < D; ++c)
+      Xb[((size_t)(r / 128) * (D / 64) + c / 64) * 8192 + ((((r / 16) % 8) * 2 + (c / 32) % 2) * 64 + ((c / 8) % 4) * 16 + r % 16) * 8 + c % 8] = f32_to_f16(X[r * D + c]);
   float *dX, *dq, *dD, *dbound; long long* dI; void *dXb, *ws;
   maxn *= 1.000001f;
   CHECK(hipMalloc((void**)&dX, sizeof(float) * N * D)); CHECK(hipMalloc((void**)&dq, sizeof(float) * Q * D));
   CHECK(hipMalloc((void**)&dD, sizeof(float) * Q * k)); CHECK(hipMalloc((void**)&dI, sizeof(long long) * Q * k));
-  CHECK(hipMalloc(&dXb, 2 * (size_t)N * D)); CHECK(hipMalloc((void**)&dbound, 8)); CHECK(hipMemset(dbound, 0, 8));
+  CHECK(hipMalloc(&dXb, 2 * NSH)); CHECK(hipMemset(dXb, 0, 2 * NSH)); CHECK(hipMalloc((void**)&dbound, 8)); CHECK(hipMemset(dbound, 0, 8));
   CHECK(hipMemcpy(dX, X, sizeof(float) * N * D, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dq, q, sizeof(float) * Q * D, hipMemcpyHostToDevice));
-  /* shard maintenance on the device: bf16 shadow + the bounds {max |row|, max |row - bf16(row)|}; checked against the host copies */
-  LRX(lrx_shard_commit_rows(dX, D, N, D, dXb, D, 0, dbound, NULL));
+  /* shard maintenance on the device: fp16 shadow + the bounds {max |row|, max |row - fp16(row)|}; checked against the host copies */
+  LRX(lrx_shard_commit_rows(dX, D, N, D, dXb, 0, dbound, NULL));
   CHECK(hipDeviceSynchronize());
-  { unsigned short* Xb2 = (unsigned short*)malloc(2 * (size_t)N * D); float hb[2];
-    CHECK(hipMemcpy(Xb2, dXb, 2 * (size_t)N * D, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hb, dbound, 8, hipMemcpyDeviceToHost));
-    if (memcmp(Xb, Xb2, 2 * (size_t)N * D) != 0) { printf("lrx_shard_commit_rows: shadow differs from host RNE\n"); return 5; }
-    if (fabsf(hb[0] / maxn - 1.f) > 1e-5f || !(hb[1] > 0.f && hb[1] < hb[0] / 200.f)) { printf("lrx_shard_commit_rows: bounds %g %g (host max norm %g)\n", hb[0], hb[1], maxn); return 5; }
+  { unsigned short* Xb2 = (unsigned short*)malloc(2 * NSH); float hb[2];
+    CHECK(hipMemcpy(Xb2, dXb, 2 * NSH, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hb, dbound, 8, hipMemcpyDeviceToHost));
+    if (memcmp(Xb, Xb2, 2 * NSH) != 0) { printf("lrx_shard_commit_rows: shadow differs from host RNE / the documented tile layout\n"); return 5; }
+    if (fabsf(hb[0] / maxn - 1.f) > 1e-5f || !(hb[1] > 0.f && hb[1] < hb[0] / 1500.f)) { printf("lrx_shard_commit_rows: bounds %g %g (host max norm %g)\n", hb[0], hb[1], maxn); return 5; }
     free(Xb2); }
   const size_t wsb = lrx_flat_ip_bounded_workspace_bytes(N, D, Q, k);
   CHECK(hipMalloc(&ws, wsb)); CHECK(hipMemset(ws, 0, wsb));
   float* hD = (float*)malloc(sizeof(float) * Q * k); long long* hI = (long long*)malloc(sizeof(long long) * Q * k);
   int bad = 0;
-  LRX(lrx_flat_ip_search(dX, N, D, D, dq, Q, k, 0, dD, (int64_t*)dI, ws, wsb, NULL));
+  LRX(lrx_flat_ip_search(dX, N, D, D, NULL, dq, Q, k, 0, dD, (int64_t*)dI, ws, wsb, NULL));      /* bounds not handed over: measured by the call */
   CHECK(hipDeviceSynchronize());
   CHECK(hipMemcpy(hD, dD, sizeof(float) * Q * k, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hI, dI, sizeof(long long) * Q * k, hipMemcpyDeviceToHost));
   bad += check_topk(X, q, N, D, Q, k, hD, hI, "lrx_flat_ip_search");
-  LRX(lrx_flat_ip_search_bounded(dX, N, D, D, dXb, D, dbound, dq, Q, k, 0, dD, (int64_t*)dI, ws, wsb, NULL));
+  LRX(lrx_flat_ip_search_bounded(dX, N, D, D, dXb, dbound, dq, Q, k, 0, dD, (int64_t*)dI, ws, wsb, LRX_SEARCH_FILTER_AUTO, NULL));
   CHECK(hipDeviceSynchronize());
   CHECK(hipMemcpy(hD, dD, sizeof(float) * Q * k, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hI, dI, sizeof(long long) * Q * k, hipMemcpyDeviceToHost));
   bad += check_topk(X, q, N, D, Q, k, hD, hI, "lrx_flat_ip_search_bounded");
   /* argument errors come back as codes + message, never as a crash */
-  if (lrx_flat_ip_search(dX, N, D, D, dq, Q, 0, 0, dD, (int64_t*)dI, ws, wsb, NULL) == 0 || strlen(lrx_last_error()) == 0) { printf("k = 0 was accepted\n"); ++bad; }
-  if (lrx_flat_ip_search(dX, N, D, D, dq, Q, k, 0, dD, (int64_t*)dI, ws, 16, NULL) == 0) { printf("a 16-byte workspace was accepted\n"); ++bad; }
+  if (lrx_flat_ip_search(dX, N, D, D, dbound, dq, Q, 0, 0, dD, (int64_t*)dI, ws, wsb, NULL) == 0 || strlen(lrx_last_error()) == 0) { printf("k = 0 was accepted\n"); ++bad; }
+  if (lrx_flat_ip_search(dX, N, D, D, dbound, dq, Q, k, 0, dD, (int64_t*)dI, ws, 16, NULL) == 0) { printf("a 16-byte workspace was accepted\n"); ++bad; }
+  if (lrx_flat_ip_search_bounded(dX, N, D, D, dXb, dbound, dq, Q, k, 0, dD, (int64_t*)dI, ws, wsb, 64, NULL) == 0) { printf("unknown search flags were accepted\n"); ++bad; }
   printf(bad ? "ABI SMOKE FAILED (%d mismatches)\n" : "ABI SMOKE OK\n", bad);
   return bad ? 4 : 0;
 }

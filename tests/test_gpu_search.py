@@ -258,8 +258,8 @@ def test_two_pass_adversarial_bf16_rounding():
 
 
 @pytest.mark.parametrize("Q", [1, 20, 100])
-def test_bf16_shadow_filter_gives_the_same_exact_result(Q):
-    """The filter pass may stream a bf16 copy of the rows instead of the fp32 rows (half the bytes): same error band, same exact
+def test_fp16_shadow_filter_gives_the_same_exact_result(Q):
+    """The filter pass may stream the fp16 shadow of the rows instead of the fp32 rows (half the bytes): same error band, same exact
     rescoring from fp32 -> bitwise the same scores and ids as without the shadow, for every query batch size."""
     from lightretriever_amd import FlatIPIndex
     rng = np.random.default_rng(40 + Q)
@@ -268,10 +268,10 @@ def test_bf16_shadow_filter_gives_the_same_exact_result(Q):
     q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))
     a = FlatIPIndex(D, capacity=N)
     a.add(X[:25000]); a.add(X[25000:])
-    assert a._xb is not None and a._xb.dtype == torch.bfloat16 and torch.equal(a.shadow_rows(), torch.from_numpy(X).cuda().to(torch.bfloat16))
+    assert a._xb is not None and a._xb.dtype == torch.float16 and torch.equal(a.shadow_rows(), torch.from_numpy(X).cuda().to(torch.float16))
     Da, Ia = a.search(q, k)
     b = FlatIPIndex(D, capacity=N)
-    b.shadow_bf16 = False
+    b.shadow_f16 = False
     b.add(X)
     assert b._xb is None
     Db, Ib = b.search(q, k)

@@ -13,16 +13,20 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def search_mode():
-    from lightretriever_amd import _lib
-    lib = _lib.lib()
-    yield lib.lrx_search_set_mode
-    lib.lrx_search_set_mode(0)
+    """Selects the filter of lrx_flat_ip_search_bounded (its `flags` argument, include/lrx.h LRX_SEARCH_FILTER_*) for every FlatIPIndex.search of
+    the test: 0 auto, 1 score-matrix filter, 2 score-free filter, 3 score-free without the GEMM main pass."""
+    from lightretriever_amd import FlatIPIndex
+
+    def set_mode(m):
+        FlatIPIndex.search_flags = int(m)
+    yield set_mode
+    FlatIPIndex.search_flags = 0
 
 
 def _index(X, shadow=True, id_base=0, pieces=2):
     from lightretriever_amd import FlatIPIndex
     idx = FlatIPIndex(X.shape[1], capacity=X.shape[0], id_base=id_base)
-    idx.shadow_bf16 = shadow
+    idx.shadow_f16 = shadow
     step = -(-X.shape[0] // pieces)
     for s in range(0, X.shape[0], step):
         idx.add(X[s:s + step])
@@ -78,9 +82,9 @@ def test_tiled_shadow_layout_is_the_documented_one():
     N, D = 1000, 192
     X = rng.standard_normal((N, D)).astype(np.float32)
     idx = _index(X, pieces=3)
-    assert idx._xb.ndim == 1
+    assert idx._xb.ndim == 1 and idx._xb.dtype == torch.float16
     flat = idx._xb.view(torch.int16).cpu().numpy()
-    want = torch.from_numpy(X).to(torch.bfloat16).view(torch.int16).numpy()
+    want = torch.from_numpy(X).to(torch.float16).view(torch.int16).numpy()
     r = rng.integers(0, N, size=4000)
     k = rng.integers(0, D, size=4000)
     off = ((r // 128) * (D // 64) + k // 64) * 8192 + ((((r // 16) % 8) * 2 + (k // 32) % 2) * 64 + ((k // 8) % 4) * 16 + r % 16) * 8 + k % 8
@@ -97,17 +101,17 @@ def test_workspace_stops_growing_at_256_queries():
     assert int(lib.lrx_flat_ip_bounded_workspace_bytes(10_000_000, 256, 100, 100)) < 1.1 * full + (64 << 20)
 
 
-def test_adversarial_bf16_rounding_midpoints(search_mode):
-    """bf16 has unit roundoff 2^-8 (8-bit significand).  Rows whose elements all sit just below a rounding midpoint lose
-    0.36 % of their score in the filter; rows with half their elements just above one gain as much and outrank them there although
-    they are worse.  The band is built from the measured |q - bf16(q)| and |x - bf16(x)|, so the exact top-k must survive on both
+def test_adversarial_fp16_rounding_midpoints(search_mode):
+    """ADVICE r1, moved to the fp16 filter of round 3: fp16 has unit roundoff 2^-11.  Rows whose elements all sit just below a rounding
+    midpoint lose 0.05 % of their score in the filter; rows with half their elements just above one gain as much and outrank them there
+    although they are worse.  The band is built from the measured |q - fp16(q)| and |x - fp16(x)|, so the exact top-k must survive on both
     filters and equal the six-product path."""
     rng = np.random.default_rng(5)
     N, D, Q, k = 40000, 128, 48, 10
     X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32)) * np.float32(0.9)
-    w = np.float32(1 + 2.0 ** -8 - 2.0 ** -12)          # rounds DOWN to 1.0            (exact 1.00366)
-    a = np.float32(1 + 2.0 ** -8 + 2.0 ** -12)          # rounds UP   to 1 + 2^-7       (exact 1.00415, filter 1.00781)
-    b = np.float32(1 - 2.0 ** -9 + 2.0 ** -12)          # rounds UP   to 1.0            (exact 0.99829)
+    w = np.float32(1 + 2.0 ** -11 - 2.0 ** -15)         # rounds DOWN to 1.0            (exact 1.000458)
+    a = np.float32(1 + 2.0 ** -11 + 2.0 ** -15)         # rounds UP   to 1 + 2^-10      (exact 1.000519, filter 1.000977)
+    b = np.float32(1 - 2.0 ** -12 + 2.0 ** -15)         # rounds UP   to 1.0            (exact 0.999786)
     q = np.abs(O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32)))
     q[:Q // 2] = w * np.float32(2.0) ** rng.integers(-3, 1, size=(Q // 2, D)).astype(np.float32)   # queries made of understated elements too
     s = np.float32(0.9 / np.sqrt(D))
@@ -115,14 +119,14 @@ def test_adversarial_bf16_rounding_midpoints(search_mode):
     for j in range(Q):
         # block j = the pattern scaled by (1 - j / 1000): block 0 holds every query's exact top-10 (all q > 0, rows parallel to 1)
         for t in range(12):                               # the true winners: all elements understated, filter score 2.0 (in units of s)
-            X[j * 40 + t] = s * w * np.float32(1 - 1e-4 * t) * np.float32(1 - 1e-3 * j)
-        for t in range(12, 30):                           # decoys: exact 2.00244 < 2.00732, filter 2.00781 > 2.0
-            X[j * 40 + t] = s * np.where(half, a, b).astype(np.float32) * np.float32(1 - 5e-6 * t) * np.float32(1 - 1e-3 * j)
+            X[j * 40 + t] = s * w * np.float32(1 - 1.2e-5 * t) * np.float32(1 - 1e-3 * j)
+        for t in range(12, 30):                           # decoys: exact mean 1.000153 < 1.000458, filter 1.000488 > 1.0
+            X[j * 40 + t] = s * np.where(half, a, b).astype(np.float32) * np.float32(1 - 6e-7 * t) * np.float32(1 - 1e-3 * j)
     Do, Io = O.flat_ip_topk(q, X, k)
-    Xb = torch.from_numpy(X).to(torch.bfloat16).float().numpy()
-    qb = torch.from_numpy(q).to(torch.bfloat16).float().numpy()
-    bf_rank = np.argsort(-(qb.astype(np.float64) @ Xb.astype(np.float64).T), axis=1)[:, :k]
-    assert (np.sort(bf_rank, 1) != np.sort(Io, 1)).any(axis=1).mean() > 0.9     # a bf16-only ranking gets (almost) every query wrong
+    Xh = torch.from_numpy(X).to(torch.float16).float().numpy()
+    qh = torch.from_numpy(q).to(torch.float16).float().numpy()
+    h_rank = np.argsort(-(qh.astype(np.float64) @ Xh.astype(np.float64).T), axis=1)[:, :k]
+    assert (np.sort(h_rank, 1) != np.sort(Io, 1)).any(axis=1).mean() > 0.9      # an fp16-only ranking gets (almost) every query wrong
     idx = _index(X)
     res = {}
     for mode in (1, 2):
@@ -139,6 +143,25 @@ def test_adversarial_bf16_rounding_midpoints(search_mode):
         assert (Ig.cpu().numpy() < 12).all()                 # block 0's understated winners, not the overstated decoys
 
 
+def test_rows_outside_the_fp16_range_fall_back_to_the_exact_path(search_mode):
+    """The shadow saturates at +-65504: a row with larger elements shows up as a huge measured rounding error E -> an unusable band -> every
+    query takes the exact six-product fallback.  Slow, never wrong -- and no inf / NaN anywhere."""
+    rng = np.random.default_rng(6)
+    N, D, Q, k = 30000, 128, 20, 10
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32))
+    X[777] *= np.float32(4e6)                                # elements ~ 3e5 > 65504
+    X[12345, 5] = np.float32(1e5)
+    q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))
+    idx = _index(X)
+    assert torch.isfinite(idx.shadow_rows().float()).all() and float(idx._bounds[1]) > 1e4
+    for mode in (2, 1):
+        search_mode(mode)
+        Dg, Ig = idx.search(q, k)
+        assert torch.isfinite(Dg).all()
+        check_against_oracle(Dg, Ig, q, X, k, score_tol=0.5)          # (scores ~ 1e5: fp32 resolution of the exact value)
+        np.testing.assert_array_equal(Ig.cpu().numpy(), O.flat_ip_topk(q, X, k)[1])
+
+
 def test_candidate_list_overflow_falls_back_per_query(search_mode):
     """More rows inside T' - 2 eps than a candidate list holds (near-duplicate corpus): those queries must come back from the gated
     six-product fallback, everything exact."""
@@ -153,7 +176,7 @@ def test_candidate_list_overflow_falls_back_per_query(search_mode):
     idx = _index(X)
     search_mode(2)
     Dg, Ig = idx.search(q, k)
-    check_against_oracle(Dg, Ig, q, X, k, score_tol=3e-6, max_mismatch=0.12)
+    check_against_oracle(Dg, Ig, q, X, k, score_tol=3e-6, max_mismatch=0.02)    # (ids may only differ where fp32-rounded exact scores tie)
     Do, Io = O.flat_ip_topk(q[5:], X, k)
     assert (Ig[5:].cpu().numpy() == Io).mean() > 0.999
     Xd = np.repeat(X[:50], 400, axis=0)                          # 20 000 rows, every vector 400 times: exact ties, lowest row first
@@ -179,6 +202,37 @@ def test_candidate_list_overflow_falls_back_per_query(search_mode):
     np.testing.assert_array_equal(I3.cpu().numpy(), I3_o)
 
 
+@pytest.mark.parametrize("cluster,k", [(800, 100), (6000, 300), (9000, 2048)])
+def test_near_tie_cluster_around_the_kth_score_is_resolved_exactly(cluster, k, search_mode):
+    """`cluster` rows within 3e-7 relative of each other straddle the k-th place -- far inside the fp32 accumulation noise of
+    the six-product score matrix, so no selection BY those scores can be trusted.  The plain path and the gated fallback rescore every row
+    within 2 eps6(q) of the k-th matrix score (all of the cluster; more than 4096 of them -> the streaming form) and must return exactly the
+    fp64 oracle's ids under the (score desc, row asc) rule, on every path."""
+    rng = np.random.default_rng(cluster + k)
+    N, D, Q = 60000, 128, 6
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32)) * np.float32(0.5)
+    base = O.l2_normalize(rng.standard_normal((1, D)).astype(np.float32))[0]
+    rows = rng.choice(N, size=cluster, replace=False)
+    X[rows] = base[None, :] * (1.0 + rng.uniform(-3e-7, 3e-7, size=(cluster, 1))).astype(np.float32)
+    better = rng.choice(np.setdiff1d(np.arange(N), rows), size=k // 2, replace=False)     # k/2 clearly better rows: the k-th place falls inside the cluster
+    X[better] = base[None, :] * np.float32(1.5)
+    q = np.repeat(base[None, :], Q, 0) * rng.uniform(0.5, 2.0, size=(Q, 1)).astype(np.float32)
+    q[1:] += (1e-4 * rng.standard_normal((Q - 1, D))).astype(np.float32)
+    Do, Io = O.flat_ip_topk(q, X, k)
+    idx = _index(X)
+    got = {}
+    idx.two_pass = False
+    got["plain"] = idx.search(q, k)
+    idx.two_pass = True
+    for mode in (2, 1):
+        search_mode(mode)
+        got["bounded%d" % mode] = idx.search(q, k)
+    search_mode(0)
+    for name, (Dg, Ig) in got.items():
+        np.testing.assert_array_equal(Ig.cpu().numpy(), Io, err_msg=name)
+        np.testing.assert_array_equal(Dg.cpu().numpy(), Do, err_msg=name)          # the exactly rescored fp32 values, bit for bit
+
+
 def test_non_finite_query_does_not_poison_the_batch(search_mode):
     rng = np.random.default_rng(3)
     N, D, Q, k = 30000, 64, 40, 5
@@ -201,7 +255,7 @@ def test_shard_commit_rows_kernel_shadow_and_bounds():
     X = (rng.standard_normal((N, D)) * rng.uniform(0.1, 4.0, size=(N, 1))).astype(np.float32)
     idx = FlatIPIndex(D)
     idx.add(X[:1000]); idx.add(X[1000:])
-    xb = torch.from_numpy(X).cuda().to(torch.bfloat16)
+    xb = torch.from_numpy(X).cuda().to(torch.float16)
     assert idx._xb.ndim == 1 and torch.equal(idx.shadow_rows(), xb)            # tiled layout, same values
     R = np.linalg.norm(X.astype(np.float64), axis=1).max()
     E = np.linalg.norm(X.astype(np.float64) - xb.float().cpu().numpy().astype(np.float64), axis=1).max()
@@ -211,13 +265,11 @@ def test_shard_commit_rows_kernel_shadow_and_bounds():
     idx._xb.zero_(); idx._bounds.zero_()
     idx.refresh_norm_bound()
     assert torch.equal(idx.shadow_rows(), xb) and np.array_equal(idx._bounds.cpu().numpy(), b)
-    # the row-major layout of the same index: same shadow values, same bounds
-    idx.shadow_layout = "rows"
-    idx._xb = None
-    idx._bounds.zero_()
-    idx.refresh_norm_bound()
-    # (bounds: the two layouts have their own kernels, i.e. summation orders -- equal to fp32 rounding)
-    assert idx._xb.ndim == 2 and torch.equal(idx._xb[:N], xb) and np.allclose(idx._bounds.cpu().numpy(), b, rtol=2e-6, atol=0)
+    # an index without a shadow measures the same bounds (bounds-only kernel; its own summation order -- equal to fp32 rounding)
+    idx2 = FlatIPIndex(D)
+    idx2.shadow_f16 = False
+    idx2.add(X)
+    assert idx2._xb is None and np.allclose(idx2._bounds.cpu().numpy(), b, rtol=2e-6, atol=0)
 
 
 def test_encoder_writes_shadow_and_bounds_of_the_slot_it_fills():
@@ -244,12 +296,12 @@ def test_encoder_writes_shadow_and_bounds_of_the_slot_it_fills():
     assert all(b <= a for a, b in calls), f"commit() re-read encoder rows: {calls}"
     ref = enc.encode_packed(ids, cu, int(lens.max()))
     assert torch.equal(idx.vectors[3:], ref)
-    assert torch.equal(idx.shadow_rows()[3:40], ref.to(torch.bfloat16))
+    assert torch.equal(idx.shadow_rows()[3:40], ref.to(torch.float16))
     b = idx._bounds.cpu().numpy()
-    assert 1.0 <= b[0] < 1.00001 and 0 < b[1] < 2.0 ** -8
+    assert 1.0 <= b[0] < 1.00001 and 0 < b[1] < 2.0 ** -11
     # in-place re-encode of committed rows (what bench.py does) keeps shadow + bounds valid without refresh_norm_bound()
     enc.encode_packed(ids, cu, int(lens.max()), out=idx._x[3:40])
-    assert torch.equal(idx.shadow_rows()[3:40], ref.to(torch.bfloat16))
+    assert torch.equal(idx.shadow_rows()[3:40], ref.to(torch.float16))
     # MRL slice narrower than the shard row: not a shard slot, plain output
     out = enc.encode_packed(ids, cu, int(lens.max()), out_dim=64)
     assert out.shape == (37, 64)
@@ -275,7 +327,7 @@ def test_rows_rewritten_after_a_partial_commit_get_fresh_shadow_and_bounds():
     extra = (O.l2_normalize(rng.standard_normal((30000, 256)).astype(np.float32)) * np.float32(3.0))   # larger norms: stale bounds would be too small
     idx.add(extra)
     X = np.concatenate([idx.vectors[:60].cpu().numpy(), extra])
-    assert torch.equal(idx.shadow_rows(), torch.from_numpy(X).cuda().to(torch.bfloat16))
+    assert torch.equal(idx.shadow_rows(), torch.from_numpy(X).cuda().to(torch.float16))
     assert idx._bounds[0].item() >= 3.0 * (1 - 1e-6)
     q = O.l2_normalize(rng.standard_normal((40, 256)).astype(np.float32))
     Dg, Ig = idx.search(q, 10)
@@ -285,24 +337,22 @@ def test_rows_rewritten_after_a_partial_commit_get_fresh_shadow_and_bounds():
     enc.encode_packed(ids, cu, int(lens.max()), out=idx2.append_slot(100))
     idx2.append_slot(30000).copy_(torch.from_numpy(extra))
     idx2.commit(30000)
-    assert torch.equal(idx2.shadow_rows(), torch.from_numpy(extra).cuda().to(torch.bfloat16))
+    assert torch.equal(idx2.shadow_rows(), torch.from_numpy(extra).cuda().to(torch.float16))
     check_against_oracle(*idx2.search(q, 10), q, extra, 10)
 
 
-@pytest.mark.parametrize("layout", ["tiled", "rows"])
-def test_shadow_switched_on_after_rows_were_added_is_built_from_the_rows(layout):
-    """shadow_bf16 = True on an index that already holds rows must not leave their shadow uninitialised."""
+def test_shadow_switched_on_after_rows_were_added_is_built_from_the_rows():
+    """shadow_f16 = True on an index that already holds rows must not leave their shadow uninitialised."""
     from lightretriever_amd import FlatIPIndex
     rng = np.random.default_rng(12)
     X = O.l2_normalize(rng.standard_normal((30000, 128)).astype(np.float32))
     idx = FlatIPIndex(128, capacity=40000)
-    idx.shadow_bf16 = False
-    idx.shadow_layout = layout
+    idx.shadow_f16 = False
     idx.add(X[:20000])
     assert idx._xb is None
-    idx.shadow_bf16 = True
+    idx.shadow_f16 = True
     idx.add(X[20000:])
-    assert torch.equal(idx.shadow_rows(), torch.from_numpy(X).cuda().to(torch.bfloat16))
+    assert torch.equal(idx.shadow_rows(), torch.from_numpy(X).cuda().to(torch.float16))
     q = O.l2_normalize(rng.standard_normal((50, 128)).astype(np.float32))
     check_against_oracle(*idx.search(q, 10), q, X, 10)
 
@@ -409,24 +459,21 @@ def test_search_on_a_side_stream_equals_default_stream(search_mode):
 @pytest.mark.parametrize("N,D,Q,k", [(50000, 128, 100, 10), (33001, 2048, 300, 5), (20011, 64, 1, 50), (70000, 1024, 256, 100), (9000, 192, 40, 7),
                                      # N mod 256 in (0, 128]: a score-matrix launch covers one 128-row block more than the tiled shadow holds
                                      (4200, 64, 40, 5), (70001, 128, 3, 20)])
-def test_tiled_and_row_major_shadow_give_the_same_bits(N, D, Q, k, search_mode):
-    """The shadow layout only changes how the filter pass addresses the same bf16 values: hits are bitwise the same, for both filters,
-    for shards that end inside a 128-row block, and for rows that arrive in pieces (add) or through the encoder-slot path."""
+def test_shadow_built_in_pieces_and_across_reallocations_gives_the_same_bits(N, D, Q, k, search_mode):
+    """Rows that arrive in pieces (add), through a shard that is re-allocated with committed rows in it, and shards that end inside a 128-row
+    block: same fp16 shadow values, same hits on both filters."""
     from lightretriever_amd import FlatIPIndex
     rng = np.random.default_rng(N + Q)
     X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32)) * rng.uniform(0.3, 2.0, size=(N, 1)).astype(np.float32)
     q = O.l2_normalize(rng.standard_normal((Q, D)).astype(np.float32))
     res = {}
-    for layout in ("tiled", "rows"):
-        idx = FlatIPIndex(D, capacity=N // 3)                       # grows twice: the shadow is re-allocated with committed rows in it
-        idx.shadow_layout = layout
-        for s in range(0, N, 7001):
-            idx.add(X[s:s + 7001])
-        assert torch.equal(idx.shadow_rows(), torch.from_numpy(X).cuda().to(torch.bfloat16))
-        for mode in (1, 2):
-            search_mode(mode)
-            res[layout, mode] = idx.search(q, k)
+    idx = FlatIPIndex(D, capacity=N // 3)                           # grows twice: the shadow is re-allocated with committed rows in it
+    for s in range(0, N, 7001):
+        idx.add(X[s:s + 7001])
+    assert torch.equal(idx.shadow_rows(), torch.from_numpy(X).cuda().to(torch.float16))
+    for mode in (1, 2):
+        search_mode(mode)
+        res[mode] = idx.search(q, k)
     search_mode(0)
-    for key in res:
-        assert torch.equal(res[key][0], res["rows", 1][0]) and torch.equal(res[key][1], res["rows", 1][1]), key
-    check_against_oracle(*res["tiled", 2], q, X, k)
+    assert torch.equal(res[1][0], res[2][0]) and torch.equal(res[1][1], res[2][1])
+    check_against_oracle(*res[2], q, X, k)

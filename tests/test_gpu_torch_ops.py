@@ -54,14 +54,20 @@ def test_search_ops(lrx):
     D1, I1 = lrx.flat_ip_topk(qd, Xd, k)
     np.testing.assert_array_equal(I1.cpu().numpy(), Io)
     np.testing.assert_allclose(D1.cpu().numpy(), Do, atol=2e-6)
-    xb = torch.empty(N, D, dtype=torch.bfloat16, device="cuda")
+    xb = torch.empty(-(-N // 128) * 128 * D, dtype=torch.float16, device="cuda")       # the tiled fp16 shadow (include/lrx.h), whole 128-row blocks
     bounds = torch.zeros(2, device="cuda")
     lrx.shard_commit_rows(Xd, xb, bounds)
-    assert torch.equal(xb, Xd.to(torch.bfloat16)) and 1.0 <= float(bounds[0]) < 1.00001
-    D2, I2 = lrx.flat_ip_topk_bounded(qd, Xd, xb, bounds, k, 7)
-    assert torch.equal(I2, I1 + 7) and torch.equal(D2, D1)
     idx = FlatIPIndex(D, id_base=7)
     idx.add(X)
+    assert torch.equal(xb, idx._xb[:xb.numel()]) and torch.equal(idx.shadow_rows(), Xd.to(torch.float16)) and 1.0 <= float(bounds[0]) < 1.00001
+    assert torch.equal(bounds, idx._bounds)
+    D2, I2 = lrx.flat_ip_topk_bounded(qd, Xd, xb, bounds, k, 7)
+    assert torch.equal(I2, I1 + 7) and torch.equal(D2, D1)
+    for flags in (1, 2):                                            # the filter choice travels with the call (no process-wide switch)
+        Df, If = lrx.flat_ip_topk_bounded(qd, Xd, xb, bounds, k, 7, flags)
+        assert torch.equal(If, I2) and torch.equal(Df, D2)
+    D1b, I1b = lrx.flat_ip_topk(qd, Xd, k, 0, bounds)               # plain path with the shard's bounds handed over: no extra pass, same hits
+    assert torch.equal(I1b, I1) and torch.equal(D1b, D1)
     D3, I3 = idx.search(qd, k)                                       # the ctypes path: same bits
     assert torch.equal(I3, I2) and torch.equal(D3, D2)
     Dm, Im = lrx.merge_topk(torch.stack([D1[:, :5], D1[:, 5:]]).contiguous(), torch.stack([I1[:, :5], I1[:, 5:]]).contiguous())
@@ -91,8 +97,8 @@ def test_query_and_unit_kernel_ops(lrx):
     wqkv = (torch.randn((nq + 2 * nkv) * d, 128, device="cuda") * 0.1).bfloat16()
     cu = torch.tensor([0, 100, 101, 300], dtype=torch.int32, device="cuda")
     pos = ops.build_positions(cu, T)
-    cos = torch.cos(torch.arange(512, device="cuda")[:, None] * 0.01 * torch.arange(d // 2, device="cuda")[None, :]).bfloat16().float().contiguous()
-    sin = torch.sin(torch.arange(512, device="cuda")[:, None] * 0.01 * torch.arange(d // 2, device="cuda")[None, :]).bfloat16().float().contiguous()
+    cos = torch.cos(torch.arange(512, device="cuda")[:, None] * 0.01 * torch.arange(d // 2, device="cuda")[None, :]).contiguous()
+    sin = torch.sin(torch.arange(512, device="cuda")[:, None] * 0.01 * torch.arange(d // 2, device="cuda")[None, :]).contiguous()
     qkv = lrx.rope_qkv_gemm(a, wqkv, None, pos, cos, sin, nq, nkv, d)
     assert torch.equal(qkv, ops.gemm_qkv_rope(a, wqkv, pos, cos, sin, nq, nkv, d))
     assert torch.equal(lrx.attn_varlen(qkv, cu, 200, nq, nkv, d), ops.attn_varlen_causal(qkv, cu, 200, nq, nkv, d))

@@ -10,14 +10,14 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(7)
     idx = FlatIPIndex(D, capacity=N)
     if os.environ.get("LAYOUT"):      # shadow layout: tiled (default) | rows
-        idx.shadow_layout = os.environ["LAYOUT"]
+        raise SystemExit("LAYOUT: the row-major shadow is gone (round 3): the shadow is the tiled fp16 layout of include/lrx.h")
     slot = idx.append_slot(N)
     for s in range(0, N, 65536):
         e = min(s + 65536, N)
         slot[s:e] = torch.nn.functional.normalize(torch.randn(e - s, D, generator=g, device="cuda"), dim=-1)
     idx.commit(N)
-    if os.environ.get("MODE"):        # 1 = score-matrix filter, 2 = score-free filter (lrx_search_set_mode)
-        idx.lib.lrx_search_set_mode(int(os.environ["MODE"]))
+    if os.environ.get("MODE"):        # 1 = score-matrix filter, 2 = score-free filter (FlatIPIndex.search_flags -> the flags argument of lrx_flat_ip_search_bounded)
+        setattr(idx, "search_flags", int(os.environ["MODE"]))
     K = int(os.environ.get("K", 100))
     for Q in [int(x) for x in os.environ.get("QS", "1,16,32,48,100,128").split(",")]:
         q = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device="cuda"), dim=-1)

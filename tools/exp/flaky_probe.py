@@ -23,9 +23,9 @@ for r in range(rounds):
     q = torch.randn(Q, D, generator=g, device="cuda")
     if r != 21: continue
     print("round", r, Q, k, mode)
-    idx.lib.lrx_search_set_mode(mode); D2, I2 = idx.search(q, k)
-    idx.lib.lrx_search_set_mode(1); D1, I1 = idx.search(q, k)
-    idx.lib.lrx_search_set_mode(0)
+    setattr(idx, "search_flags", mode); D2, I2 = idx.search(q, k)
+    setattr(idx, "search_flags", 1); D1, I1 = idx.search(q, k)
+    setattr(idx, "search_flags", 0)
     bad = ((D1 != D2) | (I1 != I2)).any(dim=1).nonzero().flatten().tolist()
     print("bad queries", bad)
     for b in bad[:2]:

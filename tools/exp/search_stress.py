@@ -21,11 +21,11 @@ for (N, D) in [(1_000_000, 256), (600_000, 512), (3_000_001, 256), (400_000, 102
         Q = int(rng.choice([1, 2, 7, 16, 33, 64, 100, 113, 128, 129, 200, 256, 300])); k = int(rng.choice([1, 10, 100, 500, 1000, 2048]))
         q = torch.randn(Q, D, generator=g, device="cuda")
         mode = int(rng.choice([0, 2, 3]))
-        idx.lib.lrx_search_set_mode(mode)
+        setattr(idx, "search_flags", mode)
         D2, I2 = idx.search(q, k)
-        idx.lib.lrx_search_set_mode(1)
+        setattr(idx, "search_flags", 1)
         D1, I1 = idx.search(q, k)
-        idx.lib.lrx_search_set_mode(0)
+        setattr(idx, "search_flags", 0)
         if not (torch.equal(D1, D2) and torch.equal(I1, I2)):
             fails += 1
             bad = ((D1 != D2) | (I1 != I2)).any(dim=1).nonzero().flatten().tolist()
@@ -33,12 +33,12 @@ for (N, D) in [(1_000_000, 256), (600_000, 512), (3_000_001, 256), (400_000, 102
             # which side moves when the two searches are repeated?  and which one agrees with an fp64 reference?
             ref = (q[bad[:4]].double() @ idx.vectors.double().T).topk(k, dim=1)
             for m in (mode, 1, mode, 1):
-                idx.lib.lrx_search_set_mode(m)
+                setattr(idx, "search_flags", m)
                 Dx, Ix = idx.search(q, k)
                 print("   again mode", m, "== first mode-%d run:" % mode, bool(torch.equal(Dx, D2) and torch.equal(Ix, I2)), "== first mode-1 run:",
                       bool(torch.equal(Dx, D1) and torch.equal(Ix, I1)), "| ids equal to fp64 top-k for the first bad queries:",
                       [bool(torch.equal(Ix[b], ref.indices[i])) for i, b in enumerate(bad[:4])], flush=True)
-            idx.lib.lrx_search_set_mode(0)
+            setattr(idx, "search_flags", 0)
     print((N, D), "done", flush=True)
     del idx
 print("stress failures", fails)

@@ -15,12 +15,12 @@ for (N, D, Q, k) in [(300000, 256, 20, 1000), (300001, 512, 100, 1000), (280000,
         slot[s:e] = torch.nn.functional.normalize(torch.randn(e - s, D, generator=g, device="cuda"), dim=-1)
     idx.commit(N)
     q = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device="cuda"), dim=-1)
-    idx.lib.lrx_search_set_mode(2)
+    setattr(idx, "search_flags", 2)
     D2, I2 = idx.search(q, k)
     torch.cuda.synchronize()
-    idx.lib.lrx_search_set_mode(1)
+    setattr(idx, "search_flags", 1)
     D1, I1 = idx.search(q, k)
     torch.cuda.synchronize()
-    idx.lib.lrx_search_set_mode(0)
+    setattr(idx, "search_flags", 0)
     print((N, D, Q, k), "equal" if torch.equal(D1, D2) and torch.equal(I1, I2) else "DIFFERENT", flush=True)
     del idx

@@ -61,12 +61,12 @@ def main():
         N_ = int(rng.choice([300, 4097, 5000, 20000, 70001])); D = int(rng.choice([32, 64, 96, 128, 192, 256, 320, 512, 1024])); Q = int(rng.choice([1, 3, 17, 33, 100, 130, 150, 200, 256, 300])); kk = int(rng.choice([1, 5, 100, 257]))
         X = O.l2_normalize(rng.standard_normal((N_, D)).astype(np.float32)) * rng.uniform(0.2, 2.0, size=(N_, 1)).astype(np.float32)
         qq = rng.standard_normal((Q, D)).astype(np.float32)
-        idx = FlatIPIndex(D, capacity=N_); idx.shadow_bf16 = bool(rng.integers(0, 4)); idx.shadow_layout = str(rng.choice(["tiled", "tiled", "rows"])); idx.add(X)
-        idx.lib.lrx_search_set_mode(int(rng.integers(0, 4)))       # 0 auto, 1 score-matrix filter, 2 score-free filter, 3 same without the GEMM pass: same hits
+        idx = FlatIPIndex(D, capacity=N_); idx.shadow_f16 = bool(rng.integers(0, 4)); idx.add(X)
+        setattr(idx, "search_flags", int(rng.integers(0, 4)))       # 0 auto, 1 score-matrix filter, 2 score-free filter, 3 same without the GEMM pass: same hits
         Dg, Ig = idx.search(qq, kk)
-        idx.lib.lrx_search_set_mode(1)
+        setattr(idx, "search_flags", 1)
         D1, I1 = idx.search(qq, kk)
-        idx.lib.lrx_search_set_mode(0)
+        setattr(idx, "search_flags", 0)
         check("search modes", bool(torch.equal(Dg, D1) and torch.equal(Ig, I1)), (N_, D, Q, kk))
         Dg, Ig = Dg.cpu().numpy(), Ig.cpu().numpy()
         Do, Io = O.flat_ip_topk(qq, X, kk)
