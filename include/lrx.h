@@ -336,7 +336,7 @@ enum {
   LRX_SEARCH_FILTER_SCORE_FREE = 2,      /* the score-free (candidate-list) filter whenever the shard is large enough for a sample   */
   LRX_SEARCH_FILTER_SCORE_FREE_NO_GEMM = 3 /* like 2, but chunks of 129..256 queries never take the GEMM kernel for the main pass   */
 };
-size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k);
+size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags);
 int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_shadow, const float* row_bounds,
                                const float* q, int32_t n_queries, int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids,
                                void* workspace, size_t workspace_bytes, int32_t flags, void* stream);

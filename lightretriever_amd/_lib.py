@@ -54,7 +54,7 @@ SIGNATURES = {
     "lrx_sparse_compact": (_I32, [_P, _I32, _I32, _I64, _I32, _I32, _P, _P, _P, _P]),
     "lrx_hit_contributions": (_I32, [_P, _P, _I32, _I32, _I64, _I32, C.c_double, C.c_double, _P, _I64, _P]),
     "lrx_hit_union": (_I32, [_P, _P, _I32, _I32, _I64, _P, _P, _P, _P]),
-    "lrx_flat_ip_bounded_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
+    "lrx_flat_ip_bounded_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32, _I32]),
     "lrx_flat_ip_search_bounded": (_I32, [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _I32, _P]),
     "lrx_shard_commit_rows": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _P, _P]),
     "lrx_pool_norm_shard": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P]),

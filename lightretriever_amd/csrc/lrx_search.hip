@@ -2102,20 +2102,21 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   return p;
 }
 
-extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
-  // the search walks the queries in chunks of 256 (shadow) or 128 (fp32 rows), each chunk with its own plan over the same buffer; the
-  // size covers every filter choice (flags), so a workspace sized here serves any call on that shard shape
+extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags) {
+  // the search walks the queries in chunks of 256 (shadow) or 128 (fp32 rows), each chunk with its own plan over the same buffer; sized
+  // for the filter `flags` selects (the score-matrix filter of LRX_SEARCH_FILTER_MATRIX needs [min(Q, 256), rows] floats), with or
+  // without a shadow
   const int32_t nq = n_queries > 0 ? n_queries : 1;
+  const int mode = flags & 3;
   size_t need = lrx_flat_ip_workspace_bytes(n_rows, dim, nq < 128 ? nq : 128, k);   // tiny shards / few queries without shadow: plain path in chunks of 128
   for (int sh = 0; sh < 2; ++sh) {
     const int chunk = sh ? 256 : 128;
     const int sizes[2] = {nq < chunk ? nq : chunk, nq > chunk ? nq % chunk : 0};
     for (int i = 0; i < 2; ++i)
-      if (sizes[i] > 0)
-        for (int mode = 1; mode <= 3; ++mode) {
-          const size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, mode).total;
-          need = t > need ? t : need;
-        }
+      if (sizes[i] > 0) {
+        const size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, mode).total;
+        need = t > need ? t : need;
+      }
   }
   return need + 512;
 }
@@ -2128,8 +2129,8 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
   LRX_CHECK_ARG(n_rows >= 0 && n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
   LRX_CHECK_ARG((flags & ~3) == 0, "flat_ip_search_bounded: unknown flags 0x%x", flags);
   if (n_queries <= 0) return LRX_OK;
-  if (workspace_bytes < lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k)) {
-    lrx_set_error("flat_ip_search_bounded: workspace %zu B < required %zu B", workspace_bytes, lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k));
+  if (workspace_bytes < lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k, flags)) {
+    lrx_set_error("flat_ip_search_bounded: workspace %zu B < required %zu B", workspace_bytes, lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k, flags));
     return LRX_ERR_WORKSPACE;
   }
   const int mode = flags & 3;
@@ -2150,7 +2151,7 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
   for (int q0 = 0; q0 < n_queries; q0 += chunk) {
     const int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
     const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, mode);
-    if (p.total > workspace_bytes) {      // (cannot happen with a workspace sized by lrx_flat_ip_bounded_workspace_bytes)
+    if (p.total > workspace_bytes) {      // (cannot happen with a workspace sized by lrx_flat_ip_bounded_workspace_bytes for the same flags)
       lrx_set_error("flat_ip_search_bounded: chunk of %d queries needs %zu B of workspace, %zu given", nq, p.total, workspace_bytes);
       return LRX_ERR_WORKSPACE;
     }

@@ -171,7 +171,7 @@ std::tuple<at::Tensor, at::Tensor> flat_ip_topk_bounded(const at::Tensor& q, con
                 "flat_ip_topk_bounded: x_shadow must be the 1-D tiled fp16 shadow of x (whole 128-row blocks)");
   }
   at::Tensor d = at::empty({q.size(0), k}, q.options()), i = at::empty({q.size(0), k}, q.options().dtype(at::kLong));
-  const size_t wsb = lrx_flat_ip_bounded_workspace_bytes(x.size(0), (int32_t)x.size(1), (int32_t)q.size(0), (int32_t)k);
+  const size_t wsb = lrx_flat_ip_bounded_workspace_bytes(x.size(0), (int32_t)x.size(1), (int32_t)q.size(0), (int32_t)k, (int32_t)flags);
   at::Tensor ws = bytes((int64_t)wsb, q);
   lrx_check(lrx_flat_ip_search_bounded(x.data_ptr<float>(), x.size(0), x.size(0) ? x.stride(0) : x.size(1), (int32_t)x.size(1),
                                        x_shadow.has_value() ? x_shadow->data_ptr() : nullptr, row_bounds.data_ptr<float>(), q.data_ptr<float>(),

@@ -216,7 +216,8 @@ class FlatIPIndex:
         # the bounded search needs a workspace that stops growing at 256 queries; the six-product path (two_pass = False) a
         # [queries, rows] fp32 score matrix.  Either way the queries go through in chunks that keep it under max_workspace_bytes
         # (results do not depend on the chunking).
-        ws_bytes = self.lib.lrx_flat_ip_bounded_workspace_bytes if self.two_pass else self.lib.lrx_flat_ip_workspace_bytes
+        flags = int(self.search_flags)
+        ws_bytes = (lambda n, d, nq, kk: self.lib.lrx_flat_ip_bounded_workspace_bytes(n, d, nq, kk, flags)) if self.two_pass else self.lib.lrx_flat_ip_workspace_bytes
         chunk = Q
         while chunk > 1 and int(ws_bytes(self.ntotal, self.d, chunk, k)) > int(self.max_workspace_bytes):
             chunk = 256 if chunk > 256 else (128 if chunk > 128 else chunk // 2)
@@ -231,7 +232,7 @@ class FlatIPIndex:
             if self.two_pass:
                 _lib.check(self.lib.lrx_flat_ip_search_bounded(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(xb), _lib.ptr(self._bounds), _lib.ptr(qc),
                                                                qc.shape[0], k, self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws),
-                                                               self._ws.numel(), int(self.search_flags), _lib.current_stream()))
+                                                               self._ws.numel(), flags, _lib.current_stream()))
             else:
                 _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(self._bounds), _lib.ptr(qc), qc.shape[0], k,
                                                        self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))

@@ -87,7 +87,7 @@ int main(void) {
     if (memcmp(Xb, Xb2, 2 * NSH) != 0) { printf("lrx_shard_commit_rows: shadow differs from host RNE / the documented tile layout\n"); return 5; }
     if (fabsf(hb[0] / maxn - 1.f) > 1e-5f || !(hb[1] > 0.f && hb[1] < hb[0] / 1500.f)) { printf("lrx_shard_commit_rows: bounds %g %g (host max norm %g)\n", hb[0], hb[1], maxn); return 5; }
     free(Xb2); }
-  const size_t wsb = lrx_flat_ip_bounded_workspace_bytes(N, D, Q, k);
+  const size_t wsb = lrx_flat_ip_bounded_workspace_bytes(N, D, Q, k, LRX_SEARCH_FILTER_AUTO);
   CHECK(hipMalloc(&ws, wsb)); CHECK(hipMemset(ws, 0, wsb));
   float* hD = (float*)malloc(sizeof(float) * Q * k); long long* hI = (long long*)malloc(sizeof(long long) * Q * k);
   int bad = 0;

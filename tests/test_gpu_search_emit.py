@@ -94,11 +94,14 @@ def test_tiled_shadow_layout_is_the_documented_one():
 def test_workspace_stops_growing_at_256_queries():
     from lightretriever_amd import _lib
     lib = _lib.lib()
-    w = [int(lib.lrx_flat_ip_bounded_workspace_bytes(10_000_000, 256, nq, 100)) for nq in (100, 256, 1000, 7000)]
+    w = [int(lib.lrx_flat_ip_bounded_workspace_bytes(10_000_000, 256, nq, 100, 0)) for nq in (100, 256, 1000, 7000)]
     assert w[1] == w[2] == w[3] and w[0] <= w[1]
     assert w[3] < 6 << 30                                        # round 1: 280 GB of [queries, rows] scores for 7000 queries
     full = 10_000_000 * 100 * 4
-    assert int(lib.lrx_flat_ip_bounded_workspace_bytes(10_000_000, 256, 100, 100)) < 1.1 * full + (64 << 20)
+    assert int(lib.lrx_flat_ip_bounded_workspace_bytes(10_000_000, 256, 100, 100, 0)) < 1.1 * full + (64 << 20)
+    # top_k = 1000 (the reference's default): lists of 64 Ki entries, 128 MB for 256 queries -- still independent of the query count
+    w1k = [int(lib.lrx_flat_ip_bounded_workspace_bytes(1_000_000, 2048, nq, 1000, 0)) for nq in (256, 5000)]
+    assert w1k[0] == w1k[1] < 1 << 30
 
 
 def test_adversarial_fp16_rounding_midpoints(search_mode):
