@@ -727,10 +727,11 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
   // hits a wave parks in LDS: as many as the 160 KiB of the CU allow next to the q ring (one workgroup per CU).  A pass emits ~5 000 hits per
   // query, i.e. 2.4 x queries per wave: with 320 entries most waves of a 100-query pass had to flush once in mid-pass (one memory-side atomic
   // per hit, the wave waits, the workgroup waits for it at the next barrier): 630 us against 580 us for the same pass with hardly any hits
-  constexpr int WCAP_FIT = ((160 * 1024 - QB * QBYTES - QT * 64 - 1024) / (WV * 12)) / 64 * 64;
+  constexpr int WQC_BYTES = QT * 16 * 4;          // per wave: hits per query of a mid-pass flush, then the first global slot (see flush)
+  constexpr int WCAP_FIT = ((160 * 1024 - QB * QBYTES - QT * 64 - 1024 - WV * (WQC_BYTES + 16)) / (WV * 12)) / 64 * 64;
   constexpr int WCAP = WCAP_FIT > 1024 ? 1024 : WCAP_FIT;
   static_assert(WCAP >= 256, "hit lists do not fit next to the q ring");
-  constexpr int WL_BYTES = WCAP * 12 + 16;
+  constexpr int WL_BYTES = WCAP * 12 + 16 + WQC_BYTES;
   __shared__ __attribute__((aligned(1024))) char smem[QB * QBYTES + WV * WL_BYTES + QT * 16 * 4];
   float* sthr = (float*)(smem + QB * QBYTES + WV * WL_BYTES);   // the thresholds (LDS: they are needed once per block, not per k-step)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -793,14 +794,26 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
     return (const bf16x8*)(Xb + ((int64_t)b * (D / 64)) * 8192 + wave * 1024) + lane;
   };
   unsigned int wcnt = 0;                           // entries in this wave's list (wave-uniform)
-  auto flush = [&]() {                             // mid-pass, by the wave alone: one reservation per hit
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  unsigned int* wqc = (unsigned int*)((char*)wl + WCAP * 12 + 16);
+  // mid-pass flush, by the wave alone, ONE global reservation per (wave, query with hits) -- round 2 reserved per hit (memory-side atomics
+  // on ~100 addresses: fine while a pass emitted 5 k hits per query; at top_k = 1000 it emits ~26 k per query, every wave flushes in
+  // mid-pass, and the 2.6 M single-hit reservations of a 100-query pass took 3.3 ms).  LDS operations of one wave execute in order, so
+  // the phases below need no barrier: count per query (the LDS atomic's return value is the hit's rank inside the wave's batch),
+  // reserve, scatter.
+  auto flush = [&]() {
     const unsigned int tot = min(wcnt, (unsigned int)WCAP);
+    for (int t = lane; t < QT * 16; t += 64) wqc[t] = 0u;
     for (unsigned int i = lane; i < tot; i += 64) {
-      const unsigned long long w = wl[i];
       const unsigned int col = wq[i];
-      const unsigned int gp = atomicAdd(&cnt[col * CNT_STRIDE], 1u);
-      if (gp < cap) cand[(int64_t)col * cap + gp] = w;
+      wq[i] = col | (atomicAdd(&wqc[col], 1u) << 8);                 // (col < 256, rank < 1024)
+    }
+    for (int t = lane; t < QT * 16; t += 64) {
+      const unsigned int c = wqc[t];
+      if (c) wqc[t] = atomicAdd(&cnt[t * CNT_STRIDE], c);
+    }
+    for (unsigned int i = lane; i < tot; i += 64) {
+      const unsigned int e = wq[i], col = e & 255u, slot = wqc[col] + (e >> 8);
+      if (slot < cap) cand[(int64_t)col * cap + slot] = wl[i];
     }
     wcnt = 0;
   };

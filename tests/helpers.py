@@ -50,3 +50,11 @@ def load_search_ref():
             a = st[k]
             st[k] = np.frombuffer(base64.b64decode(a["b64"]), dtype=a["dtype"]).reshape(a["shape"]).copy()
     return fx
+
+
+def flat_ip_topk_fp64(q, X, k):
+    """The product's definition of the result, evaluated on the host: every inner product accumulated in fp64 and rounded ONCE to fp32, hits
+    by (score descending, row ascending).  For tests whose rows tie inside the noise of an fp32 summation (O.flat_ip_topk is a numpy sgemm)."""
+    S = (np.asarray(q, np.float64) @ np.asarray(X, np.float64).T).astype(np.float32)
+    order = np.lexsort((np.broadcast_to(np.arange(S.shape[1]), S.shape), -S), axis=-1)[:, :k]
+    return np.take_along_axis(S, order, axis=1), order

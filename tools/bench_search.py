@@ -35,7 +35,7 @@ def main():
             samp = torch.arange(0, nb, ss, device="cuda").repeat_interleave(128) * 128 + torch.arange(128, device="cuda").repeat((nb + ss - 1) // ss)
             samp = samp[samp < N]
             for qi in range(4):
-                qb = q[qi].to(torch.bfloat16)
+                qb = q[qi].to(torch.float16)
                 sc = (xb @ qb).float()
                 eps = float((q[qi] - qb.float()).norm() * idx._bounds[0] + qb.float().norm() * (idx._bounds[1] + (D + 32) * 2.0 ** -23 * idx._bounds[0]))
                 tp = float(sc[samp].topk(k).values[-1]); kth = float(sc.topk(k).values[-1])
