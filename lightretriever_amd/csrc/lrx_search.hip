@@ -919,7 +919,11 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
         }
       ovf = 0;
     }
-    if (wcnt > WCAP - 96) flush();                 // (wave-uniform)
+    // (wave-uniform.)  Flushed at half full: a step of RT blocks adds ~8 hits per wave at k = 100 but ~80 at the reference's top_k = 1000 (~150 at
+    // 2048), and a hit that finds the list full flags its query for the exact fallback -- with the 96-entry margin of round 2 every
+    // 100-query pass at k = 1000 sent queries there (2.9 ms of six-product pass + select for a 0.7 ms filter pass)
+    // (Tried: all waves flushing at the same, host-scheduled steps so that the stalls coincide: 670 -> 681 us at k = 1000, not kept.)
+    if (wcnt > WCAP / 2) flush();
   }
   // ---- final flush, by the workgroup: one list reservation per (workgroup, query) instead of one per hit.  The ~5e5 hits of a pass would
   //      otherwise reach the ~100 list counters at the same time, at the end of the pass, and the memory-side atomics of one address
@@ -2024,7 +2028,8 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
   __syncthreads();
   if (tot <= (int)blockDim.x) {
     // the usual case, a few hundred band rows: rank by counting (the packed (score, row) words are distinct, so the ranks are the sorted
-    // positions; every thread walks the list with broadcast LDS reads -- no barrier-separated sort stages: 14 -> 12 us)
+    // positions; every thread walks the list with broadcast LDS reads -- no barrier-separated sort stages: 14 -> 12 us).  (Measured for the
+    // ~1200 entries of top_k = 1000 with two entries per thread: 52 us against 33 for the 2048-entry bitonic sort -- not extended.)
     if (tid < tot) {
       const unsigned long long me = s_cand[tid];
       int r = 0;
