@@ -20,6 +20,7 @@
 //  3. k_merge_topk: merge of R per-shard [Q,k] lists (after the RCCL all-gather) with the same ordering rule.
 #include "lrx_common.h"
 #include <float.h>
+#include <stdlib.h>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -1202,7 +1203,10 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
 #endif
       const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31);
       const int n_cu = lrx_cu_count();
-      const bool two_blocks = !emit && fm.bmode == 1 && nwg < (1ll << 31);
+      // sample pass: two blocks per workgroup (the q slice is fetched once per 256 rows) once there are more sample blocks than CUs; a
+      // sample that fits the chip in one round runs one block per workgroup -- its time is the time of ONE workgroup's blocks through
+      // one CU (~20 us per 512-KiB block), not a throughput question (125 k-row shard: 34 -> ~20 us, 1M x 2048 at ss = 32: 52 -> ~27 us)
+      const bool two_blocks = !emit && fm.bmode == 1 && nwg < (1ll << 31) && nwg > lrx_cu_count();
       // sample pass of a large shard (more than two block pairs per CU): persistent workgroups
       const bool persistent_store = two_blocks && fm.group_max && gate == nullptr && sp != nullptr && bp != nullptr && qt <= 8 && (dim / 64) % XPF == 0 &&
                                     (nwg + 1) / 2 > 2 * (int64_t)n_cu;
@@ -2077,6 +2081,9 @@ static size_t ints_before_cnt(int nq) { return ((size_t)nq + 1 + 63) & ~(size_t)
 // (1/20 of the shard goes through the sample pass); larger k: the capacity grows with k (64 k, a power of two) so that the stride stays
 // at 20 -- round 2 kept 16 Ki entries for every k, which at the reference's default top_k = 1000 meant ss = 2: half of the shard went
 // through the sample pass and its [Q, N/2] score matrix.
+#ifndef SAMPLE_SS_MAX
+#define SAMPLE_SS_MAX 32   // (20 in round 2: the bf16 band doubled the list entries per sample row)
+#endif
 static unsigned int cand_cap_for(int32_t k) {
   unsigned int cap = CAND_CAP_MIN;
   while (cap < 64u * (unsigned int)(k > 0 ? k : 1)) cap <<= 1;
@@ -2094,8 +2101,13 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   p.nblk_ld = (p.nblk + 3) & ~(int64_t)3;
   p.cap = cand_cap_for(k);
   int ss = (int)(p.cap / (3u * (unsigned int)(k > 0 ? k : 1)));
-  ss = ss > 20 ? 20 : (ss < 2 ? 2 : ss);
+  static int ss_max = 0;                                   // (LRX_SS_MAX: A/B runs of the sample stride on one box)
+  if (ss_max == 0) { const char* e = getenv("LRX_SS_MAX"); ss_max = e && atoi(e) >= 2 ? atoi(e) : SAMPLE_SS_MAX; }
   const int64_t nwg = lrx_cdiv(n_rows > 0 ? n_rows : 1, p.rb);
+  // stride 32 where the sample still fills the chip (1M x 2048: 0.733 -> 0.716 ms per 100-query search on one box); smaller shards keep 20 --
+  // their sample is one block per workgroup either way and the weaker threshold costs more in the main pass (125 k rows: 0.194 vs 0.200 ms)
+  const int ss_cap = nwg >= 4096 ? ss_max : (ss_max < 20 ? ss_max : 20);
+  ss = ss > ss_cap ? ss_cap : (ss < 2 ? 2 : ss);
   while (ss > 2 && (lrx_cdiv(nwg, ss) - 1) * p.rb < 2 * (int64_t)k) ss >>= 1;
   const int64_t nsamp = lrx_cdiv(nwg, ss);
   const bool feasible = (nsamp - 1) * p.rb >= 2 * (int64_t)k && nwg - nsamp >= 1 && dim % 4 == 0 && (shadow || nq > 16 * (SPLIT_MIN_QT - 1));

@@ -223,6 +223,11 @@ class FlatIPIndex:
             chunk = 256 if chunk > 256 else (128 if chunk > 128 else chunk // 2)
         need = int(ws_bytes(self.ntotal, self.d, chunk, k))
         if self._ws is None or self._ws.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                # an allocation made under HIP-graph capture lives in the graph's private pool: the index would keep pointing at memory that
+                # goes back to the allocator with the graph (the memory-access fault of round 2's capture probe)
+                raise _lib.LrxError("FlatIPIndex.search under graph capture: the search workspace must exist before the capture starts -- "
+                                    "run one eager search with the same number of queries and k first")
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         ldx = self._x.stride(0) if self._x.shape[0] else self.d

@@ -461,6 +461,51 @@ def test_search_on_a_side_stream_equals_default_stream(search_mode):
     torch.cuda.current_stream().wait_stream(side)
 
 
+@pytest.mark.parametrize("N,D,Q,k,two_pass", [(200000, 256, 100, 100, True), (40000, 1024, 200, 10, True), (30000, 128, 48, 1000, True), (30000, 64, 20, 10, False)])
+def test_search_captured_in_a_hip_graph_replays_bit_identically(N, D, Q, k, two_pass):
+    """VERDICT r2 item 7.  The library never allocates and never synchronises, so a search is capturable: a torch.cuda.graph of
+    FlatIPIndex.search replays the eager result bit for bit, also with new queries written into the captured input buffer (score-free chain,
+    GEMM main pass for 129..256 queries, k = 1000, plain path).  The one allocation on the way is the index's lazily sized workspace: made
+    under capture it would belong to the graph's private pool -- search() refuses that (the cause of round 2's memory-access fault:
+    tools/exp/graph_probe.py shows the workspace address handed out again once the graph is gone)."""
+    from lightretriever_amd import FlatIPIndex, _lib
+    g = torch.Generator(device="cuda").manual_seed(N + Q)
+    idx = FlatIPIndex(D, capacity=N)
+    idx.two_pass = two_pass
+    slot = idx.append_slot(N)
+    slot.copy_(torch.nn.functional.normalize(torch.randn(N, D, generator=g, device="cuda"), dim=-1))
+    idx.commit(N)
+    q = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device="cuda"), dim=-1)
+    cold = torch.cuda.CUDAGraph()
+    with pytest.raises(_lib.LrxError, match="workspace must exist"):
+        with torch.cuda.graph(cold):                                  # first search of this shape under capture: refused, nothing launched
+            idx.search(q, k)
+    del cold
+    De, Ie = idx.search(q, k)
+    De, Ie = De.clone(), Ie.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        idx.search(q, k)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        Dg, Ig = idx.search(q, k)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(Ig, Ie) and torch.equal(Dg, De)
+    q2 = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device="cuda"), dim=-1)
+    D2, I2 = idx.search(q2, k)
+    D2, I2 = D2.clone(), I2.clone()
+    q.copy_(q2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(Ig, I2) and torch.equal(Dg, D2)
+    check_against_oracle(Dg, Ig, q2.cpu().numpy(), idx.vectors.cpu().numpy(), k)
+
+
 @pytest.mark.parametrize("N,D,Q,k", [(50000, 128, 100, 10), (33001, 2048, 300, 5), (20011, 64, 1, 50), (70000, 1024, 256, 100), (9000, 192, 40, 7),
                                      # N mod 256 in (0, 128]: a score-matrix launch covers one 128-row block more than the tiled shadow holds
                                      (4200, 64, 40, 5), (70001, 128, 3, 20)])
