@@ -157,7 +157,7 @@ def cpu_baseline(cfg, seq_len, topk, dim):
                     "docs_timed": N0, "seconds_measured": round(cfg0_run_s, 2), "encode_seconds": round(enc0_s, 2),
                     "search_and_merge_seconds": round(cfg0_run_s - enc0_s, 3), "docs_per_s": round(N0 / enc0_s, 2),
                     "seconds_scaled_to_1000_docs": round(cfg0_run_s - enc0_s + enc0_s * 1000 / N0, 1),
-                    "scaling": "the encode (> 99 % of the time) is linear in the document count: 1000 / %d x the measured encode time + the measured search" % N0},
+                    "scaling": f"the encode (more than 99 percent of the time) is linear in the document count: 1000 / {N0} x the measured encode time + the measured search"},
         "search": {"value": round(nq / srch_s, 2), "unit": "queries/s", "kind": "port", "cores": cores,
                    "sample": f"oracle flat_ip_topk (numpy sgemm + lexsort) Q={nq}, k={topk} over {n_sample} x {dim} fp32 rows "
                              f"({srch_s:.2f}s); per-query cost scales linearly with rows",
@@ -529,9 +529,21 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 Dgr, Igr = index.search(qg, args.topk)
-            g_ms, g_med = time_search(graph.replay, n_pass)
+            def back_to_back(fn, n):                 # one event pair around n calls queued without a gap: what a serving loop sees
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / n
+            g_ms = back_to_back(graph.replay, 2 * n_pass)
+            e_ms = back_to_back(lambda: index.search(qg, args.topk), 2 * n_pass)
             De_, Ie_ = index.search(qg, args.topk)
-            search["graph_replay"] = {"ms": round(g_ms, 4), "ms_median": round(g_med, 4), "bit_identical_to_eager": bool(torch.equal(Dgr, De_) and torch.equal(Igr, Ie_)),
+            search["graph_replay"] = {"ms_back_to_back": round(g_ms, 4), "eager_ms_back_to_back": round(e_ms, 4), "calls": 2 * n_pass,
+                                      "bit_identical_to_eager": bool(torch.equal(Dgr, De_) and torch.equal(Igr, Ie_)),
                                       "roofline_frac": round(alg_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
             del graph
         except Exception as e:  # noqa: BLE001
