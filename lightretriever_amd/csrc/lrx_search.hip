@@ -2247,6 +2247,9 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       if (rc != LRX_OK) return rc;
       // parts per query: the 1024-thread workgroups of the refine step run one per CU, so REF_SPLIT x nq of them beyond the CU count take
       // a second round of ~40 us each (Q = 100: 400 workgroups, 82 us) -- fewer, larger parts then finish sooner
+      // (Round 3, measured and not kept: with the narrow fp16 band (~130 rows at k = 100) ONE workgroup per query that also sorts and writes
+      // the result, no merge launch: 0.723 / 0.739 vs 0.715 / 0.731 ms on the same box -- the serial select + rescore of one workgroup costs
+      // more than the merge launch saves.)
       nsplit = (int64_t)nq * REF_SPLIT <= lrx_cu_count() ? REF_SPLIT : ((int64_t)nq * 2 <= lrx_cu_count() ? 2 : 1);
       hipLaunchKernelGGL(k_refine_band, dim3(nq, nsplit), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
                          (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt, nsplit, p.cap);
