@@ -165,8 +165,8 @@ def cpu_baseline(cfg, seq_len, topk, dim):
     }
 
 
-PMC_SUMMARY = os.environ.get("LRX_PMC_SUMMARY", "profiles/r02_pmc_summary.json")   # offline rocprofv3 --pmc passes (tools/pmc_traffic.sh)
-PMC_MFMA = os.environ.get("LRX_PMC_MFMA", "profiles/r02_pmc_mfma.json")
+PMC_SUMMARY = os.environ.get("LRX_PMC_SUMMARY", "profiles/r03_pmc_summary.json")   # offline rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+PMC_MFMA = os.environ.get("LRX_PMC_MFMA", "profiles/r03_pmc_mfma.json")
 
 
 def git_blob_sha(rel_path):
@@ -204,7 +204,7 @@ def pmc_mfma(kernel_key):
     """(mfma busy fraction, effective clock GHz) of a kernel from the committed PMC pass (tools/pmc_mfma.sh) or (None, None)."""
     try:
         d = json.load(open(os.path.join(ROOT, PMC_MFMA)))[kernel_key]
-        return d["mfma_busy_frac"], d["effective_clock_GHz"]
+        return d.get("mfma_busy_frac", d.get("mfma_busy_over_cu_busy_x4simd")), d["effective_clock_GHz"]
     except (OSError, KeyError, ValueError):
         return None, None
 
