@@ -36,6 +36,16 @@ def test_encode_packed_op_equals_ctypes_path_and_oracle(lrx):
     mrl = torch.empty(len(lens), 64, device="cuda")
     lrx.encode_packed(tid, tcu, max(lens), enc.handle, mrl, 64, True)
     assert torch.equal(mrl, enc.encode_packed(tid, tcu, max(lens), out_dim=64))
+    # `out` = committed rows of an index shard -- the op takes the shard's shadow + bounds like the ctypes path does by itself, so the
+    # rows' fp16 shadow and the bounds follow an in-place re-encode (without them the caller must run shard_commit_rows afterwards)
+    from lightretriever_amd import FlatIPIndex
+    idx = FlatIPIndex(256, capacity=64)
+    idx.add(torch.randn(10, 256, device="cuda") * 0.01)
+    idx._bounds.zero_()
+    lrx.encode_packed(tid, tcu, max(lens), enc.handle, idx._x[3:3 + len(lens)], 0, True, idx._xb, 3, idx._bounds)
+    assert torch.equal(idx._x[3:8], ref) and torch.equal(idx.shadow_rows()[3:8], ref.to(torch.float16)) and 1.0 <= float(idx._bounds[0]) < 1.00001
+    with pytest.raises(RuntimeError, match="tiled"):
+        lrx.encode_packed(tid, tcu, max(lens), enc.handle, idx._x[3:8], 0, True, idx._xb.view(-1, 256), 3, idx._bounds)      # not the 1-D tiled shadow
     # errors surface as RuntimeError with liblrx's message
     with pytest.raises(RuntimeError, match="liblrx error|must be"):
         lrx.encode_packed(tid.long(), tcu, max(lens), enc.handle, out)
