@@ -237,7 +237,7 @@ def _hf_model_for(cfg):
 FULL_DEPTH_MARGINS = {}     # preset -> {variant: max (1 - cos)}; printed by the last case (pytest -s) and by tools/parity_margin.py --all
 
 
-@pytest.mark.parametrize("preset", ["llama31_8b", "qwen25_7b", "llama32_3b", "qwen25_3b", "qwen25_1_5b"])
+@pytest.mark.parametrize("preset", ["llama31_8b", "qwen25_7b", "llama32_3b", "qwen25_3b", "qwen25_1_5b", "llama32_1b"])
 def test_full_depth_hf_parity(preset):
     """every released backbone at its REAL depth (32 / 28 / 28 / 36 / 28 layers; BASELINE configs 2-4 are the 32-layer
     Llama-3.1-8B), random-init at the real config, documents of 512 / 1 / 129 / ... tokens, against the HF transformers fp32 model on the
@@ -265,17 +265,18 @@ def test_full_depth_hf_parity(preset):
     h = torch.stack(hs)
     ref, ref256 = torch.nn.functional.normalize(h, dim=-1), torch.nn.functional.normalize(h[:, :256], dim=-1)
     m = {}
-    assert enc.precise                                                   # >= 20 layers: fp32 residual stream, exact weights (encoder.PRECISE_FROM_LAYERS)
-    out = enc.encode_packed(ids, cu, 512)
+    assert enc.precise == (cfg.num_layers >= 20)                         # >= 20 layers: fp32 residual stream, exact weights (encoder.PRECISE_FROM_LAYERS);
+    out = enc.encode_packed(ids, cu, 512)                                # the 16-layer Llama-3.2-1B (the headline model) keeps the bf16 stream
     assert torch.equal(out, enc.encode_packed(ids, cu, 512))
     per_doc = (1 - (ref * out).sum(-1)).tolist()
     m["precise"] = max(per_doc)
     m["precise_mrl256"] = (1 - (ref256 * enc.encode_packed(ids, cu, 512, out_dim=256)).sum(-1)).max().item()
     del enc
     torch.cuda.empty_cache()
-    # for the record (not asserted): the bf16 residual stream with folded norm weights -- the 16-layer headline configuration -- at this depth
-    enc_b = LrxEncoder(dataclasses.replace(cfg, precise_stream=False), sd)
-    m["bf16_stream_folded"] = (1 - (ref * enc_b.encode_packed(ids, cu, 512)).sum(-1)).max().item()
+    # for the record (not asserted): the other stream mode at this depth (deep models: the bf16 stream with folded norm weights, i.e. the
+    # headline configuration; the 1B: the precise stream)
+    enc_b = LrxEncoder(dataclasses.replace(cfg, precise_stream=not (cfg.num_layers >= 20)), sd)
+    m["bf16_stream_folded" if cfg.num_layers >= 20 else "precise_stream_for_comparison"] = (1 - (ref * enc_b.encode_packed(ids, cu, 512)).sum(-1)).max().item()
     del enc_b, sd
     torch.cuda.empty_cache()
     FULL_DEPTH_MARGINS[preset] = m
