@@ -41,7 +41,8 @@ def main():
             got = ops.gemm_bf16_nt(At, Bi, epilogue=2).float(); want = (torch.nn.functional.silu(g) * u).to(torch.bfloat16).float()
         tol = 2.0 ** -7 * want.abs() + 2.0 ** -7 * ref.abs().max() * 0.02 + 1e-3
         bad = ((got - want).abs() > tol).float().mean().item()
-        check("gemm", bad < 2e-3 and got.shape == want.shape, (M, N, K, epi, bad))
+        # (a rounding-boundary flip of the bf16 intermediate of the residual epilogue is worth one element: with M = 1 a single one is > 2e-3 of the row)
+        check("gemm", (bad < 2e-3 or bad * got.numel() <= 2.5) and got.shape == want.shape, (M, N, K, epi, bad))
         # ---- attention
         d = int(rng.choice([64, 128])); nkv = int(rng.choice([1, 2, 4])); grp = int(rng.choice([1, 2, 4, 6, 7, 8])); nq = nkv * grp
         lens = [int(x) for x in rng.integers(1, 300, size=int(rng.integers(1, 6)))]
