@@ -446,6 +446,48 @@ def test_precise_stream_encoder_is_closer_to_fp32_than_the_bf16_stream(name):
     assert min_cos(out[True], out[False]) > 0.999
 
 
+@pytest.mark.parametrize("name", ["llama_small_d64", "qwen2_small"])
+def test_precise_stream_covers_every_encode_entry_point(name):
+    """The fp32 residual stream through the other users of the layer loop: lrx_encode_packed_sparse (dense rows equal lrx_encode_packed's, sparse
+    rows track the bf16-stream ones), lrx_encode_prefixed (shared prefix == the same sequences encoded in full), ragged batches with a
+    one-token sequence, and a Qwen-style model (q|k|v bias in rotary-pair order)."""
+    from dataclasses import asdict, replace
+    from helpers import load_model_golden, min_cos
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    if name == "qwen2_small":
+        cfg_o = O.EncoderConfig(vocab_size=300, hidden_size=256, num_layers=3, num_q_heads=2, num_kv_heads=1, head_dim=128, intermediate_size=320,
+                                rms_eps=1e-6, rope_theta=1e6, rope_type="default", qkv_bias=True, max_positions=256)
+        w = O.random_weights(cfg_o, seed=9, std=0.05)
+        rng = np.random.default_rng(3)
+        lens = [70, 1, 33, 128, 5]
+        ids = rng.integers(0, 300, size=sum(lens)).astype(np.int32)
+        cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        max_len = max(lens)
+    else:
+        cfg_o, w, _, ids, cu, max_len = load_model_golden(name)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    tid, tcu = torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda()
+    want = O.encode_passage(cfg_o, w, ids, cu, bf16=False)
+    encs = {p: LrxEncoder(replace(EncoderConfig(**asdict(cfg_o)), precise_stream=p), sd) for p in (False, True)}
+    out = {p: e.encode_packed(tid, tcu, max_len) for p, e in encs.items()}
+    assert 1 - min_cos(out[True].cpu().numpy(), want) <= max(1e-4, 0.8 * (1 - min_cos(out[False].cpu().numpy(), want)))
+    dense, sparse = encs[True].encode_packed_sparse(tid, tcu, max_len)
+    assert torch.allclose(dense, out[True], atol=1e-6)                              # (pooled tail vs full last layer: same rows)
+    _, sparse_b = encs[False].encode_packed_sparse(tid, tcu, max_len)
+    nz = (sparse > 0) | (sparse_b > 0)
+    assert (sparse[nz] - sparse_b[nz]).abs().max() < 0.15 and ((sparse > 0) == (sparse_b > 0)).float().mean() > 0.99
+    # shared-prefix encode in the precise mode == the same sequences encoded in full
+    B, P1, S2 = 9, 6, 2
+    rng = np.random.default_rng(1)
+    prefix = torch.from_numpy(rng.integers(0, cfg_o.vocab_size, size=P1).astype(np.int32)).cuda()
+    suffix = torch.from_numpy(rng.integers(0, cfg_o.vocab_size, size=(B, S2)).astype(np.int32)).cuda()
+    fast = encs[True].encode_prefixed(prefix, suffix)
+    full_ids = torch.cat([torch.cat([prefix, suffix[b]]) for b in range(B)]).contiguous()
+    full_cu = (torch.arange(B + 1, dtype=torch.int32, device="cuda") * (P1 + S2)).contiguous()
+    full = encs[True].encode_packed(full_ids, full_cu, P1 + S2, normalize=False)
+    assert min_cos(fast.cpu().numpy(), full.cpu().numpy()) > 1 - 2e-4 and torch.allclose(fast.norm(dim=1), full.norm(dim=1), rtol=5e-3)
+
+
 def test_folded_and_unfolded_encoders_agree_and_both_match_fp32():
     """Same checkpoint through both pipelines: pooled embeddings within bf16 noise of each other, and the folded one is not
     further from the fp32 oracle than the HF rounding order is."""
