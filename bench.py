@@ -311,6 +311,9 @@ def extra_legs(args, dev, headline_index):
     # ---- BASELINE configs[2] / configs[3] index shape (8B width) and configs[4] (MRL 256, 10M rows) on one GPU
     legs["config2_search_1Mx4096"] = search_leg(1_000_000, 4096, 100, 100, dev, 20, seed=51)
     legs["config4_search_10Mx256"] = search_leg(10_000_000, 256, 100, 100, dev, 20, seed=61)
+    # ---- what ONE rank of the 8-GPU configurations holds (10M rows row-sharded 8 ways): configs[3] 1.25M x 4096, configs[4] 1.25M x 256
+    legs["config3_per_rank_shard_1250kx4096"] = search_leg(1_250_000, 4096, 100, 100, dev, 20, seed=71)
+    legs["config4_per_rank_shard_1250kx256"] = search_leg(1_250_000, 256, 100, 100, dev, 20, seed=81)
     # ---- BASELINE configs[2]: Llama-3.1-8B dims, 128 documents x seq_len per step
     cfg8 = EncoderConfig.llama31_8b(args.seq_len)
     enc8 = LrxEncoder.random_init(cfg8, seed=0, device=dev)
