@@ -1730,13 +1730,13 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Bounded two-pass search (rows with known bounds R >= max |x_row| and E >= max |x_row - bf16(x_row)|): the same exact top-k at close
-// to ONE pass over the bf16 shadow of the shard, without ever writing a [queries, rows] score matrix.
-//   filter  s~ = bf16(q) . bf16(x) with ONE bf16 MFMA product (instead of six), fp32 accumulation.  With q~ = bf16(q), x~ = bf16(x):
+// Bounded two-pass search (rows with known bounds R >= max |x_row| and E >= max |x_row - fp16(x_row)|): the same exact top-k at close
+// to ONE pass over the fp16 shadow of the shard, without ever writing a [queries, rows] score matrix.
+//   filter  s~ = fp16(q) . fp16(x) with ONE f16 MFMA product (instead of six bf16 ones), fp32 accumulation.  With q~ = fp16(q), x~ = fp16(x):
 //           s - s~ = (q - q~).x + q~.(x - x~) + (accumulation error), so by Cauchy-Schwarz
 //             |s - s~| <= eps(q) = |q - q~| R + |q~| E + (D + 32) 2^-23 |q~| R          (query_eps_block; |q - q~| and |q~| are computed
-//           from the actual query, E from the actual rows at commit: ~0.0036 |q| R for typical data; the worst case of two roundings
-//           with unit roundoff 2^-8 each is 0.0078 |q| R).
+//           from the actual query, E from the actual rows at commit: ~7e-4 |q| R for normalised rows at D = 2048 -- a third of it the
+//           accumulation term; the bf16 filter of round 2 had 3.7e-3).
 //   sample  every ss-th 128-row block is scored first, into a small compact matrix; T' = its k-th largest score is a lower bound of
 //           kth~, the k-th largest filter score of the whole shard (k sample rows reach it).
 //   main    all other blocks; the epilogue keeps only rows with s~ >= T' - 2 eps, appended to a per-query candidate list (~1e-3 of the
@@ -1744,7 +1744,7 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
 //           largest of (s~ - eps), so its s~ >= kth~ - 2 eps >= T' - 2 eps.
 //   refine  kth~ = k-th largest s~ of the list (exact: the list holds every row >= T' - 2 eps), the rows with s~ >= kth~ - 2 eps
 //           are rescored exactly from the fp32 rows (fp64 accumulation, rounded once to fp32) by REF_SPLIT workgroups per query and
-//           sorted (score desc, row asc).  Typical band content at 1M x 2048 normalised rows: ~300 rows.
+//           sorted (score desc, row asc).  Typical band content at 1M x 2048 normalised rows, k = 100: ~130 rows.
 //   fallback: a query whose list or band overflows (near-duplicate corpora) raises a device flag; the six-product pass + select +
 //           rescore are always enqueued behind it, gated on that flag (they return at once when it is 0), and overwrite only the
 //           flagged queries.  No host synchronisation anywhere.

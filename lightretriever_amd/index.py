@@ -15,7 +15,7 @@ _SHARDS = weakref.WeakValueDictionary()   # fp32 storage pointer -> FlatIPIndex 
 
 def shard_of(out: torch.Tensor):
     """(index, first_row) when `out` is a view of whole rows of a live FlatIPIndex's fp32 storage, else None.  LrxEncoder.encode_packed
-    uses it to hand the shard's bf16 shadow rows and bounds to the encoder's last kernel (lrx_encode_packed_shard)."""
+    uses it to hand the shard's fp16 shadow rows and bounds to the encoder's last kernel (lrx_encode_packed_shard)."""
     if not _SHARDS or out.dtype != torch.float32 or out.ndim != 2:
         return None
     idx = _SHARDS.get(out.untyped_storage().data_ptr())
