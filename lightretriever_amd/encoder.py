@@ -18,7 +18,12 @@ import torch
 from . import _lib
 
 
-PRECISE_FROM_LAYERS = 20    # measured (tests/test_gpu_encoder.py::test_full_depth_hf_parity): 16 layers keep 1 - cos < 4e-4 on the bf16 stream
+# When the fp32 residual stream is switched on by default.  Measured at full depth against the HF fp32 model (random-init weights,
+# tests/test_gpu_encoder.py::test_full_depth_hf_parity, profiles/r03_full_depth_parity.jsonl), 1 - cos on the bf16 stream grows like
+# ~9e-9 x layers x hidden_size: 1B (16 x 2048) 2.8e-4, Qwen2.5-1.5B (28 x 1536) 4.1e-4, Qwen2.5-3B (36 x 2048) 7.7e-4, Llama-3.2-3B
+# (28 x 3072) 6.8e-4, Qwen2.5-7B (28 x 3584) 8.3e-4, Llama-3.1-8B (32 x 4096) 1.28e-3.  Above layers x hidden = 60 000 (predicted 5.4e-4,
+# less than a factor two from the 1e-3 budget) the precise stream runs (1.2e-4 ... 6.2e-4 on the same models, 2-3 % slower).
+PRECISE_FROM_LAYERS_X_HIDDEN = 60_000
 
 
 @dataclass
@@ -40,12 +45,14 @@ class EncoderConfig:
     qkv_bias: bool = False
     max_positions: int = 512
     fold_norm: bool = True      # RMSNorm weights folded into the next projection at load time (lrx_encoder_config.norm_folded)
-    # fp32 residual stream + exact weights, the norm weight on the bf16 activation operand (lrx_encoder_config.precise_stream): None = from
-    # PRECISE_FROM_LAYERS layers on (deep backbones spend the 1e-3 cosine budget on the bf16 stream and the folded weights otherwise)
+    # fp32 residual stream + exact weights, the norm weight on the bf16 activation operand (lrx_encoder_config.precise_stream): None = by
+    # model size (PRECISE_FROM_LAYERS_X_HIDDEN: deep, wide backbones spend the 1e-3 cosine budget on the bf16 stream and the folded weights)
     precise_stream: Optional[bool] = None
 
     def use_precise_stream(self) -> bool:
-        return self.num_layers >= PRECISE_FROM_LAYERS if self.precise_stream is None else bool(self.precise_stream)
+        if self.precise_stream is not None:
+            return bool(self.precise_stream)
+        return self.num_layers * self.hidden_size >= PRECISE_FROM_LAYERS_X_HIDDEN
 
     @staticmethod
     def llama32_1b(max_positions: int = 512) -> "EncoderConfig":
