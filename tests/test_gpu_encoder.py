@@ -282,7 +282,7 @@ def test_full_depth_hf_parity(preset):
     del enc_b, sd
     torch.cuda.empty_cache()
     FULL_DEPTH_MARGINS[preset] = m
-    print("full-depth parity %s (%d layers): %s" % (preset, cfg.num_layers, {k: "%.2e" % v for k, v in m.items()}))
+    print("full-depth parity %s (%d layers): %s" % (preset, cfg.num_layers, {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in m.items()}))
     import json, os
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):                                   # (the margins DESIGN.md section 3 quotes come from this file)
