@@ -250,7 +250,7 @@ def search_leg(n_rows, dim, nq, k, dev, passes, index=None, seed=21):
         index, _ = synthetic_index(n_rows, dim, dev, seed)
     q = torch.nn.functional.normalize(torch.randn(nq, dim, generator=g, device=dev), dim=-1)
     mean_ms, med_ms = time_search(lambda: index.search(q, k), passes)
-    out = {"workload": "exact top-%d of %d queries over %d x %d fp32 rows (+ tiled bf16 shadow), one GPU, HIP events around lrx_flat_ip_search_bounded"
+    out = {"workload": "exact top-%d of %d queries over %d x %d fp32 rows (+ tiled fp16 shadow), one GPU, HIP events around lrx_flat_ip_search_bounded"
                        % (k, nq, n_rows, dim),
            "ms": round(mean_ms, 4), "ms_median": round(med_ms, 4), "passes": passes, "queries_per_s": round(nq / (mean_ms * 1e-3), 1),
            "roofline": hbm_roofline(n_rows, dim, nq, k, mean_ms)}
@@ -501,7 +501,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         srch_s = float(t.item())
         local_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(n_pass)) / n_pass
-        # the filter pass streams the bf16 shadow of the shard (2 B/element); the exact rescoring of the few hundred band rows per
+        # the filter pass streams the fp16 shadow of the shard (2 B/element); the exact rescoring of the few hundred band rows per
         # query comes on top (measured: `traffic`) -- the fp32 rows themselves are never streamed
         shadow = index._xb is not None and index.two_pass
         alg_bytes = shard_rows * D * (2 if shadow else 4) + args.queries * D * 4 + args.queries * args.topk * 12
@@ -514,7 +514,7 @@ def main():
                          "frac": round(alg_bytes / (local_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "traffic": pmc_search_traffic() if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100 and D == 2048) else None,
                          "algorithmic_bytes": alg_bytes, "traffic_source": {"file": PMC_SUMMARY, "git_blob": git_blob_sha(PMC_SUMMARY), "note": "offline rocprofv3 --pmc passes, not measured by this run"},
-                         "kernel": "two-pass exact search without a score matrix: k_filter_xreg / k_filter_xreg_emit (single-product filter over the tiled bf16 shadow of the shard, corpus fragments streamed through registers, HBM-bound; a strided 1/20 sample first -> k_sample_threshold, then persistent workgroups over the rest, emitting only rows above the threshold) + k_refine_band/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
+                         "kernel": "two-pass exact search without a score matrix: k_filter_xreg / k_filter_xreg_emit (single-product filter over the tiled fp16 shadow of the shard, corpus fragments streamed through registers, HBM-bound; a strided 1/20 sample first -> k_sample_threshold, then persistent workgroups over the rest, emitting only rows above the threshold) + k_refine_band/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
                          "fp32_equiv_tflops": round(2.0 * args.queries * D * shard_rows / (local_ms * 1e-3) / 1e12, 2),
                          "fp32_mfma_peak_for_reference": PEAK_F32_MFMA_TFLOPS},
         }

@@ -278,7 +278,7 @@ def test_shard_commit_rows_kernel_shadow_and_bounds():
 
 
 def test_encoder_writes_shadow_and_bounds_of_the_slot_it_fills():
-    """lrx_encode_packed_shard: rows encoded into a FlatIPIndex slot arrive with their bf16 shadow and the shard bounds -- commit() has
+    """lrx_encode_packed_shard: rows encoded into a FlatIPIndex slot arrive with their fp16 shadow and the shard bounds -- commit() has
     nothing left to do (no second pass over the rows), and searching them needs no refresh."""
     from dataclasses import asdict
     from lightretriever_amd import EncoderConfig, FlatIPIndex, LrxEncoder
@@ -421,7 +421,7 @@ def test_baseline_index_shapes_properties(N, D, search_mode):
 
 @pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.get_device_properties(0).total_memory < 270 << 30, reason="needs one 288-GB GPU")
 def test_config3_10m_x_4096_single_gpu_properties():
-    """BASELINE config 3's whole index on ONE GPU: 164 GB of fp32 rows + 82 GB bf16 shadow + < 6 GB of search workspace.  Deselect
+    """BASELINE config 3's whole index on ONE GPU: 164 GB of fp32 rows + 82 GB fp16 shadow + < 6 GB of search workspace.  Deselect
     with -k 'not config3' when the box is short on time: filling the rows takes about a minute."""
     from lightretriever_amd import FlatIPIndex
     N, D, Q, k = 10_000_000, 4096, 100, 100
