@@ -280,12 +280,18 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     // ---- search filter epilogue: nothing is stored per (row, query).  Lane (fr, fq) of wave (wr, wc) holds rows h*128 + wr*64 +
     //      mi*16 + fr and query columns hp*128 + wc*32 + ni*16 + fq*4 + r.  Hits (~5e-3 of the scores) first go to a per-wave list in
     //      the idle LDS (an LDS atomic per 16x16 sub-tile that has any: ~100 cycles, against ~2 us for a global one, and this
-    //      workgroup has the CU to itself), then the wave reserves the global slots of all its hits with ONE round of atomics.
+    //      workgroup has the CU to itself).  A parked hit also takes its rank among the WORKGROUP's hits of its query (a second LDS
+    //      atomic), so the global slots of a query are reserved by ONE atomic per (tile, query): 485 -> 428 us per launch where a fifth
+    //      of the scores were hits (top-1000 of 100 k rows at sample stride 20; the stride rule of plan_chunk now keeps the hit rate
+    //      near 2 %, lrx_search.hip).
     constexpr int WCAP = 512;                                   // hits a wave can park in LDS; more go straight to the global lists
     unsigned long long* wl = (unsigned long long*)(smem + wave * (WCAP * 12 + 64));
     unsigned int* wq = (unsigned int*)(wl + WCAP);
     unsigned int* wn = wq + WCAP;                                // the wave's hit count
+    unsigned int* qc = (unsigned int*)(smem + 8 * (WCAP * 12 + 64));   // hits of the workgroup per query column; then their global base
     if (lane == 0) *wn = 0;
+    if (tid < GBN) qc[tid] = 0;
+    __syncthreads();
     float t16[2][2][4];
 #pragma unroll
     for (int hp = 0; hp < 2; ++hp)
@@ -317,7 +323,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
                 if (mok && v[r] >= t16[hp][ni][r]) {
                   const unsigned int col = hp * 128 + wc * 32 + ni * 16 + fq * 4 + r;
                   const unsigned long long w = sel_pack(f2key(v[r]), m);
-                  if (p < WCAP) { wl[p] = w; wq[p] = col; }
+                  if (p < WCAP) { wl[p] = w; wq[p] = col | (atomicAdd(&qc[col], 1u) << 8); }   // rank < 256 rows of the tile
                   else {                                        // list full (a tile of near-duplicates): straight to the query's list
                     const unsigned int gp = atomicAdd(&em.cnt[col * CNT_STRIDE], 1u);
                     if (gp < em.cap) em.cand[(int64_t)col * em.cap + gp] = w;
@@ -327,12 +333,17 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
             }
           }
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's list is complete (nobody else touches it)
+    __syncthreads();                                             // every wave's list and the per-query counts are complete
+    if (tid < GBN) {
+      const unsigned int n = qc[tid];
+      if (n) qc[tid] = atomicAdd(&em.cnt[tid * CNT_STRIDE], n);  // the count may pass cap: that IS the overflow signal downstream
+    }
+    __syncthreads();
     const unsigned int total = min(*wn, (unsigned int)WCAP);
     for (unsigned int i = lane; i < total; i += 64) {
       const unsigned long long w = wl[i];
-      const unsigned int col = wq[i];
-      const unsigned int gp = atomicAdd(&em.cnt[col * CNT_STRIDE], 1u);
+      const unsigned int e = wq[i], col = e & 255u;
+      const unsigned int gp = qc[col] + (e >> 8);
       if (gp < em.cap) em.cand[(int64_t)col * em.cap + gp] = w;
     }
     return;

@@ -2100,14 +2100,33 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   p.nblk = p.ld / SP_ROWS;
   p.nblk_ld = (p.nblk + 3) & ~(int64_t)3;
   p.cap = cand_cap_for(k);
-  int ss = (int)(p.cap / (3u * (unsigned int)(k > 0 ? k : 1)));
-  static int ss_max = 0;                                   // (LRX_SS_MAX: A/B runs of the sample stride on one box)
-  if (ss_max == 0) { const char* e = getenv("LRX_SS_MAX"); ss_max = e && atoi(e) >= 2 ? atoi(e) : SAMPLE_SS_MAX; }
+  static int ss_max = 0, ss_force = 0;                     // (LRX_SS_MAX / LRX_SS_FORCE: A/B runs of the sample stride on one box)
+  if (ss_max == 0) {
+    const char* e = getenv("LRX_SS_MAX");
+    const char* f = getenv("LRX_SS_FORCE");
+    ss_force = f && atoi(f) >= 2 ? atoi(f) : 0;
+    ss_max = e && atoi(e) >= 2 ? atoi(e) : SAMPLE_SS_MAX;
+  }
   const int64_t nwg = lrx_cdiv(n_rows > 0 ? n_rows : 1, p.rb);
-  // stride 32 where the sample still fills the chip (1M x 2048: 0.733 -> 0.716 ms per 100-query search on one box); smaller shards keep 20 --
-  // their sample is one block per workgroup either way and the weaker threshold costs more in the main pass (125 k rows: 0.194 vs 0.200 ms)
-  const int ss_cap = nwg >= 4096 ? ss_max : (ss_max < 20 ? ss_max : 20);
-  ss = ss > ss_cap ? ss_cap : (ss < 2 ? 2 : ss);
+  // The sample stride trades the sample pass against the hits of the main pass: T' is the k-th best of the sample, so ~k * ss rows per query
+  // reach it (appended, selected from and band-checked in the refine step), while the sample pass scores rows / ss rows per query into a
+  // matrix and runs apart from the persistent main pass.  Three measured rules (tools/exp/ss_sweep.sh, same-box A/B, 100 queries unless noted):
+  //  (a) hits: cost ~ a * rows / ss + b * k * ss -> ss ~ sqrt(rows / k); factor 0.25 from top-1000: 1M x 2048 0.96 ms at 8 vs 1.03 at 20,
+  //      256 queries 1.72 at 4 vs 1.95; 100 k rows 0.34 at 2 vs 0.44 (256 queries 0.67 vs 1.00: a fifth of all scores were hits at 20);
+  //  (b) chip fill: a sample of few blocks per CU is a launch that mostly waits -- by blocks per CU of the shard (k = 100): 3.8 (125 k rows)
+  //      best at 2-6, 7.6 (250 k) at 4: 0.263 vs 0.276 at 20, 15 (500 k) at 8: 0.42 vs 0.44, 30 (1M) at 32: 0.715 vs 0.721 at 16, 0.733 at 8;
+  //  (c) powers of two only: odd strides are slower by 3-8 % at every size (1M: 0.75-0.76 at 15 against 0.72 at 16; 250 k: 0.286 at 3
+  //      against 0.263 at 4) -- the main pass then walks runs of an even number of blocks with its even number of workgroups.
+  const int64_t bpc = nwg / lrx_cu_count();
+  const int ss_fill = bpc < 6 ? 2 : (bpc < 12 ? 4 : (bpc < 24 ? 8 : 32));
+  const int ss_hits = (int)(0.25 * 1.41 * sqrt((double)(n_rows > 0 ? n_rows : 1) / (double)(k > 0 ? k : 1)));   // (x sqrt 2: to the NEAREST power of two below)
+  const int ss_list = (int)(p.cap / (3u * (unsigned int)(k > 0 ? k : 1)));   // ~k * ss hits per query must fit the list three times over
+  int ss_lim = ss_hits < ss_list ? ss_hits : ss_list;
+  ss_lim = ss_lim < ss_fill ? ss_lim : ss_fill;
+  int ss = 2;
+  while (ss * 2 <= ss_lim) ss *= 2;
+  ss = ss > ss_max ? ss_max : (ss < 2 ? 2 : ss);
+  if (ss_force) ss = ss_force < ss_list ? ss_force : ss_list;
   while (ss > 2 && (lrx_cdiv(nwg, ss) - 1) * p.rb < 2 * (int64_t)k) ss >>= 1;
   const int64_t nsamp = lrx_cdiv(nwg, ss);
   const bool feasible = (nsamp - 1) * p.rb >= 2 * (int64_t)k && nwg - nsamp >= 1 && dim % 4 == 0 && (shadow || nq > 16 * (SPLIT_MIN_QT - 1));
