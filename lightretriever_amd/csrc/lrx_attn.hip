@@ -397,27 +397,32 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // d = 64, S <= 512: K/V-resident kernel.  One workgroup = (sequence, kv head): the whole K and V of that kv head
 // (<= 512 keys x 128 B, 64 KiB each) is staged ONCE into LDS (the tiled kernel above re-loads every K/V tile for each of
-// the q tiles that needs it: 4.5x the bytes at S = 512, which saturates the per-CU load path), then 16 waves walk the
-// (q head, 32-row q block) tasks with no barrier in the main loop: wave w -> head w % GRP, q blocks g, 2NG-1-g, 2NG+g,
-// 4NG-1-g, ... (g = w / GRP, NG = 16 / GRP) so every wave gets the same number of 32x32 sub-tiles under the causal
-// triangle.  Inside a task the QK^T product of sub-tile u+1 is issued before the softmax of sub-tile u.
+// the q tiles that needs it: 4.5x the bytes at S = 512, which saturates the per-CU load path), then 16 waves work through
+// the (q head of the group, 32-row q block) tasks with no barrier in the main loop.  Tasks are handed out from an LDS
+// counter, LARGEST FIRST (q block nsub-1 of every head, then nsub-2, ...): a wave that finishes takes the next one, so
+// the pair ends on 1-sub-tile tasks.  (Round 3: the static assignment -- wave w -> head w % grp, blocks g, 2NG-1-g, ... --
+// gave every wave the same number of sub-tiles but not the same time: with 4 waves per SIMD sharing its VALU a wave's
+// pace depends on its neighbours, and the waves of a pair finished up to 40 % apart; a lone wave runs at ~45 % of what
+// four do together.  tools/exp/attn_trace.py: 17 % of a pair was spent waiting at its final barrier.)  Any group size.
+// Inside a task the QK^T product of sub-tile u+1 is issued before the softmax of sub-tile u.
 // ---------------------------------------------------------------------------------------------------------------
-template <int GRP>
 __global__ void __launch_bounds__(1024)
 k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu, int nq, int nkv, __bf16* __restrict__ out,
                   float scale_log2, int n_pairs) {
   constexpr int D = 64;
   using G = AttnGeom<D>;
-  constexpr int KS = D / 16, DT = D / 32, NG = 16 / GRP;
+  constexpr int KS = D / 16, DT = D / 32;
   constexpr int MAXK = 512;
   __shared__ __attribute__((aligned(1024))) char smem[2 * MAXK * G::ROW_BYTES];  // K [512][128 B] | V [512][128 B]
   char* const sKb = smem;
   char* const sVb = smem + MAXK * G::ROW_BYTES;
+  __shared__ int s_next_task;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int64_t RS = (int64_t)(nq + 2 * nkv) * D;
+  const int grp = nq / nkv;
   // persistent workgroups (one per CU: 128 KiB of LDS) walk the (sequence, kv head) pairs: a workgroup's successor used to start
   // ~10 us after its exit (see k_attn_varlen_causal)
   for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
@@ -426,6 +431,7 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
   if (len <= 0) continue;
   const __bf16* kbase = qkv + (int64_t)s0 * RS + (int64_t)(nq + hk) * D;
   const __bf16* vbase = kbase + (int64_t)nkv * D;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)s0 * ((int64_t)nq * D)), 0, len * nq * (D * 2), 0x00020000);
 
   // ---- stage all K/V rows of this kv head (rows >= len are clamped copies; the causal mask hides them)
   const int ninst = ((len + 63) >> 6) * G::INSTS;   // 1-KiB LDS-DMA instructions per operand
@@ -439,36 +445,61 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
     __builtin_amdgcn_global_load_lds((gptr_t)vp, (lptr_t)(sVb + j * 1024), 16, 0, 0);
   }
 
-  int koff[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) koff[ks] = r * G::ROW_BYTES + (((2 * ks + h) ^ G::xk(r)) << 4);
-  int voff[DT];
+  // lane constants of the fragment reads: ONE register each, the other k-steps / d tiles by XOR (the swizzles are XORs of the 16-B chunk
+  // index, so chunk (2 ks + h) ^ x = (h ^ x) ^ (2 ks)) -- the arrays cost registers this 128-VGPR kernel spills otherwise, and every
+  // scratch reload is followed by a vmcnt(0) that also waits for the previous task's output stores
+  const int koff0 = r * G::ROW_BYTES + ((h ^ G::xk(r)) << 4);
+  int voff0;
   {
     const int g4 = lane >> 4, i4 = lane & 15, qd = i4 >> 2, p4 = i4 & 3;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-      voff[dt] = qd * G::ROW_BYTES + (((dt * 4 + 2 * (g4 & 1) + (p4 >> 1)) ^ G::xv(qd)) << 4) + 8 * (p4 & 1);
+    voff0 = qd * G::ROW_BYTES + (((2 * (g4 & 1) + (p4 >> 1)) ^ G::xv(qd)) << 4) + 8 * (p4 & 1);
   }
-  const int head = wave % GRP, g = wave / GRP;
-  const int hq = hk * GRP + head;
   const int nsub = (len + 31) >> 5;
-
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int n_tasks = nsub * grp;
+  // task t = (q block nsub - 1 - t / grp, head t % grp): the first 16 are the waves' own, the rest come from the counter (reset here: every
+  // wave left the previous pair's task loop before the barrier that ends it)
+  if (tid == 0) s_next_task = 16;
+  bf16x8 qf[KS];
+  auto load_q = [&](const int t) {
+    const int qrow = min((nsub - 1 - t / grp) * 32 + r, len - 1);
+    const __bf16* qp = qkv + ((int64_t)s0 + qrow) * RS + (int64_t)(hk * grp + t % grp) * D + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  };
+  // The same loads as inline asm, for the prefetch of the NEXT task's fragments: hipcc's wait insertion does not see them.  With counted
+  // loads it guards every later product of the task with vmcnt(3..0) (any path on which qf might still be in flight), and those waits also
+  // cover the previous task's output stores: ~2 us of store acknowledgement exposed per task (0.07 ms of a 0.61-ms launch).  The one wait
+  // these loads need is the explicit vmcnt(4) at the top of a task: the four loads are older than the task's four (always issued) stores.
+  auto prefetch_q = [&](const int t) {
+    const int qrow = min((nsub - 1 - t / grp) * 32 + r, len - 1);
+    const __bf16* qp = qkv + ((int64_t)s0 + qrow) * RS + (int64_t)(hk * grp + t % grp) * D + h * 8;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                 : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3])
+                 : "v"(qp)
+                 : "memory");
+  };
+  static_assert(KS == 4, "prefetch_q issues four 16-byte loads per lane");
+  int t = wave;
+  if (t < n_tasks) load_q(t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K/V staged (and the first task's q fragments here)
   __syncthreads();
 
-  for (int k = 0;; ++k) {
-    const int blk = (k >> 1) * 2 * NG;
-    if (blk >= nsub) break;
-    const int i = blk + ((k & 1) ? 2 * NG - 1 - g : g);   // this wave's q block (32 rows), wave-uniform
-    if (i >= nsub) continue;
+  while (t < n_tasks) {
+    int tn = 0;
+    if (lane == 0) tn = atomicAdd(&s_next_task, 1);   // LDS; the next task is known before this one starts: its q fragments are prefetched below
+    tn = __builtin_amdgcn_readfirstlane(tn);
+    const bool have_next = tn < n_tasks;
+    const int i = nsub - 1 - t / grp;                 // this task's q block (wave-uniform)
+    const int hq = hk * grp + t % grp;
     const int q0 = i * 32;
-    bf16x8 qf[KS];
-    {
-      const int qrow = min(q0 + r, len - 1);
-      const __bf16* qp = qkv + ((int64_t)s0 + qrow) * RS + (int64_t)hq * D + h * 8;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-    }
+    // issue priority by task size: the SIMD's arbiter serves its OLDEST ready wave first, so with four VALU-bound waves the youngest one
+    // crawls (tools/exp/attn_trace.py: 3.0 us per sub-tile against 0.6 for its neighbours) and the pair ended on that wave's first, large
+    // task.  A large task now outranks the smaller ones the other waves have moved on to.
+    if (i >= 12) __builtin_amdgcn_s_setprio(3);
+    else if (i >= 8) __builtin_amdgcn_s_setprio(2);
+    else if (i >= 4) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
     f32x16 o[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -478,8 +509,10 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
 
     auto qk_product = [&](const char* kt_base) -> f32x16 {
       bf16x8 kf[KS];
+      int kb = koff0;
+      asm volatile("" : "+v"(kb));            // (keeps the three XORed copies from being hoisted to kernel entry and spilled)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kt_base + koff[ks]);
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kt_base + (kb ^ (ks << 5)));
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       f32x16 acc = attn_mfma(kf[0], qf[0], zero);
 #pragma unroll
@@ -488,19 +521,6 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
     };
 
     auto softmax_pv = [&](f32x16& sc, const int u) {
-      // ---- V^T fragments (inline asm: see the tiled kernel)
-      s16x4 vt[2][DT][2];
-      {
-        const uint32_t vb = (uint32_t)(uintptr_t)(lds_char_ptr)(sVb + (u * 32 + 4 * h) * G::ROW_BYTES);
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const uint32_t a = vb + sp * 16 * G::ROW_BYTES + voff[dt];
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[sp][dt][0]) : "v"(a));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[sp][dt][1]) : "v"(a), "i"(8 * G::ROW_BYTES));
-          }
-      }
       if (u == i) {   // diagonal sub-tile
         const int lim = r - 4 * h;
 #pragma unroll
@@ -520,7 +540,9 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
       m = mnew;
       const float mc = -mnew * scale_log2;
       {
-        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two scores per VALU slot); exp2 itself is scalar-per-lane
+        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two scores per VALU slot); exp2 itself is scalar-per-lane.  (Round 3: the same
+        // with single-issue v_fma / v_add forced by inline asm -- the microarchitecture guide prices a packed op beside MFMAs above the
+        // two it replaces -- measured 0.618-0.622 against 0.604 ms here: with four waves per SIMD the fewer issue slots win.)
         const f32x2 c2 = {scale_log2, scale_log2}, m2 = {mc, mc};
         f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
@@ -533,6 +555,21 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
           ps2 += e;
         }
         l = l * alpha + (ps2[0] + ps2[1]);
+      }
+      // ---- V^T fragments (inline asm: see the tiled kernel); requested only now: 16 registers that are not live under the exponentials
+      s16x4 vt[2][DT][2];
+      {
+        const uint32_t vb = (uint32_t)(uintptr_t)(lds_char_ptr)(sVb + (u * 32 + 4 * h) * G::ROW_BYTES);
+        int vo = voff0;
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const uint32_t a = vb + sp * 16 * G::ROW_BYTES + (vo ^ (dt << 6));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[sp][dt][0]) : "v"(a));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[sp][dt][1]) : "v"(a), "i"(8 * G::ROW_BYTES));
+          }
       }
       if (!__all(alpha == 1.0f)) {
 #pragma unroll
@@ -559,13 +596,22 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
           o[dt] = attn_mfma(uu.v, pf[sp], o[dt]);
         }
     };
-    // two named score accumulators ping-pong (no register copies): product u+1 is issued before softmax u
+    // two named score accumulators ping-pong (no register copies): product u+1 is issued before softmax u.  The q fragments of the next
+    // task are requested right after this task's LAST product (prefetch_q: loads the compiler does not count, see there).
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this task's q fragments have landed (the 4 output stores of the previous task may still fly)
     f32x16 sa = qk_product(sKb), sb;
+    if (i == 0 && have_next) prefetch_q(tn);
     for (int u = 0; u <= i; u += 2) {
-      if (u + 1 <= i) sb = qk_product(sKb + (u + 1) * 32 * G::ROW_BYTES);
+      if (u + 1 <= i) {
+        sb = qk_product(sKb + (u + 1) * 32 * G::ROW_BYTES);
+        if (u + 1 == i && have_next) prefetch_q(tn);
+      }
       softmax_pv(sa, u);
       if (u + 1 > i) break;
-      if (u + 2 <= i) sa = qk_product(sKb + (u + 2) * 32 * G::ROW_BYTES);
+      if (u + 2 <= i) {
+        sa = qk_product(sKb + (u + 2) * 32 * G::ROW_BYTES);
+        if (u + 2 == i && have_next) prefetch_q(tn);
+      }
       softmax_pv(sb, u + 1);
     }
     // ---- normalise and store this task's rows
@@ -576,18 +622,39 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
     }
     const float inv = 1.0f / ltot;
     const int q = q0 + r;
-    if (q < len) {
-      __bf16* op = out + ((int64_t)s0 + q) * ((int64_t)nq * D) + (int64_t)hq * D + 4 * h;
+    // ---- store: lane (r, h) holds of row r the 4-element groups d = dt*32 + 8*g4 + 4*h + (0..3) -- written as they lie that is sixteen
+    //      8-byte pieces per 128-B row from eight store instructions that each touch 64 lines (measured: 0.10 ms of a 0.64-ms launch,
+    //      tools/exp/attn_resident_ablation.sh).  One v_permlane32_swap per register pair hands lane (r, 0) the partner's dt = 0 groups and
+    //      lane (r, 1) the partner's dt = 1 groups: every lane then owns 64 contiguous bytes of its row, four 16-byte stores.
+    uint32_t pk[DT][4][2];
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          bf16x4 v;
+      for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g4 + e] * inv);
-          *(bf16x4*)(op + dt * 32 + 8 * g4) = v;
+        for (int e = 0; e < 2; ++e) {
+          union { bf16x2 v; uint32_t u; } cv;
+          cv.v[0] = f2bf(o[dt][4 * g4 + 2 * e] * inv);
+          cv.v[1] = f2bf(o[dt][4 * g4 + 2 * e + 1] * inv);
+          pk[dt][g4][e] = cv.u;
         }
+    static_assert(DT == 2, "the lane-pair exchange below assumes two 32-wide d tiles");
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      u32x4 w;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        // (vdst.upper <-> src.lower) lower lanes: [0] own dt0, [1] partner's dt0; upper lanes: [0] partner's dt1, [1] own dt1
+        auto rr = __builtin_amdgcn_permlane32_swap(pk[0][g4][e], pk[1][g4][e], false, false);
+        w[e] = rr[0];
+        w[2 + e] = rr[1];
+      }
+      // a raw buffer store through the sequence's descriptor: rows >= len fall outside num_records and are dropped by the range check, so
+      // the task always issues exactly four stores -- the compiler can then wait for the prefetched q fragments with vmcnt(4); with a
+      // branch around each store it had to use vmcnt(0), which also waits for these stores to be acknowledged (~2 us per task)
+      __builtin_amdgcn_raw_buffer_store_b128(w, orsrc, (q * nq + hq) * (D * 2) + 64 * h + 16 * g4, 0, 0);
     }
+    t = tn;
   }
   __syncthreads();     // every wave is done with this pair's K/V before the next pair is staged over it
   }  // pairs
@@ -953,7 +1020,7 @@ extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens
   hipStream_t s = (hipStream_t)stream;
   static int force_tiled = -1;   // LRX_ATTN_TILED=1: dev switch for A/B runs of the two d = 64 kernels
   if (force_tiled < 0) { const char* e = getenv("LRX_ATTN_TILED"); force_tiled = e ? atoi(e) : 0; }
-  if (!force_tiled && head_dim == 64 && max_seqlen <= 512 && !last_tile_only && (grp == 1 || grp == 2 || grp == 4 || grp == 8)) {
+  if (!force_tiled && head_dim == 64 && max_seqlen <= 512 && !last_tile_only) {
     const float scale_log2 = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
     static int n_cu64 = 0;
     if (n_cu64 == 0) {
@@ -964,14 +1031,7 @@ extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens
     }
     const int n_pairs = n_seqs * num_kv_heads;
     dim3 grid(n_pairs < n_cu64 ? n_pairs : n_cu64), block(1024);
-    const __bf16* in = (const __bf16*)qkv;
-    __bf16* o = (__bf16*)out;
-    switch (grp) {
-      case 1: hipLaunchKernelGGL(k_attn_resident64<1>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2, n_pairs); break;
-      case 2: hipLaunchKernelGGL(k_attn_resident64<2>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2, n_pairs); break;
-      case 4: hipLaunchKernelGGL(k_attn_resident64<4>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2, n_pairs); break;
-      default: hipLaunchKernelGGL(k_attn_resident64<8>, grid, block, 0, s, in, cu_seqlens, num_q_heads, num_kv_heads, o, scale_log2, n_pairs); break;
-    }
+    hipLaunchKernelGGL(k_attn_resident64, grid, block, 0, s, (const __bf16*)qkv, cu_seqlens, num_q_heads, num_kv_heads, (__bf16*)out, scale_log2, n_pairs);
     LRX_LAUNCH_CHECK();
     return LRX_OK;
   }

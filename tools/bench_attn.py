@@ -13,7 +13,7 @@ def main():
     for (nq, nkv, d) in shapes:
         T = B * S
         g = torch.Generator(device="cuda").manual_seed(0)
-        qkv = torch.randn(T, (nq + 2 * nkv) * d, generator=g, device="cuda").to(torch.bfloat16)
+        qkv = torch.randn(T, (nq + 2 * nkv) * d, generator=g, device="cuda").to(torch.float16)
         cu = (torch.arange(B + 1, device="cuda") * S).to(torch.int32)
         for _ in range(2):
             ops.attn_varlen_causal(qkv, cu, S, nq, nkv, d)
