@@ -162,10 +162,15 @@ def attn_oracle(qkv, cu, nq, nkv, d):
     (128, 6, 2, [200, 64, 1]),       # group 3 (Llama-3.2-3B: 24 q / 8 kv heads)
     (128, 5, 1, [131, 40]),          # group 5: parts of 3 + 2 heads
     (128, 12, 1, [97, 130]),         # group 12: three workgroups of 4 heads
-    (64, 3, 1, [150, 33]),           # groups 3, 5, 7 at head_dim 64 (tiled kernel; the LDS-resident one takes 1, 2, 4, 8)
+    (64, 3, 1, [150, 33]),           # groups 3, 5, 7, 16 at head_dim 64: the LDS-resident kernel hands out (head, q block) tasks for any group
     (64, 10, 2, [129, 64]),
     (64, 7, 1, [100, 2]),
-    (64, 16, 1, [90, 70]),           # group 16: two workgroups of 8 heads
+    (64, 16, 1, [90, 70]),
+    (64, 14, 2, [512, 511, 1]),      # Qwen2.5-0.5B head layout at the resident kernel's longest sequence
+    (64, 8, 2, [600, 40]),           # longer than 512 tokens: the tiled kernel at head_dim 64
+    (64, 3, 1, [530, 33]),           # ... with an odd group
+    (64, 16, 1, [513, 70]),          # ... group 16: two workgroups of 8 heads
+    (128, 4, 1, [700, 64]),
 ])
 def test_attention_varlen_causal(d, nq, nkv, lens):
     from lightretriever_amd import ops
