@@ -342,6 +342,37 @@ def extra_legs(args, dev, headline_index):
                      "avg_launch_ms": round(gu8["ms"] / max(gu8["launches"], 1), 4), "launches": gu8["launches"], "traffic": None}}
     del enc8, out8, ids8
     torch.cuda.empty_cache()
+    # ---- SURVEY 8d's ragged variant of the headline encoder: lengths clip(lognormal(5.3, 0.6), 16, S) sorted longest first (the reference
+    #      sorts its corpus that way, hybrid_search.py:273-276), 256 documents per step, 1 warm-up + 3 timed steps
+    import numpy as np
+    cfg1 = EncoderConfig.llama32_1b(args.seq_len)
+    enc1 = LrxEncoder.random_init(cfg1, seed=0, device=dev)
+    B1, n1 = 256, 4
+    rng = np.random.default_rng(4321)
+    lens = np.sort(np.clip(rng.lognormal(5.3, 0.6, size=n1 * B1), 16, S).astype(np.int64))[::-1]
+    g1 = torch.Generator(device=dev).manual_seed(78)
+    rb = []
+    for i in range(n1):
+        l = lens[i * B1:(i + 1) * B1]
+        rb.append((torch.randint(1000, 127000, (int(l.sum()),), generator=g1, device=dev, dtype=torch.int64).to(torch.int32),
+                   torch.tensor(np.concatenate([[0], np.cumsum(l)]), dtype=torch.int32, device=dev), int(l.max())))
+    out1 = torch.empty(B1, cfg1.hidden_size, device=dev)
+    enc1.encode_packed(rb[0][0], rb[0][1], rb[0][2], out=out1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(1, n1):
+        enc1.encode_packed(rb[i][0], rb[i][1], rb[i][2], out=out1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter() - t0
+    tl = lens[B1:]
+    legs["ragged_encode_llama32_1b"] = {
+        "workload": "lightretriever-llama3.2-1b dims bf16, %d docs/step, lengths clip(lognormal(5.3,0.6),16,%d) sorted longest first, %d timed steps "
+                    "after 1 warm-up (SURVEY 8d ragged variant; not the headline)" % (B1, S, n1 - 1),
+        "docs_per_s": round((n1 - 1) * B1 / t1, 1), "tokens_per_s": round(float(tl.sum()) / t1, 0), "mean_tokens_per_doc": round(float(tl.mean()), 1),
+        "longest_doc": int(tl.max()), "shortest_doc": int(tl.min()),
+        "end_to_end_tflops": round(float(sum(cfg1.flops_per_doc(int(x)) for x in tl)) / t1 / 1e12, 1)}
+    del enc1, out1, rb
+    torch.cuda.empty_cache()
     return legs
 
 
