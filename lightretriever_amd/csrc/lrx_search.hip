@@ -1287,6 +1287,8 @@ extern "C" int lrx_flat_ip_scores(const float* X, int64_t n_rows, int64_t ldx, i
 // ---------------------------------------------------------------------------------------------------------------
 
 // sort buf[0..P) descending (P power of two), all threads of the block participate
+// (Round 3, measured and not kept: workgroup barriers only before the 20 of 66 stages of a 2048-element sort that pair elements of different
+// waves -- k_refine_merge at top-1000 stayed at 35 us: a stage costs its LDS read -> compare -> write latency, ~0.5 us, not its barrier.)
 __device__ void bitonic_sort_desc(unsigned long long* buf, int P) {
   for (int k = 2; k <= P; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
