@@ -2271,6 +2271,8 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       // (Round 3, measured and not kept: with the narrow fp16 band (~130 rows at k = 100) ONE workgroup per query that also sorts and writes
       // the result, no merge launch: 0.723 / 0.739 vs 0.715 / 0.731 ms on the same box -- the serial select + rescore of one workgroup costs
       // more than the merge launch saves.)
+      // (Round 3, measured and not kept: the number of parts, 1..8, that leaves the fewest CUs idle over whole rounds -- 5 for 100 queries:
+      // top-1000 0.959 ms against 0.951 with 2 parts, top-100 0.730 against 0.719, 8 parts 1.00 / 0.747: the gather is bound chip-wide.)
       nsplit = (int64_t)nq * REF_SPLIT <= lrx_cu_count() ? REF_SPLIT : ((int64_t)nq * 2 <= lrx_cu_count() ? 2 : 1);
       hipLaunchKernelGGL(k_refine_band, dim3(nq, nsplit), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
                          (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt, nsplit, p.cap);
