@@ -77,6 +77,26 @@ def test_medium_model_within_1e3_cosine_of_fp32_oracle(d, bias):
     assert 1 - min_cos(out, want) <= COS_TOL, 1 - min_cos(out, want)
 
 
+@pytest.mark.parametrize("d,nq,nkv", [(64, 8, 2), (128, 4, 2)])
+def test_documents_longer_than_512_tokens_against_the_fp32_oracle(d, nq, nkv):
+    """Past 512 tokens head_dim 64 leaves the LDS-resident attention kernel for the tiled one, and the RoPE table is walked beyond the
+    reference's default p_max_len: same 1e-3 bar against the fp32 restatement, plus the same documents encoded one by one."""
+    cfg = O.EncoderConfig(vocab_size=1000, hidden_size=nq * d, num_layers=3, num_q_heads=nq, num_kv_heads=nkv, head_dim=d,
+                          intermediate_size=1024, rope_type="llama3", rope_factor=8.0, rope_original_max_position=256, max_positions=2048)
+    w = O.random_weights(cfg, seed=11 + d, std=0.03)
+    rng = np.random.default_rng(5 + d)
+    lens = [1500, 513, 700, 40, 512]
+    ids = rng.integers(0, 1000, size=sum(lens)).astype(np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    want = O.encode_passage(cfg, w, ids, cu, bf16=False)
+    enc = make_encoder(cfg, w)
+    out = enc.encode_packed(to_dev(ids, torch.int32), to_dev(cu, torch.int32), max(lens)).cpu().numpy()
+    assert 1 - min_cos(out, want) <= COS_TOL, 1 - min_cos(out, want)
+    for b in (0, 3):
+        one = enc.encode_packed(to_dev(ids[cu[b]:cu[b + 1]], torch.int32), to_dev(np.array([0, lens[b]], np.int32), torch.int32), lens[b]).cpu().numpy()
+        assert 1 - min_cos(one, out[b:b + 1]) < 2e-5
+
+
 def test_writes_in_place_into_index_rows_and_is_batch_invariant():
     cfg, w, ids, cu, max_len = medium_case(64)
     enc = make_encoder(cfg, w)
