@@ -381,13 +381,26 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
         *(bf16x4*)(sW + r * G::ROW_BYTES + ((((dt * 4 + g4_) ^ (r & (G::CH - 1))) << 4) | (h << 3))) = v;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // same wave wrote, same wave reads: no barrier
-    __bf16* ob = out + (int64_t)s0 * ((int64_t)nq * D) + (int64_t)hq * D;
+    // Read-out: all QINST row segments into registers first, then QINST buffer stores through the sequence's descriptor (rows >= len fall
+    // outside num_records and are dropped: no branch per store).  The LDS addresses are recomputed from the lane id HERE (the empty asm
+    // keeps them from being hoisted out of the item loop): hoisted, four of them were spilled, and every scratch reload came with a
+    // vmcnt(0) that waited for the store issued just before it -- four serial store round trips, 6 us per item
+    // (tools/exp/attn_trace_tiled.py: 35 % of the launch at S = 512).
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)s0 * ((int64_t)nq * D)), 0, len * nq * (D * 2), 0x00020000);
+    u32x4 ov[QINST];
 #pragma unroll
     for (int j = 0; j < QINST; ++j) {
-      const int s_ = j * 64 + lane;
+      const int s_ = j * 64 + ln;
       const int row = s_ / G::CH, ch = s_ % G::CH;
-      const bf16x8 v = *(const bf16x8*)(sW + row * G::ROW_BYTES + ((ch ^ (row & (G::CH - 1))) << 4));
-      if (q0 + row < len) *(bf16x8*)(ob + (int64_t)(q0 + row) * ((int64_t)nq * D) + ch * 8) = v;
+      ov[j] = *(const u32x4*)(sW + row * G::ROW_BYTES + ((ch ^ (row & (G::CH - 1))) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < QINST; ++j) {
+      const int s_ = j * 64 + ln;
+      const int row = s_ / G::CH, ch = s_ % G::CH;
+      __builtin_amdgcn_raw_buffer_store_b128(ov[j], orsrc, ((q0 + row) * nq + hq) * (D * 2) + ch * 16, 0, 0);
     }
   }
   ic = inext;
