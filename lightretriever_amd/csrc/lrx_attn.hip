@@ -163,18 +163,16 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     return true;
   };
 
-  // ---- lane-constant LDS read offsets
-  int koff[KS];  // K row read: row (sub*32 + r), logical chunk 2ks + h
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) koff[ks] = r * G::ROW_BYTES + (((2 * ks + h) ^ G::xk(r)) << 4);
-  // V transposed read: 16-lane group g = lane>>4, i = lane&15, qd = i>>2, p = i&3; block row = key_base + qd,
-  // columns dt*32 + 16*(g&1) + 4p .. +3  ->  logical chunk dt*4 + 2*(g&1) + (p>>1), byte 8*(p&1) inside it
-  int voff[DT];
+  // ---- lane-constant LDS read offsets: ONE register each, the other k-steps / d tiles by XOR (both swizzles are XORs of the 16-B chunk
+  //      index and the chunk's own k-step / d-tile bits are disjoint from the rest): at head_dim 128 this kernel sits at its 256-VGPR
+  //      budget, twelve offset registers are ten too many.
+  // K row read: row (sub*32 + r), logical chunk 2ks + h;  V transposed read: 16-lane group g = lane>>4, i = lane&15, qd = i>>2, p = i&3;
+  // block row = key_base + qd, columns dt*32 + 16*(g&1) + 4p .. +3  ->  logical chunk dt*4 + 2*(g&1) + (p>>1), byte 8*(p&1) inside it
+  const int koff0 = r * G::ROW_BYTES + ((h ^ G::xk(r)) << 4);
+  int voff0;
   {
     const int g = lane >> 4, i = lane & 15, qd = i >> 2, p = i & 3;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-      voff[dt] = qd * G::ROW_BYTES + (((dt * 4 + 2 * (g & 1) + (p >> 1)) ^ G::xv(qd)) << 4) + 8 * (p & 1);
+    voff0 = qd * G::ROW_BYTES + (((2 * (g & 1) + (p >> 1)) ^ G::xv(qd)) << 4) + 8 * (p & 1);
   }
 
   // Q block of an item for this wave: rows q0 .. q0 + 31 of its head, requested into the wave's staging block with the K-tile
@@ -196,8 +194,10 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     }
   };
   auto read_q = [&](bf16x8 (&dst)[KS]) {
+    int kb = koff0;
+    asm volatile("" : "+v"(kb));              // (not hoisted into KS loop-invariant registers)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const bf16x8*)(sW + koff[ks]);
+    for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const bf16x8*)(sW + (kb ^ (ks << 5)));
   };
 
   Walk wc = {0, 0, (int)blockIdx.x};
@@ -233,14 +233,19 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     for (int t = 0; t < 16; ++t) o[dt][t] = 0.f;
   float m = -1e30f, l = 0.f;
 
-  auto qk_product = [&](const char* kt_base, const int (&koff_)[KS], const bf16x8 (&qf_)[KS]) -> f32x16 {
+  auto qk_product = [&](const char* kt_base, const bf16x8 (&qf_)[KS]) -> f32x16 {
     bf16x8 kf[KS];
+    int kb = koff0;
+    asm volatile("" : "+v"(kb));
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kt_base + koff_[ks]);
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kt_base + (kb ^ (ks << 5)));
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // inline-constant C operand
     f32x16 acc = attn_mfma(kf[0], qf_[0], zero);
 #pragma unroll
     for (int ks = 1; ks < KS; ++ks) acc = attn_mfma(kf[ks], qf_[ks], acc);
+    // (Round 3, measured and not kept: sched_group_barriers that put three fragment reads ahead of the MFMA chain and one read per MFMA
+    // after it -- left alone, hipcc walks the eight fragments of a head_dim-128 product through ONE register quad, read / lgkmcnt(0) / MFMA --
+    // 1.207 ms against 1.17-1.19: the second wave of the SIMD already covers those waits.)
     return acc;
   };
   // lane <-> lane^32 exchange on the VALU (v_permlane32_swap) instead of an LDS round trip (ds_bpermute)
@@ -254,11 +259,13 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     s16x4 vt[2][DT][2];
     {
       const uint32_t vb = (uint32_t)(uintptr_t)(lds_char_ptr)(v_base + 4 * h * G::ROW_BYTES);
+      int vo = voff0;
+      asm volatile("" : "+v"(vo));
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const uint32_t a = vb + sp * 16 * G::ROW_BYTES + voff[dt];
+          const uint32_t a = vb + sp * 16 * G::ROW_BYTES + (vo ^ (dt << 6));
           asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[sp][dt][0]) : "v"(a));
           asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[sp][dt][1]) : "v"(a), "i"(8 * G::ROW_BYTES));
         }
@@ -345,9 +352,9 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     const bool two = (kt * 64 + 32 <= q0);   // wave-uniform: second sub-tile not entirely above the diagonal
     const bool more = stage_next();                              // tile (this + 2) of the stream, whichever item it belongs to
     if (active) {
-      f32x16 s0_ = qk_product(sK, koff, qf);
+      f32x16 s0_ = qk_product(sK, qf);
       f32x16 s1_;
-      if (two) s1_ = qk_product(sK + 32 * G::ROW_BYTES, koff, qf);
+      if (two) s1_ = qk_product(sK + 32 * G::ROW_BYTES, qf);
       softmax_pv(s0_, sV, kt * 64 == q0);
       if (two) softmax_pv(s1_, sV + 32 * G::ROW_BYTES, kt * 64 + 32 == q0);
     }
