@@ -510,7 +510,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
         }
       }
     }
-  __syncthreads();
+  __syncthreads();   // (also waits for the residual rows; measured in round 3: an LDS-only wait here, the loads left in flight, is 1 % slower on the O-projection)
   if (EPI == EPI_MAXAGG) {
     // Segmented column maximum of the staged bf16 logits tile (utils/max_linear_map.py:8-88 without the [B,S,V] tensor):
     // wave w owns columns [32w, 32w+32); a lane walks rows (lane>>3) + 8*step holding 4 columns.  Rows map to output rows
