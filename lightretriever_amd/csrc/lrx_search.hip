@@ -1,23 +1,31 @@
-// Flat inner-product search over an HBM-resident fp32 corpus shard (replaces faiss.IndexFlatIP.search).
+// Flat inner-product search over an HBM-resident fp32 corpus shard (replaces faiss.IndexFlatIP.search).  Map of this file, in source order:
 //
-//  1. k_flat_ip_scores<QT> (Q <= 32; k_flat_ip_scores_split<QT> above that, see its header): scores[Q, ld] = q . X^T with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: bitwise an fp32 fma
-//     chain).  HBM-bound for Q <= ~48 (X is streamed exactly once per <=128 queries), fp32-matrix bound above.
-//     Workgroup = 4 waves x 64 corpus rows; X and q k-slices (32 floats = one 128-B line per row) are staged with
-//     16-byte global_load_lds into 2 LDS stages, XOR-swizzled on the source address for conflict-free ds_read_b128.
-//     The k summation order is permuted (lane group g of a 16-k block owns k = 4g..4g+3) so one ds_read_b128 feeds
-//     four MFMA steps; both operands use the same permutation.
-//     The epilogue also emits the per-(query, 256-row block) maximum.
-//  2. k_topk_select: one workgroup per query.  Fast path: threshold = k-th largest block maximum (at least k elements
-//     are >= it, so the true top-k all pass), ONE scan of the row gathering everything >= threshold (typically ~k
-//     elements), LDS bitonic sort on (score desc, row asc).  Fallback when the gather overflows (heavy ties) or the
-//     index is small: exact 4 x 8-bit radix select of the k-th largest score + gather of everything strictly greater
-//     plus the lowest-row-id ties.  Deterministic output regardless of atomics order on both paths.
-//  2b. Every path ends with exact rescoring of the selected rows (k_topk_select_rescore / k_refine_topk: fp64 accumulation, one rounding
-//     to fp32), so the reported scores do not depend on the path, the query batch size or the shard layout.  For Q > 32 and rows
-//     with a known norm bound the search is two-pass (lrx_flat_ip_search_bounded): a single-product bf16 FILTER pass
-//     (k_flat_ip_scores_split<QT, 1, ..>, HBM-bound) + exact refinement of the rows inside a rigorous error band, with the
-//     six-product pass as a device-gated fallback.
-//  3. k_merge_topk: merge of R per-shard [Q,k] lists (after the RCCL all-gather) with the same ordering rule.
+//  A. Score kernels (what a search streams the shard through)
+//     k_flat_ip_scores<QT>            exact-fp32 MFMA (v_mfma_f32_16x16x4_f32 = an fp32 fma chain), <= 32 queries; writes scores[Q, ld] + block maxima.
+//                                     The plain path (lrx_flat_ip_search) for few queries.
+//     k_flat_ip_scores_split<..NP..>  NP = 3: six bf16 products ~ fp32 (plain path above 32 queries; the gated exact fallback of the bounded
+//                                     search).  NP = 1: one fp16 product straight from the fp32 rows (filter for shards without a shadow).
+//     k_filter_xreg / _store / _emit  the filter of the bounded search over the tiled fp16 shadow (lrx_shadow_off): corpus fragments go
+//                                     HBM -> registers, queries sit in LDS.  k_filter_xreg: the strided SAMPLE (scores + 16-row group maxima,
+//                                     or the whole score matrix in LRX_SEARCH_FILTER_MATRIX mode); _store: its persistent form for large
+//                                     samples; _emit: the persistent MAIN pass -- rows reaching the query's threshold are appended to
+//                                     per-query candidate lists (per-wave LDS lists, one reservation per (wave, query) per flush).
+//                                     (129..256 queries: the main pass runs on the GEMM kernel, lrx_gemm.hip EPI_EMIT.)
+//     launch_scores(), k_pack_queries_xb, k_round_queries: query planes / fragment order + the chain's zero-fills; kernel dispatch.
+//  B. Selection
+//     radix_select_kth*, select_topk_sorted, bitonic_sort_desc: exact k-th / top-k of a score row or a candidate list (one workgroup).
+//     k_topk_select, k_topk_select_rescore: the plain path's finish -- RIGOROUS: every row within eps6(q) of the k-th matrix score is
+//                                     rescored exactly (fp64 accumulation, one rounding), best k kept; streaming form for huge tie bands.
+//  C. The bounded (two-pass) search, lrx_flat_ip_search_bounded: plan_chunk (sample stride, list capacity, workspace layout) ->
+//     pack -> sample -> k_sample_threshold (T' = k-th best of the sample, thr = T' - 2 eps(q), lists opened with the sample's rows) ->
+//     main pass (_emit) -> k_refine_band (k-th filter score of the list, exact rescoring of the band rows from the fp32 shard) ->
+//     k_refine_merge (sorted top-k; or the query's fallback flag) -> gated exact fallback (scores_split<NP=3> + select_rescore).
+//     k_refine_topk: the refine step of the score-matrix filter (tiny shards, FILTER_MATRIX).  query_eps_block: the per-query error bound.
+//  D. Shard maintenance: k_shard_bounds, k_shard_rows_tiled (lrx_shard_commit_rows): fp16 shadow rows + {max |x|, max |x - fp16(x)|}.
+//  E. Multi-GPU result exchange: k_pack_topk / lrx_pack_topk, k_merge_topk / lrx_merge_topk[_packed] (after the RCCL all-gather).
+//
+// Every path ends with exact rescoring of the selected rows, so the reported scores do not depend on the path, the query batch size or
+// the shard layout; ties go to the lower row id.  Dead ends that were measured and dropped are noted where they would have gone.
 #include "lrx_common.h"
 #include <float.h>
 #include <stdlib.h>
