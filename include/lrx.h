@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define LRX_ABI_VERSION 4
+#define LRX_ABI_VERSION 5
 
 enum {
   LRX_OK = 0,
@@ -174,6 +174,11 @@ int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens
 /* Number of out-of-range token ids any embedding gather (stand-alone or inside lrx_encode_*) has met since the last reset; -1 if the
  * read failed.  SYNCHRONISES the device (a blocking copy): call it at a point where the caller waits for results anyway.         */
 int64_t lrx_device_error_count(int32_t reset);
+/* (ABI 5) fp16 range events since the last reset: q|k|v elements of the fused QKV + RoPE epilogue and fp16-shadow elements of pooled rows
+ * that were NaN or beyond +-65504 and were stored as a finite +-65504 (counted once per wave instruction that saw any, so "0 or not" is
+ * the meaningful reading).  0 on every checkpoint whose q|k|v stay inside fp16's range -- the precondition of the fp16 attention path;
+ * a non-zero count means the embeddings of that call are not the model's.  -1 if the read failed.  SYNCHRONISES like the call above. */
+int64_t lrx_device_saturation_count(int32_t reset);
 
 /* LlamaRMSNorm (modeling_llama.py:53-67): y = w * bf16(x * rsqrt(mean(x^2) + eps)); x, w, y bf16; rows x hidden */
 int lrx_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t hidden, float eps, void* stream);
@@ -322,7 +327,10 @@ int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim,
  * candidate list, ~1e-3 of the rows; capacity 64 k rounded up to a power of two, at least 16 Ki); the rows within 2 eps of the list's
  * k-th score are rescored exactly from the fp32 rows (fp64 accumulation, one rounding) and sorted.  Queries whose list or band
  * overflows (near-duplicate corpora, rows outside fp16's range) are redone by the six-product path (gated on a device flag, no host
- * sync).  Scores returned are the exactly rescored ones.  Bounds smaller than the true values void the guarantee.
+ * sync).  Scores returned are the exactly rescored ones.  Bounds smaller than the true values void the guarantee.  row_bounds[1] <= 0
+ * means "E not measured": the library then uses 2^-11 R + sqrt(dim) 2^-25, a bound for every shard with R <= 65504 (elements in fp16's
+ * normal or subnormal range); with R > 65504 it uses E = R, i.e. every query takes the six-product path (exact, slower).
+ * The CU count that sizes the persistent launches is cached per process for the device that was current at the first call.
  * X_shadow (optional, NULL = convert the fp32 rows on the fly: half the queries/s): the shard's TILED FP16 SHADOW kept by the caller
  * next to the fp32 rows -- round-to-nearest-even per element, saturating at +-65504; dim % 64 == 0; layout at lrx_shard_commit_rows;
  * row 0 of the array is the shard's row 0.

@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRX_LIB_DEV_VARIANT") or os.path.join(HERE, "liblrx.so")   # env override: tools/ diagnostics only
 LRX_PROF_CLASSES = 8
-ABI_VERSION = 4   # LRX_ABI_VERSION of include/lrx.h
+ABI_VERSION = 5   # LRX_ABI_VERSION of include/lrx.h
 # lrx_flat_ip_search_bounded flags (LRX_SEARCH_FILTER_*): A/B runs and tests; the hits do not depend on them
 SEARCH_FILTER_AUTO, SEARCH_FILTER_MATRIX, SEARCH_FILTER_SCORE_FREE, SEARCH_FILTER_SCORE_FREE_NO_GEMM = 0, 1, 2, 3
 PROF_CLASS_NAMES = ["gemm_store", "gemm_resid", "gemm_swiglu", "attention", "rmsnorm", "rope", "other", "gemm_maxagg"]
@@ -69,6 +69,7 @@ SIGNATURES = {
     "lrx_get_profile": (_I32, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "lrx_embedding_gather": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "lrx_device_error_count": (_I64, [_I32]),
+    "lrx_device_saturation_count": (_I64, [_I32]),
     "lrx_rmsnorm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P]),
     "lrx_gemm_bf16_nt": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "lrx_gemm_qkv_rope": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),

@@ -997,6 +997,17 @@ extern "C" int lrx_attn_prefix_suffix(const void* qkv, const void* prefix_kv, in
   return LRX_OK;
 }
 
+// CU count of the device that was current at the FIRST call (cached per process; include/lrx.h says so).  A C++11 function-local static:
+// concurrent first calls from several host threads initialise it once.
+static int attn_cu_count() {
+  static const int n = []() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }();
+  return n;
+}
+
 template <int D, int GRP>
 static int launch_attn(const void* qkv, const int32_t* cu, int n_seqs, int max_seqlen, int nq, int nkv, void* out, int last_tile_only,
                        hipStream_t s, int nparts = 1) {
@@ -1006,13 +1017,7 @@ static int launch_attn(const void* qkv, const int32_t* cu, int n_seqs, int max_s
   LRX_CHECK_ARG(n_items < (1ll << 31), "attn: %lld work items", (long long)n_items);
   // persistent workgroups, as many as the chip keeps resident at once: the d = 128 ring (96 KiB) and the 256-VGPR budget admit one
   // per CU; d = 64 workgroups are small enough for more (2-stage 32-KiB rings), so they get a slot count that covers that
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LRX_ERR_HIP;
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int n_cu = attn_cu_count();
   const int per_cu = D == 128 ? 1 : (GRP <= 2 ? 4 : 2);
   const int64_t slots = (int64_t)n_cu * per_cu;
   // grouped item list (see the kernel): needs a full grid that splits evenly over the 8 XCDs; gs = slots of one XCD that share a
@@ -1038,17 +1043,11 @@ extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens
   if (total_tokens == 0 || n_seqs == 0) return LRX_OK;
   int grp = num_q_heads / num_kv_heads;
   hipStream_t s = (hipStream_t)stream;
-  static int force_tiled = -1;   // LRX_ATTN_TILED=1: dev switch for A/B runs of the two d = 64 kernels
-  if (force_tiled < 0) { const char* e = getenv("LRX_ATTN_TILED"); force_tiled = e ? atoi(e) : 0; }
+  // LRX_ATTN_TILED=1: dev switch for A/B runs of the two d = 64 kernels (read once; C++11 static initialisation is thread-safe)
+  static const int force_tiled = []() { const char* e = getenv("LRX_ATTN_TILED"); return e ? atoi(e) : 0; }();
   if (!force_tiled && head_dim == 64 && max_seqlen <= 512 && !last_tile_only) {
     const float scale_log2 = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
-    static int n_cu64 = 0;
-    if (n_cu64 == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LRX_ERR_HIP;
-      n_cu64 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu64 = attn_cu_count();
     const int n_pairs = n_seqs * num_kv_heads;
     dim3 grid(n_pairs < n_cu64 ? n_pairs : n_cu64), block(1024);
     hipLaunchKernelGGL(k_attn_resident64, grid, block, 0, s, (const __bf16*)qkv, cu_seqlens, num_q_heads, num_kv_heads, (__bf16*)out, scale_log2, n_pairs);

@@ -49,6 +49,19 @@ struct RopeArgs {
 __device__ __forceinline__ __bf16 f2h_bits(float v) {   // fp16 (saturating) in the kernel's 16-bit container type
   return __builtin_bit_cast(__bf16, (_Float16)fminf(fmaxf(v, -65504.f), 65504.f));
 }
+// q|k|v elements of the fused QKV epilogue that left fp16's range (|v| > 65504) or were NaN -- both become a finite 65504 in the store
+// above, which is a silent change of the model's arithmetic: counted here, read by lrx_device_saturation_count (one atomic per wave
+// that saw any, i.e. none on a healthy checkpoint).
+__device__ unsigned int g_qkv_fp16_saturations = 0;
+unsigned int lrx_gemm_saturations(int reset, int* ok) {
+  unsigned int v = 0;
+  *ok = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_qkv_fp16_saturations), sizeof(v)) == hipSuccess;
+  if (*ok && reset && v) {
+    const unsigned int z = 0;
+    *ok = hipMemcpyToSymbol(HIP_SYMBOL(g_qkv_fp16_saturations), &z, sizeof(z)) == hipSuccess;
+  }
+  return v;
+}
 
 // Search filter pass (EPI_EMIT): A = the shard's tiled FP16 shadow (lrx_shadow_off), B = fp16 queries (f16 MFMA); no C.  A score reaching thr[query] is appended
 // to the query's candidate list (lrx_search.hip).  ss > 0: m-tile t of the launch is the t-th 256-row tile that is NOT in the sample
@@ -478,8 +491,14 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
             }
           }
           bf16x4 o1, o2;
+          bool sat = false;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { o1[r] = f2h_bits(x1[r]); o2[r] = f2h_bits(x2[r]); }
+          for (int r = 0; r < 4; ++r) {
+            sat |= !(fabsf(x1[r]) <= 65504.f) | !(fabsf(x2[r]) <= 65504.f);    // (NaN fails the comparison too)
+            o1[r] = f2h_bits(x1[r]);
+            o2[r] = f2h_bits(x2[r]);
+          }
+          if (sat) atomicAdd(&g_qkv_fp16_saturations, 1u);
           const int c1 = cb + fq * 4, c2 = c1 + 16;
           *(bf16x4*)(smem + row * (CW * 2) + ((((c1 >> 3) ^ (row & 15)) << 4) | ((c1 & 4) << 1))) = o1;
           *(bf16x4*)(smem + row * (CW * 2) + ((((c2 >> 3) ^ (row & 15)) << 4) | ((c2 & 4) << 1))) = o2;
@@ -601,8 +620,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 
 // m-tiles per group of the block -> tile map, per epilogue class (measured, see the kernel); LRX_GEMM_GM overrides it for sweeps
 static int gemm_group_m(int epilogue, int K) {
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("LRX_GEMM_GM"); env = e ? atoi(e) : 0; }
+  static const int env = []() { const char* e = getenv("LRX_GEMM_GM"); return e ? atoi(e) : 0; }();   // (thread-safe one-time read)
   if (env > 0) return env;
   // 1B shapes (K = 2048): gate-up 6, o/down 4, qkv 8; 8B shapes (K = 4096): within 2 % for 2..8, gate-up best at 8 (1596 TFLOP/s)
   return epilogue == EPI_SWIGLU ? (K >= 4096 ? 8 : 6) : (epilogue == EPI_RESID ? 4 : 8);

@@ -1158,12 +1158,12 @@ struct FilterMode {
 // query_eps_block); gate != NULL: the whole pass is skipped unless *gate != 0.  One call covers at most one query chunk (128 queries, 256
 // for the shadow filter); `ld` is the row stride of `scores` / rounded row count.  Xs = the shard's tiled fp16 shadow (planes == 1) or NULL.
 static int lrx_cu_count() {
-  static int n_cu = 0;
-  if (n_cu == 0) {
+  // cached per process for the device that was current at the first call (include/lrx.h); C++11 static initialisation: thread-safe
+  static const int n_cu = []() {
     int dev = 0;
     hipDeviceProp_t prop;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }();
   return n_cu;
 }
 
@@ -1776,7 +1776,7 @@ struct RadixShared {
 };
 
 // eps(q) of the header comment; all threads of the (<= 1024-thread) block take part, fixed summation order.  Optionally stages the
-// query row in LDS (s_q).  bounds = {R, E}; E <= 0 means "unknown": 2^-11 R (unit roundoff of fp16).
+// query row in LDS (s_q).  bounds = {R, E}; E <= 0 means "not measured": bounded from R below.
 __device__ float query_eps_block(const float* __restrict__ qglob, int D, const float* __restrict__ bounds, float* s_q, float* s_red /* 32 */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   float a = 0.f, b = 0.f;
@@ -1794,7 +1794,12 @@ __device__ float query_eps_block(const float* __restrict__ qglob, int D, const f
   float A = 0.f, B = 0.f;
   for (int w = 0; w < nw; ++w) { A += s_red[w]; B += s_red[16 + w]; }
   __syncthreads();
-  const float R = bounds[0], E = bounds[1] > 0.f ? bounds[1] : R * 0.00048828125f;   // unknown E: fp16's unit roundoff 2^-11 (rows inside fp16's normal range)
+  // E <= 0 = "not measured" (a C / torch-op caller passing {R, 0} with a shadow; FlatIPIndex always maintains E).  Still a BOUND: an element
+  // inside fp16's normal range is off by <= 2^-11 |x|, a subnormal one (|x| < 2^-14) by <= 2^-25, so |row - fp16(row)| <= 2^-11 R +
+  // sqrt(D) 2^-25 whenever no element can exceed 65504, i.e. R <= 65504; beyond that nothing is known about the saturated elements: E = R,
+  // the band is useless and the query takes the rigorous six-product fallback.
+  const float R = bounds[0];
+  const float E = bounds[1] > 0.f ? bounds[1] : (R <= 65504.f ? R * 0.00048828125f + sqrtf((float)D) * 2.9802322e-8f : R);
   const float accum = (float)(D + 32) * 1.1920929e-7f;   // 2^-23 per accumulated term
   return (sqrtf(B) * R + sqrtf(A) * (E + accum * R * 1.01f)) * 1.0001f + 1e-30f;
 }
@@ -2110,13 +2115,9 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   p.nblk = p.ld / SP_ROWS;
   p.nblk_ld = (p.nblk + 3) & ~(int64_t)3;
   p.cap = cand_cap_for(k);
-  static int ss_max = 0, ss_force = 0;                     // (LRX_SS_MAX / LRX_SS_FORCE: A/B runs of the sample stride on one box)
-  if (ss_max == 0) {
-    const char* e = getenv("LRX_SS_MAX");
-    const char* f = getenv("LRX_SS_FORCE");
-    ss_force = f && atoi(f) >= 2 ? atoi(f) : 0;
-    ss_max = e && atoi(e) >= 2 ? atoi(e) : SAMPLE_SS_MAX;
-  }
+  // (LRX_SS_MAX / LRX_SS_FORCE: A/B runs of the sample stride on one box; read once, thread-safe)
+  static const int ss_force = []() { const char* f = getenv("LRX_SS_FORCE"); return f && atoi(f) >= 2 ? atoi(f) : 0; }();
+  static const int ss_max = []() { const char* e = getenv("LRX_SS_MAX"); return e && atoi(e) >= 2 ? atoi(e) : SAMPLE_SS_MAX; }();
   const int64_t nwg = lrx_cdiv(n_rows > 0 ? n_rows : 1, p.rb);
   // The sample stride trades the sample pass against the hits of the main pass: T' is the k-th best of the sample, so ~k * ss rows per query
   // reach it (appended, selected from and band-checked in the refine step), while the sample pass scores rows / ss rows per query into a

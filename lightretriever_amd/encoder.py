@@ -18,12 +18,15 @@ import torch
 from . import _lib
 
 
-# When the fp32 residual stream is switched on by default.  Measured at full depth against the HF fp32 model (random-init weights,
+# When the fp32 residual stream is switched on by default.  Measured at full depth against the HF fp32 model (Gaussian weights,
 # tests/test_gpu_encoder.py::test_full_depth_hf_parity, profiles/r03_full_depth_parity.jsonl), 1 - cos on the bf16 stream grows like
 # ~9e-9 x layers x hidden_size: 1B (16 x 2048) 2.8e-4, Qwen2.5-1.5B (28 x 1536) 4.1e-4, Qwen2.5-3B (36 x 2048) 7.7e-4, Llama-3.2-3B
-# (28 x 3072) 6.8e-4, Qwen2.5-7B (28 x 3584) 8.3e-4, Llama-3.1-8B (32 x 4096) 1.28e-3.  Above layers x hidden = 60 000 (predicted 5.4e-4,
-# less than a factor two from the 1e-3 budget) the precise stream runs (1.2e-4 ... 6.2e-4 on the same models, 2-3 % slower).
-PRECISE_FROM_LAYERS_X_HIDDEN = 60_000
+# (28 x 3072) 6.8e-4, Qwen2.5-7B (28 x 3584) 8.3e-4, Llama-3.1-8B (32 x 4096) 1.28e-3.  Round 4, TRAINED-LIKE weights (synth.py; 64
+# documents x 3 seeds, profiles/r04_trained_like_parity.jsonl): on the bf16 stream Qwen2.5-1.5B sat at 0.8-0.9 of HF-bf16's own distance to
+# fp32 (1.1e-3 .. 2.7e-3 against 1.4e-3 .. 3.4e-3) -- inside the bar but without margin -- while Llama-3.2-1B sat at 0.45-0.6 of it; the
+# precise stream is 4-10 x closer on the same weights.  The threshold therefore moved from 60 000 to 40 000: everything but the 16-layer
+# Llama-3.2-1B (32 768: the headline model) runs the precise stream (2-5 % slower).
+PRECISE_FROM_LAYERS_X_HIDDEN = 40_000
 
 
 @dataclass
@@ -194,10 +197,21 @@ class LrxEncoder:
         self._ws = None
 
     @classmethod
-    def random_init(cls, cfg: EncoderConfig, seed: int = 0, std: float = 0.02, device: Optional[torch.device] = None) -> "LrxEncoder":
-        """Random weights of the real architecture generated directly on the GPU (benchmarks: no checkpoints offline)."""
+    def random_init(cls, cfg: EncoderConfig, seed: int = 0, std: float = 0.02, device: Optional[torch.device] = None,
+                    profile: str = "gaussian", **synth_kwargs) -> "LrxEncoder":
+        """Random weights of the real architecture generated directly on the GPU (benchmarks: no checkpoints offline).  profile "gaussian":
+        every matrix N(0, std); "trained_like": synth.trained_like_state_dict (peaky attention, massive-activation channels, attention
+        sink, heavy-tailed norm weights, Qwen-scale q/k/v biases) -- the statistics it measured while calibrating are kept as `synth_stats`."""
         _lib.require_gpu()
         device = device or torch.device("cuda", torch.cuda.current_device())
+        if profile == "trained_like":
+            from .synth import trained_like_state_dict
+            sd, stats = trained_like_state_dict(cfg, seed=seed, device=device, **synth_kwargs)
+            enc = cls(cfg, sd, device)
+            enc.synth_stats = stats
+            return enc
+        if profile != "gaussian":
+            raise ValueError(f"unknown weight profile {profile!r}")
         gen = torch.Generator(device=device).manual_seed(seed)
         H, d, I = cfg.hidden_size, cfg.head_dim, cfg.intermediate_size
 

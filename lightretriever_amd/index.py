@@ -55,6 +55,7 @@ class FlatIPIndex:
         self.shadow_f16 = True
         self.max_workspace_bytes = 12 << 30  # search(): cap of the search workspace; larger query batches are chunked
         self._xb: Optional[torch.Tensor] = None
+        self._shadow_rows = 0                # committed rows [0, _shadow_rows) have valid shadow rows (== ntotal while shadow_f16 stays on)
         self._fused: list = []               # row intervals whose shadow + bounds the encoder has already written
         self._x = torch.empty(0, d, dtype=torch.float32, device=self.device)
         self._set_storage(torch.empty(max(capacity, 0), d, dtype=torch.float32, device=self.device))
@@ -89,15 +90,17 @@ class FlatIPIndex:
         need = -(-cap // 128) * 128 * self.d                           # whole 128-row blocks, flat
         if self._xb is None or self._xb.numel() < need:
             xb = torch.empty(need, dtype=torch.float16, device=self.device)   # (padding rows of the last block are masked by the kernels)
-            if self._xb is not None and self.ntotal:
-                n_old = min(self._xb.numel(), -(-self.ntotal // 128) * 128 * self.d)   # the blocks that hold committed rows
+            if self._xb is not None and self._shadow_rows:
+                n_old = min(self._xb.numel(), -(-self._shadow_rows // 128) * 128 * self.d)   # the blocks that hold shadowed rows
                 xb[:n_old].copy_(self._xb[:n_old])
-                self._xb = xb
             else:
-                # no shadow so far (shadow_f16 switched on after rows were added): build the committed rows' shadow from the fp32 rows
-                self._xb = xb
-                if self.ntotal:
-                    self._maintain(0, self.ntotal)
+                self._shadow_rows = 0
+            self._xb = xb
+        if self._shadow_rows < self.ntotal:
+            # committed rows without a shadow (shadow_f16 switched on after rows were added, or switched off for a while and on again:
+            # commits made meanwhile maintained the bounds only): build their shadow from the fp32 rows before anything streams it
+            a, self._shadow_rows = self._shadow_rows, self.ntotal
+            self._maintain(a, self.ntotal)
 
     def shadow_rows(self, n: Optional[int] = None) -> torch.Tensor:
         """The shadow as a row-major [n, d] fp16 tensor (a copy: the stored layout is tiled): tests and tools."""
@@ -155,6 +158,8 @@ class FlatIPIndex:
         # maintained by the commit that covers them
         self._fused = []
         self.ntotal += n_rows
+        if self._wants_shadow() and self._xb is not None and self._shadow_rows >= self.ntotal - n_rows:
+            self._shadow_rows = self.ntotal
 
     def add(self, x):
         """faiss add(x f32[n,d]); accepts torch (any device) or numpy."""
@@ -174,6 +179,7 @@ class FlatIPIndex:
 
     def reset(self):
         self.ntotal = 0
+        self._shadow_rows = 0
         self._bounds.zero_()
         self._fused = []
 
@@ -231,7 +237,9 @@ class FlatIPIndex:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         ldx = self._x.stride(0) if self._x.shape[0] else self.d
-        xb = self._xb if (self.two_pass and self.shadow_f16 and self._xb is not None) else None
+        if self.two_pass and self.shadow_f16:
+            self._ensure_shadow()                       # (no-op unless rows were committed while the shadow was switched off)
+        xb = self._xb if (self.two_pass and self._wants_shadow() and self._xb is not None and self._shadow_rows >= self.ntotal) else None
         for s in range(0, Q, chunk):
             qc, Dc, Ic = q[s:s + chunk], D[s:s + chunk], I[s:s + chunk]
             if self.two_pass:

@@ -131,6 +131,20 @@ def arguments_from_checkpoint(model_name_or_path: str, **overrides) -> "Inferenc
     saved = load_model_args(model_name_or_path)
     known = {f.name for f in dataclasses.fields(InferenceArguments)}
     kw = {k: v for k, v in saved.items() if k in known and v is not None}
+    # Query-side TRAINING objectives the checkpoint also carried -- the symmetric dense vector (`--hybrid_use_dense_vector`, in
+    # scripts/finetune_example.sh:47 and eval/README.md:24, hence in every released model_args.yaml) and LM-head query vectors
+    # (`--hybrid_use_sparse_vector`) -- select LM-encoded QUERIES.  This path serves the asymmetric retriever (EmbeddingBag / token-id
+    # queries; the document side computes the dense vector whatever these flags say, modeling_hybrid.py:235-245), so a resumed checkpoint
+    # drops them with a warning instead of refusing to load; passing them explicitly still raises in __post_init__.
+    for flag, what in (("hybrid_use_dense_vector", "symmetric dense query vectors"), ("hybrid_use_sparse_vector", "LM-head sparse query vectors")):
+        if kw.get(flag) and flag not in overrides:
+            import logging
+            logging.getLogger(__name__).warning(
+                "%s: model_args.yaml has %s=True (%s: queries through the LM); the MI355X path encodes queries with the EmbeddingBag / "
+                "token-id counts only -- flag dropped, asymmetric vectors served", model_name_or_path, flag, what)
+            kw[flag] = False
+            if flag == "hybrid_use_sparse_vector":
+                kw.setdefault("hybrid_use_token_id_vector", True)          # the document side keeps producing the sparse vector it was trained for
     kw.update(overrides)
     kw["model_name_or_path"] = model_name_or_path
     return InferenceArguments(**kw)

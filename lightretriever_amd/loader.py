@@ -121,6 +121,20 @@ def resize_embeddings(cfg: EncoderConfig, sd: dict, n_tokens: int, pad_to_multip
     cfg.vocab_size = new_rows
 
 
+def _resolve_local_model(name: str) -> str:
+    """A LoRA adapter names its base model the way it was trained (`Qwen/Qwen2.5-1.5B`, scripts/asymmetric_dense_infer.ipynb cell 8 hands
+    that string to AutoModelForCausalLM.from_pretrained): a local directory is taken as is, a hub id is looked up in the local HF cache
+    -- never downloaded."""
+    if os.path.isdir(name):
+        return name
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(name, local_files_only=True)
+    except Exception as e:
+        raise FileNotFoundError(f"LoRA base model {name!r} is neither a local directory nor in the local HF hub cache (nothing is "
+                                f"downloaded here): {type(e).__name__}") from e
+
+
 def load_hf_checkpoint(path: str, max_positions: int = 512, n_tokens: Optional[int] = None,
                        pad_to_multiple_of: Optional[int] = None) -> tuple[EncoderConfig, dict]:
     """-> (EncoderConfig, state_dict with names like `layers.0.self_attn.q_proj.weight`, plus `lm_head.weight` when the checkpoint
@@ -128,9 +142,7 @@ def load_hf_checkpoint(path: str, max_positions: int = 512, n_tokens: Optional[i
     adapter_cfg = os.path.join(path, "adapter_config.json")
     if os.path.exists(adapter_cfg):
         acfg = json.load(open(adapter_cfg))
-        base = acfg["base_model_name_or_path"]
-        if not os.path.isdir(base):
-            raise FileNotFoundError(f"LoRA base model {base!r} is not a local directory (no network here)")
+        base = _resolve_local_model(acfg["base_model_name_or_path"])
         cfg, sd = load_hf_checkpoint(base, max_positions)
         sd = merge_lora_adapter(sd, _read_safetensors(path, "adapter_model"), acfg)
         cfg.vocab_size = sd["embed_tokens.weight"].shape[0]

@@ -45,14 +45,25 @@ def test_golden_models_within_reference_bf16_band(name):
 
 
 @pytest.mark.parametrize("name", ["llama_small_d64", "llama_small_d128"])
-def test_hidden_states_track_bf16_oracle(name):
+def test_hidden_states_layer_by_layer_against_the_fp32_oracle(name):
+    """Per-layer check (the small goldens carry no hidden states of their own, the oracle that produces them is pinned
+    by the tiny goldens' `layer_hidden` in tests/test_oracle_golden.py): the model truncated to its first l layers, every token's final-norm
+    hidden state against the fp32 restatement.  Bounds = what bf16 output rounding plus l layers of bf16 operands leave (measured 2-3 x
+    below): a wrong mask, position, head mapping or residual in ANY layer moves a token by percent, not by 1e-3."""
+    import dataclasses
     cfg, w, g, ids, cu, max_len = load_model_golden(name)
-    enc = make_encoder(cfg, w)
-    h = enc.encode_hidden(to_dev(ids, torch.int32), to_dev(cu, torch.int32), max_len).float().cpu().numpy()
-    want = O.encoder_forward_packed(cfg, w, ids, cu, bf16=True)
-    # bf16 pipelines with different rounding points: compare per-token direction and overall scale
-    assert min_cos(h, want) > 0.995
-    assert abs(np.linalg.norm(h) / np.linalg.norm(want) - 1) < 1e-2
+    for l in range(1, cfg.num_layers + 1):
+        cfg_l = dataclasses.replace(cfg, num_layers=l)
+        enc = make_encoder(cfg_l, w)
+        h = enc.encode_hidden(to_dev(ids, torch.int32), to_dev(cu, torch.int32), max_len).float().cpu().numpy().astype(np.float64)
+        want = O.encoder_forward_packed(cfg_l, w, ids, cu, bf16=False).astype(np.float64)
+        rel = np.linalg.norm(h - want, axis=1) / np.linalg.norm(want, axis=1)
+        cos_gap = 1 - (h * want).sum(1) / (np.linalg.norm(h, axis=1) * np.linalg.norm(want, axis=1))
+        print("layer-by-layer %s depth %d: rel L2 max %.2e, 1-cos max %.2e" % (name, l, rel.max(), cos_gap.max()))
+        # measured (d = 64, three layers): rel 8.0e-3 / 1.03e-2 / 1.27e-2, 1 - cos 3.2e-5 / 5.4e-5 / 8.0e-5 -- one bf16 output rounding plus
+        # ~2.4e-3 (2.4e-5) per layer
+        assert rel.max() < 1.0e-2 + 3e-3 * l and cos_gap.max() < 4e-5 + 3e-5 * l, (name, l, rel.max(), cos_gap.max())
+        assert abs(np.linalg.norm(h) / np.linalg.norm(want) - 1) < 2e-3
 
 
 def medium_case(d, qkv_bias=False, seed=3):
@@ -235,77 +246,33 @@ def test_released_backbone_dims_hf_parity(preset, layers):
     torch.cuda.empty_cache()
 
 
-def _hf_model_for(cfg):
-    """The HF transformers model (fp32, on the GPU) of an EncoderConfig: what finetune/modeling_hybrid.py:248-260 calls."""
-    common = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_layers,
-                  num_attention_heads=cfg.num_q_heads, num_key_value_heads=cfg.num_kv_heads, rms_norm_eps=cfg.rms_eps, attn_implementation="sdpa")
-    if cfg.qkv_bias:
-        from transformers import Qwen2Config, Qwen2Model
-        hf_cfg = Qwen2Config(max_position_embeddings=32768, rope_parameters={"rope_type": "default", "rope_theta": cfg.rope_theta},
-                             use_sliding_window=False, **common)
-        with torch.device("cuda"):
-            return Qwen2Model(hf_cfg).float().eval()
-    from transformers import LlamaConfig, LlamaModel
-    hf_cfg = LlamaConfig(head_dim=cfg.head_dim, max_position_embeddings=131072,
-                         rope_parameters={"rope_type": "llama3", "rope_theta": cfg.rope_theta, "factor": cfg.rope_factor,
-                                          "low_freq_factor": cfg.rope_low_freq_factor, "high_freq_factor": cfg.rope_high_freq_factor,
-                                          "original_max_position_embeddings": cfg.rope_original_max_position}, **common)
-    with torch.device("cuda"):
-        return LlamaModel(hf_cfg).float().eval()
+FULL_DEPTH_CASES = [(p, sd) for p in ("llama31_8b", "qwen25_7b") for sd in (0, 1, 2)] + [(p, 0) for p in ("llama32_3b", "qwen25_3b", "qwen25_1_5b", "llama32_1b")]
 
 
-FULL_DEPTH_MARGINS = {}     # preset -> {variant: max (1 - cos)}; printed by the last case (pytest -s) and by tools/parity_margin.py --all
-
-
-@pytest.mark.parametrize("preset", ["llama31_8b", "qwen25_7b", "llama32_3b", "qwen25_3b", "qwen25_1_5b", "llama32_1b"])
-def test_full_depth_hf_parity(preset):
-    """every released backbone at its REAL depth (32 / 28 / 28 / 36 / 28 layers; BASELINE configs 2-4 are the 32-layer
-    Llama-3.1-8B), random-init at the real config, documents of 512 / 1 / 129 / ... tokens, against the HF transformers fp32 model on the
-    same GPU (the forward finetune/modeling_hybrid.py:248-278 runs): 1 - cos <= 1e-3 for the full embedding and for the MRL slice
-    out_dim = 256 (BASELINE config 5).  Round 3: with the bf16 residual stream of round 2 the 32-layer model was at 2.4e-3 -- deep
-    backbones now run the precise stream (fp32 stream, exact weights; fp32 RoPE and fp16 q|k|v for every model)."""
-    import dataclasses
-    from lightretriever_amd import EncoderConfig, LrxEncoder
+@pytest.mark.parametrize("preset,seed", FULL_DEPTH_CASES)
+def test_full_depth_hf_parity(preset, seed):
+    """Every released backbone at its REAL depth (32 / 28 / 28 / 36 / 28 / 16 layers; BASELINE configs 2-4 are the 32-layer Llama-3.1-8B),
+    Gaussian random-init at the real config, against the HF transformers fp32 model on the same GPU (the forward
+    finetune/modeling_hybrid.py:248-278 runs): 1 - cos <= 1e-3 for the full embedding and for the MRL slice out_dim = 256 (BASELINE config 5).
+    Round 4 (VERDICT r3 item 2): 64 documents of mixed lengths (512, 1, 2, 511, ...) instead of 7, three weight seeds for the 8B and the 7B;
+    the MAX is asserted, p50 / p99 recorded (gpurun_out/r04_full_depth_parity.jsonl -> profiles/).  The trained-like counterpart of this
+    test is tests/test_gpu_trained_like.py."""
+    import json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import parity_margin as pm
+    from lightretriever_amd import EncoderConfig, encoder as E
     cfg = getattr(EncoderConfig, preset)()
-    enc = LrxEncoder.random_init(cfg, seed=5)
-    g = torch.Generator().manual_seed(2024)
-    lens = [512, 1, 129, 300, 64, 511, 17]
-    ids = torch.randint(1000, 127000, (sum(lens),), generator=g, dtype=torch.int64).to(torch.int32).cuda()
-    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32).cuda()
-    hf = _hf_model_for(cfg)
-    sd = enc.hf_state_dict()
-    missing, unexpected = hf.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
-    assert not unexpected and all("rotary" in m for m in missing), (missing, unexpected)
-    hs = []
-    with torch.no_grad():
-        for b in range(len(lens)):
-            hs.append(hf(input_ids=ids[cu[b]:cu[b + 1]].long()[None], use_cache=False).last_hidden_state[0, -1])
-    del hf
-    torch.cuda.empty_cache()
-    h = torch.stack(hs)
-    ref, ref256 = torch.nn.functional.normalize(h, dim=-1), torch.nn.functional.normalize(h[:, :256], dim=-1)
-    m = {}
-    deep = cfg.num_layers * cfg.hidden_size >= 60_000                    # encoder.PRECISE_FROM_LAYERS_X_HIDDEN: fp32 residual stream + exact weights;
-    assert enc.precise == deep                                           # Llama-3.2-1B (the headline model) and Qwen2.5-1.5B keep the bf16 stream
-    out = enc.encode_packed(ids, cu, 512)
-    assert torch.equal(out, enc.encode_packed(ids, cu, 512))
-    per_doc = (1 - (ref * out).sum(-1)).tolist()
-    m["default_mode"] = "precise_stream" if deep else "bf16_stream_folded_norm"
-    m["precise"] = max(per_doc)                                          # (key names kept from the first version of this test: the DEFAULT mode's margins)
-    m["precise_mrl256"] = (1 - (ref256 * enc.encode_packed(ids, cu, 512, out_dim=256)).sum(-1)).max().item()
-    del enc
-    torch.cuda.empty_cache()
-    # for the record (not asserted): the other stream mode at this depth (deep models: the bf16 stream with folded norm weights, i.e. the
-    # headline configuration; the 1B: the precise stream)
-    enc_b = LrxEncoder(dataclasses.replace(cfg, precise_stream=not deep), sd)
-    m["bf16_stream_folded" if deep else "precise_stream_for_comparison"] = (1 - (ref * enc_b.encode_packed(ids, cu, 512)).sum(-1)).max().item()
-    del enc_b, sd
-    torch.cuda.empty_cache()
-    FULL_DEPTH_MARGINS[preset] = m
-    print("full-depth parity %s (%d layers): %s" % (preset, cfg.num_layers, {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in m.items()}))
-    import json, os
-    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    rec = pm.measure(preset, seed=seed, profile="gaussian", n_docs=64)
+    deep = cfg.num_layers * cfg.hidden_size >= E.PRECISE_FROM_LAYERS_X_HIDDEN      # fp32 residual stream + exact weights; only Llama-3.2-1B (the
+    assert rec["stream"] == ("precise_fp32" if deep else "bf16_folded_norm")         # headline model) keeps the bf16 stream
+    assert deep == (preset != "llama32_1b")
+    print("full-depth parity %s seed %d (%d layers, %s): max %.2e p99 %.2e p50 %.2e; MRL-256 max %.2e; HF bf16 %.2e" % (
+        preset, seed, cfg.num_layers, rec["stream"], rec["lrx_vs_fp32"]["max"], rec["lrx_vs_fp32"]["p99"], rec["lrx_vs_fp32"]["p50"],
+        rec["lrx_vs_fp32_mrl"]["max"], rec["hfbf16_vs_fp32"]["max"]))
+    out_dir = os.path.join(root, "gpurun_out")
     if os.path.isdir(out_dir):                                   # (the margins DESIGN.md section 3 quotes come from this file)
-        with open(os.path.join(out_dir, "full_depth_parity.jsonl"), "a") as f:
-            f.write(json.dumps({"preset": preset, "layers": cfg.num_layers, **m}) + "\n")
-    assert max(m["precise"], m["precise_mrl256"]) <= COS_TOL, (preset, m, per_doc)
+        with open(os.path.join(out_dir, "r04_full_depth_parity.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    assert rec["fp16_saturations"] == 0
+    assert max(rec["lrx_vs_fp32"]["max"], rec["lrx_vs_fp32_mrl"]["max"]) <= COS_TOL, (preset, seed, rec)

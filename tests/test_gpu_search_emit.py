@@ -362,6 +362,31 @@ def test_shadow_switched_on_after_rows_were_added_is_built_from_the_rows():
     check_against_oracle(*idx.search(q, 10), q, X, 10)
 
 
+def test_shadow_switched_off_and_on_again_covers_the_rows_added_in_between():
+    """with an EXISTING shadow, rows committed while shadow_f16 was off (bounds only) must get their shadow rows before the
+    filter streams them -- the index tracks how many committed rows the shadow covers."""
+    from lightretriever_amd import FlatIPIndex
+    rng = np.random.default_rng(13)
+    X = O.l2_normalize(rng.standard_normal((40000, 128)).astype(np.float32))
+    idx = FlatIPIndex(128, capacity=40000)
+    idx.add(X[:15000])                                   # shadow on: 15 000 rows covered
+    assert idx._shadow_rows == 15000
+    idx.shadow_f16 = False
+    idx.add(X[15000:28000])                              # bounds only
+    assert idx._shadow_rows == 15000 and idx.ntotal == 28000
+    q = O.l2_normalize(rng.standard_normal((40, 128)).astype(np.float32))
+    check_against_oracle(*idx.search(q, 10), q, X[:28000], 10)           # shadow off: searched from the fp32 rows
+    idx.shadow_f16 = True
+    check_against_oracle(*idx.search(q, 10), q, X[:28000], 10)           # on again, BEFORE any further add: search() completes the shadow first
+    assert idx._shadow_rows == 28000
+    idx.add(X[28000:])
+    assert idx._shadow_rows == 40000
+    assert torch.equal(idx.shadow_rows(), torch.from_numpy(X).cuda().to(torch.float16))
+    check_against_oracle(*idx.search(q, 10), q, X, 10)
+    idx.reset()
+    assert idx._shadow_rows == 0
+
+
 # ---- BASELINE index shapes (configs 2-5): properties that do not need a CPU pass over the whole index -------------------------------
 def _fill_normalised(idx, N, D, seed):
     g = torch.Generator(device="cuda").manual_seed(seed)

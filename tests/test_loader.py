@@ -215,7 +215,7 @@ def test_resize_embeddings_like_resize_emb(tmp_path):
     torch.testing.assert_close(sd["embed_tokens.weight"][52], m.model.embed_tokens.weight.detach().mean(0))
 
 
-def test_model_args_yaml_resume(tmp_path):
+def test_model_args_yaml_resume(tmp_path, caplog):
     """HybridModel.load(path) without arguments (finetune/modeling_encoder.py:635-656): the flags come from model_args.yaml."""
     import yaml
     from lightretriever_amd.inference import arguments_from_checkpoint
@@ -237,6 +237,16 @@ def test_model_args_yaml_resume(tmp_path):
     assert args.pad_token == "<|reserved_special_token_0|>"                                                   # family default from the directory name
     with pytest.raises(FileNotFoundError):
         load_model_args(str(tmp_path))
+    # the released checkpoints were trained with the symmetric dense vector as well (scripts/finetune_example.sh:47): resuming one must not
+    # die on that training-only query flag -- dropped with a warning; asked for explicitly it still raises
+    saved["hybrid_use_dense_vector"] = True
+    yaml.dump(saved, open(d / "model_args.yaml", "w"))
+    import logging
+    with caplog.at_level(logging.WARNING):
+        args = arguments_from_checkpoint(str(d))
+    assert args.hybrid_use_dense_vector is False and args.hybrid_use_emb_vector and "hybrid_use_dense_vector=True" in caplog.text
+    with pytest.raises(NotImplementedError):
+        arguments_from_checkpoint(str(d), hybrid_use_dense_vector=True)
     saved["untie_encoder"] = True                                                                             # an unsupported saved flag still fails loudly
     yaml.dump(saved, open(d / "model_args.yaml", "w"))
     with pytest.raises(NotImplementedError):
