@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra single-GPU legs (BASELINE configs 2-4, 8-way shard, top_k = 1000)")
     ap.add_argument("--no-sparse", action="store_true", help="skip the dense+sparse document-vector leg (SURVEY 8f N2)")
+    ap.add_argument("--legs", default="all", help="comma list of encode,search,sparse,configs,cpu (default all): one leg per run gives one "
+                    "rocprofv3 kernel-stats file per leg (tools/final_profile.sh); a partial run is marked `partial_run` and is not the headline")
+    ap.add_argument("--config-legs", default="all", help="comma list of the `configs` entries to run (default all)")
     ap.add_argument("--ragged", action="store_true",
                     help="document lengths ~ clip(lognormal(5.3, 0.6), 16, seq_len), sorted longest first (mirrors hybrid_search.py:273-276) "
                          "instead of the fixed-length headline workload")
@@ -267,6 +270,187 @@ def extra_legs(args, dev, headline_index):
     CORPUS_CHUNK_SIZE = 100 000 (eval/call_evaluate_mteb.sh:9-10) and over the 1M index."""
     from lightretriever_amd import EncoderConfig, LrxEncoder
     legs = {}
+    only = None if args.config_legs == "all" else set(args.config_legs.split(","))
+    want = lambda name: only is None or name in only
+    if want("measured_ceilings"):
+        legs["measured_ceilings"] = measured_ceilings(dev)
+    if want("search_clustered"):
+        legs["search_clustered"] = clustered_search_legs(dev)
+    if want("n1_embedding_bag_build"):
+        legs["n1_embedding_bag_build"] = embedding_bag_build_leg(args, dev)
+    if want("n4_index_persistence"):
+        legs["n4_index_persistence"] = index_persistence_leg(dev)
+    if want("top_k_1000"):
+        legs["top_k_1000"] = topk1000_legs(dev, headline_index)
+    if want("search_per_shard_8way"):
+        legs["search_per_shard_8way"] = per_shard_leg(dev)
+    # ---- BASELINE configs[2] / configs[3] index shape (8B width) and configs[4] (MRL 256, 10M rows) on one GPU; what ONE rank of the 8-GPU
+    #      configurations holds (10M rows row-sharded 8 ways): configs[3] 1.25M x 4096, configs[4] 1.25M x 256
+    for name, shape in (("config2_search_1Mx4096", (1_000_000, 4096, 51)), ("config4_search_10Mx256", (10_000_000, 256, 61)),
+                        ("config3_per_rank_shard_1250kx4096", (1_250_000, 4096, 71)), ("config4_per_rank_shard_1250kx256", (1_250_000, 256, 81))):
+        if want(name):
+            legs[name] = search_leg(shape[0], shape[1], 100, 100, dev, 20, seed=shape[2])
+    if want("config2_encode_llama31_8b"):
+        legs["config2_encode_llama31_8b"] = encode_8b_leg(args, dev)
+    if want("ragged_encode_llama32_1b"):
+        legs["ragged_encode_llama32_1b"] = ragged_encode_leg(args, dev)
+    return legs
+
+
+def measured_ceilings(dev):
+    """measured ceilings next to the spec peaks, IN this run on this box: (a) a plain streaming read of 4 GiB (liblrx's
+    k_stream_read: nothing but 16-B loads in flight) -- the HBM rate the search filter can at best approach; (b) the vendor bf16 GEMM
+    (torch.matmul -> hipBLASLt) on the four projection shapes of the headline model, no fused epilogue -- what a library GEMM reaches
+    under the same power cap."""
+    import ctypes as C
+    from lightretriever_amd import _lib
+    lib = _lib.lib()
+    out = {}
+    buf = torch.empty(1 << 30, dtype=torch.int32, device=dev)           # 4 GiB (well beyond the 256-MiB Infinity Cache)
+    buf.zero_()
+    best = None
+    for n_wg in (1024, 2048, 4096, 8192):
+        sink = torch.zeros(n_wg, dtype=torch.int32, device=dev)
+        fn = lambda: _lib.check(lib.lrx_probe_stream_read(_lib.ptr(buf), buf.numel() * 4, _lib.ptr(sink), n_wg, _lib.current_stream()))
+        ms, _ = time_search(fn, 6)
+        gbs = buf.numel() * 4 / (ms * 1e-3) / 1e9
+        if best is None or gbs > best[1]:
+            best = (n_wg, gbs)
+    del buf
+    out["hbm_stream_read"] = {"value": round(best[1], 1), "unit": "GB/s", "bytes": 4 << 30, "workgroups": best[0],
+                              "frac_of_spec_peak": round(best[1] / PEAK_HBM_GBS, 4), "kernel": "k_stream_read (lrx_probe_stream_read)"}
+    M = 131072
+    g = torch.Generator(device=dev).manual_seed(0)
+    vg = {}
+    for name, N, K in (("gate_up", 16384, 2048), ("qkv", 3072, 2048), ("o", 2048, 2048), ("down", 2048, 8192)):
+        A = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
+        B = (torch.randn(N, K, generator=g, device=dev) * 0.02).to(torch.bfloat16)
+        ms, med = time_search(lambda: torch.matmul(A, B.t()), 10, warm=3)
+        vg[name] = {"M": M, "N": N, "K": K, "ms_median": round(med, 4), "tflops": round(2.0 * M * N * K / (med * 1e-3) / 1e12, 1)}
+        del A, B
+    out["vendor_gemm_bf16"] = {"library": "torch.matmul (hipBLASLt / rocBLAS), plain C = A B^T, no fused epilogue", "shapes": vg,
+                               "gate_up_frac_of_spec_peak": round(vg["gate_up"]["tflops"] / PEAK_BF16_TFLOPS, 4)}
+    torch.cuda.empty_cache()
+    return out
+
+
+def clustered_search_legs(dev):
+    """the headline search on NON-iid rows -- 1 000 vMF-like clusters (intra-cluster cosine ~0.9), 1 % exact duplicates,
+    queries near cluster centres -- rows iid over the clusters and rows stored cluster by cluster; next to the time: the rows per query that
+    passed the filter threshold and reached the refine step, and the queries that took the exact fallback.  Exactness of the same
+    workload: tests/test_gpu_search_clustered.py."""
+    from lightretriever_amd import FlatIPIndex, _lib
+    from lightretriever_amd.synth import clustered_corpus, cluster_queries
+    lib = _lib.lib()
+    out = {}
+    N, D, Q, k, passes = 1_000_000, 2048, 100, 100, 20
+    for order in ("shuffled", "by_cluster"):
+        idx = FlatIPIndex(D, capacity=N, device=dev)
+        info = clustered_corpus(idx.append_slot(N), n_clusters=1000, intra_cos=0.9, dup_frac=0.01, seed=5, order=order)
+        idx.commit(N)
+        q = cluster_queries(info["centres"], Q, query_cos=0.9, seed=6)
+        idx.search(q, k)
+        hits = idx.last_list_counts().float()
+        torch.cuda.synchronize()
+        lib.lrx_search_fallback_count(1)
+        mean_ms, med_ms = time_search(lambda: idx.search(q, k), passes, warm=1)
+        n_fb = int(lib.lrx_search_fallback_count(1))
+        out[order] = {"workload": "exact top-%d of %d queries near cluster centres over %d x %d rows in 1000 clusters (intra-cluster cosine 0.9, "
+                                  "1 %% exact duplicates), rows %s" % (k, Q, N, D, "iid over the clusters" if order == "shuffled" else "stored cluster by cluster"),
+                      "ms": round(mean_ms, 4), "ms_median": round(med_ms, 4), "passes": passes, "roofline": hbm_roofline(N, D, Q, k, mean_ms),
+                      "filter_hits_per_query": {"mean": round(hits.mean().item(), 1), "max": int(hits.max().item()), "list_capacity": 16384},
+                      "fallback_queries_per_pass": round(n_fb / (passes + 1), 2)}
+        del idx, info
+        torch.cuda.empty_cache()
+    return out
+
+
+def embedding_bag_build_leg(args, dev):
+    """Row N1 (finetune/nonctx_emb_utils.py:239-313): seconds to build the [vocab, H] query table of the headline model -- the shared-prefix
+    build (prefix encoded once, lrx_encode_prefixed) over the whole vocabulary, and the reference's literal loop (every `[bos] prompt tok
+    [eos]` sequence in full, lrx_encode_packed) timed on 20 000 rows and scaled."""
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    cfg = EncoderConfig.llama32_1b(args.seq_len)
+    enc = LrxEncoder.random_init(cfg, seed=0, device=dev)
+    V, H, P, bs = cfg.vocab_size, cfg.hidden_size, 21, 5000           # [bos] + a 20-token instruction
+    pre = torch.randint(5, 1000, (P,), dtype=torch.int32, device=dev)
+    L = P + 2
+
+    def fast():
+        table = torch.empty(V, H, dtype=torch.float32, device=dev)
+        step = bs * max(1, L // 2)
+        for s0 in range(0, V, step):
+            e = min(s0 + step, V)
+            suf = torch.empty(e - s0, 2, dtype=torch.int32, device=dev)
+            suf[:, 0] = torch.arange(s0, e, dtype=torch.int32, device=dev)
+            suf[:, 1] = 2
+            enc.encode_prefixed(pre, suf, out=table[s0:e])
+        return table
+
+    def literal(rows):
+        table = torch.empty(rows, H, dtype=torch.float32, device=dev)
+        base = torch.empty(bs, L, dtype=torch.int32, device=dev)
+        base[:, :P] = pre
+        base[:, -1] = 2
+        for s0 in range(0, rows, bs):
+            e = min(s0 + bs, rows)
+            base[:e - s0, -2] = torch.arange(s0, e, dtype=torch.int32, device=dev)
+            cu = (torch.arange(e - s0 + 1, device=dev, dtype=torch.int64) * L).to(torch.int32)
+            enc.encode_packed(base[:e - s0].reshape(-1), cu, L, out=table[s0:e], normalize=False)
+        return table
+
+    fast()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tf = fast()
+    torch.cuda.synchronize()
+    t_fast = time.perf_counter() - t0
+    rows = 20000
+    literal(bs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tl = literal(rows)
+    torch.cuda.synchronize()
+    t_lit = (time.perf_counter() - t0) * V / rows
+    cos = torch.nn.functional.cosine_similarity(tf[:rows], tl, dim=-1).min().item()
+    del enc, tf, tl
+    torch.cuda.empty_cache()
+    return {"workload": "EmbeddingBag table [%d, %d] of lightretriever-llama3.2-1b dims, %d-token shared prefix + [tok, eos]" % (V, H, P),
+            "shared_prefix_build_s": round(t_fast, 3), "literal_full_sequence_build_s_scaled_from_%d_rows" % rows: round(t_lit, 3),
+            "speedup": round(t_lit / t_fast, 2), "min_cosine_between_the_two_tables": round(cos, 6)}
+
+
+def index_persistence_leg(dev):
+    """Row N4 (retriever/faiss_search.py:99-123): save / load rate of a shard in the Faiss flat-index file layout (200 000 x 2048 fp32 =
+    1.6 GB through /tmp), and that the reloaded shard returns the same bits."""
+    import tempfile
+    from lightretriever_amd import FlatIPIndex
+    N, D = 200_000, 2048
+    idx, g = synthetic_index(N, D, dev, 91)
+    q = torch.nn.functional.normalize(torch.randn(100, D, generator=g, device=dev), dim=-1)
+    D0, I0 = idx.search(q, 100)
+    gb = N * D * 4 / 1e9
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
+        f = os.path.join(td, "shard.flat.faiss")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx.save(f)
+        t_save = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        idx2 = FlatIPIndex.load(f, device=dev)
+        torch.cuda.synchronize()
+        t_load = time.perf_counter() - t0
+    D1, I1 = idx2.search(q, 100)
+    same = bool(torch.equal(D0, D1) and torch.equal(I0, I1))
+    del idx, idx2
+    torch.cuda.empty_cache()
+    return {"workload": "FlatIPIndex.save / load of %d x %d fp32 rows (%.2f GB, Faiss IndexFlatIP file layout) through a temporary directory; the "
+                        "load includes rebuilding the fp16 shadow and the bounds on the GPU" % (N, D, gb),
+            "save_gb_per_s": round(gb / t_save, 2), "load_gb_per_s": round(gb / t_load, 2), "save_s": round(t_save, 2), "load_s": round(t_load, 2),
+            "hits_identical_after_reload": same}
+
+
+def topk1000_legs(dev, headline_index):
     # ---- top_k = 1000 (the reference's default), Q = 100 and 1000, over the headline index and over one 100k-row chunk
     k1000 = {}
     if headline_index is not None and headline_index.d == 2048 and headline_index.ntotal == 1_000_000:
@@ -279,9 +463,12 @@ def extra_legs(args, dev, headline_index):
     for Qx, passes in ((100, 20), (1000, 5)):
         k1000["100kx2048_Q%d" % Qx] = search_leg(100_000, 2048, Qx, 1000, dev, passes, index=idx100k)
     del idx100k
-    legs["top_k_1000"] = k1000
+    return k1000
+
+
+def per_shard_leg(dev):
     # ---- the per-rank shard of the 8-GPU headline search: 125 000 x 2048, Q = 100, k = 100, + the exchange on a 1-rank RCCL group
-    from lightretriever_amd.sharded import exchange_merge
+    from lightretriever_amd.sharded import ShardedFlatIPIndex, _collective
     sh, g = synthetic_index(125_000, 2048, dev, 41)
     q = torch.nn.functional.normalize(torch.randn(100, 2048, generator=g, device=dev), dim=-1)
     local_ms, local_med = time_search(lambda: sh.search(q, 100), 40)
@@ -294,27 +481,31 @@ def extra_legs(args, dev, headline_index):
                 port = so.getsockname()[1]
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
-        exchange_merge(*sh.search(q, 100), force_collective=True, id_base=0)       # communicator set-up outside the timing
+        os.environ["LRX_FORCE_COLLECTIVE"] = "1"                                   # one-rank rehearsal: the exchange runs its collective
+        shd = ShardedFlatIPIndex(sh)
+        assert _collective(None, False)
+        shd.search(q, 100)                                                         # communicator set-up outside the timing
         rccl = "1-rank RCCL all_gather_into_tensor"
-        full_ms, full_med = time_search(lambda: exchange_merge(*sh.search(q, 100), force_collective=True, id_base=0), 40)
+        full_ms, full_med = time_search(lambda: shd.search(q, 100), 40)
     except Exception as e:  # noqa: BLE001  (the local time stands on its own; say why the exchange is missing)
         rccl = "unavailable: %r" % (e,)
         full_ms = full_med = None
-    legs["search_per_shard_8way"] = {
-        "workload": "what ONE rank of an 8-GPU run of the headline search does: exact top-100 of 100 queries over its 125 000 x 2048 shard, then "
-                    "lrx_pack_topk -> all-gather of [Q,k] words -> lrx_merge_topk_packed", "local_search_ms": round(local_ms, 4),
+    finally:
+        os.environ.pop("LRX_FORCE_COLLECTIVE", None)
+    out = {
+        "workload": "what ONE rank of an 8-GPU run of the headline search does: exact top-100 of 100 queries over its 125 000 x 2048 shard (the wire "
+                    "words written by the search's own last kernel) -> all-gather of [Q,k] words -> lrx_merge_topk_packed", "local_search_ms": round(local_ms, 4),
         "local_search_ms_median": round(local_med, 4), "with_exchange_ms": None if full_ms is None else round(full_ms, 4),
         "with_exchange_ms_median": None if full_med is None else round(full_med, 4), "exchange": rccl,
         "roofline": hbm_roofline(125_000, 2048, 100, 100, local_ms)}
     del sh
     torch.cuda.empty_cache()
-    # ---- BASELINE configs[2] / configs[3] index shape (8B width) and configs[4] (MRL 256, 10M rows) on one GPU
-    legs["config2_search_1Mx4096"] = search_leg(1_000_000, 4096, 100, 100, dev, 20, seed=51)
-    legs["config4_search_10Mx256"] = search_leg(10_000_000, 256, 100, 100, dev, 20, seed=61)
-    # ---- what ONE rank of the 8-GPU configurations holds (10M rows row-sharded 8 ways): configs[3] 1.25M x 4096, configs[4] 1.25M x 256
-    legs["config3_per_rank_shard_1250kx4096"] = search_leg(1_250_000, 4096, 100, 100, dev, 20, seed=71)
-    legs["config4_per_rank_shard_1250kx256"] = search_leg(1_250_000, 256, 100, 100, dev, 20, seed=81)
+    return out
+
+
+def encode_8b_leg(args, dev):
     # ---- BASELINE configs[2]: Llama-3.1-8B dims, 128 documents x seq_len per step
+    from lightretriever_amd import EncoderConfig, LrxEncoder
     cfg8 = EncoderConfig.llama31_8b(args.seq_len)
     enc8 = LrxEncoder.random_init(cfg8, seed=0, device=dev)
     B8, S = 128, args.seq_len
@@ -333,7 +524,7 @@ def extra_legs(args, dev, headline_index):
     gu8 = enc8.get_profile()["gemm_swiglu"]
     enc8.set_profiling(False)
     tf8 = gu8["flops"] / (gu8["ms"] * 1e-3) / 1e12 if gu8["ms"] > 0 else 0.0
-    legs["config2_encode_llama31_8b"] = {
+    out = {
         "workload": "lightretriever-llama3.1-8b dims bf16, %d docs/step x seq_len %d, 2 timed steps after 1 warm-up (BASELINE configs[2] encoder)" % (B8, S),
         "docs_per_s": round(2 * B8 / t8, 2), "ms_per_step": round(1e3 * t8 / 2, 2),
         "end_to_end_tflops": round(2 * B8 / t8 * cfg8.flops_per_doc(S) / 1e12, 1),
@@ -342,9 +533,15 @@ def extra_legs(args, dev, headline_index):
                      "avg_launch_ms": round(gu8["ms"] / max(gu8["launches"], 1), 4), "launches": gu8["launches"], "traffic": None}}
     del enc8, out8, ids8
     torch.cuda.empty_cache()
+    return out
+
+
+def ragged_encode_leg(args, dev):
     # ---- SURVEY 8d's ragged variant of the headline encoder: lengths clip(lognormal(5.3, 0.6), 16, S) sorted longest first (the reference
     #      sorts its corpus that way, hybrid_search.py:273-276), 256 documents per step, 1 warm-up + 3 timed steps
     import numpy as np
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    S = args.seq_len
     cfg1 = EncoderConfig.llama32_1b(args.seq_len)
     enc1 = LrxEncoder.random_init(cfg1, seed=0, device=dev)
     B1, n1 = 256, 4
@@ -365,7 +562,7 @@ def extra_legs(args, dev, headline_index):
     torch.cuda.synchronize()
     t1 = time.perf_counter() - t0
     tl = lens[B1:]
-    legs["ragged_encode_llama32_1b"] = {
+    out = {
         "workload": "lightretriever-llama3.2-1b dims bf16, %d docs/step, lengths clip(lognormal(5.3,0.6),16,%d) sorted longest first, %d timed steps "
                     "after 1 warm-up (SURVEY 8d ragged variant; not the headline)" % (B1, S, n1 - 1),
         "docs_per_s": round((n1 - 1) * B1 / t1, 1), "tokens_per_s": round(float(tl.sum()) / t1, 0), "mean_tokens_per_doc": round(float(tl.mean()), 1),
@@ -373,7 +570,14 @@ def extra_legs(args, dev, headline_index):
         "end_to_end_tflops": round(float(sum(cfg1.flops_per_doc(int(x)) for x in tl)) / t1 / 1e12, 1)}
     del enc1, out1, rb
     torch.cuda.empty_cache()
-    return legs
+    return out
+
+
+def shard_split(index_rows, rank, world):
+    """(rows, first global row) of rank `rank` of a row-sharded index of `index_rows` rows: contiguous ranges, index_rows // world rows
+    each, the remainder one row each to the first ranks -- every row has exactly one owner for ANY world size."""
+    base, rem = divmod(index_rows, world)
+    return base + (1 if rank < rem else 0), rank * base + min(rank, rem)
 
 
 def launch_ranks(args):
@@ -411,6 +615,8 @@ def main():
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ["LRX_FORCE_COLLECTIVE"] = "1"      # the one-rank rehearsal runs the exchange's all-gather + merge too (sharded.py)
     dev = torch.device("cuda", local_rank)
 
     from lightretriever_amd import EncoderConfig, FlatIPIndex, LrxEncoder
@@ -420,9 +626,26 @@ def main():
            "qwen2.5-1.5b": EncoderConfig.qwen25_1_5b, "qwen2.5-3b": EncoderConfig.qwen25_3b, "qwen2.5-7b": EncoderConfig.qwen25_7b}[args.model](args.seq_len)
     if os.environ.get("LRX_FOLD_NORM") is not None:          # dev A/B switch; the default is the library's (folded)
         cfg.fold_norm = os.environ["LRX_FOLD_NORM"] != "0"
-    enc = LrxEncoder.random_init(cfg, seed=0, device=dev)
+    all_legs = ("encode", "search", "sparse", "configs", "cpu")
+    legs = set(all_legs) if args.legs == "all" else set(args.legs.split(","))
+    if legs - set(all_legs):
+        sys.stderr.write("bench.py: unknown --legs %s\n" % sorted(legs - set(all_legs)))
+        sys.exit(2)
+    partial = legs != set(all_legs)
+    if args.no_search:
+        legs.discard("search")
+    if args.no_sparse:
+        legs.discard("sparse")
+    if args.no_configs:
+        legs.discard("configs")
+    if args.no_cpu_baseline:
+        legs.discard("cpu")
+    need_enc = bool(legs & {"encode", "sparse"})
+    enc = LrxEncoder.random_init(cfg, seed=0, device=dev) if need_enc else None
     B, S, H = args.batch_docs, args.seq_len, cfg.hidden_size
     D = args.mrl_dim or H                       # embedding / index width (MRL slice of the pooled state when < H)
+    from lightretriever_amd import _lib
+    lrx = _lib.lib()
 
     # ---- synthetic inputs, resident in HBM: ids uniform in [1000,127000), bos first / eos last
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -445,8 +668,10 @@ def main():
             batches.append((ids_i, cu_i, int(l.max()), int(l.sum()), float(sum(cfg.flops_per_doc(int(x)) for x in l)) / B))
 
     # ---- index shard: rows/world rows of L2-normalised N(0,1) fp32 (seed 7); encoded batches overwrite its first rows
-    shard_rows = args.index_rows // world
-    index = FlatIPIndex(D, capacity=max(shard_rows, n_batches * B), device=dev, id_base=rank * shard_rows)
+    # (row r of the index belongs to the rank whose [id_base, id_base + shard_rows) holds it; a remainder of index_rows % world rows goes
+    # one each to the first ranks: every row of the index is searched whatever the world size)
+    shard_rows, id_base = shard_split(args.index_rows, rank, world)
+    index = FlatIPIndex(D, capacity=max(shard_rows, n_batches * B), device=dev, id_base=id_base)
     gi = torch.Generator(device=dev).manual_seed(7 + rank)
     slot = index.append_slot(shard_rows)
     for s in range(0, shard_rows, 65536):
@@ -457,7 +682,7 @@ def main():
     # query-side synthetic inputs (8-32 random token ids per query -> EmbeddingBag(mean) over a synthetic [V, D] table), generated NOW: no
     # torch kernel runs between the first encode launch and the last search launch
     qsets = {}
-    if not args.no_search:
+    if "search" in legs:
         gq = torch.Generator(device=dev).manual_seed(99)      # same queries on every rank (replicated query side)
         table = torch.randn(cfg.vocab_size, D, generator=gq, device=dev)
         for Qx in (args.queries, 1, 1000):
@@ -483,31 +708,36 @@ def main():
     # ---- encode leg: W warmup steps, then EXACTLY K timed steps between barrier + synchronize.  Inside the timed region only the
     #      dominant kernel (gate-up GEMM, class 2) is bracketed by HIP events on the launch stream -- read after the region, no
     #      host sync inside it; the per-class table comes from two extra fully profiled steps afterwards.
-    for i in range(args.warmup):
-        encode_step(i)
-    enc.lib.lrx_set_profiling(1 << 3)
-    barrier_sync(distributed)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        encode_step(args.warmup + i)
-    barrier_sync(distributed)
-    enc_s = time.perf_counter() - t0
-    gu_timed = enc.get_profile()["gemm_swiglu"]
-    t = torch.tensor([enc_s], device=dev, dtype=torch.float64)
-    if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    enc_s = float(t.item())
-    docs_per_s = world * B * args.steps / enc_s
-    enc.set_profiling(True)
-    n_prof = min(2, args.steps)
-    for i in range(n_prof):
-        encode_step(args.warmup + i)
-    prof = enc.get_profile()
-    enc.set_profiling(False)
+    # k_trace_marker<0> ... <1> bracket the HEADLINE legs in a rocprofv3 kernel trace (tools/check_trace_clean.py counts every kernel between
+    # them that is not liblrx's)
+    _lib.check(lrx.lrx_trace_marker(0, _lib.current_stream()))
+    enc_s, docs_per_s, gu_timed, prof, n_prof = None, None, None, {}, 0
+    if "encode" in legs:
+        for i in range(args.warmup):
+            encode_step(i)
+        enc.lib.lrx_set_profiling(1 << 3)
+        barrier_sync(distributed)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            encode_step(args.warmup + i)
+        barrier_sync(distributed)
+        enc_s = time.perf_counter() - t0
+        gu_timed = enc.get_profile()["gemm_swiglu"]
+        t = torch.tensor([enc_s], device=dev, dtype=torch.float64)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        enc_s = float(t.item())
+        docs_per_s = world * B * args.steps / enc_s
+        enc.set_profiling(True)
+        n_prof = min(2, args.steps)
+        for i in range(n_prof):
+            encode_step(args.warmup + i)
+        prof = enc.get_profile()
+        enc.set_profiling(False)
 
     # ---- search leg (queries: 8-32 random token ids -> EmbeddingBag(mean) over a synthetic [V,H] table -> normalise)
     search = None
-    if not args.no_search:
+    if "search" in legs:
         from lightretriever_amd import ops
         q_ids, offs = qsets[args.queries]
         # a search pass is ~1 ms against ~180 ms for an encode step: K passes would be dominated by the fixed cost of the two barriers
@@ -522,9 +752,10 @@ def main():
         for i in range(n_pass):
             q = ops.embedding_bag_mean(table, q_ids, offs, normalize=True)
             ev[2 * i].record()
-            Dk, Ik = index.search(q, args.topk)
+            Dk, Ik, Wk = sharded.local_search(q, args.topk)        # (with more than one rank the search's last kernel also writes the wire words)
             ev[2 * i + 1].record()
-            Dk, Ik = sharded.finish(Dk, Ik)
+            Dk, Ik = sharded.finish(Dk, Ik, Wk)
+        _lib.check(lrx.lrx_trace_marker(1, _lib.current_stream()))
         barrier_sync(distributed)
         srch_s = time.perf_counter() - t0
         t = torch.tensor([srch_s], device=dev, dtype=torch.float64)
@@ -545,7 +776,7 @@ def main():
                          "frac": round(alg_bytes / (local_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "traffic": pmc_search_traffic() if (args.index_rows == 1_000_000 and world == 1 and args.queries == 100 and D == 2048) else None,
                          "algorithmic_bytes": alg_bytes, "traffic_source": {"file": PMC_SUMMARY, "git_blob": git_blob_sha(PMC_SUMMARY), "note": "offline rocprofv3 --pmc passes, not measured by this run"},
-                         "kernel": "two-pass exact search without a score matrix: k_filter_xreg / k_filter_xreg_emit (single-product filter over the tiled fp16 shadow of the shard, corpus fragments streamed through registers, HBM-bound; a strided 1/20 sample first -> k_sample_threshold, then persistent workgroups over the rest, emitting only rows above the threshold) + k_refine_band/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
+                         "kernel": "two-pass exact search without a score matrix: k_filter_xreg / k_filter_xreg_emit (single-product filter over the tiled fp16 shadow of the shard, corpus fragments streamed through registers, HBM-bound; a strided sample of the shard's 128-row blocks first -- every 32nd block at 1M rows, every 2nd on a 125k-row shard: plan_chunk -> k_sample_threshold, then persistent workgroups over the rest, emitting only rows above the threshold) + k_refine_band/k_refine_merge (exact fp64-accumulated rescoring of the error band from the fp32 rows); six-product pass as device-gated fallback (local shard search, HIP events)", "corpus_bytes_per_element_streamed": 2 if shadow else 4, "ms": round(local_ms, 4),
                          "fp32_equiv_tflops": round(2.0 * args.queries * D * shard_rows / (local_ms * 1e-3) / 1e12, 2),
                          "fp32_mfma_peak_for_reference": PEAK_F32_MFMA_TFLOPS},
         }
@@ -601,8 +832,10 @@ def main():
         search["other_query_counts"] = other
 
     # ---- dense + sparse document vectors (row N2): same batches through lrx_encode_packed_sparse; not part of `value`
+    if "search" not in legs:
+        _lib.check(lrx.lrx_trace_marker(1, _lib.current_stream()))
     sparse = None
-    if not args.no_sparse and batches is None:
+    if "sparse" in legs and batches is None:
         n_sp = min(2, args.steps)
         enc.encode_packed_sparse(ids_all[0].reshape(-1), cu, S)
         enc.lib.lrx_set_profiling(1 << 8)                    # events around the max-aggregation GEMM (class 7) only
@@ -628,6 +861,16 @@ def main():
 
     if rank != 0:
         if distributed:
+            dist.destroy_process_group()
+        return
+
+    if "encode" not in legs:
+        line = {"partial_run": sorted(legs), "metric": "partial run (profiling aid): not the headline line", "value": None, "unit": "docs/s", "n_gpus": world,
+                "search": search, "sparse": sparse}
+        if world == 1 and "configs" in legs and batches is None:
+            line["configs"] = extra_legs(args, dev, index if (D == 2048 and args.index_rows == 1_000_000) else None)
+        print(json.dumps(line), flush=True)
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
@@ -679,12 +922,22 @@ def main():
         "search": search,
         "sparse": sparse,
     }
-    if world == 1 and not args.no_configs and not args.no_search and batches is None:
+    if partial:
+        line["partial_run"] = sorted(legs)
+    if world == 1 and "configs" in legs and batches is None:
         try:
             line["configs"] = extra_legs(args, dev, index if (D == 2048 and args.index_rows == 1_000_000) else None)
+            mc = line["configs"].get("measured_ceilings")
+            if mc:                                         # the ceilings measured in this run, next to the spec peaks of `roofline`
+                roofline["measured_ceilings"] = {"vendor_gemm_same_shape_tflops": mc["vendor_gemm_bf16"]["shapes"]["gate_up"]["tflops"],
+                                                 "frac_of_vendor_gemm": round(achieved / mc["vendor_gemm_bf16"]["shapes"]["gate_up"]["tflops"], 4),
+                                                 "hbm_stream_read_gbs": mc["hbm_stream_read"]["value"]}
+                if search is not None:
+                    search["roofline"]["measured_ceiling_gbs"] = mc["hbm_stream_read"]["value"]
+                    search["roofline"]["frac_of_measured_ceiling"] = round(search["roofline"]["achieved"] / mc["hbm_stream_read"]["value"], 4)
         except Exception as e:  # noqa: BLE001  (additional legs: never take the headline line down with them)
             line["configs"] = {"failed": "%r" % (e,)}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and "cpu" in legs:
         try:
             cb = cpu_baseline(cfg, S, args.topk, D)
             if cb.get("search"):

@@ -161,6 +161,12 @@ int lrx_encode_packed_sparse(const lrx_encoder_config* cfg, const lrx_encoder_we
  * (2*M*N*K for GEMMs, 2*2*d*sum_s(s*(s+1)/2)*nq for causal attention), 0 for the memory-bound classes.            */
 #define LRX_PROF_CLASSES 8
 void lrx_set_profiling(int32_t enabled);
+/* (ABI 5) Measurement aids.  lrx_trace_marker: an empty kernel named k_trace_marker<id> (id 0..3) on `stream` -- delimits a region of a
+ * rocprofv3 kernel trace (tools/check_trace_clean.py).  lrx_probe_stream_read: n_workgroups workgroups stream `bytes` (a multiple of 16)
+ * of `buf` with 16-B loads and xor everything into sink[n_workgroups] (device, uint32): bytes / its duration = the read rate this box
+ * reaches, the in-run ceiling bench.py reports next to the 8 TB/s of the spec.                                                    */
+int lrx_trace_marker(int32_t id, void* stream);
+int lrx_probe_stream_read(const void* buf, size_t bytes, uint32_t* sink, int32_t n_workgroups, void* stream);
 int lrx_get_profile(float* ms, double* flops, int32_t* launches);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -348,6 +354,22 @@ size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t 
 int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_shadow, const float* row_bounds,
                                const float* q, int32_t n_queries, int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids,
                                void* workspace, size_t workspace_bytes, int32_t flags, void* stream);
+/* (ABI 5) The same search for a rank of a row-sharded index: besides (out_scores, out_ids) the LAST kernel of the chain also writes the
+ * k results of every query as the 64-bit wire words of the exchange (out_wire [n_queries, k]; format and row_map as lrx_pack_topk
+ * below), so nothing runs between the local search and the RCCL all-gather.  out_wire == NULL: identical to the call above.       */
+int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_shadow, const float* row_bounds,
+                                    const float* q, int32_t n_queries, int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids,
+                                    const int64_t* row_map, uint64_t* out_wire, void* workspace, size_t workspace_bytes, int32_t flags,
+                                    void* stream);
+/* (ABI 5) Statistics for tools and bench legs.  lrx_search_fallback_count: queries any bounded search of this process has sent to its
+ * exact six-product fallback since the last reset (list / band overflow: a performance event, the results are exact either way);
+ * SYNCHRONISES like lrx_device_error_count.  lrx_flat_ip_bounded_list_counts: counts_out[n_queries] (device, uint32) = candidate-list
+ * entries of each query of the last chunk of the last search that used `workspace` -- the rows that passed the filter and reached the
+ * refine step; pass that search's own (n_rows, dim, n_queries <= 256, k, flags) and whether it had a shadow; zeros when that search
+ * ran the score-matrix filter.  Asynchronous on `stream`.                                                                          */
+int64_t lrx_search_fallback_count(int32_t reset);
+int lrx_flat_ip_bounded_list_counts(const void* workspace, int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags,
+                                    int32_t has_shadow, uint32_t* counts_out, void* stream);
 
 /* Shard maintenance (FaissIndex.build / IndexFlatIP.add, retriever/faiss_index.py:45-58, for rows that were not written by
  * lrx_encode_packed_shard): one read of n_rows fp32 rows writes their fp16 shadow (X_shadow may be NULL: bounds only) and raises

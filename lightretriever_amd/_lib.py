@@ -56,6 +56,9 @@ SIGNATURES = {
     "lrx_hit_union": (_I32, [_P, _P, _I32, _I32, _I64, _P, _P, _P, _P]),
     "lrx_flat_ip_bounded_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32, _I32]),
     "lrx_flat_ip_search_bounded": (_I32, [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _I32, _P]),
+    "lrx_flat_ip_search_bounded_wire": (_I32, [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _I32, _I64, _P, _P, _P, _P, _P, _SZ, _I32, _P]),
+    "lrx_search_fallback_count": (_I64, [_I32]),
+    "lrx_flat_ip_bounded_list_counts": (_I32, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "lrx_shard_commit_rows": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _P, _P]),
     "lrx_pool_norm_shard": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P]),
     "lrx_gemm_bf16_nt_resid32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
@@ -68,6 +71,8 @@ SIGNATURES = {
     "lrx_set_profiling": (None, [_I32]),
     "lrx_get_profile": (_I32, [C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "lrx_embedding_gather": (_I32, [_P, _P, _I32, _I32, _I32, _P, _P]),
+    "lrx_trace_marker": (_I32, [_I32, _P]),
+    "lrx_probe_stream_read": (_I32, [_P, _SZ, _P, _I32, _P]),
     "lrx_device_error_count": (_I64, [_I32]),
     "lrx_device_saturation_count": (_I64, [_I32]),
     "lrx_rmsnorm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P]),

@@ -82,6 +82,53 @@ extern "C" int lrx_embed_stream32(const void* table, const int32_t* ids, int32_t
   return LRX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Measurement aids (bench.py, tools/): named no-op kernels that delimit a region of a rocprofv3 kernel trace, and a plain streaming read
+// of a buffer -- the HBM read rate this box reaches with nothing but 16-B loads in flight, the in-run ceiling next to the 8 TB/s spec.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ID>
+__global__ void k_trace_marker() {}
+
+extern "C" int lrx_trace_marker(int32_t id, void* stream) {
+  LRX_CHECK_ARG(id >= 0 && id < 4, "trace_marker: id %d out of range (0..3)", id);
+  hipStream_t s = (hipStream_t)stream;
+  switch (id) {
+    case 0: hipLaunchKernelGGL(k_trace_marker<0>, dim3(1), dim3(64), 0, s); break;
+    case 1: hipLaunchKernelGGL(k_trace_marker<1>, dim3(1), dim3(64), 0, s); break;
+    case 2: hipLaunchKernelGGL(k_trace_marker<2>, dim3(1), dim3(64), 0, s); break;
+    default: hipLaunchKernelGGL(k_trace_marker<3>, dim3(1), dim3(64), 0, s); break;
+  }
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// Each workgroup walks its contiguous slice with 8 independent 16-B loads per thread per step (128 KiB per workgroup step, like the
+// search filter's fragment stream); the xor of everything goes to sink[workgroup] so that the loads cannot be dropped.
+__global__ void __launch_bounds__(256) k_stream_read(const u32x4* __restrict__ buf, int64_t n16, int64_t per_wg, uint32_t* __restrict__ sink) {
+  const int64_t a = (int64_t)blockIdx.x * per_wg, b = min(a + per_wg, n16);
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (int64_t i = a + threadIdx.x; i < b; i += 8 * 256) {
+    u32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = i + j * 256 < b ? __builtin_nontemporal_load(buf + i + j * 256) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc ^= v[j];
+  }
+  uint32_t x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x ^= __shfl_xor(x, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicXor(sink + blockIdx.x, x);
+}
+
+extern "C" int lrx_probe_stream_read(const void* buf, size_t bytes, uint32_t* sink, int32_t n_workgroups, void* stream) {
+  LRX_CHECK_ARG(buf && sink && bytes % 16 == 0 && n_workgroups > 0, "probe_stream_read: bad operand");
+  const int64_t n16 = (int64_t)(bytes / 16);
+  const int64_t per = ((n16 + n_workgroups - 1) / n_workgroups + 2047) / 2048 * 2048;
+  hipLaunchKernelGGL(k_stream_read, dim3(n_workgroups), dim3(256), 0, (hipStream_t)stream, (const u32x4*)buf, n16, per, sink);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
 // fp16 shadow elements k_pool_norm had to clamp (|v| > 65504 or NaN: an unnormalised row of a broken checkpoint); the shard's E bound keeps
 // the SEARCH exact in that case, this counter makes the event visible (lrx_device_saturation_count).
 __device__ unsigned int g_shadow_fp16_saturations = 0;

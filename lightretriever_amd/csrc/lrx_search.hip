@@ -1574,14 +1574,10 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red /* 16 */) {
   return t;
 }
 
-__global__ void __launch_bounds__(SEL_THREADS)
-k_topk_select_rescore(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base, const float* __restrict__ blkmax, int nblk,
-                      int nblk_ld, const float* __restrict__ X, int64_t ldx, int D, const float* __restrict__ q, float* __restrict__ out_scores,
-                      int64_t* __restrict__ out_ids, const int* __restrict__ gate, const int* __restrict__ qflags, const float* __restrict__ bounds) {
-  __shared__ SelShared sh;
-  __shared__ float s_red[16];
-  if (gate != nullptr && *gate == 0) return;                 // fallback launch of the bounded search: nothing overflowed
-  if (qflags != nullptr && qflags[blockIdx.x] == 0) return;  // ... or not this query
+__device__ __forceinline__ void select_rescore_query(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base,
+                                                     const float* __restrict__ blkmax, int nblk, int nblk_ld, const float* __restrict__ X, int64_t ldx,
+                                                     int D, const float* __restrict__ q, float* __restrict__ out_scores, int64_t* __restrict__ out_ids,
+                                                     const float* __restrict__ bounds, SelShared& sh, float* s_red) {
   const float* row = scores + (int64_t)blockIdx.x * ld;
   float* os = out_scores + (int64_t)blockIdx.x * k;
   int64_t* oi = out_ids + (int64_t)blockIdx.x * k;
@@ -1691,6 +1687,31 @@ k_topk_select_rescore(const float* __restrict__ scores, int64_t ld, int64_t N, i
   }
 }
 
+// The last kernel of every bounded search (one workgroup per query).  gate / qflags: the exact fallback runs only for a flagged query of
+// a chunk in which something overflowed.  wire (round 4, optional): the query's k results -- whoever wrote them, this workgroup or
+// k_refine_merge one launch earlier -- also leave as the 64-bit words of the multi-GPU exchange (lrx_pack_topk's format; row_map as
+// there), so a sharded search needs no packing launch between the local search and the all-gather.
+__global__ void __launch_bounds__(SEL_THREADS)
+k_topk_select_rescore(const float* __restrict__ scores, int64_t ld, int64_t N, int k, int64_t id_base, const float* __restrict__ blkmax, int nblk,
+                      int nblk_ld, const float* __restrict__ X, int64_t ldx, int D, const float* __restrict__ q, float* __restrict__ out_scores,
+                      int64_t* __restrict__ out_ids, const int* __restrict__ gate, const int* __restrict__ qflags, const float* __restrict__ bounds,
+                      unsigned long long* __restrict__ wire, const int64_t* __restrict__ row_map) {
+  __shared__ SelShared sh;
+  __shared__ float s_red[16];
+  const bool idle = (gate != nullptr && *gate == 0) ||                  // fallback launch of the bounded search: nothing overflowed
+                    (qflags != nullptr && qflags[blockIdx.x] == 0);     // ... or not this query
+  if (!idle) select_rescore_query(scores, ld, N, k, id_base, blkmax, nblk, nblk_ld, X, ldx, D, q, out_scores, out_ids, bounds, sh, s_red);
+  if (wire == nullptr) return;
+  __syncthreads();                                            // (this workgroup's own stores of the rows it is about to read)
+  const float* os = out_scores + (int64_t)blockIdx.x * k;
+  const int64_t* oi = out_ids + (int64_t)blockIdx.x * k;
+  for (int i = threadIdx.x; i < k; i += SEL_THREADS) {
+    int64_t id = oi[i];
+    if (id >= 0 && row_map != nullptr) id = row_map[id - id_base];
+    wire[(int64_t)blockIdx.x * k + i] = ((unsigned long long)__float_as_uint(os[i]) << 32) | (unsigned long long)(id >= 0 ? (uint32_t)id : 0xFFFFFFFFu);
+  }
+}
+
 extern "C" size_t lrx_flat_ip_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k) {
   (void)k;
   const size_t ld = (size_t)lrx_flat_ip_score_ld(n_rows), nq = (size_t)(n_queries > 0 ? n_queries : 1);
@@ -1730,7 +1751,8 @@ extern "C" int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, i
       row_bounds = wb;
     }
     hipLaunchKernelGGL(k_topk_select_rescore, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, (const float*)scores, ld, n_rows, k, id_base,
-                       (const float*)blkmax, nblk, nblk_ld, X, ldx, dim, q, out_scores, out_ids, (const int*)nullptr, (const int*)nullptr, row_bounds);
+                       (const float*)blkmax, nblk, nblk_ld, X, ldx, dim, q, out_scores, out_ids, (const int*)nullptr, (const int*)nullptr, row_bounds,
+                       (unsigned long long*)nullptr, (const int64_t*)nullptr);
   } else {
     hipLaunchKernelGGL(k_topk_select, dim3(n_queries), dim3(SEL_THREADS), 0, (hipStream_t)stream, scores, ld, n_rows, k, id_base, blkmax, nblk,
                        nblk_ld, out_scores, out_ids, (const int*)nullptr, (const int*)nullptr);
@@ -2012,6 +2034,19 @@ k_refine_topk(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
   if (tid == 0) part_cnt[qi * REF_SPLIT + part] = overflow ? -1 : nc;
 }
 
+// Queries the bounded search sent to its exact six-product fallback (candidate list or band overflow: near-duplicate clusters, rows outside
+// fp16's range) since the last reset -- a performance event, not an error: read by lrx_search_fallback_count.
+__device__ unsigned int g_search_fallback_queries = 0;
+extern "C" int64_t lrx_search_fallback_count(int32_t reset) {
+  unsigned int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_search_fallback_queries), sizeof(v)) != hipSuccess) return -1;
+  if (reset && v) {
+    const unsigned int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_search_fallback_queries), &z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return (int64_t)v;
+}
+
 // Merge of the REF_SPLIT published lists of a query (one workgroup per query; the kernel boundary orders it after the refine kernel --
 // an in-kernel "last part merges" ticket needed device-scope fences that cost more than this launch): sort, write the top-k; a part
 // that overflowed flags the query for the gated six-product fallback.
@@ -2034,7 +2069,7 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
     tot += cnt[p] < 0 ? 0 : cnt[p];
   }
   if (any_over || tot < keff) {               // (tot < keff: a non-finite query or threshold -- the exact path sorts it out)
-    if (tid == 0) { qflags[qi] = 1; atomicOr(any_flag, 1); }
+    if (tid == 0) { qflags[qi] = 1; atomicOr(any_flag, 1); atomicAdd(&g_search_fallback_queries, 1u); }
     return;
   }
   int base = 0;
@@ -2184,6 +2219,14 @@ extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t di
 extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_shadow, const float* row_bounds,
                                           const float* q, int32_t n_queries, int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids,
                                           void* workspace, size_t workspace_bytes, int32_t flags, void* stream) {
+  return lrx_flat_ip_search_bounded_wire(X, n_rows, ldx, dim, X_shadow, row_bounds, q, n_queries, k, id_base, out_scores, out_ids, nullptr, nullptr,
+                                         workspace, workspace_bytes, flags, stream);
+}
+
+extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_shadow, const float* row_bounds,
+                                               const float* q, int32_t n_queries, int32_t k, int64_t id_base, float* out_scores, int64_t* out_ids,
+                                               const int64_t* row_map, uint64_t* out_wire, void* workspace, size_t workspace_bytes, int32_t flags,
+                                               void* stream) {
   LRX_CHECK_ARG(row_bounds != nullptr, "flat_ip_search_bounded: null row_bounds (device pointer to {max |x_row|, max |x_row - fp16(x_row)|})");
   LRX_CHECK_ARG(k > 0 && k <= SEL_MAXK, "flat_ip_search: k=%d out of range (1..%d)", k, SEL_MAXK);
   LRX_CHECK_ARG(n_rows >= 0 && n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
@@ -2204,7 +2247,8 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
                                         out_ids + (int64_t)q0 * k, workspace, workspace_bytes, stream);
       if (rc != LRX_OK) return rc;
     }
-    return LRX_OK;
+    // (the plain path of tiny shards has no fused tail: the wire words by the stand-alone packing kernel)
+    return out_wire != nullptr ? lrx_pack_topk(out_scores, out_ids, row_map, id_base, (int64_t)n_queries * k, out_wire, stream) : LRX_OK;
   }
   hipStream_t s = (hipStream_t)stream;
   const int chunk = shadow ? 256 : 128;
@@ -2316,10 +2360,30 @@ extern "C" int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_topk_select_rescore, dim3(nf), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax,
                          (int)p.nblk, (int)p.nblk_ld, X, ldx, dim, qc + (int64_t)f0 * dim, osc + (int64_t)f0 * k, oic + (int64_t)f0 * k,
-                         (const int*)any_flag, (const int*)(flg + f0), row_bounds);
+                         (const int*)any_flag, (const int*)(flg + f0), row_bounds,
+                         out_wire != nullptr ? (unsigned long long*)out_wire + ((int64_t)q0 + f0) * k : (unsigned long long*)nullptr, row_map);
       LRX_LAUNCH_CHECK();
     }
   }
+  return LRX_OK;
+}
+
+// Statistics of the LAST bounded search that used `workspace` (tools, bench legs, tests): the number of candidate-list entries each query
+// of the last chunk ended up with -- the rows that passed the filter threshold and reached the refine step.  Same (n_rows, dim,
+// n_queries <= 256 (128 without a shadow), k, flags, has_shadow) as that search; zeros when it ran the score-matrix filter.
+__global__ void k_copy_list_counts(const unsigned int* __restrict__ cnt, int nq, unsigned int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq) out[i] = cnt == nullptr ? 0u : cnt[(size_t)i * CNT_STRIDE];
+}
+extern "C" int lrx_flat_ip_bounded_list_counts(const void* workspace, int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags,
+                                               int32_t has_shadow, uint32_t* counts_out, void* stream) {
+  const bool shadow = has_shadow && dim % 64 == 0;
+  LRX_CHECK_ARG(workspace && counts_out && n_queries > 0 && n_queries <= (shadow ? 256 : 128), "bounded_list_counts: one query chunk only (n_queries=%d)", n_queries);
+  const BoundedPlan p = plan_chunk(n_rows, dim, n_queries, k, shadow, flags & 3);
+  const int* flg = (const int*)((const char*)workspace + p.off_ints);
+  const unsigned int* cnt = p.emit && n_rows > REF_CAND ? (const unsigned int*)(flg + ints_before_cnt(n_queries)) : nullptr;
+  hipLaunchKernelGGL(k_copy_list_counts, dim3((n_queries + 255) / 256), dim3(256), 0, (hipStream_t)stream, cnt, n_queries, counts_out);
+  LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
 

@@ -206,9 +206,10 @@ class FlatIPIndex:
         return self._x[:self.ntotal]
 
     # -- search --------------------------------------------------------------------------------------------------
-    def search(self, q, k: int):
+    def search(self, q, k: int, wire_out: Optional[torch.Tensor] = None, row_map: Optional[torch.Tensor] = None):
         """-> (D f32[Q,k], I i64[Q,k]) device tensors, descending scores, ids = id_base + row, ties -> lower id,
-        (-FLT_MAX, -1) padding when k > ntotal."""
+        (-FLT_MAX, -1) padding when k > ntotal.  wire_out (int64 [Q,k], optional): also filled with the exchange words of a row-sharded
+        search (lrx_pack_topk's format, `row_map` applied) by the last kernel of the search itself."""
         if not isinstance(q, torch.Tensor):
             q = torch.from_numpy(q)
         q = q.to(device=self.device, dtype=torch.float32).contiguous()
@@ -219,6 +220,8 @@ class FlatIPIndex:
         I = torch.empty(Q, k, dtype=torch.int64, device=self.device)
         if Q == 0:
             return D, I
+        if wire_out is not None and not (wire_out.is_cuda and wire_out.dtype == torch.int64 and wire_out.is_contiguous() and tuple(wire_out.shape) == (Q, k)):
+            raise ValueError("wire_out must be a contiguous int64 CUDA tensor [Q, k]")
         # the bounded search needs a workspace that stops growing at 256 queries; the six-product path (two_pass = False) a
         # [queries, rows] fp32 score matrix.  Either way the queries go through in chunks that keep it under max_workspace_bytes
         # (results do not depend on the chunking).
@@ -243,13 +246,26 @@ class FlatIPIndex:
         for s in range(0, Q, chunk):
             qc, Dc, Ic = q[s:s + chunk], D[s:s + chunk], I[s:s + chunk]
             if self.two_pass:
-                _lib.check(self.lib.lrx_flat_ip_search_bounded(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(xb), _lib.ptr(self._bounds), _lib.ptr(qc),
-                                                               qc.shape[0], k, self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws),
-                                                               self._ws.numel(), flags, _lib.current_stream()))
+                _lib.check(self.lib.lrx_flat_ip_search_bounded_wire(
+                    _lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(xb), _lib.ptr(self._bounds), _lib.ptr(qc), qc.shape[0], k, self.id_base,
+                    _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(row_map), _lib.ptr(wire_out[s:s + chunk]) if wire_out is not None else None,
+                    _lib.ptr(self._ws), self._ws.numel(), flags, _lib.current_stream()))
             else:
                 _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(self._bounds), _lib.ptr(qc), qc.shape[0], k,
                                                        self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))
+        if wire_out is not None and not self.two_pass:
+            _lib.check(self.lib.lrx_pack_topk(_lib.ptr(D), _lib.ptr(I), _lib.ptr(row_map), int(self.id_base), Q * k, _lib.ptr(wire_out), _lib.current_stream()))
+        self._last_search = (Q if Q <= chunk else (Q - 1) % chunk + 1, k, flags, xb is not None)
         return D, I
+
+    def last_list_counts(self) -> torch.Tensor:
+        """uint32-valued int64 tensor [q]: candidate-list entries per query of the last chunk of the last two-pass search (the rows that
+        passed the filter threshold and reached the refine step) -- statistics for tools and bench legs."""
+        nq, k, flags, has_shadow = self._last_search
+        out = torch.zeros(nq, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.lrx_flat_ip_bounded_list_counts(_lib.ptr(self._ws), self.ntotal, self.d, nq, k, flags, int(has_shadow), _lib.ptr(out),
+                                                            _lib.current_stream()))
+        return out.to(torch.int64)
 
 
 def merge_topk(D_parts: torch.Tensor, I_parts: torch.Tensor):

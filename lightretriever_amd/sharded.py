@@ -66,10 +66,17 @@ def _all_gather_words(packed: torch.Tensor, world: int, group) -> torch.Tensor:
     return out.view((world, Q) + tuple(packed.shape[1:])).to(dev)
 
 
+def _collective(group, force_collective: bool) -> bool:
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    force_collective = force_collective or os.environ.get("LRX_FORCE_COLLECTIVE") == "1"
+    return world > 1 or (force_collective and dist.is_initialized())
+
+
 def exchange_merge(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.ProcessGroup] = None, row_map: Optional[torch.Tensor] = None,
-                   id_base: int = 0, force_collective: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
+                   id_base: int = 0, force_collective: bool = False, words: Optional[torch.Tensor] = None) -> tuple[torch.Tensor, torch.Tensor]:
     """This shard's device-resident (scores f32 [Q,k], ids i64 [Q,k]) -> the global top-k on every rank:
-    lrx_pack_topk (row map applied, one 64-bit word per hit) -> ONE RCCL all-gather -> lrx_merge_topk_packed.  No torch kernels."""
+    lrx_pack_topk (row map applied, one 64-bit word per hit) -> ONE RCCL all-gather -> lrx_merge_topk_packed.  No torch kernels.
+    words: the wire words when the search has already written them (FlatIPIndex.search(wire_out=...)): the packing launch is skipped."""
     from . import _lib
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     force_collective = force_collective or os.environ.get("LRX_FORCE_COLLECTIVE") == "1"
@@ -79,8 +86,9 @@ def exchange_merge(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.Proces
     lib = _lib.lib()
     Q, k = D.shape
     D, I = D.contiguous(), I.contiguous()
-    words = torch.empty(Q, k, dtype=torch.int64, device=D.device)
-    _lib.check(lib.lrx_pack_topk(_lib.ptr(D), _lib.ptr(I), _lib.ptr(row_map), int(id_base), Q * k, _lib.ptr(words), _lib.current_stream()))
+    if words is None:
+        words = torch.empty(Q, k, dtype=torch.int64, device=D.device)
+        _lib.check(lib.lrx_pack_topk(_lib.ptr(D), _lib.ptr(I), _lib.ptr(row_map), int(id_base), Q * k, _lib.ptr(words), _lib.current_stream()))
     allw = _all_gather_words(words, world, group) if collective else words.unsqueeze(0)
     Dm = torch.empty(Q, k, dtype=torch.float32, device=D.device)
     Im = torch.empty(Q, k, dtype=torch.int64, device=D.device)
@@ -102,9 +110,17 @@ class ShardedFlatIPIndex:
             raise ValueError(f"ShardedFlatIPIndex: global row {top} does not fit the 32-bit field of the exchange word")
 
     def search(self, q: torch.Tensor, k: int):
-        D, I = self.shard.search(q, k)
-        return self.finish(D, I)
+        return self.finish(*self.local_search(q, k))
 
-    def finish(self, D: torch.Tensor, I: torch.Tensor):
+    def local_search(self, q: torch.Tensor, k: int):
+        """This rank's part: (scores, ids, wire words or None).  When an exchange will follow, the search's last kernel writes the wire
+        words itself (no packing launch between the local search and the all-gather)."""
+        if not (_collective(self.group, False) or self.row_map is not None):
+            return (*self.shard.search(q, k), None)
+        words = torch.empty(q.shape[0], k, dtype=torch.int64, device=self.shard.device)
+        D, I = self.shard.search(q, k, wire_out=words, row_map=self.row_map)
+        return D, I, words
+
+    def finish(self, D: torch.Tensor, I: torch.Tensor, words: Optional[torch.Tensor] = None):
         """local (scores, ids) of this shard -> global top-k on every rank (row map, all-gather, on-device merge)."""
-        return exchange_merge(D, I, self.group, row_map=self.row_map, id_base=self.shard.id_base)
+        return exchange_merge(D, I, self.group, row_map=self.row_map, id_base=self.shard.id_base, words=words)

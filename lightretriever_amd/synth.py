@@ -246,3 +246,47 @@ def trained_like_state_dict(cfg, seed: int = 0, device=None, logit_sigma=(5.0, 1
         "stream_max_over_median_max": max(l["stream_max_over_median"] for l in L), "stream_max": max(l["stream_max"] for l in L),
         "embedding_typical": round(typ0, 5)}
     return sd, stats
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Synthetic CORPORA for the search legs.  iid Gaussian rows are the easy case for a sample-thresholded filter; embedding corpora are
+# clustered (topics), carry exact duplicates, and are often stored grouped by source.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def clustered_corpus(slot: torch.Tensor, n_clusters: int = 1000, intra_cos: float = 0.9, dup_frac: float = 0.01, seed: int = 0,
+                     order: str = "shuffled", chunk_rows: int = 65536) -> dict:
+    """Fills `slot` ([n, d] fp32 view of an index shard, on the GPU) with unit rows x = sqrt(c) centre + sqrt(1 - c) u (u a random unit
+    vector): von-Mises-Fisher-like clusters whose members have cosine ~c = intra_cos to each other; dup_frac of the rows are exact copies
+    of another row.  order: "shuffled" (cluster membership iid over the rows) or "by_cluster" (the rows of a cluster are contiguous -- a
+    corpus stored by topic / source: a strided block sample misses whole clusters).  -> {"centres": [n_clusters, d], "assign": [n] int64}"""
+    n, d = slot.shape
+    dev = slot.device
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    centres = torch.nn.functional.normalize(torch.randn(n_clusters, d, generator=gen, device=dev), dim=-1)
+    if order == "by_cluster":
+        assign = (torch.arange(n, device=dev) * n_clusters // n).to(torch.int64)
+    elif order == "shuffled":
+        assign = torch.randint(0, n_clusters, (n,), generator=gen, device=dev)
+    else:
+        raise ValueError(order)
+    a, b = math.sqrt(intra_cos), math.sqrt(1.0 - intra_cos)
+    for s in range(0, n, chunk_rows):
+        e = min(s + chunk_rows, n)
+        u = torch.nn.functional.normalize(torch.randn(e - s, d, generator=gen, device=dev), dim=-1)
+        x = torch.nn.functional.normalize(a * centres[assign[s:e]] + b * u, dim=-1)
+        n_dup = int(dup_frac * (e - s))
+        if n_dup:
+            dst = torch.randperm(e - s, generator=gen, device=dev)[:n_dup]
+            src = torch.randint(0, e - s, (n_dup,), generator=gen, device=dev)
+            x[dst] = x[src]                                                   # exact copies (ties: the lower row wins)
+            assign[s:e][dst] = assign[s:e][src]
+        slot[s:e] = x
+    return {"centres": centres, "assign": assign}
+
+
+def cluster_queries(centres: torch.Tensor, n_queries: int, query_cos: float = 0.9, seed: int = 1) -> torch.Tensor:
+    """Unit queries near randomly chosen cluster centres (cosine ~query_cos to the centre)."""
+    dev = centres.device
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    c = centres[torch.randint(0, centres.shape[0], (n_queries,), generator=gen, device=dev)]
+    u = torch.nn.functional.normalize(torch.randn(n_queries, centres.shape[1], generator=gen, device=dev), dim=-1)
+    return torch.nn.functional.normalize(math.sqrt(query_cos) * c + math.sqrt(1.0 - query_cos) * u, dim=-1)

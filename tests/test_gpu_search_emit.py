@@ -207,6 +207,56 @@ def test_candidate_list_overflow_falls_back_per_query(search_mode):
     np.testing.assert_array_equal(I3.cpu().numpy(), I3_o)
 
 
+def test_wire_words_written_by_the_search_itself_equal_the_packing_kernel(search_mode):
+    """Round 4: a row-sharded search lets the chain's last kernel write the 64-bit exchange words (lrx_flat_ip_search_bounded_wire), with or
+    without a row map, for results that came from the refine step AND for results the gated fallback rewrote; equal to lrx_pack_topk."""
+    from lightretriever_amd import _lib
+    from lightretriever_amd.sharded import ShardedFlatIPIndex, pack_pairs, unpack_pairs
+    rng = np.random.default_rng(21)
+    N, D, k = 90000, 128, 20
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32))
+    base = X[123].copy()
+    X[10000:40000] = O.l2_normalize(base[None, :] + 1e-4 * rng.standard_normal((30000, D)).astype(np.float32))   # near-copies: list overflow
+    q = O.l2_normalize(rng.standard_normal((300, D)).astype(np.float32))                                         # two chunks of queries
+    q[:5] = O.l2_normalize(base[None, :] + 0.01 * rng.standard_normal((5, D)).astype(np.float32))                # ... five of them take the fallback
+    q[270:273] = q[:3]
+    qd = torch.from_numpy(q).cuda()
+    idx = _index(X, id_base=1000)
+    row_map = torch.from_numpy(rng.permutation(N).astype(np.int64) * 3 + 7).cuda()
+    lib = _lib.lib()
+    for mode in (0, 2, 1):
+        search_mode(mode)
+        lib.lrx_search_fallback_count(1)
+        D0, I0 = idx.search(qd, k)
+        n_fb = lib.lrx_search_fallback_count(1)
+        assert n_fb >= 8 if mode != 1 else n_fb >= 0, n_fb                     # (the flagged queries of both chunks were counted)
+        for rm in (None, row_map):
+            words = torch.full((300, k), -7, dtype=torch.int64, device="cuda")
+            D1, I1 = idx.search(qd, k, wire_out=words, row_map=rm)
+            assert torch.equal(D1, D0) and torch.equal(I1, I0)
+            want_ids = I0 if rm is None else rm[I0 - 1000]
+            assert torch.equal(words, pack_pairs(D0, want_ids))
+            Du, Iu = unpack_pairs(words)
+            assert torch.equal(Du, D0) and torch.equal(Iu, want_ids)
+    search_mode(0)
+    # list counts of the last chunk (44 queries): every query reached the refine step with at least k rows; the overflowed ones say so
+    D0, I0 = idx.search(qd, k)
+    cnts = idx.last_list_counts()
+    assert cnts.numel() == 44 and (cnts >= k).all()
+    assert (cnts[14:17] > 16384).all()                                        # queries 270..272 = the near-copy queries: more hits than the list holds
+    # a sharded index with a row map goes through local_search -> finish without a packing launch and gives the mapped global rows
+    sh = ShardedFlatIPIndex(idx, row_map=row_map)
+    Dl, Il, W = sh.local_search(qd, k)
+    assert W is not None and torch.equal(W, pack_pairs(D0, row_map[I0 - 1000]))
+    Ds, Is = sh.finish(Dl, Il, W)
+    assert torch.equal(Ds, D0) and torch.equal(Is, row_map[I0 - 1000])
+    # tiny shard (plain path) and k > ntotal padding
+    small = _index(X[:300], id_base=5)
+    words = torch.zeros(300, 400, dtype=torch.int64, device="cuda")
+    Dp, Ip = small.search(qd, 400, wire_out=words)
+    assert (Ip[:, 300:] == -1).all() and torch.equal(words, pack_pairs(Dp, Ip))
+
+
 @pytest.mark.parametrize("cluster,k", [(800, 100), (6000, 300), (9000, 2048)])
 def test_near_tie_cluster_around_the_kth_score_is_resolved_exactly(cluster, k, search_mode):
     """`cluster` rows within 3e-7 relative of each other straddle the k-th place -- far inside the fp32 accumulation noise of
