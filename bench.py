@@ -358,7 +358,7 @@ def clustered_search_legs(dev):
         out[order] = {"workload": "exact top-%d of %d queries near cluster centres over %d x %d rows in 1000 clusters (intra-cluster cosine 0.9, "
                                   "1 %% exact duplicates), rows %s" % (k, Q, N, D, "iid over the clusters" if order == "shuffled" else "stored cluster by cluster"),
                       "ms": round(mean_ms, 4), "ms_median": round(med_ms, 4), "passes": passes, "roofline": hbm_roofline(N, D, Q, k, mean_ms),
-                      "filter_hits_per_query": {"mean": round(hits.mean().item(), 1), "max": int(hits.max().item()), "list_capacity": 16384},
+                      "filter_hits_per_query": {"mean": round(hits.mean().item(), 1), "max": int(hits.max().item()), "list_capacity": 65536},
                       "fallback_queries_per_pass": round(n_fb / (passes + 1), 2)}
         del idx, info
         torch.cuda.empty_cache()

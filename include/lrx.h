@@ -330,7 +330,7 @@ int lrx_flat_ip_search(const float* X, int64_t n_rows, int64_t ldx, int32_t dim,
  * accumulation) bounds every score to +- eps(q) = |q - fp16(q)| R + |fp16(q)| E + (D+32) 2^-23 |fp16(q)| R (~7e-4 |q| R on normalised
  * rows; the bf16 filter of round 2 had 3.7e-3); a strided sample of the shard (every ss-th 128-row block, scored first) gives a lower
  * bound T' of the k-th largest filter score; the pass over the rest keeps only rows with filter score >= T' - 2 eps (a per-query
- * candidate list, ~1e-3 of the rows; capacity 64 k rounded up to a power of two, at least 16 Ki); the rows within 2 eps of the list's
+ * candidate list, ~1e-3 of the rows; capacity 64 k rounded up to a power of two, at least 64 Ki); the rows within 2 eps of the list's
  * k-th score are rescored exactly from the fp32 rows (fp64 accumulation, one rounding) and sorted.  Queries whose list or band
  * overflows (near-duplicate corpora, rows outside fp16's range) are redone by the six-product path (gated on a device flag, no host
  * sync).  Scores returned are the exactly rescored ones.  Bounds smaller than the true values void the guarantee.  row_bounds[1] <= 0

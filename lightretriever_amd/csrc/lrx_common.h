@@ -35,7 +35,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- candidate lists of the score-free search filter (lrx_search.hip; the 256-query filter pass lives in lrx_gemm.hip)
-#define CAND_CAP_MIN 16384   // smallest per-query capacity of the filter pass's candidate list (score-free filter); grows with k (lrx_search.hip: plan_chunk)
+#define CAND_CAP_MIN 65536   // (16 Ki until round 4: a corpus stored cluster by cluster put single queries at 17 k hits, and ONE overflowing query costs the whole chunk the six-product pass) smallest per-query capacity of the filter pass's candidate list (score-free filter); grows with k (lrx_search.hip: plan_chunk)
 #define CNT_STRIDE 64    // list fill counters sit 256 B apart: the reservations of different queries go to different memory channels
 
 __device__ __forceinline__ uint32_t f2key(float f) {  // monotone: larger float -> larger key

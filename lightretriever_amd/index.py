@@ -255,7 +255,8 @@ class FlatIPIndex:
                                                        self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))
         if wire_out is not None and not self.two_pass:
             _lib.check(self.lib.lrx_pack_topk(_lib.ptr(D), _lib.ptr(I), _lib.ptr(row_map), int(self.id_base), Q * k, _lib.ptr(wire_out), _lib.current_stream()))
-        self._last_search = (Q if Q <= chunk else (Q - 1) % chunk + 1, k, flags, xb is not None)
+        lib_chunk = 256 if (xb is not None and self.d % 64 == 0) else 128          # the library walks a call's queries in chunks of this size
+        self._last_search = (((Q - 1) % chunk) % lib_chunk + 1, k, flags, xb is not None)
         return D, I
 
     def last_list_counts(self) -> torch.Tensor:
