@@ -1209,8 +1209,10 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
 #ifndef XPF_S
 #define XPF_S 4   // ring depth of the one-workgroup-per-block form (8: no faster at D = 2048, 13 % slower at 10M x 256, Q = 1)
 #endif
-      const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31);
       const int n_cu = lrx_cu_count();
+      // (LRX_EMIT_PERSIST_MIN_BPC: dev switch for A/B runs -- main passes with fewer blocks per CU than this run one workgroup per block)
+      static const int persist_min_bpc = []() { const char* e = getenv("LRX_EMIT_PERSIST_MIN_BPC"); return e ? atoi(e) : 0; }();
+      const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31) && nwg >= (int64_t)persist_min_bpc * n_cu;
       // sample pass: two blocks per workgroup (the q slice is fetched once per 256 rows) once there are more sample blocks than CUs; a
       // sample that fits the chip in one round runs one block per workgroup -- its time is the time of ONE workgroup's blocks through
       // one CU (~20 us per 512-KiB block), not a throughput question (125 k-row shard: 34 -> ~20 us, 1M x 2048 at ss = 32: 52 -> ~27 us)

@@ -181,6 +181,51 @@ std::tuple<at::Tensor, at::Tensor> flat_ip_topk_bounded(const at::Tensor& q, con
   return {d, i};
 }
 
+// The same search for one rank of a row-sharded index: also returns the [Q, k] int64 wire words of the exchange (lrx_pack_topk's format,
+// row_map applied), written by the search's own last kernel -- all_gather_into_tensor them and hand the result to merge_topk_packed.
+std::tuple<at::Tensor, at::Tensor, at::Tensor> flat_ip_topk_bounded_wire(const at::Tensor& q, const at::Tensor& x, const c10::optional<at::Tensor>& x_shadow,
+                                                                         const at::Tensor& row_bounds, int64_t k, int64_t id_base,
+                                                                         const c10::optional<at::Tensor>& row_map, int64_t flags) {
+  DevGuard guard(q.device());
+  need(q, "q", at::kFloat, 2);
+  need(x, "x", at::kFloat, 2);
+  need(row_bounds, "row_bounds", at::kFloat, 1);
+  TORCH_CHECK(q.is_contiguous() && q.size(1) == x.size(1) && row_bounds.numel() == 2, "flat_ip_topk_bounded_wire: q [Q,D] contiguous, x [N,D], row_bounds [2]");
+  if (x_shadow.has_value()) {
+    TORCH_CHECK(x_shadow->is_cuda() && x_shadow->scalar_type() == at::kHalf && x_shadow->dim() == 1 && x_shadow->is_contiguous() &&
+                    x_shadow->numel() >= ((x.size(0) + 127) / 128) * 128 * x.size(1),
+                "flat_ip_topk_bounded_wire: x_shadow must be the 1-D tiled fp16 shadow of x (whole 128-row blocks)");
+  }
+  if (row_map.has_value()) {
+    need(*row_map, "row_map", at::kLong, 1);
+    TORCH_CHECK(row_map->is_contiguous() && row_map->numel() >= x.size(0), "flat_ip_topk_bounded_wire: row_map int64 [>= N] contiguous");
+  }
+  at::Tensor d = at::empty({q.size(0), k}, q.options()), i = at::empty({q.size(0), k}, q.options().dtype(at::kLong));
+  at::Tensor w = at::empty({q.size(0), k}, q.options().dtype(at::kLong));
+  const size_t wsb = lrx_flat_ip_bounded_workspace_bytes(x.size(0), (int32_t)x.size(1), (int32_t)q.size(0), (int32_t)k, (int32_t)flags);
+  at::Tensor ws = bytes((int64_t)wsb, q);
+  lrx_check(lrx_flat_ip_search_bounded_wire(x.data_ptr<float>(), x.size(0), x.size(0) ? x.stride(0) : x.size(1), (int32_t)x.size(1),
+                                            x_shadow.has_value() ? x_shadow->data_ptr() : nullptr, row_bounds.data_ptr<float>(), q.data_ptr<float>(),
+                                            (int32_t)q.size(0), (int32_t)k, id_base, d.data_ptr<float>(), i.data_ptr<int64_t>(),
+                                            row_map.has_value() ? row_map->data_ptr<int64_t>() : nullptr, (uint64_t*)w.data_ptr<int64_t>(), ws.data_ptr(), wsb,
+                                            (int32_t)flags, cur_stream()),
+            "flat_ip_topk_bounded_wire");
+  return {d, i, w};
+}
+
+// [R, Q, k] gathered wire words -> the global top-k (lrx_merge_topk_packed)
+std::tuple<at::Tensor, at::Tensor> merge_topk_packed(const at::Tensor& words) {
+  DevGuard guard(words.device());
+  need(words, "words", at::kLong, 3);
+  TORCH_CHECK(words.is_contiguous(), "merge_topk_packed: [R,Q,k] contiguous int64 words");
+  const int64_t R = words.size(0), Q = words.size(1), k = words.size(2);
+  at::Tensor d = at::empty({Q, k}, words.options().dtype(at::kFloat)), i = at::empty({Q, k}, words.options());
+  lrx_check(lrx_merge_topk_packed((const uint64_t*)words.data_ptr<int64_t>(), (int32_t)R, (int32_t)Q, (int32_t)k, d.data_ptr<float>(), i.data_ptr<int64_t>(),
+                                  cur_stream()),
+            "merge_topk_packed");
+  return {d, i};
+}
+
 // x_shadow: 1-D tiled fp16 shadow (whole 128-row blocks) with row0 = index of x's first row in it, or None (bounds only)
 void shard_commit_rows(const at::Tensor& x, const c10::optional<at::Tensor>& x_shadow, at::Tensor row_bounds, int64_t row0) {
   DevGuard guard(x.device());
@@ -221,6 +266,8 @@ TORCH_LIBRARY(lrx, m) {
   m.def("embedding_bag_mean(Tensor table, Tensor ids, Tensor offsets, int padding_idx=-1, int out_dim=0, bool normalize=True) -> Tensor");
   m.def("flat_ip_topk(Tensor q, Tensor x, int k, int id_base=0, Tensor? row_bounds=None) -> (Tensor, Tensor)");
   m.def("flat_ip_topk_bounded(Tensor q, Tensor x, Tensor? x_shadow, Tensor row_bounds, int k, int id_base=0, int flags=0) -> (Tensor, Tensor)");
+  m.def("flat_ip_topk_bounded_wire(Tensor q, Tensor x, Tensor? x_shadow, Tensor row_bounds, int k, int id_base=0, Tensor? row_map=None, int flags=0) -> (Tensor, Tensor, Tensor)");
+  m.def("merge_topk_packed(Tensor words) -> (Tensor, Tensor)");
   m.def("shard_commit_rows(Tensor x, Tensor(a!)? x_shadow, Tensor(b!) row_bounds, int row0=0) -> ()");
   m.def("merge_topk(Tensor d_parts, Tensor i_parts) -> (Tensor, Tensor)");
 }
@@ -234,6 +281,8 @@ TORCH_LIBRARY_IMPL(lrx, CUDA, m) {   // (the ROCm build of PyTorch dispatches HI
   m.impl("embedding_bag_mean", &embedding_bag_mean);
   m.impl("flat_ip_topk", &flat_ip_topk);
   m.impl("flat_ip_topk_bounded", &flat_ip_topk_bounded);
+  m.impl("flat_ip_topk_bounded_wire", &flat_ip_topk_bounded_wire);
+  m.impl("merge_topk_packed", &merge_topk_packed);
   m.impl("shard_commit_rows", &shard_commit_rows);
   m.impl("merge_topk", &merge_topk);
 }

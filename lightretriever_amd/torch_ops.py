@@ -16,7 +16,7 @@ from . import _lib
 HERE = os.path.dirname(os.path.abspath(__file__))
 TORCH_LIB_PATH = os.path.join(HERE, "liblrx_torch.so")
 OPS = ("encode_packed", "rmsnorm", "rope_qkv_gemm", "attn_varlen", "swiglu_gemm", "embedding_bag_mean", "flat_ip_topk", "flat_ip_topk_bounded",
-       "shard_commit_rows", "merge_topk")
+       "flat_ip_topk_bounded_wire", "merge_topk_packed", "shard_commit_rows", "merge_topk")
 
 _loaded = False
 

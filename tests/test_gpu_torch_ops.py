@@ -84,6 +84,21 @@ def test_search_ops(lrx):
     Dm, Im = lrx.merge_topk(torch.stack([D1[:, :5], D1[:, 5:]]).contiguous(), torch.stack([I1[:, :5], I1[:, 5:]]).contiguous())
     Dm2, Im2 = merge_topk(torch.stack([D1[:, :5], D1[:, 5:]]), torch.stack([I1[:, :5], I1[:, 5:]]))
     assert torch.equal(Dm, Dm2) and torch.equal(Im, Im2) and torch.equal(Im, I1[:, :5])
+    # the sharded form: the search's last kernel writes the exchange words; two "ranks" (halves of the rows, whole 128-row blocks each) gathered
+    # and merged == the whole shard
+    from lightretriever_amd.sharded import pack_pairs
+    row_map = torch.arange(N, device="cuda", dtype=torch.int64) * 2 + 1
+    Dw, Iw, W = lrx.flat_ip_topk_bounded_wire(qd, Xd, xb, bounds, k, 7, row_map)
+    assert torch.equal(Dw, D2) and torch.equal(Iw, I2) and torch.equal(W, pack_pairs(D2, row_map[I2 - 7]))
+    half = (N // 2) // 128 * 128
+    parts = []
+    for a, b in ((0, half), (half, N)):
+        bnd = torch.zeros(2, device="cuda")
+        xs = torch.empty(-(-(b - a) // 128) * 128 * D, dtype=torch.float16, device="cuda")
+        lrx.shard_commit_rows(Xd[a:b], xs, bnd)
+        parts.append(lrx.flat_ip_topk_bounded_wire(qd, Xd[a:b], xs, bnd, k, a)[2])
+    Dg, Ig = lrx.merge_topk_packed(torch.stack(parts).contiguous())
+    assert torch.equal(Ig, I1) and torch.equal(Dg, D1)
     with pytest.raises(RuntimeError, match="liblrx error"):
         lrx.flat_ip_topk(qd, Xd, 5000)
 
