@@ -2,6 +2,7 @@
 (retriever/faiss_index.py:20-73: add / search / reset / ntotal), backed by lrx_flat_ip_search."""
 from __future__ import annotations
 
+import ctypes as C
 import weakref
 from typing import Optional
 
@@ -42,7 +43,10 @@ class FlatIPIndex:
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.ntotal = 0
         self.id_base = id_base  # added to local row numbers (global row of this shard's row 0)
-        self._ws = None
+        self._ws = None                      # search workspace of lane 0 (the only one unless searches are pipelined over lanes)
+        self._lane_ws: dict = {}             # lane != 0 -> its own workspace: searches in flight on different HIP streams must not share one
+        self.chunk_lanes = 2                 # a search of more queries than one library chunk (256) alternates its chunks over this many internal streams
+        self._chunk_streams = None
         # {max |row|, max |row - fp16(row)|} over the committed rows, kept on the device (no host sync): the error bound of the fp16
         # filter pass of lrx_flat_ip_search_bounded is built from them.  two_pass = False forces the six-product path for every search.
         self._bounds = torch.zeros(2, dtype=torch.float32, device=self.device)
@@ -206,10 +210,30 @@ class FlatIPIndex:
         return self._x[:self.ntotal]
 
     # -- search --------------------------------------------------------------------------------------------------
-    def search(self, q, k: int, wire_out: Optional[torch.Tensor] = None, row_map: Optional[torch.Tensor] = None):
+    def _lane_workspace(self, lane: int, need: int) -> torch.Tensor:
+        ws = self._ws if lane == 0 else self._lane_ws.get(lane)
+        if ws is None or ws.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                # an allocation made under HIP-graph capture lives in the graph's private pool: the index would keep pointing at memory that
+                # goes back to the allocator with the graph (the memory-access fault of round 2's capture probe)
+                raise _lib.LrxError("FlatIPIndex.search under graph capture: the search workspace must exist before the capture starts -- "
+                                    "run one eager search with the same number of queries and k first")
+            ws = None
+            if lane == 0:
+                self._ws = None
+                ws = self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            else:
+                self._lane_ws.pop(lane, None)
+                ws = self._lane_ws[lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
+                # (allocated under whatever stream is current, used on the lane's stream for the rest of its life: tell the caching allocator)
+                ws.record_stream(torch.cuda.current_stream())
+        return ws
+
+    def search(self, q, k: int, wire_out: Optional[torch.Tensor] = None, row_map: Optional[torch.Tensor] = None, lane: int = 0):
         """-> (D f32[Q,k], I i64[Q,k]) device tensors, descending scores, ids = id_base + row, ties -> lower id,
         (-FLT_MAX, -1) padding when k > ntotal.  wire_out (int64 [Q,k], optional): also filled with the exchange words of a row-sharded
-        search (lrx_pack_topk's format, `row_map` applied) by the last kernel of the search itself."""
+        search (lrx_pack_topk's format, `row_map` applied) by the last kernel of the search itself.  lane: which of the index's search
+        workspaces to use -- searches that may be in flight at the same time (different HIP streams: pipeline.SearchLanes) take different lanes."""
         if not isinstance(q, torch.Tensor):
             q = torch.from_numpy(q)
         q = q.to(device=self.device, dtype=torch.float32).contiguous()
@@ -230,41 +254,59 @@ class FlatIPIndex:
         chunk = Q
         while chunk > 1 and int(ws_bytes(self.ntotal, self.d, chunk, k)) > int(self.max_workspace_bytes):
             chunk = 256 if chunk > 256 else (128 if chunk > 128 else chunk // 2)
-        need = int(ws_bytes(self.ntotal, self.d, chunk, k))
-        if self._ws is None or self._ws.numel() < need:
-            if torch.cuda.is_current_stream_capturing():
-                # an allocation made under HIP-graph capture lives in the graph's private pool: the index would keep pointing at memory that
-                # goes back to the allocator with the graph (the memory-access fault of round 2's capture probe)
-                raise _lib.LrxError("FlatIPIndex.search under graph capture: the search workspace must exist before the capture starts -- "
-                                    "run one eager search with the same number of queries and k first")
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         ldx = self._x.stride(0) if self._x.shape[0] else self.d
         if self.two_pass and self.shadow_f16:
             self._ensure_shadow()                       # (no-op unless rows were committed while the shadow was switched off)
         xb = self._xb if (self.two_pass and self._wants_shadow() and self._xb is not None and self._shadow_rows >= self.ntotal) else None
-        for s in range(0, Q, chunk):
+        lib_chunk = 256 if (xb is not None and self.d % 64 == 0) else 128          # the library walks a call's queries in chunks of this size
+        # More queries than one library chunk: the chunks are independent searches over the same rows, so they alternate between two
+        # internal HIP streams (own workspaces), forked from and joined back into the caller's stream inside this call -- the short
+        # latency-bound kernels that frame one chunk's passes overlap the other chunk's passes (Q = 1000, top-1000 over a 100 k-row
+        # chunk, the reference's operating point: 2.45 -> ~2.2 ms; the stream semantics of the call do not change).  Not under graph capture.
+        fork = (self.two_pass and self.chunk_lanes > 1 and Q > lib_chunk and lane == 0 and not torch.cuda.is_current_stream_capturing())
+        if fork:
+            chunk = min(chunk, lib_chunk)
+        need = int(ws_bytes(self.ntotal, self.d, chunk, k))
+        ws = self._lane_workspace(lane, need)
+        cur = torch.cuda.current_stream()
+        if fork:
+            if self._chunk_streams is None:
+                self._chunk_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.chunk_lanes)]
+            lane_ws = [ws] + [self._lane_workspace(-j, need) for j in range(1, self.chunk_lanes)]   # (lane 0's own workspace is the first)
+            start = torch.cuda.Event()
+            start.record(cur)
+        for j, s in enumerate(range(0, Q, chunk)):
             qc, Dc, Ic = q[s:s + chunk], D[s:s + chunk], I[s:s + chunk]
+            if fork:
+                st = self._chunk_streams[j % self.chunk_lanes]
+                if j < self.chunk_lanes:
+                    st.wait_event(start)
+                ws = lane_ws[j % self.chunk_lanes]
+                stream = C.c_void_p(st.cuda_stream)
+            else:
+                stream = _lib.current_stream()
             if self.two_pass:
                 _lib.check(self.lib.lrx_flat_ip_search_bounded_wire(
                     _lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(xb), _lib.ptr(self._bounds), _lib.ptr(qc), qc.shape[0], k, self.id_base,
                     _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(row_map), _lib.ptr(wire_out[s:s + chunk]) if wire_out is not None else None,
-                    _lib.ptr(self._ws), self._ws.numel(), flags, _lib.current_stream()))
+                    _lib.ptr(ws), ws.numel(), flags, stream))
             else:
                 _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(self._bounds), _lib.ptr(qc), qc.shape[0], k,
-                                                       self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream()))
+                                                       self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(ws), ws.numel(), stream))
+        if fork:
+            for st in self._chunk_streams:
+                cur.wait_stream(st)
         if wire_out is not None and not self.two_pass:
             _lib.check(self.lib.lrx_pack_topk(_lib.ptr(D), _lib.ptr(I), _lib.ptr(row_map), int(self.id_base), Q * k, _lib.ptr(wire_out), _lib.current_stream()))
-        lib_chunk = 256 if (xb is not None and self.d % 64 == 0) else 128          # the library walks a call's queries in chunks of this size
-        self._last_search = (((Q - 1) % chunk) % lib_chunk + 1, k, flags, xb is not None)
+        self._last_search = (((Q - 1) % chunk) % lib_chunk + 1, k, flags, xb is not None, ws)
         return D, I
 
     def last_list_counts(self) -> torch.Tensor:
         """uint32-valued int64 tensor [q]: candidate-list entries per query of the last chunk of the last two-pass search (the rows that
         passed the filter threshold and reached the refine step) -- statistics for tools and bench legs."""
-        nq, k, flags, has_shadow = self._last_search
+        nq, k, flags, has_shadow, ws = self._last_search
         out = torch.zeros(nq, dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.lrx_flat_ip_bounded_list_counts(_lib.ptr(self._ws), self.ntotal, self.d, nq, k, flags, int(has_shadow), _lib.ptr(out),
+        _lib.check(self.lib.lrx_flat_ip_bounded_list_counts(_lib.ptr(ws), self.ntotal, self.d, nq, k, flags, int(has_shadow), _lib.ptr(out),
                                                             _lib.current_stream()))
         return out.to(torch.int64)
 

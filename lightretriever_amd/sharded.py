@@ -109,16 +109,16 @@ class ShardedFlatIPIndex:
         if top >= 2 ** 32 - 1:
             raise ValueError(f"ShardedFlatIPIndex: global row {top} does not fit the 32-bit field of the exchange word")
 
-    def search(self, q: torch.Tensor, k: int):
-        return self.finish(*self.local_search(q, k))
+    def search(self, q: torch.Tensor, k: int, lane: int = 0):
+        return self.finish(*self.local_search(q, k, lane=lane))
 
-    def local_search(self, q: torch.Tensor, k: int):
+    def local_search(self, q: torch.Tensor, k: int, lane: int = 0):
         """This rank's part: (scores, ids, wire words or None).  When an exchange will follow, the search's last kernel writes the wire
         words itself (no packing launch between the local search and the all-gather)."""
         if not (_collective(self.group, False) or self.row_map is not None):
-            return (*self.shard.search(q, k), None)
+            return (*self.shard.search(q, k, lane=lane), None)
         words = torch.empty(q.shape[0], k, dtype=torch.int64, device=self.shard.device)
-        D, I = self.shard.search(q, k, wire_out=words, row_map=self.row_map)
+        D, I = self.shard.search(q, k, wire_out=words, row_map=self.row_map, lane=lane)
         return D, I, words
 
     def finish(self, D: torch.Tensor, I: torch.Tensor, words: Optional[torch.Tensor] = None):

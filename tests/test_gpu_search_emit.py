@@ -207,6 +207,54 @@ def test_candidate_list_overflow_falls_back_per_query(search_mode):
     np.testing.assert_array_equal(I3.cpu().numpy(), I3_o)
 
 
+def test_searches_in_flight_on_two_streams_give_the_same_bits():
+    """Round 4: pipeline.SearchLanes keeps two searches in flight on two HIP streams (own workspaces); a search of more than 256 queries
+    alternates its 256-query chunks over two internal streams inside the call.  Same bits as one search after the other, also with a
+    row-map exchange tail, also when the caller consumes results late."""
+    from lightretriever_amd import FlatIPIndex
+    from lightretriever_amd.pipeline import SearchLanes
+    from lightretriever_amd.sharded import ShardedFlatIPIndex
+    rng = np.random.default_rng(31)
+    N, D, k = 70000, 256, 50
+    X = O.l2_normalize(rng.standard_normal((N, D)).astype(np.float32))
+    idx = _index(X)
+    qs = [torch.from_numpy(O.l2_normalize(rng.standard_normal((n, D)).astype(np.float32))).cuda() for n in (100, 37, 256, 100, 700, 1)]
+    idx.chunk_lanes = 1
+    want = [idx.search(q, k) for q in qs]                               # one stream, no internal fork
+    idx.chunk_lanes = 2
+    for q, (Dw, Iw) in zip(qs, want):                                   # the 700-query search forks its three chunks
+        Dg, Ig = idx.search(q, k)
+        assert torch.equal(Dg, Dw) and torch.equal(Ig, Iw)
+    lanes = SearchLanes(idx, lanes=2)
+    pend = [lanes.submit(q, k) for q in qs * 3]
+    for i, h in enumerate(pend):
+        Dg, Ig = h.result()
+        assert torch.equal(Dg, want[i % len(qs)][0]) and torch.equal(Ig, want[i % len(qs)][1])
+    # the query producer on the lane's stream, results consumed one submit late (the serving-loop pattern)
+    table = torch.randn(500, D, device="cuda")
+    from lightretriever_amd import ops
+    ids = torch.randint(0, 500, (40 * 9,), device="cuda")
+    offs = torch.arange(0, 40 * 9, 9, device="cuda")
+    qe = ops.embedding_bag_mean(table, ids, offs, normalize=True)
+    De, Ie = idx.search(qe, k)
+    prev = None
+    for _ in range(6):
+        h = lanes.submit(lambda: ops.embedding_bag_mean(table, ids, offs, normalize=True), k)
+        if prev is not None:
+            Dg, Ig = prev.result()
+            assert torch.equal(Dg, De) and torch.equal(Ig, Ie)
+        prev = h
+    lanes.drain()
+    row_map = torch.from_numpy(rng.permutation(N).astype(np.int64)).cuda()
+    sh = ShardedFlatIPIndex(idx, row_map=row_map)
+    Ds, Is = sh.search(qs[0], k)
+    lanes_s = SearchLanes(sh, lanes=3)
+    for h in [lanes_s.submit(qs[0], k) for _ in range(5)]:
+        Dg, Ig = h.result()
+        assert torch.equal(Dg, Ds) and torch.equal(Ig, Is)
+    torch.cuda.synchronize()
+
+
 def test_wire_words_written_by_the_search_itself_equal_the_packing_kernel(search_mode):
     """Round 4: a row-sharded search lets the chain's last kernel write the 64-bit exchange words (lrx_flat_ip_search_bounded_wire), with or
     without a row map, for results that came from the refine step AND for results the gated fallback rewrote; equal to lrx_pack_topk."""
