@@ -304,6 +304,8 @@ def extra_legs(args, dev, headline_index):
         legs["config2_encode_llama31_8b"] = encode_8b_leg(args, dev)
     if want("ragged_encode_llama32_1b"):
         legs["ragged_encode_llama32_1b"] = ragged_encode_leg(args, dev)
+    if want("encode_llama32_1b_precise_stream"):
+        legs["encode_llama32_1b_precise_stream"] = precise_stream_leg(args, dev)
     # (round 4's additions run after the legs of round 3, whose numbers stay comparable: the search legs are sensitive to what ran before them)
     if want("search_clustered"):
         legs["search_clustered"] = clustered_search_legs(dev)
@@ -557,6 +559,34 @@ def encode_8b_leg(args, dev):
                      "avg_launch_ms": round(gu8["ms"] / max(gu8["launches"], 1), 4), "launches": gu8["launches"], "traffic": None}}
     del enc8, out8, ids8
     torch.cuda.empty_cache()
+    return out
+
+
+def precise_stream_leg(args, dev):
+    """The headline model on the OTHER arithmetic: fp32 residual stream + exact weights (what every larger backbone runs by default).  The
+    price of the 4 x smaller distance to the fp32 model that DESIGN.md section 3 reports for it on trained-like weights."""
+    import dataclasses
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    B, S = 256, args.seq_len
+    out = {}
+    for name, precise in (("bf16_stream_folded_norm", False), ("precise_fp32_stream", True)):
+        cfg = dataclasses.replace(EncoderConfig.llama32_1b(S), precise_stream=precise)
+        enc = LrxEncoder.random_init(cfg, seed=0, device=dev)
+        g = torch.Generator(device=dev).manual_seed(79)
+        ids = torch.randint(1000, 127000, (4, B * S), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+        cu = (torch.arange(B + 1, device=dev, dtype=torch.int64) * S).to(torch.int32)
+        o = torch.empty(B, cfg.hidden_size, device=dev)
+        enc.encode_packed(ids[0], cu, S, out=o)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in (1, 2, 3):
+            enc.encode_packed(ids[i], cu, S, out=o)
+        torch.cuda.synchronize()
+        out[name] = {"docs_per_s": round(3 * B / (time.perf_counter() - t0), 1)}
+        del enc, o, ids
+        torch.cuda.empty_cache()
+    out["workload"] = "lightretriever-llama3.2-1b dims bf16, 256 docs/step x seq_len %d, 3 timed steps after 1 warm-up, both stream modes on this box" % S
+    out["precise_over_bf16"] = round(out["precise_fp32_stream"]["docs_per_s"] / out["bf16_stream_folded_norm"]["docs_per_s"], 4)
     return out
 
 
