@@ -168,8 +168,8 @@ def cpu_baseline(cfg, seq_len, topk, dim):
     }
 
 
-PMC_SUMMARY = os.environ.get("LRX_PMC_SUMMARY", "profiles/r03_pmc_summary.json")   # offline rocprofv3 --pmc passes (tools/pmc_traffic.sh)
-PMC_MFMA = os.environ.get("LRX_PMC_MFMA", "profiles/r03_pmc_mfma.json")
+PMC_SUMMARY = os.environ.get("LRX_PMC_SUMMARY", "profiles/r04_pmc_summary.json")   # offline rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+PMC_MFMA = os.environ.get("LRX_PMC_MFMA", "profiles/r04_pmc_mfma.json")
 
 
 def git_blob_sha(rel_path):
@@ -982,10 +982,11 @@ def main():
         "offline_profile": {"pmc_summary": {"file": PMC_SUMMARY, "git_blob": git_blob_sha(PMC_SUMMARY)},
                             "pmc_mfma": {"file": PMC_MFMA, "git_blob": git_blob_sha(PMC_MFMA), "mfma_busy_frac": pmc_mfma("k_gemm_bf16_nt<2>")[0],
                                          "effective_clock_ghz": pmc_mfma("k_gemm_bf16_nt<2>")[1]},
-                            "gemm_power": {"file": "profiles/r01_gemm_power.txt", "git_blob": git_blob_sha("profiles/r01_gemm_power.txt"),
-                                           "package_power_w_during_gemm_loop": "1383-1390 of 1400 (cap)", "shader_clock_ghz_during_gemm_loop": 1.76},
-                            "gemm_ablation": {"file": "profiles/r01_gemm_ablation.txt", "git_blob": git_blob_sha("profiles/r01_gemm_ablation.txt"),
-                                              "mfma_only_loop_of_same_kernel_tflops": 1827, "vendor_gemm_same_shape_no_epilogue_tflops": 1471}}
+                            "gemm_power": {"file": "profiles/r04_gemm_power.txt", "git_blob": git_blob_sha("profiles/r04_gemm_power.txt"),
+                                           "note": "tools/power_probe.sh on the round-4 gate-up kernel: rocm-smi package power / shader clock while one launch loops",
+                                           "random_operands": {"tflops": 1432, "shader_clock_ghz": 1.85, "package_power_w": "1373-1377 of 1400 (cap)"},
+                                           "constant_or_zero_operands": {"tflops": "1925-1936", "shader_clock_ghz": 2.40, "package_power_w": "1086-1242"},
+                                           "vendor_gemm_same_shape_random_operands": {"tflops": 1449, "shader_clock_ghz": 1.85, "package_power_w": 1390}}}
                            if args.model == "llama3.2-1b" else None,
         "model_flops_per_doc": fl_doc,
         "end_to_end_tflops": round(docs_per_s / world * fl_doc / 1e12, 2),

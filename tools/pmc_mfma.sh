@@ -38,3 +38,4 @@ for k, c in cnt.items():
     out[k] = e
 print(json.dumps(out, indent=1))
 PY
+rm -rf $OUT/a

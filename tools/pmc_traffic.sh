@@ -28,3 +28,4 @@ json.dump(out, open("$OUT/summary.json", "w"), indent=1)
 for k in ("k_gemm_bf16_nt<2>", "k_filter_xreg<emit>", "k_filter_xreg<scores>", "k_sample_threshold", "k_refine_band", "k_refine_merge"):
     if k in out: print(k, round(out[k]["hbm_bytes_per_launch"] / 1e6, 1), "MB per launch")
 PY
+rm -rf $OUT/enc $OUT/srch   # (raw per-dispatch counter files: tens of MB; gpurun merges back at most 64 MiB)
