@@ -1392,6 +1392,35 @@ __device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, u
   return prefix;
 }
 
+// the same for a SHORT row (n <= 4 * SEL_THREADS, n % 4 == 0, 16-byte aligned): every thread keeps its four keys in registers, so the four
+// digit passes read nothing but their LDS histograms (the group maxima of a per-rank shard's sample: 3.9 k values -- k_sample_threshold
+// 14.6 -> ~12 us)
+template <class SH>
+__device__ uint32_t radix_select_kth_small(const float* __restrict__ row, int n, unsigned int kk, SH& sh) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  uint32_t key[4];
+  const bool have = 4 * tid < n;
+  if (have) {
+    const f32x4 v = *(const f32x4*)(row + 4 * tid);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) key[e] = f2key(v[e]);
+  }
+  uint32_t prefix = 0, mask = 0;
+  unsigned int neq;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 16 * 256; i += SEL_THREADS) (&sh.hist[0][0])[i] = 0;
+    __syncthreads();
+    if (have) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((key[e] & mask) == prefix) atomicAdd(&sh.hist[wave][(key[e] >> shift) & 255], 1u);
+    }
+    prefix |= (uint32_t)radix_pick(sh, kk, neq) << shift;
+    mask |= 0xFFu << shift;
+  }
+  return prefix;
+}
+
 // the same over the score keys (upper halves) of a packed candidate list
 template <class SH>
 __device__ uint32_t radix_select_kth_list(const unsigned long long* __restrict__ list, int n, unsigned int kk, SH& sh) {
@@ -1858,6 +1887,8 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
     __syncthreads();
     unsigned int ne, nq_;
     kth = key2f(radix_select_kth(bmaxL, nblk, (unsigned int)k, sh, ne, nq_));
+  } else if (gsz == 16 && ng >= k && ng <= 4 * SEL_THREADS) {
+    kth = key2f(radix_select_kth_small(bm, ng, (unsigned int)k, sh));
   } else if (gsz == 16 && ng >= k) {
     unsigned int ne, nq_;
     kth = key2f(radix_select_kth(bm, ng, (unsigned int)k, sh, ne, nq_));
@@ -1971,6 +2002,9 @@ k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
   __syncthreads();
   if (!overflow) {
     const unsigned long long* list = cand + (int64_t)qi * cap;
+    // (Round 4, measured and not kept: the k-th score of lists of <= 1024 entries by counting -- every thread one key, ranks from broadcast LDS
+    // reads, no barrier-separated passes: 32.1-33.0 us against 28.7-29.0 for this kernel on the 125 k-row shard, same box, three runs each:
+    // its lists hold ~800 entries there and the O(n^2 / threads) walk loses to four radix passes.)
     const float kth = key2f(radix_select_kth_list(list, (int)n, (unsigned int)k, rs));
     const float thr = kth - 2.0f * eps[qi];
     for (int i = part + nsplit * tid; i < (int)n; i += nsplit * 1024) {
