@@ -1256,7 +1256,9 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
     if (qsplit != nullptr && qt >= SPLIT_MIN_QT) {
       const int rb = planes == 3 ? 128 : 16 * SPF_RT * SPF_WV;
       const int64_t nwg = fm.nblocks >= 0 ? fm.nblocks : ld_full / rb;
-      const int64_t gated_cap = 8 * (int64_t)lrx_cu_count();   // grid of a gated (normally idle) six-product launch
+      // grid of a gated (normally idle) six-product launch: its workgroups walk the blocks.  (Round 4: 1 x, 2 x and 8 x CUs idle equally fast --
+      // 4.7-5.0 us under rocprofv3, of which ~3 us are the profiler's per-dispatch overhead: an empty kernel costs 1.5 us per dependent launch.)
+      const int64_t gated_cap = 8 * (int64_t)lrx_cu_count();
       if (nwg == 0) continue;
       if (fm.bmode != 2 && !fm.planes_ready) {
         int threads = (dim / 32) * qt * 64;
