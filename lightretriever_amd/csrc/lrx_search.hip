@@ -2379,6 +2379,8 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
       // (Round 3, measured and not kept: the number of parts, 1..8, that leaves the fewest CUs idle over whole rounds -- 5 for 100 queries:
       // top-1000 0.959 ms against 0.951 with 2 parts, top-100 0.730 against 0.719, 8 parts 1.00 / 0.747: the gather is bound chip-wide.)
       nsplit = (int64_t)nq * REF_SPLIT <= lrx_cu_count() ? REF_SPLIT : ((int64_t)nq * 2 <= lrx_cu_count() ? 2 : 1);
+      // (Round 4, re-measured on the per-rank shard sizes, 100 queries: 125 k x 2048 0.190 / 0.178-0.181 / 0.190 / 0.191-0.192 ms for 1 / 2 / 3 / 4 parts,
+      // 1.25M x 256 0.202 / 0.196-0.198 / 0.208 / 0.202-0.208, 1M x 2048 0.741 / 0.722-0.726 / 0.735 / 0.738-0.743: two parts everywhere.)
       hipLaunchKernelGGL(k_refine_band, dim3(nq, nsplit), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
                          (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt, nsplit, p.cap);
       LRX_LAUNCH_CHECK();
