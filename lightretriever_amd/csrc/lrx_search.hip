@@ -724,6 +724,10 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
 // the thresholds stay in registers, and hits (~1e-3 of the scores) are parked in a per-wave LDS list that is written to the queries'
 // candidate lists once, at the end (or when it fills up).  RT = blocks worked on at a time (the q slice is read from LDS once for both).
 // Requires D / 64 to be a multiple of PF (the ring phase is the same at every block start); other shapes use k_filter_xreg<.., EMIT>.
+// (Round 4, measured and not kept: for narrow rows (D = 256: a block is 64 KiB, an epilogue every four k-steps) TWO persistent workgroups per
+// CU with half the LDS each, one block at a time, so that one's epilogue runs under the other's loads -- 96 VGPRs, 78 KiB LDS, correct, and
+// 1.25M x 256 / Q = 100 went from 0.201-0.206 to 0.276-0.284 ms, 10M x 256 from 0.99 to 1.26: with one block in work the q fragments are read
+// from LDS once per block instead of once per two, and that, not the epilogue, is what the narrow-row pass is short of.  Q = 1, 32: no change.)
 template <int QT, int PF, int RT>
 __global__ void __launch_bounds__(576, (QT > 8 || RT > 1) ? 3 : 5)   // (second argument: waves per SIMD -> two workgroups of nine waves per CU need five)
 k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, int nblocks, int bmode, int ss,
