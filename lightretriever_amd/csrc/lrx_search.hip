@@ -1321,6 +1321,64 @@ __device__ void bitonic_sort_desc(unsigned long long* buf, int P) {
   __syncthreads();
 }
 
+// The same sort for P = E x blockDim.x entries with E = 2 or 4 consecutive entries per thread IN REGISTERS (round 4): of the 66 stages of a
+// 2048-entry sort 11 pair entries of one thread, 45 pair threads of one wave (64-bit lane exchange, no LDS, no barrier) and only 10 pair
+// different waves (LDS round trip + two barriers).  The LDS version above pays ~0.5 us of read -> compare -> write latency for every one of
+// the 66: k_refine_merge at top_k = 1000 (1 200 entries -> P = 2048) 33 us; this one ~10.  blockDim.x a multiple of 64, P = E * blockDim.x.
+template <int E>
+__device__ void bitonic_sort_desc_regs(unsigned long long* buf, int P) {
+  static_assert(E == 2 || E == 4, "two or four entries per thread");
+  const int t = threadIdx.x, base = t * E;
+  unsigned long long v[E];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < E; ++r) v[r] = buf[base + r];
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < E) {
+        // partner inside the thread: entries r and r ^ j
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int rp = r ^ j;
+          if (rp > r && rp < E) {
+            const bool upr = ((base + r) & k) == 0;
+            const unsigned long long a = v[r], b = v[rp];
+            if (upr ? (a < b) : (a > b)) { v[r] = b; v[rp] = a; }
+          }
+        }
+      } else if (j < 64 * E) {
+        // partner thread t ^ (j / E) in the same wave; the entry at the lower index keeps the larger word when (index & k) == 0
+        const int pl = j / E;
+        const bool lower = (t & pl) == 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const unsigned long long o = __shfl_xor(v[r], pl, 64);
+          const bool upr = ((base + r) & k) == 0;                 // (the same for both partners: they differ in bit j < k only)
+          const bool keep_max = lower == upr;
+          v[r] = keep_max ? (v[r] > o ? v[r] : o) : (v[r] < o ? v[r] : o);
+        }
+      } else {
+        // partner in another wave: through LDS
+#pragma unroll
+        for (int r = 0; r < E; ++r) buf[base + r] = v[r];
+        __syncthreads();
+        const bool lower = (base & j) == 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const unsigned long long o = buf[(base + r) ^ j];
+          const bool upr = ((base + r) & k) == 0;
+          const bool keep_max = lower == upr;
+          v[r] = keep_max ? (v[r] > o ? v[r] : o) : (v[r] < o ? v[r] : o);
+        }
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r) buf[base + r] = v[r];
+  __syncthreads();
+}
+
 #define SEL_THREADS 1024
 #define SEL_MAXK 2048
 #define SEL_CAND 4096   // candidate capacity of the fast path (and of the exact path's output list)
@@ -2157,7 +2215,9 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
   int P = 1;
   while (P < tot) P <<= 1;
   for (int i = tot + tid; i < P; i += blockDim.x) s_cand[i] = 0ull;
-  bitonic_sort_desc(s_cand, P);
+  if (P == 2 * (int)blockDim.x) bitonic_sort_desc_regs<2>(s_cand, P);          // (the sorts load after their own barrier: the zero fill above is seen)
+  else if (P == 4 * (int)blockDim.x) bitonic_sort_desc_regs<4>(s_cand, P);
+  else bitonic_sort_desc(s_cand, P);
   for (int i = tid; i < keff; i += blockDim.x) {
     const unsigned long long c = s_cand[i];
     os[i] = key2f((uint32_t)(c >> 32));
