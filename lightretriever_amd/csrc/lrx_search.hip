@@ -1324,10 +1324,11 @@ __device__ void bitonic_sort_desc(unsigned long long* buf, int P) {
 // The same sort for P = E x blockDim.x entries with E = 2 or 4 consecutive entries per thread IN REGISTERS (round 4): of the 66 stages of a
 // 2048-entry sort 11 pair entries of one thread, 45 pair threads of one wave (64-bit lane exchange, no LDS, no barrier) and only 10 pair
 // different waves (LDS round trip + two barriers).  The LDS version above pays ~0.5 us of read -> compare -> write latency for every one of
-// the 66: k_refine_merge at top_k = 1000 (1 200 entries -> P = 2048) 33 us; this one ~10.  blockDim.x a multiple of 64, P = E * blockDim.x.
+// the 66: k_refine_merge at top_k = 1000 (1 200 entries -> P = 2048) 34 us; this one 21.  Also the merge of the gathered per-shard lists
+// (k_merge_topk: 8 shards x top-100 = 800 entries -> P = 1024, 55 stages).  blockDim.x a multiple of 64 (or one partial wave), P = E * blockDim.x.
 template <int E>
 __device__ void bitonic_sort_desc_regs(unsigned long long* buf, int P) {
-  static_assert(E == 2 || E == 4, "two or four entries per thread");
+  static_assert(E == 2 || E == 4 || E == 8 || E == 16, "2 .. 16 entries per thread");
   const int t = threadIdx.x, base = t * E;
   unsigned long long v[E];
   __syncthreads();
@@ -2643,7 +2644,14 @@ k_merge_topk(const float* __restrict__ in_scores, const int64_t* __restrict__ in
     }
     buf[i] = c;
   }
-  bitonic_sort_desc(buf, P);
+  // (the launch picks blockDim.x = P / E, E = 2 .. 16, for P >= 128: the sort runs in registers; smaller P: one wave's worth, the LDS form)
+  switch (P >= 128 ? P / (int)blockDim.x : 0) {
+    case 2: bitonic_sort_desc_regs<2>(buf, P); break;
+    case 4: bitonic_sort_desc_regs<4>(buf, P); break;
+    case 8: bitonic_sort_desc_regs<8>(buf, P); break;
+    case 16: bitonic_sort_desc_regs<16>(buf, P); break;
+    default: bitonic_sort_desc(buf, P);
+  }
   for (int i = threadIdx.x; i < k; i += blockDim.x) {
     unsigned long long c = i < P ? buf[i] : 0ull;
     int64_t o = (int64_t)qi * k + i;
@@ -2662,7 +2670,9 @@ static int merge_launch(const float* in_scores, const int64_t* in_ids, const uns
   if (smem > 48 * 1024) {
     LRX_HIP(hipFuncSetAttribute((const void*)k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   }
-  hipLaunchKernelGGL(k_merge_topk, dim3(n_queries), dim3(1024), smem, (hipStream_t)stream, in_scores, in_ids, in_packed, n_parts, n_queries, k,
+  // P >= 128: P / E threads with E = 2 (P <= 2048), 4, 8, 16 entries per thread in registers; below: the LDS sort on 64 threads per 64 entries
+  const int threads = P >= 128 ? (P <= 2048 ? P / 2 : 1024) : 64;
+  hipLaunchKernelGGL(k_merge_topk, dim3(n_queries), dim3(threads), smem, (hipStream_t)stream, in_scores, in_ids, in_packed, n_parts, n_queries, k,
                      out_scores, out_ids);
   LRX_LAUNCH_CHECK();
   return LRX_OK;

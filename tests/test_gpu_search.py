@@ -303,3 +303,30 @@ def test_query_chunking_under_a_workspace_cap_changes_nothing():
         assert idx._ws.numel() < ws_full
         assert torch.equal(D0, D1) and torch.equal(I0, I1)
     check_against_oracle(D0, I0, q, X, k)
+
+
+@pytest.mark.parametrize("R,k", [(1, 7), (2, 30), (2, 64), (8, 100), (3, 333), (8, 256), (2, 2048), (7, 1000), (8, 2048), (5, 1)])
+def test_merge_topk_every_sort_width_against_a_host_sort(R, k):
+    """lrx_merge_topk / lrx_merge_topk_packed over the whole range of R x k (round 4: the sort behind them runs in registers, 2 .. 16 entries
+    per thread, for 128 .. 16384 padded entries; the LDS form below that): random scores with exact ties across parts, -1 padding, against a
+    host sort by (score descending, id ascending)."""
+    from lightretriever_amd import merge_topk, _lib
+    from lightretriever_amd.sharded import pack_pairs
+    g = torch.Generator().manual_seed(R * 10007 + k)
+    Q = 13
+    D = torch.randint(0, 50, (R, Q, k), generator=g).float() / 7.0              # many exact ties
+    I = torch.stack([torch.randperm(R * k * 3, generator=g)[:R * k].view(R, k) for _ in range(Q)], 1).to(torch.int64)   # distinct ids per query
+    pad = torch.rand(R, Q, k, generator=g) < 0.1
+    D[pad], I[pad] = -3.4028234663852886e38, -1
+    Dm, Im = merge_topk(D.cuda(), I.cuda())
+    words = pack_pairs(D, I).cuda()
+    D2 = torch.empty(Q, k, device="cuda")
+    I2 = torch.empty(Q, k, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib().lrx_merge_topk_packed(_lib.ptr(words), R, Q, k, _lib.ptr(D2), _lib.ptr(I2), _lib.current_stream()))
+    for q in range(Q):
+        ent = [(float(D[r, q, j]), int(I[r, q, j])) for r in range(R) for j in range(k) if int(I[r, q, j]) >= 0]
+        ent.sort(key=lambda e: (-e[0], e[1]))
+        want = ent[:k] + [(-3.4028234663852886e38, -1)] * max(0, k - len(ent))
+        for got_d, got_i in ((Dm, Im), (D2, I2)):
+            assert got_i[q].tolist() == [e[1] for e in want], (R, k, q)
+            assert got_d[q].tolist() == [e[0] for e in want]
