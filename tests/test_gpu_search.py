@@ -318,6 +318,12 @@ def test_merge_topk_every_sort_width_against_a_host_sort(R, k):
     I = torch.stack([torch.randperm(R * k * 3, generator=g)[:R * k].view(R, k) for _ in range(Q)], 1).to(torch.int64)   # distinct ids per query
     pad = torch.rand(R, Q, k, generator=g) < 0.1
     D[pad], I[pad] = -3.4028234663852886e38, -1
+    if (R + k) % 2 == 0:
+        # lists in order (what searches return; the merge then ranks by binary search instead of sorting): sort every list by (score desc, id asc),
+        # padding last
+        key = torch.where(I >= 0, D.double() * 1e9 - I.double() * 1e-3, torch.full_like(D, -1e30, dtype=torch.float64))
+        order = key.argsort(dim=-1, descending=True)
+        D, I = torch.gather(D, -1, order), torch.gather(I, -1, order)
     Dm, Im = merge_topk(D.cuda(), I.cuda())
     words = pack_pairs(D, I).cuda()
     D2 = torch.empty(Q, k, device="cuda")

@@ -10,7 +10,8 @@ for k in (100, 1000):
         Q = 100
         g = torch.Generator(device="cuda").manual_seed(1)
         sc = torch.randn(R, Q, k, generator=g, device="cuda").sort(dim=-1, descending=True).values
-        ids = torch.randint(0, 1 << 30, (R, Q, k), generator=g, device="cuda")
+        # rows ascending along each list: exact score ties (a few per 100 k draws) then sit in (score desc, row asc) order, as a search returns them
+        ids = (torch.arange(k, device="cuda")[None, None, :] * R + torch.arange(R, device="cuda")[:, None, None]).expand(R, Q, k).contiguous()
         words = ((sc.view(torch.int32).to(torch.int64) << 32) | ids).contiguous()
         D = torch.empty(Q, k, device="cuda"); I = torch.empty(Q, k, dtype=torch.int64, device="cuda")
         fn = lambda: lib.lrx_merge_topk_packed(_lib.ptr(words), R, Q, k, _lib.ptr(D), _lib.ptr(I), _lib.current_stream())
