@@ -827,6 +827,10 @@ def main():
         #      gets.  Reported next to `value`, not as it.
         pipe = None
         try:
+            if world > 1:
+                # (more than one rank: the lanes' all-gathers would interleave on the communicator from two streams -- correct by construction, but
+                # it has never run on hardware, and a hang here would cost the whole line: the one-rank figures are in `configs`)
+                raise RuntimeError("skipped with more than one rank")
             from lightretriever_amd.pipeline import SearchLanes
             lanes = SearchLanes(sharded, lanes=2)
             mk = lambda: ops.embedding_bag_mean(table, q_ids, offs, normalize=True)
