@@ -2649,7 +2649,7 @@ k_merge_topk(const float* __restrict__ in_scores, const int64_t* __restrict__ in
   //      that list's entries in front of it -- a binary search each (words are distinct: a row belongs to one shard), no barrier-separated
   //      stages.  8 x top-100: 13.6 -> ~8 us, 8 x top-1000: 96 -> ~25 us.  Checked here, not assumed: one pass over adjacent pairs; any list out
   //      of order (exact ties re-ordered by a non-monotonic row map, a foreign caller) sends the query to the sort below.
-  if (R > 1) {
+  {                                                             // (R = 1: an ordered list is its own merge)
     int bad = 0;
     __syncthreads();                                            // buf is complete: a thread looks at its neighbour's entry next
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
