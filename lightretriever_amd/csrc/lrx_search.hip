@@ -22,7 +22,13 @@
 //     k_refine_merge (sorted top-k; or the query's fallback flag) -> gated exact fallback (scores_split<NP=3> + select_rescore).
 //     k_refine_topk: the refine step of the score-matrix filter (tiny shards, FILTER_MATRIX).  query_eps_block: the per-query error bound.
 //  D. Shard maintenance: k_shard_bounds, k_shard_rows_tiled (lrx_shard_commit_rows): fp16 shadow rows + {max |x|, max |x - fp16(x)|}.
-//  E. Multi-GPU result exchange: k_pack_topk / lrx_pack_topk, k_merge_topk / lrx_merge_topk[_packed] (after the RCCL all-gather).
+//     Round 4: k_sample_threshold tightens T' to the row-exact k-th sample score when the group maxima are clumpy (corpora stored cluster by
+//     cluster); lists hold >= 64 Ki entries; lrx_flat_ip_search_bounded_wire: the chain's last kernel (k_topk_select_rescore, idle unless a
+//     query was flagged) also writes every query's results as the 64-bit exchange words; lrx_search_fallback_count /
+//     lrx_flat_ip_bounded_list_counts: statistics.
+//  E. Multi-GPU result exchange: k_pack_topk / lrx_pack_topk (stand-alone form of the wire words), k_merge_topk / lrx_merge_topk[_packed]
+//     (after the RCCL all-gather): lists that arrive in order are RANKED (binary search per other list), anything else is sorted -- in
+//     registers (bitonic_sort_desc_regs) from 128 padded entries on.
 //
 // Every path ends with exact rescoring of the selected rows, so the reported scores do not depend on the path, the query batch size or
 // the shard layout; ties go to the lower row id.  Dead ends that were measured and dropped are noted where they would have gone.
