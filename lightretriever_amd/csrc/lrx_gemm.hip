@@ -624,8 +624,9 @@ static int gemm_group_m(int epilogue, int K) {
   if (env > 0) return env;
   // 1B shapes (K = 2048): gate-up 6, o/down 4, qkv 8; 8B shapes (K = 4096): within 2 % for 2..8, gate-up best at 8 (1596 TFLOP/s).
   // Round 4 sweep (tools/exp/gm_sweep.sh, M = 131 072): qkv 1.31-1.32 ms at 0 / 4 / 8 (1.34-1.59 elsewhere); down (K = 8192) 2.94 at 2 / 4, 3.03 at 6 / 8;
-  // o (N = K = 2048) 0.882-0.887 at 3 / 6 / 12 against 0.901-0.906 at 2 / 4 / 8 -> the residual GEMM takes 6 for K <= 2048.
-  return epilogue == EPI_SWIGLU ? (K >= 4096 ? 8 : 6) : (epilogue == EPI_RESID ? (K <= 2048 ? 6 : 4) : 8);
+  // o (N = K = 2048) 0.882-0.887 at 3 / 6 / 12 against 0.901-0.906 at 2 / 4 / 8; 8B o (N = K = 4096, fp32 stream) 1.798 at 6 against 1.82-1.84 at 2 / 4 / 8,
+  // 8B down (K = 14336) 5.36-5.37 at 2 / 4 against 5.49-5.51 at 6 / 8 (tools/exp/gm_sweep_8b.sh) -> the residual GEMMs take 6 for K <= 4096, 4 above.
+  return epilogue == EPI_SWIGLU ? (K >= 4096 ? 8 : 6) : (epilogue == EPI_RESID ? (K <= 4096 ? 6 : 4) : 8);
 }
 
 extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N,
