@@ -2506,7 +2506,10 @@ extern "C" int lrx_flat_ip_bounded_list_counts(const void* workspace, int64_t n_
   LRX_CHECK_ARG(workspace && counts_out && n_queries > 0 && n_queries <= (shadow ? 256 : 128), "bounded_list_counts: one query chunk only (n_queries=%d)", n_queries);
   const BoundedPlan p = plan_chunk(n_rows, dim, n_queries, k, shadow, flags & 3);
   const int* flg = (const int*)((const char*)workspace + p.off_ints);
-  const unsigned int* cnt = p.emit && n_rows > REF_CAND ? (const unsigned int*)(flg + ints_before_cnt(n_queries)) : nullptr;
+  // (the same test lrx_flat_ip_search_bounded_wire uses to send a call down the plain path, which keeps no lists)
+  const int qt_max = ((n_queries < 128 ? n_queries : 128) + 15) / 16;
+  const bool plain = (qt_max < SPLIT_MIN_QT && !shadow) || n_rows <= REF_CAND || dim % 4 != 0;
+  const unsigned int* cnt = p.emit && !plain ? (const unsigned int*)(flg + ints_before_cnt(n_queries)) : nullptr;
   hipLaunchKernelGGL(k_copy_list_counts, dim3((n_queries + 255) / 256), dim3(256), 0, (hipStream_t)stream, cnt, n_queries, counts_out);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
