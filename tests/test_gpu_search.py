@@ -305,7 +305,7 @@ def test_query_chunking_under_a_workspace_cap_changes_nothing():
     check_against_oracle(D0, I0, q, X, k)
 
 
-@pytest.mark.parametrize("R,k", [(1, 7), (2, 30), (2, 64), (8, 100), (3, 333), (8, 256), (2, 2048), (7, 1000), (8, 2048), (5, 1)])
+@pytest.mark.parametrize("R,k", [(1, 7), (2, 30), (2, 64), (8, 100), (3, 333), (8, 256), (2, 2048), (7, 1000), (8, 2048), (8, 2047), (4, 1023), (3, 100), (5, 1)])
 def test_merge_topk_every_sort_width_against_a_host_sort(R, k):
     """lrx_merge_topk / lrx_merge_topk_packed over the whole range of R x k (round 4: the sort behind them runs in registers, 2 .. 16 entries
     per thread, for 128 .. 16384 padded entries; the LDS form below that): random scores with exact ties across parts, -1 padding, against a
