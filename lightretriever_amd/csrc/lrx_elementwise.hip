@@ -132,18 +132,22 @@ extern "C" int lrx_probe_stream_read(const void* buf, size_t bytes, uint32_t* si
 // fp16 shadow elements k_pool_norm had to clamp (|v| > 65504 or NaN: an unnormalised row of a broken checkpoint); the shard's E bound keeps
 // the SEARCH exact in that case, this counter makes the event visible (lrx_device_saturation_count).
 __device__ unsigned int g_shadow_fp16_saturations = 0;
-unsigned int lrx_gemm_saturations(int reset, int* ok);      // lrx_gemm.hip
+unsigned int lrx_gemm_saturations(int* ok);                 // lrx_gemm.hip
+int lrx_gemm_saturations_reset();
 
 extern "C" int64_t lrx_device_saturation_count(int32_t reset) {
+  // both counters are READ before either is cleared: a failing second read leaves the first one intact (-1, nothing lost)
   unsigned int v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_shadow_fp16_saturations), sizeof(v)) != hipSuccess) return -1;
+  int ok = 0;
+  const unsigned int g = lrx_gemm_saturations(&ok);
+  if (!ok) return -1;
   if (reset && v) {
     const unsigned int z = 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_shadow_fp16_saturations), &z, sizeof(z)) != hipSuccess) return -1;
   }
-  int ok = 0;
-  const unsigned int g = lrx_gemm_saturations(reset, &ok);
-  return ok ? (int64_t)v + (int64_t)g : -1;
+  if (reset && g && !lrx_gemm_saturations_reset()) return -1;
+  return (int64_t)v + (int64_t)g;
 }
 
 extern "C" int64_t lrx_device_error_count(int32_t reset) {
@@ -373,7 +377,8 @@ __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidd
     const _Float16 h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
     if (shadow) {
       shadow[lrx_shadow_off(ra, i, out_dim)] = __builtin_bit_cast(__bf16, h);
-      if (!(fabsf(v) <= 65504.f)) atomicAdd(&g_shadow_fp16_saturations, 1u);
+      // (one atomic per wave instruction that saw any; the lanes of a wave that are still in the loop vote)
+      if (__any(!(fabsf(v) <= 65504.f))) { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_shadow_fp16_saturations, 1u); }
     }
     const float d = v - (float)h;
     r2 += v * v;

@@ -53,14 +53,14 @@ __device__ __forceinline__ __bf16 f2h_bits(float v) {   // fp16 (saturating) in 
 // above, which is a silent change of the model's arithmetic: counted here, read by lrx_device_saturation_count (one atomic per wave
 // that saw any, i.e. none on a healthy checkpoint).
 __device__ unsigned int g_qkv_fp16_saturations = 0;
-unsigned int lrx_gemm_saturations(int reset, int* ok) {
+unsigned int lrx_gemm_saturations(int* ok) {                 // read only: lrx_device_saturation_count resets after BOTH counters were read
   unsigned int v = 0;
   *ok = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_qkv_fp16_saturations), sizeof(v)) == hipSuccess;
-  if (*ok && reset && v) {
-    const unsigned int z = 0;
-    *ok = hipMemcpyToSymbol(HIP_SYMBOL(g_qkv_fp16_saturations), &z, sizeof(z)) == hipSuccess;
-  }
   return v;
+}
+int lrx_gemm_saturations_reset() {
+  const unsigned int z = 0;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_qkv_fp16_saturations), &z, sizeof(z)) == hipSuccess;
 }
 
 // Search filter pass (EPI_EMIT): A = the shard's tiled FP16 shadow (lrx_shadow_off), B = fp16 queries (f16 MFMA); no C.  A score reaching thr[query] is appended
@@ -498,7 +498,9 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
             o1[r] = f2h_bits(x1[r]);
             o2[r] = f2h_bits(x2[r]);
           }
-          if (sat) atomicAdd(&g_qkv_fp16_saturations, 1u);
+          // one atomic per wave INSTRUCTION that saw any (the wave votes, its first lane reports): on a healthy checkpoint none at all, on
+          // a broken one bounded contention on the counter instead of one atomic per lane
+          if (__any(sat)) { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_qkv_fp16_saturations, 1u); }
           const int c1 = cb + fq * 4, c2 = c1 + 16;
           *(bf16x4*)(smem + row * (CW * 2) + ((((c1 >> 3) ^ (row & 15)) << 4) | ((c1 & 4) << 1))) = o1;
           *(bf16x4*)(smem + row * (CW * 2) + ((((c2 >> 3) ^ (row & 15)) << 4) | ((c2 & 4) << 1))) = o2;

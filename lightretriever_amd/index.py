@@ -30,6 +30,15 @@ def shard_of(out: torch.Tensor):
 
 
 class FlatIPIndex:
+    """One HBM-resident shard.  Memory: 4 B/element fp32 rows + 2 B/element tiled fp16 shadow + the search workspace -- per lane in use,
+    for a chunk of up to 256 queries: candidate lists of max(64 Ki, 64 k rounded up to a power of two) 8-byte entries per query (512 KiB per
+    query up to k = 1024: 134 MB per 256-query chunk), the compact sample scores and the [128, ntotal] fp32 region of the gated fallback;
+    `lrx_flat_ip_bounded_workspace_bytes` is the exact figure.  A search of MORE than 256 queries forks its 256-query chunks over
+    `chunk_lanes` (2) internal HIP streams with one workspace each (so up to 2 x the figure above) unless that would exceed
+    `max_workspace_bytes`, in which case it runs the chunks one after the other on the caller's stream.  Lanes != 0 (pipeline.SearchLanes)
+    add one workspace each.  NOT thread-safe: an index keeps search state (workspaces, internal streams, the statistics of the last search);
+    two host threads must not call search() on the same index at the same time (concurrent searches from ONE thread go through
+    SearchLanes, one lane per search in flight)."""
     # lrx_flat_ip_search_bounded flags (_lib.SEARCH_FILTER_*): which filter the bounded search runs.  A class-level default that tests and A/B
     # tools override (per index or for all); the hits do not depend on it.  (Round 2 had a process-global switch inside the library.)
     search_flags = _lib.SEARCH_FILTER_AUTO
@@ -47,6 +56,7 @@ class FlatIPIndex:
         self._lane_ws: dict = {}             # lane != 0 -> its own workspace: searches in flight on different HIP streams must not share one
         self.chunk_lanes = 2                 # a search of more queries than one library chunk (256) alternates its chunks over this many internal streams
         self._chunk_streams = None
+        self._last_search = None             # what last_list_counts() needs to find the statistics of the last two-pass search
         # {max |row|, max |row - fp16(row)|} over the committed rows, kept on the device (no host sync): the error bound of the fp16
         # filter pass of lrx_flat_ip_search_bounded is built from them.  two_pass = False forces the six-product path for every search.
         self._bounds = torch.zeros(2, dtype=torch.float32, device=self.device)
@@ -210,7 +220,10 @@ class FlatIPIndex:
         return self._x[:self.ntotal]
 
     # -- search --------------------------------------------------------------------------------------------------
-    def _lane_workspace(self, lane: int, need: int) -> torch.Tensor:
+    def _lane_workspace(self, lane: int, need: int, user_stream: Optional["torch.cuda.Stream"] = None) -> torch.Tensor:
+        """The workspace of `lane`, grown to `need` bytes.  user_stream: the stream its kernels will run on when that is not the stream
+        current now (the internal chunk streams): the caching allocator is told, so that a later regrow / free cannot hand the block to the
+        caller's stream while kernels of that stream still use it."""
         ws = self._ws if lane == 0 else self._lane_ws.get(lane)
         if ws is None or ws.numel() < need:
             if torch.cuda.is_current_stream_capturing():
@@ -225,8 +238,8 @@ class FlatIPIndex:
             else:
                 self._lane_ws.pop(lane, None)
                 ws = self._lane_ws[lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
-                # (allocated under whatever stream is current, used on the lane's stream for the rest of its life: tell the caching allocator)
-                ws.record_stream(torch.cuda.current_stream())
+        if user_stream is not None and user_stream != torch.cuda.current_stream():
+            ws.record_stream(user_stream)
         return ws
 
     def search(self, q, k: int, wire_out: Optional[torch.Tensor] = None, row_map: Optional[torch.Tensor] = None, lane: int = 0):
@@ -264,17 +277,37 @@ class FlatIPIndex:
         # latency-bound kernels that frame one chunk's passes overlap the other chunk's passes (Q = 1000, top-1000 over a 100 k-row
         # chunk, the reference's operating point: 2.45 -> ~2.2 ms; the stream semantics of the call do not change).  Not under graph capture.
         fork = (self.two_pass and self.chunk_lanes > 1 and Q > lib_chunk and lane == 0 and not torch.cuda.is_current_stream_capturing())
+        if fork and int(ws_bytes(self.ntotal, self.d, min(chunk, lib_chunk), k)) * self.chunk_lanes > int(self.max_workspace_bytes):
+            fork = False                               # one workspace per internal stream would exceed the cap: chunks one after the other
         if fork:
             chunk = min(chunk, lib_chunk)
         need = int(ws_bytes(self.ntotal, self.d, chunk, k))
-        ws = self._lane_workspace(lane, need)
         cur = torch.cuda.current_stream()
         if fork:
             if self._chunk_streams is None:
                 self._chunk_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.chunk_lanes)]
-            lane_ws = [ws] + [self._lane_workspace(-j, need) for j in range(1, self.chunk_lanes)]   # (lane 0's own workspace is the first)
+            # (lane 0's own workspace serves the first internal stream, lanes -1, -2, ... the others)
+            lane_ws = [self._lane_workspace(-j, need, user_stream=self._chunk_streams[j]) for j in range(self.chunk_lanes)]
+            ws = lane_ws[0]
             start = torch.cuda.Event()
             start.record(cur)
+        else:
+            ws = self._lane_workspace(lane, need)
+        try:
+            self._run_chunks(q, D, I, k, chunk, fork, lane_ws if fork else None, ws, start if fork else None, xb, ldx, flags, row_map, wire_out)
+        finally:
+            if fork:                                   # the side streams are joined back whatever happened in the loop
+                for st in self._chunk_streams:
+                    cur.wait_stream(st)
+        if wire_out is not None and not self.two_pass:
+            _lib.check(self.lib.lrx_pack_topk(_lib.ptr(D), _lib.ptr(I), _lib.ptr(row_map), int(self.id_base), Q * k, _lib.ptr(wire_out), _lib.current_stream()))
+        # (nq of the last library chunk of the last host chunk, the ntotal / mode the workspace was planned for, and the workspace itself)
+        last_ws = lane_ws[((Q - 1) // chunk) % self.chunk_lanes] if fork else ws
+        self._last_search = (((Q - 1) % chunk) % lib_chunk + 1, k, flags, xb is not None, last_ws, self.ntotal, bool(self.two_pass))
+        return D, I
+
+    def _run_chunks(self, q, D, I, k, chunk, fork, lane_ws, ws, start, xb, ldx, flags, row_map, wire_out):
+        Q = q.shape[0]
         for j, s in enumerate(range(0, Q, chunk)):
             qc, Dc, Ic = q[s:s + chunk], D[s:s + chunk], I[s:s + chunk]
             if fork:
@@ -293,21 +326,18 @@ class FlatIPIndex:
             else:
                 _lib.check(self.lib.lrx_flat_ip_search(_lib.ptr(self._x), self.ntotal, ldx, self.d, _lib.ptr(self._bounds), _lib.ptr(qc), qc.shape[0], k,
                                                        self.id_base, _lib.ptr(Dc), _lib.ptr(Ic), _lib.ptr(ws), ws.numel(), stream))
-        if fork:
-            for st in self._chunk_streams:
-                cur.wait_stream(st)
-        if wire_out is not None and not self.two_pass:
-            _lib.check(self.lib.lrx_pack_topk(_lib.ptr(D), _lib.ptr(I), _lib.ptr(row_map), int(self.id_base), Q * k, _lib.ptr(wire_out), _lib.current_stream()))
-        self._last_search = (((Q - 1) % chunk) % lib_chunk + 1, k, flags, xb is not None, ws)
-        return D, I
 
     def last_list_counts(self) -> torch.Tensor:
         """uint32-valued int64 tensor [q]: candidate-list entries per query of the last chunk of the last two-pass search (the rows that
-        passed the filter threshold and reached the refine step) -- statistics for tools and bench legs."""
-        nq, k, flags, has_shadow, ws = self._last_search
+        passed the filter threshold and reached the refine step) -- statistics for tools and bench legs.  Zeros when the last search was
+        not a two-pass search (no candidate lists exist); raises before the first search."""
+        if self._last_search is None:
+            raise _lib.LrxError("last_list_counts(): no search has run on this index yet")
+        nq, k, flags, has_shadow, ws, ntotal, two_pass = self._last_search
         out = torch.zeros(nq, dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.lrx_flat_ip_bounded_list_counts(_lib.ptr(ws), self.ntotal, self.d, nq, k, flags, int(has_shadow), _lib.ptr(out),
-                                                            _lib.current_stream()))
+        if two_pass:                    # the workspace layout is the one planned for the ntotal of THAT search (add() / reset() since do not matter)
+            _lib.check(self.lib.lrx_flat_ip_bounded_list_counts(_lib.ptr(ws), ntotal, self.d, nq, k, flags, int(has_shadow), _lib.ptr(out),
+                                                                _lib.current_stream()))
         return out.to(torch.int64)
 
 

@@ -1,5 +1,7 @@
 """`InferenceArguments` + `PytorchRPCExactSearchModel` under the reference's names (inference/arguments.py:19-157,
-inference/exact_search_torchrpc.py:49-101), dense asymmetric configuration only.
+inference/exact_search_torchrpc.py:49-101): the vector-type flag sets of eval/README.md:13-52 -- symmetric dense
+(`--hybrid_use_dense_vector`), asymmetric dense (`--hybrid_use_emb_vector [--noncontextual_query_embedding]`), asymmetric sparse
+(`--hybrid_use_token_id_vector`) and their combinations -- with the defaults of the reference's argument classes.
 
 No RPC: one process per GPU under torchrun; every rank constructs this object, encodes its own share and keeps the
 embeddings in its HBM shard (lightretriever_amd.sharded).  The constructor signature, attribute names and the
@@ -19,20 +21,25 @@ from .modeling import LrxExactSearchModel, LrxHybridModel
 @dataclass
 class InferenceArguments:
     model_name_or_path: Optional[str] = None
-    model_type: str = "HybridModel"
+    # inference/arguments.py:27 + exact_search_torchrpc.py:84 `_MODEL_CLS[model_type]`: "EncoderModel" (the default) = the symmetric dense
+    # encoder (queries and documents through the LM, bare tensors, hybrid_* flags not read); "HybridModel" = the vector types the hybrid_*
+    # flags select, dict results.  Both are the same kernels here.
+    model_type: str = "EncoderModel"
     inference_arch: str = "PytorchRPCExactSearchModel"
     batch_size: int = 64
     append_prompt_sep: bool = False
     q_max_len: int = 128
     p_max_len: int = 512
-    bf16: bool = True
+    # (inference/arguments.py:68-73.  The HIP encoder has ONE arithmetic: bf16 MFMA operands, fp32 accumulation, fp32 residual stream;
+    # `--bf16` is accepted and recorded in `dtype`, it does not select a different kernel.  `--fp16` is refused.)
+    bf16: bool = False
     fp16: bool = False
     seed: int = 42
     attn_implementation: str = "flash_attention_2"   # accepted for CLI compatibility; the HIP path has one implementation
     cumulative_seq: bool = True                         # packed varlen is the only layout here
     liger_kernel: bool = False
     # model args that change the dense-path numerics (finetune/arguments.py:75-335)
-    pooling_strategy: str = "lasttoken"
+    pooling_strategy: Optional[str] = None             # finetune/arguments.py:83: None; 'lasttoken' is the one implemented (None is served as it)
     score_function: str = "cos_sim"
     dense_shrink_dim: Optional[int] = None
     lowercase: bool = False
@@ -44,9 +51,9 @@ class InferenceArguments:
     pad_token: str = "<|pad|>"
     add_sep_token: bool = False
     sep_token: str = "<|sep|>"
-    hybrid_use_dense_vector: bool = False
-    hybrid_use_emb_vector: bool = True
-    noncontextual_query_embedding: bool = True
+    hybrid_use_dense_vector: bool = False              # finetune/arguments.py:175-195: all four vector types and the EmbeddingBag
+    hybrid_use_emb_vector: bool = False                # switch are off by default; eval/README.md:13-52 picks them
+    noncontextual_query_embedding: bool = False
     noncontextual_prompt_prefix: Optional[str] = None
     eval_batch_size_embedding_bag: int = 5000
     # sparse document vectors (finetune/arguments.py:203-290): passages through the LM head, queries as token-id counts
@@ -104,7 +111,7 @@ class InferenceArguments:
         if self.normalize is None:
             self.normalize = self.score_function == "cos_sim"   # finetune/arguments.py:312-317
         self.pad_token, self.sep_token = default_special_tokens(self.model_name_or_path, self.pad_token, self.sep_token)
-        if self.pooling_strategy != "lasttoken":
+        if self.pooling_strategy not in (None, "lasttoken"):
             raise NotImplementedError("the MI355X path implements the shipped 'lasttoken' pooling only")
         if self.fp16:
             raise NotImplementedError("bf16 is the compute type of the HIP encoder")
@@ -113,14 +120,21 @@ class InferenceArguments:
                               ("use_sparse_linear_projector", False), ("use_sparse_down_projector", False), ("use_icu_word_pretokenizer", False),
                               ("sparse_remove_stopwords", False), ("sparse_pool_from_unique_token_ids", False),
                               ("sparse_pool_from_original_input_ids_qry", False), ("sparse_pool_from_original_input_ids_psg", False),
-                              ("sparse_use_max_aggregation", True), ("noncontextual_query_embedding", True), ("hybrid_use_dense_vector", False)):
+                              ("sparse_use_max_aggregation", True)):
             if getattr(self, name) != default:
-                raise NotImplementedError(f"--{name}={getattr(self, name)!r}: the MI355X path implements the asymmetric retriever only "
-                                          f"(documents through the LM, queries through the EmbeddingBag / token-id counts)")
+                raise NotImplementedError(f"--{name}={getattr(self, name)!r}: not implemented by the MI355X path (one tied gpt-style encoder, "
+                                          f"LM-head max aggregation for the sparse document vector)")
+        if self.model_type not in ("EncoderModel", "HybridModel"):
+            raise NotImplementedError(f"--model_type {self.model_type}: the MI355X path serves EncoderModel and HybridModel")
+        if self.model_type == "HybridModel" and not (self.hybrid_use_dense_vector or self.hybrid_use_emb_vector or self.hybrid_use_sparse_vector
+                                                     or self.hybrid_use_token_id_vector):
+            raise ValueError("no vector type selected: pass at least one of --hybrid_use_dense_vector / --hybrid_use_emb_vector "
+                             "[--noncontextual_query_embedding] / --hybrid_use_token_id_vector (eval/README.md:13-30)")
         if self.hybrid_use_sparse_vector and not self.hybrid_use_token_id_vector:
             raise NotImplementedError("--hybrid_use_sparse_vector without --hybrid_use_token_id_vector asks for query vectors from the LM head; "
                                       "the query side here is parameter-free (token-id counts)")
-        self.encode_sparse = self.hybrid_use_sparse_vector or self.hybrid_use_token_id_vector   # modeling_hybrid.py:241-245
+        hybrid = self.model_type == "HybridModel"
+        self.encode_sparse = hybrid and (self.hybrid_use_sparse_vector or self.hybrid_use_token_id_vector)   # modeling_hybrid.py:241-245
 
 
 def arguments_from_checkpoint(model_name_or_path: str, **overrides) -> "InferenceArguments":
@@ -131,22 +145,26 @@ def arguments_from_checkpoint(model_name_or_path: str, **overrides) -> "Inferenc
     saved = load_model_args(model_name_or_path)
     known = {f.name for f in dataclasses.fields(InferenceArguments)}
     kw = {k: v for k, v in saved.items() if k in known and v is not None}
-    # Query-side TRAINING objectives the checkpoint also carried -- the symmetric dense vector (`--hybrid_use_dense_vector`, in
-    # scripts/finetune_example.sh:47 and eval/README.md:24, hence in every released model_args.yaml) and LM-head query vectors
-    # (`--hybrid_use_sparse_vector`) -- select LM-encoded QUERIES.  This path serves the asymmetric retriever (EmbeddingBag / token-id
-    # queries; the document side computes the dense vector whatever these flags say, modeling_hybrid.py:235-245), so a resumed checkpoint
-    # drops them with a warning instead of refusing to load; passing them explicitly still raises in __post_init__.
-    for flag, what in (("hybrid_use_dense_vector", "symmetric dense query vectors"), ("hybrid_use_sparse_vector", "LM-head sparse query vectors")):
-        if kw.get(flag) and flag not in overrides:
-            import logging
+    # `--hybrid_use_sparse_vector` selects LM-head sparse QUERY vectors next to the sparse document vectors; the query side of the sparse
+    # half is parameter-free here (token-id counts).  A checkpoint that was ALSO trained with `--hybrid_use_token_id_vector` is served
+    # asymmetrically (the document side keeps producing the sparse vector, modeling_hybrid.py:244-245) and the flag is dropped with a
+    # warning; one trained with LM-head query vectors ONLY has no query representation this path can produce for its sparse half: that is
+    # an error unless the caller overrides the flags.  (`--hybrid_use_dense_vector`, in every released model_args.yaml, is served as saved.)
+    if kw.get("hybrid_use_sparse_vector") and "hybrid_use_sparse_vector" not in overrides:
+        import logging
+        if kw.get("hybrid_use_token_id_vector") or overrides.get("hybrid_use_token_id_vector"):
             logging.getLogger(__name__).warning(
-                "%s: model_args.yaml has %s=True (%s: queries through the LM); the MI355X path encodes queries with the EmbeddingBag / "
-                "token-id counts only -- flag dropped, asymmetric vectors served", model_name_or_path, flag, what)
-            kw[flag] = False
-            if flag == "hybrid_use_sparse_vector":
-                kw.setdefault("hybrid_use_token_id_vector", True)          # the document side keeps producing the sparse vector it was trained for
+                "%s: model_args.yaml has hybrid_use_sparse_vector=True (LM-head sparse query vectors); the MI355X path encodes sparse queries as "
+                "token-id counts only -- flag dropped, the asymmetric sparse vectors the checkpoint was also trained for are served", model_name_or_path)
+            kw["hybrid_use_sparse_vector"] = False
+        elif "hybrid_use_token_id_vector" not in overrides:
+            raise NotImplementedError(
+                f"{model_name_or_path}: model_args.yaml has hybrid_use_sparse_vector=True without hybrid_use_token_id_vector: its sparse half needs "
+                "LM-head query vectors, which the MI355X path does not produce.  Pass hybrid_use_sparse_vector=False (dense vectors only) or "
+                "hybrid_use_token_id_vector=True (token-id-count queries against its sparse document vectors) explicitly.")
     kw.update(overrides)
     kw["model_name_or_path"] = model_name_or_path
+    kw.setdefault("model_type", "HybridModel")     # (model_args.yaml holds the training ModelArguments: no model_type; this mirrors HybridModel.load)
     return InferenceArguments(**kw)
 
 
@@ -170,14 +188,19 @@ class PytorchRPCExactSearchModel(LrxExactSearchModel):
                              sep_token=args.sep_token)
         enc = encoder_from_pretrained(args.model_name_or_path, max_positions=max(args.p_max_len, args.q_max_len, 64), device=dev, tokenizer=tok,
                                       pad_to_multiple_of=getattr(args, "pad_to_multiple_of", None))
+        hybrid = args.model_type == "HybridModel"
         hm = LrxHybridModel(enc, normalize=args.normalize, dense_shrink_dim=args.dense_shrink_dim, pad_token_id=tok.pad_token_id,
                             encode_sparse=args.encode_sparse, sep_token_id=getattr(tok, "sep_token_id", None), add_sep_token=args.add_sep_token,
                             sparse_use_relu=args.sparse_use_relu, sparse_use_log_saturation=args.sparse_use_log_saturation,
                             sparse_top_k_psg=args.sparse_top_k_psg, sparse_top_p_psg=args.sparse_top_p_psg,
-                            sparse_min_tokens_to_keep=args.sparse_min_tokens_to_keep)
+                            sparse_min_tokens_to_keep=args.sparse_min_tokens_to_keep,
+                            hybrid_use_dense_vector=args.hybrid_use_dense_vector if hybrid else True,      # EncoderModel: the symmetric dense vector
+                            hybrid_use_emb_vector=args.hybrid_use_emb_vector if hybrid else False,
+                            noncontextual_query_embedding=args.noncontextual_query_embedding if hybrid else False)
         super().__init__(model=hm, tokenizer=tok, q_max_len=args.q_max_len, p_max_len=args.p_max_len,
                          append_prompt_sep=args.append_prompt_sep, eval_batch_size_embedding_bag=args.eval_batch_size_embedding_bag,
-                         token_id_vector_type=args.token_id_vector_type, noncontextual_prompt_prefix=args.noncontextual_prompt_prefix)
+                         token_id_vector_type=args.token_id_vector_type, noncontextual_prompt_prefix=args.noncontextual_prompt_prefix,
+                         single_tensor_output=not hybrid)
         self.encoding_kwargs["anserini_vector_type"] = args.anserini_vector_type      # exact_search_torchrpc.py:100-101
         from . import rpc_shards
         rpc_shards.register_worker(self)              # the model remote calls of a driving rank will use (MODEL_REGISTRY of the reference)

@@ -41,7 +41,10 @@ class EncodeCollator:
     request, the reference's right-padded `[B, S]` ids/mask for callers that want the original layout.
     Queries (noncontextual_query_embedding): raw text, no prompt, no specials, truncated to q_max_len;
     `nonctx_tok_emb_input_ids` int64 [sum len], `nonctx_tok_emb_offsets` int64 [Q] = cumsum([0] + len[:-1])
-    (nonctx_emb_utils.py:197-219)."""
+    (nonctx_emb_utils.py:197-219).  Queries that go through the LM (symmetric dense vector, `hybrid_use_dense_vector`; the LM's input
+    embedding layer as the bag, `noncontextual_query_embedding=False`): `prompt + text` with specials, truncation 'only_first' to
+    q_max_len, packed like the documents -- the reference tokenises that for EVERY query batch (exact_search_base.py:333-345); here it
+    is made on request (`query_lm_inputs`) and rides next to the EmbeddingBag fields in the same dict."""
     tokenizer: object
     encode_is_query: bool
     q_max_len: int = 512
@@ -51,15 +54,19 @@ class EncodeCollator:
     sparse_mask: bool = False                 # also emit `sparse_mask` uint8 [T] (get_sparse_attention_mask) for the sparse branch
     sep_token_id: Optional[int] = None
     add_sep_token: bool = False
+    query_lm_inputs: Optional[bool] = None    # queries: also emit the packed `prompt + text` LM inputs (None = only when no EmbeddingBag fields are made)
 
     def __call__(self, texts: list[dict]) -> dict:
+        bag = {}
         if self.encode_is_query and self.noncontextual_query_embedding:
             enc = self.tokenizer([format_text(t) for t in texts], max_length=self.q_max_len, truncation=True,
                                  add_special_tokens=False, return_attention_mask=False)["input_ids"]
             lens = [len(e) for e in enc]
             flat = np.concatenate([np.asarray(e, dtype=np.int64) for e in enc]) if sum(lens) else np.zeros(0, np.int64)
             offsets = np.cumsum([0] + lens[:-1]).astype(np.int64)
-            return {"nonctx_tok_emb_input_ids": torch.from_numpy(flat), "nonctx_tok_emb_offsets": torch.from_numpy(offsets)}
+            bag = {"nonctx_tok_emb_input_ids": torch.from_numpy(flat), "nonctx_tok_emb_offsets": torch.from_numpy(offsets)}
+            if not self.query_lm_inputs:
+                return bag
         max_len = self.q_max_len if self.encode_is_query else self.p_max_len
         enc = self.tokenizer([format_text(t, prepend_prompt=True) for t in texts], max_length=max_len, truncation="only_first",
                              padding=False, add_special_tokens=True, return_attention_mask=False)["input_ids"]
@@ -79,6 +86,7 @@ class EncodeCollator:
             for i, e in enumerate(enc):
                 ids[i, :len(e)], mask[i, :len(e)] = e, 1
             out["padded_input_ids"], out["padded_attention_mask"] = torch.from_numpy(ids), torch.from_numpy(mask)
+        out.update(bag)
         return out
 
 
@@ -135,17 +143,26 @@ def _top_p_filter(scores: torch.Tensor, top_p: float, min_tokens_to_keep: int) -
 # per-batch operators (B3)
 # ------------------------------------------------------------------------------------------------------------------
 class LrxHybridModel:
-    """encode_passage / encode_query of the reference's HybridModel restricted to the dense asymmetric configuration
-    (`hybrid_use_emb_vector` + `noncontextual_query_embedding`; score_function cos_sim -> normalize=True)."""
+    """encode_passage / encode_query of the reference's HybridModel (one tied encoder, lasttoken pooling): documents through the LM;
+    queries as the asymmetric EmbeddingBag vector (`hybrid_use_emb_vector` + `noncontextual_query_embedding`, the default here), as the
+    symmetric dense vector (`hybrid_use_dense_vector`: the query through the same LM, modeling_hybrid.py:363-401) or as the mean of the
+    LM's input embeddings (`hybrid_use_emb_vector` without `noncontextual_query_embedding`, the reference's ablation, :476-486);
+    score_function cos_sim -> normalize=True."""
 
     def __init__(self, encoder: LrxEncoder, normalize: bool = True, dense_shrink_dim: Optional[int] = None,
                  pad_token_id: Optional[int] = None, encode_sparse: bool = False, sep_token_id: Optional[int] = None,
                  add_sep_token: bool = False, sparse_use_relu: bool = True, sparse_use_log_saturation: bool = True,
                  sparse_top_k_psg: int = 0, sparse_top_p_psg: float = 1.0, sparse_min_tokens_to_keep: int = 8,
-                 sparse_round_bf16: bool = True):
-        """The sparse_* / add_sep_token / sep_token_id fields carry the reference's ModelArguments of the same names
-        (finetune/arguments.py:220-290); encode_sparse = hybrid_use_sparse_vector or hybrid_use_token_id_vector."""
+                 sparse_round_bf16: bool = True, hybrid_use_dense_vector: bool = False, hybrid_use_emb_vector: bool = True,
+                 noncontextual_query_embedding: bool = True):
+        """The sparse_* / add_sep_token / sep_token_id / hybrid_use_* / noncontextual_query_embedding fields carry the reference's
+        ModelArguments of the same names (finetune/arguments.py:175-290); encode_sparse = hybrid_use_sparse_vector or
+        hybrid_use_token_id_vector."""
         self.encoder = encoder
+        self.hybrid_use_dense_vector = hybrid_use_dense_vector
+        self.hybrid_use_emb_vector = hybrid_use_emb_vector
+        self.noncontextual_query_embedding = noncontextual_query_embedding
+        self._lm_emb_table: Optional[torch.Tensor] = None   # fp32 copy of embed_tokens, made on first use by the input-embedding bag
         self.normalize = normalize
         self.dense_shrink_dim = dense_shrink_dim
         self.pad_token_id = pad_token_id
@@ -175,18 +192,21 @@ class LrxHybridModel:
         normalize = self.normalize if normalize is None else normalize
         if encode_sparse or (encode_sparse is None and self.encode_sparse):
             return self._encode_passage_sparse(psg, bool(normalize), out)
-        ids = psg["input_ids"]
-        if "cu_seqlens" in psg:
-            ids = ids.to(self.device, non_blocking=True)
-            cu = psg["cu_seqlens"].to(self.device, non_blocking=True)
-            max_len = int(psg["max_seqlen"])
-        else:
-            if psg.get("attention_mask") is None:
-                raise KeyError("encode_passage: padded input needs attention_mask")
-            ids, cu, max_len = pack_padded_batch(ids.to(self.device), psg["attention_mask"].to(self.device))
-        reps = self.encoder.encode_packed(ids.to(torch.int32), cu.to(torch.int32), max_len, out=out, out_dim=self.dense_shrink_dim,
-                                          normalize=bool(normalize))
+        ids, cu, max_len = self._packed_lm_inputs(psg, "encode_passage")
+        reps = self.encoder.encode_packed(ids, cu, max_len, out=out, out_dim=self.dense_shrink_dim, normalize=bool(normalize))
         return {"dense_reps": reps}
+
+    def _packed_lm_inputs(self, batch: dict, who: str):
+        """(ids int32 [T], cu_seqlens int32 [B+1], max_seqlen) on the GPU from a packed batch or from the reference's padded ids + mask"""
+        if "input_ids" not in batch:
+            raise KeyError(f"{who}: the batch carries no `input_ids` (LM inputs)")
+        ids = batch["input_ids"]
+        if "cu_seqlens" in batch:
+            return (ids.to(self.device, dtype=torch.int32, non_blocking=True), batch["cu_seqlens"].to(self.device, dtype=torch.int32, non_blocking=True),
+                    int(batch["max_seqlen"]))
+        if batch.get("attention_mask") is None:
+            raise KeyError(f"{who}: padded input needs attention_mask")
+        return pack_padded_batch(ids.to(self.device), batch["attention_mask"].to(self.device))
 
     def _encode_passage_sparse(self, psg: dict, normalize: bool, out: Optional[torch.Tensor]):
         ids = psg["input_ids"]
@@ -238,18 +258,39 @@ class LrxHybridModel:
                 out.append({str(int(i)): int(v) for i, v in zip(ids[b, :n], w[b, :n])})
         return out
 
-    def encode_query(self, qry: Optional[dict], normalize: Optional[bool] = None, **kwargs):
-        """-> {"emb_reps": fp32 [Q, D]} from nonctx_tok_emb_input_ids / nonctx_tok_emb_offsets (modeling_hybrid.py:472-490)."""
+    def encode_query(self, qry: Optional[dict], normalize: Optional[bool] = None, encode_dense: Optional[bool] = None,
+                     encode_emb_reps: Optional[bool] = None, **kwargs):
+        """modeling_hybrid.py:327-500 -> a dict with, as enabled (argument override, else the model's flag -- the reference's rule :362-366):
+          `dense_reps` fp32 [Q, D]: the query (`prompt + text`, specials) through the LM, lasttoken pooling, slice, normalise (:363-401);
+          `emb_reps`   fp32 [Q, D]: EmbeddingBag mean over nonctx_tok_emb_input_ids / nonctx_tok_emb_offsets (:472-474), or -- without
+                       `noncontextual_query_embedding` -- the mean of the LM's input embeddings over the query's tokens (:476-486);
+                       slice, normalise (:487-490).
+        LM inputs: packed {"input_ids" [T], "cu_seqlens" [Q+1], "max_seqlen"} or the reference's padded ids + attention_mask."""
         if qry is None:
             return None
-        if self.emb_bag is None:
-            raise AssertionError("Please load or construct an EmbeddingBag before encoding queries")
         normalize = self.normalize if normalize is None else normalize
-        ids = qry["nonctx_tok_emb_input_ids"].to(self.device, dtype=torch.int64)
-        offs = qry["nonctx_tok_emb_offsets"].to(self.device, dtype=torch.int64)
-        reps = ops.embedding_bag_mean(self.emb_bag, ids, offs, padding_idx=self.pad_token_id, out_dim=self.dense_shrink_dim,
-                                      normalize=bool(normalize))
-        return {"emb_reps": reps}
+        encode_dense = bool(encode_dense or (encode_dense is None and self.hybrid_use_dense_vector))
+        encode_emb = bool(encode_emb_reps or (encode_emb_reps is None and self.hybrid_use_emb_vector))
+        out = {}
+        lm_in = self._packed_lm_inputs(qry, "encode_query") if (encode_dense or (encode_emb and not self.noncontextual_query_embedding)) else None
+        if encode_dense:
+            out["dense_reps"] = self.encoder.encode_packed(lm_in[0], lm_in[1], lm_in[2], out_dim=self.dense_shrink_dim, normalize=bool(normalize))
+        if encode_emb and self.noncontextual_query_embedding:
+            if self.emb_bag is None:
+                raise AssertionError("Please load or construct an EmbeddingBag before encoding queries")
+            ids = qry["nonctx_tok_emb_input_ids"].to(self.device, dtype=torch.int64)
+            offs = qry["nonctx_tok_emb_offsets"].to(self.device, dtype=torch.int64)
+            out["emb_reps"] = ops.embedding_bag_mean(self.emb_bag, ids, offs, padding_idx=self.pad_token_id, out_dim=self.dense_shrink_dim,
+                                                     normalize=bool(normalize))
+        elif encode_emb:
+            # the LM's own input embedding layer as the bag: every real token of the query counts (the attention mask is what the packed
+            # layout already encodes), no padding_idx -- `pooling(inputs_embeds, attention_mask, 'mean')`
+            if self._lm_emb_table is None:
+                self._lm_emb_table = self.encoder.embed.float().contiguous()
+            ids, cu = lm_in[0].to(torch.int64), lm_in[1]
+            out["emb_reps"] = ops.embedding_bag_mean(self._lm_emb_table, ids, cu[:-1].to(torch.int64).contiguous(), padding_idx=None,
+                                                     out_dim=self.dense_shrink_dim, normalize=bool(normalize))
+        return out
 
     # -- EmbeddingBag construction (nonctx_emb_utils.py:239-313) --------------------------------------------------------
     def construct_embedding_bag(self, tokenizer, prompt: Optional[str] = None, batch_size: int = 5000, vocab_len: Optional[int] = None,
@@ -446,6 +487,9 @@ class LrxExactSearchModel:
     noncontextual_prompt_prefix: Optional[str] = None   # finetune/arguments.py: prepended to the query prompt inside the EmbeddingBag table
     max_batch_tokens: int = 131072             # encode(): consecutive batches are merged up to this many tokens (0 = off; 256 x 512)
     max_batch_docs: int = 2048                 # ... and this many documents (bounds the [docs, vocab] sparse activations)
+    # the reference's EncoderModel returns a bare Tensor, its HybridModel a dict (exact_search_torchrpc.py:288-295: "if emb is single emb
+    # type, we should return the emb alone"): True = hand back the only representation itself
+    single_tensor_output: bool = False
 
     def __post_init__(self):
         # every id the tokenizer can produce needs an embedding row (the reference grows the matrix with resize_emb,
@@ -476,22 +520,39 @@ class LrxExactSearchModel:
         return items
 
     def encode_queries(self, queries, batch_size: int, show_progress_bar: bool = True, convert_to_tensor: bool = True, **kwargs):
-        items = _as_items(queries)
-        # the query prompt lives inside the EmbeddingBag table (exact_search_torchrpc.py:139-160): the model's query_prompt, else the
-        # `prompt` column of the first query, with noncontextual_prompt_prefix in front; rebuilt when it changes
-        prompt = self.query_prompt or (items[0].get("prompt") if items and isinstance(items[0], dict) else None)
-        if self.noncontextual_prompt_prefix:
-            prompt = self.noncontextual_prompt_prefix + prompt if prompt else self.noncontextual_prompt_prefix
-        if self.model.emb_bag is None or self.model.emb_bag_prompt != prompt:
-            self.model.construct_embedding_bag(self.tokenizer, prompt=prompt, batch_size=self.eval_batch_size_embedding_bag)
-        coll = EncodeCollator(self.tokenizer, encode_is_query=True, q_max_len=self.q_max_len, p_max_len=self.p_max_len)
-        outs = []
-        for s in range(0, len(items), batch_size):
-            outs.append(self.model.encode_query(coll(items[s:s + batch_size]))["emb_reps"])
-        reps = torch.cat(outs, 0)
-        res = {"emb_reps": reps if convert_to_tensor else reps.cpu().numpy()}
-        if self.model.encode_sparse:
+        """-> {"emb_reps"?, "dense_reps"?, "token_id_reps"?} by the model's flags (exact_search_base.py:94-122 + exact_search_torchrpc.py:139-170)."""
+        items = self.parse_texts(queries, prompt=self.query_prompt)        # the `prompt` column the LM-encoded query vectors prepend
+        hm = self.model
+        use_dense = bool(getattr(hm, "hybrid_use_dense_vector", False))
+        use_emb = bool(getattr(hm, "hybrid_use_emb_vector", True))
+        nonctx = bool(getattr(hm, "noncontextual_query_embedding", True))
+        if use_emb and nonctx:
+            # the query prompt lives inside the EmbeddingBag table (exact_search_torchrpc.py:139-160): the model's query_prompt, else the
+            # `prompt` column of the first query, with noncontextual_prompt_prefix in front; rebuilt when it changes
+            prompt = self.query_prompt or (items[0].get("prompt") if items and isinstance(items[0], dict) else None)
+            if self.noncontextual_prompt_prefix:
+                prompt = self.noncontextual_prompt_prefix + prompt if prompt else self.noncontextual_prompt_prefix
+            if hm.emb_bag is None or hm.emb_bag_prompt != prompt:
+                hm.construct_embedding_bag(self.tokenizer, prompt=prompt, batch_size=self.eval_batch_size_embedding_bag)
+        need_lm = use_dense or (use_emb and not nonctx)
+        coll = EncodeCollator(self.tokenizer, encode_is_query=True, q_max_len=self.q_max_len, p_max_len=self.p_max_len,
+                              noncontextual_query_embedding=use_emb and nonctx, query_lm_inputs=need_lm)
+        outs: dict = {}
+        for s in (range(0, len(items), batch_size) if (need_lm or (use_emb and nonctx)) else ()):     # (token-id-only models tokenise in token_id_reps)
+            for k, v in hm.encode_query(coll(items[s:s + batch_size])).items():
+                outs.setdefault(k, []).append(v)
+        res = {}
+        for k, parts in outs.items():
+            reps = torch.cat(parts, 0)
+            res[k] = reps if convert_to_tensor else reps.cpu().numpy()
+        if hm.encode_sparse:
             res["token_id_reps"] = self.token_id_reps(items)
+        return self._unwrap(res)
+
+    def _unwrap(self, res: dict):
+        if self.single_tensor_output:
+            assert len(res) == 1, f"Not single representations: {list(res)}"
+            return next(iter(res.values()))
         return res
 
     def encode_corpus(self, corpus, batch_size: int, show_progress_bar: bool = True, convert_to_tensor: bool = True,
@@ -510,7 +571,7 @@ class LrxExactSearchModel:
             from . import rpc_shards
             names = rpc_shards.rpc_workers()
             if len(names) > 1 and rpc_shards._WORKER.get("model") is self:
-                return rpc_shards.encode_fanout(names, items, batch_size, convert_to_tensor, self.model.device)
+                return self._unwrap(rpc_shards.encode_fanout(names, items, batch_size, convert_to_tensor, self.model.device))
         coll = EncodeCollator(self.tokenizer, encode_is_query=False, q_max_len=self.q_max_len, p_max_len=self.p_max_len, sparse_mask=sparse,
                               sep_token_id=self.model.sep_token_id, add_sep_token=self.model.add_sep_token)
         D = self.model.dense_shrink_dim or self.model.encoder.cfg.hidden_size
@@ -525,4 +586,4 @@ class LrxExactSearchModel:
         res = {"dense_reps": reps if convert_to_tensor else reps.cpu().numpy()}
         if sparse:
             res["sparse_reps"] = sparse_json
-        return res
+        return self._unwrap(res)

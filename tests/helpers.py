@@ -58,3 +58,12 @@ def flat_ip_topk_fp64(q, X, k):
     S = (np.asarray(q, np.float64) @ np.asarray(X, np.float64).T).astype(np.float32)
     order = np.lexsort((np.broadcast_to(np.arange(S.shape[1]), S.shape), -S), axis=-1)[:, :k]
     return np.take_along_axis(S, order, axis=1), order
+
+
+def load_query_modes():
+    """tests/golden/query_modes.npz (gen_query_goldens.py: the reference's encode_query in its LM-encoded modes on the llama_small_d64
+    model) -> (oracle cfg, weights, fixture, meta dict)."""
+    import json
+    cfg, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    g = np.load(os.path.join(GOLDEN, "query_modes.npz"))
+    return cfg, w, g, json.loads(bytes(g["meta_json"]).decode())

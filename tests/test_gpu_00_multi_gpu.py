@@ -1,0 +1,83 @@
+"""Multi-GPU (RCCL) execution of the sharded search path -- the file sorts FIRST among the `-m gpu` files so that on a multi-GPU box the
+children are started before anything in this pytest process has touched a GPU (`torch.cuda.device_count()` does not initialise it).
+
+  * on ANY GPU box: the worker script (tests/dist_workers/rccl_cases.py) under `torch.distributed.run --nproc-per-node 1` with the exchange
+    forced -- the same code, one RCCL rank: proves the script and the launch shape;
+  * gated on `torch.cuda.device_count() >= 2`: the same script with R = 2, 4, 8 ranks as available -- ShardedFlatIPIndex.search over RCCL ==
+    one index bit for bit (k = 100 and 1000, a row count no R divides, contiguous and interleaved shards, a duplicate pair across shards),
+    pipeline.SearchLanes over the communicator, HybridSearch.search over RCCL ranks == single process -- and `bench.py --gpus R`, whose
+    line must report `rccl_ranks == R` and the per-rank shard sizes.
+
+Replaces retriever/faiss_index.py:60-70 (Faiss IndexShards over all GPUs) and the RPC fan-out of inference/exact_search_torchrpc.py:243-328.
+A failing rank exits non-zero (torch.distributed.run reports it); no process that has initialised a GPU is ever re-exec'ed."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_workers", "rccl_cases.py")
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LRX_FORCE_COLLECTIVE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def _run_ranks(n_ranks, cases, timeout=900):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), WORKER, cases]
+    out = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, "rank failure (rc %d)\n%s\n%s" % (out.returncode, out.stdout[-3000:], out.stderr[-6000:])
+    assert "RCCL_ALL_OK ranks=%d" % n_ranks in out.stdout, out.stdout[-3000:]
+    return [l for l in out.stdout.splitlines() if l.startswith("RCCL_CASE_OK")]
+
+
+def _ranks_available():
+    n = torch.cuda.device_count()                    # (no GPU initialisation on this image)
+    return [r for r in (2, 4, 8) if r <= n]
+
+
+def test_worker_script_with_one_rccl_rank_and_the_exchange_forced():
+    notes = _run_ranks(1, "sharded,lanes,hybrid")
+    assert len(notes) == 3, notes
+    print("\n".join(notes))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL ranks on distinct devices)")
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_sharded_search_lanes_and_hybrid_search_over_rccl_ranks(n_ranks):
+    if n_ranks not in _ranks_available():
+        pytest.skip("only %d GPU(s) visible" % torch.cuda.device_count())
+    notes = _run_ranks(n_ranks, "sharded,lanes,hybrid")
+    assert len(notes) == 3, notes
+    print("\n".join(notes))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL ranks on distinct devices)")
+def test_bench_line_reports_the_rccl_ranks_and_the_shard_sizes():
+    n_ranks = max(_ranks_available())
+    rows = 1_000_003                                 # no R divides it: the remainder rows go one each to the first ranks
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--legs", "encode,search",
+                          "--index-rows", str(rows)], env=_env(), capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-6000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == n_ranks and line["rccl_ranks"] == n_ranks and line["config"]["parallelism"] == "dp%d" % n_ranks
+    s = line["search"]
+    assert s["rccl_ranks"] == n_ranks and len(s["shard_rows_per_rank"]) == n_ranks and sum(s["shard_rows_per_rank"]) == rows
+    assert max(s["shard_rows_per_rank"]) - min(s["shard_rows_per_rank"]) <= 1 and s["value"] > 0
+    assert s["two_in_flight"].get("identical_to_one_at_a_time") is True, s["two_in_flight"]     # the lanes ran over the communicator
+    assert line["search_qps"] == s["value"] and line["headline"]["rccl_ranks"] == n_ranks

@@ -209,7 +209,8 @@ def test_checkpoint_dir_to_search_via_reference_entry_point(tmp_path):
     m.save_pretrained(ckpt, safe_serialization=True)
     for f in os.listdir(os.path.join(GOLDEN, "tok")):
         shutil.copy(os.path.join(GOLDEN, "tok", f), ckpt)
-    args = InferenceArguments(model_name_or_path=ckpt, q_max_len=16, p_max_len=48, batch_size=8, eval_batch_size_embedding_bag=128)
+    args = InferenceArguments(model_name_or_path=ckpt, q_max_len=16, p_max_len=48, batch_size=8, eval_batch_size_embedding_bag=128, model_type="HybridModel",
+                              hybrid_use_emb_vector=True, noncontextual_query_embedding=True, bf16=True)
     model = PytorchRPCExactSearchModel(args)
     model.query_prompt = "query: "
     rng = np.random.default_rng(5)
@@ -303,7 +304,7 @@ def test_cli_arguments_wire_the_sparse_branch_through_the_reference_entry_point(
         shutil.copy(os.path.join(GOLDEN, "tok", f), ckpt)
     (args,) = HfArgumentParser(InferenceArguments).parse_args_into_dataclasses(
         ["--model_name_or_path", ckpt, "--q_max_len", "16", "--p_max_len", "48", "--batch_size", "8", "--eval_batch_size_embedding_bag", "128",
-         "--hybrid_use_emb_vector", "--hybrid_use_token_id_vector", "--hybrid_use_sparse_vector", "--sparse_use_relu", "--sparse_use_log_saturation",
+         "--model_type", "HybridModel", "--hybrid_use_emb_vector", "--noncontextual_query_embedding", "--hybrid_use_token_id_vector", "--hybrid_use_sparse_vector", "--sparse_use_relu", "--sparse_use_log_saturation",
          "--sparse_top_k_psg", "12", "--token_id_vector_type", "bow", "--anserini_vector_type", "JsonVectorCollection"])
     assert args.encode_sparse and args.normalize
     model = PytorchRPCExactSearchModel(args)

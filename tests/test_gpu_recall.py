@@ -1,0 +1,43 @@
+"""End-to-end retrieval agreement: north_star asks for "embeddings matching the reference within 1e-3 cosine AND
+identical top-k recall on the same inputs".  The search half is exact on given embeddings (tests/test_gpu_search*.py); this test closes
+the loop: ONE synthetic corpus (>= 20 000 ragged documents) and ONE query set (200 asymmetric EmbeddingBag queries + 200 symmetric dense
+queries) at Llama-3.2-1B dims and depth, trained-like weights, through three complete pipelines on the same GPU --
+
+    lrx      lrx_encode_packed / lrx_encode_prefixed / lrx_embedding_bag_mean -> FlatIPIndex
+    HF fp32  the HF transformers model (what finetune/modeling_hybrid.py:205-278, :363-401, :472-490 execute), fp32 -> FlatIPIndex
+    HF bf16  the same module in bf16 (the reference's --bf16 run)                                               -> FlatIPIndex
+
+(every pipeline builds its own documents, its own EmbeddingBag table and its own queries; the hits are retriever/faiss_index.py:27-40's).
+Asserted: overlap@100 and the top-10 rank agreement of lrx against HF fp32 are at least those of HF bf16 against HF fp32 -- i.e. switching
+from the reference's own bf16 run to this build moves the retrieved sets TOWARDS the exact-arithmetic result, not away from it -- plus
+absolute floors.  The numbers go to gpurun_out/r05_recall.jsonl (-> profiles/)."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_retrieved_sets_agree_with_the_fp32_reference_at_least_as_well_as_hf_bf16_does():
+    import recall_probe as rp
+    n_docs = int(os.environ.get("LRX_RECALL_DOCS", "20000"))
+    rec = rp.measure("llama32_1b", n_docs=n_docs, n_queries=200, seed=0, profile="trained_like", k=100)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "r05_recall.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    print(json.dumps(rec))
+    assert rec["stream"] == "precise_fp32"                                  # the default mode, the one bench.py times
+    assert rec["doc_lrx_vs_fp32_max_1mcos"] <= 1e-3, rec                    # every one of the 20 000 documents within 1e-3 cosine
+    assert rec["q_dense_lrx_vs_fp32_max_1mcos"] <= 1e-3 and rec["q_emb_lrx_vs_fp32_max_1mcos"] <= 1e-3, rec
+    for kind in ("emb", "dense"):
+        a, b = rec[kind]["lrx_vs_fp32"], rec[kind]["hfbf16_vs_fp32"]
+        assert a["overlap_at_100"] >= b["overlap_at_100"], (kind, a, b)
+        assert a["top10_same_position"] >= b["top10_same_position"], (kind, a, b)
+        assert a["overlap_at_10"] >= b["overlap_at_10"], (kind, a, b)
+        assert a["top1"] >= b["top1"] - 1e-9, (kind, a, b)

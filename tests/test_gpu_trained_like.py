@@ -4,11 +4,13 @@ Gaussian N(0, 0.02) weights are the easy case for 16-bit arithmetic (q.k logits 
 `LrxEncoder.random_init(profile="trained_like")` (lightretriever_amd/synth.py) draws a model with peaky attention (logit sigma 5-10),
 an attention sink, massive-activation channels, heavy-tailed norm weights and -- Qwen -- q/k/v biases of O(10-300); the generator's
 own calibration statistics are asserted, so the regime is measured rather than assumed.  The forward being matched is
-finetune/modeling_hybrid.py:248-278; the reference runs it as HF bf16 (inference/exact_search_base.py:211), so the bar is
+finetune/modeling_hybrid.py:248-278.  The bar (round 5: ABSOLUTE, for the DEFAULT mode of every backbone -- the mode bench.py times):
 
-    1 - cos(lrx, HF fp32)  <=  max(1e-3, 1 - cos(HF bf16, HF fp32))        (max over 64 documents, three weight seeds)
+    1 - cos(lrx, HF fp32)  <=  1e-3        (max over 64 documents, three weight seeds; full embedding AND the MRL-256 slice)
 
-for the full embedding and for the MRL-256 slice, with no q|k|v element outside fp16's range (lrx_device_saturation_count)."""
+with no q|k|v element outside fp16's range (lrx_device_saturation_count).  The reference itself runs the forward as HF bf16
+(inference/exact_search_base.py:211), whose own distance to fp32 is recorded next to it; only the harsher-amplification case (where HF
+bf16 itself is 5e-3 .. 6e-2 away) keeps the relative bar max(1e-3, HF bf16)."""
 import glob
 import json
 import os
@@ -36,10 +38,11 @@ def _record(rec, name):
 @pytest.mark.parametrize("preset", ["llama31_8b", "qwen25_7b", "llama32_1b", "qwen25_1_5b"])
 def test_trained_like_weights_full_depth_parity(preset, seed):
     import parity_margin as pm
-    # (the headline model runs the bf16 stream: its record also carries the precise stream's distance on the same weights, for the trade-off
-    # DESIGN.md section 3 states -- not asserted)
+    # (the headline model's record also carries the bf16 stream's distance on the same weights -- the mode rounds 1-4 benchmarked, which
+    # misses the bar; not asserted)
     rec = pm.measure(preset, seed=seed, profile="trained_like", n_docs=64, other_stream=preset == "llama32_1b")
-    _record(rec, "r04_trained_like_parity.jsonl")
+    _record(rec, "r05_trained_like_parity.jsonl")
+    assert rec["stream"] == "precise_fp32", rec["stream"]                          # the default mode of every backbone since round 5
     w = rec["weights"]
     # the regime, as measured by the generator's calibration forward on its own bf16-rounded weights
     assert w["logit_sigma_min"] >= 4.5 and w["top1_prob_mean"] >= 0.5, w           # peaky softmax in every layer
@@ -51,8 +54,7 @@ def test_trained_like_weights_full_depth_parity(preset, seed):
         assert w["max_abs_qkv"] >= 30, w
     assert rec["fp16_saturations"] == 0, rec                                        # nothing left fp16's range in the fused QKV epilogue
     for full, ref in (("lrx_vs_fp32", "hfbf16_vs_fp32"), ("lrx_vs_fp32_mrl", "hfbf16_vs_fp32_mrl")):
-        bar = max(COS_TOL, rec[ref]["max"])
-        assert rec[full]["max"] <= bar, (preset, seed, full, rec[full], rec[ref])
+        assert rec[full]["max"] <= COS_TOL, (preset, seed, full, rec[full], rec[ref])     # absolute: north_star's "within 1e-3 cosine"
     print("trained-like %s seed %d (%s): lrx %.2e (p50 %.2e), HF bf16 %.2e; MRL-256 %.2e / %.2e" % (
         preset, seed, rec["stream"], rec["lrx_vs_fp32"]["max"], rec["lrx_vs_fp32"]["p50"], rec["hfbf16_vs_fp32"]["max"],
         rec["lrx_vs_fp32_mrl"]["max"], rec["hfbf16_vs_fp32_mrl"]["max"]))
@@ -66,7 +68,7 @@ def test_trained_like_weights_harsher_amplification(preset):
     import parity_margin as pm
     rec = pm.measure(preset, seed=3, profile="trained_like", n_docs=32,
                      synth={"content_sigma": [1.5, 3.0], "attn_add": 0.25, "mlp_add": 0.35})
-    _record(rec, "r04_trained_like_parity.jsonl")
+    _record(rec, "r05_trained_like_parity.jsonl")
     assert rec["fp16_saturations"] == 0
     assert rec["lrx_vs_fp32"]["max"] <= max(COS_TOL, rec["hfbf16_vs_fp32"]["max"]), rec
     assert rec["lrx_vs_fp32_mrl"]["max"] <= max(COS_TOL, rec["hfbf16_vs_fp32_mrl"]["max"]), rec

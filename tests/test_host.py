@@ -49,6 +49,30 @@ def test_query_collator_matches_reference_tokens(tok, fx):
     assert out["nonctx_tok_emb_input_ids"].dtype == torch.int64
 
 
+def test_query_collator_lm_inputs_match_reference_tokens(tok):
+    """Round 5: queries that go through the LM (symmetric dense vector, input-embedding bag): `prompt + text` with specials, truncation to
+    q_max_len -- the packed form of the reference collator's input_ids / attention_mask (exact_search_base.py:333-345), next to the
+    EmbeddingBag fields when both are asked for."""
+    from helpers import load_query_modes
+    from lightretriever_amd.modeling import EncodeCollator, LrxExactSearchModel
+    _, _, g, meta = load_query_modes()
+    items = LrxExactSearchModel(model=None, tokenizer=tok).parse_texts(meta["queries"], prompt=meta["prompt"])
+    q_max_len = int(g["q_max_len"])
+    out = EncodeCollator(tok, encode_is_query=True, q_max_len=q_max_len, p_max_len=64, noncontextual_query_embedding=False)(items)
+    nested, _, _, cu, max_len = O.pack_padded(g["input_ids"], g["attention_mask"])
+    np.testing.assert_array_equal(out["input_ids"].numpy(), nested)
+    np.testing.assert_array_equal(out["cu_seqlens"].numpy(), cu)
+    assert out["max_seqlen"] == max_len == q_max_len and "nonctx_tok_emb_input_ids" not in out
+    both = EncodeCollator(tok, encode_is_query=True, q_max_len=q_max_len, p_max_len=64, noncontextual_query_embedding=True, query_lm_inputs=True)(items)
+    np.testing.assert_array_equal(both["input_ids"].numpy(), nested)
+    np.testing.assert_array_equal(both["nonctx_tok_emb_input_ids"].numpy(), g["nonctx_ids"])
+    np.testing.assert_array_equal(both["nonctx_tok_emb_offsets"].numpy(), g["nonctx_offsets"])
+    bag_only = EncodeCollator(tok, encode_is_query=True, q_max_len=q_max_len, p_max_len=64, noncontextual_query_embedding=True)(items)
+    assert set(bag_only) == {"nonctx_tok_emb_input_ids", "nonctx_tok_emb_offsets"}
+    bare = EncodeCollator(tok, encode_is_query=True, q_max_len=q_max_len, p_max_len=64, noncontextual_query_embedding=False)(meta["queries"])
+    np.testing.assert_array_equal(bare["input_ids"].numpy(), O.pack_padded(g["input_ids_noprompt"], g["attention_mask_noprompt"])[0])
+
+
 def test_format_text_rules():
     from lightretriever_amd.modeling import format_text
     assert format_text({"title": "T", "text": "x"}) == "T x"
@@ -460,7 +484,8 @@ def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_m
     import pytest
     from transformers import HfArgumentParser
     from lightretriever.inference.arguments import InferenceArguments
-    parse = lambda *a: HfArgumentParser(InferenceArguments).parse_args_into_dataclasses(["--model_name_or_path", "meta-llama/Llama-3.2-1B", *a])[0]
+    parse = lambda *a: HfArgumentParser(InferenceArguments).parse_args_into_dataclasses(["--model_name_or_path", "meta-llama/Llama-3.2-1B",
+                                                                                         "--model_type", "HybridModel", *a])[0]
     a = parse("--hybrid_use_emb_vector", "--noncontextual_query_embedding", "--lowercase", "--add_sep_token", "--add_bos_num", "1", "--add_eos_num", "1",
               "--pooling_strategy", "lasttoken", "--score_function", "cos_sim", "--attn_implementation", "flash_attention_2", "--cumulative_seq",
               "--liger_kernel", "--bf16", "--batch_size", "256", "--p_max_len", "512", "--q_max_len", "512", "--inference_arch", "PytorchRPCExactSearchModel",
@@ -469,11 +494,26 @@ def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_m
     assert (a.pad_token, a.sep_token) == ("<|reserved_special_token_0|>", "<|reserved_special_token_1|>")      # llama defaults (arguments.py:286-310)
     b = parse("--hybrid_use_token_id_vector", "--sparse_use_relu", "--sparse_use_log_saturation", "--score_function", "dot")
     assert b.encode_sparse and b.normalize is False and b.sparse_use_relu and b.token_id_vector_type == "sum"
-    for bad in (["--untie_encoder"], ["--hybrid_use_dense_vector"], ["--hybrid_use_sparse_vector"], ["--enable_bidirectional_attention"],
-                ["--use_sparse_linear_projector"], ["--sparse_remove_stopwords"], ["--hybrid_model_architecture", "bert"], ["--fp16"],
-                ["--pooling_strategy", "mean"], ["--sparse_use_max_aggregation", "False"], ["--noncontextual_query_embedding", "False"]):
+    # the reference's own eval recipe (eval/README.md:13-52): symmetric dense vector; and the LM-embedding-layer ablation
+    c = parse("--hybrid_use_dense_vector", "--bf16", "--q_max_len", "512", "--p_max_len", "512", "--pooling_strategy", "lasttoken", "--sparse_use_max_aggregation",
+              "True", "--sparse_use_relu", "--sparse_use_log_saturation", "--cumulative_seq", "--liger_kernel")
+    assert c.hybrid_use_dense_vector and not c.hybrid_use_emb_vector and not c.encode_sparse and c.dtype == torch.bfloat16
+    d = parse("--hybrid_use_emb_vector")
+    assert d.hybrid_use_emb_vector and d.noncontextual_query_embedding is False
+    for bad in (["--hybrid_use_emb_vector", "--untie_encoder"], ["--hybrid_use_sparse_vector"], ["--hybrid_use_emb_vector", "--enable_bidirectional_attention"],
+                ["--hybrid_use_emb_vector", "--use_sparse_linear_projector"], ["--hybrid_use_emb_vector", "--sparse_remove_stopwords"],
+                ["--hybrid_use_emb_vector", "--hybrid_model_architecture", "bert"], ["--hybrid_use_emb_vector", "--fp16"],
+                ["--hybrid_use_emb_vector", "--pooling_strategy", "mean"], ["--hybrid_use_emb_vector", "--sparse_use_max_aggregation", "False"]):
         with pytest.raises(NotImplementedError):
             parse(*bad)
+    with pytest.raises(ValueError, match="no vector type selected"):
+        parse()
+    # the defaults are the reference's (finetune/arguments.py:175-195, inference/arguments.py:27,68): nothing selected, fp32 container, EncoderModel
+    e = InferenceArguments(model_name_or_path="/x/llama")
+    assert (e.model_type, e.bf16, e.hybrid_use_dense_vector, e.hybrid_use_emb_vector, e.noncontextual_query_embedding, e.hybrid_use_token_id_vector,
+            e.pooling_strategy, e.dtype) == ("EncoderModel", False, False, False, False, False, None, None)
+    with pytest.raises(NotImplementedError):
+        InferenceArguments(model_name_or_path="/x/llama", model_type="RerankerModel")
 
 
 def test_rpc_shard_mode_is_inactive_without_an_rpc_agent():
@@ -509,8 +549,8 @@ def test_reference_eval_arguments_build_on_the_import_path_shim():
     (a,) = HfArgumentParser(mod.EvalArguments).parse_args_into_dataclasses(
         ["--model_name_or_path", "results/lightretriever-llama3.2-1b", "--benchmark_name", "BEIR", "--top_k", "1000", "--inference_arch",
          "PytorchRPCExactSearchModel", "--output_dir", "/tmp/out", "--batch_size", "256", "--corpus_chunk_size", "100000",
-         "--hybrid_use_emb_vector", "--noncontextual_query_embedding", "--lowercase", "--add_sep_token", "--pooling_strategy", "lasttoken",
-         "--score_function", "cos_sim", "--q_max_len", "512", "--p_max_len", "512", "--bf16"])
+         "--model_type", "HybridModel", "--hybrid_use_emb_vector", "--noncontextual_query_embedding", "--lowercase", "--add_sep_token", "--pooling_strategy",
+         "lasttoken", "--score_function", "cos_sim", "--q_max_len", "512", "--p_max_len", "512", "--bf16"])
     assert a.top_k == 1000 and a.corpus_chunk_size == 100000 and a.normalize is True and a.encode_sparse is False
     assert a.model_type == "HybridModel" and a.inference_arch == "PytorchRPCExactSearchModel" and max(a.k_values) <= a.top_k
 

@@ -99,7 +99,7 @@ def test_reference_import_paths_resolve():
     from lightretriever.retriever.faiss_search import FlatIPFaissSearch
     from lightretriever.retriever.anserini_search import AnseriniSearch
     assert DEVICE_TYPE in ("cuda", "cpu") and DIST_BACKEND in ("nccl", "gloo")
-    args = InferenceArguments(model_name_or_path="/x/llama", score_function="dot")
+    args = InferenceArguments(model_name_or_path="/x/llama", score_function="dot", bf16=True)
     assert args.normalize is False and args.dtype == torch.bfloat16
     for cls in (RerankerModel, DummyModel, AnseriniSearch):
         with pytest.raises(NotImplementedError):
@@ -237,16 +237,30 @@ def test_model_args_yaml_resume(tmp_path, caplog):
     assert args.pad_token == "<|reserved_special_token_0|>"                                                   # family default from the directory name
     with pytest.raises(FileNotFoundError):
         load_model_args(str(tmp_path))
-    # the released checkpoints were trained with the symmetric dense vector as well (scripts/finetune_example.sh:47): resuming one must not
-    # die on that training-only query flag -- dropped with a warning; asked for explicitly it still raises
+    assert args.model_type == "HybridModel"                                                                   # (this mirrors HybridModel.load)
+    # the released checkpoints were trained with the symmetric dense vector as well (scripts/finetune_example.sh:47): since round 5 it is
+    # served as saved (queries through the LM next to the EmbeddingBag vector)
     saved["hybrid_use_dense_vector"] = True
     yaml.dump(saved, open(d / "model_args.yaml", "w"))
+    args = arguments_from_checkpoint(str(d))
+    assert args.hybrid_use_dense_vector and args.hybrid_use_emb_vector and args.noncontextual_query_embedding
+    # LM-head sparse QUERY vectors are not produced here.  A checkpoint also trained for token-id queries keeps its asymmetric sparse half
+    # (flag dropped, warning); one whose yaml carries `hybrid_use_token_id_vector: false` (the reference dumps every field) cannot be served
+    # silently without its sparse half: loud error unless the caller decides
     import logging
+    saved["hybrid_use_sparse_vector"] = True
+    yaml.dump(saved, open(d / "model_args.yaml", "w"))
     with caplog.at_level(logging.WARNING):
         args = arguments_from_checkpoint(str(d))
-    assert args.hybrid_use_dense_vector is False and args.hybrid_use_emb_vector and "hybrid_use_dense_vector=True" in caplog.text
-    with pytest.raises(NotImplementedError):
-        arguments_from_checkpoint(str(d), hybrid_use_dense_vector=True)
+    assert args.hybrid_use_sparse_vector is False and args.hybrid_use_token_id_vector and args.encode_sparse and "hybrid_use_sparse_vector=True" in caplog.text
+    saved["hybrid_use_token_id_vector"] = False
+    yaml.dump(saved, open(d / "model_args.yaml", "w"))
+    with pytest.raises(NotImplementedError, match="LM-head query vectors"):
+        arguments_from_checkpoint(str(d))
+    assert arguments_from_checkpoint(str(d), hybrid_use_token_id_vector=True).encode_sparse                  # the caller's explicit choice
+    args = arguments_from_checkpoint(str(d), hybrid_use_sparse_vector=False)
+    assert not args.encode_sparse and args.hybrid_use_dense_vector
+    saved["hybrid_use_sparse_vector"], saved["hybrid_use_token_id_vector"] = False, True
     saved["untie_encoder"] = True                                                                             # an unsupported saved flag still fails loudly
     yaml.dump(saved, open(d / "model_args.yaml", "w"))
     with pytest.raises(NotImplementedError):

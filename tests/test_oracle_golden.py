@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import lrx_oracle as O
-from helpers import GOLDEN, MODEL_GOLDENS, load_model_golden, load_search_ref, min_cos
+from helpers import GOLDEN, MODEL_GOLDENS, load_model_golden, load_query_modes, load_search_ref, min_cos
 
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -307,3 +307,25 @@ def test_fusion_restatement_is_bit_identical_to_reference():
     assert O.fuse_scores_linear(two, [0.5, 0.5], eps=1e-6) == g["linear_5050"]
     assert O.fuse_scores_linear(three, [0.5, 0.3, 0.2]) == g["linear_three"]
     assert set(g["rrf"]) == set(g["dense"]) | set(g["sparse"])                # queries of either system
+
+
+def test_lm_encoded_query_modes_match_the_reference():
+    """Round 5: the oracle against the reference's own encode_query in its LM-encoded modes (tests/golden/gen_query_goldens.py):
+    symmetric dense vector (modeling_hybrid.py:363-401) = the passage operator on `prompt + query` tokens; the LM's input embedding layer
+    as the bag (:476-486) = mean of embedding rows over the real tokens; EncoderModel.encode_query = the same dense vector."""
+    cfg, w, g, meta = load_query_modes()
+    ids, _, _, cu, _ = O.pack_padded(g["input_ids"], g["attention_mask"])
+    np.testing.assert_allclose(O.encode_passage(cfg, w, ids.astype(np.int32), cu), g["dense_reps"], atol=2e-5)
+    np.testing.assert_allclose(O.encode_passage(cfg, w, ids.astype(np.int32), cu, dense_shrink_dim=int(g["shrink"])), g["dense_reps_mrl"], atol=2e-5)
+    np.testing.assert_array_equal(g["encoder_model_query"], g["dense_reps"])
+    ids_n, _, _, cu_n, _ = O.pack_padded(g["input_ids_noprompt"], g["attention_mask_noprompt"])
+    np.testing.assert_allclose(O.encode_passage(cfg, w, ids_n.astype(np.int32), cu_n), g["dense_reps_noprompt"], atol=2e-5)
+    ids_d, _, _, cu_d, _ = O.pack_padded(g["doc_input_ids"], g["doc_attention_mask"])
+    np.testing.assert_allclose(O.encode_passage(cfg, w, ids_d.astype(np.int32), cu_d), g["doc_dense_reps"], atol=2e-5)
+    # input-embedding bag: the restated EmbeddingBag over embed_tokens with the sequence starts as offsets, no padding_idx
+    table = w["embed_tokens.weight"].astype(np.float32)
+    np.testing.assert_allclose(O.encode_query_emb(table, ids.astype(np.int64), cu[:-1].astype(np.int64)), g["emb_reps_lm_embedding"], atol=2e-6)
+    np.testing.assert_allclose(O.encode_query_emb(table, ids.astype(np.int64), cu[:-1].astype(np.int64), dense_shrink_dim=int(g["shrink"])),
+                               g["emb_reps_lm_embedding_mrl"], atol=2e-6)
+    # the autocast run (bf16 matmuls on the fp32 model: what call_batch_encode does on this CPU) stays inside the bf16 band of the fp32 result
+    assert min_cos(g["dense_reps_autocast"], g["dense_reps"]) > 0.995
