@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define LRX_ABI_VERSION 5
+#define LRX_ABI_VERSION 6
 
 enum {
   LRX_OK = 0,
@@ -265,6 +265,12 @@ int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, const void* bi
 int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions,
                             const float* cos, const float* sin, int32_t M, int32_t K, int32_t num_q_heads,
                             int32_t num_kv_heads, int32_t head_dim, const float* rscale, void* stream);
+/* (ABI 6) heads [head0, head0 + n_heads) of the fused projection -- numbered q_0 .. q_{nq-1}, k_0 .. k_{nkv-1}, v_0 .. v_{nkv-1} -- from that
+ * row slice of Wqkv / bias into that column slice of C (rows of C keep the full (nq + 2 nkv) * d width).  lrx_encode_packed uses it in the
+ * FINAL layer: k|v for every token, q only for the gathered last-token rows (the only q rows the pooled output depends on).            */
+int lrx_gemm_qkv_rope_slice(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions,
+                            const float* cos, const float* sin, int32_t M, int32_t K, int32_t num_q_heads,
+                            int32_t num_kv_heads, int32_t head_dim, const float* rscale, int32_t head0, int32_t n_heads, void* stream);
 /* Precise residual stream (lrx_encoder_config.precise_stream).  x32[M, N] (fp32, in place) += A[M, K] * B[N, K]^T; a16_out (bf16 [M, N],
  * may be NULL) = bf16(x32 * gamma[n]) (gamma bf16 [N], NULL = 1): the next projection's operand; ss_part as above, from the fp32 row.   */
 int lrx_gemm_bf16_nt_resid32(const void* A, const void* B, float* x32, void* a16_out, const void* gamma, int32_t M, int32_t N,
@@ -282,6 +288,9 @@ int lrx_finalize_rscale(const float* ss_part, int32_t n_parts, int32_t rows, int
 
 /* dst[b, :] = src[cu_seqlens[b+1]-1, :]  (bf16 rows of `width` elements): the last-token rows, compacted. */
 int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, int32_t width, void* dst, void* stream);
+/* (ABI 6) the inverse: dst[cu_seqlens[b+1]-1, 0:width] = src[b, 0:width]  (16-bit elements; rows of dst are dst_row_stride elements apart) */
+int lrx_scatter_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, int32_t width, void* dst, int64_t dst_row_stride,
+                          void* stream);
 
 /* Last-token pooling + final RMSNorm on the pooled rows only + MRL slice + L2 normalise -> fp32 rows.
  * hidden = residual stream BEFORE the final norm [T, H] bf16; cu_seqlens == NULL means `hidden` already holds the

@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRX_LIB_DEV_VARIANT") or os.path.join(HERE, "liblrx.so")   # env override: tools/ diagnostics only
 LRX_PROF_CLASSES = 8
-ABI_VERSION = 5   # LRX_ABI_VERSION of include/lrx.h
+ABI_VERSION = 6   # LRX_ABI_VERSION of include/lrx.h
 # lrx_flat_ip_search_bounded flags (LRX_SEARCH_FILTER_*): A/B runs and tests; the hits do not depend on them
 SEARCH_FILTER_AUTO, SEARCH_FILTER_MATRIX, SEARCH_FILTER_SCORE_FREE, SEARCH_FILTER_SCORE_FREE_NO_GEMM = 0, 1, 2, 3
 PROF_CLASS_NAMES = ["gemm_store", "gemm_resid", "gemm_swiglu", "attention", "rmsnorm", "rope", "other", "gemm_maxagg"]
@@ -81,6 +81,8 @@ SIGNATURES = {
     "lrx_build_positions": (_I32, [_P, _I32, _I32, _P, _P]),
     "lrx_attn_varlen_causal": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "lrx_gather_last_rows": (_I32, [_P, _P, _I32, _I32, _P, _P]),
+    "lrx_scatter_last_rows": (_I32, [_P, _P, _I32, _I32, _P, _I64, _P]),
+    "lrx_gemm_qkv_rope_slice": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _P]),
     "lrx_pool_norm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P]),
     "lrx_embedding_bag_mean": (_I32, [_P, _I32, _I32, _P, _I64, _P, _I32, _I64, _P, _I64, _I32, _I32, _P]),
     "lrx_flat_ip_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),

@@ -100,6 +100,8 @@ struct EncWs {
   float *x32, *xr32;          // precise_stream: the fp32 residual stream (and its pooled-tail rows)
   int32_t* pos;
   float *rsA, *rsB, *ssp;     // folded RMSNorm: row scales for the two norms of a layer, per-n-tile sum-of-squares partials
+  int32_t* posr;              // final layer: positions / row scales of the last-token rows (the q projection runs on those rows only)
+  float* rsr;
   size_t total;
 };
 static EncWs carve(const lrx_encoder_config* c, int64_t T, int64_t B, char* base) {
@@ -120,6 +122,8 @@ static EncWs carve(const lrx_encoder_config* c, int64_t T, int64_t B, char* base
   w.ar = base + off; off += align_up((size_t)B * HM * 2, 1024);
   w.hr = base + off; off += align_up((size_t)B * H * 2, 1024);
   w.actr = base + off; off += align_up((size_t)B * I * 2, 1024);
+  w.posr = (int32_t*)(base + off); off += align_up((size_t)B * 4 + 32, 1024);
+  w.rsr = (float*)(base + off); off += align_up((size_t)B * 4 + 32, 1024);
   w.x32 = w.xr32 = nullptr;
   if (c->precise_stream) {
     w.x32 = (float*)(base + off); off += align_up((size_t)T * H * 4, 1024);
@@ -189,8 +193,26 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
     const lrx_layer_weights& L = w->layers[l];
     const bool last = l == c->num_layers - 1;
     if (!scaled) { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
+    const void* Aqkv = scaled ? ws.x : ws.h;
+    const void* bq = c->qkv_bias ? L.bqkv : nullptr;
+    if (tail_cu != nullptr && last && hk.after_qkv == nullptr && T > 2 * n_tail && c->num_layers > 1) {
+      // FINAL layer of a pooled encode: k|v of every token, q of the n_tail last-token rows only (nothing else of q reaches the output: the
+      // attention below is restricted to each sequence's last q tile and only its last row is gathered).  The last rows of the operand, of
+      // the row scale and of the positions are compacted (ws.hr, ws.rsr, ws.posr: free here), projected, and the q rows scattered back
+      // (ws.ar is free until the attention output is gathered).  Rows of the last q tile other than the last keep stale q values: finite
+      // (the previous layer's -- hence num_layers > 1: a one-layer model would leave uninitialised memory there), per-row independent, never read out.
+      const int B = n_tail;
+      { ProfScope p(s, 0, 2.0 * T * (double)(2 * nkv * d) * H + 2.0 * B * (double)QD * H);
+        if ((rc = lrx_gemm_qkv_rope_slice(Aqkv, L.wqkv, ws.qkv, bq, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, scaled ? ws.rsA : nullptr, nq, 2 * nkv, s))) return rc;
+        if ((rc = lrx_gather_last_rows(Aqkv, tail_cu, B, H, ws.hr, s))) return rc;
+        if ((rc = lrx_gather_rows_u32(ws.pos, tail_cu, B, ws.posr, s))) return rc;
+        if (scaled && (rc = lrx_gather_rows_u32(ws.rsA, tail_cu, B, ws.rsr, s))) return rc;
+        // (C = ws.ar viewed with the full q|k|v row width: only its first QD columns are written)
+        if ((rc = lrx_gemm_qkv_rope_slice(ws.hr, L.wqkv, ws.ar, bq, ws.posr, w->rope_cos, w->rope_sin, B, H, nq, 0, d, scaled ? ws.rsr : nullptr, 0, nq, s))) return rc;
+        if ((rc = lrx_scatter_last_rows(ws.ar, tail_cu, B, QD, ws.qkv, QKV, s))) return rc; }
+    } else
     { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);   // QKV projection with (row scale,) bias + RoPE fused into the epilogue
-      if ((rc = lrx_gemm_qkv_rope_fused(scaled ? ws.x : ws.h, L.wqkv, ws.qkv, c->qkv_bias ? L.bqkv : nullptr, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d,
+      if ((rc = lrx_gemm_qkv_rope_fused(Aqkv, L.wqkv, ws.qkv, bq, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d,
                                         scaled ? ws.rsA : nullptr, s))) return rc; }
     if (hk.after_qkv) { rc = hk.after_qkv(hk.ctx, l, s); if (rc == 1) break; if (rc) return rc; }
     if (tail_cu != nullptr && last) {

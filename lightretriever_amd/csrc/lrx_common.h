@@ -88,3 +88,6 @@ int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows,
 // lrx_gemm.hip: the GEMM kernel with the segmented-maximum epilogue (used by lrx_sparse_max_aggregate)
 int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias, const int32_t* row_seg, float* out, int64_t ldo, int M, int N,
                                   int K, hipStream_t stream);
+
+// lrx_elementwise.hip: dst[b] = src[cu_seqlens[b + 1] - 1] for 4-byte elements (positions, row scales of the last-token rows)
+int lrx_gather_rows_u32(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, void* dst, hipStream_t stream);

@@ -439,6 +439,38 @@ extern "C" int lrx_gather_last_rows(const void* src, const int32_t* cu_seqlens, 
   return LRX_OK;
 }
 
+__global__ void __launch_bounds__(256) k_gather_rows_u32(const uint32_t* __restrict__ src, const int32_t* __restrict__ cu, int n_seqs, uint32_t* __restrict__ dst) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < n_seqs) dst[b] = src[cu[b + 1] - 1];
+}
+int lrx_gather_rows_u32(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, void* dst, hipStream_t stream) {
+  if (n_seqs == 0) return LRX_OK;
+  hipLaunchKernelGGL(k_gather_rows_u32, dim3(lrx_cdiv(n_seqs, 256)), dim3(256), 0, stream, (const uint32_t*)src, cu_seqlens, n_seqs, (uint32_t*)dst);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// the inverse: compact rows back to the last-token positions of a wider row-major buffer (the final layer's q rows)
+__global__ void __launch_bounds__(256) k_scatter_last_rows(const bf16x8* __restrict__ src, const int32_t* __restrict__ cu, int n_seqs, int chunks,
+                                                           bf16x8* __restrict__ dst, int64_t dst_chunks) {
+  int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n_seqs) return;
+  int lane = threadIdx.x & 63;
+  int64_t d = ((int64_t)cu[b + 1] - 1) * dst_chunks, s = (int64_t)b * chunks;
+  for (int c = lane; c < chunks; c += 64) dst[d + c] = src[s + c];
+}
+
+extern "C" int lrx_scatter_last_rows(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, int32_t width, void* dst, int64_t dst_row_stride,
+                                     void* stream) {
+  LRX_CHECK_ARG(width % 8 == 0 && dst_row_stride % 8 == 0 && dst_row_stride >= width, "scatter_last_rows: width=%d / stride=%lld must be multiples of 8",
+                width, (long long)dst_row_stride);
+  if (n_seqs == 0) return LRX_OK;
+  hipLaunchKernelGGL(k_scatter_last_rows, dim3(lrx_cdiv(n_seqs, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)src, cu_seqlens, n_seqs,
+                     width / 8, (bf16x8*)dst, dst_row_stride / 8);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // EmbeddingBag(mode='mean', padding_idx): one block per bag, thread = column, ids walked in order (same fp32 summation
 // order as the sequential CPU kernel), then slice + optional L2 normalise.

@@ -44,6 +44,7 @@ struct RopeArgs {
   const float* sin;
   int rope_cols;             // columns [0, rope_cols) are q|k heads to rotate; the rest (v) is stored as is
   int head_dim;
+  int ldc;                   // row stride of C in elements, 0 = N (a column slice of the q|k|v buffer: lrx_gemm_qkv_rope_slice)
 };
 
 __device__ __forceinline__ __bf16 f2h_bits(float v) {   // fp16 (saturating) in the kernel's 16-bit container type
@@ -584,7 +585,8 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     }
     return;
   }
-  const int ldc = (EPI == EPI_SWIGLU) ? (N >> 1) : N;
+  const int ncols = (EPI == EPI_SWIGLU) ? (N >> 1) : N;                 // columns of C this launch produces
+  const int ldc = (EPI == EPI_ROPE && rope.ldc > 0) ? rope.ldc : ncols;  // ... inside rows of this stride
   const int c0 = (EPI == EPI_SWIGLU) ? (n0 >> 1) : n0;
   {
 #pragma unroll
@@ -592,7 +594,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     const int q = it * 512 + tid;
     const int row = q / CPR, ch = q % CPR;
     const int m = m0 + row, n = c0 + ch * 8;
-    const bool inb = m < M && n < ldc;
+    const bool inb = m < M && n < ncols;
     if (!(EPI == EPI_RESID && nrm.ss_part != nullptr) && !inb) continue;   // (with ss_part every lane stays for the row reduction)
     bf16x8 v = *(const bf16x8*)(smem + row * (CW * 2) + ((ch ^ (row & 15)) << 4));
     if (EPI == EPI_RESID) {
@@ -652,7 +654,7 @@ extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, con
   hipStream_t s = (hipStream_t)stream;
   const __bf16 *a = (const __bf16*)A, *b = (const __bf16*)B, *bi = (const __bf16*)bias, *re = (const __bf16*)resid;
   __bf16* c = (__bf16*)C;
-  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
   MaxAggArgs nomx = {nullptr, nullptr, 0};
   NormArgs nrm = {rscale, ss_part, gemm_group_m(epilogue, K)};
   switch (epilogue) {
@@ -673,16 +675,31 @@ extern "C" int lrx_gemm_qkv_rope(const void* A, const void* Wqkv, void* C, const
 extern "C" int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos,
                                        const float* sin, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
                                        const float* rscale, void* stream) {
-  const int N = (num_q_heads + 2 * num_kv_heads) * head_dim;
+  return lrx_gemm_qkv_rope_slice(A, Wqkv, C, bias, positions, cos, sin, M, K, num_q_heads, num_kv_heads, head_dim, rscale, 0,
+                                 num_q_heads + 2 * num_kv_heads, stream);
+}
+
+// Heads [head0, head0 + n_heads) of the fused q|k|v projection (heads numbered q_0 .. q_{nq-1}, k_0 .. k_{nkv-1}, v_0 .. v_{nkv-1}): the same
+// kernel over that row slice of Wqkv / bias, writing that column slice of C (whose rows keep the full q|k|v width).  The encoder's FINAL
+// layer needs k|v of every token but q of the pooled (last) tokens only: lrx_encode_packed runs the k|v slice over all rows and the q slice
+// over the gathered last rows (two thirds of that layer's projection FLOPs are not computed).
+extern "C" int lrx_gemm_qkv_rope_slice(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos,
+                                       const float* sin, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                       const float* rscale, int32_t head0, int32_t n_heads, void* stream) {
+  const int n_all = num_q_heads + 2 * num_kv_heads;
   LRX_CHECK_ARG(M >= 0 && K > 0 && K % GBK == 0, "gemm_qkv_rope: bad shape M=%d K=%d", M, K);
   LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "gemm_qkv_rope: head_dim=%d unsupported", head_dim);
   LRX_CHECK_ARG(positions && cos && sin, "gemm_qkv_rope: null rope inputs");
+  LRX_CHECK_ARG(head0 >= 0 && n_heads > 0 && head0 + n_heads <= n_all, "gemm_qkv_rope: head slice [%d, %d) outside 0..%d", head0, head0 + n_heads, n_all);
   if (M == 0) return LRX_OK;
+  const int N = n_heads * head_dim, col0 = head0 * head_dim;
+  const int rope_cols = (num_q_heads + num_kv_heads) * head_dim - col0;          // rotating columns of the slice (<= 0: v heads only)
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
-  RopeArgs rope = {positions, cos, sin, (num_q_heads + num_kv_heads) * head_dim, head_dim};
-  hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)Wqkv,
-                     (__bf16*)C, (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{rscale, nullptr, 8}, EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
+  RopeArgs rope = {positions, cos, sin, rope_cols < 0 ? 0 : (rope_cols > N ? N : rope_cols), head_dim, n_all * head_dim};
+  hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A,
+                     (const __bf16*)Wqkv + (int64_t)col0 * K, (__bf16*)C + col0, bias ? (const __bf16*)bias + col0 : (const __bf16*)nullptr,
+                     (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0}, NormArgs{rscale, nullptr, 8},
+                     EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -696,7 +713,7 @@ extern "C" int lrx_gemm_bf16_nt_resid32(const void* A, const void* B, float* x32
   LRX_CHECK_ARG(x32 != nullptr, "gemm_resid32: null residual stream");
   if (M == 0) return LRX_OK;
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
-  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID32>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)B,
                      (__bf16*)a16_out, (const __bf16*)gamma, (const __bf16*)x32, M, N, K, tiles_m, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
                      NormArgs{nullptr, ss_part, gemm_group_m(EPI_RESID, K)}, EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
@@ -714,10 +731,11 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   LRX_CHECK_ARG(row_seg && out && ldo >= N, "max_aggregate: bad output spec");
   if (M == 0) return LRX_OK;
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
-  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
   MaxAggArgs mx = {row_seg, out, ldo};
+  static const int maxagg_gm = []() { const char* e = getenv("LRX_MAXAGG_GM"); return e && atoi(e) > 0 ? atoi(e) : LRX_MAXAGG_GM; }();   // (sweeps: tools/exp/maxagg_gm_sweep.sh)
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
-                     (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, LRX_MAXAGG_GM},
+                     (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, maxagg_gm},
                      EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
@@ -732,7 +750,7 @@ int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows,
   LRX_CHECK_ARG(dim > 0 && dim % GBK == 0 && nq > 0 && nq <= GBN && n_rows < (1ll << 31), "filter_emit: bad shape rows=%lld nq=%d dim=%d",
                 (long long)n_rows, nq, dim);
   if (n_tiles <= 0) return LRX_OK;
-  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64};
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_EMIT>, dim3((unsigned)n_tiles), dim3(512), 0, stream, (const __bf16*)Xb, (const __bf16*)q16, (__bf16*)nullptr,
                      (const __bf16*)nullptr, (const __bf16*)nullptr, (int)n_rows, nq, dim, (int)n_tiles, 1, none, MaxAggArgs{nullptr, nullptr, 0},
                      NormArgs{nullptr, nullptr, 8}, EmitArgs{thr, cand, cnt, ss, cap});

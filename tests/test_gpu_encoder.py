@@ -128,16 +128,27 @@ def test_writes_in_place_into_index_rows_and_is_batch_invariant():
     np.testing.assert_array_equal(rev, full[order])
 
 
-def test_pooled_tail_equals_full_forward():
-    """encode_packed (final layer's O-proj/MLP only on the pooled rows) == pooling the full encode_hidden output."""
+@pytest.mark.parametrize("precise", [False, True])
+def test_pooled_tail_equals_full_forward(precise):
+    """encode_packed (final layer's O-proj/MLP only on the pooled rows) == pooling the full encode_hidden output.  bf16 stream: the same
+    bf16 rows, equal to 1e-6.  Precise stream (the default): encode_hidden hands out the final-norm rows ROUNDED to bf16 while encode_packed
+    normalises the fp32 rows without that rounding (HF's two bf16 roundings are skipped on an fp32 stream) -- equal to bf16 output rounding:
+    2^-9 per element, ~1e-5 in cosine."""
+    import dataclasses
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    from dataclasses import asdict
     for d in (64, 128):
         cfg, w, ids, cu, max_len = medium_case(d)
-        enc = make_encoder(cfg, w)
+        enc = LrxEncoder(dataclasses.replace(EncoderConfig(**asdict(cfg)), precise_stream=precise), {k: torch.from_numpy(v) for k, v in w.items()})
         tid, tcu = to_dev(ids, torch.int32), to_dev(cu, torch.int32)
         h = enc.encode_hidden(tid, tcu, max_len).float()
         want = torch.nn.functional.normalize(h[tcu[1:].long() - 1], dim=-1)
         got = enc.encode_packed(tid, tcu, max_len)
-        assert torch.allclose(got, want, atol=1e-6), (got - want).abs().max()
+        if not precise:
+            assert torch.allclose(got, want, atol=1e-6), (got - want).abs().max()
+        else:
+            assert (1 - (got.double() * want.double()).sum(-1)).max().item() < 2e-5
+            assert torch.allclose(got, want, atol=2 ** -8 * want.abs().max().item()), (got - want).abs().max()
 
 
 def test_argument_errors():

@@ -32,10 +32,11 @@ from parity_margin import hf_model_for
 
 
 def synthetic_corpus(cfg, n_docs, n_queries, seed, sub_vocab=4096, max_len=512, sink=None):
-    """Ragged documents (lengths clip(lognormal(4.8, 0.7), 16, max_len), sink token first) over a sub-vocabulary of `sub_vocab` token
-    ids; every query = 8..32 tokens drawn from one document (so a query shares its bag of tokens with at least that document)."""
+    """Ragged documents (lengths clip(lognormal(4.8, 0.7), 16, max_len - 1) + the eos the encoders append, sink token first) over a
+    sub-vocabulary of `sub_vocab` token ids; every query = 8..32 tokens drawn from one document (so a query shares its bag of tokens with
+    at least that document)."""
     rng = np.random.default_rng(4242 + seed)
-    lens = np.clip(rng.lognormal(4.8, 0.7, size=n_docs), 16, max_len).astype(np.int64)
+    lens = np.clip(rng.lognormal(4.8, 0.7, size=n_docs), 16, max_len - 1).astype(np.int64)
     lo = 2000
     docs = [rng.integers(lo, lo + sub_vocab, size=int(l)).astype(np.int64) for l in lens]
     if sink is not None:
