@@ -734,10 +734,26 @@ k_filter_xreg(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __r
 // CU with half the LDS each, one block at a time, so that one's epilogue runs under the other's loads -- 96 VGPRs, 78 KiB LDS, correct, and
 // 1.25M x 256 / Q = 100 went from 0.201-0.206 to 0.276-0.284 ms, 10M x 256 from 0.99 to 1.26: with one block in work the q fragments are read
 // from LDS once per block instead of once per two, and that, not the epilogue, is what the narrow-row pass is short of.  Q = 1, 32: no change.)
+// LDS bytes of the persistent emitting pass (q ring + per-wave hit lists + thresholds)
+template <int QT>
+struct EmitLds {
+  static constexpr int WV = 8;
+  static constexpr int QBYTES = 2 * QT * 1024;
+  static constexpr int QB = QT > 8 ? 3 : 4;
+  static constexpr int WQC_BYTES = QT * 16 * 4;
+  static constexpr int WCAP_FIT = ((160 * 1024 - QB * QBYTES - QT * 64 - 1024 - WV * (WQC_BYTES + 16)) / (WV * 12)) / 64 * 64;
+  static constexpr int WCAP = WCAP_FIT > 1024 ? 1024 : WCAP_FIT;
+  static constexpr int WL_BYTES = WCAP * 12 + 16 + WQC_BYTES;
+  static constexpr int BYTES = QB * QBYTES + WV * WL_BYTES + QT * 16 * 4;
+};
+
+// thr_ready / thr_target (fused kernel): the thresholds are published by other workgroups of the SAME launch -- the first block step's K loop
+// runs before they are needed; each consumer wave then polls *thr_ready until it reaches thr_target (the selection items were all claimed by
+// running workgroups before this workgroup got here, so the wait ends) and loads the thresholds past the L1.  NULL: thr is final at launch.
 template <int QT, int PF, int RT>
-__global__ void __launch_bounds__(576, (QT > 8 || RT > 1) ? 3 : 5)   // (second argument: waves per SIMD -> two workgroups of nine waves per CU need five)
-k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, int nblocks, int bmode, int ss,
-                   int unit, const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, unsigned int cap) {
+__device__ __forceinline__ void filter_emit_body(char* smem, const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, int nblocks, int bmode, int ss,
+                   int unit, const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, unsigned int cap,
+                   const unsigned int* thr_ready, unsigned int thr_target) {
   constexpr int WV = 8;
   constexpr int QINST = 2 * QT;
   constexpr int QBYTES = QINST * 1024;
@@ -751,11 +767,13 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
   constexpr int WCAP = WCAP_FIT > 1024 ? 1024 : WCAP_FIT;
   static_assert(WCAP >= 256, "hit lists do not fit next to the q ring");
   constexpr int WL_BYTES = WCAP * 12 + 16 + WQC_BYTES;
-  __shared__ __attribute__((aligned(1024))) char smem[QB * QBYTES + WV * WL_BYTES + QT * 16 * 4];
+  static_assert(EmitLds<QT>::BYTES == QB * QBYTES + WV * WL_BYTES + QT * 16 * 4, "EmitLds out of sync");
   float* sthr = (float*)(smem + QB * QBYTES + WV * WL_BYTES);   // the thresholds (LDS: they are needed once per block, not per k-step)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < QT * 16; i += 576) sthr[i] = i < nq ? thr[i] : FLT_MAX;
+  if (thr_ready == nullptr) {
+    for (int i = tid; i < QT * 16; i += 576) sthr[i] = i < nq ? thr[i] : FLT_MAX;
+  }
   __syncthreads();
   // this workgroup's blocks: launch indices blockIdx.x + i * gridDim.x, i < nbw (the counts differ by at most one block over the grid),
   // walked RT at a time; an odd one out at the end is worked on with its own block in the second slot (cache hits, result dropped)
@@ -899,6 +917,15 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
         }
       }
     }
+    if (thr_ready != nullptr && j == 0) {
+      // thresholds published by the selection step of this launch: every consumer wave waits for itself and fills the (shared) table with the
+      // same values -- a wave reads the table only after its own complete write, so no barrier is needed
+      if (lane == 0)
+        while (__hip_atomic_load(thr_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < thr_target) __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      for (int i = lane; i < QT * 16; i += 64) sthr[i] = i < nq ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FLT_MAX;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     // ---- block epilogue: D[i = corpus row][j = query]: lane holds query fi of tile b, rows fq*4 + {0..3}.  LDS only: a wave tile with
     //      more hits than the list holds (near-duplicate rows) pushes the query's counter past the list capacity instead -> flagged, redone by the fallback
 #pragma unroll
@@ -969,6 +996,160 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
     const unsigned int slot = qbase[col] + atomicAdd(&qcnt[col], 1u);
     if (slot < cap) cand[(int64_t)col * cap + slot] = wl[i];
   }
+}
+
+template <int QT, int PF, int RT>
+__global__ void __launch_bounds__(576, (QT > 8 || RT > 1) ? 3 : 5)   // (second argument: waves per SIMD -> two workgroups of nine waves per CU need five)
+k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, int nblocks, int bmode, int ss,
+                   int unit, const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, unsigned int cap) {
+  __shared__ __attribute__((aligned(1024))) char smem[EmitLds<QT>::BYTES];
+  filter_emit_body<QT, PF, RT>(smem, Xb, N, D, qs, nq, nblocks, bmode, ss, unit, thr, cand, cnt, cap, nullptr, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FUSED filter chain (round 5): sample pass -> threshold selection -> main pass in ONE persistent launch, without a grid barrier.
+//
+// The three-launch chain leaves the memory system idle twice (the ramp-down of the sample pass, the ~12-us selection, the ramp-up of the
+// main pass): on a per-rank shard of 125 k x 2048 rows that is ~30 of 155 us.  Here every workgroup
+//   S: claims sample blocks from a counter (block j of the sample = corpus block j * ss) and scores them like k_filter_xreg (compact score
+//      rows + the maxima of the 16-row wave groups), counting each finished block in `done_s`;
+//   -- waits until done_s == n_samp.  Every sample block was claimed by a workgroup that is RUNNING (the counter hands out work only to
+//      workgroups that execute), so the wait ends whatever share of the grid is resident -- unlike a grid barrier, which deadlocks when
+//      two such launches (two searches in flight: pipeline.SearchLanes) each hold part of the chip and wait for their own absent workgroups;
+//   T: claims queries from a second counter and runs the selection of k_sample_threshold for them (threshold, eps, the sample rows that
+//      open the candidate list), counting in `done_t`;
+//   M: walks its share of the non-sample blocks like k_filter_xreg_emit; the first block step's K loop runs BEFORE the thresholds are
+//      needed, each consumer wave then waits for done_t == n_queries (claimed work of running workgroups again) and loads them.
+// Workgroups that find no selection left go straight to M and stream while the (at most n_queries) others select: HBM never idles.
+// ---------------------------------------------------------------------------------------------------------------
+struct FusedCtl {              // five counters in the zero-initialised ints of the workspace (k_pack_queries_xb clears them)
+  unsigned int ctr_s, done_s, ctr_t, done_t, pad;
+};
+
+// one 128-row sample block (RT = 1): the body of k_filter_xreg<QT, PF, false, 1> with group maxima; all nine waves call it together.
+// li = index of the block inside the sample (where its scores go), blk = corpus block.
+template <int QT, int PF>
+__device__ __forceinline__ void filter_sample_block(char* smem, const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq,
+                                                    float* __restrict__ scores, int64_t ld, float* __restrict__ gmax, int nblk_ld, int64_t blk, int64_t li) {
+  constexpr int WV = 8, RB = 128;
+  constexpr int QINST = 2 * QT;
+  constexpr int QBYTES = QINST * 1024;
+  constexpr int SEG = RB * 4 + 16;                 // epilogue staging: one query's 128 scores + pad
+  constexpr int QB = QT > 8 ? 2 : 4;
+  static_assert((QB - 2) * QINST <= 63, "vmcnt immediate");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = D / 64;
+  const int fi = lane & 15, fq = lane >> 4;
+  f32x4 acc[QT];
+#pragma unroll
+  for (int b = 0; b < QT; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave == WV) {
+    const __bf16* pq = qs + (int64_t)lane * 8;
+    auto stage_q = [&](int kt) {
+      char* sQ = smem + (kt % QB) * QBYTES;
+#pragma unroll
+      for (int j = 0; j < QINST; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(pq + ((int64_t)kt * QINST + j) * 512), (lptr_t)(sQ + j * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p < QB - 1; ++p)
+      if (p < nk) stage_q(p);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + QB - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QB - 2) * QINST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + QB - 1 < nk) stage_q(kt + QB - 1);
+    }
+  } else {
+    const bf16x8* px = (const bf16x8*)(Xb + (min(blk, (N - 1) >> 7) * (int64_t)(D / 64)) * 8192 + wave * 1024) + lane;
+    bf16x8 xf[PF][2];
+    auto load = [&](int slot, int kt) __attribute__((always_inline)) {
+      xf[slot][0] = __builtin_nontemporal_load(px + (int64_t)kt * 1024);
+      xf[slot][1] = __builtin_nontemporal_load(px + (int64_t)kt * 1024 + 64);
+    };
+    auto step = [&](int u, int kt, bool fetch) __attribute__((always_inline)) {
+      if (fetch) load((u + PF - 1) % PF, kt + PF - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* sQ = smem + (kt % QB) * QBYTES + lane * 16;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int b = 0; b < QT; ++b) {
+          const bf16x8 qf = *(const bf16x8*)(sQ + (ks * QT + b) * 1024);
+          acc[b] = mfma_f16(xf[u][ks], qf, acc[b]);
+        }
+    };
+    int kt0 = 0;
+    if (2 * PF - 2 < nk) {
+#pragma unroll
+      for (int p = 0; p < PF - 1; ++p) {
+        load(p, p);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      for (; kt0 + 2 * PF - 2 < nk; kt0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) step(u, kt0 + u, true);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PF - 1; ++p)
+        if (p < nk) load(p, p);
+    }
+    for (; kt0 < nk; kt0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        if (kt0 + u < nk) step(u, kt0 + u, kt0 + u + PF - 1 < nk);
+    }
+  }
+  // ---- epilogue: group maxima from registers, scores through the (dead) q ring
+  float* wmax = (float*)smem;                      // [8 waves][QT*16]
+  constexpr int LDS_Q = QB * QBYTES > 16 * SEG ? QB * QBYTES : 16 * SEG;
+  constexpr int QPT = (LDS_Q / SEG / 16) < QT ? (LDS_Q / SEG / 16) : QT;   // q-tiles staged per pass
+  static_assert(QPT >= 1, "epilogue staging does not fit");
+  constexpr int NPASS = (QT + QPT - 1) / QPT;
+  const int64_t n0 = blk * RB, n0s = li * RB;
+  __syncthreads();
+  if (wave < WV) {
+#pragma unroll
+    for (int b = 0; b < QT; ++b) {
+      const int qi = b * 16 + fi;
+      float mx = -FLT_MAX;
+      const int64_t n = n0 + wave * 16 + fq * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= N) acc[b][e] = -FLT_MAX;
+        mx = fmaxf(mx, acc[b][e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (fq == 0) wmax[wave * (QT * 16) + qi] = mx;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < QT * 16 * WV; t += 576) {
+    const int qi = t >> 3, w = t & 7;
+    if (qi < nq) gmax[(int64_t)qi * (8 * (int64_t)nblk_ld) + li * 8 + w] = wmax[w * (QT * 16) + qi];
+  }
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    __syncthreads();
+    if (wave < WV) {
+#pragma unroll
+      for (int b = 0; b < QT; ++b)
+        if (b / QPT == ps) *(f32x4*)(smem + ((b - ps * QPT) * 16 + fi) * SEG + (wave * 16 + fq * 4) * 4) = acc[b];
+    }
+    __syncthreads();
+    const int nqt = (QT - ps * QPT) < QPT ? (QT - ps * QPT) : QPT;
+    for (int idx = tid; idx < nqt * 16 * (RB / 4); idx += 576) {
+      const int ql = idx / (RB / 4), c = idx % (RB / 4);
+      const int qi = ps * QPT * 16 + ql;
+      if (qi < nq) *(f32x4*)(scores + (int64_t)qi * ld + n0s + c * 4) = *(const f32x4*)(smem + ql * SEG + c * 16);
+    }
+  }
+  __syncthreads();                                 // the staging region is free again (next block's q ring, or the selection's tables)
 }
 
 // The sample pass of a LARGE shard as persistent workgroups (same walk as k_filter_xreg_emit, score stores instead of hit lists): with one
@@ -1162,6 +1343,17 @@ struct FilterMode {
   bool planes_ready = false;              // six-product pass: `qsplit` already holds the planes (see PreSplit)
   bool group_max = false;                 // shadow kernels, score stores: `blkmax` receives the maxima of the 16-row wave groups
                                           // (8 per block, row stride 8 x nblk_ld) instead of one maximum per 128-row block
+  const struct FusedArgs* fused = nullptr; // sample + selection + main pass in ONE launch (k_filter_fused) right after the query packing
+};
+struct FusedArgs {
+  int64_t ld_s;
+  int nblk_s, nblk_ld_s, nsamp, nmain, ss, k;
+  const float* bounds;
+  float *thr, *eps;
+  unsigned long long* cand;
+  unsigned int* cnt;
+  unsigned int cap;
+  FusedCtl* ctl;
 };
 
 // planes = 3: fp32-grade scores (six bf16 products); planes = 1: one fp16 product (filter pass of the bounded search, error bound
@@ -1178,6 +1370,8 @@ static int lrx_cu_count() {
 }
 
 static int filter_rows_per_wg(bool shadow) { return shadow ? 128 : 16 * SPF_RT * SPF_WV; }
+static int launch_filter_fused(const void* Xs, int64_t n_rows, int dim, const __bf16* qsplit, int nq, int qt, float* scores, float* gmax, const float* qf32,
+                               const FusedArgs& fa, hipStream_t s);
 
 static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const float* q, int32_t n_queries, float* scores,
                          float* blkmax, __bf16* qsplit, void* stream, int planes = 3, const int* gate = nullptr, const void* Xs = nullptr,
@@ -1212,6 +1406,11 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
         ps.nb_xb = (threads + 255) / 256;
         hipLaunchKernelGGL(k_pack_queries_xb, dim3(ps.nb_xb + (ps.ngroups > 0 ? ps.blocks[0] + ps.blocks[1] : 0)), dim3(256), 0, s, qp, nq, dim, qt, qsplit,
                            fm.zero, fm.nzero, ps);
+      }
+      if (fm.fused != nullptr) {   // the whole filter chain of the score-free search in one persistent launch
+        const int rc = launch_filter_fused(Xs, n_rows, dim, qsplit, nq, qt, sp, bp, qp, *fm.fused, s);
+        if (rc != LRX_OK) return rc;
+        continue;
       }
       // Main pass of the score-free filter: persistent workgroups, one per CU (D / 64 a multiple of the ring depth); everything
       // else: one workgroup per 128-row block
@@ -1438,13 +1637,13 @@ __device__ __forceinline__ unsigned int radix_pick(SH& sh, unsigned int& kk, uns
 template <class SH>
 __device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, unsigned int kk, SH& sh, unsigned int& need_eq,
                                      unsigned int& neq) {
-  const int tid = threadIdx.x, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = tid >> 6, NT = blockDim.x;   // (any block of >= 256 threads, at most 16 waves)
   uint32_t prefix = 0, mask = 0;
   const int64_t n4 = n >> 2;
   for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = tid; i < 16 * 256; i += SEL_THREADS) (&sh.hist[0][0])[i] = 0;
+    for (int i = tid; i < 16 * 256; i += NT) (&sh.hist[0][0])[i] = 0;
     __syncthreads();
-    for (int64_t i = tid; i < n4; i += SEL_THREADS) {
+    for (int64_t i = tid; i < n4; i += NT) {
       f32x4 v = *(const f32x4*)(row + 4 * i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1452,7 +1651,7 @@ __device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, u
         if ((key & mask) == prefix) atomicAdd(&sh.hist[wave][(key >> shift) & 255], 1u);
       }
     }
-    for (int64_t i = 4 * n4 + tid; i < n; i += SEL_THREADS) {
+    for (int64_t i = 4 * n4 + tid; i < n; i += NT) {
       uint32_t key = f2key(row[i]);
       if ((key & mask) == prefix) atomicAdd(&sh.hist[wave][(key >> shift) & 255], 1u);
     }
@@ -1463,12 +1662,12 @@ __device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, u
   return prefix;
 }
 
-// the same for a SHORT row (n <= 4 * SEL_THREADS, n % 4 == 0, 16-byte aligned): every thread keeps its four keys in registers, so the four
+// the same for a SHORT row (n <= 4 * blockDim.x, n % 4 == 0, 16-byte aligned): every thread keeps its four keys in registers, so the four
 // digit passes read nothing but their LDS histograms (the group maxima of a per-rank shard's sample: 3.9 k values -- k_sample_threshold
 // 14.6 -> ~12 us)
 template <class SH>
 __device__ uint32_t radix_select_kth_small(const float* __restrict__ row, int n, unsigned int kk, SH& sh) {
-  const int tid = threadIdx.x, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = tid >> 6, NT = blockDim.x;   // (any block of >= 256 threads, at most 16 waves)
   uint32_t key[4];
   const bool have = 4 * tid < n;
   if (have) {
@@ -1479,7 +1678,7 @@ __device__ uint32_t radix_select_kth_small(const float* __restrict__ row, int n,
   uint32_t prefix = 0, mask = 0;
   unsigned int neq;
   for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = tid; i < 16 * 256; i += SEL_THREADS) (&sh.hist[0][0])[i] = 0;
+    for (int i = tid; i < 16 * 256; i += NT) (&sh.hist[0][0])[i] = 0;
     __syncthreads();
     if (have) {
 #pragma unroll
@@ -1495,13 +1694,13 @@ __device__ uint32_t radix_select_kth_small(const float* __restrict__ row, int n,
 // the same over the score keys (upper halves) of a packed candidate list
 template <class SH>
 __device__ uint32_t radix_select_kth_list(const unsigned long long* __restrict__ list, int n, unsigned int kk, SH& sh) {
-  const int tid = threadIdx.x, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = tid >> 6, NT = blockDim.x;   // (any block of >= 256 threads, at most 16 waves)
   uint32_t prefix = 0, mask = 0;
   unsigned int neq;
   for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = tid; i < 16 * 256; i += SEL_THREADS) (&sh.hist[0][0])[i] = 0;
+    for (int i = tid; i < 16 * 256; i += NT) (&sh.hist[0][0])[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += SEL_THREADS) {
+    for (int i = tid; i < n; i += NT) {
       const uint32_t key = (uint32_t)(list[i] >> 32);
       if ((key & mask) == prefix) atomicAdd(&sh.hist[wave][(key >> shift) & 255], 1u);
     }
@@ -1935,13 +2134,22 @@ __device__ float query_eps_block(const float* __restrict__ qglob, int D, const f
 //   16 (register-streaming kernels: maxima of the 16-row wave groups, row stride 8 * nblk_ld): T' = the k-th largest GROUP maximum -- k
 //       different rows reach it, so it is a lower bound too, and with ~30 groups per wanted row it is the ~(1.02 k)-th score: one radix
 //       select over nblk * 8 values instead of select + gather + sort over the scores (40 -> 15 us at 1M x 2048, k = 100; 78 -> 41 us at 10M x 256).
-__global__ void __launch_bounds__(SEL_THREADS)
-k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, int k, const float* __restrict__ blkmax, int nblk, int nblk_ld,
+// (device function: one workgroup of 256 .. 1024 threads works on query qi -- k_sample_threshold below, and the selection step inside the fused
+// filter kernel.  SORTED = false compiles the select_topk_sorted branch out (1024-thread code; the fused kernel's plan guarantees >= k groups).)
+struct ThrShared {
+  SelShared sh;
+  float s_red[32];
+  unsigned int s_fill;
+};
+template <bool SORTED>
+__device__ __forceinline__ void sample_threshold_query(ThrShared& ts, int qi, const float* __restrict__ scores, int64_t ld_s, int64_t Ns, int k,
+                   const float* __restrict__ blkmax, int nblk, int nblk_ld,
                    const float* __restrict__ q, int D, const float* __restrict__ bounds, int rb, int ss, int64_t N, float* __restrict__ thr_out,
                    float* __restrict__ eps_out, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, int gsz, unsigned int cap) {
-  __shared__ SelShared sh;
-  __shared__ float s_red[32];
-  const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  SelShared& sh = ts.sh;
+  float* s_red = ts.s_red;
+  unsigned int& s_fill = ts.s_fill;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x;
   const float* row = scores + (int64_t)qi * ld_s;
   const int ng = gsz == 16 ? nblk * 8 : nblk;                    // entries of this query's maxima
   const float* bm = blkmax + (int64_t)qi * (gsz == 16 ? 8 * (int64_t)nblk_ld : (int64_t)nblk_ld);
@@ -1950,23 +2158,25 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
     // a large sample (10M x 256: 31 k groups): the k-th largest BLOCK maximum is as good a bound (k different rows reach it; with >= 8 k
     // blocks it is the ~(1.06 k)-th score) and the four passes of its select run over an LDS copy of 1/8 of the values (43 -> 22 us)
     float* bmaxL = (float*)sh.cand;
-    for (int b = tid; b < nblk; b += SEL_THREADS) {
+    for (int b = tid; b < nblk; b += NT) {
       const f32x4 g0 = *(const f32x4*)(bm + (int64_t)b * 8), g1 = *(const f32x4*)(bm + (int64_t)b * 8 + 4);
       bmaxL[b] = fmaxf(fmaxf(fmaxf(g0[0], g0[1]), fmaxf(g0[2], g0[3])), fmaxf(fmaxf(g1[0], g1[1]), fmaxf(g1[2], g1[3])));
     }
-    for (int b = nblk + tid; b < ((nblk + 3) & ~3); b += SEL_THREADS) bmaxL[b] = -FLT_MAX;
+    for (int b = nblk + tid; b < ((nblk + 3) & ~3); b += NT) bmaxL[b] = -FLT_MAX;
     __syncthreads();
     unsigned int ne, nq_;
     kth = key2f(radix_select_kth(bmaxL, nblk, (unsigned int)k, sh, ne, nq_));
-  } else if (gsz == 16 && ng >= k && ng <= 4 * SEL_THREADS) {
+  } else if (gsz == 16 && ng >= k && ng <= 4 * NT) {
     kth = key2f(radix_select_kth_small(bm, ng, (unsigned int)k, sh));
   } else if (gsz == 16 && ng >= k) {
     unsigned int ne, nq_;
     kth = key2f(radix_select_kth(bm, ng, (unsigned int)k, sh, ne, nq_));
-  } else {
+  } else if constexpr (SORTED) {
     // (group maxima: fewer than k groups -- a shard of a few thousand rows -- fall back to the scores themselves, without block pruning)
     select_topk_sorted(row, Ns, k, gsz == 16 ? nullptr : bm, gsz == 16 ? 0 : nblk, sh);   // (the plan guarantees >= 2k valid sample rows)
     kth = key2f((uint32_t)(sh.cand[k - 1] >> 32));
+  } else {
+    kth = -FLT_MAX;                                              // (not reachable: the fused plan requires >= k sample groups)
   }
   __syncthreads();
   const float eps = query_eps_block(q + (int64_t)qi * D, D, bounds, nullptr, s_red);
@@ -1974,13 +2184,12 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
   // this workgroup is the only writer of the query's list until the main pass starts: slots come from an LDS counter (a global
   // atomic per hit cost ~2 us of round trip per qualifying block and wave: 49 -> 3x us for the kernel), the count is stored once
   unsigned long long* list = cand + (int64_t)qi * cap;
-  __shared__ unsigned int s_fill;
   if (tid == 0) { s_fill = 0; sh.neq = 0; }
   __syncthreads();
   if (gsz == 16) {
     // qualifying 16-row groups first (all threads), then their rows, 16 lanes per group
     unsigned int* glist = (unsigned int*)sh.eqs;                 // 2 * SEL_EQCAP entries
-    for (int g = tid; g < ng; g += SEL_THREADS)
+    for (int g = tid; g < ng; g += NT)
       if (bm[g] >= thr) {
         const unsigned int p = atomicAdd(&sh.neq, 1u);
         if (p < 2 * SEL_EQCAP) glist[p] = (unsigned int)g;
@@ -1990,7 +2199,7 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
     if (ngl > 2 * SEL_EQCAP) {                                   // (near-duplicate rows: more groups than any list would hold -> exact fallback)
       if (tid == 0) s_fill = cap + 1;
     } else {
-      for (unsigned int idx = tid; idx < ngl * 16; idx += SEL_THREADS) {
+      for (unsigned int idx = tid; idx < ngl * 16; idx += NT) {
         const int64_t j = (int64_t)glist[idx >> 4] * 16 + (idx & 15);
         const float v = row[j];
         const int64_t g = (j / rb) * ((int64_t)ss * rb) + (j % rb);
@@ -2001,7 +2210,7 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
       }
     }
   } else {
-    for (int b = wave; b < nblk; b += SEL_THREADS / 64)
+    for (int b = wave; b < nblk; b += NT / 64)
       if (bm[b] >= thr) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -2032,6 +2241,84 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
     eps_out[qi] = eps;
     cnt[qi * CNT_STRIDE] = nfill;       // (the chunk's memset zeroed it; nobody else has touched it yet)
   }
+}
+
+__global__ void __launch_bounds__(SEL_THREADS)
+k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, int k, const float* __restrict__ blkmax, int nblk, int nblk_ld,
+                   const float* __restrict__ q, int D, const float* __restrict__ bounds, int rb, int ss, int64_t N, float* __restrict__ thr_out,
+                   float* __restrict__ eps_out, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, int gsz, unsigned int cap) {
+  __shared__ ThrShared ts;
+  sample_threshold_query<true>(ts, blockIdx.x, scores, ld_s, Ns, k, blkmax, nblk, nblk_ld, q, D, bounds, rb, ss, N, thr_out, eps_out, cand, cnt, gsz, cap);
+}
+
+// ---- the fused filter kernel (see filter_sample_block above for the design): selection + the two passes in one persistent launch
+template <int QT>
+struct FusedLds {
+  static constexpr int SAMPLE = ((QT > 8 ? 2 : 4) * 2 * QT * 1024) > 16 * (128 * 4 + 16) ? ((QT > 8 ? 2 : 4) * 2 * QT * 1024) : 16 * (128 * 4 + 16);
+  static constexpr int A = EmitLds<QT>::BYTES > SAMPLE ? EmitLds<QT>::BYTES : SAMPLE;
+  static constexpr int BYTES = A > (int)sizeof(ThrShared) + 64 ? A : (int)sizeof(ThrShared) + 64;
+};
+
+template <int QT, int PF, int RT>
+__global__ void __launch_bounds__(576, 3)
+k_filter_fused(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, float* __restrict__ scores, int64_t ld_s,
+               float* __restrict__ gmax, int nblk_s, int nblk_ld_s, int nsamp, int nmain, int ss, int k, const float* __restrict__ qf32,
+               const float* __restrict__ bounds, float* __restrict__ thr, float* __restrict__ eps, unsigned long long* __restrict__ cand,
+               unsigned int* __restrict__ cnt, unsigned int cap, FusedCtl* __restrict__ ctl) {
+  __shared__ __attribute__((aligned(1024))) char smem[FusedLds<QT>::BYTES];
+  __shared__ unsigned int s_item;
+  const int tid = threadIdx.x;
+  // ---- S: sample blocks
+  for (;;) {
+    if (tid == 0) s_item = atomicAdd(&ctl->ctr_s, 1u);
+    __syncthreads();
+    const unsigned int li = s_item;
+    __syncthreads();
+    if (li >= (unsigned int)nsamp) break;
+    filter_sample_block<QT, PF>(smem, Xb, N, D, qs, nq, scores, ld_s, gmax, nblk_ld_s, (int64_t)li * ss, (int64_t)li);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // every thread's score / maxima stores before the count below
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(&ctl->done_s, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- T: selection for the queries this workgroup can claim (first look: nothing claimed -> nothing to wait for)
+  for (;;) {
+    if (tid == 0) s_item = atomicAdd(&ctl->ctr_t, 1u);
+    __syncthreads();
+    const unsigned int qi = s_item;
+    __syncthreads();
+    if (qi >= (unsigned int)nq) break;
+    if (tid == 0)
+      while (__hip_atomic_load(&ctl->done_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)nsamp) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    sample_threshold_query<false>(*(ThrShared*)smem, (int)qi, scores, ld_s, (int64_t)nsamp * 128, k, gmax, nblk_s, nblk_ld_s, qf32, D, bounds, 128, ss, N,
+                                  thr, eps, cand, cnt, 16, cap);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(&ctl->done_t, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- M: this workgroup's share of the other blocks (static: nobody waits for a main block)
+  if (nmain > 0 && (int)blockIdx.x < (nmain + RT - 1) / RT)
+    filter_emit_body<QT, PF, RT>(smem, Xb, N, D, qs, nq, nmain, 2, ss, 1, thr, cand, cnt, cap, &ctl->done_t, (unsigned int)nq);
+}
+
+static int launch_filter_fused(const void* Xs, int64_t n_rows, int dim, const __bf16* qsplit, int nq, int qt, float* scores, float* gmax, const float* qf32,
+                               const FusedArgs& fa, hipStream_t s) {
+  const int n_cu = lrx_cu_count();
+  // two blocks at a time (the q slice is read from LDS once for both) once a workgroup has at least four such steps; fewer, finer steps otherwise
+  const bool rt2 = fa.nmain >= 8 * n_cu;
+#define LRX_FU(QQ)                                                                                                                               \
+  case QQ:                                                                                                                                        \
+    if (rt2) hipLaunchKernelGGL((k_filter_fused<QQ, (QQ == 8 ? 2 : 4), 2>), dim3(n_cu), dim3(576), 0, s, (const __bf16*)Xs, n_rows, dim, qsplit, nq, scores, fa.ld_s, \
+                                gmax, fa.nblk_s, fa.nblk_ld_s, fa.nsamp, fa.nmain, fa.ss, fa.k, qf32, fa.bounds, fa.thr, fa.eps, fa.cand, fa.cnt, fa.cap, fa.ctl);  \
+    else hipLaunchKernelGGL((k_filter_fused<QQ, (QQ == 8 ? 2 : 4), 1>), dim3(n_cu), dim3(576), 0, s, (const __bf16*)Xs, n_rows, dim, qsplit, nq, scores, fa.ld_s,     \
+                            gmax, fa.nblk_s, fa.nblk_ld_s, fa.nsamp, fa.nmain, fa.ss, fa.k, qf32, fa.bounds, fa.thr, fa.eps, fa.cand, fa.cnt, fa.cap, fa.ctl);      \
+    break;
+  switch (qt) { LRX_FU(1) LRX_FU(2) LRX_FU(3) LRX_FU(4) LRX_FU(5) LRX_FU(6) LRX_FU(7) LRX_FU(8)
+    default: lrx_set_error("filter_fused: %d query tiles", qt); return LRX_ERR_INVALID; }
+#undef LRX_FU
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
 }
 
 // exact rescoring of nc candidate rows (s_cand: row numbers): one half-wave per row (fp64 accumulation of the fp32 products, one
@@ -2236,6 +2523,7 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
 // flags & 3 (lrx.h LRX_SEARCH_FILTER_*): 0 = choose the filter per chunk, 1 = always the score-matrix filter, 2 = the score-free filter
 // whenever the shape allows, 3 = like 2 but never the GEMM kernel for the main pass (A/B runs).  Per call: no process-wide state.
 struct BoundedPlan {
+  bool fused;                           // emit + one persistent launch for sample, selection and main pass (k_filter_fused)
   bool emit;
   bool gemm;                            // emit: the main pass runs on the GEMM kernel (129..256 queries over the tiled shadow)
   int ss, rb;
@@ -2247,7 +2535,7 @@ struct BoundedPlan {
 };
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static size_t ints_before_cnt(int nq) { return ((size_t)nq + 1 + 63) & ~(size_t)63; }
+static size_t ints_before_cnt(int nq) { return ((size_t)nq + 1 + 8 + 63) & ~(size_t)63; }   // flags[nq], any_flag, ..., the fused kernel's five counters in the last 8
 
 // Candidate-list capacity and sample stride for top-k: ~k * ss rows reach the sample's k-th score, the fp16 band adds ~30 % -- the list
 // should end up around a third full (a list that overflows sends its query to the exact fallback).  k <= 256: 16 Ki entries and ss = 20
@@ -2263,7 +2551,13 @@ static unsigned int cand_cap_for(int32_t k) {
   return cap;
 }
 
-static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow, int mode) {
+// (LRX_SEARCH_FUSED=0: the three-launch chain of rounds 2-4, for A/B runs; read once, thread-safe)
+static bool search_use_fused() {
+  static const bool v = []() { const char* e = getenv("LRX_SEARCH_FUSED"); return !(e && atoi(e) == 0); }();
+  return v;
+}
+
+static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow, int mode, bool want_fused) {
   BoundedPlan p;
   memset(&p, 0, sizeof(p));
   // more than 128 queries over the shadow: the main pass is the GEMM kernel on 256-row tiles (the sample then moves in 256-row units)
@@ -2296,11 +2590,22 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   while (ss * 2 <= ss_lim) ss *= 2;
   ss = ss > ss_max ? ss_max : (ss < 2 ? 2 : ss);
   if (ss_force) ss = ss_force < ss_list ? ss_force : ss_list;
-  while (ss > 2 && (lrx_cdiv(nwg, ss) - 1) * p.rb < 2 * (int64_t)k) ss >>= 1;
+  // Fused launch (<= 128 queries over the shadow, D / 64 a multiple of the ring depth): the sample runs inside the persistent kernel, at the
+  // chip's full rate, so chip fill is no concern and a block costs the same in either pass -- the sample is ONE block per workgroup (every CU
+  // works through the sample phase together; a larger sample would only lengthen the wait before the selection), unless the hit / list rules ask for more
+  const bool fused_ok = want_fused && shadow && !p.gemm && nq <= 128 && dim % 256 == 0 && n_rows < (1ll << 31) - 256;
+  if (fused_ok && !ss_force) {
+    int lim = ss_hits < ss_list ? ss_hits : ss_list;
+    lim = lim < 2 ? 2 : (lim > 64 ? 64 : lim);
+    const int one_round = (int)lrx_cdiv(nwg, lrx_cu_count());
+    ss = one_round < 2 ? 2 : (one_round > lim ? lim : one_round);
+  }
+  while (ss > 2 && (lrx_cdiv(nwg, ss) - 1) * p.rb < 2 * (int64_t)k) ss = fused_ok ? ss - 1 : ss >> 1;
   const int64_t nsamp = lrx_cdiv(nwg, ss);
   const bool feasible = (nsamp - 1) * p.rb >= 2 * (int64_t)k && nwg - nsamp >= 1 && dim % 4 == 0 && (shadow || nq > 16 * (SPLIT_MIN_QT - 1));
   if (!feasible) p.gemm = false;
   p.emit = feasible && mode != 1 && (mode >= 2 || n_rows >= 16384);
+  p.fused = p.emit && fused_ok && !p.gemm;
   p.ss = ss;
   p.nsamp_wg = nsamp;
   p.nmain_wg = nwg - nsamp;
@@ -2332,7 +2637,9 @@ extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t di
     const int sizes[2] = {nq < chunk ? nq : chunk, nq > chunk ? nq % chunk : 0};
     for (int i = 0; i < 2; ++i)
       if (sizes[i] > 0) {
-        const size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, mode).total;
+        size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, mode, false).total;
+        const size_t tf = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, mode, true).total;   // (either chain may run: LRX_SEARCH_FUSED)
+        t = tf > t ? tf : t;
         need = t > need ? t : need;
       }
   }
@@ -2375,9 +2682,10 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
   }
   hipStream_t s = (hipStream_t)stream;
   const int chunk = shadow ? 256 : 128;
+  const bool use_fused = search_use_fused();
   for (int q0 = 0; q0 < n_queries; q0 += chunk) {
     const int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
-    const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, mode);
+    const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, mode, use_fused);
     if (p.total > workspace_bytes) {      // (cannot happen with a workspace sized by lrx_flat_ip_bounded_workspace_bytes for the same flags)
       lrx_set_error("flat_ip_search_bounded: chunk of %d queries needs %zu B of workspace, %zu given", nq, p.total, workspace_bytes);
       return LRX_ERR_WORKSPACE;
@@ -2426,12 +2734,22 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
       fs.group_max = shadow;                                  // the register-streaming kernels hand over the maxima of their 16-row wave groups
       if (clear_in_pack) { fs.zero = flg; fs.nzero = (int)nclear; }
       fs.presplit = presplit;
+      FusedArgs fa;
+      if (p.fused && clear_in_pack) {
+        fa.ld_s = p.ld_s; fa.nblk_s = (int)p.nblk_s; fa.nblk_ld_s = (int)p.nblk_ld_s; fa.nsamp = (int)p.nsamp_wg; fa.nmain = (int)p.nmain_wg; fa.ss = p.ss; fa.k = k;
+        fa.bounds = row_bounds; fa.thr = thr; fa.eps = eps; fa.cand = cand; fa.cnt = cnt; fa.cap = p.cap;
+        fa.ctl = (FusedCtl*)(flg + ints_before_cnt(nq) - 8);
+        fs.fused = &fa;
+      }
       rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_shadow : nullptr, p.ld_s, fs);
       if (rc != LRX_OK) return rc;
+      if (fs.fused == nullptr)
       hipLaunchKernelGGL(k_sample_threshold, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld_s, p.nsamp_wg * p.rb, k, (const float*)blkmax,
                          (int)p.nblk_s, (int)p.nblk_ld_s, qc, dim, row_bounds, p.rb, p.ss, n_rows, thr, eps, cand, cnt, fs.group_max ? 16 : 128, p.cap);
       LRX_LAUNCH_CHECK();
-      if (p.gemm) {
+      if (fs.fused != nullptr) {
+        rc = LRX_OK;                                            // sample, selection and main pass are done
+      } else if (p.gemm) {
         __bf16* q16 = (__bf16*)(ws + p.off_q16);
         hipLaunchKernelGGL(k_round_queries, dim3((unsigned)lrx_cdiv((int64_t)nq * dim, 1024)), dim3(256), 0, s, qc, (int64_t)nq * dim, q16);
         LRX_LAUNCH_CHECK();
@@ -2504,7 +2822,7 @@ extern "C" int lrx_flat_ip_bounded_list_counts(const void* workspace, int64_t n_
                                                int32_t has_shadow, uint32_t* counts_out, void* stream) {
   const bool shadow = has_shadow && dim % 64 == 0;
   LRX_CHECK_ARG(workspace && counts_out && n_queries > 0 && n_queries <= (shadow ? 256 : 128), "bounded_list_counts: one query chunk only (n_queries=%d)", n_queries);
-  const BoundedPlan p = plan_chunk(n_rows, dim, n_queries, k, shadow, flags & 3);
+  const BoundedPlan p = plan_chunk(n_rows, dim, n_queries, k, shadow, flags & 3, search_use_fused());
   const int* flg = (const int*)((const char*)workspace + p.off_ints);
   // (the same test lrx_flat_ip_search_bounded_wire uses to send a call down the plain path, which keeps no lists)
   const int qt_max = ((n_queries < 128 ? n_queries : 128) + 15) / 16;
