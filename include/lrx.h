@@ -180,6 +180,10 @@ int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens
 /* Number of out-of-range token ids any embedding gather (stand-alone or inside lrx_encode_*) has met since the last reset; -1 if the
  * read failed.  SYNCHRONISES the device (a blocking copy): call it at a point where the caller waits for results anyway.         */
 int64_t lrx_device_error_count(int32_t reset);
+/* (ABI 6) Measurement aid: with LRX_FUSED_PHASES bit 7 set in the environment the fused filter launch of the bounded search (sample + selection
+ * + main pass in one persistent kernel) records per-workgroup phase timestamps (100 MHz clock; 8 words per workgroup: start, sample done,
+ * selection start, selection done, first main K loop done, thresholds seen, ..., end); this copies the first n_words of them to the host.     */
+int lrx_probe_fused_timestamps(uint64_t* out, int32_t n_words);
 /* (ABI 5) fp16 range events since the last reset: q|k|v elements of the fused QKV + RoPE epilogue and fp16-shadow elements of pooled rows
  * that were NaN or beyond +-65504 and were stored as a finite +-65504 (counted once per wave instruction that saw any, so "0 or not" is
  * the meaningful reading).  0 on every checkpoint whose q|k|v stay inside fp16's range -- the precondition of the fp16 attention path;
@@ -357,7 +361,12 @@ enum {
   LRX_SEARCH_FILTER_AUTO = 0,            /* score-free filter from 16 Ki rows on, score-matrix filter below                         */
   LRX_SEARCH_FILTER_MATRIX = 1,          /* always the score-matrix filter                                                           */
   LRX_SEARCH_FILTER_SCORE_FREE = 2,      /* the score-free (candidate-list) filter whenever the shard is large enough for a sample   */
-  LRX_SEARCH_FILTER_SCORE_FREE_NO_GEMM = 3 /* like 2, but chunks of 129..256 queries never take the GEMM kernel for the main pass   */
+  LRX_SEARCH_FILTER_SCORE_FREE_NO_GEMM = 3, /* like 2, but chunks of 129..256 queries never take the GEMM kernel for the main pass   */
+  /* (ABI 6) OR-ed onto one of the above: the FUSED launch of the score-free filter -- sample pass, threshold selection and main pass in one
+   * persistent kernel, for chunks of <= 128 queries over a shadow with dim % 256 == 0 -- is chosen by a measured rule (<= 32 queries, dim >= 512,
+   * k <= 256, <= 8 blocks of 128 rows per CU: small query batches over a per-rank shard); these two bits force it on wherever it is eligible, or off */
+  LRX_SEARCH_FUSED_ALWAYS = 4,
+  LRX_SEARCH_FUSED_NEVER = 8
 };
 size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags);
 int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_shadow, const float* row_bounds,

@@ -9,6 +9,7 @@ LRX_PROF_CLASSES = 8
 ABI_VERSION = 6   # LRX_ABI_VERSION of include/lrx.h
 # lrx_flat_ip_search_bounded flags (LRX_SEARCH_FILTER_*): A/B runs and tests; the hits do not depend on them
 SEARCH_FILTER_AUTO, SEARCH_FILTER_MATRIX, SEARCH_FILTER_SCORE_FREE, SEARCH_FILTER_SCORE_FREE_NO_GEMM = 0, 1, 2, 3
+SEARCH_FUSED_ALWAYS, SEARCH_FUSED_NEVER = 4, 8       # OR-ed on: the fused filter launch wherever eligible / never (default: a measured rule)
 PROF_CLASS_NAMES = ["gemm_store", "gemm_resid", "gemm_swiglu", "attention", "rmsnorm", "rope", "other", "gemm_maxagg"]
 
 
@@ -81,6 +82,7 @@ SIGNATURES = {
     "lrx_build_positions": (_I32, [_P, _I32, _I32, _P, _P]),
     "lrx_attn_varlen_causal": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "lrx_gather_last_rows": (_I32, [_P, _P, _I32, _I32, _P, _P]),
+    "lrx_probe_fused_timestamps": (_I32, [_P, _I32]),
     "lrx_scatter_last_rows": (_I32, [_P, _P, _I32, _I32, _P, _I64, _P]),
     "lrx_gemm_qkv_rope_slice": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _P]),
     "lrx_pool_norm": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P]),

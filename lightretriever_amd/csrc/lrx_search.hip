@@ -753,7 +753,7 @@ struct EmitLds {
 template <int QT, int PF, int RT>
 __device__ __forceinline__ void filter_emit_body(char* smem, const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, int nblocks, int bmode, int ss,
                    int unit, const float* __restrict__ thr, unsigned long long* __restrict__ cand, unsigned int* __restrict__ cnt, unsigned int cap,
-                   const unsigned int* thr_ready, unsigned int thr_target) {
+                   const unsigned int* thr_ready, unsigned int thr_target, unsigned long long* ts = nullptr) {
   constexpr int WV = 8;
   constexpr int QINST = 2 * QT;
   constexpr int QBYTES = QINST * 1024;
@@ -920,9 +920,12 @@ __device__ __forceinline__ void filter_emit_body(char* smem, const __bf16* __res
     if (thr_ready != nullptr && j == 0) {
       // thresholds published by the selection step of this launch: every consumer wave waits for itself and fills the (shared) table with the
       // same values -- a wave reads the table only after its own complete write, so no barrier is needed
+      if (ts != nullptr && tid == 0) ts[4] = __builtin_amdgcn_s_memrealtime();
       if (lane == 0)
         while (__hip_atomic_load(thr_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < thr_target) __builtin_amdgcn_s_sleep(8);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (ts != nullptr && tid == 0) ts[5] = __builtin_amdgcn_s_memrealtime();
+      // (no acquire fence: the thresholds are read with device-scope loads, which do not go through this XCD's caches; an agent-scope acquire
+      // here would invalidate the L2 once per wave -- 2048 times per launch, under the streaming pass)
       for (int i = lane; i < QT * 16; i += 64) sthr[i] = i < nq ? __hip_atomic_load(thr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FLT_MAX;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
@@ -1006,6 +1009,28 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
   filter_emit_body<QT, PF, RT>(smem, Xb, N, D, qs, nq, nblocks, bmode, ss, unit, thr, cand, cnt, cap, nullptr, 0u);
 }
 
+// Device-scope ("sc1") loads / stores: data one workgroup writes and another workgroup of the SAME launch reads (the fused filter kernel) must
+// not live in an XCD's L2 -- the eight L2s of the chip are not coherent with each other inside a kernel.  An agent-scope fence would do it too
+// (buffer_wbl2 / buffer_inv of the whole L2, per wave that executes it): measured 0.31 vs 0.18 ms on a 125 k-row shard.  COH = false: plain accesses.
+template <bool COH>
+__device__ __forceinline__ float ld1(const float* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ f32x4 ld4(const float* p) {          // 16-byte aligned
+  if constexpr (COH) {
+    const unsigned long long a = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{__uint_as_float((unsigned int)a), __uint_as_float((unsigned int)(a >> 32)), __uint_as_float((unsigned int)b), __uint_as_float((unsigned int)(b >> 32))};
+  } else return *(const f32x4*)p;
+}
+__device__ __forceinline__ void st1_coh(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st4_coh(float* p, f32x4 v) {     // 16-byte aligned
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__float_as_uint(v[0]) | ((unsigned long long)__float_as_uint(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((unsigned long long*)p + 1, (unsigned long long)__float_as_uint(v[2]) | ((unsigned long long)__float_as_uint(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // FUSED filter chain (round 5): sample pass -> threshold selection -> main pass in ONE persistent launch, without a grid barrier.
 //
@@ -1022,6 +1047,8 @@ k_filter_xreg_emit(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16
 //      needed, each consumer wave then waits for done_t == n_queries (claimed work of running workgroups again) and loads them.
 // Workgroups that find no selection left go straight to M and stream while the (at most n_queries) others select: HBM never idles.
 // ---------------------------------------------------------------------------------------------------------------
+// dev aid (LRX_FUSED_PHASES bit 7): per-workgroup phase timestamps (100 MHz s_memrealtime) of the last fused launch, read by lrx_probe_fused_timestamps
+__device__ unsigned long long g_fused_ts[1024 * 8];
 struct FusedCtl {              // five counters in the zero-initialised ints of the workspace (k_pack_queries_xb clears them)
   unsigned int ctr_s, done_s, ctr_t, done_t, pad;
 };
@@ -1131,7 +1158,7 @@ __device__ __forceinline__ void filter_sample_block(char* smem, const __bf16* __
   __syncthreads();
   for (int t = tid; t < QT * 16 * WV; t += 576) {
     const int qi = t >> 3, w = t & 7;
-    if (qi < nq) gmax[(int64_t)qi * (8 * (int64_t)nblk_ld) + li * 8 + w] = wmax[w * (QT * 16) + qi];
+    if (qi < nq) st1_coh(gmax + (int64_t)qi * (8 * (int64_t)nblk_ld) + li * 8 + w, wmax[w * (QT * 16) + qi]);
   }
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
@@ -1143,10 +1170,12 @@ __device__ __forceinline__ void filter_sample_block(char* smem, const __bf16* __
     }
     __syncthreads();
     const int nqt = (QT - ps * QPT) < QPT ? (QT - ps * QPT) : QPT;
-    for (int idx = tid; idx < nqt * 16 * (RB / 4); idx += 576) {
-      const int ql = idx / (RB / 4), c = idx % (RB / 4);
+    // (read by other workgroups of this launch: device-scope stores, 8 bytes per lane so that one wave instruction writes four whole 128-byte lines)
+    for (int idx = tid; idx < nqt * 16 * (RB / 2); idx += 576) {
+      const int ql = idx / (RB / 2), c = idx % (RB / 2);
       const int qi = ps * QPT * 16 + ql;
-      if (qi < nq) *(f32x4*)(scores + (int64_t)qi * ld + n0s + c * 4) = *(const f32x4*)(smem + ql * SEG + c * 16);
+      if (qi < nq) __hip_atomic_store((unsigned long long*)(scores + (int64_t)qi * ld + n0s) + c, *(const unsigned long long*)(smem + ql * SEG + c * 8), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();                                 // the staging region is free again (next block's q ring, or the selection's tables)
@@ -1354,6 +1383,7 @@ struct FusedArgs {
   unsigned int* cnt;
   unsigned int cap;
   FusedCtl* ctl;
+  int phases;                             // 7 = sample + selection + main pass (dev: LRX_FUSED_PHASES = 1 or 3 leaves the rest to the old kernels)
 };
 
 // planes = 3: fp32-grade scores (six bf16 products); planes = 1: one fp16 product (filter pass of the bounded search, error bound
@@ -1634,7 +1664,7 @@ __device__ __forceinline__ unsigned int radix_pick(SH& sh, unsigned int& kk, uns
 
 // exact radix select (4 x 8 bit) of the kk-th largest key of row[0..n): returns the key, the number of elements
 // equal to it that belong to the top-kk (need_eq) and how many elements carry that key in total (neq).
-template <class SH>
+template <class SH, bool COH = false>
 __device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, unsigned int kk, SH& sh, unsigned int& need_eq,
                                      unsigned int& neq) {
   const int tid = threadIdx.x, wave = tid >> 6, NT = blockDim.x;   // (any block of >= 256 threads, at most 16 waves)
@@ -1644,7 +1674,7 @@ __device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, u
     for (int i = tid; i < 16 * 256; i += NT) (&sh.hist[0][0])[i] = 0;
     __syncthreads();
     for (int64_t i = tid; i < n4; i += NT) {
-      f32x4 v = *(const f32x4*)(row + 4 * i);
+      f32x4 v = ld4<COH>(row + 4 * i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         uint32_t key = f2key(v[e]);
@@ -1652,7 +1682,7 @@ __device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, u
       }
     }
     for (int64_t i = 4 * n4 + tid; i < n; i += NT) {
-      uint32_t key = f2key(row[i]);
+      uint32_t key = f2key(ld1<COH>(row + i));
       if ((key & mask) == prefix) atomicAdd(&sh.hist[wave][(key >> shift) & 255], 1u);
     }
     prefix |= (uint32_t)radix_pick(sh, kk, neq) << shift;
@@ -1665,13 +1695,13 @@ __device__ uint32_t radix_select_kth(const float* __restrict__ row, int64_t n, u
 // the same for a SHORT row (n <= 4 * blockDim.x, n % 4 == 0, 16-byte aligned): every thread keeps its four keys in registers, so the four
 // digit passes read nothing but their LDS histograms (the group maxima of a per-rank shard's sample: 3.9 k values -- k_sample_threshold
 // 14.6 -> ~12 us)
-template <class SH>
+template <class SH, bool COH = false>
 __device__ uint32_t radix_select_kth_small(const float* __restrict__ row, int n, unsigned int kk, SH& sh) {
   const int tid = threadIdx.x, wave = tid >> 6, NT = blockDim.x;   // (any block of >= 256 threads, at most 16 waves)
   uint32_t key[4];
   const bool have = 4 * tid < n;
   if (have) {
-    const f32x4 v = *(const f32x4*)(row + 4 * tid);
+    const f32x4 v = ld4<COH>(row + 4 * tid);
 #pragma unroll
     for (int e = 0; e < 4; ++e) key[e] = f2key(v[e]);
   }
@@ -2141,7 +2171,7 @@ struct ThrShared {
   float s_red[32];
   unsigned int s_fill;
 };
-template <bool SORTED>
+template <bool SORTED, bool COH = false>
 __device__ __forceinline__ void sample_threshold_query(ThrShared& ts, int qi, const float* __restrict__ scores, int64_t ld_s, int64_t Ns, int k,
                    const float* __restrict__ blkmax, int nblk, int nblk_ld,
                    const float* __restrict__ q, int D, const float* __restrict__ bounds, int rb, int ss, int64_t N, float* __restrict__ thr_out,
@@ -2159,7 +2189,7 @@ __device__ __forceinline__ void sample_threshold_query(ThrShared& ts, int qi, co
     // blocks it is the ~(1.06 k)-th score) and the four passes of its select run over an LDS copy of 1/8 of the values (43 -> 22 us)
     float* bmaxL = (float*)sh.cand;
     for (int b = tid; b < nblk; b += NT) {
-      const f32x4 g0 = *(const f32x4*)(bm + (int64_t)b * 8), g1 = *(const f32x4*)(bm + (int64_t)b * 8 + 4);
+      const f32x4 g0 = ld4<COH>(bm + (int64_t)b * 8), g1 = ld4<COH>(bm + (int64_t)b * 8 + 4);
       bmaxL[b] = fmaxf(fmaxf(fmaxf(g0[0], g0[1]), fmaxf(g0[2], g0[3])), fmaxf(fmaxf(g1[0], g1[1]), fmaxf(g1[2], g1[3])));
     }
     for (int b = nblk + tid; b < ((nblk + 3) & ~3); b += NT) bmaxL[b] = -FLT_MAX;
@@ -2167,10 +2197,10 @@ __device__ __forceinline__ void sample_threshold_query(ThrShared& ts, int qi, co
     unsigned int ne, nq_;
     kth = key2f(radix_select_kth(bmaxL, nblk, (unsigned int)k, sh, ne, nq_));
   } else if (gsz == 16 && ng >= k && ng <= 4 * NT) {
-    kth = key2f(radix_select_kth_small(bm, ng, (unsigned int)k, sh));
+    kth = key2f(radix_select_kth_small<SelShared, COH>(bm, ng, (unsigned int)k, sh));
   } else if (gsz == 16 && ng >= k) {
     unsigned int ne, nq_;
-    kth = key2f(radix_select_kth(bm, ng, (unsigned int)k, sh, ne, nq_));
+    kth = key2f(radix_select_kth<SelShared, COH>(bm, ng, (unsigned int)k, sh, ne, nq_));
   } else if constexpr (SORTED) {
     // (group maxima: fewer than k groups -- a shard of a few thousand rows -- fall back to the scores themselves, without block pruning)
     select_topk_sorted(row, Ns, k, gsz == 16 ? nullptr : bm, gsz == 16 ? 0 : nblk, sh);   // (the plan guarantees >= 2k valid sample rows)
@@ -2190,7 +2220,7 @@ __device__ __forceinline__ void sample_threshold_query(ThrShared& ts, int qi, co
     // qualifying 16-row groups first (all threads), then their rows, 16 lanes per group
     unsigned int* glist = (unsigned int*)sh.eqs;                 // 2 * SEL_EQCAP entries
     for (int g = tid; g < ng; g += NT)
-      if (bm[g] >= thr) {
+      if (ld1<COH>(bm + g) >= thr) {
         const unsigned int p = atomicAdd(&sh.neq, 1u);
         if (p < 2 * SEL_EQCAP) glist[p] = (unsigned int)g;
       }
@@ -2201,7 +2231,7 @@ __device__ __forceinline__ void sample_threshold_query(ThrShared& ts, int qi, co
     } else {
       for (unsigned int idx = tid; idx < ngl * 16; idx += NT) {
         const int64_t j = (int64_t)glist[idx >> 4] * 16 + (idx & 15);
-        const float v = row[j];
+        const float v = ld1<COH>(row + j);
         const int64_t g = (j / rb) * ((int64_t)ss * rb) + (j % rb);
         if (g < N && v >= thr) {
           const unsigned int p = atomicAdd(&s_fill, 1u);
@@ -2237,9 +2267,15 @@ __device__ __forceinline__ void sample_threshold_query(ThrShared& ts, int qi, co
   if (gsz == 16 && nfill > 2u * (unsigned int)k && nfill <= cap)
     thr_final = fmaxf(thr, key2f(radix_select_kth_list(list, (int)nfill, (unsigned int)k, sh)) - 2.0f * eps);
   if (tid == 0) {
-    thr_out[qi] = thr_final;
-    eps_out[qi] = eps;
-    cnt[qi * CNT_STRIDE] = nfill;       // (the chunk's memset zeroed it; nobody else has touched it yet)
+    if constexpr (COH) {                // read by other workgroups of this launch (the main phase): device-scope stores
+      st1_coh(thr_out + qi, thr_final);
+      st1_coh(eps_out + qi, eps);
+      __hip_atomic_store(cnt + qi * CNT_STRIDE, nfill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      thr_out[qi] = thr_final;
+      eps_out[qi] = eps;
+      cnt[qi * CNT_STRIDE] = nfill;       // (the chunk's memset zeroed it; nobody else has touched it yet)
+    }
   }
 }
 
@@ -2264,42 +2300,68 @@ __global__ void __launch_bounds__(576, 3)
 k_filter_fused(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __restrict__ qs, int nq, float* __restrict__ scores, int64_t ld_s,
                float* __restrict__ gmax, int nblk_s, int nblk_ld_s, int nsamp, int nmain, int ss, int k, const float* __restrict__ qf32,
                const float* __restrict__ bounds, float* __restrict__ thr, float* __restrict__ eps, unsigned long long* __restrict__ cand,
-               unsigned int* __restrict__ cnt, unsigned int cap, FusedCtl* __restrict__ ctl) {
+               unsigned int* __restrict__ cnt, unsigned int cap, FusedCtl* __restrict__ ctl, int phases) {
   __shared__ __attribute__((aligned(1024))) char smem[FusedLds<QT>::BYTES];
   __shared__ unsigned int s_item;
   const int tid = threadIdx.x;
+  // (phases: bit 0 = S, 1 = T, 2 = M -- all three in the product; LRX_FUSED_PHASES = 1 or 3 lets the old kernels take over the later ones (bisecting
+  // aid), bit 7 records the phase timestamps lrx_probe_fused_timestamps reads)
+  unsigned long long* ts = (phases & 128) && blockIdx.x < 1024 ? g_fused_ts + blockIdx.x * 8 : nullptr;
+  if (ts != nullptr && tid == 0) { ts[0] = __builtin_amdgcn_s_memrealtime(); ts[2] = 0; ts[4] = 0; ts[5] = 0; }
+  // (Claim loops: ONE single-thread region per iteration, in the middle of the loop body.  With "if (tid == 0) count; } ... top: if (tid == 0)
+  // claim" the compiler merged the two regions across the back edge and structurised the result as nested exec-mask loops -- lanes 1..63 of
+  // wave 0 then ran on through the barriers of the next iteration before lane 0 had claimed its item: the first version of this kernel hung.)
   // ---- S: sample blocks
-  for (;;) {
+  if (phases & 1) {
     if (tid == 0) s_item = atomicAdd(&ctl->ctr_s, 1u);
-    __syncthreads();
-    const unsigned int li = s_item;
-    __syncthreads();
-    if (li >= (unsigned int)nsamp) break;
-    filter_sample_block<QT, PF>(smem, Xb, N, D, qs, nq, scores, ld_s, gmax, nblk_ld_s, (int64_t)li * ss, (int64_t)li);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // every thread's score / maxima stores before the count below
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(&ctl->done_s, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      __syncthreads();
+      const unsigned int li = __builtin_amdgcn_readfirstlane(s_item);   // (scalar: the loop exit is a uniform branch)
+      if (li >= (unsigned int)nsamp) break;
+      filter_sample_block<QT, PF>(smem, Xb, N, D, qs, nq, scores, ld_s, gmax, nblk_ld_s, (int64_t)li * ss, (int64_t)li);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every thread's device-scope score / maxima stores have landed ...
+      __syncthreads();                                            // (also: every thread has read s_item)
+      if (tid == 0) {
+        __hip_atomic_fetch_add(&ctl->done_s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the block is counted
+        s_item = atomicAdd(&ctl->ctr_s, 1u);
+      }
+    }
   }
+  __syncthreads();
+  if (ts != nullptr && tid == 0) ts[1] = __builtin_amdgcn_s_memrealtime();
   // ---- T: selection for the queries this workgroup can claim (first look: nothing claimed -> nothing to wait for)
-  for (;;) {
+  if (phases & 2) {
     if (tid == 0) s_item = atomicAdd(&ctl->ctr_t, 1u);
-    __syncthreads();
-    const unsigned int qi = s_item;
-    __syncthreads();
-    if (qi >= (unsigned int)nq) break;
-    if (tid == 0)
-      while (__hip_atomic_load(&ctl->done_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)nsamp) __builtin_amdgcn_s_sleep(8);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    sample_threshold_query<false>(*(ThrShared*)smem, (int)qi, scores, ld_s, (int64_t)nsamp * 128, k, gmax, nblk_s, nblk_ld_s, qf32, D, bounds, 128, ss, N,
-                                  thr, eps, cand, cnt, 16, cap);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(&ctl->done_t, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      __syncthreads();
+      const unsigned int qi = __builtin_amdgcn_readfirstlane(s_item);
+      if (qi >= (unsigned int)nq) break;
+      if (tid == 0)
+        while (__hip_atomic_load(&ctl->done_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)nsamp) __builtin_amdgcn_s_sleep(8);
+      __syncthreads();
+      if (ts != nullptr && tid == 0 && ts[2] == 0) ts[2] = __builtin_amdgcn_s_memrealtime();
+      sample_threshold_query<false, true>(*(ThrShared*)smem, (int)qi, scores, ld_s, (int64_t)nsamp * 128, k, gmax, nblk_s, nblk_ld_s, qf32, D, bounds, 128, ss, N,
+                                    thr, eps, cand, cnt, 16, cap);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (thread 0's device-scope stores of thr / eps / list count have landed)
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(&ctl->done_t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_item = atomicAdd(&ctl->ctr_t, 1u);
+      }
+    }
   }
+  __syncthreads();
+  if (ts != nullptr && tid == 0) ts[3] = __builtin_amdgcn_s_memrealtime();
   // ---- M: this workgroup's share of the other blocks (static: nobody waits for a main block)
-  if (nmain > 0 && (int)blockIdx.x < (nmain + RT - 1) / RT)
-    filter_emit_body<QT, PF, RT>(smem, Xb, N, D, qs, nq, nmain, 2, ss, 1, thr, cand, cnt, cap, &ctl->done_t, (unsigned int)nq);
+  if ((phases & 4) && nmain > 0 && (int)blockIdx.x < (nmain + RT - 1) / RT)
+    filter_emit_body<QT, PF, RT>(smem, Xb, N, D, qs, nq, nmain, 2, ss, 1, thr, cand, cnt, cap, &ctl->done_t, (unsigned int)nq, ts);
+  if (ts != nullptr && tid == 0) ts[6] = __builtin_amdgcn_s_memrealtime();
+}
+
+extern "C" int lrx_probe_fused_timestamps(uint64_t* out, int32_t n_words) {
+  LRX_CHECK_ARG(out != nullptr && n_words > 0 && n_words <= 1024 * 8, "probe_fused_timestamps: bad buffer");
+  LRX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_ts), (size_t)n_words * 8));
+  return LRX_OK;
 }
 
 static int launch_filter_fused(const void* Xs, int64_t n_rows, int dim, const __bf16* qsplit, int nq, int qt, float* scores, float* gmax, const float* qf32,
@@ -2310,9 +2372,9 @@ static int launch_filter_fused(const void* Xs, int64_t n_rows, int dim, const __
 #define LRX_FU(QQ)                                                                                                                               \
   case QQ:                                                                                                                                        \
     if (rt2) hipLaunchKernelGGL((k_filter_fused<QQ, (QQ == 8 ? 2 : 4), 2>), dim3(n_cu), dim3(576), 0, s, (const __bf16*)Xs, n_rows, dim, qsplit, nq, scores, fa.ld_s, \
-                                gmax, fa.nblk_s, fa.nblk_ld_s, fa.nsamp, fa.nmain, fa.ss, fa.k, qf32, fa.bounds, fa.thr, fa.eps, fa.cand, fa.cnt, fa.cap, fa.ctl);  \
+                                gmax, fa.nblk_s, fa.nblk_ld_s, fa.nsamp, fa.nmain, fa.ss, fa.k, qf32, fa.bounds, fa.thr, fa.eps, fa.cand, fa.cnt, fa.cap, fa.ctl, fa.phases);  \
     else hipLaunchKernelGGL((k_filter_fused<QQ, (QQ == 8 ? 2 : 4), 1>), dim3(n_cu), dim3(576), 0, s, (const __bf16*)Xs, n_rows, dim, qsplit, nq, scores, fa.ld_s,     \
-                            gmax, fa.nblk_s, fa.nblk_ld_s, fa.nsamp, fa.nmain, fa.ss, fa.k, qf32, fa.bounds, fa.thr, fa.eps, fa.cand, fa.cnt, fa.cap, fa.ctl);      \
+                            gmax, fa.nblk_s, fa.nblk_ld_s, fa.nsamp, fa.nmain, fa.ss, fa.k, qf32, fa.bounds, fa.thr, fa.eps, fa.cand, fa.cnt, fa.cap, fa.ctl, fa.phases);      \
     break;
   switch (qt) { LRX_FU(1) LRX_FU(2) LRX_FU(3) LRX_FU(4) LRX_FU(5) LRX_FU(6) LRX_FU(7) LRX_FU(8)
     default: lrx_set_error("filter_fused: %d query tiles", qt); return LRX_ERR_INVALID; }
@@ -2551,13 +2613,16 @@ static unsigned int cand_cap_for(int32_t k) {
   return cap;
 }
 
-// (LRX_SEARCH_FUSED=0: the three-launch chain of rounds 2-4, for A/B runs; read once, thread-safe)
-static bool search_use_fused() {
-  static const bool v = []() { const char* e = getenv("LRX_SEARCH_FUSED"); return !(e && atoi(e) == 0); }();
+// LRX_SEARCH_FUSED: unset = the measured rule in plan_chunk (small query batches over small shards), 0 = never (the three-launch chain of rounds
+// 2-4), 1 = wherever the fused kernel is eligible (A/B runs: tools/exp/fused_ab.sh).  Read once, thread-safe.
+static int search_fused_mode() {
+  static const int v = []() { const char* e = getenv("LRX_SEARCH_FUSED"); return e ? (atoi(e) == 0 ? 0 : 1) : -1; }();
   return v;
 }
+// fused preference of a call: -1 = by the rule, 0 = never, 1 = wherever eligible; flag bits LRX_SEARCH_FUSED_NEVER / _ALWAYS win over the environment
+static int fused_pref_of(int flags) { return (flags & 8) ? 0 : ((flags & 4) ? 1 : search_fused_mode()); }
 
-static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow, int mode, bool want_fused) {
+static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k, bool shadow, int mode, int fused_pref) {
   BoundedPlan p;
   memset(&p, 0, sizeof(p));
   // more than 128 queries over the shadow: the main pass is the GEMM kernel on 256-row tiles (the sample then moves in 256-row units)
@@ -2593,7 +2658,13 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   // Fused launch (<= 128 queries over the shadow, D / 64 a multiple of the ring depth): the sample runs inside the persistent kernel, at the
   // chip's full rate, so chip fill is no concern and a block costs the same in either pass -- the sample is ONE block per workgroup (every CU
   // works through the sample phase together; a larger sample would only lengthen the wait before the selection), unless the hit / list rules ask for more
-  const bool fused_ok = want_fused && shadow && !p.gemm && nq <= 128 && dim % 256 == 0 && n_rows < (1ll << 31) - 256;
+  // Where it pays (profiles/r05_fused_ab.txt, same box, fused / chain): 125 k x 2048, k = 100: 0.91 / 0.97 / 0.96 at Q = 1 / 16 / 32 but 1.03 / 1.15 at
+  // 64 / 100 -- with seven query tiles ONE block per workgroup is bound by its LDS fragment reads and MFMA issue (36 us against 22 us for a block
+  // of the two-at-a-time main pass: profiles/r05_fused_timeline.txt), and every selection waits for the slowest sample block; 250 k rows 0.97-0.99
+  // up to Q = 32; 1M x 2048 and 1M x 4096 1.00-1.03; D = 256 (q resident, no per-step barrier) 1.07-1.22; k = 1000 1.08-1.20.  Hence the rule:
+  // at most 32 queries, D >= 512, k <= 256, at most 8 blocks per CU.  LRX_SEARCH_FUSED=1 lifts the rule (not the eligibility).
+  const bool fused_rule = nq <= 32 && dim >= 512 && k <= 256 && nwg <= 8 * (int64_t)lrx_cu_count();
+  const bool fused_ok = fused_pref != 0 && (fused_rule || fused_pref == 1) && shadow && !p.gemm && nq <= 128 && dim % 256 == 0 && n_rows < (1ll << 31) - 256;
   if (fused_ok && !ss_force) {
     int lim = ss_hits < ss_list ? ss_hits : ss_list;
     lim = lim < 2 ? 2 : (lim > 64 ? 64 : lim);
@@ -2637,8 +2708,8 @@ extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t di
     const int sizes[2] = {nq < chunk ? nq : chunk, nq > chunk ? nq % chunk : 0};
     for (int i = 0; i < 2; ++i)
       if (sizes[i] > 0) {
-        size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, mode, false).total;
-        const size_t tf = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, mode, true).total;   // (either chain may run: LRX_SEARCH_FUSED)
+        size_t t = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, mode, 0).total;
+        const size_t tf = plan_chunk(n_rows, dim, sizes[i], k, sh != 0, mode, 1).total;   // (either chain may run: flags, LRX_SEARCH_FUSED)
         t = tf > t ? tf : t;
         need = t > need ? t : need;
       }
@@ -2660,7 +2731,7 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
   LRX_CHECK_ARG(row_bounds != nullptr, "flat_ip_search_bounded: null row_bounds (device pointer to {max |x_row|, max |x_row - fp16(x_row)|})");
   LRX_CHECK_ARG(k > 0 && k <= SEL_MAXK, "flat_ip_search: k=%d out of range (1..%d)", k, SEL_MAXK);
   LRX_CHECK_ARG(n_rows >= 0 && n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
-  LRX_CHECK_ARG((flags & ~3) == 0, "flat_ip_search_bounded: unknown flags 0x%x", flags);
+  LRX_CHECK_ARG((flags & ~15) == 0 && (flags & 12) != 12, "flat_ip_search_bounded: unknown flags 0x%x", flags);
   if (n_queries <= 0) return LRX_OK;
   if (workspace_bytes < lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k, flags)) {
     lrx_set_error("flat_ip_search_bounded: workspace %zu B < required %zu B", workspace_bytes, lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k, flags));
@@ -2682,7 +2753,7 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
   }
   hipStream_t s = (hipStream_t)stream;
   const int chunk = shadow ? 256 : 128;
-  const bool use_fused = search_use_fused();
+  const int use_fused = fused_pref_of(flags);
   for (int q0 = 0; q0 < n_queries; q0 += chunk) {
     const int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
     const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, mode, use_fused);
@@ -2739,15 +2810,17 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
         fa.ld_s = p.ld_s; fa.nblk_s = (int)p.nblk_s; fa.nblk_ld_s = (int)p.nblk_ld_s; fa.nsamp = (int)p.nsamp_wg; fa.nmain = (int)p.nmain_wg; fa.ss = p.ss; fa.k = k;
         fa.bounds = row_bounds; fa.thr = thr; fa.eps = eps; fa.cand = cand; fa.cnt = cnt; fa.cap = p.cap;
         fa.ctl = (FusedCtl*)(flg + ints_before_cnt(nq) - 8);
+        static const int fused_phases = []() { const char* e = getenv("LRX_FUSED_PHASES"); const int v = e ? atoi(e) : 7; return (v & 7) == 1 || (v & 7) == 3 || (v & 7) == 7 ? (v & 135) : 7; }();
+        fa.phases = fused_phases;
         fs.fused = &fa;
       }
       rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_shadow : nullptr, p.ld_s, fs);
       if (rc != LRX_OK) return rc;
-      if (fs.fused == nullptr)
+      if (fs.fused == nullptr || !(fa.phases & 2))
       hipLaunchKernelGGL(k_sample_threshold, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld_s, p.nsamp_wg * p.rb, k, (const float*)blkmax,
                          (int)p.nblk_s, (int)p.nblk_ld_s, qc, dim, row_bounds, p.rb, p.ss, n_rows, thr, eps, cand, cnt, fs.group_max ? 16 : 128, p.cap);
       LRX_LAUNCH_CHECK();
-      if (fs.fused != nullptr) {
+      if (fs.fused != nullptr && (fa.phases & 4)) {
         rc = LRX_OK;                                            // sample, selection and main pass are done
       } else if (p.gemm) {
         __bf16* q16 = (__bf16*)(ws + p.off_q16);
@@ -2822,7 +2895,7 @@ extern "C" int lrx_flat_ip_bounded_list_counts(const void* workspace, int64_t n_
                                                int32_t has_shadow, uint32_t* counts_out, void* stream) {
   const bool shadow = has_shadow && dim % 64 == 0;
   LRX_CHECK_ARG(workspace && counts_out && n_queries > 0 && n_queries <= (shadow ? 256 : 128), "bounded_list_counts: one query chunk only (n_queries=%d)", n_queries);
-  const BoundedPlan p = plan_chunk(n_rows, dim, n_queries, k, shadow, flags & 3, search_use_fused());
+  const BoundedPlan p = plan_chunk(n_rows, dim, n_queries, k, shadow, flags & 3, fused_pref_of(flags));
   const int* flg = (const int*)((const char*)workspace + p.off_ints);
   // (the same test lrx_flat_ip_search_bounded_wire uses to send a call down the plain path, which keeps no lists)
   const int qt_max = ((n_queries < 128 ? n_queries : 128) + 15) / 16;
