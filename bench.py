@@ -515,7 +515,20 @@ def per_shard_leg(dev):
         full_ms = full_med = pipe_x = None
     finally:
         os.environ.pop("LRX_FORCE_COLLECTIVE", None)
+    # small query batches on the same shard (a serving loop that does not wait for 100 queries): the fused filter launch (sample + selection + main pass
+    # in one persistent kernel, picked by the rule of lrx_search.hip:plan_chunk up to 32 queries) against the three-launch chain forced by flag
+    from lightretriever_amd import _lib as _l
+    small = {}
+    for Qs in (1, 16, 32):
+        qs_ = torch.nn.functional.normalize(torch.randn(Qs, 2048, generator=g, device=dev), dim=-1)
+        sh.search_flags = _l.SEARCH_FILTER_AUTO
+        f_ms, _ = time_search(lambda: sh.search(qs_, 100), 30)
+        sh.search_flags = _l.SEARCH_FILTER_AUTO | _l.SEARCH_FUSED_NEVER
+        c_ms, _ = time_search(lambda: sh.search(qs_, 100), 30)
+        small["Q%d" % Qs] = {"fused_ms": round(f_ms, 4), "three_launch_chain_ms": round(c_ms, 4), "roofline_frac_fused": hbm_roofline(125_000, 2048, Qs, 100, f_ms)["frac"]}
+    sh.search_flags = _l.SEARCH_FILTER_AUTO
     out = {
+        "small_batches": small,
         "workload": "what ONE rank of an 8-GPU run of the headline search does: exact top-100 of 100 queries over its 125 000 x 2048 shard (the wire "
                     "words written by the search's own last kernel) -> all-gather of [Q,k] words -> lrx_merge_topk_packed", "local_search_ms": round(local_ms, 4),
         "local_search_ms_median": round(local_med, 4), "with_exchange_ms": None if full_ms is None else round(full_ms, 4),

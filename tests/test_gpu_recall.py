@@ -35,7 +35,7 @@ def test_retrieved_sets_agree_with_the_fp32_reference_at_least_as_well_as_hf_bf1
     assert rec["stream"] == "precise_fp32"                                  # the default mode, the one bench.py times
     assert rec["doc_lrx_vs_fp32_max_1mcos"] <= 1e-3, rec                    # every one of the 20 000 documents within 1e-3 cosine
     assert rec["q_dense_lrx_vs_fp32_max_1mcos"] <= 1e-3 and rec["q_emb_lrx_vs_fp32_max_1mcos"] <= 1e-3, rec
-    for kind in ("emb", "dense"):
+    for kind in ("emb", "dense", "emb_mrl", "dense_mrl"):                   # full width and the MRL-256 slice (BASELINE configs[4])
         a, b = rec[kind]["lrx_vs_fp32"], rec[kind]["hfbf16_vs_fp32"]
         assert a["overlap_at_100"] >= b["overlap_at_100"], (kind, a, b)
         assert a["top10_same_position"] >= b["top10_same_position"], (kind, a, b)
@@ -43,5 +43,5 @@ def test_retrieved_sets_agree_with_the_fp32_reference_at_least_as_well_as_hf_bf1
         assert a["top1"] >= b["top1"] - 1e-9, (kind, a, b)
         # absolute floors (measured, profiles/r05_recall.jsonl: overlap@100 0.975 / 0.968, overlap@10 0.981 / 0.967, top-1 0.93 / 0.96 for emb / dense on a
         # corpus whose 100th and 101st fp32 scores are 7e-5 apart -- HF bf16 reaches 0.92 / 0.92, 0.94 / 0.91, 0.74 / 0.89 there)
-        if n_docs >= 20000:
+        if n_docs >= 20000 and not kind.endswith("_mrl"):
             assert a["overlap_at_100"] >= 0.95 and a["overlap_at_10"] >= 0.94 and a["top1"] >= 0.88, (kind, a)

@@ -118,7 +118,7 @@ def agreement(I_a, I_ref):
             "top1": float((a[:, 0] == r[:, 0]).mean())}
 
 
-def measure(preset="llama32_1b", n_docs=20000, n_queries=200, seed=0, profile="trained_like", k=100, sub_vocab=4096, prompt_len=20, log=print) -> dict:
+def measure(preset="llama32_1b", n_docs=20000, n_queries=200, seed=0, profile="trained_like", k=100, sub_vocab=4096, prompt_len=20, mrl_dim=256, log=print) -> dict:
     from lightretriever_amd import EncoderConfig, FlatIPIndex, LrxEncoder, ops
     from lightretriever_amd.synth import sink_token
     cfg = getattr(EncoderConfig, preset)()
@@ -154,6 +154,13 @@ def measure(preset="llama32_1b", n_docs=20000, n_queries=200, seed=0, profile="t
     q_den_lrx = lrx_encode(enc, queries, prefix=prefix, suffix=[eos])
     hits = {"lrx": {"emb": idx.search(q_emb_lrx, k)[1].clone(), "dense": idx.search(q_den_lrx, k)[1].clone()}}
     X_lrx = idx.vectors.clone()
+
+    def mrl(x):                                   # dense_shrink_dim: slice, then normalise (modeling_hybrid.py:274-277, :487-490)
+        return torch.nn.functional.normalize(x[:, :mrl_dim].float(), dim=-1).contiguous()
+    # BASELINE configs[4]: MRL-256 embeddings -- the first 256 dims of the un-normalised pooled state, renormalised; slicing the normalised rows and
+    # renormalising is the same vector.  (lrx: the kernel's own out_dim path is held to this by tests/test_gpu_encoder.py.)
+    hits["lrx"]["emb_mrl"] = search(mrl(X_lrx), mrl(q_emb_lrx))[1]
+    hits["lrx"]["dense_mrl"] = search(mrl(X_lrx), mrl(q_den_lrx))[1]
     torch.cuda.synchronize()
     rec["lrx_seconds"] = round(time.time() - t0, 2)
     sd = enc.hf_state_dict()
@@ -173,7 +180,8 @@ def measure(preset="llama32_1b", n_docs=20000, n_queries=200, seed=0, profile="t
         table = hf_encode(hf, vocab, prefix=prefix, suffix=[eos], normalize=False)
         q_emb = bag_queries(table, queries, lo)
         q_den = hf_encode(hf, queries, prefix=prefix, suffix=[eos])
-        hits[name] = {"emb": search(X[name], q_emb)[1], "dense": search(X[name], q_den)[1]}
+        hits[name] = {"emb": search(X[name], q_emb)[1], "dense": search(X[name], q_den)[1],
+                      "emb_mrl": search(mrl(X[name]), mrl(q_emb))[1], "dense_mrl": search(mrl(X[name]), mrl(q_den))[1]}
         if name == "hf_fp32":
             # how hard the ranking problem is: the fp32 pipeline's score gap between its hits k and k + 1, and between hits 10 and 11
             for kind, qq in (("emb", q_emb), ("dense", q_den)):
@@ -193,7 +201,8 @@ def measure(preset="llama32_1b", n_docs=20000, n_queries=200, seed=0, profile="t
     torch.cuda.empty_cache()
     rec["doc_lrx_vs_fp32_max_1mcos"] = float((1 - (X_lrx.double() * X["hf_fp32"].double()).sum(-1)).max())
     rec["doc_hfbf16_vs_fp32_max_1mcos"] = float((1 - (X["hf_bf16"].double() * X["hf_fp32"].double()).sum(-1)).max())
-    for kind in ("emb", "dense"):
+    rec["mrl_dim"] = mrl_dim
+    for kind in ("emb", "dense", "emb_mrl", "dense_mrl"):
         rec[kind] = {"lrx_vs_fp32": agreement(hits["lrx"][kind], hits["hf_fp32"][kind]),
                      "hfbf16_vs_fp32": agreement(hits["hf_bf16"][kind], hits["hf_fp32"][kind]),
                      "lrx_vs_hfbf16": agreement(hits["lrx"][kind], hits["hf_bf16"][kind])}
