@@ -3,7 +3,7 @@ children are started before anything in this pytest process has touched a GPU (`
 
   * on ANY GPU box: the worker script (tests/dist_workers/rccl_cases.py) under `torch.distributed.run --nproc-per-node 1` with the exchange
     forced -- the same code, one RCCL rank: proves the script and the launch shape;
-  * gated on `torch.cuda.device_count() >= 2`: the same script with R = 2, 4, 8 ranks as available -- ShardedFlatIPIndex.search over RCCL ==
+  * gated on `torch.cuda.device_count() >= 2`: the same script with R = 2 and 4 ranks as available -- ShardedFlatIPIndex.search over RCCL ==
     one index bit for bit (k = 100 and 1000, a row count no R divides, contiguous and interleaved shards, a duplicate pair across shards),
     pipeline.SearchLanes over the communicator, HybridSearch.search over RCCL ranks == single process -- and `bench.py --gpus R`, whose
     line must report `rccl_ranks == R` and the per-rank shard sizes.
@@ -37,18 +37,31 @@ def _env():
     return env
 
 
-def _run_ranks(n_ranks, cases, timeout=900):
+def _run(cmd, timeout):
+    """child in its own process group; on a timeout the whole group (launcher + ranks) is killed by its group id -- never by pattern"""
+    import signal
+    p = subprocess.Popen(cmd, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        pytest.fail("timed out after %d s: %s\n%s\n%s" % (timeout, " ".join(cmd[-6:]), out[-2000:], err[-4000:]))
+    return p.returncode, out, err
+
+
+def _run_ranks(n_ranks, cases, timeout=420):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), WORKER, cases]
-    out = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=timeout)
-    assert out.returncode == 0, "rank failure (rc %d)\n%s\n%s" % (out.returncode, out.stdout[-3000:], out.stderr[-6000:])
-    assert "RCCL_ALL_OK ranks=%d" % n_ranks in out.stdout, out.stdout[-3000:]
-    return [l for l in out.stdout.splitlines() if l.startswith("RCCL_CASE_OK")]
+    rc, out, err = _run(cmd, timeout)
+    assert rc == 0, "rank failure (rc %d)\n%s\n%s" % (rc, out[-3000:], err[-6000:])
+    assert "RCCL_ALL_OK ranks=%d" % n_ranks in out, out[-3000:]
+    return [l for l in out.splitlines() if l.startswith("RCCL_CASE_OK")]
 
 
 def _ranks_available():
     n = torch.cuda.device_count()                    # (no GPU initialisation on this image)
-    return [r for r in (2, 4, 8) if r <= n]
+    return [r for r in (2, 4) if r <= n]             # (at most 4 ranks: the GPU boxes allow few processes on the cards at once; 8 is the driver's bench)
 
 
 def test_worker_script_with_one_rccl_rank_and_the_exchange_forced():
@@ -58,7 +71,7 @@ def test_worker_script_with_one_rccl_rank_and_the_exchange_forced():
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL ranks on distinct devices)")
-@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+@pytest.mark.parametrize("n_ranks", [2, 4])
 def test_sharded_search_lanes_and_hybrid_search_over_rccl_ranks(n_ranks):
     if n_ranks not in _ranks_available():
         pytest.skip("only %d GPU(s) visible" % torch.cuda.device_count())
@@ -71,10 +84,10 @@ def test_sharded_search_lanes_and_hybrid_search_over_rccl_ranks(n_ranks):
 def test_bench_line_reports_the_rccl_ranks_and_the_shard_sizes():
     n_ranks = max(_ranks_available())
     rows = 1_000_003                                 # no R divides it: the remainder rows go one each to the first ranks
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--legs", "encode,search",
-                          "--index-rows", str(rows)], env=_env(), capture_output=True, text=True, timeout=1200)
-    assert out.returncode == 0, out.stderr[-6000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    rc, out, err = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--legs", "encode,search",
+                         "--index-rows", str(rows)], 600)
+    assert rc == 0, err[-6000:]
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == n_ranks and line["rccl_ranks"] == n_ranks and line["config"]["parallelism"] == "dp%d" % n_ranks
     s = line["search"]
     assert s["rccl_ranks"] == n_ranks and len(s["shard_rows_per_rank"]) == n_ranks and sum(s["shard_rows_per_rank"]) == rows
