@@ -168,8 +168,8 @@ def cpu_baseline(cfg, seq_len, topk, dim):
     }
 
 
-PMC_SUMMARY = os.environ.get("LRX_PMC_SUMMARY", "profiles/r04_pmc_summary.json")   # offline rocprofv3 --pmc passes (tools/pmc_traffic.sh)
-PMC_MFMA = os.environ.get("LRX_PMC_MFMA", "profiles/r04_pmc_mfma.json")
+PMC_SUMMARY = os.environ.get("LRX_PMC_SUMMARY", "profiles/r05_pmc_summary.json")   # offline rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+PMC_MFMA = os.environ.get("LRX_PMC_MFMA", "profiles/r05_pmc_mfma.json")
 
 
 def git_blob_sha(rel_path):
@@ -516,7 +516,7 @@ def per_shard_leg(dev):
     finally:
         os.environ.pop("LRX_FORCE_COLLECTIVE", None)
     # small query batches on the same shard (a serving loop that does not wait for 100 queries): the fused filter launch (sample + selection + main pass
-    # in one persistent kernel, picked by the rule of lrx_search.hip:plan_chunk up to 32 queries) against the three-launch chain forced by flag
+    # in one persistent kernel, picked by the rule of lrx_search.hip:plan_chunk up to 16 queries) against the three-launch chain forced by flag
     from lightretriever_amd import _lib as _l
     small = {}
     for Qs in (1, 16, 32):

@@ -363,7 +363,7 @@ enum {
   LRX_SEARCH_FILTER_SCORE_FREE = 2,      /* the score-free (candidate-list) filter whenever the shard is large enough for a sample   */
   LRX_SEARCH_FILTER_SCORE_FREE_NO_GEMM = 3, /* like 2, but chunks of 129..256 queries never take the GEMM kernel for the main pass   */
   /* (ABI 6) OR-ed onto one of the above: the FUSED launch of the score-free filter -- sample pass, threshold selection and main pass in one
-   * persistent kernel, for chunks of <= 128 queries over a shadow with dim % 256 == 0 -- is chosen by a measured rule (<= 32 queries, dim >= 512,
+   * persistent kernel, for chunks of <= 128 queries over a shadow with dim % 256 == 0 -- is chosen by a measured rule (<= 16 queries, dim >= 512,
    * k <= 256, <= 8 blocks of 128 rows per CU: small query batches over a per-rank shard); these two bits force it on wherever it is eligible, or off */
   LRX_SEARCH_FUSED_ALWAYS = 4,
   LRX_SEARCH_FUSED_NEVER = 8

@@ -2661,9 +2661,10 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   // Where it pays (profiles/r05_fused_ab.txt, same box, fused / chain): 125 k x 2048, k = 100: 0.91 / 0.97 / 0.96 at Q = 1 / 16 / 32 but 1.03 / 1.15 at
   // 64 / 100 -- with seven query tiles ONE block per workgroup is bound by its LDS fragment reads and MFMA issue (36 us against 22 us for a block
   // of the two-at-a-time main pass: profiles/r05_fused_timeline.txt), and every selection waits for the slowest sample block; 250 k rows 0.97-0.99
-  // up to Q = 32; 1M x 2048 and 1M x 4096 1.00-1.03; D = 256 (q resident, no per-step barrier) 1.07-1.22; k = 1000 1.08-1.20.  Hence the rule:
-  // at most 32 queries, D >= 512, k <= 256, at most 8 blocks per CU.  LRX_SEARCH_FUSED=1 lifts the rule (not the eligibility).
-  const bool fused_rule = nq <= 32 && dim >= 512 && k <= 256 && nwg <= 8 * (int64_t)lrx_cu_count();
+  // up to Q = 32; 1M x 2048 and 1M x 4096 1.00-1.03; D = 256 (q resident, no per-step barrier) 1.07-1.22; k = 1000 1.08-1.20.  Hence the rule
+  // (Q = 32 is a tie: 0.149 / 0.155 in separate processes, 0.131 / 0.130 back to back inside bench.py, so the rule stops at one query tile):
+  // at most 16 queries, D >= 512, k <= 256, at most 8 blocks per CU.  LRX_SEARCH_FUSED=1 lifts the rule (not the eligibility).
+  const bool fused_rule = nq <= 16 && dim >= 512 && k <= 256 && nwg <= 8 * (int64_t)lrx_cu_count();
   const bool fused_ok = fused_pref != 0 && (fused_rule || fused_pref == 1) && shadow && !p.gemm && nq <= 128 && dim % 256 == 0 && n_rows < (1ll << 31) - 256;
   if (fused_ok && !ss_force) {
     int lim = ss_hits < ss_list ? ss_hits : ss_list;

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_mfma${PMC_TAG:-}
 mkdir -p $OUT
 cd /tmp
-timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -o a -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-search --no-sparse > $OUT/a.log 2>&1 || echo "pass failed"
+timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -o a -- python3 $R/bench.py --steps 2 --warmup 1 --legs encode > $OUT/a.log 2>&1 || echo "pass failed"
 python3 - <<PY
 import csv, glob, collections, json
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -16,13 +16,13 @@ for f in glob.glob("$OUT/a/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         key = None
-        for k in ("k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_attn_resident64", "k_attn_varlen_causal"):
+        for k in ("k_gemm_bf16_nt<6>", "k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_attn_resident64", "k_attn_varlen_causal"):
             if k in n: key = k
         if key: cnt[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob("$OUT/a/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        for k in ("k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_attn_resident64", "k_attn_varlen_causal"):
+        for k in ("k_gemm_bf16_nt<6>", "k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_attn_resident64", "k_attn_varlen_causal"):
             if k in n: dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
 out = {}
 for k, c in cnt.items():
