@@ -621,3 +621,57 @@ def test_trace_checker_counts_foreign_kernels_between_the_markers(tmp_path):
     assert trace(late).returncode == 1
     assert trace(clean[:4] + chain * 2 + clean[-2:]).returncode == 1      # too few searches
     assert trace([n for n in clean if "marker" not in n]).returncode == 2  # no markers
+
+
+def test_encode_queries_routes_vector_types_without_a_gpu(tok):
+    """Round 5: LrxExactSearchModel.encode_queries picks the collator outputs and the result keys from the model's flags (the reference's
+    rule, finetune/modeling_hybrid.py:362-366 + inference/exact_search_torchrpc.py:139-170); checked with a stand-in B3 operator on the CPU."""
+    from lightretriever_amd.modeling import LrxExactSearchModel
+
+    class FakeHybrid:
+        def __init__(self, dense, emb, nonctx, sparse=False):
+            self.hybrid_use_dense_vector, self.hybrid_use_emb_vector, self.noncontextual_query_embedding = dense, emb, nonctx
+            self.encode_sparse, self.emb_bag, self.emb_bag_prompt, self.seen = sparse, None, None, []
+
+        def construct_embedding_bag(self, tokenizer, prompt=None, batch_size=0):
+            self.emb_bag, self.emb_bag_prompt = torch.zeros(len(tokenizer), 4), prompt
+
+        def encode_query(self, batch):
+            self.seen.append(sorted(batch))
+            out = {}
+            if self.hybrid_use_dense_vector:
+                out["dense_reps"] = (batch["cu_seqlens"][1:] - batch["cu_seqlens"][:-1]).float()[:, None]        # = the sequence lengths
+            if self.hybrid_use_emb_vector:
+                n = batch["nonctx_tok_emb_offsets"].numel() if self.noncontextual_query_embedding else batch["cu_seqlens"].numel() - 1
+                out["emb_reps"] = torch.full((n, 1), 7.0)
+            return out
+
+    qs = ["capital of france", "a", "dense retrieval with large language models"]
+    # symmetric dense: LM inputs only, the prompt is part of the tokens, no table is built
+    hm = FakeHybrid(True, False, False)
+    m = LrxExactSearchModel(model=hm, tokenizer=tok, q_max_len=16, p_max_len=32)
+    m.query_prompt = "query: "
+    r = m.encode_queries(qs, batch_size=2)
+    assert set(r) == {"dense_reps"} and r["dense_reps"].shape == (3, 1) and hm.emb_bag is None
+    assert hm.seen == [["cu_seqlens", "input_ids", "max_seqlen"]] * 2
+    want = [min(16, len(tok("query: " + q, add_special_tokens=True)["input_ids"])) for q in qs]
+    assert r["dense_reps"][:, 0].tolist() == [float(x) for x in want]
+    assert LrxExactSearchModel(model=hm, tokenizer=tok, q_max_len=16, single_tensor_output=True).encode_queries(qs, batch_size=8).shape == (3, 1)
+    # both vectors (the released checkpoints' flags): one batch dict carries LM inputs and bag inputs; the table is built with the prompt
+    hm = FakeHybrid(True, True, True, sparse=True)
+    m = LrxExactSearchModel(model=hm, tokenizer=tok, q_max_len=16)
+    m.query_prompt = "query: "
+    r = m.encode_queries(qs, batch_size=8)
+    assert set(r) == {"dense_reps", "emb_reps", "token_id_reps"} and hm.emb_bag_prompt == "query: "
+    assert hm.seen == [["cu_seqlens", "input_ids", "max_seqlen", "nonctx_tok_emb_input_ids", "nonctx_tok_emb_offsets"]]
+    assert len(r["token_id_reps"]) == 3 and all(isinstance(d, dict) for d in r["token_id_reps"])
+    # the input-embedding ablation: LM inputs, no table; asymmetric only: bag inputs only
+    hm = FakeHybrid(False, True, False)
+    assert set(LrxExactSearchModel(model=hm, tokenizer=tok, q_max_len=16).encode_queries(qs, batch_size=8)) == {"emb_reps"} and hm.emb_bag is None
+    assert hm.seen == [["cu_seqlens", "input_ids", "max_seqlen"]]
+    hm = FakeHybrid(False, True, True)
+    assert set(LrxExactSearchModel(model=hm, tokenizer=tok, q_max_len=16).encode_queries(qs, batch_size=8)) == {"emb_reps"}
+    assert hm.seen == [["nonctx_tok_emb_input_ids", "nonctx_tok_emb_offsets"]]
+    # token-id-only model: nothing goes through the operator
+    hm = FakeHybrid(False, False, False, sparse=True)
+    assert set(LrxExactSearchModel(model=hm, tokenizer=tok, q_max_len=16).encode_queries(qs, batch_size=8)) == {"token_id_reps"} and hm.seen == []
