@@ -192,6 +192,12 @@ def test_bench_with_a_forced_one_rank_rccl_group_matches_the_plain_run():
         assert s["rccl_ranks"] == 1 and s["shard_rows_per_rank"] == [1_000_000] and s["shard_rows"] == 1_000_000 and s["index_rows"] == 1_000_000
         assert s["scaling"].startswith("strong") and s["passes"] == 20
         assert line["config"]["parallelism"] == "dp1" and line["config"]["global_batch"] == 256
+        # round 5: the timed mode is the library default (fp32 residual stream) and says so; the queries/sec half of the metric is carried as scalars at
+        # the top level, inside `config` / `roofline`, and in `headline` -- the last key of the line
+        assert line["config"]["stream_mode"].startswith("fp32-stream") and "fp32-stream" in line["config"]["workload"]
+        assert line["search_qps"] == s["value"] == line["config"]["search_qps"] == line["headline"]["search_qps"] and list(line)[-1] == "headline"
+        assert line["search_roofline_frac"] == s["roofline"]["frac"] == line["roofline"]["search_frac"] and line["search_alg_bytes"] == s["roofline"]["algorithmic_bytes"]
+        assert line["headline"]["docs_per_s"] == line["value"] and line["headline"]["stream_mode"] == line["config"]["stream_mode"]
     assert abs(forced["value"] / plain["value"] - 1) < 0.03, (forced["value"], plain["value"])
     assert forced["search"]["value"] > 0.85 * plain["search"]["value"], (forced["search"]["value"], plain["search"]["value"])
     print("bench N=1 plain %.1f docs/s, %.0f q/s; forced 1-rank RCCL group %.1f docs/s, %.0f q/s" % (
