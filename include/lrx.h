@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define LRX_ABI_VERSION 6
+#define LRX_ABI_VERSION 7
 
 enum {
   LRX_OK = 0,
@@ -219,6 +219,27 @@ int lrx_build_positions(const int32_t* cu_seqlens, int32_t n_seqs, int32_t total
 int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens,
                            int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
                            void* out, int32_t last_tile_only, void* stream);
+
+/* The same attention on a prebuilt WORK LIST (ABI 7): which (sequence, kv head, q tile) each persistent workgroup computes, and in which
+ * order, depends on cu_seqlens and the head layout only, so the encoder builds it once per batch and every layer's launch reads it
+ * (lrx_encode_* do this inside their workspace).  Results are bit-identical to lrx_attn_varlen_causal; the launch is ~10 % shorter on
+ * the tiled path (head_dim 128, or head_dim 64 beyond 512 tokens: no per-item index arithmetic).
+ *   lrx_attn_items_bytes   size of the list; bounded by (total_tokens / 64 + n_seqs) x kv heads and non-decreasing in total_tokens and
+ *                          max_seqlen (size once with the largest batch / longest sequence the caller will ever pass)
+ *   lrx_attn_build_items   fills `items` (device memory, 16-byte aligned) on `stream`; one list per (cu_seqlens, max_seqlen, head
+ *                          layout, last_tile_only) -- a list built with other arguments than the launch's gives wrong results
+ *   lrx_attn_varlen_causal_items   the launch (lrx_attn_varlen_causal's arguments + the list); `items` must stay untouched until it has
+ *                          run.  Geometries served by the K/V-resident kernel (head_dim 64, max_seqlen <= 512) do not read the list.          */
+size_t lrx_attn_items_bytes(int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads,
+                            int32_t head_dim, int32_t last_tile_only);
+int lrx_attn_build_items(const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads,
+                         int32_t num_kv_heads, int32_t head_dim, int32_t last_tile_only, void* items, size_t items_bytes, void* stream);
+int lrx_attn_varlen_causal_items(const void* qkv, const int32_t* cu_seqlens, const void* items, size_t items_bytes, int32_t n_seqs,
+                                 int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                 void* out, int32_t last_tile_only, void* stream);
+/* Diagnostics: how many list builds (since the library was loaded) found their buffer too small -- 0 as long as the buffers come from
+ * lrx_attn_items_bytes; such a build leaves an empty list (the launch then computes nothing).  Synchronises the device.                    */
+int lrx_debug_attn_items_overflow(int32_t* count);
 
 /* Attention of suffix queries over a shared prefix: qkv [n_seqs*suffix_len, (nq+2nkv)*d] (RoPE applied), prefix_kv
  * [prefix_len, 2*nkv*d] (k block | v block of one layer, RoPE applied); query j of a sequence sees the prefix keys and its own

@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRX_LIB_DEV_VARIANT") or os.path.join(HERE, "liblrx.so")   # env override: tools/ diagnostics only
 LRX_PROF_CLASSES = 8
-ABI_VERSION = 6   # LRX_ABI_VERSION of include/lrx.h
+ABI_VERSION = 7   # LRX_ABI_VERSION of include/lrx.h
 # lrx_flat_ip_search_bounded flags (LRX_SEARCH_FILTER_*): A/B runs and tests; the hits do not depend on them
 SEARCH_FILTER_AUTO, SEARCH_FILTER_MATRIX, SEARCH_FILTER_SCORE_FREE, SEARCH_FILTER_SCORE_FREE_NO_GEMM = 0, 1, 2, 3
 SEARCH_FUSED_ALWAYS, SEARCH_FUSED_NEVER = 4, 8       # OR-ed on: the fused filter launch wherever eligible / never (default: a measured rule)
@@ -81,6 +81,10 @@ SIGNATURES = {
     "lrx_gemm_qkv_rope": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "lrx_build_positions": (_I32, [_P, _I32, _I32, _P, _P]),
     "lrx_attn_varlen_causal": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "lrx_attn_items_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "lrx_attn_build_items": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _SZ, _P]),
+    "lrx_attn_varlen_causal_items": (_I32, [_P, _P, _P, _SZ, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "lrx_debug_attn_items_overflow": (_I32, [_P]),
     "lrx_gather_last_rows": (_I32, [_P, _P, _I32, _I32, _P, _P]),
     "lrx_probe_fused_timestamps": (_I32, [_P, _I32]),
     "lrx_scatter_last_rows": (_I32, [_P, _P, _I32, _I32, _P, _I64, _P]),

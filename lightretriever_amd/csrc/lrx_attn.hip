@@ -15,6 +15,7 @@
 // conflict-free ds_read_b128 row reads, the V image for conflict-free transposed reads (swizzle applied on the
 // per-lane source address, undone on the read).
 #include "lrx_common.h"
+#include <type_traits>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -407,6 +408,424 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
     for (int j = 0; j < QINST; ++j) {
       const int s_ = j * 64 + ln;
       const int row = s_ / G::CH, ch = s_ % G::CH;
+      __builtin_amdgcn_raw_buffer_store_b128(ov[j], orsrc, ((q0 + row) * nq + hq) * (D * 2) + ch * 16, 0, 0);
+    }
+  }
+  ic = inext;
+  }  // items
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: the same tile arithmetic on a PREBUILT work list, with buffer addressing (lrx_attn_varlen_causal_items; 1.10 -> 1.00 ms at
+// 256 x 512 tokens, 32 / 8 heads, d = 128, bit-identical output: profiles/r05_attn_rework.txt).
+//
+// tools/exp/attn_trace_tiled.py on the kernel above: a 64-key tile step = 0.58 us of REQUESTING the next tile + 1.6 compute + 0.75
+// barrier + 0.28 loop, and an item paid another 3.7 us around its steps -- 1.5 of them in the item walker (runtime integer divisions for
+// (sequence, kv head, part, q tile), two dependent scalar loads of cu[], once per walker) and the per-lane 64-bit source addresses of
+// 4 + 8 LDS-DMA instructions (row clamp, multiply by the row stride, swizzle): VALU work that the two waves of a SIMD pay for one after
+// the other.  PMC (tools/pmc_attn.sh): 202 VALU instructions per 32 x 32 sub-tile against 16 MFMAs, VALU issue 50 % + MFMA 32 % of the
+// SIMD cycles at an effective 1.65 GHz -- the kernel is bound by what it issues, so this one issues less:
+//   * the items of every workgroup are written once per (cu_seqlens, geometry) by k_attn_build_items as 16-byte records; the stream and
+//     the compute side fetch them with one s_load_dwordx4 each, one item ahead of use;
+//   * K, V and Q rows are fetched with buffer_load_dwordx4 ... lds through a descriptor whose base is the tile's first row and whose
+//     num_records ends at the sequence's last row: rows past the end are dropped by the range check (no clamp), the per-lane offsets
+//     (row * stride + swizzled chunk) are kernel constants, the kv-head column goes into the scalar offset: a tile request is a
+//     descriptor update on the SALU plus the load instructions;
+//   * the LDS addresses of the 24 fragment reads of a sub-tile are kernel constants plus the ring-stage base, sub-tile / half / k-step
+//     offsets ride in the instructions' immediate fields (48 of the 202 were v_xor + v_add pairs in front of those reads);
+//   * the output addresses are recomputed from the hardware lane counter inside the item epilogue: nothing lane-derived is live across
+//     the tile loop, hipcc spills nothing (a reload there waits, with its vmcnt(0), for the tile requests in flight).
+// LDS is zero-filled once per workgroup: a dropped row leaves its ring bytes alone, and P = 0 times a stale NaN would poison O.
+// ---------------------------------------------------------------------------------------------------------------
+// (a free __device__ function: called from a lambda of the kernel, the host pass of hipcc drops the whole kernel stub without a diagnostic)
+__device__ __forceinline__ void attn_buf_load_lds16(__amdgpu_buffer_rsrc_t rs, lptr_t dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
+}
+typedef __attribute__((ext_vector_type(4))) int i32x4;   // one item: {first token, length, q tile | part << 16, kv head}; length 0 ends a workgroup's list
+// The work list: int32 list_start[n_wg + 1] (padded to a multiple of 4 entries), then the workgroups' item lists back to back, each ended by a
+// zero item.  Only items that exist are stored (q tiles past a sequence's end are dropped here), so the list is bounded by
+// (total_tokens / 64 + n_seqs) x kv heads x parts + one end marker per workgroup -- known from the batch size alone.
+// One block, one thread per workgroup: count its items (the walker of k_attn_varlen_causal), scan, walk again and store.
+
+__global__ void __launch_bounds__(1024)
+k_attn_build_items(const int32_t* __restrict__ cu, int32_t* __restrict__ list_start, i32x4* __restrict__ items, int cap_items, int n_wg, int nqt, int nkv,
+                   int nparts, int n_seqs, int n_items, int gs, int last_tile_only, int* __restrict__ overflow) {
+  __shared__ int s_scan[1024];
+  const int b = threadIdx.x;
+  const int ny = nkv * nparts, n_pairs = n_seqs * ny;
+  const int xcd = b & 7, slot = b >> 3;
+  const int g4 = gs > 0 ? slot / gs : 0, jslot = gs > 0 ? slot % gs : 0, gpx = gs > 0 ? (n_wg >> 3) / gs : 1;
+  auto walk = [&](i32x4* dst) -> int {          // dst == nullptr: count only
+    int n = 0;
+    auto emit = [&](int pair, int qt_sel) {
+      const int sq = pair / ny;
+      const int s0 = cu[sq], len = cu[sq + 1] - s0;
+      const int qt = last_tile_only ? ((len - 1) >> 6) : qt_sel;      // last_tile_only: the q tile holding the sequence's last token
+      if (len <= 0 || qt * 64 >= len) return;
+      if (dst) {
+        const int yy = pair - sq * ny, hk = yy / nparts, part = yy - hk * nparts;
+        dst[n] = i32x4{s0, len, qt | (part << 16), hk};
+      }
+      ++n;
+    };
+    if (gs > 0) {
+      // (the order is explained at k_attn_varlen_causal: the q tiles of one (sequence, kv head) on `gs` workgroups of one XCD; slot j of a
+      // group takes q tiles j, j + gs, ... from the long end on even steps and from the short end on odd ones)
+      for (int step = 0;; ++step) {
+        const int v = step * gpx + g4;
+        if ((v / nparts) * 8 >= n_pairs / nparts) break;
+        const int pair = ((v / nparts) * 8 + xcd) * nparts + v % nparts;
+        if (pair >= n_pairs) continue;
+        for (int idx = jslot; idx < nqt; idx += gs) emit(pair, (step & 1) ? idx : nqt - 1 - idx);
+      }
+    } else {
+      for (int item = b; item < n_items; item += n_wg)
+        emit(last_tile_only ? item : item % n_pairs, last_tile_only ? 0 : nqt - 1 - item / n_pairs);
+    }
+    return n;
+  };
+  const int mine = b < n_wg ? walk(nullptr) + 1 : 0;            // + the end marker
+  s_scan[b] = mine;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                          // inclusive scan (n_wg <= 1024)
+    const int v = b >= o ? s_scan[b - o] : 0;
+    __syncthreads();
+    s_scan[b] += v;
+    __syncthreads();
+  }
+  if (b >= n_wg) return;
+  const int start = s_scan[b] - mine;
+  list_start[b] = start;
+  if (b == n_wg - 1) list_start[n_wg] = s_scan[b];
+  if (s_scan[n_wg - 1] + 2 > cap_items) {                        // (cannot happen: lrx_attn_items_bytes bounds the same walk)
+    if (b == 0) atomicAdd(overflow, 1);
+    if (start < cap_items) items[start] = i32x4{0, 0, 0, 0};
+    return;
+  }
+  const int n = walk(items + start);
+  items[start + n] = i32x4{0, 0, 0, 0};
+  if (b == n_wg - 1) { items[start + n + 1] = i32x4{0, 0, 0, 0}; items[start + n + 2] = i32x4{0, 0, 0, 0}; }   // padding behind the last end marker
+}
+
+template <int D, int GRP>
+__global__ void __launch_bounds__(128 * GRP)
+k_attn_stream(const __bf16* __restrict__ qkv, const int32_t* __restrict__ list_start, const i32x4* __restrict__ items, int nq, int nkv,
+              __bf16* __restrict__ out, float scale_log2) {
+  using G = AttnGeom<D>;
+  constexpr int NW = 2 * GRP;
+  constexpr int KS = D / 16, DT = D / 32;
+  constexpr int DW = attn_dma_waves(G::INSTS, NW);
+  constexpr int NST = 3;
+  constexpr int PER_TILE = 2 * (G::INSTS / DW);
+  constexpr int QO_BYTES = 32 * G::ROW_BYTES;
+  constexpr int QINST = QO_BYTES / 1024;
+  constexpr int SMEM = NST * 2 * G::TILE_BYTES + NW * QO_BYTES;
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];  // [stage][K|V] | [wave] Q/O block
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int RSB = (nq + 2 * nkv) * (D * 2);          // bytes per token row of q|k|v
+  const int grp_total = nq / nkv;
+  const i32x4* const lst = items + list_start[blockIdx.x];
+
+  i32x4 ic = lst[0];
+  if (ic[1] == 0) return;
+  for (int i = tid * 16; i < SMEM; i += 128 * GRP * 16) *(u32x4*)(smem + i) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  // ---- per-lane source offsets of the tile rows (instruction j = wave + jj * DW fills LDS bytes [j*1024, j*1024 + 1024): slot s = j*64 + lane,
+  //      row s / CH, chunk position s % CH holding logical chunk cs ^ x(row)) and of the first Q instruction
+  int voffK[G::INSTS / DW], voffV[G::INSTS / DW];
+#pragma unroll
+  for (int jj = 0; jj < G::INSTS / DW; ++jj) {
+    const int s = (wave + jj * DW) * 64 + lane;
+    const int row = s / G::CH, cs = s % G::CH;
+    voffK[jj] = row * RSB + ((cs ^ G::xk(row)) << 4);
+    voffV[jj] = row * RSB + ((cs ^ G::xv(row)) << 4);
+  }
+  const int vq0 = (lane / G::CH) * RSB + (((lane % G::CH) ^ G::xk(lane / G::CH)) << 4);
+
+  auto stage = [&](int st, const i32x4& it, int kt) {
+    if (wave >= DW) return;
+    char* sK = smem + st * (2 * G::TILE_BYTES);
+    char* sV = sK + G::TILE_BYTES;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)qkv + (int64_t)(it[0] + kt * 64) * RSB), 0, (it[1] - kt * 64) * RSB, 0x00020000);
+    const int soK = (nq + it[3]) * (D * 2), soV = soK + nkv * (D * 2);
+#pragma unroll
+    for (int jj = 0; jj < G::INSTS / DW; ++jj) {
+      const int j = wave + jj * DW;
+      attn_buf_load_lds16(rs, (lptr_t)(sK + j * 1024), voffK[jj], soK);
+      attn_buf_load_lds16(rs, (lptr_t)(sV + j * 1024), voffV[jj], soV);
+    }
+  };
+  // prefetch side of the stream: its own cursor over the list, the record after the current one already loaded
+  // prefetch side of the stream: its own index into the list, the item after the current one already loaded (a load past the list's
+  // end marker reads the next workgroup's first item or the builder's padding: never used)
+  int pi = 0;
+  i32x4 ip = ic, ipn = lst[1];
+  int ktp = 0, sp_ = 0;
+  auto stage_next = [&]() -> bool {
+    if (ip[1] == 0) return false;
+    stage(sp_, ip, ktp);
+    sp_ = sp_ == NST - 1 ? 0 : sp_ + 1;
+    if (++ktp > (ip[2] & 0xffff)) { ip = ipn; ++pi; ipn = lst[pi + 1]; ktp = 0; }
+    return true;
+  };
+
+  const int koff0 = r * G::ROW_BYTES + ((h ^ G::xk(r)) << 4);
+  int voff0;
+  {
+    const int g = lane >> 4, i = lane & 15, qd = i >> 2, p = i & 3;
+    voff0 = qd * G::ROW_BYTES + (((2 * (g & 1) + (p >> 1)) ^ G::xv(qd)) << 4) + 8 * (p & 1);
+  }
+
+  // Q block of an item for this wave (rows q0 .. q0 + 31 of its head, K-tile swizzle): instruction j covers rows j*RPI .. + RPI - 1, and
+  // x(j*RPI + row) = x(j*RPI) ^ x(row) for both geometries (the two terms use disjoint bits), so its offsets are vq0 ^ const + const
+  char* const sW = smem + NST * 2 * G::TILE_BYTES + wave * QO_BYTES;
+  auto request_q = [&](const i32x4& it) {
+    constexpr int RPI = G::ROWS_PER_INST;
+    const int qt_ = it[2] & 0xffff, part_ = it[2] >> 16;
+    const int hig = part_ * GRP + (wave % GRP);
+    const int q0_ = qt_ * 64 + (wave / GRP) * 32;
+    if (q0_ >= it[1] || hig >= grp_total) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)qkv + (int64_t)(it[0] + q0_) * RSB), 0, (it[1] - q0_) * RSB, 0x00020000);
+    const int so = (it[3] * grp_total + hig) * (D * 2);
+#pragma unroll
+    for (int j = 0; j < QINST; ++j)
+      attn_buf_load_lds16(rs, (lptr_t)(sW + j * 1024), (vq0 ^ (G::xk(j * RPI) << 4)) + j * RPI * RSB, so);
+  };
+  auto read_q = [&](bf16x8 (&dst)[KS]) {
+    int kb = koff0;
+    asm volatile("" : "+v"(kb));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const bf16x8*)(sW + (kb ^ (ks << 5)));
+  };
+
+  int ci = 0;
+  bf16x8 qf[KS];
+  request_q(ic);
+  const bool t0 = stage_next(), t1 = stage_next();
+  (void)t0;
+  if (t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (DW < NW && wave >= DW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_q(qf);
+  int cur = 0;
+
+  while (ic[1] != 0) {
+  ++ci;
+  const i32x4 inext = lst[ci];
+  const int s0 = ic[0], len = ic[1], qt = ic[2] & 0xffff, part = ic[2] >> 16, hk = ic[3];
+  const int qtile0 = qt * 64;
+  const int head_in_grp = part * GRP + (wave % GRP);
+  const int hq = hk * grp_total + min(head_in_grp, grp_total - 1);
+  const int q0 = qtile0 + (wave / GRP) * 32;
+  const bool active = q0 < len && head_in_grp < grp_total;
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) o[dt][t] = 0.f;
+  float m = -1e30f, l = 0.f;
+
+  // LDS addresses of the fragment reads: the per-lane offsets (swizzle included) are kernel constants, a tile adds its ring-stage base
+  // ONCE (set_tile_base), sub-tile, half and k-step-pair offsets ride in the instructions' immediate fields.  (PMC, tools/pmc_attn.sh: 202
+  // VALU instructions per sub-tile against 16 MFMAs -- VALU issue 50 % + MFMA 32 % of the SIMD cycles, and 48 of the 202 were the
+  // v_xor + v_add pairs in front of the 24 fragment reads.)
+  int kofs[KS], vofs[DT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kofs[ks] = koff0 ^ (ks << 5);
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) vofs[dt] = 4 * h * G::ROW_BYTES + (voff0 ^ (dt << 6));
+  uint32_t ka[KS], va[DT];     // this tile's addresses
+  auto set_tile_base = [&](int st) {
+    const uint32_t kb_ = (uint32_t)(uintptr_t)(lds_char_ptr)(smem + st * (2 * G::TILE_BYTES));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ka[ks] = kb_ + kofs[ks];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) va[dt] = kb_ + G::TILE_BYTES + vofs[dt];
+  };
+  auto qk_product = [&](int u) -> f32x16 {
+    bf16x8 kf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)((lds_char_ptr)(uintptr_t)ka[ks] + u * 32 * G::ROW_BYTES);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // inline-constant C operand
+    f32x16 acc = attn_mfma(kf[0], qf[0], zero);
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) acc = attn_mfma(kf[ks], qf[ks], acc);
+    return acc;
+  };
+  auto xhalf_max = [](float x) -> float {
+    auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(rr[0]), __uint_as_float(rr[1]));
+  };
+  // (the sub-tile arithmetic below is the one documented at k_attn_varlen_causal: V^T fragments by inline-asm transposing reads, lazy
+  // reference maximum, exp2 with the scale folded in, P^T as the B operand of the second product)
+  struct VFrag { s16x4 v[2][DT][2]; };
+  auto read_v = [&](int u, VFrag& f) {
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        if (u == 0) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.v[sp][dt][0]) : "v"(va[dt]), "i"(sp * 16 * G::ROW_BYTES));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.v[sp][dt][1]) : "v"(va[dt]), "i"(sp * 16 * G::ROW_BYTES + 8 * G::ROW_BYTES));
+        } else {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.v[sp][dt][0]) : "v"(va[dt]), "i"(32 * G::ROW_BYTES + sp * 16 * G::ROW_BYTES));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.v[sp][dt][1]) : "v"(va[dt]), "i"(32 * G::ROW_BYTES + sp * 16 * G::ROW_BYTES + 8 * G::ROW_BYTES));
+        }
+      }
+  };
+  auto wait_v = [&](VFrag& f) {
+    if constexpr (DT == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(f.v[0][0][0]), "+v"(f.v[0][0][1]), "+v"(f.v[0][1][0]), "+v"(f.v[0][1][1]), "+v"(f.v[1][0][0]), "+v"(f.v[1][0][1]),
+                     "+v"(f.v[1][1][0]), "+v"(f.v[1][1][1])
+                   :
+                   : "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(f.v[0][0][0]), "+v"(f.v[0][0][1]), "+v"(f.v[0][1][0]), "+v"(f.v[0][1][1]), "+v"(f.v[0][2 % DT][0]), "+v"(f.v[0][2 % DT][1]),
+                     "+v"(f.v[0][3 % DT][0]), "+v"(f.v[0][3 % DT][1]), "+v"(f.v[1][0][0]), "+v"(f.v[1][0][1]), "+v"(f.v[1][1][0]), "+v"(f.v[1][1][1]),
+                     "+v"(f.v[1][2 % DT][0]), "+v"(f.v[1][2 % DT][1]), "+v"(f.v[1][3 % DT][0]), "+v"(f.v[1][3 % DT][1])
+                   :
+                   : "memory");
+    }
+  };
+  auto pv = [&](const VFrag& f, const bf16x8 (&pf)[2]) {
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = f.v[sp][dt][0]; u.s.b = f.v[sp][dt][1];
+        o[dt] = attn_mfma(u.v, pf[sp], o[dt]);
+      }
+  };
+  auto rescale = [&](float alpha) {
+    if (!__all(alpha == 1.0f)) {  // wave-uniform: no q row of this wave raised its running max -> nothing to rescale (exact)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[dt][t] *= alpha;
+    }
+  };
+  // scores -> P^T fragments; returns the factor the O accumulators are due BEFORE this sub-tile's P.V is added
+  auto mask_diag = [&](f32x16& s) {          // causal mask of a sub-tile on the diagonal: reg t holds key (t&3) + 8*(t>>2) + 4h (relative), masked iff that exceeds r
+    const int lim = r - 4 * h;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s[t] = ((t & 3) + 8 * (t >> 2) > lim) ? -1e30f : s[t];
+  };
+  auto softmax = [&](f32x16& s, bf16x8 (&pf)[2]) -> float {
+    float mloc = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+    for (int t = 3; t < 15; t += 2) mloc = fmaxf(fmaxf(mloc, s[t]), s[t + 1]);
+    mloc = xhalf_max(fmaxf(mloc, s[15]));
+    const bool grow = (mloc - m) * scale_log2 > LAZY_T;
+    const float mnew = grow ? mloc : m;
+    const float alpha = grow ? __builtin_amdgcn_exp2f((m - mnew) * scale_log2) : 1.0f;
+    m = mnew;
+    const float mc = -mnew * scale_log2;
+    {
+      const f32x2 c2 = {scale_log2, scale_log2}, m2 = {mc, mc};
+      f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        f32x2 e = f32x2{s[t], s[t + 1]} * c2 + m2;
+        e[0] = __builtin_amdgcn_exp2f(e[0]);
+        e[1] = __builtin_amdgcn_exp2f(e[1]);
+        s[t] = e[0];
+        s[t + 1] = e[1];
+        ps2 += e;
+      }
+      l = l * alpha + (ps2[0] + ps2[1]);
+    }
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) pf[sp][jj] = attn_cvt(s[8 * sp + jj]);
+    return alpha;
+  };
+
+  const int nkt = qt + 1;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt == nkt - 1 && inext[1] != 0) request_q(inext);
+    const bool two = (kt * 64 + 32 <= q0);   // wave-uniform: second sub-tile not entirely above the diagonal
+    const bool more = stage_next();
+    if (active) {
+      // Both QK^T products first, each sub-tile's V^T fragments requested before its softmax.  Measured on this kernel and not kept
+      // (tools/exp/README.md, round 5; 0.978 ms as it stands): the two row halves of a head -- the two waves of a SIMD -- walking the
+      // sub-tiles in different orders so that one's LDS phases meet the other's VALU phases (+4 %); all eight K fragments in registers before
+      // the first MFMA (+2 %); one branch-poor copy of this code in which hipcc does put the first softmax between the MFMAs of the second
+      // QK^T and the second softmax between those of the first P.V (+1.5 %); 64 q rows per wave, one wave per SIMD, O in the accumulation
+      // registers (+25 %).  PMC: VALU issue 50 % + MFMA 32 % of the SIMD cycles at an effective 1.65 GHz -- what pays is fewer instructions.
+      set_tile_base(cur);
+      VFrag vf;
+      bf16x8 pf[2];
+      f32x16 s0_ = qk_product(0);
+      f32x16 s1_;
+      if (two) s1_ = qk_product(1);
+      read_v(0, vf);
+      if (kt * 64 == q0) mask_diag(s0_);
+      rescale(softmax(s0_, pf));
+      wait_v(vf);
+      pv(vf, pf);
+      if (two) {
+        read_v(1, vf);
+        if (kt * 64 + 32 == q0) mask_diag(s1_);
+        rescale(softmax(s1_, pf));
+        wait_v(vf);
+        pv(vf, pf);
+      }
+    }
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cur = cur == NST - 1 ? 0 : cur + 1;
+  }
+  if (DW < NW && wave >= DW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (inext[1] != 0) read_q(qf);
+  if (active) {
+    float ltot;
+    {
+      auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+      ltot = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+    }
+    const float inv = 1.0f / ltot;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the lane id from the hardware counter, behind a volatile zero: every address below is recomputed HERE.  Derived from threadIdx they
+    // are values live across the whole kernel, hipcc (at its 256 VGPRs) spills some, and a reload here comes with a vmcnt(0) that waits
+    // for the tile requests in flight
+    int zero_;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero_));
+    const unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero_));
+    const unsigned r_ = ln & 31, h_ = ln >> 5;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g4_ = 0; g4_ < 4; ++g4_) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g4_ + e] * inv);
+        *(bf16x4*)(sW + r_ * G::ROW_BYTES + ((((dt * 4 + g4_) ^ (r_ & (G::CH - 1))) << 4) | (h_ << 3))) = v;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)s0 * ((int64_t)nq * D)), 0, len * nq * (D * 2), 0x00020000);
+    u32x4 ov[QINST];
+#pragma unroll
+    for (int j = 0; j < QINST; ++j) {
+      const unsigned s_ = j * 64 + ln;
+      const unsigned row = s_ / G::CH, ch = s_ % G::CH;
+      ov[j] = *(const u32x4*)(sW + row * G::ROW_BYTES + ((ch ^ (row & (G::CH - 1))) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < QINST; ++j) {
+      const unsigned s_ = j * 64 + ln;
+      const unsigned row = s_ / G::CH, ch = s_ % G::CH;
       __builtin_amdgcn_raw_buffer_store_b128(ov[j], orsrc, ((q0 + row) * nq + hq) * (D * 2) + ch * 16, 0, 0);
     }
   }
@@ -1034,26 +1453,133 @@ static int launch_attn(const void* qkv, const int32_t* cu, int n_seqs, int max_s
   return LRX_OK;
 }
 
+// ---- the item-list kernel: plan (shared by the list size, the list builder and the launch), builder, launch
+struct AttnPlan { int grp, nparts, nqt, gs, n_wg, slots; int64_t n_items; };
+static AttnPlan attn_plan(int n_seqs, int max_seqlen, int nq, int nkv, int head_dim, int last_tile_only) {
+  AttnPlan p;
+  const int g = nq / nkv;
+  if (head_dim == 64) { p.grp = g <= 8 ? g : 8; p.nparts = g <= 8 ? 1 : (g + 7) / 8; }
+  else if (g <= 4) { p.grp = g; p.nparts = 1; }
+  else if (g <= 6) { p.grp = 3; p.nparts = 2; }
+  else { p.grp = 4; p.nparts = (g + 3) / 4; }
+  p.nqt = (int)lrx_cdiv(max_seqlen, 64);
+  p.n_items = (int64_t)(last_tile_only ? n_seqs : (int64_t)n_seqs * p.nqt) * nkv * p.nparts;
+  const int per_cu = head_dim == 128 ? 1 : (p.grp <= 2 ? 4 : 2);
+  const int64_t slots = (int64_t)attn_cu_count() * per_cu;
+  p.gs = 0;
+  if (!last_tile_only && p.n_items >= slots && slots % 8 == 0) {
+    const int spx = (int)(slots / 8);
+    p.gs = 1;
+    while (p.gs * 2 <= p.nqt && p.gs * 2 <= spx && spx % (p.gs * 2) == 0) p.gs *= 2;
+  }
+  p.n_wg = (int)(p.n_items < slots ? p.n_items : slots);
+  p.slots = (int)slots;
+  return p;
+}
+__device__ int g_attn_items_overflow;
+extern "C" int lrx_debug_attn_items_overflow(int* out) {   // tests: the builder never ran out of list slots (synchronises)
+  LRX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_items_overflow), sizeof(int)));
+  return LRX_OK;
+}
+static int attn_check_layout(int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim) {
+  LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "attn: head_dim=%d unsupported (64 or 128)", head_dim);
+  LRX_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "attn: nq=%d not a multiple of nkv=%d", num_q_heads, num_kv_heads);
+  return LRX_OK;
+}
+// layout of a work list: int32 list_start[hdr] | 16-byte items (k_attn_build_items); the header is sized for the chip's slot count, so the
+// items start at the same offset whatever the batch
+static size_t attn_list_hdr_bytes(const AttnPlan& p) { return (size_t)((p.slots + 1 + 3) & ~3) * 4; }
+static int64_t attn_list_item_bound(const AttnPlan& p, int n_seqs, int total_tokens, int nkv, int last_tile_only) {
+  // every sequence has ceil(len / 64) q tiles: at most total_tokens / 64 + n_seqs over the batch, and at most n_seqs x nqt
+  const int64_t by_tokens = (int64_t)total_tokens / 64 + n_seqs, by_tiles = (int64_t)n_seqs * p.nqt;
+  const int64_t tiles = last_tile_only ? n_seqs : (by_tokens < by_tiles ? by_tokens : by_tiles);
+  return tiles * nkv * p.nparts + p.slots + 3;      // + an end marker per workgroup + padding
+}
+extern "C" size_t lrx_attn_items_bytes(int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads,
+                                       int32_t head_dim, int32_t last_tile_only) {
+  if (n_seqs <= 0 || max_seqlen <= 0 || total_tokens <= 0 || attn_check_layout(num_q_heads, num_kv_heads, head_dim) != LRX_OK) return 0;
+  const AttnPlan p = attn_plan(n_seqs, max_seqlen, num_q_heads, num_kv_heads, head_dim, last_tile_only);
+  return attn_list_hdr_bytes(p) + 16 * (size_t)attn_list_item_bound(p, n_seqs, total_tokens, num_kv_heads, last_tile_only);
+}
+extern "C" int lrx_attn_build_items(const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads,
+                                    int32_t num_kv_heads, int32_t head_dim, int32_t last_tile_only, void* items, size_t items_bytes, void* stream) {
+  int rc = attn_check_layout(num_q_heads, num_kv_heads, head_dim);
+  if (rc) return rc;
+  if (n_seqs <= 0 || total_tokens <= 0) return LRX_OK;
+  LRX_CHECK_ARG(max_seqlen > 0, "attn: max_seqlen must be > 0");
+  const AttnPlan p = attn_plan(n_seqs, max_seqlen, num_q_heads, num_kv_heads, head_dim, last_tile_only);
+  LRX_CHECK_ARG(p.n_items < (1ll << 31), "attn: %lld work items", (long long)p.n_items);
+  LRX_CHECK_ARG(p.n_wg <= 1024, "attn: %d workgroups (the list builder is one block)", p.n_wg);
+  const size_t need = attn_list_hdr_bytes(p) + 16 * (size_t)attn_list_item_bound(p, n_seqs, total_tokens, num_kv_heads, last_tile_only);
+  LRX_CHECK_ARG(items != nullptr && ((uintptr_t)items & 15) == 0, "attn: the work list must be 16-byte aligned device memory");
+  LRX_CHECK_ARG(items_bytes >= need, "attn: work list %zu B < required %zu B", items_bytes, need);
+  int* ovf = nullptr;
+  LRX_HIP(hipGetSymbolAddress((void**)&ovf, HIP_SYMBOL(g_attn_items_overflow)));
+  const int64_t cap_items = (int64_t)((items_bytes - attn_list_hdr_bytes(p)) / 16);
+  hipLaunchKernelGGL(k_attn_build_items, dim3(1), dim3(1024), 0, (hipStream_t)stream, cu_seqlens, (int32_t*)items, (i32x4*)((char*)items + attn_list_hdr_bytes(p)),
+                     (int)(cap_items < (1ll << 30) ? cap_items : (1ll << 30)), p.n_wg, p.nqt, num_kv_heads, p.nparts, n_seqs, (int)p.n_items, p.gs, last_tile_only, ovf);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+static bool attn_uses_resident64(int head_dim, int max_seqlen, int last_tile_only) {
+  // LRX_ATTN_TILED=1: dev switch for A/B runs of the two d = 64 kernels (read once; C++11 static initialisation is thread-safe)
+  static const int force_tiled = []() { const char* e = getenv("LRX_ATTN_TILED"); return e ? atoi(e) : 0; }();
+  return !force_tiled && head_dim == 64 && max_seqlen <= 512 && !last_tile_only;
+}
+static int launch_resident64(const void* qkv, const int32_t* cu_seqlens, int n_seqs, int num_q_heads, int num_kv_heads, void* out, hipStream_t s) {
+  const float scale_log2 = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
+  const int n_cu64 = attn_cu_count();
+  const int n_pairs = n_seqs * num_kv_heads;
+  dim3 grid(n_pairs < n_cu64 ? n_pairs : n_cu64), block(1024);
+  hipLaunchKernelGGL(k_attn_resident64, grid, block, 0, s, (const __bf16*)qkv, cu_seqlens, num_q_heads, num_kv_heads, (__bf16*)out, scale_log2, n_pairs);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+extern "C" int lrx_attn_varlen_causal_items(const void* qkv, const int32_t* cu_seqlens, const void* items, size_t items_bytes, int32_t n_seqs,
+                                            int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                            void* out, int32_t last_tile_only, void* stream) {
+  int rc = attn_check_layout(num_q_heads, num_kv_heads, head_dim);
+  if (rc) return rc;
+  LRX_CHECK_ARG(max_seqlen > 0 || total_tokens == 0, "attn: max_seqlen must be > 0");
+  if (total_tokens == 0 || n_seqs == 0) return LRX_OK;
+  const int nq = num_q_heads, nkv = num_kv_heads;
+  hipStream_t s = (hipStream_t)stream;
+  if (attn_uses_resident64(head_dim, max_seqlen, last_tile_only)) return launch_resident64(qkv, cu_seqlens, n_seqs, nq, nkv, out, s);
+  const AttnPlan p = attn_plan(n_seqs, max_seqlen, nq, nkv, head_dim, last_tile_only);
+  const size_t need = attn_list_hdr_bytes(p) + 16 * (size_t)attn_list_item_bound(p, n_seqs, total_tokens, nkv, last_tile_only);
+  LRX_CHECK_ARG(items != nullptr && items_bytes >= need, "attn: work list %zu B < required %zu B", items_bytes, need);
+  // (a sequence's rows are addressed through one buffer descriptor: 32-bit byte offsets)
+  LRX_CHECK_ARG((int64_t)max_seqlen * (nq + 2 * nkv) * head_dim * 2 < (1ll << 31), "attn: a sequence of %d rows x %d B exceeds a buffer descriptor", max_seqlen,
+                (nq + 2 * nkv) * head_dim * 2);
+  const float scale_log2 = (1.0f / sqrtf((float)head_dim)) * 1.4426950408889634f;
+#define LRX_STREAM_CASE(DD, GG)                                                                                                                       \
+  case GG: hipLaunchKernelGGL((k_attn_stream<DD, GG>), dim3((unsigned)p.n_wg), dim3(128 * GG), 0, s, (const __bf16*)qkv, (const int32_t*)items, \
+                              (const i32x4*)((const char*)items + attn_list_hdr_bytes(p)), nq, nkv, (__bf16*)out, scale_log2); break;
+  if (head_dim == 64) {
+    switch (p.grp) {
+      LRX_STREAM_CASE(64, 1) LRX_STREAM_CASE(64, 2) LRX_STREAM_CASE(64, 3) LRX_STREAM_CASE(64, 4)
+      LRX_STREAM_CASE(64, 5) LRX_STREAM_CASE(64, 6) LRX_STREAM_CASE(64, 7) LRX_STREAM_CASE(64, 8)
+    }
+  } else {
+    switch (p.grp) { LRX_STREAM_CASE(128, 1) LRX_STREAM_CASE(128, 2) LRX_STREAM_CASE(128, 3) LRX_STREAM_CASE(128, 4) }
+  }
+#undef LRX_STREAM_CASE
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
 extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens,
                                       int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out,
                                       int32_t last_tile_only, void* stream) {
-  LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "attn: head_dim=%d unsupported (64 or 128)", head_dim);
-  LRX_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "attn: nq=%d not a multiple of nkv=%d", num_q_heads, num_kv_heads);
+  int rc = attn_check_layout(num_q_heads, num_kv_heads, head_dim);
+  if (rc) return rc;
   LRX_CHECK_ARG(max_seqlen > 0 || total_tokens == 0, "attn: max_seqlen must be > 0");
   if (total_tokens == 0 || n_seqs == 0) return LRX_OK;
   int grp = num_q_heads / num_kv_heads;
   hipStream_t s = (hipStream_t)stream;
-  // LRX_ATTN_TILED=1: dev switch for A/B runs of the two d = 64 kernels (read once; C++11 static initialisation is thread-safe)
-  static const int force_tiled = []() { const char* e = getenv("LRX_ATTN_TILED"); return e ? atoi(e) : 0; }();
-  if (!force_tiled && head_dim == 64 && max_seqlen <= 512 && !last_tile_only) {
-    const float scale_log2 = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
-    const int n_cu64 = attn_cu_count();
-    const int n_pairs = n_seqs * num_kv_heads;
-    dim3 grid(n_pairs < n_cu64 ? n_pairs : n_cu64), block(1024);
-    hipLaunchKernelGGL(k_attn_resident64, grid, block, 0, s, (const __bf16*)qkv, cu_seqlens, num_q_heads, num_kv_heads, (__bf16*)out, scale_log2, n_pairs);
-    LRX_LAUNCH_CHECK();
-    return LRX_OK;
-  }
+  if (attn_uses_resident64(head_dim, max_seqlen, last_tile_only)) return launch_resident64(qkv, cu_seqlens, n_seqs, num_q_heads, num_kv_heads, out, s);
+  // No work list: the walker kernel (k_attn_varlen_causal) derives every item's (sequence, kv head, q tile) itself -- the variant for
+  // callers without scratch memory; lrx_attn_varlen_causal_items is the faster launch.
   // Tiled kernel: GRP q heads per workgroup, nparts workgroups per kv head (heads beyond the group idle).  head_dim 64 takes up to 8
   // heads per workgroup; head_dim 128 needs ~190 VGPRs per wave, so at most 4 (more than 8 waves per workgroup would spill): groups
   // of 5-6 heads run as two workgroups of 3, 7-8 as two of 4 (the K/V tiles are staged twice, from L2), larger groups as ceil(grp/4).

@@ -102,6 +102,8 @@ struct EncWs {
   float *rsA, *rsB, *ssp;     // folded RMSNorm: row scales for the two norms of a layer, per-n-tile sum-of-squares partials
   int32_t* posr;              // final layer: positions / row scales of the last-token rows (the q projection runs on those rows only)
   float* rsr;
+  char *attn_items, *attn_items_tail;   // work lists of the attention launches (all q tiles; each sequence's last q tile), built once per batch
+  size_t attn_items_bytes, attn_items_tail_bytes;
   size_t total;
 };
 static EncWs carve(const lrx_encoder_config* c, int64_t T, int64_t B, char* base) {
@@ -124,6 +126,15 @@ static EncWs carve(const lrx_encoder_config* c, int64_t T, int64_t B, char* base
   w.actr = base + off; off += align_up((size_t)B * I * 2, 1024);
   w.posr = (int32_t*)(base + off); off += align_up((size_t)B * 4 + 32, 1024);
   w.rsr = (float*)(base + off); off += align_up((size_t)B * 4 + 32, 1024);
+  {
+    // sized for the longest sequence a call may name (check_call: max_seqlen <= max_positions; the list size is non-decreasing in
+    // max_seqlen and bounded by (T / 64 + B) x kv heads items of 16 bytes: ~300 KiB for 256 x 512 tokens and 8 kv heads)
+    const int64_t smax = c->max_positions;
+    w.attn_items_bytes = lrx_attn_items_bytes((int32_t)B, (int32_t)T, (int32_t)smax, c->num_q_heads, c->num_kv_heads, c->head_dim, 0);
+    w.attn_items_tail_bytes = lrx_attn_items_bytes((int32_t)B, (int32_t)T, (int32_t)smax, c->num_q_heads, c->num_kv_heads, c->head_dim, 1);
+    w.attn_items = base + off; off += align_up(w.attn_items_bytes + 16, 1024);
+    w.attn_items_tail = base + off; off += align_up(w.attn_items_tail_bytes + 16, 1024);
+  }
   w.x32 = w.xr32 = nullptr;
   if (c->precise_stream) {
     w.x32 = (float*)(base + off); off += align_up((size_t)T * H * 4, 1024);
@@ -246,12 +257,19 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
 struct BatchAttn { const lrx_encoder_config* c; EncWs* ws; const int32_t* cu; int n_seqs, T, max_seqlen; };
 static int batch_attn(void* ctx, int, bool last_tile, hipStream_t s) {
   const BatchAttn& a = *(const BatchAttn*)ctx;
-  return lrx_attn_varlen_causal(a.ws->qkv, a.cu, a.n_seqs, a.T, a.max_seqlen, a.c->num_q_heads, a.c->num_kv_heads, a.c->head_dim, a.ws->h, last_tile ? 1 : 0, s);
+  return lrx_attn_varlen_causal_items(a.ws->qkv, a.cu, last_tile ? a.ws->attn_items_tail : a.ws->attn_items,
+                                      last_tile ? a.ws->attn_items_tail_bytes : a.ws->attn_items_bytes, a.n_seqs, a.T, a.max_seqlen, a.c->num_q_heads,
+                                      a.c->num_kv_heads, a.c->head_dim, a.ws->h, last_tile ? 1 : 0, s);
 }
 static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu, int n_seqs,
                           int T, int max_seqlen, EncWs& ws, bool pooled_tail, hipStream_t s) {
   int rc;
   { ProfScope p(s, 6, 0); if ((rc = lrx_build_positions(cu, n_seqs, T, ws.pos, s))) return rc; }
+  // the attention work lists: one per batch, read by every layer's launch (the last layer of a pooled encode has its own: last q tiles only)
+  { ProfScope p(s, 6, 0);
+    if ((rc = lrx_attn_build_items(cu, n_seqs, T, max_seqlen, c->num_q_heads, c->num_kv_heads, c->head_dim, 0, ws.attn_items, ws.attn_items_bytes, s))) return rc;
+    if (pooled_tail && (rc = lrx_attn_build_items(cu, n_seqs, T, max_seqlen, c->num_q_heads, c->num_kv_heads, c->head_dim, 1, ws.attn_items_tail,
+                                                   ws.attn_items_tail_bytes, s))) return rc; }
   // causal attention flops: sum over sequences is not known on the host without a sync; use the dense upper bound for
   // equal-length batches: n_seqs * S*(S+1)/2 with S = T / n_seqs (exact when all sequences have the same length)
   const double S = (double)T / (double)(n_seqs > 0 ? n_seqs : 1);

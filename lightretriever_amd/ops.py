@@ -113,14 +113,36 @@ def build_positions(cu_seqlens: torch.Tensor, total_tokens: int) -> torch.Tensor
     return pos
 
 
+def attn_work_list(cu_seqlens: torch.Tensor, total_tokens: int, max_seqlen: int, nq: int, nkv: int, d: int, last_tile_only: bool = False) -> torch.Tensor:
+    """The work list of `attn_varlen_causal` for this batch layout (include/lrx.h, ABI 7): build once, pass to every layer's call."""
+    L = _lib.lib()
+    n_seqs = cu_seqlens.numel() - 1
+    nbytes = L.lrx_attn_items_bytes(n_seqs, total_tokens, max_seqlen, nq, nkv, d, int(last_tile_only))
+    items = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=cu_seqlens.device)
+    _lib.check(L.lrx_attn_build_items(_lib.ptr(cu_seqlens), n_seqs, total_tokens, max_seqlen, nq, nkv, d, int(last_tile_only), _lib.ptr(items),
+                                      items.numel(), _s()))
+    return items
+
+
 def attn_varlen_causal(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, nq: int, nkv: int, d: int,
-                       last_tile_only: bool = False) -> torch.Tensor:
+                       last_tile_only: bool = False, work_list=None) -> torch.Tensor:
+    """work_list: None -> built here (one extra small launch); a tensor from `attn_work_list` with the SAME layout arguments; False -> the
+    launch without a list (`lrx_attn_varlen_causal`: the kernel derives every item itself; same bits, ~10 % longer on the tiled path)."""
     if qkv.dtype != torch.float16:
         raise TypeError("attn_varlen_causal: qkv must be fp16 (the fused QKV + RoPE projection writes fp16)")
     T = qkv.shape[0]
     out = (torch.zeros if last_tile_only else torch.empty)(T, nq * d, dtype=torch.bfloat16, device=qkv.device)
-    _lib.check(_lib.lib().lrx_attn_varlen_causal(_lib.ptr(qkv), _lib.ptr(cu_seqlens), cu_seqlens.numel() - 1, T, max_seqlen, nq, nkv, d,
-                                                 _lib.ptr(out), int(last_tile_only), _s()))
+    n_seqs = cu_seqlens.numel() - 1
+    if work_list is False:
+        _lib.check(_lib.lib().lrx_attn_varlen_causal(_lib.ptr(qkv), _lib.ptr(cu_seqlens), n_seqs, T, max_seqlen, nq, nkv, d,
+                                                     _lib.ptr(out), int(last_tile_only), _s()))
+        return out
+    if T == 0 or n_seqs == 0:
+        return out
+    if work_list is None:
+        work_list = attn_work_list(cu_seqlens, T, max_seqlen, nq, nkv, d, last_tile_only)
+    _lib.check(_lib.lib().lrx_attn_varlen_causal_items(_lib.ptr(qkv), _lib.ptr(cu_seqlens), _lib.ptr(work_list), work_list.numel(), n_seqs, T, max_seqlen,
+                                                       nq, nkv, d, _lib.ptr(out), int(last_tile_only), _s()))
     return out
 
 

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_header_symbols():
     for s in syms:
         assert hasattr(l, s), f"{s} declared in include/lrx.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table out of sync with include/lrx.h"
-    assert _lib.lib().lrx_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib().lrx_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -32,6 +32,11 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert l.lrx_gemm_bf16_nt(None, None, None, None, None, 4, 8, 7, 0, None) == -1
     assert b"K=7" in l.lrx_last_error()
     assert l.lrx_attn_varlen_causal(None, None, 1, 4, 4, 4, 2, 16, None, 0, None) == -1
+    # the work-list variant (ABI 7): same layout checks, the list must be there and large enough
+    assert l.lrx_attn_varlen_causal_items(None, None, None, 0, 1, 4, 4, 4, 2, 16, None, 0, None) == -1
+    assert l.lrx_attn_varlen_causal_items(None, None, None, 0, 1, 4, 4, 32, 8, 128, None, 0, None) == -1 and b"work list" in l.lrx_last_error()
+    assert l.lrx_attn_build_items(None, 1, 4, 4, 32, 8, 128, 0, None, 0, None) == -1
+    assert l.lrx_attn_items_bytes(1, 4, 4, 32, 8, 128, 0) >= 16 and l.lrx_attn_items_bytes(1, 4, 4, 32, 8, 100, 0) == 0
     assert l.lrx_flat_ip_scores(None, 10, 48, 48, None, 1, None, None) == -1
     assert l.lrx_flat_ip_score_ld(1000) == 1024
     assert l.lrx_encode_workspace_bytes(None, 1, 1) == 0

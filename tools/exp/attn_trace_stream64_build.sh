@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic build of liblrx with wall-clock stamps in k_attn_varlen_causal (workgroup 0, every wave): run HERE, then on the GPU box
+# Diagnostic build of liblrx with wall-clock stamps in k_attn_stream64 (run the probe with LRX_ATTN_STREAM=2) (workgroup 0, every wave): run HERE, then on the GPU box
 #   LRX_LIB_DEV_VARIANT=$GRAFT_REPO_ROOT/lightretriever_amd/build/liblrx_atrace.so python3 tools/exp/attn_trace_tiled.py
 # Tags: 1000+qt item start, 1100 next item known, 100 tile step start, 200 tile requested, 300 computed, 400 tile landed, 500 barrier passed,
 # 1200 item's tiles done, 1300 output rows in the staging block, 1400 read back, 2000 item's output stores issued.
@@ -25,24 +25,25 @@ extern "C" int lrx_debug_read_attn_trace(void* dst, size_t bytes, void* cnt) {
     ++tr_n;                                                                                \\
   } while (0)
 ''', 1)
-i = s.index('k_attn_varlen_causal(const __bf16* __restrict__ qkv'); j = s.index('// d = 64, S <= 512: K/V-resident kernel')
+i = s.index('k_attn_stream64(const __bf16* __restrict__ qkv'); j = s.index('// d = 64, S <= 512: K/V-resident kernel')
 k = s[i:j]
 def rep(a, b):
     global k
     assert a in k, a
     k = k.replace(a, b, 1)
-rep('  Walk wc = {0, 0, (int)blockIdx.x};\n', '  int tr_n = 0;\n  Walk wc = {0, 0, (int)blockIdx.x};\n')
-rep('  while (ic.pair >= 0) {\n  const Item inext = next_item(wc);\n', '  while (ic.pair >= 0) {\n  A_TRACE(1000 + ic.qt);\n  const Item inext = next_item(wc);\n  A_TRACE(1100);\n')
+rep('  int ci = 0;\n', '  int tr_n = 0;\n  int ci = 0;\n')
+rep('  while (ic[1] != 0) {\n  ++ci;\n  const i32x4 inext = lst[ci];\n', '  while (ic[1] != 0) {\n  A_TRACE(1000 + (ic[2] & 0xffff));\n  ++ci;\n  const i32x4 inext = lst[ci];\n  A_TRACE(1100);\n')
 rep('    const bool more = stage_next();', '    A_TRACE(100);\n    const bool more = stage_next();')
-rep('    if (active) {\n      f32x16 s0_ = qk_product(sK, qf);', '    A_TRACE(200);\n    if (active) {\n      f32x16 s0_ = qk_product(sK, qf);')
-rep('    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");', '    A_TRACE(300);\n    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");')
+rep('    if (active) {\n      if (kt < qt) tile(', '    A_TRACE(200);\n    if (active) {\n      if (kt < qt) tile(')
+rep('    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");\n    else', '    A_TRACE(300);\n    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");\n    else')
 rep('    __builtin_amdgcn_s_barrier();\n    cur = cur == NST - 1 ? 0 : cur + 1;\n', '    A_TRACE(400);\n    __builtin_amdgcn_s_barrier();\n    A_TRACE(500);\n    cur = cur == NST - 1 ? 0 : cur + 1;\n')
-rep('  if (inext.pair >= 0) read_q(qf);\n  if (active) {', '  A_TRACE(1200);\n  if (inext.pair >= 0) read_q(qf);\n  if (active) {')
-rep('    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // same wave wrote, same wave reads: no barrier', '    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");\n    A_TRACE(1300);')
-rep('#pragma unroll\n    for (int j = 0; j < QINST; ++j) {\n      const int s_ = j * 64 + ln;\n      const int row = s_ / G::CH, ch = s_ % G::CH;\n      __builtin_amdgcn_raw_buffer_store_b128', '    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");\n    A_TRACE(1400);\n#pragma unroll\n    for (int j = 0; j < QINST; ++j) {\n      const int s_ = j * 64 + ln;\n      const int row = s_ / G::CH, ch = s_ % G::CH;\n      __builtin_amdgcn_raw_buffer_store_b128')
+rep('  if (inext[1] != 0) read_q(qf);\n  if (active) {', '  A_TRACE(1200);\n  if (inext[1] != 0) read_q(qf);\n  if (active) {')
+rep('    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");\n    int ln = lane;', '    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");\n    A_TRACE(1300);\n    int ln = lane;')
+rep('    const __amdgpu_buffer_rsrc_t orsrc', '    A_TRACE(1400);\n    const __amdgpu_buffer_rsrc_t orsrc')
 rep('  ic = inext;\n  }  // items', '  A_TRACE(2000);\n  ic = inext;\n  }  // items')
 open(p, 'w').write(s[:i] + k + s[j:])
 EOF
 [ $? -eq 0 ] || exit 1
+set -e
 LRX_CSRC_DIR=$D python3 -m lightretriever_amd.build --out=$R/lightretriever_amd/build/liblrx_atrace.so > /dev/null || exit 1
 echo built $R/lightretriever_amd/build/liblrx_atrace.so
