@@ -60,6 +60,6 @@ def test_tiled_attention_at_head_dim_128_has_no_scratch(attn_isa):
 
 def test_work_list_attention_has_no_scratch_at_the_shapes_the_encoders_use(attn_isa):
     # (a spilled value reloaded inside the item loop waits, with its vmcnt(0), for every tile request in flight: DESIGN.md 5.2)
-    for d, grps in ((128, (1, 2, 3, 4)), (64, (1, 2, 3, 4, 5, 6))):
+    for d, grps in ((128, (1, 2, 3, 4)), (64, (1, 2, 3, 4, 5, 6, 7, 8))):
         for grp in grps:
             assert "scratch_" not in kernel_body(attn_isa, "_Z13k_attn_streamILi%dELi%dE" % (d, grp)), (d, grp)
