@@ -16,13 +16,13 @@ for f in glob.glob("$OUT/a/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         key = None
-        for k in ("k_gemm_bf16_nt<6>", "k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_attn_resident64", "k_attn_varlen_causal"):
+        for k in ("k_gemm_bf16_nt<6>", "k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_attn_resident64", "k_attn_varlen_causal", "k_attn_stream"):
             if k in n: key = k
         if key: cnt[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob("$OUT/a/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        for k in ("k_gemm_bf16_nt<6>", "k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_attn_resident64", "k_attn_varlen_causal"):
+        for k in ("k_gemm_bf16_nt<6>", "k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_attn_resident64", "k_attn_varlen_causal", "k_attn_stream"):
             if k in n: dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
 out = {}
 for k, c in cnt.items():

@@ -28,7 +28,7 @@ def short(name):
         if m.group(2) == "1":
             return "k_flat_ip_scores_split<NP=1,%s>" % ("emit" if m.group(3).strip().endswith("true, true, true") or m.group(3).strip().endswith("false, false, true") else "scores")
         return "k_flat_ip_scores_split<NP=%s>" % m.group(2)
-    for k in ("k_sample_threshold", "k_refine_band", "k_shard_rows", "k_shard_bounds", "k_pool_norm", "k_gemm_bf16_nt<6>", "k_gemm_bf16_nt<4>", "k_refine_topk", "k_refine_merge", "k_topk_select_rescore", "k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_gemm_bf16_nt<0>", "k_attn_resident64", "k_attn_varlen_causal", "k_rmsnorm", "k_rope", "k_flat_ip_scores_split", "k_flat_ip_scores", "k_topk_select"):
+    for k in ("k_sample_threshold", "k_refine_band", "k_shard_rows", "k_shard_bounds", "k_pool_norm", "k_gemm_bf16_nt<6>", "k_gemm_bf16_nt<4>", "k_refine_topk", "k_refine_merge", "k_topk_select_rescore", "k_gemm_bf16_nt<3>", "k_gemm_bf16_nt<2>", "k_gemm_bf16_nt<1>", "k_gemm_bf16_nt<0>", "k_attn_resident64", "k_attn_varlen_causal", "k_attn_stream", "k_attn_build_items", "k_rmsnorm", "k_rope", "k_flat_ip_scores_split", "k_flat_ip_scores", "k_topk_select"):
         if k in name:
             return k
     return None
