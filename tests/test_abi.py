@@ -81,3 +81,14 @@ def test_forced_build_from_sources_compiles_every_kernel_file(tmp_path):
     for f in os.listdir(os.path.join(ROOT, "lightretriever_amd", "build")):
         if "liblrx_forced" in f:
             os.remove(os.path.join(ROOT, "lightretriever_amd", "build", f))
+
+
+def test_header_is_plain_c():
+    """include/lrx.h is the boundary a non-C++ host binds (cgo / JNI / ctypes generators): it must parse as C99 and as C++11 on its own."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "lrx.h")
+    gcc, gxx = shutil.which("gcc"), shutil.which("g++")
+    assert gcc and gxx
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call([gxx, "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
