@@ -1,5 +1,6 @@
 /* Native smoke test of the C ABI (no Python, no torch): links liblrx.so, drives lrx_flat_ip_search, lrx_flat_ip_search_bounded
- * and lrx_embedding_bag_mean with plain HIP allocations and checks them against brute force on the host.
+ * and lrx_embedding_bag_mean with plain HIP allocations and checks them against brute force on the host; the varlen causal attention
+ * without and with a work list (ABI 7) against a double-precision softmax on the host.
  * build: hipcc -x hip --offload-arch=gfx950 tests/native/abi_smoke.c -Iinclude -Llightretriever_amd -llrx -Wl,-rpath,$PWD/lightretriever_amd -o abi_smoke
  * (compiled and run by tests/test_gpu_native.py) */
 #include <hip/hip_runtime.h>
@@ -59,6 +60,70 @@ static int check_topk(const float* X, const float* q, int N, int D, int Q, int k
   return bad;
 }
 
+static float f16_to_f32(unsigned short h) {
+  const unsigned sign = (unsigned)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+  unsigned u;
+  if (e == 0) { float f = (float)m * (1.0f / 16777216.0f); memcpy(&u, &f, 4); u |= sign; }    /* subnormal: m * 2^-24 */
+  else u = sign | ((e - 15 + 127) << 23) | (m << 13);
+  float f; memcpy(&f, &u, 4); return f;
+}
+static float bf16_to_f32(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
+/* Varlen causal GQA attention: lrx_attn_varlen_causal (no scratch) and the same launch on a work list built once (ABI 7) must agree bit for
+ * bit, and both with softmax(q k^T / sqrt(d)) v computed in double from the fp16 inputs (output bf16: 2^-8 relative). */
+static int attention_smoke(void) {
+  const int nq = 8, nkv = 2, d = 128, lens[4] = {1, 70, 64, 131};
+  int cu[5] = {0, 0, 0, 0, 0}, T, maxlen = 0;
+  for (int i = 0; i < 4; ++i) { cu[i + 1] = cu[i] + lens[i]; if (lens[i] > maxlen) maxlen = lens[i]; }
+  T = cu[4];
+  const int W = (nq + 2 * nkv) * d;
+  unsigned short* qkv = (unsigned short*)malloc(2 * (size_t)T * W);
+  for (size_t i = 0; i < (size_t)T * W; ++i) qkv[i] = f32_to_f16(frand());
+  void *dqkv, *dout1, *dout2, *ditems; int* dcu;
+  CHECK(hipMalloc(&dqkv, 2 * (size_t)T * W)); CHECK(hipMalloc(&dout1, 2 * (size_t)T * nq * d)); CHECK(hipMalloc(&dout2, 2 * (size_t)T * nq * d));
+  CHECK(hipMalloc((void**)&dcu, sizeof(cu)));
+  CHECK(hipMemcpy(dqkv, qkv, 2 * (size_t)T * W, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dcu, cu, sizeof(cu), hipMemcpyHostToDevice));
+  const size_t ib = lrx_attn_items_bytes(4, T, maxlen, nq, nkv, d, 0);
+  if (ib == 0) { printf("lrx_attn_items_bytes returned 0\n"); return 1; }
+  CHECK(hipMalloc(&ditems, ib));
+  LRX(lrx_attn_varlen_causal(dqkv, dcu, 4, T, maxlen, nq, nkv, d, dout1, 0, NULL));
+  LRX(lrx_attn_build_items(dcu, 4, T, maxlen, nq, nkv, d, 0, ditems, ib, NULL));
+  LRX(lrx_attn_varlen_causal_items(dqkv, dcu, ditems, ib, 4, T, maxlen, nq, nkv, d, dout2, 0, NULL));
+  CHECK(hipDeviceSynchronize());
+  unsigned short* o1 = (unsigned short*)malloc(2 * (size_t)T * nq * d);
+  unsigned short* o2 = (unsigned short*)malloc(2 * (size_t)T * nq * d);
+  CHECK(hipMemcpy(o1, dout1, 2 * (size_t)T * nq * d, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(o2, dout2, 2 * (size_t)T * nq * d, hipMemcpyDeviceToHost));
+  int bad = 0, ovf = -1;
+  if (memcmp(o1, o2, 2 * (size_t)T * nq * d) != 0) { printf("attention: the work-list launch differs from the launch without a list\n"); ++bad; }
+  LRX(lrx_debug_attn_items_overflow(&ovf));
+  if (ovf != 0) { printf("attention: work-list builder overflow count %d\n", ovf); ++bad; }
+  double* sc = (double*)malloc(sizeof(double) * maxlen);
+  for (int b = 0; b < 4; ++b)
+    for (int i = 0; i < lens[b]; ++i)
+      for (int h = 0; h < nq; ++h) {
+        const unsigned short* qr = qkv + (size_t)(cu[b] + i) * W + h * d;
+        const int hk = h / (nq / nkv);
+        double mx = -1e300, den = 0;
+        for (int j = 0; j <= i; ++j) {
+          const unsigned short* kr = qkv + (size_t)(cu[b] + j) * W + (nq + hk) * d;
+          double s = 0;
+          for (int e = 0; e < d; ++e) s += (double)f16_to_f32(qr[e]) * (double)f16_to_f32(kr[e]);
+          sc[j] = s / sqrt((double)d);
+          if (sc[j] > mx) mx = sc[j];
+        }
+        for (int j = 0; j <= i; ++j) { sc[j] = exp(sc[j] - mx); den += sc[j]; }
+        for (int e = 0; e < d; e += 37) {            /* a few columns per row */
+          double acc = 0;
+          for (int j = 0; j <= i; ++j) acc += sc[j] * (double)f16_to_f32(qkv[(size_t)(cu[b] + j) * W + (nq + nkv + hk) * d + e]);
+          acc /= den;
+          const double got = bf16_to_f32(o2[(size_t)(cu[b] + i) * nq * d + h * d + e]);
+          if (fabs(got - acc) > 0.01 + 0.01 * fabs(acc)) { if (bad < 5) printf("attention: seq %d row %d head %d col %d: %.6f vs %.6f\n", b, i, h, e, got, acc); ++bad; }
+        }
+      }
+  free(sc); free(o1); free(o2); free(qkv);
+  return bad;
+}
+
 int main(void) {
   if (lrx_abi_version() != LRX_ABI_VERSION) { printf("ABI version mismatch: library %d, header %d\n", lrx_abi_version(), LRX_ABI_VERSION); return 1; }
   const int N = 6000, D = 64, Q = 40, k = 10;
@@ -103,6 +168,7 @@ int main(void) {
   if (lrx_flat_ip_search(dX, N, D, D, dbound, dq, Q, 0, 0, dD, (int64_t*)dI, ws, wsb, NULL) == 0 || strlen(lrx_last_error()) == 0) { printf("k = 0 was accepted\n"); ++bad; }
   if (lrx_flat_ip_search(dX, N, D, D, dbound, dq, Q, k, 0, dD, (int64_t*)dI, ws, 16, NULL) == 0) { printf("a 16-byte workspace was accepted\n"); ++bad; }
   if (lrx_flat_ip_search_bounded(dX, N, D, D, dXb, dbound, dq, Q, k, 0, dD, (int64_t*)dI, ws, wsb, 64, NULL) == 0) { printf("unknown search flags were accepted\n"); ++bad; }
+  bad += attention_smoke();
   printf(bad ? "ABI SMOKE FAILED (%d mismatches)\n" : "ABI SMOKE OK\n", bad);
   return bad ? 4 : 0;
 }
