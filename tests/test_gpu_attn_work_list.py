@@ -26,6 +26,10 @@ CASES = [
     ("d64_g7_long", 14, 2, 64, _lens(9, 40, 900), False),
     ("d64_g16_two_parts", 16, 1, 64, _lens(10, 12, 700), False),
     ("d64_resident_ignores_the_list", 32, 8, 64, _lens(11, 50, 512), False),
+    ("many_short_sequences", 8, 2, 128, [3, 70, 1, 129] * 1250, False),     # 5000 sequences: 10 000 (sequence, kv head) pairs through the one-block builder
+    ("many_short_last_tile", 8, 2, 128, [3, 70, 1, 129] * 1250, True),
+    ("one_long_sequence", 8, 2, 128, [8192, 5], False),                      # 128 q tiles: groups of 32 workgroups per (sequence, kv head)
+    ("d64_one_long_sequence", 8, 2, 64, [6000], False),
     ("tiny", 32, 8, 128, [1, 2, 63, 64, 65], False),
     ("one_token", 32, 8, 128, [1], True),
 ]
