@@ -387,7 +387,13 @@ enum {
    * persistent kernel, for chunks of <= 128 queries over a shadow with dim % 256 == 0 -- is chosen by a measured rule (<= 16 queries, dim >= 512,
    * k <= 256, <= 8 blocks of 128 rows per CU: small query batches over a per-rank shard); these two bits force it on wherever it is eligible, or off */
   LRX_SEARCH_FUSED_ALWAYS = 4,
-  LRX_SEARCH_FUSED_NEVER = 8
+  LRX_SEARCH_FUSED_NEVER = 8,
+  /* Exact rescoring of the band rows: per query (gather of its fp32 rows), or -- many queries x large k over a small shard, where every row
+   * is wanted by several queries of a chunk -- grouped by ROW: each 16-row group staged once, the query rows streamed from L2; same bits.
+   * Default: by a measured rule (rows of >= 8 KiB that a chunk of <= 256 queries wants >= 2.5 times: queries x k x 1.25 >= 2.5 x rows).
+   * OR-able with the bits above; 16 | 32 is rejected.                                                                                     */
+  LRX_SEARCH_REFINE_ROWS_ALWAYS = 16,
+  LRX_SEARCH_REFINE_ROWS_NEVER = 32
 };
 size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags);
 int lrx_flat_ip_search_bounded(const float* X, int64_t n_rows, int64_t ldx, int32_t dim, const void* X_shadow, const float* row_bounds,

@@ -9,7 +9,8 @@ LRX_PROF_CLASSES = 8
 ABI_VERSION = 7   # LRX_ABI_VERSION of include/lrx.h
 # lrx_flat_ip_search_bounded flags (LRX_SEARCH_FILTER_*): A/B runs and tests; the hits do not depend on them
 SEARCH_FILTER_AUTO, SEARCH_FILTER_MATRIX, SEARCH_FILTER_SCORE_FREE, SEARCH_FILTER_SCORE_FREE_NO_GEMM = 0, 1, 2, 3
-SEARCH_FUSED_ALWAYS, SEARCH_FUSED_NEVER = 4, 8       # OR-ed on: the fused filter launch wherever eligible / never (default: a measured rule)
+SEARCH_FUSED_ALWAYS, SEARCH_FUSED_NEVER = 4, 8
+SEARCH_REFINE_ROWS_ALWAYS, SEARCH_REFINE_ROWS_NEVER = 16, 32   # exact rescoring grouped by row / per query (include/lrx.h)       # OR-ed on: the fused filter launch wherever eligible / never (default: a measured rule)
 PROF_CLASS_NAMES = ["gemm_store", "gemm_resid", "gemm_swiglu", "attention", "rmsnorm", "rope", "other", "gemm_maxagg"]
 
 

@@ -2401,10 +2401,16 @@ __device__ __forceinline__ void refine_rescore(const float* __restrict__ X, int6
 // Refine step of the score-free filter, grid (n_queries, REF_SPLIT): every part finds kth~ in the query's candidate list (radix
 // select over ~10^3..10^4 L2-resident entries), takes every REF_SPLIT-th entry of the band [kth~ - 2 eps, inf), rescores those rows
 // exactly and publishes the packed (score, row) list (count -1 = list or band overflow); k_refine_merge finishes.
+struct RowPairs {                         // row-grouped rescoring (below): NULL pairs = the gather of refine_rescore
+  unsigned long long* pairs;              // [n_queries * REF_CAND] (row << 32 | slot in `parts`), in emission order
+  unsigned int* total;                    // number of pairs emitted
+  unsigned int* grp_cnt;                  // [groups] pairs per group of (1 << grp_shift) rows
+  int grp_shift;
+};
 __global__ void __launch_bounds__(1024)
 k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ q, const unsigned long long* __restrict__ cand,
               const unsigned int* __restrict__ cnt, const float* __restrict__ eps, int k, unsigned long long* __restrict__ parts,
-              int* __restrict__ part_cnt, int nsplit, unsigned int cap) {
+              int* __restrict__ part_cnt, int nsplit, unsigned int cap, RowPairs rp) {
   __shared__ RadixShared rs;
   __shared__ unsigned long long s_cand[REF_CAND];           // (a part holds REF_CAND / nsplit of them)
   __shared__ __attribute__((aligned(16))) float s_q[REF_QLDS];   // the query row (every rescoring re-reads it; from global its loads serialise)
@@ -2440,8 +2446,114 @@ k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
     overflow = s_ncand > pcand;
   }
   const int nc = overflow ? 0 : (int)s_ncand;
-  refine_rescore(X, ldx, D, qrow, s_cand, nc, parts + ((int64_t)qi * nsplit + part) * pcand);
+  if (rp.pairs != nullptr) {
+    // row-grouped rescoring: this part only NAMES its band rows -- (row, slot of `parts` the exact score goes to) -- and counts them per row group
+    __shared__ unsigned int s_base;
+    if (tid == 0) s_base = nc > 0 ? atomicAdd(rp.total, (unsigned int)nc) : 0u;
+    __syncthreads();
+    const unsigned int slot0 = (unsigned int)((qi * nsplit + part) * (int)pcand);
+    for (int c = tid; c < nc; c += 1024) {
+      const unsigned long long row = s_cand[c];
+      rp.pairs[s_base + c] = (row << 32) | (unsigned long long)(slot0 + (unsigned int)c);
+      atomicAdd(&rp.grp_cnt[row >> rp.grp_shift], 1u);
+    }
+  } else {
+    refine_rescore(X, ldx, D, qrow, s_cand, nc, parts + ((int64_t)qi * nsplit + part) * pcand);
+  }
   if (tid == 0) part_cnt[qi * nsplit + part] = overflow ? -1 : nc;
+}
+
+// ---- Row-grouped exact rescoring (round 5): many queries x large k over a small shard (the reference's evaluation point: top-1000 of ~1000
+// queries per 100 k-row corpus chunk, eval/call_evaluate_mteb.sh:8-10) want every fp32 row several times -- 250 queries x 1 210 band rows
+// over 100 k rows: three times -- and the per-query gather above reads it from HBM each time (2.5 GB per chunk of 250 queries against a
+// 0.8-GB shard).  Here the (row, slot) pairs the parts emitted are grouped by 16-row group (counting sort: the counts came with the
+// pairs), a workgroup stages its group's rows in LDS once and streams the query rows of its pairs from L2 through the same fp64 dot
+// product (same association, same bits as exact_dot).
+__global__ void __launch_bounds__(1024)
+k_pairs_scan(const unsigned int* __restrict__ grp_cnt, unsigned int* __restrict__ grp_off, int ngroups) {   // exclusive scan, one workgroup
+  __shared__ unsigned int s_w[16];
+  __shared__ unsigned int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int g0 = 0; g0 < ngroups + 1; g0 += 1024) {
+    const int g = g0 + tid;
+    const unsigned int v = g < ngroups ? grp_cnt[g] : 0u;
+    unsigned int x = v;                                    // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    unsigned int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += s_w[w];
+    const unsigned int carry = s_carry;
+    if (g <= ngroups) grp_off[g] = carry + wbase + x - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + wbase + x;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256)
+k_pairs_scatter(const unsigned long long* __restrict__ pairs, const unsigned int* __restrict__ total, unsigned int* __restrict__ grp_cnt,
+                const unsigned int* __restrict__ grp_off, int grp_shift, unsigned long long* __restrict__ sorted) {
+  const unsigned int n = *total;
+  for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const unsigned long long pr = pairs[i];
+    const unsigned int g = (unsigned int)(pr >> 32) >> grp_shift;
+    const unsigned int pos = grp_off[g] + atomicSub(&grp_cnt[g], 1u) - 1u;      // (leaves the counts at zero for the next chunk)
+    sorted[pos] = pr;
+  }
+}
+// exact_dot with the row in LDS and the query row in global memory: the SAME partial products in the same order (lane sub of a half-wave:
+// elements i0 + 128 u + (0..3), i0 = 4 sub, 2048-element blocks), fp64 accumulation, the same xor tree -- bit-identical to exact_dot
+__device__ __forceinline__ float exact_dot_lds_row(const float* x_lds, const float* __restrict__ qglob, int D, int lane) {
+  const int sub = lane & 31;
+  double acc = 0.0;
+  for (int i0 = sub * 4; i0 < D; i0 += 2048) {
+    f32x4 qv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u * 128;
+      qv[u] = i < D ? *(const f32x4*)(qglob + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u * 128;
+      if (i < D) {
+        const f32x4 xv = *(const f32x4*)(x_lds + i);
+        acc += (double)xv[0] * (double)qv[u][0] + (double)xv[1] * (double)qv[u][1] + (double)xv[2] * (double)qv[u][2] +
+               (double)xv[3] * (double)qv[u][3];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  return (float)acc;
+}
+#define ROWGRP_LDS_FLOATS 16384          // 64 KiB of rows per workgroup (two workgroups per CU: one stages while the other multiplies): 8 rows at D = 2048, 4 at 4096
+#define ROWGRP_THREADS 512
+__global__ void __launch_bounds__(ROWGRP_THREADS)
+k_rescore_row_groups(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const float* __restrict__ q, const unsigned long long* __restrict__ sorted,
+                     const unsigned int* __restrict__ grp_off, int grp_shift, unsigned long long* __restrict__ parts) {
+  __shared__ __attribute__((aligned(16))) float s_x[ROWGRP_LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 5;
+  const int g = blockIdx.x;
+  const unsigned int p0 = grp_off[g], p1 = grp_off[g + 1];
+  if (p0 == p1) return;
+  const int64_t r0 = (int64_t)g << grp_shift;
+  const int nrows = (int)min((int64_t)1 << grp_shift, N - r0);
+  for (int i = tid * 4; i < nrows * D; i += ROWGRP_THREADS * 4) {
+    const int rr = i / D, cc = i - rr * D;
+    *(f32x4*)(s_x + i) = REF_ROW_LOAD((const f32x4*)(X + (r0 + rr) * ldx + cc));
+  }
+  __syncthreads();
+  for (unsigned int pi = p0 + hw; pi < p1; pi += ROWGRP_THREADS / 32) {
+    const unsigned long long pr = sorted[pi];
+    const int64_t row = (int64_t)(pr >> 32);
+    const unsigned int slot = (unsigned int)pr;
+    const float sc = exact_dot_lds_row(s_x + (row - r0) * D, q + (int64_t)(slot / REF_CAND) * D, D, lane);
+    if ((lane & 31) == 0) parts[slot] = sel_pack(f2key(sc), row);
+  }
 }
 
 // Refine step of the score-matrix filter, grid (n_queries, REF_SPLIT): part s of query q owns the 128-row blocks b with b % REF_SPLIT == s:
@@ -2732,7 +2844,7 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
   LRX_CHECK_ARG(row_bounds != nullptr, "flat_ip_search_bounded: null row_bounds (device pointer to {max |x_row|, max |x_row - fp16(x_row)|})");
   LRX_CHECK_ARG(k > 0 && k <= SEL_MAXK, "flat_ip_search: k=%d out of range (1..%d)", k, SEL_MAXK);
   LRX_CHECK_ARG(n_rows >= 0 && n_rows < (1ll << 32), "flat_ip_search: shard rows=%lld out of range", (long long)n_rows);
-  LRX_CHECK_ARG((flags & ~15) == 0 && (flags & 12) != 12, "flat_ip_search_bounded: unknown flags 0x%x", flags);
+  LRX_CHECK_ARG((flags & ~63) == 0 && (flags & 12) != 12 && (flags & 48) != 48, "flat_ip_search_bounded: unknown flags 0x%x", flags);
   if (n_queries <= 0) return LRX_OK;
   if (workspace_bytes < lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k, flags)) {
     lrx_set_error("flat_ip_search_bounded: workspace %zu B < required %zu B", workspace_bytes, lrx_flat_ip_bounded_workspace_bytes(n_rows, dim, n_queries, k, flags));
@@ -2844,9 +2956,46 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
       nsplit = (int64_t)nq * REF_SPLIT <= lrx_cu_count() ? REF_SPLIT : ((int64_t)nq * 2 <= lrx_cu_count() ? 2 : 1);
       // (Round 4, re-measured on the per-rank shard sizes, 100 queries: 125 k x 2048 0.190 / 0.178-0.181 / 0.190 / 0.191-0.192 ms for 1 / 2 / 3 / 4 parts,
       // 1.25M x 256 0.202 / 0.196-0.198 / 0.208 / 0.202-0.208, 1M x 2048 0.741 / 0.722-0.726 / 0.735 / 0.738-0.743: two parts everywhere.)
-      hipLaunchKernelGGL(k_refine_band, dim3(nq, nsplit), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
-                         (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt, nsplit, p.cap);
-      LRX_LAUNCH_CHECK();
+      // Row-grouped rescoring where the chunk wants every row more than twice on average (~1.2 k band rows per query): the pairs and the
+      // group counters live in the score region, which nothing reads between the sample's selection and the gated fallback.
+      RowPairs rp = {nullptr, nullptr, nullptr, 0};
+      {
+        const int gshift = dim <= 512 ? 5 : (dim <= 1024 ? 4 : (dim <= 2048 ? 3 : 2));
+        const int64_t ngroups = (n_rows + ((int64_t)1 << gshift) - 1) >> gshift;
+        const size_t pair_bytes = align256((size_t)nq * REF_CAND * 8);
+        const size_t need = 2 * pair_bytes + align256((size_t)(ngroups + 2) * 4) * 2 + 256;
+        const bool fits = need <= p.off_qsplit && ((int64_t)1 << gshift) * dim <= ROWGRP_LDS_FLOATS && dim % 4 == 0 && ldx % 4 == 0 && ngroups < (1 << 30);
+        // measured (tools/exp/refine_rows_ab.py, profiles/r05_refine_rows_ab.txt; gather / by row, ms): 1000 queries, k = 1000 over 50 k x 2048 1.98 / 1.47,
+        // 100 k x 2048 2.20 / 2.14, 100 k x 4096 4.50 / 4.02, but 100 k x 1024 1.46 / 1.57, 200 k x 2048 2.82 / 3.49, k = 100 0.81 / 1.51: rows of
+        // >= 8 KiB that the chunk wants >= 2.5 times on average (~1.25 k band rows per query)
+        const bool rule = dim >= 2048 && (int64_t)nq * k * 5 / 4 >= (5 * n_rows) / 2;
+        if (fits && !(flags & 32) && (rule || (flags & 16))) {
+          char* b = ws;
+          rp.pairs = (unsigned long long*)b;
+          unsigned long long* sorted = (unsigned long long*)(b + pair_bytes);
+          rp.grp_cnt = (unsigned int*)(b + 2 * pair_bytes);
+          unsigned int* grp_off = (unsigned int*)(b + 2 * pair_bytes + align256((size_t)(ngroups + 2) * 4));
+          rp.total = grp_off + ngroups + 1;
+          rp.grp_shift = gshift;
+          LRX_HIP(hipMemsetAsync(rp.grp_cnt, 0, (size_t)((char*)(rp.total + 1) - (char*)rp.grp_cnt), s));
+          hipLaunchKernelGGL(k_refine_band, dim3(nq, nsplit), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
+                             (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt, nsplit, p.cap, rp);
+          LRX_LAUNCH_CHECK();
+          hipLaunchKernelGGL(k_pairs_scan, dim3(1), dim3(1024), 0, s, (const unsigned int*)rp.grp_cnt, grp_off, (int)ngroups);
+          LRX_LAUNCH_CHECK();
+          hipLaunchKernelGGL(k_pairs_scatter, dim3((unsigned)(4 * lrx_cu_count())), dim3(256), 0, s, (const unsigned long long*)rp.pairs, (const unsigned int*)rp.total,
+                             rp.grp_cnt, (const unsigned int*)grp_off, gshift, sorted);
+          LRX_LAUNCH_CHECK();
+          hipLaunchKernelGGL(k_rescore_row_groups, dim3((unsigned)ngroups), dim3(ROWGRP_THREADS), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)sorted,
+                             (const unsigned int*)grp_off, gshift, parts);
+          LRX_LAUNCH_CHECK();
+        }
+      }
+      if (rp.pairs == nullptr) {
+        hipLaunchKernelGGL(k_refine_band, dim3(nq, nsplit), dim3(1024), 0, s, X, n_rows, ldx, dim, qc, (const unsigned long long*)cand,
+                           (const unsigned int*)cnt, (const float*)eps, k, parts, part_cnt, nsplit, p.cap, rp);
+        LRX_LAUNCH_CHECK();
+      }
     } else {
       float* blkmax = scores + p.ld * (int64_t)nq;
       FilterMode fa;
