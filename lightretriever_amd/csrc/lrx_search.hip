@@ -2470,27 +2470,24 @@ k_refine_band(const float* __restrict__ X, int64_t N, int64_t ldx, int D, const 
 // pairs), a workgroup stages its group's rows in LDS once and streams the query rows of its pairs from L2 through the same fp64 dot
 // product (same association, same bits as exact_dot).
 __global__ void __launch_bounds__(1024)
-k_pairs_scan(const unsigned int* __restrict__ grp_cnt, unsigned int* __restrict__ grp_off, int ngroups) {   // exclusive scan, one workgroup
+k_pairs_scan(const unsigned int* __restrict__ grp_cnt, unsigned int* __restrict__ grp_off, int ngroups) {   // exclusive scan of ngroups + 1 entries, one workgroup
   __shared__ unsigned int s_w[16];
-  __shared__ unsigned int s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int g0 = 0; g0 < ngroups + 1; g0 += 1024) {
-    const int g = g0 + tid;
-    const unsigned int v = g < ngroups ? grp_cnt[g] : 0u;
-    unsigned int x = v;                                    // inclusive scan inside the wave
+  // every thread owns a run of consecutive groups (one pass, two barriers, whatever the group count)
+  const int per = (ngroups + 1 + 1023) / 1024;
+  const int g0 = tid * per, g1 = min(g0 + per, ngroups + 1);
+  unsigned int mine = 0;
+  for (int g = g0; g < g1; ++g) mine += g < ngroups ? grp_cnt[g] : 0u;
+  unsigned int x = mine;                                     // inclusive scan of the threads' totals inside the wave
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    if (lane == 63) s_w[wave] = x;
-    __syncthreads();
-    unsigned int wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += s_w[w];
-    const unsigned int carry = s_carry;
-    if (g <= ngroups) grp_off[g] = carry + wbase + x - v;
-    __syncthreads();
-    if (tid == 1023) s_carry = carry + wbase + x;
-    __syncthreads();
+  for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+  if (lane == 63) s_w[wave] = x;
+  __syncthreads();
+  unsigned int run = x - mine;
+  for (int w = 0; w < wave; ++w) run += s_w[w];
+  for (int g = g0; g < g1; ++g) {
+    grp_off[g] = run;
+    run += g < ngroups ? grp_cnt[g] : 0u;
   }
 }
 __global__ void __launch_bounds__(256)
