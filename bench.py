@@ -42,9 +42,12 @@ def parse():
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra single-GPU legs (BASELINE configs 2-4, 8-way shard, top_k = 1000)")
     ap.add_argument("--no-sparse", action="store_true", help="skip the dense+sparse document-vector leg (SURVEY 8f N2)")
-    ap.add_argument("--legs", default="all", help="comma list of encode,search,sparse,configs,cpu (default all): one leg per run gives one "
+    ap.add_argument("--legs", default="all", help="comma list of encode,search,sparse,sharded,configs,cpu (default all): one leg per run gives one "
                     "rocprofv3 kernel-stats file per leg (tools/final_profile.sh); a partial run is marked `partial_run` and is not the headline")
     ap.add_argument("--config-legs", default="all", help="comma list of the `configs` entries to run (default all)")
+    ap.add_argument("--sharded-rows", type=int, default=10_000_000,
+                    help="rows of the row-sharded indexes of BASELINE configs[3] / configs[4] (the `sharded` leg: runs over the communicator when "
+                         "there is one, i.e. --gpus > 1 or LRX_BENCH_FORCE_DIST=1); every rank holds shard_split(rows, rank, world) of them")
     ap.add_argument("--ragged", action="store_true",
                     help="document lengths ~ clip(lognormal(5.3, 0.6), 16, seq_len), sorted longest first (mirrors hybrid_search.py:273-276) "
                          "instead of the fixed-length headline workload")
@@ -641,6 +644,145 @@ def ragged_encode_leg(args, dev):
     return out
 
 
+def reduce_max(x, dev, distributed):
+    t = torch.tensor([x], device=dev, dtype=torch.float64)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sharded_search_leg(name, index_rows, dim, nq, k, dev, rank, world, distributed, passes, seed):
+    """One row-sharded search configuration OVER THE COMMUNICATOR (BASELINE configs[3] / configs[4]; reference: Faiss IndexShards over all GPUs,
+    retriever/faiss_index.py:60-70): this rank holds shard_split(index_rows, rank, world) synthetic rows; a pass = local exact top-k (the
+    search's last kernel writes the wire words) -> ONE all_gather_into_tensor of [Q,k] 64-bit words -> lrx_merge_topk_packed on every rank.
+    Timed between barrier + synchronize, MAX over ranks; HIP events on the launch stream split a pass into local / exchange / merge.
+    Also with two searches in flight (pipeline.SearchLanes over the communicator)."""
+    from lightretriever_amd import FlatIPIndex
+    from lightretriever_amd.sharded import ShardedFlatIPIndex
+    rows, base = shard_split(index_rows, rank, world)
+    need = rows * dim * 6 + (2 << 30)
+    free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    fits = torch.tensor([1 if need < 0.85 * free else 0], device=dev, dtype=torch.int64)
+    if distributed:
+        dist.all_reduce(fits, op=dist.ReduceOp.MIN)          # every rank takes the same branch (the leg is a sequence of collectives)
+    if int(fits.item()) == 0:
+        return {"skipped": "shard of %d x %d rows (%.1f GB with its fp16 shadow) does not fit next to what this rank holds (%.1f GB free)"
+                           % (rows, dim, need / 1e9, free / 1e9)}
+    idx = FlatIPIndex(dim, capacity=rows, device=dev, id_base=base)
+    gi = torch.Generator(device=dev).manual_seed(seed + rank)
+    slot = idx.append_slot(rows)
+    step = max(1, (1 << 27) // dim)
+    for s0 in range(0, rows, step):
+        e = min(s0 + step, rows)
+        slot[s0:e] = torch.nn.functional.normalize(torch.randn(e - s0, dim, generator=gi, device=dev), dim=-1)
+    idx.commit(rows)
+    sh = ShardedFlatIPIndex(idx)
+    gq = torch.Generator(device=dev).manual_seed(seed + 1000)      # the same queries on every rank (replicated query side)
+    q = torch.nn.functional.normalize(torch.randn(nq, dim, generator=gq, device=dev), dim=-1)
+    for _ in range(2):
+        Dm, Im = sh.search(q, k)
+    marks = [{n_: torch.cuda.Event(enable_timing=True) for n_ in ("start", "local", "gathered", "merged")} for _ in range(passes)]
+    barrier_sync(distributed)
+    t0 = time.perf_counter()
+    for m in marks:
+        m["start"].record()
+        Dl, Il, Wl = sh.local_search(q, k)
+        m["local"].record()
+        Dm, Im = sh.finish(Dl, Il, Wl, on_stage=lambda st, m=m: m[st].record())
+        if Wl is None:                                        # (no exchange: plain one-process run)
+            m["gathered"].record()
+            m["merged"].record()
+    barrier_sync(distributed)
+    wall = reduce_max(time.perf_counter() - t0, dev, distributed)
+    mean = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / passes
+    local_ms, exch_ms, merge_ms = mean("start", "local"), mean("local", "gathered"), mean("gathered", "merged")
+    local_max = reduce_max(local_ms, dev, distributed)
+    pipe = None
+    try:
+        from lightretriever_amd.pipeline import SearchLanes
+        lanes = SearchLanes(sh, lanes=2)
+        for _ in range(4):
+            lanes.submit(q, k)
+        lanes.drain()
+        n_lp = max(passes, 100)
+        barrier_sync(distributed)
+        t0 = time.perf_counter()
+        pend = [lanes.submit(q, k) for _ in range(n_lp)]
+        lanes.drain()
+        barrier_sync(distributed)
+        pipe_s = reduce_max(time.perf_counter() - t0, dev, distributed)
+        Dp_, Ip_ = pend[-1].result()
+        pipe = {"lanes": 2, "passes": n_lp, "queries_per_s": round(nq * n_lp / pipe_s, 1), "ms_per_pass": round(1e3 * pipe_s / n_lp, 4),
+                "identical_to_one_at_a_time": bool(torch.equal(Dp_, Dm) and torch.equal(Ip_, Im))}
+    except Exception as e:  # noqa: BLE001
+        pipe = {"failed": "%r" % (e,)}
+    sizes = [rows]
+    if distributed:
+        t = torch.empty(dist.get_world_size(), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(t, torch.tensor([idx.ntotal], dtype=torch.int64, device=dev))
+        sizes = t.tolist()
+    out = {"workload": "%s: exact top-%d of %d queries over %d x %d fp32 rows (+ tiled fp16 shadow) row-sharded over %d rank(s); a pass = local "
+                       "search -> all-gather of [Q,k] wire words -> on-device merge on every rank" % (name, k, nq, index_rows, dim, world),
+           "queries_per_s": round(nq * passes / wall, 1), "ms_per_pass": round(1e3 * wall / passes, 4), "passes": passes,
+           "local_search_ms": round(local_ms, 4), "local_search_ms_max_over_ranks": round(local_max, 4), "exchange_ms": round(exch_ms, 4),
+           "merge_ms": round(merge_ms, 4), "two_in_flight": pipe, "rccl_ranks": dist.get_world_size() if distributed else 1,
+           "shard_rows_per_rank": sizes, "index_rows": index_rows, "dim": dim, "scaling": "strong (fixed index row-sharded over ranks)",
+           "exchange": ("all_gather_into_tensor over %s, %d bytes per rank" % (dist.get_backend(), nq * k * 8)) if distributed else "none (one process)",
+           "roofline": hbm_roofline(rows, dim, nq, k, local_max)}
+    out["roofline"]["note"] = "this rank's shard bytes / the slowest rank's local search time"
+    del sh, idx, slot
+    torch.cuda.empty_cache()
+    return out
+
+
+def sharded_encode_8b_leg(args, dev, rank, world, distributed):
+    """BASELINE configs[2]/[3] encoder under weak scaling: every rank encodes its own 128 x seq_len batch of Llama-3.1-8B dims (replicated
+    weights, no collective on the encode path); docs/s = all ranks' documents / the slowest rank's time."""
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    cfg8 = EncoderConfig.llama31_8b(args.seq_len)
+    enc8 = LrxEncoder.random_init(cfg8, seed=0, device=dev)
+    B8, S, n_t = 128, args.seq_len, max(1, min(args.steps, 3))
+    g8 = torch.Generator(device=dev).manual_seed(77 + rank)
+    ids8 = torch.randint(1000, 127000, (1 + n_t, B8 * S), generator=g8, device=dev, dtype=torch.int64).to(torch.int32)
+    cu8 = (torch.arange(B8 + 1, device=dev, dtype=torch.int64) * S).to(torch.int32)
+    out8 = torch.empty(B8, cfg8.hidden_size, device=dev)
+    enc8.encode_packed(ids8[0], cu8, S, out=out8)
+    enc8.lib.lrx_set_profiling(1 << 3)
+    barrier_sync(distributed)
+    t0 = time.perf_counter()
+    for i in range(1, 1 + n_t):
+        enc8.encode_packed(ids8[i], cu8, S, out=out8)
+    barrier_sync(distributed)
+    t8 = reduce_max(time.perf_counter() - t0, dev, distributed)
+    gu8 = enc8.get_profile()["gemm_swiglu"]
+    enc8.set_profiling(False)
+    tf8 = gu8["flops"] / (gu8["ms"] * 1e-3) / 1e12 if gu8["ms"] > 0 else 0.0
+    out = {"workload": "lightretriever-llama3.1-8b dims bf16, %d docs/step/GPU x seq_len %d on %d rank(s), %d timed steps after 1 warm-up, barrier + "
+                       "synchronize around them, MAX over ranks" % (B8, S, world, n_t),
+           "docs_per_s": round(world * n_t * B8 / t8, 2), "ms_per_step": round(1e3 * t8 / n_t, 2), "n_gpus": world, "scaling": "weak",
+           "end_to_end_tflops_per_gpu": round(n_t * B8 / t8 * cfg8.flops_per_doc(S) / 1e12, 1),
+           "roofline": {"bound": "mfma", "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (M=%d N=%d K=%d), rank 0" % (B8 * S, 2 * cfg8.intermediate_size, cfg8.hidden_size),
+                        "achieved": round(tf8, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf8 / PEAK_BF16_TFLOPS, 4),
+                        "avg_launch_ms": round(gu8["ms"] / max(gu8["launches"], 1), 4), "launches": gu8["launches"], "traffic": None}}
+    del enc8, out8, ids8
+    torch.cuda.empty_cache()
+    return out
+
+
+def sharded_config_legs(args, dev, rank, world, distributed):
+    """The BASELINE configurations that only exist over a communicator (configs[3]: 10M x 4096 rows row-sharded, configs[4]: 10M x 256 MRL rows,
+    and the 8B encoder under weak scaling), run by EVERY rank; rank 0 keeps the dict.  With one forced RCCL rank (LRX_BENCH_FORCE_DIST=1) the
+    same code runs on one GPU (tests pass a smaller --sharded-rows)."""
+    legs = {}
+    n_pass = max(20, 2 * args.steps)
+    legs["config3_10Mx4096"] = sharded_search_leg("BASELINE configs[3] index (lightretriever-llama3.1-8b width)", args.sharded_rows, 4096,
+                                                  args.queries, args.topk, dev, rank, world, distributed, n_pass, 301)
+    legs["config4_10Mx256_mrl"] = sharded_search_leg("BASELINE configs[4] index (MRL dim 256)", args.sharded_rows, 256, args.queries, args.topk,
+                                                     dev, rank, world, distributed, n_pass, 401)
+    legs["config3_encode_llama31_8b"] = sharded_encode_8b_leg(args, dev, rank, world, distributed)
+    return legs
+
+
 def shard_split(index_rows, rank, world):
     """(rows, first global row) of rank `rank` of a row-sharded index of `index_rows` rows: contiguous ranges, index_rows // world rows
     each, the remainder one row each to the first ranks -- every row has exactly one owner for ANY world size."""
@@ -694,7 +836,7 @@ def main():
            "qwen2.5-1.5b": EncoderConfig.qwen25_1_5b, "qwen2.5-3b": EncoderConfig.qwen25_3b, "qwen2.5-7b": EncoderConfig.qwen25_7b}[args.model](args.seq_len)
     if os.environ.get("LRX_FOLD_NORM") is not None:          # dev A/B switch; the default is the library's (folded)
         cfg.fold_norm = os.environ["LRX_FOLD_NORM"] != "0"
-    all_legs = ("encode", "search", "sparse", "configs", "cpu")
+    all_legs = ("encode", "search", "sparse", "sharded", "configs", "cpu")
     legs = set(all_legs) if args.legs == "all" else set(args.legs.split(","))
     if legs - set(all_legs):
         sys.stderr.write("bench.py: unknown --legs %s\n" % sorted(legs - set(all_legs)))
@@ -969,6 +1111,18 @@ def main():
                                "frac": round(mx_fl / (mx_ms / n_sp * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(mx_ms / n_sp, 3),
                                "traffic": pmc_traffic("k_gemm_bf16_nt<4>") if (args.model == "llama3.2-1b" and B == 256 and S == 512) else None}}
 
+    # ---- BASELINE configs[3] / configs[4] + the 8B encoder over the communicator (every rank takes part; N > 1, or one forced RCCL rank)
+    sharded_legs = None
+    if distributed and "sharded" in legs and batches is None:
+        if world > 1:                              # (N = 1 keeps the headline index for the single-GPU `configs` legs below)
+            del sharded, index, slot
+            enc = None
+            torch.cuda.empty_cache()
+        try:
+            sharded_legs = sharded_config_legs(args, dev, rank, world, distributed)
+        except Exception as e:  # noqa: BLE001  (never take the headline line down; a rank that fails here fails the collectives of all)
+            sharded_legs = {"failed": "%r" % (e,)}
+
     if rank != 0:
         if distributed:
             dist.destroy_process_group()
@@ -979,6 +1133,8 @@ def main():
                 "search": search, "sparse": sparse}
         if world == 1 and "configs" in legs and batches is None:
             line["configs"] = extra_legs(args, dev, index if (D == 2048 and args.index_rows == 1_000_000) else None)
+        if sharded_legs is not None:
+            line.setdefault("configs", {}).update(sharded_legs)
         print(json.dumps(line), flush=True)
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -1059,6 +1215,8 @@ def main():
                     search["roofline"]["frac_of_measured_ceiling"] = round(search["roofline"]["achieved"] / mc["hbm_stream_read"]["value"], 4)
         except Exception as e:  # noqa: BLE001  (additional legs: never take the headline line down with them)
             line["configs"] = {"failed": "%r" % (e,)}
+    if sharded_legs is not None:
+        line.setdefault("configs", {}).update(sharded_legs)
     if world == 1 and "cpu" in legs:
         try:
             cb = cpu_baseline(cfg, S, args.topk, D)

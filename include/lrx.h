@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define LRX_ABI_VERSION 7
+#define LRX_ABI_VERSION 8
 
 enum {
   LRX_OK = 0,
@@ -137,6 +137,21 @@ int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_encoder_weights
                         int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* (ABI 8) The same with the pooling strategy of finetune/dense_pooling.py:12-82 as an argument (`--pooling_strategy`; the released models use
+ * 'lasttoken', which is what the two entry points above compute): */
+#define LRX_POOL_LASTTOKEN 0       /* the sequence's last token (dense_pooling.py:48-55) */
+#define LRX_POOL_CLS 1             /* its first token (:32-33) */
+#define LRX_POOL_MEAN 2            /* mean of the final-norm rows of all its tokens (:35-36), fp32, tokens added in order */
+#define LRX_POOL_SECOND_TO_LAST 3  /* token len - 2 (:57-67) */
+#define LRX_POOL_THIRD_TO_LAST 4   /* token len - 3 (:69-79) */
+/* LASTTOKEN runs the final layer's O-projection / MLP on the pooled rows only; every other strategy runs all layers over all tokens and pools
+ * from the residual stream (final norm inside the pooling kernel, fp32 when the stream is).  A sequence shorter than its strategy needs (the
+ * reference asserts there) gets a zero row and raises lrx_device_error_count.  'avg_first_last' / 'avg_top2' (other layers' states): not served. */
+int lrx_encode_packed_pooled(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids,
+                             const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t pooling,
+                             float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* shadow_out,
+                             int64_t shadow_row0, float* row_bounds, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Dense + sparse document vectors in one pass.  Replaces HybridModel.encode_passage with encode_sparse
  * (finetune/modeling_hybrid.py:248-323): LM forward -> dense_reps (as lrx_encode_packed; dense_out may be NULL) and
  * sparse_reps = sparsify(max over the tokens tok_mask selects of hidden_t . lm_head^T)  (aggregate, sparse_pooling.py:244-278;
@@ -177,8 +192,10 @@ int lrx_get_profile(float* ms, double* flops, int32_t* launches);
  * row is zero-filled and a device-side counter is raised (lrx_device_error_count).                                               */
 int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, int32_t vocab, void* out,
                          void* stream);
-/* Number of out-of-range token ids any embedding gather (stand-alone or inside lrx_encode_*) has met since the last reset; -1 if the
- * read failed.  SYNCHRONISES the device (a blocking copy): call it at a point where the caller waits for results anyway.         */
+/* Number of out-of-range token ids any embedding gather (stand-alone or inside lrx_encode_*) has met since the last reset, plus the
+ * attention work lists whose builder ran out of room (lrx_attn_build_items: their launches then compute nothing); -1 if the read
+ * failed.  Non-zero = the rows of those calls are not the model's.  SYNCHRONISES the device (a blocking copy): call it at a point where
+ * the caller waits for results anyway (LrxExactSearchModel.encode does, once per encode call, and raises).                         */
 int64_t lrx_device_error_count(int32_t reset);
 /* (ABI 6) Measurement aid: with LRX_FUSED_PHASES bit 7 set in the environment the fused filter launch of the bounded search (sample + selection
  * + main pass in one persistent kernel) records per-workgroup phase timestamps (100 MHz clock; 8 words per workgroup: start, sample done,
@@ -227,7 +244,9 @@ int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens, int32_t n
  *   lrx_attn_items_bytes   size of the list; bounded by (total_tokens / 64 + n_seqs) x kv heads and non-decreasing in total_tokens and
  *                          max_seqlen (size once with the largest batch / longest sequence the caller will ever pass)
  *   lrx_attn_build_items   fills `items` (device memory, 16-byte aligned) on `stream`; one list per (cu_seqlens, max_seqlen, head
- *                          layout, last_tile_only) -- a list built with other arguments than the launch's gives wrong results
+ *                          layout, last_tile_only) -- a list built with other arguments than the launch's gives wrong results.  Launches
+ *                          nothing when the launch with the same arguments would not read a list (the K/V-resident geometries below).
+ *                          At most 1024 persistent workgroups are planned (the builder is one block), whatever the CU count
  *   lrx_attn_varlen_causal_items   the launch (lrx_attn_varlen_causal's arguments + the list); `items` must stay untouched until it has
  *                          run.  Geometries served by the K/V-resident kernel (head_dim 64, max_seqlen <= 512) do not read the list.          */
 size_t lrx_attn_items_bytes(int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads,
@@ -329,6 +348,12 @@ int lrx_pool_norm(const void* hidden, const void* final_norm_w, const int32_t* c
 int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                         int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim,
                         int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream);
+
+/* (ABI 8) ... and with the pooling strategy (LRX_POOL_*; cu_seqlens required for anything but LASTTOKEN): pooling(last_hidden, mask, strategy)
+ * of finetune/dense_pooling.py:12-82 over `hidden` = the residual stream before the final norm, which runs inside (per pooled token). */
+int lrx_pool_norm_mode(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
+                       int32_t hidden_size, float eps, int32_t pooling, float* out, int64_t out_row_stride, int32_t out_dim,
+                       int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream);
 
 /* Query side.  Replaces emb_bag.forward + slice + F.normalize at finetune/modeling_hybrid.py:472-490
  * (torch.nn.EmbeddingBag mode='mean', padding_idx) with inputs from tokenize_nonctx_qry_emb_bag

@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRX_LIB_DEV_VARIANT") or os.path.join(HERE, "liblrx.so")   # env override: tools/ diagnostics only
 LRX_PROF_CLASSES = 8
-ABI_VERSION = 7   # LRX_ABI_VERSION of include/lrx.h
+ABI_VERSION = 8   # LRX_ABI_VERSION of include/lrx.h
 # lrx_flat_ip_search_bounded flags (LRX_SEARCH_FILTER_*): A/B runs and tests; the hits do not depend on them
 SEARCH_FILTER_AUTO, SEARCH_FILTER_MATRIX, SEARCH_FILTER_SCORE_FREE, SEARCH_FILTER_SCORE_FREE_NO_GEMM = 0, 1, 2, 3
 SEARCH_FUSED_ALWAYS, SEARCH_FUSED_NEVER = 4, 8
@@ -34,6 +34,9 @@ class EncoderWeightsC(C.Structure):
                 ("layers", C.POINTER(LayerWeightsC))]
 
 
+# LRX_POOL_* of include/lrx.h: `--pooling_strategy` (finetune/dense_pooling.py:12-82)
+POOLING = {"lasttoken": 0, "cls": 1, "mean": 2, "second_to_last": 3, "third_to_last": 4}
+
 _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes): exactly the entry points include/lrx.h declares
@@ -44,6 +47,9 @@ SIGNATURES = {
     "lrx_encode_packed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),
     "lrx_encode_packed_shard": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P, _I64,
                                        _P, _P, _SZ, _P]),
+    "lrx_encode_packed_pooled": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _I32, _I32, _P,
+                                        _I64, _P, _P, _SZ, _P]),
+    "lrx_pool_norm_mode": (_I32, [_P, _P, _P, _I32, _I32, _F, _I32, _P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P]),
     "lrx_encode_hidden": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _P, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "lrx_encode_prefixed_workspace_bytes": (_SZ, [C.POINTER(EncoderConfigC), _I32, _I32, _I32]),
     "lrx_encode_prefixed": (_I32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), _P, _I32, _P, _I32, _I32, _P, _I64, _I32, _I32, _P, _SZ, _P]),

@@ -495,13 +495,19 @@ k_attn_build_items(const int32_t* __restrict__ cu, int32_t* __restrict__ list_st
   }
   if (b >= n_wg) return;
   const int start = s_scan[b] - mine;
-  list_start[b] = start;
-  if (b == n_wg - 1) list_start[n_wg] = s_scan[b];
   if (s_scan[n_wg - 1] + 2 > cap_items) {                        // (cannot happen: lrx_attn_items_bytes bounds the same walk)
-    if (b == 0) atomicAdd(overflow, 1);
-    if (start < cap_items) items[start] = i32x4{0, 0, 0, 0};
+    // every workgroup's list becomes the empty list at slot 0 (the launch then reads nothing out of range and computes nothing); the
+    // counter is part of lrx_device_error_count, which the encoders' callers check: loud, not silently wrong rows
+    if (b == 0) {
+      atomicAdd(overflow, 1);
+      for (int i = 0; i < 3 && i < cap_items; ++i) items[i] = i32x4{0, 0, 0, 0};
+    }
+    list_start[b] = 0;
+    if (b == n_wg - 1) list_start[n_wg] = 0;
     return;
   }
+  list_start[b] = start;
+  if (b == n_wg - 1) list_start[n_wg] = s_scan[b];
   const int n = walk(items + start);
   items[start + n] = i32x4{0, 0, 0, 0};
   if (b == n_wg - 1) { items[start + n + 1] = i32x4{0, 0, 0, 0}; items[start + n + 2] = i32x4{0, 0, 0, 0}; }   // padding behind the last end marker
@@ -1465,7 +1471,10 @@ static AttnPlan attn_plan(int n_seqs, int max_seqlen, int nq, int nkv, int head_
   p.nqt = (int)lrx_cdiv(max_seqlen, 64);
   p.n_items = (int64_t)(last_tile_only ? n_seqs : (int64_t)n_seqs * p.nqt) * nkv * p.nparts;
   const int per_cu = head_dim == 128 ? 1 : (p.grp <= 2 ? 4 : 2);
-  const int64_t slots = (int64_t)attn_cu_count() * per_cu;
+  // (at most 1024 workgroups: the list builder is ONE 1024-thread block with a thread per workgroup -- 256 CUs x 4 on MI355X is exactly
+  // that; a part with more CUs runs the same persistent walk on 1024 of its slots instead of failing)
+  const int64_t slots_chip = (int64_t)attn_cu_count() * per_cu;
+  const int64_t slots = slots_chip < 1024 ? slots_chip : 1024;
   p.gs = 0;
   if (!last_tile_only && p.n_items >= slots && slots % 8 == 0) {
     const int spx = (int)(slots / 8);
@@ -1480,6 +1489,15 @@ __device__ int g_attn_items_overflow;
 extern "C" int lrx_debug_attn_items_overflow(int* out) {   // tests: the builder never ran out of list slots (synchronises)
   LRX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_items_overflow), sizeof(int)));
   return LRX_OK;
+}
+unsigned int lrx_attn_list_overflows(int* ok, int reset) {   // part of lrx_device_error_count (lrx_elementwise.hip)
+  int v = 0;
+  *ok = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_attn_items_overflow), sizeof(v)) == hipSuccess;
+  if (*ok && reset && v) {
+    const int z = 0;
+    *ok = hipMemcpyToSymbol(HIP_SYMBOL(g_attn_items_overflow), &z, sizeof(z)) == hipSuccess;
+  }
+  return (unsigned int)v;
 }
 static int attn_check_layout(int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim) {
   LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "attn: head_dim=%d unsupported (64 or 128)", head_dim);
@@ -1501,15 +1519,18 @@ extern "C" size_t lrx_attn_items_bytes(int32_t n_seqs, int32_t total_tokens, int
   const AttnPlan p = attn_plan(n_seqs, max_seqlen, num_q_heads, num_kv_heads, head_dim, last_tile_only);
   return attn_list_hdr_bytes(p) + 16 * (size_t)attn_list_item_bound(p, n_seqs, total_tokens, num_kv_heads, last_tile_only);
 }
+static bool attn_uses_resident64(int head_dim, int max_seqlen, int last_tile_only);
 extern "C" int lrx_attn_build_items(const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads,
                                     int32_t num_kv_heads, int32_t head_dim, int32_t last_tile_only, void* items, size_t items_bytes, void* stream) {
   int rc = attn_check_layout(num_q_heads, num_kv_heads, head_dim);
   if (rc) return rc;
   if (n_seqs <= 0 || total_tokens <= 0) return LRX_OK;
   LRX_CHECK_ARG(max_seqlen > 0, "attn: max_seqlen must be > 0");
+  // the launch with these arguments runs the K/V-resident kernel, which derives its tasks itself: nothing to build, nothing read
+  if (attn_uses_resident64(head_dim, max_seqlen, last_tile_only)) return LRX_OK;
   const AttnPlan p = attn_plan(n_seqs, max_seqlen, num_q_heads, num_kv_heads, head_dim, last_tile_only);
   LRX_CHECK_ARG(p.n_items < (1ll << 31), "attn: %lld work items", (long long)p.n_items);
-  LRX_CHECK_ARG(p.n_wg <= 1024, "attn: %d workgroups (the list builder is one block)", p.n_wg);
+  LRX_CHECK_ARG(p.n_wg <= 1024, "attn: %d workgroups (the list builder is one block)", p.n_wg);   // (attn_plan clamps its slots to 1024)
   const size_t need = attn_list_hdr_bytes(p) + 16 * (size_t)attn_list_item_bound(p, n_seqs, total_tokens, num_kv_heads, last_tile_only);
   LRX_CHECK_ARG(items != nullptr && ((uintptr_t)items & 15) == 0, "attn: the work list must be 16-byte aligned device memory");
   LRX_CHECK_ARG(items_bytes >= need, "attn: work list %zu B < required %zu B", items_bytes, need);

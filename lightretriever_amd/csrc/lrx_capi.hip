@@ -218,7 +218,8 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
         if ((rc = lrx_gather_last_rows(Aqkv, tail_cu, B, H, ws.hr, s))) return rc;
         if ((rc = lrx_gather_rows_u32(ws.pos, tail_cu, B, ws.posr, s))) return rc;
         if (scaled && (rc = lrx_gather_rows_u32(ws.rsA, tail_cu, B, ws.rsr, s))) return rc;
-        // (C = ws.ar viewed with the full q|k|v row width: only its first QD columns are written)
+        // (num_kv_heads = 0 in this call: C = ws.ar is [B, QD] with row stride QD -- the q heads are the whole row; ws.ar holds B x max(H, QD)
+        // elements, carve())
         if ((rc = lrx_gemm_qkv_rope_slice(ws.hr, L.wqkv, ws.ar, bq, ws.posr, w->rope_cos, w->rope_sin, B, H, nq, 0, d, scaled ? ws.rsr : nullptr, 0, nq, s))) return rc;
         if ((rc = lrx_scatter_last_rows(ws.ar, tail_cu, B, QD, ws.qkv, QKV, s))) return rc; }
     } else
@@ -302,26 +303,43 @@ static int final_norm_rows(const lrx_encoder_config* c, const lrx_encoder_weight
   return lrx_rmsnorm(ws.x, w->final_norm, out, T, c->hidden_size, c->rms_eps, s);
 }
 
-extern "C" int lrx_encode_packed_shard(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,
-                                       int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, float* out, int64_t out_row_stride,
-                                       int32_t out_dim, int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+extern "C" int lrx_encode_packed_pooled(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,
+                                        int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t pooling, float* out, int64_t out_row_stride,
+                                        int32_t out_dim, int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
   int rc = check_call(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, workspace, workspace_bytes);
   if (rc) return rc;
   LRX_CHECK_ARG(out && out_dim > 0 && out_dim <= cfg->hidden_size && out_row_stride >= out_dim, "encode: bad output spec (dim=%d stride=%lld)",
                 out_dim, (long long)out_row_stride);
+  LRX_CHECK_ARG(pooling >= LRX_POOL_LASTTOKEN && pooling <= LRX_POOL_THIRD_TO_LAST, "encode: pooling=%d (LRX_POOL_*)", pooling);
   hipStream_t s = (hipStream_t)stream;
   EncWs ws = carve(cfg, total_tokens, n_seqs, (char*)workspace);
   prof_begin();
-  if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, true, s))) return rc;
-  {
+  const bool pr = cfg->precise_stream != 0;
+  if (pooling == LRX_POOL_LASTTOKEN) {
+    // the released models' strategy: after the final layer's attention only the last-token rows are computed (run_layers' pooled tail)
+    if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, true, s))) return rc;
     ProfScope p(s, 6, 0);  // ws.xr / ws.xr32 holds the compacted last-token rows -> cu_seqlens = NULL
-    const bool pr = cfg->precise_stream != 0;
-    if ((rc = lrx_pool_norm_shard(pr ? (const void*)ws.xr32 : (const void*)ws.xr, w->final_norm, nullptr, n_seqs, cfg->hidden_size, cfg->rms_eps, out,
-                                  out_row_stride, out_dim, normalize, shadow_out, shadow_row0, row_bounds, pr ? 1 : 0, s)))
+    if ((rc = lrx_pool_norm_mode(pr ? (const void*)ws.xr32 : (const void*)ws.xr, w->final_norm, nullptr, n_seqs, cfg->hidden_size, cfg->rms_eps,
+                                 LRX_POOL_LASTTOKEN, out, out_row_stride, out_dim, normalize, shadow_out, shadow_row0, row_bounds, pr ? 1 : 0, s)))
+      return rc;
+  } else {
+    // any other strategy of finetune/dense_pooling.py: every layer over every token, then the final norm + pooling over the stream's rows
+    if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, false, s))) return rc;
+    ProfScope p(s, 6, 0);
+    if ((rc = lrx_pool_norm_mode(pr ? (const void*)ws.x32 : (const void*)ws.x, w->final_norm, cu_seqlens, n_seqs, cfg->hidden_size, cfg->rms_eps,
+                                 pooling, out, out_row_stride, out_dim, normalize, shadow_out, shadow_row0, row_bounds, pr ? 1 : 0, s)))
       return rc;
   }
   return prof_end(s);
+}
+
+extern "C" int lrx_encode_packed_shard(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,
+                                       int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, float* out, int64_t out_row_stride,
+                                       int32_t out_dim, int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  return lrx_encode_packed_pooled(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, LRX_POOL_LASTTOKEN, out, out_row_stride, out_dim, normalize,
+                                  shadow_out, shadow_row0, row_bounds, workspace, workspace_bytes, stream);
 }
 
 extern "C" int lrx_encode_packed(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu_seqlens,

@@ -150,14 +150,18 @@ extern "C" int64_t lrx_device_saturation_count(int32_t reset) {
   return (int64_t)v + (int64_t)g;
 }
 
+unsigned int lrx_attn_list_overflows(int* ok, int reset);   // lrx_attn.hip: attention work lists the builder could not fit (their launches compute nothing)
 extern "C" int64_t lrx_device_error_count(int32_t reset) {
   unsigned int v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bad_token_ids), sizeof(v)) != hipSuccess) return -1;
+  int ok = 0;
+  const unsigned int a = lrx_attn_list_overflows(&ok, reset);
+  if (!ok) return -1;
   if (reset && v) {
     const unsigned int z = 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_bad_token_ids), &z, sizeof(z)) != hipSuccess) return -1;
   }
-  return (int64_t)v;
+  return (int64_t)v + (int64_t)a;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -340,31 +344,59 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // row's producer.
 // F32: `hidden` holds fp32 rows (the precise residual stream): the final norm then runs in fp32 without the two bf16 roundings of HF's
 // bf16 LlamaRMSNorm (the reference for the 1e-3 bound is the fp32 model).
+// mode (LRX_POOL_*, include/lrx.h; finetune/dense_pooling.py:12-82): which row(s) of the sequence are pooled -- its last token (the
+// released models), its first ('cls'), its second / third to last, or the MEAN of the final-norm rows of all its tokens (one token at a
+// time through the same norm, fp32 accumulation in token order).  A sequence too short for its strategy (the reference asserts) gets a
+// zero row and raises the input-error counter (lrx_device_error_count).
 template <bool F32>
 __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidden_v, const __bf16* __restrict__ w,
                                                    const int32_t* __restrict__ cu, int H, float eps, float* __restrict__ out,
                                                    int64_t out_stride, int out_dim, int normalize, __bf16* __restrict__ shadow,
-                                                   int64_t shadow_row0, float* __restrict__ bounds) {
+                                                   int64_t shadow_row0, float* __restrict__ bounds, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* row = (float*)smem_raw;  // H floats
   float* red = row + H;           // 4 floats
+  float* acc = red + 4;           // H floats (LRX_POOL_MEAN only)
   int b = blockIdx.x;
-  int64_t t = cu ? (int64_t)cu[b + 1] - 1 : (int64_t)b;
-  float ss = 0.f;
-  for (int i = threadIdx.x; i < H; i += 256) {
-    const float f = F32 ? ((const float*)hidden_v)[t * H + i] : bf2f(((const __bf16*)hidden_v)[t * H + i]);
-    row[i] = f;
-    ss += f * f;
+  int64_t t0 = cu ? (int64_t)cu[b + 1] - 1 : (int64_t)b, t1 = t0 + 1;      // rows [t0, t1) are pooled
+  bool bad = false;
+  if (cu && mode != LRX_POOL_LASTTOKEN) {
+    const int64_t s0 = cu[b], s1 = cu[b + 1];
+    if (mode == LRX_POOL_MEAN) { t0 = s0; t1 = s1; bad = s1 <= s0; }
+    else {
+      t0 = mode == LRX_POOL_CLS ? s0 : s1 - (mode == LRX_POOL_SECOND_TO_LAST ? 2 : 3);
+      t1 = t0 + 1;
+      bad = t0 < s0 || s1 <= s0;
+    }
   }
-  ss = block_sum_256(ss, red);
-  float rstd = rsqrtf(ss / (float)H + eps);
+  if (bad) {
+    if (threadIdx.x == 0) atomicAdd(&g_bad_token_ids, 1u);
+    t1 = t0;                                                            // nothing pooled: a zero row goes out
+  }
+  const bool mean = mode == LRX_POOL_MEAN && cu != nullptr;
+  if (mean || bad) for (int i = threadIdx.x; i < out_dim; i += 256) { if (mean) acc[i] = 0.f; else row[i] = 0.f; }
   float n2 = 0.f;
-  for (int i = threadIdx.x; i < out_dim; i += 256) {
-    float y = F32 ? bf2f(w[i]) * (row[i] * rstd)
-                  : bf2f(f2bf(bf2f(w[i]) * bf2f(f2bf(row[i] * rstd))));  // HF LlamaRMSNorm rounding order, bf16 result
-    row[i] = y;
-    n2 += y * y;
+  for (int64_t t = t0; t < t1; ++t) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < H; i += 256) {
+      const float f = F32 ? ((const float*)hidden_v)[t * H + i] : bf2f(((const __bf16*)hidden_v)[t * H + i]);
+      row[i] = f;
+      ss += f * f;
+    }
+    ss = block_sum_256(ss, red);
+    float rstd = rsqrtf(ss / (float)H + eps);
+    for (int i = threadIdx.x; i < out_dim; i += 256) {
+      float y = F32 ? bf2f(w[i]) * (row[i] * rstd)
+                    : bf2f(f2bf(bf2f(w[i]) * bf2f(f2bf(row[i] * rstd))));  // HF LlamaRMSNorm rounding order, bf16 result
+      if (mean) acc[i] += y; else row[i] = y;
+    }
+    // (thread i owns columns i, i + 256, ... of row and acc in every loop of this kernel: no barrier needed between the tokens)
   }
+  if (mean) {
+    const float inv = t1 > t0 ? 1.0f / (float)(t1 - t0) : 0.f;
+    for (int i = threadIdx.x; i < out_dim; i += 256) row[i] = acc[i] * inv;
+  }
+  for (int i = threadIdx.x; i < out_dim; i += 256) n2 += row[i] * row[i];
   n2 = block_sum_256(n2, red);
   float scale = normalize ? 1.0f / fmaxf(sqrtf(n2), 1e-12f) : 1.0f;
   float* o = out + (int64_t)b * out_stride;
@@ -394,21 +426,33 @@ __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidd
   }
 }
 
+extern "C" int lrx_pool_norm_mode(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
+                                  int32_t hidden_size, float eps, int32_t pooling, float* out, int64_t out_row_stride, int32_t out_dim,
+                                  int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream) {
+  LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden_size, "pool_norm: out_dim=%d out of range (H=%d)", out_dim, hidden_size);
+  LRX_CHECK_ARG(shadow_out == nullptr || (out_dim % 64 == 0 && shadow_row0 >= 0), "pool_norm: the tiled shadow needs out_dim %% 64 == 0 (out_dim %d)", out_dim);
+  LRX_CHECK_ARG(pooling >= LRX_POOL_LASTTOKEN && pooling <= LRX_POOL_THIRD_TO_LAST, "pool_norm: pooling=%d (LRX_POOL_*)", pooling);
+  LRX_CHECK_ARG(pooling == LRX_POOL_LASTTOKEN || cu_seqlens != nullptr, "pool_norm: pooling %d needs cu_seqlens (rows already compacted are last-token rows)", pooling);
+  if (n_seqs == 0) return LRX_OK;
+  size_t smem = (size_t)(hidden_size + 4 + (pooling == LRX_POOL_MEAN ? hidden_size : 0)) * sizeof(float);
+  LRX_CHECK_ARG(smem <= 160 * 1024, "pool_norm: hidden_size=%d does not fit the LDS", hidden_size);
+  if (smem > 64 * 1024)        // (beyond the default dynamic-LDS limit: H > 8188, or mean pooling at H > 8190 / 2)
+    LRX_HIP(hipFuncSetAttribute(hidden_f32 ? (const void*)k_pool_norm<true> : (const void*)k_pool_norm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  if (hidden_f32)
+    hipLaunchKernelGGL(k_pool_norm<true>, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, hidden, (const __bf16*)final_norm_w, cu_seqlens,
+                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row0, row_bounds, pooling);
+  else
+    hipLaunchKernelGGL(k_pool_norm<false>, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, hidden, (const __bf16*)final_norm_w, cu_seqlens,
+                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row0, row_bounds, pooling);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
 extern "C" int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                                    int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize,
                                    void* shadow_out, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream) {
-  LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden_size, "pool_norm: out_dim=%d out of range (H=%d)", out_dim, hidden_size);
-  LRX_CHECK_ARG(shadow_out == nullptr || (out_dim % 64 == 0 && shadow_row0 >= 0), "pool_norm: the tiled shadow needs out_dim %% 64 == 0 (out_dim %d)", out_dim);
-  if (n_seqs == 0) return LRX_OK;
-  size_t smem = (size_t)(hidden_size + 4) * sizeof(float);
-  if (hidden_f32)
-    hipLaunchKernelGGL(k_pool_norm<true>, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, hidden, (const __bf16*)final_norm_w, cu_seqlens,
-                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row0, row_bounds);
-  else
-    hipLaunchKernelGGL(k_pool_norm<false>, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, hidden, (const __bf16*)final_norm_w, cu_seqlens,
-                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row0, row_bounds);
-  LRX_LAUNCH_CHECK();
-  return LRX_OK;
+  return lrx_pool_norm_mode(hidden, final_norm_w, cu_seqlens, n_seqs, hidden_size, eps, LRX_POOL_LASTTOKEN, out, out_row_stride, out_dim, normalize,
+                            shadow_out, shadow_row0, row_bounds, hidden_f32, stream);
 }
 
 extern "C" int lrx_pool_norm(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,

@@ -298,9 +298,13 @@ class LrxEncoder:
         return C.addressof(self._handle)
 
     def encode_packed(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, out: Optional[torch.Tensor] = None,
-                      out_dim: Optional[int] = None, normalize: bool = True) -> torch.Tensor:
+                      out_dim: Optional[int] = None, normalize: bool = True, pooling: str = "lasttoken") -> torch.Tensor:
         """ids int32 [T], cu_seqlens int32 [B+1] (device).  Writes fp32 [B, out_dim] rows into `out` (e.g. a slice of the
-        index shard: no host round trip) and returns it."""
+        index shard: no host round trip) and returns it.  pooling: `--pooling_strategy` of the reference (finetune/dense_pooling.py:12-82):
+        'lasttoken' (the released models), 'cls', 'mean', 'second_to_last', 'third_to_last'."""
+        if pooling not in _lib.POOLING:
+            raise NotImplementedError(f"pooling strategy {pooling!r}: served are {sorted(_lib.POOLING)} ('avg_first_last' / 'avg_top2' pool over "
+                                      "other layers' hidden states)")
         self._check_batch(ids, cu_seqlens)
         T, B = ids.numel(), cu_seqlens.numel() - 1
         D = out_dim or self.cfg.hidden_size
@@ -313,9 +317,9 @@ class LrxEncoder:
         from .index import shard_of
         hit = shard_of(out) if D == out.shape[1] else None
         shadow, srow0, bounds = hit[0].shard_sink(hit[1], B) if hit is not None else (None, 0, None)
-        _lib.check(self.lib.lrx_encode_packed_shard(C.byref(self._ccfg), C.byref(self._cw), _lib.ptr(ids), _lib.ptr(cu_seqlens), B, T,
-                                                    int(max_seqlen), _lib.ptr(out), out.stride(0), D, int(normalize), _lib.ptr(shadow),
-                                                    int(srow0), _lib.ptr(bounds), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+        _lib.check(self.lib.lrx_encode_packed_pooled(C.byref(self._ccfg), C.byref(self._cw), _lib.ptr(ids), _lib.ptr(cu_seqlens), B, T,
+                                                     int(max_seqlen), _lib.POOLING[pooling], _lib.ptr(out), out.stride(0), D, int(normalize),
+                                                     _lib.ptr(shadow), int(srow0), _lib.ptr(bounds), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
         return out[:B, :D]
 
     def encode_hidden(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int) -> torch.Tensor:

@@ -39,7 +39,7 @@ class InferenceArguments:
     cumulative_seq: bool = True                         # packed varlen is the only layout here
     liger_kernel: bool = False
     # model args that change the dense-path numerics (finetune/arguments.py:75-335)
-    pooling_strategy: Optional[str] = None             # finetune/arguments.py:83: None; 'lasttoken' is the one implemented (None is served as it)
+    pooling_strategy: Optional[str] = None             # finetune/arguments.py:85-90: None is served as the released models' 'lasttoken'; cls / mean / second_to_last / third_to_last too
     score_function: str = "cos_sim"
     dense_shrink_dim: Optional[int] = None
     lowercase: bool = False
@@ -111,8 +111,10 @@ class InferenceArguments:
         if self.normalize is None:
             self.normalize = self.score_function == "cos_sim"   # finetune/arguments.py:312-317
         self.pad_token, self.sep_token = default_special_tokens(self.model_name_or_path, self.pad_token, self.sep_token)
-        if self.pooling_strategy not in (None, "lasttoken"):
-            raise NotImplementedError("the MI355X path implements the shipped 'lasttoken' pooling only")
+        if self.pooling_strategy not in (None, "lasttoken", "cls", "mean", "second_to_last", "third_to_last"):
+            raise NotImplementedError(f"--pooling_strategy {self.pooling_strategy}: 'avg_first_last' / 'avg_top2' pool over other layers' hidden states "
+                                      "(finetune/dense_pooling.py:38-46) and are not served; lasttoken (the released models), cls, mean, "
+                                      "second_to_last and third_to_last are")
         if self.fp16:
             raise NotImplementedError("bf16 is the compute type of the HIP encoder")
         # options whose non-default value selects a part of the reference this path does not implement: fail loudly, never silently
@@ -196,7 +198,8 @@ class PytorchRPCExactSearchModel(LrxExactSearchModel):
                             sparse_min_tokens_to_keep=args.sparse_min_tokens_to_keep,
                             hybrid_use_dense_vector=args.hybrid_use_dense_vector if hybrid else True,      # EncoderModel: the symmetric dense vector
                             hybrid_use_emb_vector=args.hybrid_use_emb_vector if hybrid else False,
-                            noncontextual_query_embedding=args.noncontextual_query_embedding if hybrid else False)
+                            noncontextual_query_embedding=args.noncontextual_query_embedding if hybrid else False,
+                            pooling_strategy=args.pooling_strategy)
         super().__init__(model=hm, tokenizer=tok, q_max_len=args.q_max_len, p_max_len=args.p_max_len,
                          append_prompt_sep=args.append_prompt_sep, eval_batch_size_embedding_bag=args.eval_batch_size_embedding_bag,
                          token_id_vector_type=args.token_id_vector_type, noncontextual_prompt_prefix=args.noncontextual_prompt_prefix,

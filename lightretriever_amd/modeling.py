@@ -154,11 +154,19 @@ class LrxHybridModel:
                  add_sep_token: bool = False, sparse_use_relu: bool = True, sparse_use_log_saturation: bool = True,
                  sparse_top_k_psg: int = 0, sparse_top_p_psg: float = 1.0, sparse_min_tokens_to_keep: int = 8,
                  sparse_round_bf16: bool = True, hybrid_use_dense_vector: bool = False, hybrid_use_emb_vector: bool = True,
-                 noncontextual_query_embedding: bool = True):
+                 noncontextual_query_embedding: bool = True, pooling_strategy: Optional[str] = None):
         """The sparse_* / add_sep_token / sep_token_id / hybrid_use_* / noncontextual_query_embedding fields carry the reference's
         ModelArguments of the same names (finetune/arguments.py:175-290); encode_sparse = hybrid_use_sparse_vector or
         hybrid_use_token_id_vector."""
         self.encoder = encoder
+        # `--pooling_strategy` (finetune/arguments.py:85-90; it overrides pooling_strategy_qry / _psg, :329-331): the strategy of the dense
+        # document vector and of the LM-encoded dense query vector.  None is served as the released models' 'lasttoken'.
+        self.pooling_strategy = pooling_strategy or "lasttoken"
+        from . import _lib as _l
+        if self.pooling_strategy not in _l.POOLING:
+            raise NotImplementedError(f"--pooling_strategy {self.pooling_strategy}: served are {sorted(_l.POOLING)}")
+        if encode_sparse and self.pooling_strategy != "lasttoken":
+            raise NotImplementedError("dense + sparse document vectors in one pass (lrx_encode_packed_sparse) pool the dense vector from the last token only")
         self.hybrid_use_dense_vector = hybrid_use_dense_vector
         self.hybrid_use_emb_vector = hybrid_use_emb_vector
         self.noncontextual_query_embedding = noncontextual_query_embedding
@@ -193,7 +201,8 @@ class LrxHybridModel:
         if encode_sparse or (encode_sparse is None and self.encode_sparse):
             return self._encode_passage_sparse(psg, bool(normalize), out)
         ids, cu, max_len = self._packed_lm_inputs(psg, "encode_passage")
-        reps = self.encoder.encode_packed(ids, cu, max_len, out=out, out_dim=self.dense_shrink_dim, normalize=bool(normalize))
+        reps = self.encoder.encode_packed(ids, cu, max_len, out=out, out_dim=self.dense_shrink_dim, normalize=bool(normalize),
+                                          pooling=self.pooling_strategy)
         return {"dense_reps": reps}
 
     def _packed_lm_inputs(self, batch: dict, who: str):
@@ -274,7 +283,8 @@ class LrxHybridModel:
         out = {}
         lm_in = self._packed_lm_inputs(qry, "encode_query") if (encode_dense or (encode_emb and not self.noncontextual_query_embedding)) else None
         if encode_dense:
-            out["dense_reps"] = self.encoder.encode_packed(lm_in[0], lm_in[1], lm_in[2], out_dim=self.dense_shrink_dim, normalize=bool(normalize))
+            out["dense_reps"] = self.encoder.encode_packed(lm_in[0], lm_in[1], lm_in[2], out_dim=self.dense_shrink_dim, normalize=bool(normalize),
+                                                           pooling=self.pooling_strategy)
         if encode_emb and self.noncontextual_query_embedding:
             if self.emb_bag is None:
                 raise AssertionError("Please load or construct an EmbeddingBag before encoding queries")
@@ -490,6 +500,12 @@ class LrxExactSearchModel:
     # the reference's EncoderModel returns a bare Tensor, its HybridModel a dict (exact_search_torchrpc.py:288-295: "if emb is single emb
     # type, we should return the emb alone"): True = hand back the only representation itself
     single_tensor_output: bool = False
+    # What encode() / encode_queries() do when the device counters of the calls they made are non-zero (read ONCE per call, after the last
+    # batch was enqueued: one blocking 8-byte copy per corpus chunk).  lrx_device_error_count (token ids outside the embedding table, an
+    # attention work list that did not fit) always raises: those rows are not the model's.  lrx_device_saturation_count (q|k|v or shadow
+    # elements that were NaN or beyond fp16's +-65504 and were stored as +-65504 -- the precondition of the fp16 attention operands,
+    # csrc/lrx_gemm.hip:f2h_bits): "raise" (default), "warn" (log at WARNING with the count) or "ignore" (do not read either counter).
+    on_fp16_saturation: str = "raise"
 
     def __post_init__(self):
         # every id the tokenizer can produce needs an embedding row (the reference grows the matrix with resize_emb,
@@ -499,6 +515,29 @@ class LrxExactSearchModel:
         if enc is not None and self.tokenizer is not None and hasattr(self.tokenizer, "__len__") and len(self.tokenizer) > enc.cfg.vocab_size:
             raise ValueError(f"tokenizer has {len(self.tokenizer)} tokens but the encoder only {enc.cfg.vocab_size} embedding rows "
                              "(load the encoder with loader.encoder_from_pretrained(..., tokenizer=tokenizer))")
+
+    def _check_device_counters(self, what: str):
+        """Make the library's device-side counters loud on the product path (nobody read them).  Synchronises."""
+        if self.on_fp16_saturation == "ignore" or not isinstance(self.model, LrxHybridModel):     # (host-side tests drive the adapter with stand-ins)
+            return
+        if self.on_fp16_saturation not in ("raise", "warn"):
+            raise ValueError(f"on_fp16_saturation={self.on_fp16_saturation!r}: 'raise', 'warn' or 'ignore'")
+        from . import _lib
+        lib = _lib.lib()
+        bad, sat = int(lib.lrx_device_error_count(1)), int(lib.lrx_device_saturation_count(1))
+        if bad < 0 or sat < 0:
+            raise _lib.LrxError(f"{what}: reading the device counters failed")
+        if bad:
+            raise _lib.LrxError(f"{what}: {bad} device-side input error(s) (token ids outside the embedding table or an attention work list that "
+                                "did not fit): the rows of this call are not the model's")
+        if sat:
+            msg = (f"{what}: {sat} wave instruction(s) met q|k|v / embedding elements that were NaN or beyond fp16's +-65504 and stored them as "
+                   "+-65504: the embeddings of this call are not the model's (broken checkpoint, or activations outside the range the fp16 "
+                   "attention operands assume)")
+            if self.on_fp16_saturation == "raise":
+                raise _lib.LrxError(msg)
+            import logging
+            logging.getLogger(__name__).warning(msg)
 
     def token_id_reps(self, items: list[dict]) -> list[dict]:
         """Parameter-free sparse query vectors (exact_search_base.py:380-431): raw text with a leading whitespace, no specials,
@@ -534,6 +573,7 @@ class LrxExactSearchModel:
                 prompt = self.noncontextual_prompt_prefix + prompt if prompt else self.noncontextual_prompt_prefix
             if hm.emb_bag is None or hm.emb_bag_prompt != prompt:
                 hm.construct_embedding_bag(self.tokenizer, prompt=prompt, batch_size=self.eval_batch_size_embedding_bag)
+                self._check_device_counters("construct_embedding_bag")
         need_lm = use_dense or (use_emb and not nonctx)
         coll = EncodeCollator(self.tokenizer, encode_is_query=True, q_max_len=self.q_max_len, p_max_len=self.p_max_len,
                               noncontextual_query_embedding=use_emb and nonctx, query_lm_inputs=need_lm)
@@ -541,6 +581,8 @@ class LrxExactSearchModel:
         for s in (range(0, len(items), batch_size) if (need_lm or (use_emb and nonctx)) else ()):     # (token-id-only models tokenise in token_id_reps)
             for k, v in hm.encode_query(coll(items[s:s + batch_size])).items():
                 outs.setdefault(k, []).append(v)
+        if need_lm:                       # (the EmbeddingBag lookup has no fp16 operand; the table build checks its own rows below)
+            self._check_device_counters("encode_queries")
         res = {}
         for k, parts in outs.items():
             reps = torch.cat(parts, 0)
@@ -582,6 +624,7 @@ class LrxExactSearchModel:
             r = self.model.encode_passage(batch, out=out[s:e])
             if sparse:   # quantised {token id: weight} per document, what call_batch_encode hands to the sparse engine
                 sparse_json.extend(self.model.convert_sparse_reps_to_json(r["sparse_reps"], quantization_factor=100))
+        self._check_device_counters("encode")
         reps = out[:len(items)]
         res = {"dense_reps": reps if convert_to_tensor else reps.cpu().numpy()}
         if sparse:

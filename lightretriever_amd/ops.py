@@ -173,13 +173,14 @@ def gather_last_rows(src: torch.Tensor, cu_seqlens: torch.Tensor) -> torch.Tenso
 
 
 def pool_norm(hidden: torch.Tensor, w: torch.Tensor, cu_seqlens: torch.Tensor, eps: float, out_dim: Optional[int] = None,
-              normalize: bool = True) -> torch.Tensor:
-    """hidden bf16 [T,H] (HF's bf16 norm arithmetic) or fp32 [T,H] (the precise stream: fp32 norm)."""
+              normalize: bool = True, pooling: str = "lasttoken") -> torch.Tensor:
+    """hidden bf16 [T,H] (HF's bf16 norm arithmetic) or fp32 [T,H] (the precise stream: fp32 norm); pooling: finetune/dense_pooling.py:12-82
+    ('lasttoken', 'cls', 'mean', 'second_to_last', 'third_to_last')."""
     B, H = cu_seqlens.numel() - 1, hidden.shape[1]
     D = out_dim or H
     out = torch.empty(B, D, dtype=torch.float32, device=hidden.device)
-    _lib.check(_lib.lib().lrx_pool_norm_shard(_lib.ptr(hidden), _lib.ptr(w), _lib.ptr(cu_seqlens), B, H, eps, _lib.ptr(out), D, D, int(normalize), None, 0,
-                                              None, int(hidden.dtype == torch.float32), _s()))
+    _lib.check(_lib.lib().lrx_pool_norm_mode(_lib.ptr(hidden), _lib.ptr(w), _lib.ptr(cu_seqlens), B, H, eps, _lib.POOLING[pooling], _lib.ptr(out), D, D,
+                                             int(normalize), None, 0, None, int(hidden.dtype == torch.float32), _s()))
     return out
 
 

@@ -73,10 +73,13 @@ def _collective(group, force_collective: bool) -> bool:
 
 
 def exchange_merge(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.ProcessGroup] = None, row_map: Optional[torch.Tensor] = None,
-                   id_base: int = 0, force_collective: bool = False, words: Optional[torch.Tensor] = None) -> tuple[torch.Tensor, torch.Tensor]:
+                   id_base: int = 0, force_collective: bool = False, words: Optional[torch.Tensor] = None,
+                   on_stage=None) -> tuple[torch.Tensor, torch.Tensor]:
     """This shard's device-resident (scores f32 [Q,k], ids i64 [Q,k]) -> the global top-k on every rank:
     lrx_pack_topk (row map applied, one 64-bit word per hit) -> ONE RCCL all-gather -> lrx_merge_topk_packed.  No torch kernels.
-    words: the wire words when the search has already written them (FlatIPIndex.search(wire_out=...)): the packing launch is skipped."""
+    words: the wire words when the search has already written them (FlatIPIndex.search(wire_out=...)): the packing launch is skipped.
+    on_stage (measurement aid, bench.py): called with "gathered" / "merged" on the caller's stream right after the all-gather / the merge
+    were enqueued -- HIP events recorded there split a pass into local search, exchange and merge."""
     from . import _lib
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     force_collective = force_collective or os.environ.get("LRX_FORCE_COLLECTIVE") == "1"
@@ -90,9 +93,13 @@ def exchange_merge(D: torch.Tensor, I: torch.Tensor, group: Optional[dist.Proces
         words = torch.empty(Q, k, dtype=torch.int64, device=D.device)
         _lib.check(lib.lrx_pack_topk(_lib.ptr(D), _lib.ptr(I), _lib.ptr(row_map), int(id_base), Q * k, _lib.ptr(words), _lib.current_stream()))
     allw = _all_gather_words(words, world, group) if collective else words.unsqueeze(0)
+    if on_stage is not None:
+        on_stage("gathered")
     Dm = torch.empty(Q, k, dtype=torch.float32, device=D.device)
     Im = torch.empty(Q, k, dtype=torch.int64, device=D.device)
     _lib.check(lib.lrx_merge_topk_packed(_lib.ptr(allw), allw.shape[0], Q, k, _lib.ptr(Dm), _lib.ptr(Im), _lib.current_stream()))
+    if on_stage is not None:
+        on_stage("merged")
     return Dm, Im
 
 
@@ -121,6 +128,6 @@ class ShardedFlatIPIndex:
         D, I = self.shard.search(q, k, wire_out=words, row_map=self.row_map, lane=lane)
         return D, I, words
 
-    def finish(self, D: torch.Tensor, I: torch.Tensor, words: Optional[torch.Tensor] = None):
+    def finish(self, D: torch.Tensor, I: torch.Tensor, words: Optional[torch.Tensor] = None, on_stage=None):
         """local (scores, ids) of this shard -> global top-k on every rank (row map, all-gather, on-device merge)."""
-        return exchange_merge(D, I, self.group, row_map=self.row_map, id_base=self.shard.id_base, words=words)
+        return exchange_merge(D, I, self.group, row_map=self.row_map, id_base=self.shard.id_base, words=words, on_stage=on_stage)

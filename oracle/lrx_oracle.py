@@ -325,6 +325,48 @@ def lasttoken_pool_padded(last_hidden: np.ndarray, attention_mask: np.ndarray) -
     return last_hidden[np.arange(B), idx]
 
 
+POOLING_STRATEGIES = ("lasttoken", "cls", "mean", "second_to_last", "third_to_last")
+
+
+def pool_packed(last_hidden: np.ndarray, cu_seqlens: np.ndarray, strategy: str = "lasttoken") -> np.ndarray:
+    """pooling() of finetune/dense_pooling.py:12-82 in the packed layout [T, H] (right-padded rows in the reference; both branches of the
+    x-to-last strategies select the same token there): 'cls' = first token (:32-33), 'mean' = sum over the sequence's tokens / its length
+    (:35-36; fp32, tokens added in order), 'lasttoken' / 'second_to_last' / 'third_to_last' = token len-1 / len-2 / len-3 (:48-79; the
+    reference asserts len >= 2 / 3).  'avg_first_last' / 'avg_top2' (other layers' hidden states) are not served."""
+    cu = np.asarray(cu_seqlens, dtype=np.int64)
+    if strategy == "lasttoken":
+        return lasttoken_pool_packed(last_hidden, cu_seqlens)
+    if strategy == "cls":
+        return last_hidden[cu[:-1]]
+    if strategy in ("second_to_last", "third_to_last"):
+        back = 2 if strategy == "second_to_last" else 3
+        assert np.all(cu[1:] - cu[:-1] >= back), f"{strategy}: a sequence has fewer than {back} tokens"
+        return last_hidden[cu[1:] - back]
+    if strategy == "mean":
+        out = np.zeros((len(cu) - 1, last_hidden.shape[1]), dtype=np.float32)
+        for b in range(len(cu) - 1):
+            acc = np.zeros(last_hidden.shape[1], dtype=np.float32)
+            for t in range(cu[b], cu[b + 1]):
+                acc += last_hidden[t].astype(np.float32)
+            out[b] = acc / np.float32(cu[b + 1] - cu[b])
+        return out
+    raise NotImplementedError(strategy)
+
+
+def pool_padded(last_hidden: np.ndarray, attention_mask: np.ndarray, strategy: str) -> np.ndarray:
+    """The same on the reference's padded layout [B, S, H] + mask (literal restatement, for the goldens of pooling() itself)."""
+    B = last_hidden.shape[0]
+    m = attention_mask.astype(np.int64)
+    if strategy == "cls":
+        return last_hidden[:, 0]
+    if strategy == "mean":
+        return ((last_hidden * m[..., None]).sum(1) / m.sum(-1)[..., None]).astype(np.float32)
+    back = {"lasttoken": 1, "second_to_last": 2, "third_to_last": 3}[strategy]
+    if m[:, -1].sum() == B:
+        return last_hidden[:, -back]
+    return last_hidden[np.arange(B), m.sum(axis=1) - back]
+
+
 def l2_normalize(x: np.ndarray, eps: float = 1e-12) -> np.ndarray:
     """torch.nn.functional.normalize(p=2, dim=-1): x / max(||x||, eps)."""
     x = x.astype(np.float32)
@@ -333,10 +375,11 @@ def l2_normalize(x: np.ndarray, eps: float = 1e-12) -> np.ndarray:
 
 
 def encode_passage(cfg: EncoderConfig, w, ids, cu_seqlens, dense_shrink_dim: Optional[int] = None,
-                   normalize: bool = True, bf16: bool = False) -> np.ndarray:
-    """finetune/modeling_hybrid.py:205-278 dense branch: forward -> pooling('lasttoken') -> MRL slice -> F.normalize."""
+                   normalize: bool = True, bf16: bool = False, pooling: str = "lasttoken") -> np.ndarray:
+    """finetune/modeling_hybrid.py:205-278 dense branch: forward -> pooling(strategy; 'lasttoken' in the released models) -> MRL slice ->
+    F.normalize."""
     h = encoder_forward_packed(cfg, w, ids, cu_seqlens, bf16=bf16)
-    p = lasttoken_pool_packed(h, cu_seqlens)
+    p = pool_packed(h, cu_seqlens, pooling)
     if dense_shrink_dim:
         p = p[..., :dense_shrink_dim]
     return l2_normalize(p) if normalize else p.astype(np.float32)

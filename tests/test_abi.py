@@ -23,7 +23,7 @@ def test_library_builds_and_exports_header_symbols():
     for s in syms:
         assert hasattr(l, s), f"{s} declared in include/lrx.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table out of sync with include/lrx.h"
-    assert _lib.lib().lrx_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.lib().lrx_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_argument_errors_are_reported_without_a_gpu():

@@ -84,8 +84,8 @@ def test_sharded_search_lanes_and_hybrid_search_over_rccl_ranks(n_ranks):
 def test_bench_line_reports_the_rccl_ranks_and_the_shard_sizes():
     n_ranks = max(_ranks_available())
     rows = 1_000_003                                 # no R divides it: the remainder rows go one each to the first ranks
-    rc, out, err = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--legs", "encode,search",
-                         "--index-rows", str(rows)], 600)
+    rc, out, err = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--legs", "encode,search,sharded",
+                         "--index-rows", str(rows), "--sharded-rows", "2000003"], 900)
     assert rc == 0, err[-6000:]
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == n_ranks and line["rccl_ranks"] == n_ranks and line["config"]["parallelism"] == "dp%d" % n_ranks
@@ -94,3 +94,9 @@ def test_bench_line_reports_the_rccl_ranks_and_the_shard_sizes():
     assert max(s["shard_rows_per_rank"]) - min(s["shard_rows_per_rank"]) <= 1 and s["value"] > 0
     assert s["two_in_flight"].get("identical_to_one_at_a_time") is True, s["two_in_flight"]     # the lanes ran over the communicator
     assert line["search_qps"] == s["value"] and line["headline"]["rccl_ranks"] == n_ranks
+    # round 6: BASELINE configs[3] / configs[4] over the communicator + the 8B encoder under weak scaling
+    for key in ("config3_10Mx4096", "config4_10Mx256_mrl"):
+        c = line["configs"][key]
+        assert c["rccl_ranks"] == n_ranks and sum(c["shard_rows_per_rank"]) == 2_000_003 and max(c["shard_rows_per_rank"]) - min(c["shard_rows_per_rank"]) <= 1
+        assert c["queries_per_s"] > 0 and c["exchange_ms"] > 0 and c["two_in_flight"].get("identical_to_one_at_a_time") is True, c
+    assert line["configs"]["config3_encode_llama31_8b"]["n_gpus"] == n_ranks

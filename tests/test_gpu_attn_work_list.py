@@ -25,6 +25,10 @@ CASES = [
     ("d64_g4_long", 32, 8, 64, _lens(8, 40, 1500), False),
     ("d64_g7_long", 14, 2, 64, _lens(9, 40, 900), False),
     ("d64_g16_two_parts", 16, 1, 64, _lens(10, 12, 700), False),
+    # MHA / g = 2 at d = 64: four slots per CU -- 1024 workgroups on a 256-CU part, the one-block builder's limit (attn_plan clamps there)
+    ("d64_mha_g1_long_full_grid", 16, 16, 64, _lens(13, 24, 1100), False),
+    ("d64_g2_long_full_grid", 16, 8, 64, _lens(14, 40, 900), False),
+    ("d64_mha_last_tile", 16, 16, 64, _lens(15, 200, 512), True),
     ("d64_resident_ignores_the_list", 32, 8, 64, _lens(11, 50, 512), False),
     ("many_short_sequences", 8, 2, 128, [3, 70, 1, 129] * 1250, False),     # 5000 sequences: 10 000 (sequence, kv head) pairs through the one-block builder
     ("many_short_last_tile", 8, 2, 128, [3, 70, 1, 129] * 1250, True),

@@ -185,7 +185,7 @@ def test_bench_with_a_forced_one_rank_rccl_group_matches_the_plain_run():
     agree with the plain run within 3 % (docs/s; the search pays one extra collective + merge per pass: within 15 %)."""
     plain = _bench_line({})
     forced = _bench_line({"LRX_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29800 + os.getpid() % 1000), "RANK": "0",
-                          "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+                          "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, "--legs", "encode,search,sharded", "--sharded-rows", "1000000")
     for line in (plain, forced):
         assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["scaling"] == "weak" and line["steps"] == 4 and line["warmup"] == 1
         s = line["search"]
@@ -198,6 +198,19 @@ def test_bench_with_a_forced_one_rank_rccl_group_matches_the_plain_run():
         assert line["search_qps"] == s["value"] == line["config"]["search_qps"] == line["headline"]["search_qps"] and list(line)[-1] == "headline"
         assert line["search_roofline_frac"] == s["roofline"]["frac"] == line["roofline"]["search_frac"] and line["search_alg_bytes"] == s["roofline"]["algorithmic_bytes"]
         assert line["headline"]["docs_per_s"] == line["value"] and line["headline"]["stream_mode"] == line["config"]["stream_mode"]
+    # round 6: over a communicator the line also carries BASELINE configs[3] / configs[4] (row-sharded 4096- and 256-wide indexes; here
+    # --sharded-rows 1 000 000 on the one rank) and the 8B encoder under weak scaling -- local / exchange / merge split by HIP events
+    assert "configs" not in plain
+    fc = forced["configs"]
+    for key, dim in (("config3_10Mx4096", 4096), ("config4_10Mx256_mrl", 256)):
+        c = fc[key]
+        assert c["rccl_ranks"] == 1 and c["shard_rows_per_rank"] == [1_000_000] and c["index_rows"] == 1_000_000 and c["dim"] == dim
+        assert c["queries_per_s"] > 0 and c["local_search_ms"] > 0 and c["exchange_ms"] > 0 and c["merge_ms"] > 0
+        assert c["ms_per_pass"] >= 0.9 * (c["local_search_ms"] + c["exchange_ms"] + c["merge_ms"])
+        assert c["two_in_flight"]["identical_to_one_at_a_time"] is True and c["two_in_flight"]["queries_per_s"] > 0
+        assert c["roofline"]["bound"] == "hbm" and 0.05 < c["roofline"]["frac"] < 1.0
+    e8 = fc["config3_encode_llama31_8b"]
+    assert e8["n_gpus"] == 1 and e8["scaling"] == "weak" and e8["docs_per_s"] > 50 and 0.2 < e8["roofline"]["frac"] < 1.0
     assert abs(forced["value"] / plain["value"] - 1) < 0.03, (forced["value"], plain["value"])
     assert forced["search"]["value"] > 0.85 * plain["search"]["value"], (forced["search"]["value"], plain["search"]["value"])
     print("bench N=1 plain %.1f docs/s, %.0f q/s; forced 1-rank RCCL group %.1f docs/s, %.0f q/s" % (

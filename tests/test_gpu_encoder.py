@@ -44,6 +44,49 @@ def test_golden_models_within_reference_bf16_band(name):
     np.testing.assert_allclose(out_mrl, O.l2_normalize(out[:, :s]), atol=2e-6)
 
 
+@pytest.mark.parametrize("precise", [True, False])
+def test_pooling_strategies_against_the_reference_outputs(precise):
+    """`--pooling_strategy` cls / mean / second_to_last / third_to_last (and lasttoken through the same generic path): lrx_encode_packed_pooled
+    against what the reference's HybridModel.encode_passage / encode_query returned for each strategy on the llama_small_d64 model
+    (tests/golden/pooling.npz, made by gen_pooling_goldens.py importing the reference; finetune/dense_pooling.py:12-82,
+    finetune/modeling_hybrid.py:262-278), full width and the MRL slice, both stream modes; rows written in place into an index shard carry
+    their shadow + bounds like last-token rows do."""
+    import dataclasses
+    import os
+    from helpers import GOLDEN
+    from lightretriever_amd import FlatIPIndex
+    g = np.load(os.path.join(GOLDEN, "pooling.npz"))
+    cfg, w, g64, _, _, _ = load_model_golden("llama_small_d64")
+    band = 1 - min_cos(g64["dense_reps_bf16"], g64["dense_reps"])          # the reference's own bf16 distance on this model (last-token rows)
+    from lightretriever_amd import EncoderConfig, LrxEncoder
+    enc = LrxEncoder(EncoderConfig(**dataclasses.asdict(cfg), precise_stream=precise), {k: torch.from_numpy(v) for k, v in w.items()})
+    assert enc.precise == precise
+    ids, _, _, cu, max_len = O.pack_padded(g["input_ids"], g["attention_mask"])
+    ids_t, cu_t = to_dev(ids, torch.int32), to_dev(cu, torch.int32)
+    s = int(g["shrink"])
+    for st in O.POOLING_STRATEGIES:
+        out = enc.encode_packed(ids_t, cu_t, max_len, pooling=st).cpu().numpy()
+        gap = 1 - min_cos(out, g[f"psg_{st}"])
+        out_mrl = enc.encode_packed(ids_t, cu_t, max_len, out_dim=s, pooling=st).cpu().numpy()
+        gap_mrl = 1 - min_cos(out_mrl, g[f"psg_{st}_mrl"])
+        print("pooling %-15s %s stream: 1 - cos vs the reference's fp32 output %.2e (MRL-%d %.2e); reference bf16 band %.2e" % (
+            st, "fp32" if precise else "bf16", gap, s, gap_mrl, band))
+        assert gap <= max(COS_TOL, 1.25 * band) and gap_mrl <= max(COS_TOL, 1.5 * band), (st, gap, gap_mrl, band)
+        np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+        np.testing.assert_allclose(out_mrl, O.l2_normalize(out[:, :s]), atol=2e-6)
+        if st == "lasttoken":                                                   # the default entry point is this strategy
+            assert np.array_equal(out, enc.encode_packed(ids_t, cu_t, max_len).cpu().numpy())
+    # 'mean' rows straight into an index shard: searchable at once (shadow + bounds written by the pooling kernel)
+    idx = FlatIPIndex(cfg.hidden_size, capacity=16)
+    enc.encode_packed(ids_t, cu_t, max_len, out=idx.append_slot(len(cu) - 1), pooling="mean")
+    idx.commit(len(cu) - 1)
+    want = enc.encode_packed(ids_t, cu_t, max_len, pooling="mean")
+    assert torch.equal(idx.vectors, want)
+    D, I = idx.search(want[:3], 2)
+    assert I[:, 0].tolist() == [0, 1, 2] and torch.allclose(D[:, 0], torch.ones(3, device=D.device), atol=1e-5)
+    assert torch.equal(idx.shadow_rows().float(), want.to(torch.float16).float())
+
+
 @pytest.mark.parametrize("name", ["llama_small_d64", "llama_small_d128"])
 def test_hidden_states_layer_by_layer_against_the_fp32_oracle(name):
     """Per-layer check (the small goldens carry no hidden states of their own, the oracle that produces them is pinned

@@ -1,9 +1,12 @@
 """GPU parity: every liblrx kernel (called through the C ABI) against the CPU oracle on seeded inputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import lrx_oracle as O
+from helpers import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
@@ -212,6 +215,46 @@ def test_pool_norm(H, out_dim, normalize):
     np.testing.assert_allclose(f32(got), want, atol=3e-3 if not normalize else 3e-4, rtol=1e-2)
     if normalize:
         np.testing.assert_allclose(np.linalg.norm(f32(got), axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("pooling", ["cls", "mean", "lasttoken", "second_to_last", "third_to_last"])
+def test_pool_norm_strategies_against_the_reference_pooling(pooling):
+    """pooling() of finetune/dense_pooling.py:12-82 (tests/golden/pooling.npz holds its outputs on random tensors): k_pool_norm with an identity
+    norm weight on rows pre-scaled to unit RMS is the bare pooling -- 1e-6; then with a real norm on an fp32 stream against the oracle (the
+    fp32 norm + fp32 accumulation in token order) and on a bf16 stream (HF's rounding order)."""
+    from lightretriever_amd import _lib, ops
+    g = np.load(os.path.join(GOLDEN, "pooling.npz"))
+    for name in ("ragged", "allfull"):
+        h, m = g[f"fn_{name}_hidden"].astype(np.float64), g[f"fn_{name}_mask"]
+        # unit-RMS rows go through the norm unchanged (up to eps = 0): the kernel's output is then the reference's pooling of those rows
+        hn = (h / np.sqrt((h * h).mean(-1, keepdims=True))).astype(np.float32)
+        H = hn.shape[-1]
+        pad = np.zeros(hn.shape[:2] + (64 - H,), np.float32)                                   # H = 48 -> 64 columns; zeros keep the mean of squares ...
+        hp = np.concatenate([hn, pad], -1) * np.float32(np.sqrt(64 / H))                       # ... once the rows are rescaled to unit RMS over 64
+        packed, cu = hp[m.astype(bool)], np.concatenate([[0], np.cumsum(m.sum(1))]).astype(np.int32)
+        got = ops.pool_norm(torch.from_numpy(packed).to(dev()), bf16_t(np.ones(64, np.float32)), torch.from_numpy(cu).to(dev()), 0.0, normalize=False,
+                            pooling=pooling)
+        want = O.pool_padded(hn, m, pooling)
+        np.testing.assert_allclose(f32(got)[:, :H] / np.float32(np.sqrt(64 / H)), want, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(O.pool_padded(g[f"fn_{name}_hidden"], m, pooling), g[f"fn_{name}_{pooling}"], atol=1e-6)   # (the restatement is the reference's)
+    rng = np.random.default_rng(5)
+    lens = [3, 40, 17, 129, 5]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x, w = rnd(rng, sum(lens), 256, scale=2.0), O.round_bf16(1 + 0.1 * rng.standard_normal(256).astype(np.float32))
+    for out_dim, normalize in ((256, True), (64, True), (256, False)):
+        got32 = ops.pool_norm(torch.from_numpy(x).to(dev()), bf16_t(w), torch.from_numpy(cu).to(dev()), 1e-5, out_dim, normalize, pooling=pooling)
+        pooled = O.pool_packed(O.rmsnorm(x, w, 1e-5, bf16=False), cu, pooling)[:, :out_dim]
+        np.testing.assert_allclose(f32(got32), O.l2_normalize(pooled) if normalize else pooled, atol=2e-5, rtol=1e-5)
+        got16 = ops.pool_norm(bf16_t(x), bf16_t(w), torch.from_numpy(cu).to(dev()), 1e-5, out_dim, normalize, pooling=pooling)
+        pooled16 = O.pool_packed(O.rmsnorm(O.round_bf16(x), w, 1e-5, bf16=True), cu, pooling)[:, :out_dim]
+        np.testing.assert_allclose(f32(got16), O.l2_normalize(pooled16) if normalize else pooled16, atol=3e-3 if not normalize else 3e-4, rtol=1e-2)
+    # a sequence shorter than the strategy needs (the reference asserts, dense_pooling.py:63-66): a zero row + the input-error counter
+    if pooling in ("second_to_last", "third_to_last"):
+        lib = _lib.lib()
+        lib.lrx_device_error_count(1)
+        cu1 = torch.tensor([0, 1, 6], dtype=torch.int32, device=dev())
+        out = ops.pool_norm(torch.from_numpy(x[:6]).to(dev()), bf16_t(w), cu1, 1e-5, normalize=True, pooling=pooling)
+        assert float(out[0].abs().max()) == 0.0 and float(out[1].norm()) > 0.99 and lib.lrx_device_error_count(1) == 1
 
 
 def test_embedding_bag_bit_exact():

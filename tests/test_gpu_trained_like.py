@@ -97,6 +97,57 @@ def test_saturation_counter_sees_q_beyond_fp16_range():
     assert lib.lrx_device_saturation_count(0) == 0               # reset
 
 
+def test_encode_corpus_raises_on_fp16_saturation_and_on_bad_token_ids():
+    """the product path reads the device counters once per encode call -- a checkpoint whose q leaves fp16's range
+    raises (or warns, by choice) instead of silently returning clamped embeddings; token ids outside the table always raise.  Reference:
+    finetune/modeling_hybrid.py:248-278 computes in bf16 (range 3e38) and has no such precondition -- hence loud."""
+    import logging
+    from transformers import PreTrainedTokenizerFast
+    from helpers import GOLDEN
+    from lightretriever_amd import EncoderConfig, LrxEncoder, _lib
+    from lightretriever_amd.modeling import LrxExactSearchModel, LrxHybridModel
+    tok = PreTrainedTokenizerFast.from_pretrained(os.path.join(GOLDEN, "tok"))
+    cfg = EncoderConfig(vocab_size=max(2000, len(tok)), hidden_size=256, num_layers=2, num_q_heads=4, num_kv_heads=2, head_dim=64, intermediate_size=512,
+                        qkv_bias=True, rope_type="default", rope_theta=1e6, max_positions=128)
+    good = LrxEncoder.random_init(cfg, seed=0)
+    sd = good.hf_state_dict()
+    b = sd["layers.1.self_attn.q_proj.bias"].clone()
+    b[5] = 1e5
+    sd["layers.1.self_attn.q_proj.bias"] = b
+    bad = LrxEncoder(cfg, sd)
+    docs = ["the quick brown fox %d jumps over the lazy dog" % i for i in range(20)]
+    mk = lambda enc, **kw: LrxExactSearchModel(model=LrxHybridModel(enc, normalize=True, pad_token_id=tok.pad_token_id), tokenizer=tok, q_max_len=32,
+                                               p_max_len=64, **kw)
+    _lib.lib().lrx_device_saturation_count(1)
+    _lib.lib().lrx_device_error_count(1)
+    ok = mk(good).encode_corpus(docs, batch_size=8)["dense_reps"]
+    assert ok.shape == (20, 256) and torch.isfinite(ok).all()
+    with pytest.raises(_lib.LrxError, match="fp16"):
+        mk(bad).encode_corpus(docs, batch_size=8)
+    assert _lib.lib().lrx_device_saturation_count(0) == 0                     # read AND reset by the failing call
+    class _Grab(logging.Handler):
+        def __init__(self):
+            super().__init__(level=logging.WARNING)
+            self.msgs = []
+        def emit(self, rec):
+            self.msgs.append(rec.getMessage())
+    h = _Grab()
+    logging.getLogger("lightretriever_amd.modeling").addHandler(h)
+    try:
+        out = mk(bad, on_fp16_saturation="warn").encode_corpus(docs, batch_size=8)["dense_reps"]
+    finally:
+        logging.getLogger("lightretriever_amd.modeling").removeHandler(h)
+    assert torch.isfinite(out).all() and any("65504" in m for m in h.msgs), h.msgs
+    # a token id beyond the embedding table (a tokenizer / checkpoint mismatch the constructor cannot see): always an error
+    m = mk(good)
+    small = LrxEncoder.random_init(EncoderConfig(vocab_size=64, hidden_size=256, num_layers=2, num_q_heads=4, num_kv_heads=2, head_dim=64,
+                                                 intermediate_size=512, rope_type="default", max_positions=128), seed=1)
+    m.model = LrxHybridModel(small, normalize=True, pad_token_id=tok.pad_token_id)          # (swapped in behind __post_init__'s vocabulary check)
+    with pytest.raises(_lib.LrxError, match="token ids"):
+        m.encode_corpus(docs, batch_size=8)
+    assert _lib.lib().lrx_device_error_count(0) == 0
+
+
 def _released_checkpoint():
     """The adapter directory of lightretriever/lightretriever-qwen2.5-1.5b, if it is on this machine (LRX_RELEASED_QWEN25_1_5B or the
     HF hub cache), else None.  The base model is resolved by the loader the same way (local directory or hub cache)."""

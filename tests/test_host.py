@@ -193,6 +193,13 @@ def _bench_rank_worker(rank, world, port, index_rows, q, X, k, ret):
     dist.all_gather_into_tensor(sizes, torch.tensor([rows], dtype=torch.int64))
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the `sharded` leg's bookkeeping (BASELINE configs[3] / configs[4]: 10M rows over the communicator): gathered shard sizes + the
+    # MIN-reduced "fits" flag every rank branches on
+    sizes10m = torch.empty(world, dtype=torch.int64)
+    dist.all_gather_into_tensor(sizes10m, torch.tensor([bench.shard_split(10_000_000, rank, world)[0]], dtype=torch.int64))
+    fits = torch.tensor([0 if rank == 2 else 1], dtype=torch.int64)
+    dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+    assert sizes10m.tolist() == [2_500_000] * 4 and int(fits.item()) == 0 and bench.reduce_max(float(rank), torch.device("cpu"), True) == 3.0
     ret[rank] = (Dm, Im, sizes.tolist(), base, float(t.item()))
     dist.barrier()
     dist.destroy_process_group()
@@ -211,6 +218,10 @@ def test_bench_shard_split_covers_every_row_for_any_world_size():
             for (ra, ba), (rb, bb) in zip(parts, parts[1:]):
                 assert bb == ba + ra and 0 <= ra - rb <= 1            # contiguous, disjoint, sizes within one row of each other
     assert [bench.shard_split(1_000_000, r, 8) for r in range(8)] == [(125_000, 125_000 * r) for r in range(8)]
+    # BASELINE configs[3] / configs[4]: 10M rows over 8 ranks (bench.py's `sharded` leg), and over world sizes that do not divide them
+    assert [bench.shard_split(10_000_000, r, 8) for r in range(8)] == [(1_250_000, 1_250_000 * r) for r in range(8)]
+    assert [bench.shard_split(10_000_000, r, 3)[0] for r in range(3)] == [3_333_334, 3_333_333, 3_333_333]
+    assert bench.shard_split(10_000_000, 6, 7) == (1_428_571, 10_000_000 - 1_428_571)
 
 
 def test_bench_rank_bookkeeping_over_gloo_world4():
@@ -503,11 +514,14 @@ def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_m
     for bad in (["--hybrid_use_emb_vector", "--untie_encoder"], ["--hybrid_use_sparse_vector"], ["--hybrid_use_emb_vector", "--enable_bidirectional_attention"],
                 ["--hybrid_use_emb_vector", "--use_sparse_linear_projector"], ["--hybrid_use_emb_vector", "--sparse_remove_stopwords"],
                 ["--hybrid_use_emb_vector", "--hybrid_model_architecture", "bert"], ["--hybrid_use_emb_vector", "--fp16"],
-                ["--hybrid_use_emb_vector", "--pooling_strategy", "mean"], ["--hybrid_use_emb_vector", "--sparse_use_max_aggregation", "False"]):
+                ["--hybrid_use_emb_vector", "--pooling_strategy", "avg_top2"], ["--hybrid_use_emb_vector", "--sparse_use_max_aggregation", "False"]):
         with pytest.raises(NotImplementedError):
             parse(*bad)
     with pytest.raises(ValueError, match="no vector type selected"):
         parse()
+    # round 6: the single-layer pooling strategies of finetune/dense_pooling.py:12-82 are served
+    for st in ("cls", "mean", "second_to_last", "third_to_last"):
+        assert parse("--hybrid_use_dense_vector", "--pooling_strategy", st).pooling_strategy == st
     # the defaults are the reference's (finetune/arguments.py:175-195, inference/arguments.py:27,68): nothing selected, fp32 container, EncoderModel
     e = InferenceArguments(model_name_or_path="/x/llama")
     assert (e.model_type, e.bf16, e.hybrid_use_dense_vector, e.hybrid_use_emb_vector, e.noncontextual_query_embedding, e.hybrid_use_token_id_vector,

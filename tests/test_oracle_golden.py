@@ -329,3 +329,24 @@ def test_lm_encoded_query_modes_match_the_reference():
                                g["emb_reps_lm_embedding_mrl"], atol=2e-6)
     # the autocast run (bf16 matmuls on the fp32 model: what call_batch_encode does on this CPU) stays inside the bf16 band of the fp32 result
     assert min_cos(g["dense_reps_autocast"], g["dense_reps"]) > 0.995
+
+
+def test_pooling_strategies_match_the_reference():
+    """Round 6: pooling() itself (finetune/dense_pooling.py:12-82) and HybridModel.encode_passage / encode_query with `--pooling_strategy`
+    cls / mean / lasttoken / second_to_last / third_to_last (tests/golden/gen_pooling_goldens.py ran the reference on the llama_small_d64 model)."""
+    g = np.load(os.path.join(GOLDEN, "pooling.npz"))
+    for name in ("ragged", "allfull"):
+        h, m = g[f"fn_{name}_hidden"], g[f"fn_{name}_mask"]
+        packed, cu = h[m.astype(bool)], np.concatenate([[0], np.cumsum(m.sum(1))])
+        for st in O.POOLING_STRATEGIES:
+            np.testing.assert_allclose(O.pool_padded(h, m, st), g[f"fn_{name}_{st}"], atol=1e-6, err_msg=f"{name} {st}")
+            np.testing.assert_allclose(O.pool_packed(packed, cu, st), g[f"fn_{name}_{st}"], atol=1e-6, err_msg=f"{name} {st} (packed)")
+    cfg, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    ids, _, _, cu, _ = O.pack_padded(g["input_ids"], g["attention_mask"])
+    for st in O.POOLING_STRATEGIES:
+        np.testing.assert_allclose(O.encode_passage(cfg, w, ids.astype(np.int32), cu, pooling=st), g[f"psg_{st}"], atol=2e-5, err_msg=st)
+        np.testing.assert_allclose(O.encode_passage(cfg, w, ids.astype(np.int32), cu, pooling=st, dense_shrink_dim=int(g["shrink"])),
+                                   g[f"psg_{st}_mrl"], atol=2e-5, err_msg=st)
+        np.testing.assert_array_equal(g[f"qry_{st}"], g[f"psg_{st}"])
+    with pytest.raises(AssertionError):
+        O.pool_packed(np.zeros((3, 4), np.float32), np.array([0, 2, 3]), "second_to_last")       # the reference asserts too (:63-66)
