@@ -608,38 +608,66 @@ def other_stream_leg(args, dev):
 
 
 def ragged_encode_leg(args, dev):
-    # ---- SURVEY 8d's ragged variant of the headline encoder: lengths clip(lognormal(5.3, 0.6), 16, S) sorted longest first (the reference
-    #      sorts its corpus that way, hybrid_search.py:273-276), 256 documents per step, 1 warm-up + 3 timed steps
+    """SURVEY 8d's ragged variant of the headline encoder THROUGH THE PRODUCT'S BATCHING: 8 192 documents with lengths
+    clip(lognormal(5.3, 0.6), 16, S) sorted longest first (the reference sorts its corpus that way, retriever/hybrid_search.py:273-276), handed
+    over as the collator hands them over -- packed batches of 256 documents -- to modeling._token_budget_batches (consecutive batches merged up
+    to 131 072 tokens / 2 048 documents, the defaults of LrxExactSearchModel.encode) and LrxHybridModel.encode_passage, rows written in place.
+    Token ids resident in HBM, cu_seqlens on the host like a collator's.  Next to it, on the same encoder in the same process: the
+    fixed-length figure (256 x S per step), so that `tokens_per_s_over_fixed_length` is a same-box ratio."""
     import numpy as np
     from lightretriever_amd import EncoderConfig, LrxEncoder
+    from lightretriever_amd.modeling import LrxHybridModel, _token_budget_batches
     S = args.seq_len
-    cfg1 = EncoderConfig.llama32_1b(args.seq_len)
+    cfg1 = EncoderConfig.llama32_1b(S)
     enc1 = LrxEncoder.random_init(cfg1, seed=0, device=dev)
-    B1, n1 = 256, 4
+    hm = LrxHybridModel(enc1, normalize=True)
+    B1, n_docs, n_warm = 256, 8192, 1024
+    max_tokens, max_docs = 131072, 2048
     rng = np.random.default_rng(4321)
-    lens = np.sort(np.clip(rng.lognormal(5.3, 0.6, size=n1 * B1), 16, S).astype(np.int64))[::-1]
+    lens = np.sort(np.clip(rng.lognormal(5.3, 0.6, size=n_docs), 16, S).astype(np.int64))[::-1]
     g1 = torch.Generator(device=dev).manual_seed(78)
-    rb = []
-    for i in range(n1):
-        l = lens[i * B1:(i + 1) * B1]
-        rb.append((torch.randint(1000, 127000, (int(l.sum()),), generator=g1, device=dev, dtype=torch.int64).to(torch.int32),
-                   torch.tensor(np.concatenate([[0], np.cumsum(l)]), dtype=torch.int32, device=dev), int(l.max())))
-    out1 = torch.empty(B1, cfg1.hidden_size, device=dev)
-    enc1.encode_packed(rb[0][0], rb[0][1], rb[0][2], out=out1)
+
+    def collated(lo, hi):
+        for s0 in range(lo, hi, B1):
+            l = lens[s0:min(s0 + B1, hi)]
+            yield s0, s0 + len(l), {"input_ids": torch.randint(1000, 127000, (int(l.sum()),), generator=g1, device=dev, dtype=torch.int64).to(torch.int32),
+                                    "cu_seqlens": torch.tensor(np.concatenate([[0], np.cumsum(l)]), dtype=torch.int32), "max_seqlen": int(l.max())}
+
+    out1 = torch.empty(n_docs, cfg1.hidden_size, device=dev)
+    warm = list(collated(0, n_warm))                                  # the longest documents: the workspace reaches its final size here
+    timed = list(collated(0, n_docs))
+    for s0, e0, b in _token_budget_batches(iter(warm), max_tokens, max_docs):
+        hm.encode_passage(b, out=out1[s0:e0])
     torch.cuda.synchronize()
+    n_calls, call_tokens = 0, []
     t0 = time.perf_counter()
-    for i in range(1, n1):
-        enc1.encode_packed(rb[i][0], rb[i][1], rb[i][2], out=out1)
+    for s0, e0, b in _token_budget_batches(iter(timed), max_tokens, max_docs):
+        hm.encode_passage(b, out=out1[s0:e0])
+        n_calls += 1
+        call_tokens.append(int(b["cu_seqlens"][-1]))
     torch.cuda.synchronize()
     t1 = time.perf_counter() - t0
-    tl = lens[B1:]
+    # fixed-length reference on the same encoder: 3 steps of 256 x S after one warm-up
+    idsf = torch.randint(1000, 127000, (4, B1 * S), generator=g1, device=dev, dtype=torch.int64).to(torch.int32)
+    cuf = (torch.arange(B1 + 1, device=dev, dtype=torch.int64) * S).to(torch.int32)
+    enc1.encode_packed(idsf[0], cuf, S, out=out1[:B1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in (1, 2, 3):
+        enc1.encode_packed(idsf[i], cuf, S, out=out1[:B1])
+    torch.cuda.synchronize()
+    tf = time.perf_counter() - t0
+    fixed_tps = 3 * B1 * S / tf
     out = {
-        "workload": "lightretriever-llama3.2-1b dims bf16, %d docs/step, lengths clip(lognormal(5.3,0.6),16,%d) sorted longest first, %d timed steps "
-                    "after 1 warm-up (SURVEY 8d ragged variant; not the headline)" % (B1, S, n1 - 1),
-        "docs_per_s": round((n1 - 1) * B1 / t1, 1), "tokens_per_s": round(float(tl.sum()) / t1, 0), "mean_tokens_per_doc": round(float(tl.mean()), 1),
-        "longest_doc": int(tl.max()), "shortest_doc": int(tl.min()),
-        "end_to_end_tflops": round(float(sum(cfg1.flops_per_doc(int(x)) for x in tl)) / t1 / 1e12, 1)}
-    del enc1, out1, rb
+        "workload": "lightretriever-llama3.2-1b dims bf16, %d documents, lengths clip(lognormal(5.3,0.6),16,%d) sorted longest first, collated in batches "
+                    "of %d and merged by the product's token-budget batching (<= %d tokens, <= %d documents per encode call): %d encode calls "
+                    "(SURVEY 8d ragged variant through LrxHybridModel.encode_passage; not the headline)" % (n_docs, S, B1, max_tokens, max_docs, n_calls),
+        "docs_per_s": round(n_docs / t1, 1), "tokens_per_s": round(float(lens.sum()) / t1, 0), "mean_tokens_per_doc": round(float(lens.mean()), 1),
+        "longest_doc": int(lens.max()), "shortest_doc": int(lens.min()), "encode_calls": n_calls,
+        "tokens_per_call": {"min": min(call_tokens), "max": max(call_tokens)},
+        "end_to_end_tflops": round(float(sum(cfg1.flops_per_doc(int(x)) for x in lens)) / t1 / 1e12, 1),
+        "fixed_length_tokens_per_s_same_process": round(fixed_tps, 0), "tokens_per_s_over_fixed_length": round(float(lens.sum()) / t1 / fixed_tps, 4)}
+    del enc1, hm, out1, warm, timed
     torch.cuda.empty_cache()
     return out
 

@@ -56,7 +56,8 @@ typedef struct lrx_encoder_config {
                                  -- the norm weight rides on the activation, the weights stay exact, the row statistic is applied to the consumer's
                                  accumulator as with norm_folded.  For deep backbones: at 32 layers the bf16 stream + folded weights spend ~1.1e-3
                                  of the 1e-3 cosine budget against the fp32 model (tools/exp/rounding_budget.py); +6 B / element of traffic
-                                 per residual GEMM (~3 % of an 8B step).  LrxEncoder switches it on where layers x hidden >= 60 000.    */
+                                 per residual GEMM (~3 % of a step).  LrxEncoder switches it on for EVERY backbone (since round 5: the mode that
+                                 holds 1e-3 on trained-like weights; EncoderConfig(precise_stream=False) selects the bf16 stream).      */
 } lrx_encoder_config;
 
 /* Per-layer weights, bf16, nn.Linear layout [out, in] row-major (K contiguous).
