@@ -198,7 +198,8 @@ int lrx_embedding_gather(const void* table, const int32_t* ids, int32_t n_tokens
  * failed.  Non-zero = the rows of those calls are not the model's.  SYNCHRONISES the device (a blocking copy): call it at a point where
  * the caller waits for results anyway (LrxExactSearchModel.encode does, once per encode call, and raises).                         */
 int64_t lrx_device_error_count(int32_t reset);
-/* (ABI 6) Measurement aid: with LRX_FUSED_PHASES bit 7 set in the environment the fused filter launch of the bounded search (sample + selection
+/* (ABI 6) Measurement aid of DEV builds (-DLRX_DEV_KNOBS; the shipping library reads no environment variable and records nothing): with
+ * LRX_FUSED_PHASES bit 7 set in the environment the fused filter launch of the bounded search (sample + selection
  * + main pass in one persistent kernel) records per-workgroup phase timestamps (100 MHz clock; 8 words per workgroup: start, sample done,
  * selection start, selection done, first main K loop done, thresholds seen, ..., end); this copies the first n_words of them to the host.     */
 int lrx_probe_fused_timestamps(uint64_t* out, int32_t n_words);
@@ -436,9 +437,13 @@ int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, int64_t ldx,
  * exact six-product fallback since the last reset (list / band overflow: a performance event, the results are exact either way);
  * SYNCHRONISES like lrx_device_error_count.  lrx_flat_ip_bounded_list_counts: counts_out[n_queries] (device, uint32) = candidate-list
  * entries of each query of the last chunk of the last search that used `workspace` -- the rows that passed the filter and reached the
- * refine step; pass that search's own (n_rows, dim, n_queries <= 256, k, flags) and whether it had a shadow; zeros when that search
+ * refine step; pass that search's own (n_rows, dim, n_queries of that chunk, k, flags) and whether it had a shadow; zeros when that search
  * ran the score-matrix filter.  Asynchronous on `stream`.                                                                          */
 int64_t lrx_search_fallback_count(int32_t reset);
+/* (ABI 8) Queries per chunk the bounded search walks a call of `n_queries` in: 256 over a shadow (128 over fp32 rows), or -- where the main
+ * pass runs on the GEMM kernel (shadow, dim >= 1024, score-free filter feasible) -- ONE pass over the shadow per up to 1024 queries (equal
+ * chunks, a multiple of 16 each).  Callers that pipeline chunks themselves (FlatIPIndex.search) split at these boundaries.                */
+int32_t lrx_flat_ip_bounded_chunk_queries(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags, int32_t has_shadow);
 int lrx_flat_ip_bounded_list_counts(const void* workspace, int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags,
                                     int32_t has_shadow, uint32_t* counts_out, void* stream);
 

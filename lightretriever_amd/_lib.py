@@ -66,6 +66,7 @@ SIGNATURES = {
     "lrx_flat_ip_search_bounded": (_I32, [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _I32, _I64, _P, _P, _P, _SZ, _I32, _P]),
     "lrx_flat_ip_search_bounded_wire": (_I32, [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _I32, _I64, _P, _P, _P, _P, _P, _SZ, _I32, _P]),
     "lrx_search_fallback_count": (_I64, [_I32]),
+    "lrx_flat_ip_bounded_chunk_queries": (_I32, [_I64, _I32, _I32, _I32, _I32, _I32]),
     "lrx_flat_ip_bounded_list_counts": (_I32, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "lrx_shard_commit_rows": (_I32, [_P, _I64, _I64, _I32, _P, _I64, _P, _P]),
     "lrx_pool_norm_shard": (_I32, [_P, _P, _P, _I32, _I32, _F, _P, _I64, _I32, _I32, _P, _I64, _P, _I32, _P]),

@@ -1543,8 +1543,8 @@ extern "C" int lrx_attn_build_items(const int32_t* cu_seqlens, int32_t n_seqs, i
   return LRX_OK;
 }
 static bool attn_uses_resident64(int head_dim, int max_seqlen, int last_tile_only) {
-  // LRX_ATTN_TILED=1: dev switch for A/B runs of the two d = 64 kernels (read once; C++11 static initialisation is thread-safe)
-  static const int force_tiled = []() { const char* e = getenv("LRX_ATTN_TILED"); return e ? atoi(e) : 0; }();
+  // LRX_ATTN_TILED=1 (dev builds only): A/B runs of the two d = 64 kernels (read once; C++11 static initialisation is thread-safe)
+  static const int force_tiled = lrx_dev_knob("LRX_ATTN_TILED", 0);
   return !force_tiled && head_dim == 64 && max_seqlen <= 512 && !last_tile_only;
 }
 static int launch_resident64(const void* qkv, const int32_t* cu_seqlens, int n_seqs, int num_q_heads, int num_kv_heads, void* out, hipStream_t s) {

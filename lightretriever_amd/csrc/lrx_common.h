@@ -59,6 +59,16 @@ __host__ __device__ __forceinline__ int64_t lrx_shadow_off(int64_t r, int k, int
   return ((r >> 7) * (int64_t)(D / 64) + (k >> 6)) * 8192 + ((((r >> 4) & 7) * 2 + ((k >> 5) & 1)) * 64 + ((k >> 3) & 3) * 16 + (r & 15)) * 8 + (k & 7);
 }
 
+// Dev knobs: the environment switches of the A/B tools (sample stride, tile-group sizes, fused-launch phases, ...) exist only in
+// -DLRX_DEV_KNOBS builds (`python -m lightretriever_amd.build -DLRX_DEV_KNOBS --out=<variant>.so`, run with LRX_LIB_DEV_VARIANT=<variant>.so);
+// the shipping liblrx.so reads NO environment variable (tests/test_abi.py checks its imports): its behaviour depends on its arguments alone.
+#ifdef LRX_DEV_KNOBS
+#include <stdlib.h>
+static inline int lrx_dev_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline int lrx_dev_knob(const char*, int dflt) { return dflt; }
+#endif
+
 // host-side error plumbing -----------------------------------------------------------------------------------
 void lrx_set_error(const char* fmt, ...);
 #define LRX_CHECK_ARG(cond, ...)          \
@@ -80,7 +90,8 @@ void lrx_set_error(const char* fmt, ...);
 
 static inline int64_t lrx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// lrx_gemm.hip: the GEMM kernel as the search's filter pass for 129..256 queries: scores = Xb[rows, D] . q16[nq, D]^T (bf16 operands,
+#define LRX_EMIT_MAX_QUERIES 1024   // queries of one chunk of the bounded search over a shadow of D >= 1024 (four 256-query n-tiles per A tile)
+// lrx_gemm.hip: the GEMM kernel as the search's filter pass for 129..LRX_EMIT_MAX_QUERIES queries: scores = Xb[rows, D] . q16[nq, D]^T (bf16 operands,
 // fp32 accumulation), nothing stored, rows reaching thr[query] appended to the query's candidate list.  Covers the 256-row tiles
 // that are not in the sample (every ss-th tile): n_tiles of them.
 int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles,

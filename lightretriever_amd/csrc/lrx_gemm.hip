@@ -313,7 +313,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int col = hp * 128 + wc * 32 + ni * 16 + fq * 4 + r;
+          const int col = n0 + hp * 128 + wc * 32 + ni * 16 + fq * 4 + r;     // the query (n0 > 0: a further 256-query n-tile of a wide chunk)
           t16[hp][ni][r] = col < N ? em.thr[col] : FLT_MAX;
         }
 #pragma unroll
@@ -339,8 +339,8 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
                   const unsigned long long w = sel_pack(f2key(v[r]), m);
                   if (p < WCAP) { wl[p] = w; wq[p] = col | (atomicAdd(&qc[col], 1u) << 8); }   // rank < 256 rows of the tile
                   else {                                        // list full (a tile of near-duplicates): straight to the query's list
-                    const unsigned int gp = atomicAdd(&em.cnt[col * CNT_STRIDE], 1u);
-                    if (gp < em.cap) em.cand[(int64_t)col * em.cap + gp] = w;
+                    const unsigned int gp = atomicAdd(&em.cnt[(n0 + col) * CNT_STRIDE], 1u);
+                    if (gp < em.cap) em.cand[(int64_t)(n0 + col) * em.cap + gp] = w;
                   }
                   ++p;
                 }
@@ -350,7 +350,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     __syncthreads();                                             // every wave's list and the per-query counts are complete
     if (tid < GBN) {
       const unsigned int n = qc[tid];
-      if (n) qc[tid] = atomicAdd(&em.cnt[tid * CNT_STRIDE], n);  // the count may pass cap: that IS the overflow signal downstream
+      if (n) qc[tid] = atomicAdd(&em.cnt[(n0 + tid) * CNT_STRIDE], n);  // the count may pass cap: that IS the overflow signal downstream
     }
     __syncthreads();
     const unsigned int total = min(*wn, (unsigned int)WCAP);
@@ -358,7 +358,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
       const unsigned long long w = wl[i];
       const unsigned int e = wq[i], col = e & 255u;
       const unsigned int gp = qc[col] + (e >> 8);
-      if (gp < em.cap) em.cand[(int64_t)col * em.cap + gp] = w;
+      if (gp < em.cap) em.cand[(int64_t)(n0 + col) * em.cap + gp] = w;
     }
     return;
   }
@@ -624,7 +624,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
 
 // m-tiles per group of the block -> tile map, per epilogue class (measured, see the kernel); LRX_GEMM_GM overrides it for sweeps
 static int gemm_group_m(int epilogue, int K) {
-  static const int env = []() { const char* e = getenv("LRX_GEMM_GM"); return e ? atoi(e) : 0; }();   // (thread-safe one-time read)
+  static const int env = lrx_dev_knob("LRX_GEMM_GM", 0);   // (dev builds only; thread-safe one-time read)
   if (env > 0) return env;
   // 1B shapes (K = 2048): gate-up 6, o/down 4, qkv 8; 8B shapes (K = 4096): within 2 % for 2..8, gate-up best at 8 (1596 TFLOP/s).
   // Round 4 sweep (tools/exp/gm_sweep.sh, M = 131 072): qkv 1.31-1.32 ms at 0 / 4 / 8 (1.34-1.59 elsewhere); down (K = 8192) 2.94 at 2 / 4, 3.03 at 6 / 8;
@@ -733,7 +733,7 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
   MaxAggArgs mx = {row_seg, out, ldo};
-  static const int maxagg_gm = []() { const char* e = getenv("LRX_MAXAGG_GM"); return e && atoi(e) > 0 ? atoi(e) : LRX_MAXAGG_GM; }();   // (sweeps: tools/exp/maxagg_gm_sweep.sh)
+  static const int maxagg_gm = lrx_dev_knob("LRX_MAXAGG_GM", 0) > 0 ? lrx_dev_knob("LRX_MAXAGG_GM", 0) : LRX_MAXAGG_GM;   // (dev builds: tools/exp/maxagg_gm_sweep.sh)
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
                      (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, maxagg_gm},
                      EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
@@ -741,19 +741,27 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   return LRX_OK;
 }
 
-// The filter pass of the bounded search for 129..256 queries (lrx_search.hip): the shard's tiled fp16 shadow against the fp16 queries
+// The filter pass of the bounded search for more than 128 queries (lrx_search.hip): the shard's tiled fp16 shadow against the fp16 queries
 // on the GEMM kernel -- its 256 x 256 tile stages a query k-slice once per 256 rows and its 4-phase K loop keeps the LDS-DMA ahead of
 // the MFMAs with one workgroup per CU; the 128-row filter kernel re-stages the 32-KiB query slice for every 128 rows and is bound
 // by that L2 -> LDS traffic at 16 query tiles (1.19 ms for 256 queries over 1M x 2048; HBM floor 0.75).
+// Round 6 -- wide chunks: up to LRX_EMIT_MAX_QUERIES queries = up to four 256-query n-tiles per streamed 256-row A tile.  The block -> tile
+// map walks groups of GM m-tiles x all n-tiles with GM x n-tiles ~ 32 = the workgroups one XCD runs at a time: the n-tiles of an A tile
+// run side by side on one XCD and find it in that XCD's L2, so the shadow is read from HBM once per pass whatever the query count
+// (1000 queries over 1M x 2048: 4.1 GB instead of 4 x 4.1 GB; the pass is then MFMA-bound like the encoder's GEMMs).
 int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles,
                                 const float* thr, unsigned long long* cand, unsigned int* cnt, unsigned int cap, hipStream_t stream) {
-  LRX_CHECK_ARG(dim > 0 && dim % GBK == 0 && nq > 0 && nq <= GBN && n_rows < (1ll << 31), "filter_emit: bad shape rows=%lld nq=%d dim=%d",
+  LRX_CHECK_ARG(dim > 0 && dim % GBK == 0 && nq > 0 && nq <= LRX_EMIT_MAX_QUERIES && n_rows < (1ll << 31), "filter_emit: bad shape rows=%lld nq=%d dim=%d",
                 (long long)n_rows, nq, dim);
   if (n_tiles <= 0) return LRX_OK;
+  const int tiles_n = (nq + GBN - 1) / GBN;
+  LRX_CHECK_ARG(n_tiles * tiles_n < (1ll << 31), "filter_emit: %lld tiles", (long long)(n_tiles * tiles_n));
+  static const int gm_env = lrx_dev_knob("LRX_EMIT_GM", 0);
+  const int gm = gm_env > 0 ? gm_env : (tiles_n == 1 ? 8 : (32 + tiles_n - 1) / tiles_n);
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
-  hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_EMIT>, dim3((unsigned)n_tiles), dim3(512), 0, stream, (const __bf16*)Xb, (const __bf16*)q16, (__bf16*)nullptr,
-                     (const __bf16*)nullptr, (const __bf16*)nullptr, (int)n_rows, nq, dim, (int)n_tiles, 1, none, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{nullptr, nullptr, 8}, EmitArgs{thr, cand, cnt, ss, cap});
+  hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_EMIT>, dim3((unsigned)(n_tiles * tiles_n)), dim3(512), 0, stream, (const __bf16*)Xb, (const __bf16*)q16, (__bf16*)nullptr,
+                     (const __bf16*)nullptr, (const __bf16*)nullptr, (int)n_rows, nq, dim, (int)n_tiles, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
+                     NormArgs{nullptr, nullptr, gm}, EmitArgs{thr, cand, cnt, ss, cap});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

@@ -1449,8 +1449,8 @@ static int launch_scores(const float* X, int64_t n_rows, int64_t ldx, int32_t di
 #define XPF_S 4   // ring depth of the one-workgroup-per-block form (8: no faster at D = 2048, 13 % slower at 10M x 256, Q = 1)
 #endif
       const int n_cu = lrx_cu_count();
-      // (LRX_EMIT_PERSIST_MIN_BPC: dev switch for A/B runs -- main passes with fewer blocks per CU than this run one workgroup per block)
-      static const int persist_min_bpc = []() { const char* e = getenv("LRX_EMIT_PERSIST_MIN_BPC"); return e ? atoi(e) : 0; }();
+      // (LRX_EMIT_PERSIST_MIN_BPC, dev builds: main passes with fewer blocks per CU than this run one workgroup per block)
+      static const int persist_min_bpc = lrx_dev_knob("LRX_EMIT_PERSIST_MIN_BPC", 0);
       const bool persistent = emit && gate == nullptr && (dim / 64) % XPF == 0 && fm.bmode != 1 && nwg < (1ll << 31) && nwg >= (int64_t)persist_min_bpc * n_cu;
       // sample pass: two blocks per workgroup (the q slice is fetched once per 256 rows) once there are more sample blocks than CUs; a
       // sample that fits the chip in one round runs one block per workgroup -- its time is the time of ONE workgroup's blocks through
@@ -2206,7 +2206,7 @@ __device__ __forceinline__ void sample_threshold_query(ThrShared& ts, int qi, co
     select_topk_sorted(row, Ns, k, gsz == 16 ? nullptr : bm, gsz == 16 ? 0 : nblk, sh);   // (the plan guarantees >= 2k valid sample rows)
     kth = key2f((uint32_t)(sh.cand[k - 1] >> 32));
   } else {
-    kth = -FLT_MAX;                                              // (not reachable: the fused plan requires >= k sample groups)
+    kth = -FLT_MAX;                                              // (not reachable: plan_chunk admits the fused launch only with >= k sample groups)
   }
   __syncthreads();
   const float eps = query_eps_block(q + (int64_t)qi * D, D, bounds, nullptr, s_red);
@@ -2648,7 +2648,7 @@ k_refine_merge(const unsigned long long* __restrict__ parts, const int* __restri
     tot += cnt[p] < 0 ? 0 : cnt[p];
   }
   if (any_over || tot < keff) {               // (tot < keff: a non-finite query or threshold -- the exact path sorts it out)
-    if (tid == 0) { qflags[qi] = 1; atomicOr(any_flag, 1); atomicAdd(&g_search_fallback_queries, 1u); }
+    if (tid == 0) { qflags[qi] = 1; atomicOr(any_flag + (qi >> 7), 1); atomicAdd(&g_search_fallback_queries, 1u); }   // (the flag of the query's 128-query group)
     return;
   }
   int base = 0;
@@ -2706,7 +2706,10 @@ struct BoundedPlan {
 };
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static size_t ints_before_cnt(int nq) { return ((size_t)nq + 1 + 8 + 63) & ~(size_t)63; }   // flags[nq], any_flag, ..., the fused kernel's five counters in the last 8
+// flags[nq], any_flag[8] (one per 128-query group of the chunk: the gated fallback of a group runs when one of ITS queries overflowed), ...,
+// the fused kernel's five counters in the last 8
+#define ANY_FLAG_GROUPS (LRX_EMIT_MAX_QUERIES / 128)
+static size_t ints_before_cnt(int nq) { return ((size_t)nq + ANY_FLAG_GROUPS + 8 + 63) & ~(size_t)63; }
 
 // Candidate-list capacity and sample stride for top-k: ~k * ss rows reach the sample's k-th score, the fp16 band adds ~30 % -- the list
 // should end up around a third full (a list that overflows sends its query to the exact fallback).  k <= 256: 16 Ki entries and ss = 20
@@ -2722,10 +2725,11 @@ static unsigned int cand_cap_for(int32_t k) {
   return cap;
 }
 
-// LRX_SEARCH_FUSED: unset = the measured rule in plan_chunk (small query batches over small shards), 0 = never (the three-launch chain of rounds
-// 2-4), 1 = wherever the fused kernel is eligible (A/B runs: tools/exp/fused_ab.sh).  Read once, thread-safe.
+// LRX_SEARCH_FUSED (dev builds only; the `flags` bits LRX_SEARCH_FUSED_ALWAYS / _NEVER are the per-call form): unset = the measured rule in
+// plan_chunk (small query batches over small shards), 0 = never (the three-launch chain of rounds 2-4), 1 = wherever the fused kernel is
+// eligible (A/B runs: tools/exp/fused_ab.sh).  Read once, thread-safe.
 static int search_fused_mode() {
-  static const int v = []() { const char* e = getenv("LRX_SEARCH_FUSED"); return e ? (atoi(e) == 0 ? 0 : 1) : -1; }();
+  static const int v = lrx_dev_knob("LRX_SEARCH_FUSED", -1) < 0 ? -1 : (lrx_dev_knob("LRX_SEARCH_FUSED", -1) == 0 ? 0 : 1);
   return v;
 }
 // fused preference of a call: -1 = by the rule, 0 = never, 1 = wherever eligible; flag bits LRX_SEARCH_FUSED_NEVER / _ALWAYS win over the environment
@@ -2741,9 +2745,9 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   p.nblk = p.ld / SP_ROWS;
   p.nblk_ld = (p.nblk + 3) & ~(int64_t)3;
   p.cap = cand_cap_for(k);
-  // (LRX_SS_MAX / LRX_SS_FORCE: A/B runs of the sample stride on one box; read once, thread-safe)
-  static const int ss_force = []() { const char* f = getenv("LRX_SS_FORCE"); return f && atoi(f) >= 2 ? atoi(f) : 0; }();
-  static const int ss_max = []() { const char* e = getenv("LRX_SS_MAX"); return e && atoi(e) >= 2 ? atoi(e) : SAMPLE_SS_MAX; }();
+  // (LRX_SS_MAX / LRX_SS_FORCE, dev builds: A/B runs of the sample stride on one box; read once, thread-safe)
+  static const int ss_force = lrx_dev_knob("LRX_SS_FORCE", 0) >= 2 ? lrx_dev_knob("LRX_SS_FORCE", 0) : 0;
+  static const int ss_max = lrx_dev_knob("LRX_SS_MAX", 0) >= 2 ? lrx_dev_knob("LRX_SS_MAX", 0) : SAMPLE_SS_MAX;
   const int64_t nwg = lrx_cdiv(n_rows > 0 ? n_rows : 1, p.rb);
   // The sample stride trades the sample pass against the hits of the main pass: T' is the k-th best of the sample, so ~k * ss rows per query
   // reach it (appended, selected from and band-checked in the refine step), while the sample pass scores rows / ss rows per query into a
@@ -2774,7 +2778,7 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   // (Q = 32 is a tie: 0.149 / 0.155 in separate processes, 0.131 / 0.130 back to back inside bench.py, so the rule stops at one query tile):
   // at most 16 queries, D >= 512, k <= 256, at most 8 blocks per CU.  LRX_SEARCH_FUSED=1 lifts the rule (not the eligibility).
   const bool fused_rule = nq <= 16 && dim >= 512 && k <= 256 && nwg <= 8 * (int64_t)lrx_cu_count();
-  const bool fused_ok = fused_pref != 0 && (fused_rule || fused_pref == 1) && shadow && !p.gemm && nq <= 128 && dim % 256 == 0 && n_rows < (1ll << 31) - 256;
+  bool fused_ok = fused_pref != 0 && (fused_rule || fused_pref == 1) && shadow && !p.gemm && nq <= 128 && dim % 256 == 0 && n_rows < (1ll << 31) - 256;
   if (fused_ok && !ss_force) {
     int lim = ss_hits < ss_list ? ss_hits : ss_list;
     lim = lim < 2 ? 2 : (lim > 64 ? 64 : lim);
@@ -2783,6 +2787,9 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   }
   while (ss > 2 && (lrx_cdiv(nwg, ss) - 1) * p.rb < 2 * (int64_t)k) ss = fused_ok ? ss - 1 : ss >> 1;
   const int64_t nsamp = lrx_cdiv(nwg, ss);
+  // (the fused kernel's selection works on the maxima of the sample's 16-row groups alone -- it has no sorted fallback over the scores --
+  // and needs k of them: nsamp blocks x 8 groups.  Smaller samples take the three-launch chain.)
+  if (nsamp * (p.rb / 16) < (int64_t)k) fused_ok = false;
   const bool feasible = (nsamp - 1) * p.rb >= 2 * (int64_t)k && nwg - nsamp >= 1 && dim % 4 == 0 && (shadow || nq > 16 * (SPLIT_MIN_QT - 1));
   if (!feasible) p.gemm = false;
   p.emit = feasible && mode != 1 && (mode >= 2 || n_rows >= 16384);
@@ -2797,8 +2804,9 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   const size_t prim = p.emit ? (size_t)nq * (size_t)(p.ld_s + 8 * p.nblk_ld_s) : (size_t)nq * (size_t)(p.ld + p.nblk_ld);   // (sample: group maxima, 8 per block)
   p.off_qsplit = align256((prim > fb ? prim : fb) * sizeof(float));
   p.off_q16 = align256(p.off_qsplit + split_ws_bytes(dim));
-  p.off_qs3 = align256(p.off_q16 + (size_t)256 * dim * 2);          // planes of the gated fallback, two groups of <= 128 queries
-  p.off_ints = align256(p.off_qs3 + 2 * split_ws_bytes(dim));
+  const size_t nq256 = ((size_t)(nq > 256 ? nq : 256) + 255) & ~(size_t)255;   // (a wide chunk: up to LRX_EMIT_MAX_QUERIES queries)
+  p.off_qs3 = align256(p.off_q16 + nq256 * dim * 2);                // planes of the gated fallback, groups of <= 128 queries
+  p.off_ints = align256(p.off_qs3 + (nq256 / 128) * split_ws_bytes(dim));
   // ints: flags[nq], any_flag, pad to 64 ints, cnt[nq * CNT_STRIDE] (one memset) | part_cnt[nq * REF_SPLIT] | thr[nq] | eps[nq]
   p.off_parts = align256(p.off_ints + sizeof(int) * (ints_before_cnt(nq) + (size_t)nq * (CNT_STRIDE + 2 + REF_SPLIT)));
   p.off_cand = align256(p.off_parts + (size_t)nq * REF_CAND * 8);
@@ -2806,15 +2814,34 @@ static BoundedPlan plan_chunk(int64_t n_rows, int32_t dim, int32_t nq, int32_t k
   return p;
 }
 
+// Queries per chunk of one call.  256 over a shadow (128 over fp32 rows) -- or, round 6, a WIDE chunk of up to LRX_EMIT_MAX_QUERIES where the
+// main pass can run on the GEMM kernel (shadow, D >= 1024, the score-free filter feasible): the query count is split into equal chunks (a
+// multiple of 16 each), so that 1000 queries are ONE pass over the shadow instead of four.  LRX_SEARCH_WIDE_MAX (dev builds): A/B of the width.
+static int chunk_queries(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, bool shadow, int mode) {
+  const int base = shadow ? 256 : 128;
+  if (!shadow || n_queries <= base) return base;
+  static const int wide_env = lrx_dev_knob("LRX_SEARCH_WIDE_MAX", 0);
+  const int wide_max = wide_env >= 256 && wide_env <= LRX_EMIT_MAX_QUERIES ? (wide_env & ~255) : LRX_EMIT_MAX_QUERIES;
+  if (wide_max <= base) return base;
+  const int nchunks = (n_queries + wide_max - 1) / wide_max;
+  const int wide = (((n_queries + nchunks - 1) / nchunks) + 15) & ~15;
+  const BoundedPlan p = plan_chunk(n_rows, dim, wide < n_queries ? wide : n_queries, k, shadow, mode, 0);
+  return (p.gemm && p.emit) ? wide : base;
+}
+
+extern "C" int32_t lrx_flat_ip_bounded_chunk_queries(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags, int32_t has_shadow) {
+  return chunk_queries(n_rows, dim, n_queries > 0 ? n_queries : 1, k, has_shadow && dim % 64 == 0, flags & 3);
+}
+
 extern "C" size_t lrx_flat_ip_bounded_workspace_bytes(int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags) {
-  // the search walks the queries in chunks of 256 (shadow) or 128 (fp32 rows), each chunk with its own plan over the same buffer; sized
-  // for the filter `flags` selects (the score-matrix filter of LRX_SEARCH_FILTER_MATRIX needs [min(Q, 256), rows] floats), with or
-  // without a shadow
+  // the search walks the queries in chunks (chunk_queries: 256 over a shadow, up to LRX_EMIT_MAX_QUERIES where the GEMM main pass applies; 128
+  // over fp32 rows), each chunk with its own plan over the same buffer; sized for the filter `flags` selects (the score-matrix filter of
+  // LRX_SEARCH_FILTER_MATRIX needs [min(Q, 256), rows] floats), with or without a shadow
   const int32_t nq = n_queries > 0 ? n_queries : 1;
   const int mode = flags & 3;
   size_t need = lrx_flat_ip_workspace_bytes(n_rows, dim, nq < 128 ? nq : 128, k);   // tiny shards / few queries without shadow: plain path in chunks of 128
   for (int sh = 0; sh < 2; ++sh) {
-    const int chunk = sh ? 256 : 128;
+    const int chunk = chunk_queries(n_rows, dim, nq, k, sh != 0, mode);
     const int sizes[2] = {nq < chunk ? nq : chunk, nq > chunk ? nq % chunk : 0};
     for (int i = 0; i < 2; ++i)
       if (sizes[i] > 0) {
@@ -2862,11 +2889,12 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
     return out_wire != nullptr ? lrx_pack_topk(out_scores, out_ids, row_map, id_base, (int64_t)n_queries * k, out_wire, stream) : LRX_OK;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int chunk = shadow ? 256 : 128;
+  const int chunk = chunk_queries(n_rows, dim, n_queries, k, shadow, mode);
   const int use_fused = fused_pref_of(flags);
   for (int q0 = 0; q0 < n_queries; q0 += chunk) {
     const int nq = n_queries - q0 < chunk ? n_queries - q0 : chunk;
     const BoundedPlan p = plan_chunk(n_rows, dim, nq, k, shadow, mode, use_fused);
+    LRX_CHECK_ARG(nq <= (shadow ? 256 : 128) || (p.gemm && p.emit), "flat_ip_search_bounded: a chunk of %d queries without the GEMM main pass", nq);
     if (p.total > workspace_bytes) {      // (cannot happen with a workspace sized by lrx_flat_ip_bounded_workspace_bytes for the same flags)
       lrx_set_error("flat_ip_search_bounded: chunk of %d queries needs %zu B of workspace, %zu given", nq, p.total, workspace_bytes);
       return LRX_ERR_WORKSPACE;
@@ -2878,7 +2906,7 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
     float* scores = (float*)ws;
     __bf16* qsplit = (__bf16*)(ws + p.off_qsplit);
     int* flg = (int*)(ws + p.off_ints);
-    int* any_flag = flg + nq;
+    int* any_flag = flg + nq;                 // [ANY_FLAG_GROUPS]: one per 128-query group of the chunk
     unsigned int* cnt = (unsigned int*)(flg + ints_before_cnt(nq));
     int* part_cnt = (int*)(cnt + (size_t)nq * CNT_STRIDE);
     float* thr = (float*)(part_cnt + (size_t)nq * REF_SPLIT);
@@ -2891,20 +2919,26 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
     if (!clear_in_pack) LRX_HIP(hipMemsetAsync(flg, 0, sizeof(int) * nclear, s));
     // ... and so are the hi/mid/lo query planes of the gated six-product fallback (groups of <= 128 queries; <= 32 queries run the
     // exact-fp32 kernel, which needs none)
-    PreSplit presplit;
     __bf16* qs3 = (__bf16*)(ws + p.off_qs3);
-    if (shadow) {
-      presplit.qs3 = qs3;
-      presplit.stride = (int64_t)(split_ws_bytes(dim) / sizeof(__bf16));
-      for (int f0 = 0, g = 0; f0 < nq; f0 += 128, ++g) {
-        const int nf = nq - f0 < 128 ? nq - f0 : 128, qtf = (nf + 15) / 16;
-        presplit.nf[g] = nf;
-        presplit.qt[g] = qtf;
-        presplit.blocks[g] = qtf >= SPLIT_MIN_QT ? ((dim / 32) * qtf * 64 + 255) / 256 : 0;
-        presplit.ngroups = g + 1;
+    const int64_t qs3_stride = (int64_t)(split_ws_bytes(dim) / sizeof(__bf16));
+    // (per 256-query sub-chunk j of the chunk: the plane sets of its two 128-query groups, qs3 + (2 j + g) * stride)
+    auto presplit_of = [&](int j) {
+      PreSplit ps;
+      if (!shadow) return ps;
+      const int n0 = j * 256, nj = nq - n0 < 256 ? nq - n0 : 256;
+      ps.qs3 = qs3 + (int64_t)(2 * j) * qs3_stride;
+      ps.stride = qs3_stride;
+      for (int f0 = 0, g = 0; f0 < nj; f0 += 128, ++g) {
+        const int nf = nj - f0 < 128 ? nj - f0 : 128, qtf = (nf + 15) / 16;
+        ps.nf[g] = nf;
+        ps.qt[g] = qtf;
+        ps.blocks[g] = qtf >= SPLIT_MIN_QT ? ((dim / 32) * qtf * 64 + 255) / 256 : 0;
+        ps.ngroups = g + 1;
       }
-      if (presplit.blocks[0] + presplit.blocks[1] == 0) presplit.ngroups = 0;
-    }
+      if (ps.blocks[0] + ps.blocks[1] == 0) ps.ngroups = 0;
+      return ps;
+    };
+    const PreSplit presplit = presplit_of(0);
     int rc;
     int nsplit = REF_SPLIT;                   // parts per query of the refine step
     if (p.emit) {
@@ -2920,11 +2954,19 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
         fa.ld_s = p.ld_s; fa.nblk_s = (int)p.nblk_s; fa.nblk_ld_s = (int)p.nblk_ld_s; fa.nsamp = (int)p.nsamp_wg; fa.nmain = (int)p.nmain_wg; fa.ss = p.ss; fa.k = k;
         fa.bounds = row_bounds; fa.thr = thr; fa.eps = eps; fa.cand = cand; fa.cnt = cnt; fa.cap = p.cap;
         fa.ctl = (FusedCtl*)(flg + ints_before_cnt(nq) - 8);
-        static const int fused_phases = []() { const char* e = getenv("LRX_FUSED_PHASES"); const int v = e ? atoi(e) : 7; return (v & 7) == 1 || (v & 7) == 3 || (v & 7) == 7 ? (v & 135) : 7; }();
+        static const int fused_phases = []() { const int v = lrx_dev_knob("LRX_FUSED_PHASES", 7); return (v & 7) == 1 || (v & 7) == 3 || (v & 7) == 7 ? (v & 135) : 7; }();   // (dev builds)
         fa.phases = fused_phases;
         fs.fused = &fa;
       }
-      rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_shadow : nullptr, p.ld_s, fs);
+      // (a wide chunk: the sample pass -- 1 / ss of the rows -- runs once per 256-query sub-chunk into that sub-chunk's rows of the compact
+      // score matrix and of the group maxima; the first launch's packing kernel clears the ints of the whole chunk)
+      rc = LRX_OK;
+      for (int j = 0, n0 = 0; n0 < nq && rc == LRX_OK; ++j, n0 += 256) {
+        FilterMode fj = fs;
+        if (j > 0) { fj.zero = nullptr; fj.nzero = 0; fj.presplit = presplit_of(j); }
+        rc = launch_scores(X, n_rows, ldx, dim, qc + (int64_t)n0 * dim, nq - n0 < 256 ? nq - n0 : 256, scores + (int64_t)n0 * p.ld_s,
+                           blkmax + (int64_t)n0 * (fs.group_max ? 8 : 1) * p.nblk_ld_s, qsplit, stream, 1, nullptr, shadow ? X_shadow : nullptr, p.ld_s, fj);
+      }
       if (rc != LRX_OK) return rc;
       if (fs.fused == nullptr || !(fa.phases & 2))
       hipLaunchKernelGGL(k_sample_threshold, dim3(nq), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld_s, p.nsamp_wg * p.rb, k, (const float*)blkmax,
@@ -3017,13 +3059,15 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
       const int nf = nq - f0 < 128 ? nq - f0 : 128;
       float* blkmax = scores + p.ld * (int64_t)nf;
       FilterMode ff;
-      ff.planes_ready = presplit.ngroups > 0;                 // written by the packing kernel at the head of the chain
-      rc = launch_scores(X, n_rows, ldx, dim, qc + (int64_t)f0 * dim, nf, scores, blkmax, ff.planes_ready ? qs3 + (f0 / 128) * presplit.stride : qsplit, stream, 3,
-                         any_flag, nullptr, 0, ff);
+      const PreSplit psf = presplit_of(f0 / 256);
+      ff.planes_ready = psf.ngroups > 0;                      // written by the packing kernel(s) at the head of the chain
+      const int* gate = any_flag + f0 / 128;                  // this group's flag: raised by k_refine_merge when one of its queries overflowed
+      rc = launch_scores(X, n_rows, ldx, dim, qc + (int64_t)f0 * dim, nf, scores, blkmax, ff.planes_ready ? qs3 + (f0 / 128) * qs3_stride : qsplit, stream, 3,
+                         gate, nullptr, 0, ff);
       if (rc != LRX_OK) return rc;
       hipLaunchKernelGGL(k_topk_select_rescore, dim3(nf), dim3(SEL_THREADS), 0, s, (const float*)scores, p.ld, n_rows, k, id_base, (const float*)blkmax,
                          (int)p.nblk, (int)p.nblk_ld, X, ldx, dim, qc + (int64_t)f0 * dim, osc + (int64_t)f0 * k, oic + (int64_t)f0 * k,
-                         (const int*)any_flag, (const int*)(flg + f0), row_bounds,
+                         gate, (const int*)(flg + f0), row_bounds,
                          out_wire != nullptr ? (unsigned long long*)out_wire + ((int64_t)q0 + f0) * k : (unsigned long long*)nullptr, row_map);
       LRX_LAUNCH_CHECK();
     }
@@ -3041,7 +3085,7 @@ __global__ void k_copy_list_counts(const unsigned int* __restrict__ cnt, int nq,
 extern "C" int lrx_flat_ip_bounded_list_counts(const void* workspace, int64_t n_rows, int32_t dim, int32_t n_queries, int32_t k, int32_t flags,
                                                int32_t has_shadow, uint32_t* counts_out, void* stream) {
   const bool shadow = has_shadow && dim % 64 == 0;
-  LRX_CHECK_ARG(workspace && counts_out && n_queries > 0 && n_queries <= (shadow ? 256 : 128), "bounded_list_counts: one query chunk only (n_queries=%d)", n_queries);
+  LRX_CHECK_ARG(workspace && counts_out && n_queries > 0 && n_queries <= (shadow ? LRX_EMIT_MAX_QUERIES : 128), "bounded_list_counts: one query chunk only (n_queries=%d)", n_queries);
   const BoundedPlan p = plan_chunk(n_rows, dim, n_queries, k, shadow, flags & 3, fused_pref_of(flags));
   const int* flg = (const int*)((const char*)workspace + p.off_ints);
   // (the same test lrx_flat_ip_search_bounded_wire uses to send a call down the plain path, which keeps no lists)

@@ -31,9 +31,10 @@ def shard_of(out: torch.Tensor):
 
 class FlatIPIndex:
     """One HBM-resident shard.  Memory: 4 B/element fp32 rows + 2 B/element tiled fp16 shadow + the search workspace -- per lane in use,
-    for a chunk of up to 256 queries: candidate lists of max(64 Ki, 64 k rounded up to a power of two) 8-byte entries per query (512 KiB per
-    query up to k = 1024: 134 MB per 256-query chunk), the compact sample scores and the [128, ntotal] fp32 region of the gated fallback;
-    `lrx_flat_ip_bounded_workspace_bytes` is the exact figure.  A search of MORE than 256 queries forks its 256-query chunks over
+    for a chunk of up to 256 queries (up to 1024 where the main pass runs on the GEMM kernel: shadow, d >= 1024, more than 256 queries in the
+    call): candidate lists of max(64 Ki, 64 k rounded up to a power of two) 8-byte entries per query (512 KiB per
+    query up to k = 1024: 134 MB per 256-query chunk, 0.5 GB per 1024), the compact sample scores and the [128, ntotal] fp32 region of the gated fallback;
+    `lrx_flat_ip_bounded_workspace_bytes` is the exact figure.  A search of MORE queries than one library chunk forks its chunks over
     `chunk_lanes` (2) internal HIP streams with one workspace each (so up to 2 x the figure above) unless that would exceed
     `max_workspace_bytes`, in which case it runs the chunks one after the other on the caller's stream.  Lanes != 0 (pipeline.SearchLanes)
     add one workspace each.  NOT thread-safe: an index keeps search state (workspaces, internal streams, the statistics of the last search);
@@ -271,7 +272,11 @@ class FlatIPIndex:
         if self.two_pass and self.shadow_f16:
             self._ensure_shadow()                       # (no-op unless rows were committed while the shadow was switched off)
         xb = self._xb if (self.two_pass and self._wants_shadow() and self._xb is not None and self._shadow_rows >= self.ntotal) else None
-        lib_chunk = 256 if (xb is not None and self.d % 64 == 0) else 128          # the library walks a call's queries in chunks of this size
+        # the library walks a call's queries in chunks of this size: 256 over the shadow (128 without) or, where its main pass runs on the GEMM
+        # kernel (D >= 1024), ONE pass over the shadow per up to 1024 queries (lrx_flat_ip_bounded_chunk_queries, round 6)
+        has_xb = xb is not None and self.d % 64 == 0
+        lib_chunk_of = lambda n: int(self.lib.lrx_flat_ip_bounded_chunk_queries(self.ntotal, self.d, n, k, flags, int(has_xb))) if self.two_pass else 128
+        lib_chunk = lib_chunk_of(min(Q, chunk))
         # More queries than one library chunk: the chunks are independent searches over the same rows, so they alternate between two
         # internal HIP streams (own workspaces), forked from and joined back into the caller's stream inside this call -- the short
         # latency-bound kernels that frame one chunk's passes overlap the other chunk's passes (Q = 1000, top-1000 over a 100 k-row
@@ -303,7 +308,8 @@ class FlatIPIndex:
             _lib.check(self.lib.lrx_pack_topk(_lib.ptr(D), _lib.ptr(I), _lib.ptr(row_map), int(self.id_base), Q * k, _lib.ptr(wire_out), _lib.current_stream()))
         # (nq of the last library chunk of the last host chunk, the ntotal / mode the workspace was planned for, and the workspace itself)
         last_ws = lane_ws[((Q - 1) // chunk) % self.chunk_lanes] if fork else ws
-        self._last_search = (((Q - 1) % chunk) % lib_chunk + 1, k, flags, xb is not None, last_ws, self.ntotal, bool(self.two_pass))
+        n_last_call = (Q - 1) % chunk + 1                                    # queries of the last library call ...
+        self._last_search = ((n_last_call - 1) % lib_chunk_of(n_last_call) + 1, k, flags, xb is not None, last_ws, self.ntotal, bool(self.two_pass))   # ... and of its last chunk
         return D, I
 
     def _run_chunks(self, q, D, I, k, chunk, fork, lane_ws, ws, start, xb, ldx, flags, row_map, wire_out):

@@ -26,6 +26,26 @@ def test_library_builds_and_exports_header_symbols():
     assert _lib.lib().lrx_abi_version() == _lib.ABI_VERSION == 8
 
 
+def test_shipping_library_reads_no_environment_variable():
+    """the A/B switches of the tools (sample stride, tile groups, fused-launch phases, ...) live behind -DLRX_DEV_KNOBS; the
+    shipping liblrx.so neither imports getenv nor carries the knob names -- its behaviour depends on its arguments alone."""
+    import re
+    import subprocess
+    from lightretriever_amd import _lib
+    assert os.path.basename(_lib.LIB_PATH) == "liblrx.so" or os.environ.get("LRX_LIB_DEV_VARIANT")
+    lib = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "liblrx.so")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"\bU (secure_)?getenv\b", syms), [l for l in syms.splitlines() if "getenv" in l]
+    blob = open(lib, "rb").read()
+    for knob in (b"LRX_SS_FORCE", b"LRX_SS_MAX", b"LRX_SEARCH_FUSED", b"LRX_FUSED_PHASES", b"LRX_EMIT_PERSIST_MIN_BPC", b"LRX_GEMM_GM", b"LRX_MAXAGG_GM",
+                 b"LRX_ATTN_TILED", b"LRX_SEARCH_WIDE_MAX", b"LRX_EMIT_GM"):
+        assert knob not in blob, knob
+    # ... and no source under csrc/ calls getenv outside the dev-knob helper
+    csrc = os.path.join(os.path.dirname(lib), "csrc")
+    hits = [(f, i + 1) for f in sorted(os.listdir(csrc)) for i, l in enumerate(open(os.path.join(csrc, f), errors="replace")) if "getenv(" in l]
+    assert hits == [("lrx_common.h", hits[0][1])] and len(hits) == 1, hits
+
+
 def test_argument_errors_are_reported_without_a_gpu():
     l = _lib.lib()
     # invalid shapes are rejected on the host before any launch

@@ -41,6 +41,11 @@ def _index(X, shadow=True, id_base=0, pieces=2):
     (33000, 4096, 48, 100, "unit", True),                       # the 8B width (BASELINE configs 2-3)
     # 129..256 queries over a wide shard: the main pass runs on the GEMM kernel (256-row tiles, sample in 256-row units)
     (40000, 1024, 200, 10, "unit", True), (33001, 2048, 300, 5, "mixed", True), (70000, 1024, 256, 100, "unit", True), (20000, 1088, 129, 3, "unit", True),
+    # round 6 -- WIDE chunks: more than 256 queries over a shadow of D >= 1024 are ONE pass of the GEMM kernel per up to 1024 queries (2-4 query
+    # n-tiles per streamed A tile; the sample pass, the fallback planes and the group flags per 256 / 128 queries inside): 600 = 3 n-tiles with a
+    # ragged last one, 1000 / 1024 = 4, 1100 = two balanced chunks of 560 + 540, the 8B width, k = 1000 (row-grouped rescoring over the chunk)
+    (70000, 1024, 600, 100, "unit", True), (40000, 2048, 1000, 10, "mixed", True), (50000, 1024, 1100, 20, "unit", True),
+    (33000, 4096, 513, 100, "unit", True), (30000, 1024, 1024, 1000, "unit", True), (20480, 1536, 257, 64, "mixed", True),
     (60000, 256, 100, 100, "unit", False), (45000, 128, 128, 10, "mixed", False), (30011, 96, 40, 64, "unit", False),   # fp32 rows converted on the fly
     # the register-streaming filter kernels of the tiled shadow: persistent main pass (D/64 % 4 == 0: 512, 768; whole q resident in LDS at
     # 256), one-workgroup-per-block form otherwise (192 = 3 slices), odd block counts for the two-blocks-at-a-time walk, 9..16 query tiles
@@ -100,9 +105,14 @@ def test_workspace_stops_growing_at_256_queries():
     assert w[3] < 6 << 30                                        # round 1: 280 GB of [queries, rows] scores for 7000 queries
     full = 10_000_000 * 100 * 4
     assert int(lib.lrx_flat_ip_bounded_workspace_bytes(10_000_000, 256, 100, 100, 0)) < 1.1 * full + (64 << 20)
-    # top_k = 1000 (the reference's default): lists of 64 Ki entries, 128 MB for 256 queries -- still independent of the query count
-    w1k = [int(lib.lrx_flat_ip_bounded_workspace_bytes(1_000_000, 2048, nq, 1000, 0)) for nq in (256, 5000)]
-    assert w1k[0] == w1k[1] < 1 << 30
+    # top_k = 1000 (the reference's default): lists of 64 Ki entries, 128 MB for 256 queries.  D >= 1024 (round 6): a call of more than 256
+    # queries is walked in WIDE chunks of up to 1024 (one GEMM pass over the shadow each): the workspace stops growing there
+    w1k = [int(lib.lrx_flat_ip_bounded_workspace_bytes(1_000_000, 2048, nq, 1000, 0)) for nq in (256, 1024, 5000, 50000)]
+    assert w1k[0] < 1 << 30 and w1k[0] < w1k[1] and w1k[2] <= w1k[1] and w1k[3] <= w1k[1] < 2 << 30
+    ch = lambda n, d=2048, rows=1_000_000: int(lib.lrx_flat_ip_bounded_chunk_queries(rows, d, n, 100, 0, 1))
+    assert [ch(n) for n in (1, 100, 256, 257, 1000, 1024, 1025, 3000)] == [256, 256, 256, 272, 1008, 1024, 528, 1008]
+    assert ch(1000, d=256) == 256 and ch(1000, rows=3000) == 256 and int(lib.lrx_flat_ip_bounded_chunk_queries(1_000_000, 2048, 1000, 100, 0, 0)) == 128
+    assert int(lib.lrx_flat_ip_bounded_chunk_queries(1_000_000, 2048, 1000, 100, 1, 1)) == 256     # (score-matrix filter forced: no wide chunks)
 
 
 def test_adversarial_fp16_rounding_midpoints(search_mode):

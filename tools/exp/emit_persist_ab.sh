@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the LRX_* switches below exist only in a -DLRX_DEV_KNOBS build of the library: tools/dev_lib.sh builds it and exports LRX_LIB_DEV_VARIANT)
+. "$(dirname "$0")/../dev_lib.sh"
 # A/B: persistent main pass (one workgroup per CU walking its blocks) vs one workgroup per 128-row block, on the per-rank shard sizes
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for shape in "125000 2048" "250000 2048" "500000 2048" "1250000 256"; do

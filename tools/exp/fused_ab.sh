@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the LRX_* switches below exist only in a -DLRX_DEV_KNOBS build of the library: tools/dev_lib.sh builds it and exports LRX_LIB_DEV_VARIANT)
+. "$(dirname "$0")/../dev_lib.sh"
 # Round 5: the fused filter launch (k_filter_fused: sample + selection + main pass) against the three-launch chain, same box, one process per
 # (shape, mode).  usage: tools/exp/fused_ab.sh > gpurun_out/r05_fused_ab.txt
 set -u

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the LRX_* switches below exist only in a -DLRX_DEV_KNOBS build of the library: tools/dev_lib.sh builds it and exports LRX_LIB_DEV_VARIANT)
+. "$(dirname "$0")/../dev_lib.sh"
 # dev: the fused launch against the three-launch chain on the per-rank shard, with the phase timeline of the fused kernel
 for v in "1" "0"; do
   echo "== 125000x2048 fused=$v"

@@ -1,4 +1,6 @@
-"""Dev: one bounded search on a small shard with the fused launch, checked against the fp64 host evaluation (bisecting aid: LRX_FUSED_PHASES)."""
+"""Dev: one bounded search on a small shard with the fused launch, checked against the fp64 host evaluation (bisecting aid: LRX_FUSED_PHASES).
+Needs a -DLRX_DEV_KNOBS build of the library (`. tools/dev_lib.sh` builds it and exports LRX_LIB_DEV_VARIANT): the shipping liblrx.so reads no
+environment variable."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))

@@ -1,4 +1,6 @@
-"""Dev: per-workgroup phase timeline of one fused filter launch (LRX_FUSED_PHASES must include bit 7 = 128)."""
+"""Dev: per-workgroup phase timeline of one fused filter launch (LRX_FUSED_PHASES must include bit 7 = 128).
+Needs a -DLRX_DEV_KNOBS build of the library (`. tools/dev_lib.sh` builds it and exports LRX_LIB_DEV_VARIANT): the shipping liblrx.so reads no
+environment variable."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the LRX_* switches below exist only in a -DLRX_DEV_KNOBS build of the library: tools/dev_lib.sh builds it and exports LRX_LIB_DEV_VARIANT)
+. "$(dirname "$0")/../dev_lib.sh"
 # larger sample strides now that the candidate lists hold 64 Ki entries (LRX_SS_MAX caps the rule; 32 is the shipped cap)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for shape in "10000000 256" "1000000 4096" "1250000 4096" "1000000 2048"; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the LRX_* switches below exist only in a -DLRX_DEV_KNOBS build of the library: tools/dev_lib.sh builds it and exports LRX_LIB_DEV_VARIANT)
+. "$(dirname "$0")/../dev_lib.sh"
 # sample stride (LRX_SS_FORCE sets it; "rule" = the library's own choice) against shard size, k and query count: where the emission of k*ss hits per query starts to cost more than a
 # larger sample.  CFGS="rows,k,queries ..." SSS="2 4 8 ..."
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the LRX_* switches below exist only in a -DLRX_DEV_KNOBS build of the library: tools/dev_lib.sh builds it and exports LRX_LIB_DEV_VARIANT)
+. "$(dirname "$0")/dev_lib.sh"
 # Package power + shader clock (rocm-smi, one sample per second) while a GEMM-only loop runs, one block per variant:
 #   tools/power_probe.sh            -> the round-4 table: gate-up kernel (random / constant / zero operands), block->tile group sizes with
 #                                      more and less fabric traffic, the plain-store epilogue, the vendor GEMM on the same shape
