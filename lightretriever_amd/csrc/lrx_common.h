@@ -96,6 +96,9 @@ static inline int64_t lrx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // that are not in the sample (every ss-th tile): n_tiles of them.
 int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles,
                                 const float* thr, unsigned long long* cand, unsigned int* cnt, unsigned int cap, hipStream_t stream);
+// lrx_gemm.hip: ... and as its sample pass (n_tiles sample tiles: corpus tiles 0, ss, 2 ss, ...): fp32 scores [nq, ld_s] + 16-row-group maxima
+int lrx_gemm_filter_sample_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles, float* scores, float* gmax,
+                                  int64_t ld_s, int nblk_ld_s, hipStream_t stream);
 // lrx_gemm.hip: the GEMM kernel with the segmented-maximum epilogue (used by lrx_sparse_max_aggregate)
 int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias, const int32_t* row_seg, float* out, int64_t ldo, int M, int N,
                                   int K, hipStream_t stream);

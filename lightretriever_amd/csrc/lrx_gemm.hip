@@ -31,7 +31,9 @@
 #define GBK 64
 #define HALF_BYTES 16384
 
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE = 3, EPI_MAXAGG = 4, EPI_EMIT = 5, EPI_RESID32 = 6 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE = 3, EPI_MAXAGG = 4, EPI_EMIT = 5, EPI_RESID32 = 6, EPI_SAMPLE = 7 };
+// the two instantiations of the search: A = the shard's tiled fp16 shadow, B = fp16 queries, f16 MFMA
+#define EPI_IS_SEARCH(E) ((E) == EPI_EMIT || (E) == EPI_SAMPLE)
 
 // Fused QKV epilogue (EPI_ROPE, round 3): the rows of the q and k heads of Wqkv arrive in ROTARY-PAIR order (include/lrx.h: physical
 // column 32 g + 16 i + t of a head = logical column i d/2 + 16 g + t), so the two accumulators a lane holds for a 16 x 32 block -- columns
@@ -67,12 +69,19 @@ int lrx_gemm_saturations_reset() {
 // Search filter pass (EPI_EMIT): A = the shard's tiled FP16 shadow (lrx_shadow_off), B = fp16 queries (f16 MFMA); no C.  A score reaching thr[query] is appended
 // to the query's candidate list (lrx_search.hip).  ss > 0: m-tile t of the launch is the t-th 256-row tile that is NOT in the sample
 // (the sample = every ss-th tile).
+// Sample pass (EPI_SAMPLE, round 6): m-tile t of the launch IS sample tile t (corpus tile t * ss); its scores go out as fp32 into the compact
+// sample matrix (scores[query, ld_s], sample row 256 t + row) together with the maxima of its 16-row groups (gmax[query, 8 nblk_ld_s], 8 per
+// 128-row block) -- what k_sample_threshold selects from (lrx_search.hip).
 struct EmitArgs {
   const float* thr;          // [nq]
   unsigned long long* cand;  // [nq, cap]
   unsigned int* cnt;         // [nq * CNT_STRIDE]
   int ss;
   unsigned int cap;          // capacity of one candidate list
+  float* scores;             // EPI_SAMPLE: [nq, ld_s]
+  float* gmax;               //             [nq, 8 * nblk_ld_s]
+  int64_t ld_s;
+  int nblk_ld_s;
 };
 
 struct MaxAggArgs {
@@ -120,7 +129,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 template <int EPI>
 __device__ __forceinline__ f32x4 gemm_mfma(bf16x8 x, bf16x8 y, f32x4 c) {
-  if constexpr (EPI == EPI_EMIT) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+  if constexpr (EPI_IS_SEARCH(EPI)) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
 }
 
@@ -142,7 +151,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   const int tin = t_lin - group * width;
   const int tm = first_m + tin % gsz, tn = tin / gsz;
   // (filter pass: the tm-th tile outside the strided sample)
-  const int tmx = (EPI == EPI_EMIT && em.ss > 1) ? (tm / (em.ss - 1)) * em.ss + 1 + tm % (em.ss - 1) : tm;
+  const int tmx = EPI == EPI_SAMPLE ? tm * em.ss : ((EPI == EPI_EMIT && em.ss > 1) ? (tm / (em.ss - 1)) * em.ss + 1 + tm % (em.ss - 1) : tm);
   const int m0 = tmx * GBM, n0 = tn * GBN;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -156,7 +165,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   for (int i = 0; i < 2; ++i) {
     int s = (wave * 2 + i) * 64 + lane;
     int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
-    if (EPI == EPI_EMIT) {
+    if (EPI_IS_SEARCH(EPI)) {
       // tiled shadow: a half-tile (128 rows x 64) IS one 16-KiB fragment-major tile of the source -> copied linearly, 1 KiB per request
       // (the LDS image is then fragment-major too: laneoffA below); blocks past the last one re-read it, masked in the epilogue
       const int64_t lastb = (int64_t)(M - 1) >> 7;
@@ -172,14 +181,13 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   }
   char* const dma_dst = smem + wave * 2048;  // + buf*65536 + slot*16384 + i*1024
 #define G_KOFF(KT) ((KT) * GBK)
-  const int a_ks = (EPI == EPI_EMIT) ? 8192 : GBK;   // elements from one K-tile of an A row to the next
+  const int a_ks = EPI_IS_SEARCH(EPI) ? 8192 : GBK;   // elements from one K-tile of an A row to the next
 #define G_ISSUE_(P, SLOT, BUF, KOFF)                                                                                       \
   do {                                                                                                                     \
     __builtin_amdgcn_global_load_lds((gptr_t)(P[0] + (KOFF)), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES), 16, 0, 0);        \
     __builtin_amdgcn_global_load_lds((gptr_t)(P[1] + (KOFF)), (lptr_t)(dma_dst + (BUF) * 65536 + (SLOT) * HALF_BYTES + 1024), 16, 0, 0); \
   } while (0)
 #define G_ISSUE(P, SLOT, BUF, KT) G_ISSUE_(P, SLOT, BUF, ((SLOT) < 2 ? (int64_t)(KT) * a_ks : (int64_t)G_KOFF(KT)))   /* slots 0/1 = A halves */
-
 
   // ---- fragment read offsets
   const int fr = lane & 15, fq = lane >> 4;
@@ -189,7 +197,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   for (int ks = 0; ks < 2; ++ks) laneoff[ks] = fr * 128 + (((ks * 4 + fq) ^ xs) << 4);
   int laneoffA[2];               // A-side fragment offsets: the swizzled row image, or (tiled shadow) the fragment-major tile [16-row group][ks][lane]
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) laneoffA[ks] = (EPI == EPI_EMIT) ? ks * 1024 + lane * 16 : laneoff[ks];
+  for (int ks = 0; ks < 2; ++ks) laneoffA[ks] = EPI_IS_SEARCH(EPI) ? ks * 1024 + lane * 16 : laneoff[ks];
   const int a_off = (wr * 64) * 128, b_off = 2 * HALF_BYTES + (wc * 32) * 128;
 
   f32x4 acc[2][2][4][2];
@@ -222,7 +230,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
-      rsv[h][mi] = (EPI != EPI_MAXAGG && EPI != EPI_RESID && EPI != EPI_EMIT && nrm.rscale != nullptr) ? nrm.rscale[min(m0 + h * 128 + wr * 64 + mi * 16 + fr, M - 1)] : 1.0f;
+      rsv[h][mi] = (EPI != EPI_MAXAGG && EPI != EPI_RESID && !EPI_IS_SEARCH(EPI) && nrm.rscale != nullptr) ? nrm.rscale[min(m0 + h * 128 + wr * 64 + mi * 16 + fr, M - 1)] : 1.0f;
 
   int rposv[2][4];             // EPI_ROPE: positions of this lane's 8 rows (the table lookups of the epilogue depend on them)
 #pragma unroll
@@ -290,6 +298,48 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   //      (now idle) 128 KiB of LDS -- 16-B chunk index XOR (row & 15): conflict-free ds_write_b64 and ds_read_b128 -- and
   //      written row-major, 16 B per lane: every wave instruction moves two full 512-B row segments.  The residual is
   //      read the same way and added to the bf16-rounded product (exactly the reference's bf16 `residual + linear(x)`).
+  if constexpr (EPI == EPI_SAMPLE) {
+    // ---- sample pass of the search: fp32 scores into the compact sample matrix [query, sample row] + the maxima of the 16-row groups.
+    //      Lane (fr, fq) of wave (wr, wc) holds rows h*128 + wr*64 + mi*16 + fr and query columns hp*128 + wc*32 + ni*16 + fq*4 + r: stored
+    //      straight from that layout a wave instruction writes four 64-B pieces of four queries' rows (measured: 610 us for the 125 MB of a
+    //      1000-query sample of 1M rows).  Instead the tile goes through the idle LDS TRANSPOSED, one 128-query half at a time (128 KiB):
+    //      LDS[query][256 rows] fp32, 16-B chunk index XOR ((query >> 2) & 3) << 2 -- the four fq lanes of a write land in four different
+    //      16-bank windows, a read-out instruction takes one query's whole 1-KiB row run (one permuted chunk per lane) -- and leaves as full
+    //      1-KiB runs; the 16 rows of a group are then the four lanes of a quad: two DPP steps give its maximum.
+    const int64_t gstride = 8 * (int64_t)em.nblk_ld_s;
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
+      if (hp) __syncthreads();                                   // the first half has been read out
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int row = h * 128 + wr * 64 + mi * 16 + fr;
+          const bool mok = (int64_t)m0 + row < M;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int cl = wc * 32 + ni * 16 + fq * 4 + r;     // query column inside this half; (cl >> 2) & 3 == fq
+              *(float*)(smem + cl * 1024 + ((((row >> 2) ^ (fq << 2))) << 4) + (row & 3) * 4) = mok ? acc[h][hp][mi][ni][r] : -FLT_MAX;
+            }
+        }
+      __syncthreads();
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int cl = it * 8 + wave, col = n0 + hp * 128 + cl;  // (wave-uniform)
+        const f32x4 v = *(const f32x4*)(smem + cl * 1024 + ((lane ^ (((cl >> 2) & 3) << 2)) << 4));   // rows 4 lane .. 4 lane + 3 of query `col`
+        float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4E, 0xF, 0xF, true)));    // quad_perm [2,3,0,1]
+        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
+        if (col < N) {
+          *(f32x4*)(em.scores + (int64_t)col * em.ld_s + (int64_t)tm * GBM + lane * 4) = v;
+          if ((lane & 3) == 0) em.gmax[(int64_t)col * gstride + (int64_t)tm * 16 + (lane >> 2)] = mx;   // group (128-row block 2 tm + row / 128, 16-row group) = 16 tm + row / 16
+        }
+      }
+    }
+    return;
+  }
   if constexpr (EPI == EPI_EMIT) {
     // ---- search filter epilogue: nothing is stored per (row, query).  Lane (fr, fq) of wave (wr, wc) holds rows h*128 + wr*64 +
     //      mi*16 + fr and query columns hp*128 + wc*32 + ni*16 + fq*4 + r.  Hits (~5e-3 of the scores) first go to a per-wave list in
@@ -658,9 +708,9 @@ extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, con
   MaxAggArgs nomx = {nullptr, nullptr, 0};
   NormArgs nrm = {rscale, ss_part, gemm_group_m(epilogue, K)};
   switch (epilogue) {
-    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u}); break;
-    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u}); break;
-    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u}); break;
+    case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0}); break;
+    case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0}); break;
+    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0}); break;
   }
   LRX_LAUNCH_CHECK();
   return LRX_OK;
@@ -699,7 +749,7 @@ extern "C" int lrx_gemm_qkv_rope_slice(const void* A, const void* Wqkv, void* C,
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A,
                      (const __bf16*)Wqkv + (int64_t)col0 * K, (__bf16*)C + col0, bias ? (const __bf16*)bias + col0 : (const __bf16*)nullptr,
                      (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0}, NormArgs{rscale, nullptr, 8},
-                     EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
+                     EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -716,7 +766,7 @@ extern "C" int lrx_gemm_bf16_nt_resid32(const void* A, const void* B, float* x32
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID32>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)B,
                      (__bf16*)a16_out, (const __bf16*)gamma, (const __bf16*)x32, M, N, K, tiles_m, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{nullptr, ss_part, gemm_group_m(EPI_RESID, K)}, EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
+                     NormArgs{nullptr, ss_part, gemm_group_m(EPI_RESID, K)}, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -736,7 +786,7 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
   static const int maxagg_gm = lrx_dev_knob("LRX_MAXAGG_GM", 0) > 0 ? lrx_dev_knob("LRX_MAXAGG_GM", 0) : LRX_MAXAGG_GM;   // (dev builds: tools/exp/maxagg_gm_sweep.sh)
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_MAXAGG>, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, (const __bf16*)B, (__bf16*)nullptr,
                      (const __bf16*)bias, (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, none, mx, NormArgs{nullptr, nullptr, maxagg_gm},
-                     EmitArgs{nullptr, nullptr, nullptr, 0, 0u});
+                     EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -761,7 +811,24 @@ int lrx_gemm_filter_emit_launch(const void* Xb, const void* q16, int64_t n_rows,
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_EMIT>, dim3((unsigned)(n_tiles * tiles_n)), dim3(512), 0, stream, (const __bf16*)Xb, (const __bf16*)q16, (__bf16*)nullptr,
                      (const __bf16*)nullptr, (const __bf16*)nullptr, (int)n_rows, nq, dim, (int)n_tiles, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
-                     NormArgs{nullptr, nullptr, gm}, EmitArgs{thr, cand, cnt, ss, cap});
+                     NormArgs{nullptr, nullptr, gm}, EmitArgs{thr, cand, cnt, ss, cap, nullptr, nullptr, 0, 0});
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// The SAMPLE pass of the same search on the same kernel (round 6): every ss-th 256-row tile of the shadow against all queries, scores and
+// 16-row-group maxima stored for k_sample_threshold.  (Rounds 2-5 ran it on the 128-row register-streaming kernel, which at 16 query tiles
+// spends 170 us on ONE block per workgroup -- 0.68 of the 4.0 ms of a 1000-query search went there.)
+int lrx_gemm_filter_sample_launch(const void* Xb, const void* q16, int64_t n_rows, int nq, int dim, int ss, int64_t n_tiles, float* scores, float* gmax,
+                                  int64_t ld_s, int nblk_ld_s, hipStream_t stream) {
+  LRX_CHECK_ARG(dim > 0 && dim % GBK == 0 && nq > 0 && nq <= LRX_EMIT_MAX_QUERIES && n_rows < (1ll << 31) && ss >= 1 && scores && gmax,
+                "filter_sample: bad shape rows=%lld nq=%d dim=%d", (long long)n_rows, nq, dim);
+  if (n_tiles <= 0) return LRX_OK;
+  const int tiles_n = (nq + GBN - 1) / GBN;
+  RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
+  hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SAMPLE>, dim3((unsigned)(n_tiles * tiles_n)), dim3(512), 0, stream, (const __bf16*)Xb, (const __bf16*)q16, (__bf16*)nullptr,
+                     (const __bf16*)nullptr, (const __bf16*)nullptr, (int)n_rows, nq, dim, (int)n_tiles, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
+                     NormArgs{nullptr, nullptr, tiles_n == 1 ? 8 : (32 + tiles_n - 1) / tiles_n}, EmitArgs{nullptr, nullptr, nullptr, ss, 0u, scores, gmax, ld_s, nblk_ld_s});
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }

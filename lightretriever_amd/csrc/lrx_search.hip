@@ -2958,14 +2958,24 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
         fa.phases = fused_phases;
         fs.fused = &fa;
       }
-      // (a wide chunk: the sample pass -- 1 / ss of the rows -- runs once per 256-query sub-chunk into that sub-chunk's rows of the compact
-      // score matrix and of the group maxima; the first launch's packing kernel clears the ints of the whole chunk)
-      rc = LRX_OK;
-      for (int j = 0, n0 = 0; n0 < nq && rc == LRX_OK; ++j, n0 += 256) {
-        FilterMode fj = fs;
-        if (j > 0) { fj.zero = nullptr; fj.nzero = 0; fj.presplit = presplit_of(j); }
-        rc = launch_scores(X, n_rows, ldx, dim, qc + (int64_t)n0 * dim, nq - n0 < 256 ? nq - n0 : 256, scores + (int64_t)n0 * p.ld_s,
-                           blkmax + (int64_t)n0 * (fs.group_max ? 8 : 1) * p.nblk_ld_s, qsplit, stream, 1, nullptr, shadow ? X_shadow : nullptr, p.ld_s, fj);
+      __bf16* q16 = (__bf16*)(ws + p.off_q16);
+      if (p.gemm) {
+        // More than 128 queries over a shadow of D >= 1024: BOTH passes on the GEMM kernel (round 6; the 128-row register-streaming kernel needs
+        // 170 us for one sample block at 16 query tiles).  The packing kernel still runs once per 256-query sub-chunk: it clears the ints of the
+        // chunk (first launch) and writes the fallback planes of the sub-chunk's two 128-query groups.
+        for (int j = 0, n0 = 0; n0 < nq; ++j, n0 += 256) {
+          const int nj = nq - n0 < 256 ? nq - n0 : 256, qtj = (nj + 15) / 16;
+          PreSplit ps = presplit_of(j);
+          ps.nb_xb = ((dim / 64) * 2 * qtj * 64 + 255) / 256;
+          hipLaunchKernelGGL(k_pack_queries_xb, dim3(ps.nb_xb + (ps.ngroups > 0 ? ps.blocks[0] + ps.blocks[1] : 0)), dim3(256), 0, s, qc + (int64_t)n0 * dim, nj, dim, qtj,
+                             qsplit, j == 0 ? fs.zero : (int*)nullptr, j == 0 ? fs.nzero : 0, ps);
+          LRX_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(k_round_queries, dim3((unsigned)lrx_cdiv((int64_t)nq * dim, 1024)), dim3(256), 0, s, qc, (int64_t)nq * dim, q16);
+        LRX_LAUNCH_CHECK();
+        rc = lrx_gemm_filter_sample_launch(X_shadow, q16, n_rows, nq, dim, p.ss, p.nsamp_wg, scores, blkmax, p.ld_s, (int)p.nblk_ld_s, s);
+      } else {
+        rc = launch_scores(X, n_rows, ldx, dim, qc, nq, scores, blkmax, qsplit, stream, 1, nullptr, shadow ? X_shadow : nullptr, p.ld_s, fs);
       }
       if (rc != LRX_OK) return rc;
       if (fs.fused == nullptr || !(fa.phases & 2))
@@ -2975,9 +2985,6 @@ extern "C" int lrx_flat_ip_search_bounded_wire(const float* X, int64_t n_rows, i
       if (fs.fused != nullptr && (fa.phases & 4)) {
         rc = LRX_OK;                                            // sample, selection and main pass are done
       } else if (p.gemm) {
-        __bf16* q16 = (__bf16*)(ws + p.off_q16);
-        hipLaunchKernelGGL(k_round_queries, dim3((unsigned)lrx_cdiv((int64_t)nq * dim, 1024)), dim3(256), 0, s, qc, (int64_t)nq * dim, q16);
-        LRX_LAUNCH_CHECK();
         rc = lrx_gemm_filter_emit_launch(X_shadow, q16, n_rows, nq, dim, p.ss, p.nmain_wg, thr, cand, cnt, p.cap, s);
       } else {
         FilterMode fm;
