@@ -1108,7 +1108,16 @@ def main():
             tx = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
             if distributed:
                 dist.all_reduce(tx, op=dist.ReduceOp.MAX)
-            other[str(Qx)] = {"queries_per_s": round(Qx * n_px / float(tx.item()), 1), "ms_per_pass": round(1e3 * float(tx.item()) / n_px, 4), "passes": n_px}
+            ms_x = 1e3 * float(tx.item()) / n_px
+            # which bound applies: one query streams the shard's fp16 shadow once (HBM); 1000 queries are one pass of the f16 MFMA
+            # GEMM over it (wide chunks: the shadow is read once per <= 1024 queries) -- both fractions, the applicable one named
+            hb = hbm_roofline(shard_rows, D, Qx, args.topk, ms_x)
+            tf = 2.0 * Qx * D * shard_rows / (ms_x * 1e-3) / 1e12
+            other[str(Qx)] = {"queries_per_s": round(Qx * n_px / float(tx.item()), 1), "ms_per_pass": round(ms_x, 4), "passes": n_px,
+                              "roofline": {"bound": "hbm" if Qx <= 128 else "mfma", "frac": hb["frac"] if Qx <= 128 else round(tf / PEAK_BF16_TFLOPS, 4),
+                                           "hbm_frac": hb["frac"], "hbm_achieved_gbs": hb["achieved"], "mfma_f16_tflops": round(tf, 1),
+                                           "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4), "mfma_peak_tflops": PEAK_BF16_TFLOPS,
+                                           "note": "whole pass incl. EmbeddingBag + exchange; f16 dense MFMA peak = the bf16 figure"}}
         search["other_query_counts"] = other
 
     # ---- dense + sparse document vectors (row N2): same batches through lrx_encode_packed_sparse; not part of `value`

@@ -1,4 +1,5 @@
 #!/bin/bash
+# RETIRED (round 6): the switch this script drove is gone from the library -- its result is in profiles/r04_*.txt and is now a constant of plan_chunk / launch_scores.
 # (the LRX_* switches below exist only in a -DLRX_DEV_KNOBS build of the library: tools/dev_lib.sh builds it and exports LRX_LIB_DEV_VARIANT)
 . "$(dirname "$0")/../dev_lib.sh"
 # A/B: persistent main pass (one workgroup per CU walking its blocks) vs one workgroup per 128-row block, on the per-rank shard sizes
