@@ -30,8 +30,9 @@ class InferenceArguments:
     append_prompt_sep: bool = False
     q_max_len: int = 128
     p_max_len: int = 512
-    # (inference/arguments.py:68-73.  The HIP encoder has ONE arithmetic: bf16 MFMA operands, fp32 accumulation, fp32 residual stream;
-    # `--bf16` is accepted and recorded in `dtype`, it does not select a different kernel.  `--fp16` is refused.)
+    # (inference/arguments.py:68-73.  The HIP encoder has ONE arithmetic: bf16 MFMA operands, fp32 accumulation, fp32 residual stream, fp16
+    # q|k|v|P; `--bf16` and `--fp16` are accepted and recorded in `dtype`, neither selects a different kernel: the result is within 1e-3
+    # cosine of the fp32 model either way -- closer to it than the reference's own bf16 run)
     bf16: bool = False
     fp16: bool = False
     seed: int = 42
@@ -115,8 +116,8 @@ class InferenceArguments:
             raise NotImplementedError(f"--pooling_strategy {self.pooling_strategy}: 'avg_first_last' / 'avg_top2' pool over other layers' hidden states "
                                       "(finetune/dense_pooling.py:38-46) and are not served; lasttoken (the released models), cls, mean, "
                                       "second_to_last and third_to_last are")
-        if self.fp16:
-            raise NotImplementedError("bf16 is the compute type of the HIP encoder")
+        if self.fp16 and self.bf16:
+            raise ValueError("--bf16 and --fp16 are mutually exclusive (inference/arguments.py:68-73)")
         # options whose non-default value selects a part of the reference this path does not implement: fail loudly, never silently
         for name, default in (("hybrid_model_architecture", "gpt"), ("untie_encoder", False), ("enable_bidirectional_attention", False),
                               ("use_sparse_linear_projector", False), ("use_sparse_down_projector", False), ("use_icu_word_pretokenizer", False),
@@ -170,6 +171,22 @@ def arguments_from_checkpoint(model_name_or_path: str, **overrides) -> "Inferenc
     return InferenceArguments(**kw)
 
 
+def host_threads_per_rank() -> int:
+    """CPU threads this rank's tokenizer should use: the cores this process may run on (affinity mask capped by the cgroup quota) divided by
+    the ranks of the node.  The Rust tokenizer parallelises a batch over a rayon pool of ALL visible CPUs by default; with one process per
+    GPU that is 8 pools of 256 threads on a 16-core quota (tools/bench_host_ranks.py).  The reference sizes its DataLoader worker pool the
+    same way (inference/exact_search_torchrpc.py:176-203)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    ranks = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1)
+    return max(1, n // max(1, ranks))
+
+
 class PytorchRPCExactSearchModel(LrxExactSearchModel):
     """Drop-in for eval/eval_utils.py:179 `PytorchRPCExactSearchModel(args)`."""
 
@@ -183,6 +200,8 @@ class PytorchRPCExactSearchModel(LrxExactSearchModel):
         self.args = args
         dev = torch.device("cuda", args.local_rank if args.local_rank >= 0 else torch.cuda.current_device())
         torch.cuda.set_device(dev)
+        # the tokenizer's thread pool is sized on its first parallel call: this rank's share of the host cores (an explicit RAYON_NUM_THREADS wins)
+        os.environ.setdefault("RAYON_NUM_THREADS", str(host_threads_per_rank()))
         tok = load_tokenizer(args.model_name_or_path, lowercase=args.lowercase and args.edit_tokenizer_normalizers,
                              add_bos_num=args.add_bos_num if args.edit_tokenizer_post_processor else -1,
                              add_eos_num=args.add_eos_num if args.edit_tokenizer_post_processor else -1,

@@ -309,7 +309,7 @@ def test_full_depth_hf_parity(preset, seed):
     Gaussian random-init at the real config, against the HF transformers fp32 model on the same GPU (the forward
     finetune/modeling_hybrid.py:248-278 runs): 1 - cos <= 1e-3 for the full embedding and for the MRL slice out_dim = 256 (BASELINE config 5).
     Round 4 (VERDICT r3 item 2): 64 documents of mixed lengths (512, 1, 2, 511, ...) instead of 7, three weight seeds for the 8B and the 7B;
-    the MAX is asserted, p50 / p99 recorded (gpurun_out/r05_full_depth_parity.jsonl -> profiles/).  The trained-like counterpart of this
+    the MAX is asserted, p50 / p99 recorded (gpurun_out/r06_full_depth_parity.jsonl -> profiles/).  The trained-like counterpart of this
     test is tests/test_gpu_trained_like.py."""
     import json, os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -325,7 +325,7 @@ def test_full_depth_hf_parity(preset, seed):
         rec["lrx_vs_fp32_mrl"]["max"], rec["hfbf16_vs_fp32"]["max"]))
     out_dir = os.path.join(root, "gpurun_out")
     if os.path.isdir(out_dir):                                   # (the margins DESIGN.md section 3 quotes come from this file)
-        with open(os.path.join(out_dir, "r05_full_depth_parity.jsonl"), "a") as f:
+        with open(os.path.join(out_dir, "r06_full_depth_parity.jsonl"), "a") as f:
             f.write(json.dumps(rec) + "\n")
     assert rec["fp16_saturations"] == 0
     assert max(rec["lrx_vs_fp32"]["max"], rec["lrx_vs_fp32_mrl"]["max"]) <= COS_TOL, (preset, seed, rec)

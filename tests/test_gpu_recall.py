@@ -10,7 +10,7 @@ queries) at Llama-3.2-1B dims and depth, trained-like weights, through three com
 (every pipeline builds its own documents, its own EmbeddingBag table and its own queries; the hits are retriever/faiss_index.py:27-40's).
 Asserted: overlap@100 and the top-10 rank agreement of lrx against HF fp32 are at least those of HF bf16 against HF fp32 -- i.e. switching
 from the reference's own bf16 run to this build moves the retrieved sets TOWARDS the exact-arithmetic result, not away from it -- plus
-absolute floors.  The numbers go to gpurun_out/r05_recall.jsonl (-> profiles/)."""
+absolute floors.  The numbers go to gpurun_out/r06_recall.jsonl (-> profiles/)."""
 import json
 import os
 import sys
@@ -29,7 +29,7 @@ def test_retrieved_sets_agree_with_the_fp32_reference_at_least_as_well_as_hf_bf1
     rec = rp.measure("llama32_1b", n_docs=n_docs, n_queries=200, seed=0, profile="trained_like", k=100)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "r05_recall.jsonl"), "a") as f:
+        with open(os.path.join(out_dir, "r06_recall.jsonl"), "a") as f:
             f.write(json.dumps(rec) + "\n")
     print(json.dumps(rec))
     assert rec["stream"] == "precise_fp32"                                  # the default mode, the one bench.py times
@@ -41,7 +41,7 @@ def test_retrieved_sets_agree_with_the_fp32_reference_at_least_as_well_as_hf_bf1
         assert a["top10_same_position"] >= b["top10_same_position"], (kind, a, b)
         assert a["overlap_at_10"] >= b["overlap_at_10"], (kind, a, b)
         assert a["top1"] >= b["top1"] - 1e-9, (kind, a, b)
-        # absolute floors (measured, profiles/r05_recall.jsonl: overlap@100 0.975 / 0.968, overlap@10 0.981 / 0.967, top-1 0.93 / 0.96 for emb / dense on a
+        # absolute floors (measured, profiles/r06_recall.jsonl: overlap@100 0.975 / 0.968, overlap@10 0.981 / 0.967, top-1 0.93 / 0.96 for emb / dense on a
         # corpus whose 100th and 101st fp32 scores are 7e-5 apart -- HF bf16 reaches 0.92 / 0.92, 0.94 / 0.91, 0.74 / 0.89 there)
         if n_docs >= 20000 and not kind.endswith("_mrl"):
             assert a["overlap_at_100"] >= 0.95 and a["overlap_at_10"] >= 0.94 and a["top1"] >= 0.88, (kind, a)

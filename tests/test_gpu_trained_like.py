@@ -41,7 +41,7 @@ def test_trained_like_weights_full_depth_parity(preset, seed):
     # (the headline model's record also carries the bf16 stream's distance on the same weights -- the mode rounds 1-4 benchmarked, which
     # misses the bar; not asserted)
     rec = pm.measure(preset, seed=seed, profile="trained_like", n_docs=64, other_stream=preset == "llama32_1b")
-    _record(rec, "r05_trained_like_parity.jsonl")
+    _record(rec, "r06_trained_like_parity.jsonl")
     assert rec["stream"] == "precise_fp32", rec["stream"]                          # the default mode of every backbone since round 5
     w = rec["weights"]
     # the regime, as measured by the generator's calibration forward on its own bf16-rounded weights
@@ -60,6 +60,25 @@ def test_trained_like_weights_full_depth_parity(preset, seed):
         rec["lrx_vs_fp32_mrl"]["max"], rec["hfbf16_vs_fp32_mrl"]["max"]))
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("preset", ["llama31_8b", "qwen25_7b"])
+def test_trained_like_wide_sample_where_the_tail_lives(preset, seed):
+    """64 documents read 6-7e-4 for the 8B where the worst of an 8 000-document sample crosses 1e-3 by a
+    tenth -- the asserted sample was too small to see the tail.  512 documents per backbone (one HF fp32 pass of ~130 k
+    tokens is the cost): the 99.9th percentile must hold the 1e-3 bar, the maximum and the count above it are reported, and the maximum itself
+    must stay within 1.25e-3 (the recorded tail) and 4 x closer to fp32 than HF's own bf16 run."""
+    import parity_margin as pm
+    rec = pm.measure(preset, seed=seed, profile="trained_like", n_docs=512)
+    _record(rec, "r06_trained_like_wide.jsonl")
+    full, mrl, hf16 = rec["lrx_vs_fp32"], rec["lrx_vs_fp32_mrl"], rec["hfbf16_vs_fp32"]
+    print("trained-like %s seed %d, 512 documents: lrx p50 %.2e p99 %.2e p99.9 %.2e max %.2e (%d over 1e-3; worst document %d tokens); MRL-256 p99.9 %.2e max %.2e; "
+          "HF bf16 p99.9 %.2e max %.2e" % (preset, seed, full["p50"], full["p99"], full["p999"], full["max"], full["over_1e-3"], rec["worst_doc_len"],
+                                        mrl["p999"], mrl["max"], hf16["p999"], hf16["max"]))
+    assert rec["stream"] == "precise_fp32" and rec["fp16_saturations"] == 0 and full["n"] == 512
+    assert full["p999"] <= COS_TOL and mrl["p999"] <= 1.25 * COS_TOL, (full, mrl)
+    assert full["max"] <= 1.25 * COS_TOL and full["max"] <= hf16["max"] / 4, (full, hf16)
+
+
 @pytest.mark.parametrize("preset", ["llama32_1b", "llama31_8b"])
 def test_trained_like_weights_harsher_amplification(preset):
     """The one free parameter of the synthetic profile is how strongly a layer amplifies a perturbation of the residual stream (content
@@ -68,7 +87,7 @@ def test_trained_like_weights_harsher_amplification(preset):
     import parity_margin as pm
     rec = pm.measure(preset, seed=3, profile="trained_like", n_docs=32,
                      synth={"content_sigma": [1.5, 3.0], "attn_add": 0.25, "mlp_add": 0.35})
-    _record(rec, "r05_trained_like_parity.jsonl")
+    _record(rec, "r06_trained_like_parity.jsonl")
     assert rec["fp16_saturations"] == 0
     assert rec["lrx_vs_fp32"]["max"] <= max(COS_TOL, rec["hfbf16_vs_fp32"]["max"]), rec
     assert rec["lrx_vs_fp32_mrl"]["max"] <= max(COS_TOL, rec["hfbf16_vs_fp32_mrl"]["max"]), rec

@@ -513,12 +513,16 @@ def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_m
     assert d.hybrid_use_emb_vector and d.noncontextual_query_embedding is False
     for bad in (["--hybrid_use_emb_vector", "--untie_encoder"], ["--hybrid_use_sparse_vector"], ["--hybrid_use_emb_vector", "--enable_bidirectional_attention"],
                 ["--hybrid_use_emb_vector", "--use_sparse_linear_projector"], ["--hybrid_use_emb_vector", "--sparse_remove_stopwords"],
-                ["--hybrid_use_emb_vector", "--hybrid_model_architecture", "bert"], ["--hybrid_use_emb_vector", "--fp16"],
+                ["--hybrid_use_emb_vector", "--hybrid_model_architecture", "bert"],
                 ["--hybrid_use_emb_vector", "--pooling_strategy", "avg_top2"], ["--hybrid_use_emb_vector", "--sparse_use_max_aggregation", "False"]):
         with pytest.raises(NotImplementedError):
             parse(*bad)
     with pytest.raises(ValueError, match="no vector type selected"):
         parse()
+    # round 6: `--fp16` is accepted like `--bf16` (recorded in dtype; one arithmetic); both at once is the reference's own contradiction
+    assert parse("--hybrid_use_emb_vector", "--fp16").dtype == torch.float16
+    with pytest.raises(ValueError):
+        parse("--hybrid_use_emb_vector", "--fp16", "--bf16")
     # round 6: the single-layer pooling strategies of finetune/dense_pooling.py:12-82 are served
     for st in ("cls", "mean", "second_to_last", "third_to_last"):
         assert parse("--hybrid_use_dense_vector", "--pooling_strategy", st).pooling_strategy == st
@@ -689,3 +693,44 @@ def test_encode_queries_routes_vector_types_without_a_gpu(tok):
     # token-id-only model: nothing goes through the operator
     hm = FakeHybrid(False, False, False, sparse=True)
     assert set(LrxExactSearchModel(model=hm, tokenizer=tok, q_max_len=16).encode_queries(qs, batch_size=8)) == {"token_id_reps"} and hm.seen == []
+
+
+def test_host_threads_per_rank_divides_the_usable_cores(monkeypatch):
+    """Round 6: one process per GPU shares the node's host cores -- the tokenizer pool of a rank gets cores / ranks
+    threads (at least one), never the default of every visible CPU."""
+    from lightretriever_amd import inference
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)), raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    one = inference.host_threads_per_rank()
+    assert 1 <= one <= 16
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert inference.host_threads_per_rank() == max(1, one // 8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "64")
+    assert inference.host_threads_per_rank() == 1
+
+
+def test_prefetched_token_budget_batches_preserve_input_order():
+    """encode()'s host pipeline -- collation one worker thread ahead (_prefetch_batches) + token-budget merging (_token_budget_batches) -- hands
+    the encoder every document exactly once, in input order, whatever the batch size and budget: row i of the output is input i
+    (inference/exact_search_torchrpc.py:243-295 assembles by index for the same guarantee)."""
+    from lightretriever_amd.modeling import _prefetch_batches, _token_budget_batches
+    rng = np.random.default_rng(3)
+    lens = rng.integers(1, 60, size=1003).tolist()
+    items = [{"i": i, "n": n} for i, n in enumerate(lens)]
+
+    def coll(batch):                                            # packed collator stand-in: the document's index as its token ids
+        ids = torch.cat([torch.full((b["n"],), b["i"], dtype=torch.int32) for b in batch])
+        return {"input_ids": ids, "cu_seqlens": torch.tensor([0] + list(np.cumsum([b["n"] for b in batch])), dtype=torch.int32),
+                "max_seqlen": max(b["n"] for b in batch)}
+
+    for bs, budget, max_docs in ((16, 500, 64), (7, 0, 64), (64, 4000, 100), (1003, 10 ** 6, 10 ** 6), (5, 10 ** 6, 11)):
+        seen = []
+        for s, e, b in _token_budget_batches(_prefetch_batches(coll, items, bs), budget, max_docs):
+            cu = b["cu_seqlens"].tolist()
+            assert e - s == len(cu) - 1 and (budget <= 0 or cu[-1] <= max(budget, max(lens[s:e]) * bs)) and e - s <= max(max_docs, bs)
+            for j in range(e - s):
+                seg = b["input_ids"][cu[j]:cu[j + 1]]
+                assert seg.numel() == lens[s + j] and bool((seg == s + j).all())
+            seen.extend(range(s, e))
+        assert seen == list(range(len(items)))

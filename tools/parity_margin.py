@@ -76,7 +76,8 @@ def gaps(a, b):
 
 def summary(g):
     g = g.cpu().numpy()
-    return {"max": float(g.max()), "p99": float(np.quantile(g, 0.99)), "p50": float(np.median(g)), "argmax": int(g.argmax())}
+    return {"max": float(g.max()), "p999": float(np.quantile(g, 0.999)), "p99": float(np.quantile(g, 0.99)), "p50": float(np.median(g)), "argmax": int(g.argmax()),
+            "over_1e-3": int((g > 1e-3).sum()), "n": int(g.size)}
 
 
 def measure(preset: str, seed: int = 0, profile: str = "trained_like", n_docs: int = 64, mrl: int = 256, other_stream: bool = False, synth=None) -> dict:
