@@ -672,11 +672,27 @@ def ragged_encode_leg(args, dev):
     return out
 
 
+def coll_device(dev):
+    """Where the bench's own tiny collectives (timing reductions, shard sizes) live: on the GPU over RCCL; on the host when the process group is
+    gloo (LRX_BENCH_BACKEND=gloo: the rehearsal of N > 1 ranks on ONE GPU, tests/test_gpu_00_multi_gpu.py -- RCCL refuses two ranks per device)."""
+    return torch.device("cpu") if (dist.is_initialized() and dist.get_backend() == "gloo") else dev
+
+
 def reduce_max(x, dev, distributed):
-    t = torch.tensor([x], device=dev, dtype=torch.float64)
+    t = torch.tensor([x], device=coll_device(dev), dtype=torch.float64)
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_counts(n, dev, distributed):
+    """[n of rank 0, n of rank 1, ...] as RCCL (or gloo) reports it"""
+    if not distributed:
+        return [int(n)]
+    cd = coll_device(dev)
+    t = torch.empty(dist.get_world_size(), dtype=torch.int64, device=cd)
+    dist.all_gather_into_tensor(t, torch.tensor([int(n)], dtype=torch.int64, device=cd))
+    return t.tolist()
 
 
 def sharded_search_leg(name, index_rows, dim, nq, k, dev, rank, world, distributed, passes, seed):
@@ -690,7 +706,7 @@ def sharded_search_leg(name, index_rows, dim, nq, k, dev, rank, world, distribut
     rows, base = shard_split(index_rows, rank, world)
     need = rows * dim * 6 + (2 << 30)
     free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-    fits = torch.tensor([1 if need < 0.85 * free else 0], device=dev, dtype=torch.int64)
+    fits = torch.tensor([1 if need < 0.85 * free else 0], device=coll_device(dev), dtype=torch.int64)
     if distributed:
         dist.all_reduce(fits, op=dist.ReduceOp.MIN)          # every rank takes the same branch (the leg is a sequence of collectives)
     if int(fits.item()) == 0:
@@ -744,11 +760,7 @@ def sharded_search_leg(name, index_rows, dim, nq, k, dev, rank, world, distribut
                 "identical_to_one_at_a_time": bool(torch.equal(Dp_, Dm) and torch.equal(Ip_, Im))}
     except Exception as e:  # noqa: BLE001
         pipe = {"failed": "%r" % (e,)}
-    sizes = [rows]
-    if distributed:
-        t = torch.empty(dist.get_world_size(), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(t, torch.tensor([idx.ntotal], dtype=torch.int64, device=dev))
-        sizes = t.tolist()
+    sizes = gather_counts(idx.ntotal, dev, distributed)
     out = {"workload": "%s: exact top-%d of %d queries over %d x %d fp32 rows (+ tiled fp16 shadow) row-sharded over %d rank(s); a pass = local "
                        "search -> all-gather of [Q,k] wire words -> on-device merge on every rank" % (name, k, nq, index_rows, dim, world),
            "queries_per_s": round(nq * passes / wall, 1), "ms_per_pass": round(1e3 * wall / passes, 4), "passes": passes,
@@ -849,10 +861,18 @@ def main():
     # LRX_BENCH_FORCE_DIST=1: create the RCCL process group (and run every collective of the N>1 path) even with one rank --
     # the single-GPU rehearsal of the `torch.distributed.run` launch the driver uses for N = 2, 4, 8
     distributed = world > 1 or os.environ.get("LRX_BENCH_FORCE_DIST") == "1"
+    # LRX_BENCH_BACKEND=gloo + LRX_BENCH_ONE_GPU=1: the rehearsal of an N-rank run on a box with ONE GPU (every rank on device 0, collectives over
+    # gloo with the wire words staged through the host: sharded.py) -- every branch of the N > 1 path runs; the numbers mean nothing
+    backend = os.environ.get("LRX_BENCH_BACKEND", "nccl")
+    if os.environ.get("LRX_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         if world == 1:
             os.environ["LRX_FORCE_COLLECTIVE"] = "1"      # the one-rank rehearsal runs the exchange's all-gather + merge too (sharded.py)
     dev = torch.device("cuda", local_rank)
@@ -937,9 +957,7 @@ def main():
     # of the timed regions)
     rccl_ranks, shard_rows_all = (1, [shard_rows])
     if distributed:
-        sizes = torch.empty(dist.get_world_size(), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(sizes, torch.tensor([index.ntotal], dtype=torch.int64, device=dev))
-        rccl_ranks, shard_rows_all = dist.get_world_size(), sizes.tolist()
+        rccl_ranks, shard_rows_all = dist.get_world_size(), gather_counts(index.ntotal, dev, distributed)
 
     def encode_step(i):
         out = index._x[i * B:(i + 1) * B]           # in place into the shard (no host round trip)
@@ -966,10 +984,7 @@ def main():
         barrier_sync(distributed)
         enc_s = time.perf_counter() - t0
         gu_timed = enc.get_profile()["gemm_swiglu"]
-        t = torch.tensor([enc_s], device=dev, dtype=torch.float64)
-        if distributed:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        enc_s = float(t.item())
+        enc_s = reduce_max(enc_s, dev, distributed)
         docs_per_s = world * B * args.steps / enc_s
         enc.set_profiling(True)
         n_prof = min(2, args.steps)
@@ -1001,10 +1016,7 @@ def main():
         _lib.check(lrx.lrx_trace_marker(1, _lib.current_stream()))
         barrier_sync(distributed)
         srch_s = time.perf_counter() - t0
-        t = torch.tensor([srch_s], device=dev, dtype=torch.float64)
-        if distributed:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        srch_s = float(t.item())
+        srch_s = reduce_max(srch_s, dev, distributed)
         local_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(n_pass)) / n_pass
         # the filter pass streams the fp16 shadow of the shard (2 B/element); the exact rescoring of the few hundred band rows per
         # query comes on top (measured: `traffic`) -- the fp32 rows themselves are never streamed
@@ -1033,10 +1045,7 @@ def main():
             barrier_sync(distributed)
             pipe_s = time.perf_counter() - t0
             Dp_, Ip_ = pend[-1].result()
-            t = torch.tensor([pipe_s], device=dev, dtype=torch.float64)
-            if distributed:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            pipe_s = float(t.item())
+            pipe_s = reduce_max(pipe_s, dev, distributed)
             pipe = {"lanes": 2, "passes": n_lp, "queries_per_s": round(args.queries * n_lp / pipe_s, 2), "ms_per_pass": round(1e3 * pipe_s / n_lp, 4),
                     "identical_to_one_at_a_time": bool(torch.equal(Dp_, Dk) and torch.equal(Ip_, Ik))}
         except Exception as e:  # noqa: BLE001  (the one-at-a-time figure then stands as the value)
@@ -1105,15 +1114,13 @@ def main():
             for _ in range(n_px):
                 sharded.search(ops.embedding_bag_mean(table, ids_x, offs_x, normalize=True), args.topk)
             barrier_sync(distributed)
-            tx = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            if distributed:
-                dist.all_reduce(tx, op=dist.ReduceOp.MAX)
-            ms_x = 1e3 * float(tx.item()) / n_px
+            sx = reduce_max(time.perf_counter() - t0, dev, distributed)
+            ms_x = 1e3 * sx / n_px
             # which bound applies: one query streams the shard's fp16 shadow once (HBM); 1000 queries are one pass of the f16 MFMA
             # GEMM over it (wide chunks: the shadow is read once per <= 1024 queries) -- both fractions, the applicable one named
             hb = hbm_roofline(shard_rows, D, Qx, args.topk, ms_x)
             tf = 2.0 * Qx * D * shard_rows / (ms_x * 1e-3) / 1e12
-            other[str(Qx)] = {"queries_per_s": round(Qx * n_px / float(tx.item()), 1), "ms_per_pass": round(ms_x, 4), "passes": n_px,
+            other[str(Qx)] = {"queries_per_s": round(Qx * n_px / sx, 1), "ms_per_pass": round(ms_x, 4), "passes": n_px,
                               "roofline": {"bound": "hbm" if Qx <= 128 else "mfma", "frac": hb["frac"] if Qx <= 128 else round(tf / PEAK_BF16_TFLOPS, 4),
                                            "hbm_frac": hb["frac"], "hbm_achieved_gbs": hb["achieved"], "mfma_f16_tflops": round(tf, 1),
                                            "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4), "mfma_peak_tflops": PEAK_BF16_TFLOPS,
@@ -1136,10 +1143,7 @@ def main():
         sp_s = time.perf_counter() - t0
         mx_ms = enc.get_profile()["gemm_maxagg"]["ms"]
         enc.set_profiling(False)
-        t = torch.tensor([sp_s], device=dev, dtype=torch.float64)
-        if distributed:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        sp_s = float(t.item())
+        sp_s = reduce_max(sp_s, dev, distributed)
         mx_fl = 2.0 * B * S * cfg.vocab_size * H
         sparse = {"metric": "docs/sec with dense + sparse (LM-head max aggregation, relu, log1p) vectors", "value": round(world * B * n_sp / sp_s, 2),
                   "unit": "docs/s", "steps": n_sp, "ms_per_step": round(1e3 * sp_s / n_sp, 3),

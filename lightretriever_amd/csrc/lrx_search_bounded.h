@@ -199,6 +199,16 @@ k_sample_threshold(const float* __restrict__ scores, int64_t ld_s, int64_t Ns, i
 }
 
 // ---- the fused filter kernel (see filter_sample_block above for the design): selection + the two passes in one persistent launch
+// MEMORY ORDERING: data one workgroup publishes for another INSIDE this launch (sample scores, group maxima, thr, eps, list
+// counts, the done_s / done_t counters) moves by device-scope (sc1) stores and loads issued in program order, with RELAXED atomics on the
+// counters and `s_waitcnt vmcnt(0)` between a workgroup's data stores and its counter increment.  That is NOT the HIP / LLVM memory model's
+// release / acquire pairing -- it relies on gfx9-family behaviour: a wave's vector-memory stores to device-coherent lines reach the L2 / fabric
+// in issue order once vmcnt has drained, and sc1 loads bypass the non-coherent per-XCD L2 lines.  Agent-scope release / acquire was measured:
+// buffer_wbl2 / buffer_inv per wave put the launch at 0.31 ms against 0.18 ms for the three-launch chain (0.24 with one fencing wave per
+// workgroup), profiles/r05_fused_ab.txt.  Hence the assumption is pinned to the architecture this library is written for:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "k_filter_fused: the cross-workgroup publication protocol is validated on gfx942 / gfx950 only (see the comment above)"
+#endif
 template <int QT>
 struct FusedLds {
   static constexpr int SAMPLE = ((QT > 8 ? 2 : 4) * 2 * QT * 1024) > 16 * (128 * 4 + 16) ? ((QT > 8 ? 2 : 4) * 2 * QT * 1024) : 16 * (128 * 4 + 16);
@@ -215,8 +225,8 @@ k_filter_fused(const __bf16* __restrict__ Xb, int64_t N, int D, const __bf16* __
   __shared__ __attribute__((aligned(1024))) char smem[FusedLds<QT>::BYTES];
   __shared__ unsigned int s_item;
   const int tid = threadIdx.x;
-  // (phases: bit 0 = S, 1 = T, 2 = M -- all three in the product; LRX_FUSED_PHASES = 1 or 3 lets the old kernels take over the later ones (bisecting
-  // aid), bit 7 records the phase timestamps lrx_probe_fused_timestamps reads)
+  // (phases: bit 0 = S, 1 = T, 2 = M -- the host always passes all three; bit 7 (dev builds: LRX_FUSED_PHASES=128) records the phase timestamps
+  // lrx_probe_fused_timestamps reads)
   unsigned long long* ts = (phases & 128) && blockIdx.x < 1024 ? g_fused_ts + blockIdx.x * 8 : nullptr;
   if (ts != nullptr && tid == 0) { ts[0] = __builtin_amdgcn_s_memrealtime(); ts[2] = 0; ts[4] = 0; ts[5] = 0; }
   // (Claim loops: ONE single-thread region per iteration, in the middle of the loop body.  With "if (tid == 0) count; } ... top: if (tid == 0)

@@ -37,10 +37,10 @@ def _env():
     return env
 
 
-def _run(cmd, timeout):
+def _run(cmd, timeout, extra_env=None):
     """child in its own process group; on a timeout the whole group (launcher + ranks) is killed by its group id -- never by pattern"""
     import signal
-    p = subprocess.Popen(cmd, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    p = subprocess.Popen(cmd, env=dict(_env(), **(extra_env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
         out, err = p.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
@@ -100,3 +100,31 @@ def test_bench_line_reports_the_rccl_ranks_and_the_shard_sizes():
         assert c["rccl_ranks"] == n_ranks and sum(c["shard_rows_per_rank"]) == 2_000_003 and max(c["shard_rows_per_rank"]) - min(c["shard_rows_per_rank"]) <= 1
         assert c["queries_per_s"] > 0 and c["exchange_ms"] > 0 and c["two_in_flight"].get("identical_to_one_at_a_time") is True, c
     assert line["configs"]["config3_encode_llama31_8b"]["n_gpus"] == n_ranks
+
+
+def test_bench_with_two_ranks_on_one_gpu_over_gloo_runs_every_branch_of_the_n_gt_1_path():
+    """Round 6: the driver's N > 1 launch shape (`torch.distributed.run --nproc-per-node N bench.py --gpus N`) with TWO ranks on any box --
+    both on device 0, the process group over gloo (RCCL refuses two ranks per device; LRX_BENCH_BACKEND / LRX_BENCH_ONE_GPU are rehearsal
+    switches, the numbers mean nothing).  What it proves that the one-rank RCCL rehearsal cannot: the `world > 1` branches of bench.py (shards
+    by shard_split, rank != 0 leaving after the collectives, the headline index dropped before the sharded legs, BASELINE configs[3] / [4]
+    and the 8B encoder over a two-rank communicator, lanes over it) run to a well-formed line.  Replaces retriever/faiss_index.py:60-70."""
+    rows, srows = 200_003, 300_001
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--legs", "encode,search,sharded", "--index-rows", str(rows),
+           "--sharded-rows", str(srows)]
+    rc, out, err = _run(cmd, 1100, {"LRX_BENCH_BACKEND": "gloo", "LRX_BENCH_ONE_GPU": "1"})
+    assert rc == 0, err[-6000:]
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 512
+    s = line["search"]
+    assert s["shard_rows_per_rank"] == [100_002, 100_001] and s["rccl_ranks"] == 2 and s["value"] > 0
+    assert s["two_in_flight"].get("identical_to_one_at_a_time") is True, s["two_in_flight"]
+    assert set(s["other_query_counts"]) == {"1", "1000"} and s["other_query_counts"]["1000"]["roofline"]["bound"] == "mfma"
+    for key, dim in (("config3_10Mx4096", 4096), ("config4_10Mx256_mrl", 256)):
+        c = line["configs"][key]
+        assert c["rccl_ranks"] == 2 and c["shard_rows_per_rank"] == [150_001, 150_000] and c["dim"] == dim and c["queries_per_s"] > 0
+        assert c["exchange"].startswith("all_gather_into_tensor over gloo") and c["exchange_ms"] > 0 and c["merge_ms"] > 0
+        assert c["two_in_flight"].get("identical_to_one_at_a_time") is True, c["two_in_flight"]
+    e8 = line["configs"]["config3_encode_llama31_8b"]
+    assert e8["n_gpus"] == 2 and e8["docs_per_s"] > 0
+    assert list(line)[-1] == "headline" and line["headline"]["rccl_ranks"] == 2
