@@ -67,7 +67,7 @@ class InferenceArguments:
     sparse_min_tokens_to_keep: int = 8
     sparse_top_p_psg: float = 1.0
     sparse_top_k_psg: int = 0
-    sparse_top_p_qry: float = 1.0                       # (query side is parameter-free here: accepted, unused)
+    sparse_top_p_qry: float = 1.0                       # the *_qry ratios of get_sparse_emb: applied to LM-head sparse query vectors (--hybrid_use_sparse_vector)
     sparse_top_k_qry: int = 0
     normalize: Optional[bool] = None                    # None -> derived from score_function
     # accepted for CLI compatibility with the reference's argument classes; the options below marked (*) must keep their default
@@ -133,9 +133,6 @@ class InferenceArguments:
                                                      or self.hybrid_use_token_id_vector):
             raise ValueError("no vector type selected: pass at least one of --hybrid_use_dense_vector / --hybrid_use_emb_vector "
                              "[--noncontextual_query_embedding] / --hybrid_use_token_id_vector (eval/README.md:13-30)")
-        if self.hybrid_use_sparse_vector and not self.hybrid_use_token_id_vector:
-            raise NotImplementedError("--hybrid_use_sparse_vector without --hybrid_use_token_id_vector asks for query vectors from the LM head; "
-                                      "the query side here is parameter-free (token-id counts)")
         hybrid = self.model_type == "HybridModel"
         self.encode_sparse = hybrid and (self.hybrid_use_sparse_vector or self.hybrid_use_token_id_vector)   # modeling_hybrid.py:241-245
 
@@ -148,23 +145,8 @@ def arguments_from_checkpoint(model_name_or_path: str, **overrides) -> "Inferenc
     saved = load_model_args(model_name_or_path)
     known = {f.name for f in dataclasses.fields(InferenceArguments)}
     kw = {k: v for k, v in saved.items() if k in known and v is not None}
-    # `--hybrid_use_sparse_vector` selects LM-head sparse QUERY vectors next to the sparse document vectors; the query side of the sparse
-    # half is parameter-free here (token-id counts).  A checkpoint that was ALSO trained with `--hybrid_use_token_id_vector` is served
-    # asymmetrically (the document side keeps producing the sparse vector, modeling_hybrid.py:244-245) and the flag is dropped with a
-    # warning; one trained with LM-head query vectors ONLY has no query representation this path can produce for its sparse half: that is
-    # an error unless the caller overrides the flags.  (`--hybrid_use_dense_vector`, in every released model_args.yaml, is served as saved.)
-    if kw.get("hybrid_use_sparse_vector") and "hybrid_use_sparse_vector" not in overrides:
-        import logging
-        if kw.get("hybrid_use_token_id_vector") or overrides.get("hybrid_use_token_id_vector"):
-            logging.getLogger(__name__).warning(
-                "%s: model_args.yaml has hybrid_use_sparse_vector=True (LM-head sparse query vectors); the MI355X path encodes sparse queries as "
-                "token-id counts only -- flag dropped, the asymmetric sparse vectors the checkpoint was also trained for are served", model_name_or_path)
-            kw["hybrid_use_sparse_vector"] = False
-        elif "hybrid_use_token_id_vector" not in overrides:
-            raise NotImplementedError(
-                f"{model_name_or_path}: model_args.yaml has hybrid_use_sparse_vector=True without hybrid_use_token_id_vector: its sparse half needs "
-                "LM-head query vectors, which the MI355X path does not produce.  Pass hybrid_use_sparse_vector=False (dense vectors only) or "
-                "hybrid_use_token_id_vector=True (token-id-count queries against its sparse document vectors) explicitly.")
+    # (`--hybrid_use_sparse_vector` -- LM-head sparse QUERY vectors next to the sparse document vectors, modeling_hybrid.py:404-438 -- is served
+    # as saved since round 6, like `--hybrid_use_dense_vector` and `--hybrid_use_token_id_vector`.)
     kw.update(overrides)
     kw["model_name_or_path"] = model_name_or_path
     kw.setdefault("model_type", "HybridModel")     # (model_args.yaml holds the training ModelArguments: no model_type; this mirrors HybridModel.load)
@@ -218,7 +200,9 @@ class PytorchRPCExactSearchModel(LrxExactSearchModel):
                             hybrid_use_dense_vector=args.hybrid_use_dense_vector if hybrid else True,      # EncoderModel: the symmetric dense vector
                             hybrid_use_emb_vector=args.hybrid_use_emb_vector if hybrid else False,
                             noncontextual_query_embedding=args.noncontextual_query_embedding if hybrid else False,
-                            pooling_strategy=args.pooling_strategy)
+                            pooling_strategy=args.pooling_strategy, hybrid_use_sparse_vector=args.hybrid_use_sparse_vector if hybrid else False,
+                            hybrid_use_token_id_vector=args.hybrid_use_token_id_vector if hybrid else False,
+                            sparse_top_k_qry=args.sparse_top_k_qry, sparse_top_p_qry=args.sparse_top_p_qry)
         super().__init__(model=hm, tokenizer=tok, q_max_len=args.q_max_len, p_max_len=args.p_max_len,
                          append_prompt_sep=args.append_prompt_sep, eval_batch_size_embedding_bag=args.eval_batch_size_embedding_bag,
                          token_id_vector_type=args.token_id_vector_type, noncontextual_prompt_prefix=args.noncontextual_prompt_prefix,

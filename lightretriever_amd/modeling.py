@@ -154,7 +154,8 @@ class LrxHybridModel:
                  add_sep_token: bool = False, sparse_use_relu: bool = True, sparse_use_log_saturation: bool = True,
                  sparse_top_k_psg: int = 0, sparse_top_p_psg: float = 1.0, sparse_min_tokens_to_keep: int = 8,
                  sparse_round_bf16: bool = True, hybrid_use_dense_vector: bool = False, hybrid_use_emb_vector: bool = True,
-                 noncontextual_query_embedding: bool = True, pooling_strategy: Optional[str] = None):
+                 noncontextual_query_embedding: bool = True, pooling_strategy: Optional[str] = None, hybrid_use_sparse_vector: bool = False,
+                 sparse_top_k_qry: int = 0, sparse_top_p_qry: float = 1.0, hybrid_use_token_id_vector: Optional[bool] = None):
         """The sparse_* / add_sep_token / sep_token_id / hybrid_use_* / noncontextual_query_embedding fields carry the reference's
         ModelArguments of the same names (finetune/arguments.py:175-290); encode_sparse = hybrid_use_sparse_vector or
         hybrid_use_token_id_vector."""
@@ -168,6 +169,13 @@ class LrxHybridModel:
         if encode_sparse and self.pooling_strategy != "lasttoken":
             raise NotImplementedError("dense + sparse document vectors in one pass (lrx_encode_packed_sparse) pool the dense vector from the last token only")
         self.hybrid_use_dense_vector = hybrid_use_dense_vector
+        # `--hybrid_use_sparse_vector`: LM-encoded sparse QUERY vectors (LM head max aggregation on the query's tokens, modeling_hybrid.py:404-438;
+        # the `spr` / `den_spr` query modes); the document side produces its sparse vector whenever encode_sparse is on
+        self.hybrid_use_sparse_vector = hybrid_use_sparse_vector
+        # `--hybrid_use_token_id_vector`: parameter-free sparse queries (token-id counts); None = whenever the sparse half is on without LM-head queries
+        self.hybrid_use_token_id_vector = (encode_sparse and not hybrid_use_sparse_vector) if hybrid_use_token_id_vector is None else hybrid_use_token_id_vector
+        self.sparse_top_k_qry = sparse_top_k_qry
+        self.sparse_top_p_qry = sparse_top_p_qry
         self.hybrid_use_emb_vector = hybrid_use_emb_vector
         self.noncontextual_query_embedding = noncontextual_query_embedding
         self._lm_emb_table: Optional[torch.Tensor] = None   # fp32 copy of embed_tokens, made on first use by the input-embedding bag
@@ -217,7 +225,12 @@ class LrxHybridModel:
             raise KeyError(f"{who}: padded input needs attention_mask")
         return pack_padded_batch(ids.to(self.device), batch["attention_mask"].to(self.device))
 
-    def _encode_passage_sparse(self, psg: dict, normalize: bool, out: Optional[torch.Tensor]):
+    def _encode_passage_sparse(self, psg: dict, normalize: bool, out: Optional[torch.Tensor], top_k: Optional[int] = None,
+                               top_p: Optional[float] = None, want_dense: bool = True):
+        """dense (optional) + sparse vectors of a batch in one pass.  top_k / top_p: the sampling ratios of get_sparse_emb (modeling_hybrid.py:189-200) --
+        the passage ones by default, the *_qry ones when encode_query calls."""
+        top_k = self.sparse_top_k_psg if top_k is None else top_k
+        top_p = self.sparse_top_p_psg if top_p is None else top_p
         ids = psg["input_ids"]
         if "cu_seqlens" in psg:
             cu_host, ids_host = psg["cu_seqlens"], ids
@@ -229,14 +242,16 @@ class LrxHybridModel:
             tok_mask = torch.from_numpy(sparse_token_mask(ids_host.cpu().numpy(), cu_host.cpu().numpy(), self.sep_token_id, self.add_sep_token))
         dense, sparse = self.encoder.encode_packed_sparse(
             ids_host.to(self.device, dtype=torch.int32), cu_host.to(self.device, dtype=torch.int32), max_len,
-            tok_mask=tok_mask.to(self.device, dtype=torch.uint8).contiguous(), dense_dim=self.dense_shrink_dim, normalize=normalize,
+            tok_mask=tok_mask.to(self.device, dtype=torch.uint8).contiguous(), dense_dim=self.dense_shrink_dim, normalize=normalize, want_dense=want_dense,
             relu=self.sparse_use_relu, log1p=self.sparse_use_log_saturation, round_bf16=self.sparse_round_bf16,
-            top_k=0 if 0 < self.sparse_top_p_psg < 1 else self.sparse_top_k_psg, min_tokens_to_keep=self.sparse_min_tokens_to_keep)
-        if 0 < self.sparse_top_p_psg < 1:
+            top_k=0 if 0 < top_p < 1 else top_k, min_tokens_to_keep=self.sparse_min_tokens_to_keep)
+        if 0 < top_p < 1:
             # optional nucleus filter (sparse_pooling.py:64-90), off in the published configuration: plain device tensor ops,
             # then the top-k threshold kernel on its result (the reference's order: top-p before top-k)
-            sparse = _top_p_filter(sparse, self.sparse_top_p_psg, self.sparse_min_tokens_to_keep)
-            ops.sparsify_(sparse, relu=False, log1p=False, top_k=self.sparse_top_k_psg, min_tokens_to_keep=self.sparse_min_tokens_to_keep)
+            sparse = _top_p_filter(sparse, top_p, self.sparse_min_tokens_to_keep)
+            ops.sparsify_(sparse, relu=False, log1p=False, top_k=top_k, min_tokens_to_keep=self.sparse_min_tokens_to_keep)
+        if not want_dense:
+            return {"sparse_reps": sparse}
         if out is not None:
             out[:dense.shape[0]].copy_(dense)
             dense = out[:dense.shape[0]]
@@ -267,8 +282,15 @@ class LrxHybridModel:
                 out.append({str(int(i)): int(v) for i, v in zip(ids[b, :n], w[b, :n])})
         return out
 
+    def convert_sparse_reps_to_pseudo_text(self, reps: torch.Tensor, quantization_factor: int = 100, convert_id_to_token: bool = False,
+                                           vocab_dict: Optional[dict] = None) -> list[str]:
+        """Each token repeated its quantised weight times, space-joined (finetune/sparse_converter_mixin.py:63-101, :162-189): the form
+        call_batch_encode gives a sparse QUERY vector (inference/exact_search_base.py:231-236); an empty vector becomes "-1"."""
+        return [" ".join(tok for tok, freq in d.items() for _ in range(freq))
+                for d in self.convert_sparse_reps_to_json(reps, quantization_factor, convert_id_to_token, vocab_dict)]
+
     def encode_query(self, qry: Optional[dict], normalize: Optional[bool] = None, encode_dense: Optional[bool] = None,
-                     encode_emb_reps: Optional[bool] = None, **kwargs):
+                     encode_emb_reps: Optional[bool] = None, encode_sparse: Optional[bool] = None, **kwargs):
         """modeling_hybrid.py:327-500 -> a dict with, as enabled (argument override, else the model's flag -- the reference's rule :362-366):
           `dense_reps` fp32 [Q, D]: the query (`prompt + text`, specials) through the LM, lasttoken pooling, slice, normalise (:363-401);
           `emb_reps`   fp32 [Q, D]: EmbeddingBag mean over nonctx_tok_emb_input_ids / nonctx_tok_emb_offsets (:472-474), or -- without
@@ -280,7 +302,15 @@ class LrxHybridModel:
         normalize = self.normalize if normalize is None else normalize
         encode_dense = bool(encode_dense or (encode_dense is None and self.hybrid_use_dense_vector))
         encode_emb = bool(encode_emb_reps or (encode_emb_reps is None and self.hybrid_use_emb_vector))
+        encode_spr = bool(encode_sparse or (encode_sparse is None and self.hybrid_use_sparse_vector))
         out = {}
+        if encode_spr:
+            # `sparse_reps` fp32 [Q, V] (:404-438): LM head max aggregation over the query's tokens (sparse attention mask), relu / log1p, the *_qry
+            # sampling ratios; the dense vector of the same forward comes out of the same pass (last-token pooling)
+            if encode_dense and self.pooling_strategy != "lasttoken":
+                raise NotImplementedError("dense + sparse query vectors in one pass pool the dense vector from the last token only")
+            out.update(self._encode_passage_sparse(qry, bool(normalize), None, top_k=self.sparse_top_k_qry, top_p=self.sparse_top_p_qry, want_dense=encode_dense))
+            encode_dense = False
         lm_in = self._packed_lm_inputs(qry, "encode_query") if (encode_dense or (encode_emb and not self.noncontextual_query_embedding)) else None
         if encode_dense:
             out["dense_reps"] = self.encoder.encode_packed(lm_in[0], lm_in[1], lm_in[2], out_dim=self.dense_shrink_dim, normalize=bool(normalize),
@@ -559,10 +589,13 @@ class LrxExactSearchModel:
         return items
 
     def encode_queries(self, queries, batch_size: int, show_progress_bar: bool = True, convert_to_tensor: bool = True, **kwargs):
-        """-> {"emb_reps"?, "dense_reps"?, "token_id_reps"?} by the model's flags (exact_search_base.py:94-122 + exact_search_torchrpc.py:139-170)."""
+        """-> {"emb_reps"?, "dense_reps"?, "sparse_reps"?, "token_id_reps"?} by the model's flags (exact_search_base.py:94-122 +
+        exact_search_torchrpc.py:139-170).  `sparse_reps` (`--hybrid_use_sparse_vector`): the LM-head query vectors as the quantised pseudo text
+        call_batch_encode makes of them (inference/exact_search_base.py:231-236)."""
         items = self.parse_texts(queries, prompt=self.query_prompt)        # the `prompt` column the LM-encoded query vectors prepend
         hm = self.model
         use_dense = bool(getattr(hm, "hybrid_use_dense_vector", False))
+        use_spr = bool(getattr(hm, "hybrid_use_sparse_vector", False))
         use_emb = bool(getattr(hm, "hybrid_use_emb_vector", True))
         nonctx = bool(getattr(hm, "noncontextual_query_embedding", True))
         if use_emb and nonctx:
@@ -574,20 +607,27 @@ class LrxExactSearchModel:
             if hm.emb_bag is None or hm.emb_bag_prompt != prompt:
                 hm.construct_embedding_bag(self.tokenizer, prompt=prompt, batch_size=self.eval_batch_size_embedding_bag)
                 self._check_device_counters("construct_embedding_bag")
-        need_lm = use_dense or (use_emb and not nonctx)
+        need_lm = use_dense or use_spr or (use_emb and not nonctx)
         coll = EncodeCollator(self.tokenizer, encode_is_query=True, q_max_len=self.q_max_len, p_max_len=self.p_max_len,
-                              noncontextual_query_embedding=use_emb and nonctx, query_lm_inputs=need_lm)
+                              noncontextual_query_embedding=use_emb and nonctx, query_lm_inputs=need_lm, sparse_mask=use_spr,
+                              sep_token_id=getattr(hm, "sep_token_id", None), add_sep_token=bool(getattr(hm, "add_sep_token", False)))
         outs: dict = {}
+        spr_text: list[str] = []
         for s in (range(0, len(items), batch_size) if (need_lm or (use_emb and nonctx)) else ()):     # (token-id-only models tokenise in token_id_reps)
             for k, v in hm.encode_query(coll(items[s:s + batch_size])).items():
-                outs.setdefault(k, []).append(v)
+                if k == "sparse_reps":    # [batch, vocab] fp32 on the GPU -> quantised pseudo text per query (only the non-zeros come to the host)
+                    spr_text.extend(hm.convert_sparse_reps_to_pseudo_text(v, quantization_factor=100))
+                else:
+                    outs.setdefault(k, []).append(v)
         if need_lm:                       # (the EmbeddingBag lookup has no fp16 operand; the table build checks its own rows below)
             self._check_device_counters("encode_queries")
         res = {}
         for k, parts in outs.items():
             reps = torch.cat(parts, 0)
             res[k] = reps if convert_to_tensor else reps.cpu().numpy()
-        if hm.encode_sparse:
+        if use_spr:
+            res["sparse_reps"] = spr_text
+        if getattr(hm, "hybrid_use_token_id_vector", hm.encode_sparse):
             res["token_id_reps"] = self.token_id_reps(items)
         return self._unwrap(res)
 

@@ -306,8 +306,12 @@ class HybridSearch:
                 results["emb"] = self.dense_search.retrieve_with_emb(query_emb["emb_reps"], query_ids, top_k=top_k)
         if sparse and self.sparse_search is not None and query_emb.get("token_id_reps") is not None:
             results["tok"] = self.sparse_search.retrieve_with_emb(query_emb["token_id_reps"], query_ids, top_k=top_k)
-            if "emb" in results:
-                results["emb_tok"] = self._fuse_results(results["emb"], results["tok"], weights=self.fuse_weights)
+        if sparse and self.sparse_search is not None and query_emb.get("sparse_reps") is not None:       # LM-head sparse queries (hybrid_search.py:166-172)
+            results["spr"] = self.sparse_search.retrieve_with_emb(query_emb["sparse_reps"], query_ids, top_k=top_k)
+            if "den" in results:
+                results["den_spr"] = self._fuse_results(results["den"], results["spr"], weights=self.fuse_weights)
+        if "emb" in results and "tok" in results:
+            results["emb_tok"] = self._fuse_results(results["emb"], results["tok"], weights=self.fuse_weights)
         return results
 
     def search(self, corpus, queries, top_k: int = 1000, score_function: str = None, return_sorted: bool = False,
@@ -315,26 +319,36 @@ class HybridSearch:
         query_ids, queries_list = _ids_and_list(queries)
         qe = self.model.encode_queries(queries_list, batch_size=self.batch_size, show_progress_bar=self.show_progress_bar,
                                        convert_to_tensor=self.convert_to_tensor)
-        assert isinstance(qe, dict) and ("dense_reps" in qe or "emb_reps" in qe)
+        assert isinstance(qe, dict) and any(k in qe for k in ("dense_reps", "emb_reps", "sparse_reps", "token_id_reps"))
         results, default = {}, None
         # one corpus pass serves every enabled query representation (they share the document `dense_reps`)
         kinds = [(k, name) for k, name in (("dense_reps", "den"), ("emb_reps", "emb")) if qe.get(k) is not None]
         # sparse half (hybrid_search.py:330-375): every chunk's document vectors go into the engine as they are encoded, the engine is
         # searched once at the end with the queries' token-id counts, `emb_tok` is the fusion of the two final hit lists
         use_tok = self.sparse_search is not None and qe.get("token_id_reps") is not None
+        use_spr = self.sparse_search is not None and qe.get("sparse_reps") is not None      # LM-head sparse query vectors (pseudo text), hybrid_search.py:364-369
         on_chunk = None
-        if use_tok:
+        if use_tok or use_spr:
             def on_chunk(chunk_ids, enc):
                 assert enc.get("sparse_reps") is not None, "sparse engine given but encode_corpus returned no sparse_reps"
                 self.sparse_search.index(enc["sparse_reps"], list(chunk_ids))
         multi = _chunked_dense_search(self.dense_search, [qe[k] for k, _ in kinds], query_ids, corpus, top_k, ignore_identical_ids, on_chunk=on_chunk)
-        for (_, name), res in zip(kinds, multi):
-            results[name] = res
-            default = res
+        dense_res = dict(zip([name for _, name in kinds], multi))
+        tok_res = self.sparse_search.retrieve_with_emb(query_emb=qe["token_id_reps"], query_ids=query_ids, top_k=top_k) if use_tok else None
+        spr_res = self.sparse_search.retrieve_with_emb(query_emb=qe["sparse_reps"], query_ids=query_ids, top_k=top_k) if use_spr else None
+        # result names and the default (the LAST one set) in the reference's order (hybrid_search.py:380-403): den, spr, emb, tok, den_spr, emb_tok
+        if "den" in dense_res:
+            results["den"] = default = dense_res["den"]
+        if use_spr:
+            results["spr"] = default = spr_res
+        if "emb" in dense_res:
+            results["emb"] = default = dense_res["emb"]
         if use_tok:
-            results["tok"] = default = self.sparse_search.retrieve_with_emb(query_emb=qe["token_id_reps"], query_ids=query_ids, top_k=top_k)
-            if "emb" in results:
-                results["emb_tok"] = default = self._fuse_results(results["emb"], results["tok"], weights=self.fuse_weights)
+            results["tok"] = default = tok_res
+        if "den" in dense_res and use_spr:
+            results["den_spr"] = default = self._fuse_results(dense_res["den"], spr_res, weights=self.fuse_weights)
+        if "emb" in dense_res and use_tok:
+            results["emb_tok"] = default = self._fuse_results(dense_res["emb"], tok_res, weights=self.fuse_weights)
         self._clear()
         return results if self.return_all_results else default
 

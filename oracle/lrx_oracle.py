@@ -700,6 +700,19 @@ def sparse_reps_to_json(reps: np.ndarray, quantization_factor: int = 100, vocab:
     return out
 
 
+def sparse_reps_to_pseudo_text(reps: np.ndarray, quantization_factor: int = 100, vocab: Optional[dict] = None) -> list[str]:
+    """finetune/sparse_converter_mixin.py:162-189 (convert_sparse_reps_to_pseudo_text_pt): every token (ascending id) repeated its quantised weight
+    times, space-joined -- what call_batch_encode hands the sparse engine for a QUERY vector (inference/exact_search_base.py:231-236); an empty
+    vector becomes "-1"."""
+    return [" ".join(tok for tok, freq in d.items() for _ in range(freq)) for d in sparse_reps_to_json(reps, quantization_factor, vocab)]
+
+
+def encode_query_sparse(cfg: EncoderConfig, w, ids, cu_seqlens, tok_mask, lm_head: Optional[np.ndarray] = None, bf16: bool = True, **sparsify_kw):
+    """HybridModel.encode_query's sparse branch (modeling_hybrid.py:404-438): the passage pipeline on the query's tokens; get_sparse_emb(is_query=True)
+    differs only in WHICH top-p / top-k ratios apply (sparse_top_p_qry / sparse_top_k_qry, :189-200) -- pass them as top_p / top_k."""
+    return encode_passage_sparse(cfg, w, ids, cu_seqlens, tok_mask, lm_head=lm_head, bf16=bf16, **sparsify_kw)
+
+
 def encode_passage_sparse(cfg: EncoderConfig, w, ids, cu_seqlens, tok_mask, lm_head: Optional[np.ndarray] = None, bf16: bool = True, **sparsify_kw):
     """HybridModel.encode_passage's sparse branch (modeling_hybrid.py:280-323) on packed input: LM forward -> final-norm hidden
     states -> max aggregation with the (tied unless given) LM head -> sparsify."""

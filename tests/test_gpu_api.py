@@ -320,7 +320,9 @@ def test_cli_arguments_wire_the_sparse_branch_through_the_reference_entry_point(
     want = LrxExactSearchModel(model=hm, tokenizer=model.tokenizer, q_max_len=16, p_max_len=48).encode_corpus(docs, batch_size=8)
     assert torch.equal(got["dense_reps"], want["dense_reps"]) and got["sparse_reps"] == want["sparse_reps"]
     q = model.encode_queries(["capital of france", "dense retrieval retrieval"], batch_size=8)
-    assert set(q) == {"emb_reps", "token_id_reps"} and all(v == 1 for d in q["token_id_reps"] for v in d.values())   # 'bow'
+    # (round 6: `--hybrid_use_sparse_vector` is served -- the LM-head query vectors ride along as pseudo text, like the reference's call_batch_encode)
+    assert set(q) == {"emb_reps", "token_id_reps", "sparse_reps"} and all(v == 1 for d in q["token_id_reps"] for v in d.values())   # 'bow'
+    assert len(q["sparse_reps"]) == 2 and all(isinstance(t, str) and t for t in q["sparse_reps"])
 
 
 def test_embedding_bag_prompt_selection_follows_the_reference():

@@ -131,7 +131,10 @@ class _DictImpactEngine:
 
     def retrieve_with_emb(self, query_emb, query_ids, top_k, **kw):
         out = {}
+        from collections import Counter
         for qid, qv in zip(query_ids, query_emb):
+            if isinstance(qv, str):                                  # pseudo text of an LM-head sparse query vector: tokens repeated by weight
+                qv = Counter(qv.split())
             sc = {pid: float(sum(c * dv.get(t, 0) for t, c in qv.items())) for pid, dv in self.docs.items()}
             top = sorted(((s, p) for p, s in sc.items() if s > 0), key=lambda x: (-x[0], x[1]))[:top_k]
             out[qid] = {p: s for s, p in top}
@@ -176,3 +179,37 @@ def test_hybrid_search_feeds_a_sparse_engine_per_chunk_and_fuses_at_the_end():
     assert res["emb_tok"] == fuse_scores_linear([emb_only, tok_want], weights=[0.6, 0.4])
     assert HybridSearch(model, batch_size=8, corpus_chunk_size=25, fuse_weights=[0.6, 0.4], sparse_search=_DictImpactEngine()).search(
         corpus, queries, top_k=10) == res["emb_tok"]                              # default result = the fused list
+
+
+def test_hybrid_search_serves_the_spr_and_den_spr_query_modes():
+    """Round 6 (`--hybrid_use_sparse_vector`): LM-head sparse query vectors reach the sparse engine as pseudo text; result kinds and the default
+    follow retriever/hybrid_search.py:364-403 -- den, spr, den_spr (the default when both are on), next to emb / tok / emb_tok when those flags
+    are on too."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_api import build_stack, synth_corpus
+    from helpers import load_model_golden
+    from lightretriever_amd.modeling import LrxExactSearchModel, LrxHybridModel
+    from lightretriever_amd.retriever import HybridSearch
+    from lightretriever_amd.score_fuse_utils import fuse_scores_linear
+    cfg_o, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    tok, enc, _, _ = build_stack(cfg_o, w)
+    hs = LrxHybridModel(enc, normalize=True, pad_token_id=tok.pad_token_id, encode_sparse=True, sparse_top_k_psg=24, hybrid_use_sparse_vector=True,
+                        hybrid_use_dense_vector=True, hybrid_use_emb_vector=False, sparse_top_k_qry=12)
+    model = LrxExactSearchModel(model=hs, tokenizer=tok, q_max_len=32, p_max_len=64)
+    corpus = synth_corpus(np.random.default_rng(2), 60)
+    queries = {"q0": "capital of france paris", "q1": "dense retrieval with large language models", "q2": "amd instinct memory search"}
+    res = HybridSearch(model, batch_size=8, corpus_chunk_size=25, fuse_weights=[0.6, 0.4], return_all_results=True, sparse_search=_DictImpactEngine()).search(
+        corpus, queries, top_k=10)
+    assert list(res) == ["den", "spr", "den_spr"]
+    enc_all = model.encode_corpus(list(corpus.values()), batch_size=8)
+    ref_engine = _DictImpactEngine()
+    ref_engine.index(enc_all["sparse_reps"], list(corpus))
+    qe = model.encode_queries(list(queries.values()), batch_size=8)
+    assert set(qe) == {"dense_reps", "sparse_reps"} and all(isinstance(t, str) for t in qe["sparse_reps"])
+    spr_want = ref_engine.retrieve_with_emb(qe["sparse_reps"], list(queries), 10)
+    assert res["spr"] == spr_want and all(len(v) > 0 for v in spr_want.values())
+    den_only = HybridSearch(model, batch_size=8, corpus_chunk_size=25, return_all_results=True).search(corpus, queries, top_k=10)["den"]
+    assert res["den"] == den_only and res["den_spr"] == fuse_scores_linear([den_only, spr_want], weights=[0.6, 0.4])
+    assert HybridSearch(model, batch_size=8, corpus_chunk_size=25, fuse_weights=[0.6, 0.4], sparse_search=_DictImpactEngine()).search(
+        corpus, queries, top_k=10) == res["den_spr"]                              # default = the last kind set, like the reference

@@ -175,6 +175,71 @@ def test_encode_passage_sparse_sampling_options(kw, key):
     assert np.abs(sp[both] - want[both]).max() < 0.06
 
 
+def test_encode_query_sparse_matches_the_reference():
+    """Round 6: `--hybrid_use_sparse_vector` -- LM-encoded sparse QUERY vectors (finetune/modeling_hybrid.py:404-438; the `spr` / `den_spr` query modes
+    of retriever/hybrid_search.py:160-180) next to the dense vector of the same forward, against what the reference's encode_query returned
+    (tests/golden/sparse_query.npz, gen_sparse_query_goldens.py); the *_qry sampling ratios apply, not the passage ones; the pseudo text of a
+    query vector is the reference converter's up to the bf16 band of the logits."""
+    from lightretriever_amd.modeling import LrxHybridModel
+    cfg_o, w, sp, enc, _ = _sparse_model()
+    g = np.load(os.path.join(GOLDEN, "sparse_query.npz"))
+    mk = lambda **kw: LrxHybridModel(enc, normalize=True, encode_sparse=True, hybrid_use_sparse_vector=True, hybrid_use_dense_vector=True,
+                                     hybrid_use_emb_vector=False, sep_token_id=int(g["sep_token_id"]), add_sep_token=True, sparse_round_bf16=False, **kw)
+    qry = {"input_ids": torch.from_numpy(g["input_ids"]), "attention_mask": torch.from_numpy(g["attention_mask"])}
+    out = mk().encode_query(qry)
+    assert set(out) == {"dense_reps", "sparse_reps"}
+    spq, dn = out["sparse_reps"].cpu().numpy(), out["dense_reps"].cpu().numpy()
+    assert spq.shape == g["sparse_reps"].shape and np.abs(spq - g["sparse_reps"]).max() < 0.06
+    np.testing.assert_array_equal((g["sparse_reps"] > 0).sum(1) == 0, (spq > 0).sum(1) == 0)
+    assert ((spq > 0) == (g["sparse_reps"] > 0)).mean() > 0.985 and min_cos(dn, g["dense_reps"]) > 0.998
+    only = mk().encode_query(qry, encode_dense=False)
+    assert set(only) == {"sparse_reps"} and torch.equal(only["sparse_reps"], out["sparse_reps"])
+    # the query-side ratios (the passage ones, set differently, must not be the ones applied)
+    for kw, key in ((dict(sparse_top_k_qry=8, sparse_min_tokens_to_keep=4, sparse_top_k_psg=16), "sparse_reps_top8_qry"),
+                    (dict(sparse_top_p_qry=0.4, sparse_min_tokens_to_keep=8, sparse_top_p_psg=0.9), "sparse_reps_topp_qry")):
+        got, want = mk(**kw).encode_query(qry)["sparse_reps"].cpu().numpy(), g[key]
+        np.testing.assert_array_equal((got > 0).sum(1) == 0, (want > 0).sum(1) == 0)
+        nz_got, nz_want = (got > 0).sum(1), (want > 0).sum(1)
+        if "sparse_top_k_qry" in kw:
+            assert (nz_got[nz_want > 0] >= nz_want[nz_want > 0]).all() and (nz_got <= nz_want + 2).all()
+        both = (got > 0) & (want > 0)
+        assert both.sum() / max(1, (want > 0).sum()) > 0.9 and np.abs(got[both] - want[both]).max() < 0.06
+    # pseudo text (what call_batch_encode hands the sparse engine for a query): token ids repeated by their quantised weight
+    txt = mk().convert_sparse_reps_to_pseudo_text(out["sparse_reps"], 100)
+    ref = json.load(open(os.path.join(GOLDEN, "sparse_query_text.json")))["quant100_row1"][0]
+    from collections import Counter
+    a, b = Counter(txt[1].split()), Counter(ref.split())
+    assert txt[2] == "-1" and all(abs(a.get(k, 0) - b.get(k, 0)) <= 6 for k in set(a) | set(b))
+    assert mk().convert_sparse_reps_to_pseudo_text(torch.tensor([[0.5 / 7, 1.5 / 7, 2.5 / 7, -3.0, 0.0, 0.07], [0.0] * 6]), 7) == json.load(open(os.path.join(GOLDEN, "sparse_query_text.json")))["quant7_halves"]
+
+
+def test_encode_queries_returns_sparse_pseudo_text_for_the_spr_mode():
+    """B2 level: `--hybrid_use_sparse_vector` without token-id queries -> encode_queries returns one pseudo-text string per query
+    (inference/exact_search_base.py:231-236) and no token_id_reps; with both flags, both."""
+    from transformers import PreTrainedTokenizerFast
+    from lightretriever_amd.modeling import LrxExactSearchModel, LrxHybridModel
+    cfg_o, w, sp, enc, _ = _sparse_model()
+    tok = PreTrainedTokenizerFast.from_pretrained(os.path.join(GOLDEN, "tok"))
+    mk = lambda **kw: LrxExactSearchModel(model=LrxHybridModel(enc, normalize=True, encode_sparse=True, hybrid_use_sparse_vector=True, hybrid_use_emb_vector=False,
+                                                               pad_token_id=tok.pad_token_id, **kw), tokenizer=tok, q_max_len=32, p_max_len=48)
+    qs = ["dense retrieval with large language models", "a", "memory search"]
+    r = mk().encode_queries(qs, batch_size=2)
+    assert set(r) == {"sparse_reps"} and len(r["sparse_reps"]) == 3 and all(isinstance(t, str) for t in r["sparse_reps"])
+    toks = r["sparse_reps"][0].split()
+    assert len(toks) > 10 and all(t.isdigit() and int(t) < cfg_o.vocab_size for t in toks)
+    both = mk(hybrid_use_token_id_vector=True, hybrid_use_dense_vector=True).encode_queries(qs, batch_size=3)
+    assert set(both) == {"sparse_reps", "token_id_reps", "dense_reps"} and both["sparse_reps"] == r["sparse_reps"] and both["dense_reps"].shape == (3, cfg_o.hidden_size)
+    # each query separately (batching must not matter) against the oracle's pipeline
+    from lightretriever_amd.modeling import format_text
+    e = tok([format_text({"text": qs[0]}, prepend_prompt=True)], max_length=32, truncation="only_first", add_special_tokens=True)["input_ids"][0]
+    tm = np.ones(len(e), bool)
+    tm[0] = tm[-1] = False
+    want = O.sparse_reps_to_json(O.encode_query_sparse(cfg_o, w, np.asarray(e, np.int32), np.array([0, len(e)], np.int32), tm, bf16=True, relu=True, log1p=True), 100)[0]
+    from collections import Counter
+    got = Counter(toks)
+    assert all(abs(got.get(k, 0) - want.get(k, 0)) <= 5 for k in set(got) | set(want))
+
+
 def test_packed_input_with_collator_mask_equals_padded_input():
     cfg_o, w, g, enc, hm = _sparse_model()
     from lightretriever_amd.modeling import sparse_token_mask

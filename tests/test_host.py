@@ -511,7 +511,7 @@ def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_m
     assert c.hybrid_use_dense_vector and not c.hybrid_use_emb_vector and not c.encode_sparse and c.dtype == torch.bfloat16
     d = parse("--hybrid_use_emb_vector")
     assert d.hybrid_use_emb_vector and d.noncontextual_query_embedding is False
-    for bad in (["--hybrid_use_emb_vector", "--untie_encoder"], ["--hybrid_use_sparse_vector"], ["--hybrid_use_emb_vector", "--enable_bidirectional_attention"],
+    for bad in (["--hybrid_use_emb_vector", "--untie_encoder"], ["--hybrid_use_emb_vector", "--enable_bidirectional_attention"],
                 ["--hybrid_use_emb_vector", "--use_sparse_linear_projector"], ["--hybrid_use_emb_vector", "--sparse_remove_stopwords"],
                 ["--hybrid_use_emb_vector", "--hybrid_model_architecture", "bert"],
                 ["--hybrid_use_emb_vector", "--pooling_strategy", "avg_top2"], ["--hybrid_use_emb_vector", "--sparse_use_max_aggregation", "False"]):
@@ -519,6 +519,9 @@ def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_m
             parse(*bad)
     with pytest.raises(ValueError, match="no vector type selected"):
         parse()
+    # round 6: `--hybrid_use_sparse_vector` alone (LM-head sparse queries, the `spr` mode) is served; token-id queries only with their own flag
+    sp = parse("--hybrid_use_sparse_vector", "--sparse_top_k_qry", "32")
+    assert sp.hybrid_use_sparse_vector and sp.encode_sparse and not sp.hybrid_use_token_id_vector and sp.sparse_top_k_qry == 32
     # round 6: `--fp16` is accepted like `--bf16` (recorded in dtype; one arithmetic); both at once is the reference's own contradiction
     assert parse("--hybrid_use_emb_vector", "--fp16").dtype == torch.float16
     with pytest.raises(ValueError):

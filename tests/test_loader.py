@@ -107,7 +107,7 @@ def test_reference_import_paths_resolve():
     assert HybridSearch.name() == "hybrid_search" and FlatIPFaissSearch.name() == "faiss_search"
     assert callable(PytorchRPCExactSearchModel)
     with pytest.raises(NotImplementedError):
-        InferenceArguments(model_name_or_path="/x", pooling_strategy="mean")
+        InferenceArguments(model_name_or_path="/x", pooling_strategy="avg_first_last")      # (pools over other layers' states; cls / mean / x_to_last are served)
 
 
 # ---- round 2: loader hardening ------------------------------------------------------------------
@@ -244,20 +244,16 @@ def test_model_args_yaml_resume(tmp_path, caplog):
     yaml.dump(saved, open(d / "model_args.yaml", "w"))
     args = arguments_from_checkpoint(str(d))
     assert args.hybrid_use_dense_vector and args.hybrid_use_emb_vector and args.noncontextual_query_embedding
-    # LM-head sparse QUERY vectors are not produced here.  A checkpoint also trained for token-id queries keeps its asymmetric sparse half
-    # (flag dropped, warning); one whose yaml carries `hybrid_use_token_id_vector: false` (the reference dumps every field) cannot be served
-    # silently without its sparse half: loud error unless the caller decides
-    import logging
+    # round 6: LM-head sparse QUERY vectors (`hybrid_use_sparse_vector`, modeling_hybrid.py:404-438) are served as saved -- next to token-id
+    # queries when the checkpoint has both, alone when it has only them; an explicit override still wins
     saved["hybrid_use_sparse_vector"] = True
     yaml.dump(saved, open(d / "model_args.yaml", "w"))
-    with caplog.at_level(logging.WARNING):
-        args = arguments_from_checkpoint(str(d))
-    assert args.hybrid_use_sparse_vector is False and args.hybrid_use_token_id_vector and args.encode_sparse and "hybrid_use_sparse_vector=True" in caplog.text
+    args = arguments_from_checkpoint(str(d))
+    assert args.hybrid_use_sparse_vector and args.hybrid_use_token_id_vector and args.encode_sparse
     saved["hybrid_use_token_id_vector"] = False
     yaml.dump(saved, open(d / "model_args.yaml", "w"))
-    with pytest.raises(NotImplementedError, match="LM-head query vectors"):
-        arguments_from_checkpoint(str(d))
-    assert arguments_from_checkpoint(str(d), hybrid_use_token_id_vector=True).encode_sparse                  # the caller's explicit choice
+    args = arguments_from_checkpoint(str(d))
+    assert args.hybrid_use_sparse_vector and not args.hybrid_use_token_id_vector and args.encode_sparse
     args = arguments_from_checkpoint(str(d), hybrid_use_sparse_vector=False)
     assert not args.encode_sparse and args.hybrid_use_dense_vector
     saved["hybrid_use_sparse_vector"], saved["hybrid_use_token_id_vector"] = False, True

@@ -350,3 +350,32 @@ def test_pooling_strategies_match_the_reference():
         np.testing.assert_array_equal(g[f"qry_{st}"], g[f"psg_{st}"])
     with pytest.raises(AssertionError):
         O.pool_packed(np.zeros((3, 4), np.float32), np.array([0, 2, 3]), "second_to_last")       # the reference asserts too (:63-66)
+
+
+def test_sparse_query_vectors_match_the_reference():
+    """Round 6: HybridModel.encode_query with `hybrid_use_sparse_vector` (finetune/modeling_hybrid.py:404-438; gen_sparse_query_goldens.py ran the
+    reference): the passage pipeline on the query's tokens with the *_qry sampling ratios, and the quantised pseudo text call_batch_encode
+    makes of a query vector (the reference's own torch restatement of its Rust converter)."""
+    g = np.load(os.path.join(GOLDEN, "sparse_query.npz"))
+    sp = _sparse_golden()
+    cfg, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    ids, _, _, cu, _ = O.pack_padded(g["input_ids"], g["attention_mask"])
+    am = g["attention_mask"].astype(bool)
+    tm = sp["mask_noprompt"][am]
+    got = O.encode_query_sparse(cfg, w, ids, cu, tm, bf16=False, relu=True, log1p=True)
+    np.testing.assert_allclose(got, g["sparse_reps"], atol=2e-5)
+    np.testing.assert_array_equal(got > 0, g["sparse_reps"] > 0)
+    np.testing.assert_array_equal(g["sparse_only"], g["sparse_reps"])
+    np.testing.assert_allclose(O.encode_passage(cfg, w, ids.astype(np.int32), cu), g["dense_reps"], atol=2e-5)      # the dense vector of the same call
+    # the *_qry ratios on the reference's own pre-threshold values: same support (the passage ratios set next to them must not apply)
+    for key, kw in (("sparse_reps_top8_qry", dict(top_k=8, min_tokens_to_keep=4)), ("sparse_reps_topp_qry", dict(top_p=0.4, min_tokens_to_keep=8))):
+        want = g[key]
+        thr = O.sparsify(sp["agg_noprompt"], relu=True, log1p=True, **kw)
+        np.testing.assert_allclose(thr, want, atol=1e-6)
+        np.testing.assert_array_equal(thr > 0, want > 0)
+    assert (g["sparse_reps_top8_qry"] > 0).sum(1).max() == 8
+    txt = json.load(open(os.path.join(GOLDEN, "sparse_query_text.json")))
+    assert O.sparse_reps_to_pseudo_text(g["sparse_reps"][1:2], 100) == txt["quant100_row1"]
+    assert O.sparse_reps_to_pseudo_text(g["sparse_reps_top8_qry"], 100) == txt["quant100_top8"]
+    assert O.sparse_reps_to_pseudo_text(np.array([[0.5 / 7, 1.5 / 7, 2.5 / 7, -3.0, 0.0, 0.07], [0.0] * 6], np.float32), 7) == txt["quant7_halves"]
+    assert txt["quant7_halves"][1] == "-1"
