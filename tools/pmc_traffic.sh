@@ -7,7 +7,7 @@
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/pmc_r05
+OUT=$R/gpurun_out/pmc_r06
 mkdir -p $OUT/enc $OUT/srch
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
