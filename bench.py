@@ -171,8 +171,8 @@ def cpu_baseline(cfg, seq_len, topk, dim):
     }
 
 
-PMC_SUMMARY = os.environ.get("LRX_PMC_SUMMARY", "profiles/r05_pmc_summary.json")   # offline rocprofv3 --pmc passes (tools/pmc_traffic.sh)
-PMC_MFMA = os.environ.get("LRX_PMC_MFMA", "profiles/r05_pmc_mfma.json")
+PMC_SUMMARY = os.environ.get("LRX_PMC_SUMMARY", "profiles/r06_pmc_summary.json")   # offline rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+PMC_MFMA = os.environ.get("LRX_PMC_MFMA", "profiles/r06_pmc_mfma.json")
 
 
 def git_blob_sha(rel_path):
