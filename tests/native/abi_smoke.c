@@ -168,6 +168,23 @@ int main(void) {
   if (lrx_flat_ip_search(dX, N, D, D, dbound, dq, Q, 0, 0, dD, (int64_t*)dI, ws, wsb, NULL) == 0 || strlen(lrx_last_error()) == 0) { printf("k = 0 was accepted\n"); ++bad; }
   if (lrx_flat_ip_search(dX, N, D, D, dbound, dq, Q, k, 0, dD, (int64_t*)dI, ws, 16, NULL) == 0) { printf("a 16-byte workspace was accepted\n"); ++bad; }
   if (lrx_flat_ip_search_bounded(dX, N, D, D, dXb, dbound, dq, Q, k, 0, dD, (int64_t*)dI, ws, wsb, 64, NULL) == 0) { printf("unknown search flags were accepted\n"); ++bad; }
+  /* (ABI 8) how many queries one pass over the shadow serves: 256 for small / narrow shards, wide chunks over a wide shadow */
+  if (lrx_flat_ip_bounded_chunk_queries(N, D, 1000, k, LRX_SEARCH_FILTER_AUTO, 1) != 256 || lrx_flat_ip_bounded_chunk_queries(1000000, 2048, 1000, 100, LRX_SEARCH_FILTER_AUTO, 1) != 1008 ||
+      lrx_flat_ip_bounded_chunk_queries(1000000, 2048, 1000, 100, LRX_SEARCH_FILTER_AUTO, 0) != 128) { printf("lrx_flat_ip_bounded_chunk_queries: unexpected chunking\n"); ++bad; }
+  /* (ABI 8) pooling strategies on rows that need no model: mean of two unit-RMS rows through an all-ones norm weight, no normalisation */
+  { const int H = 64; float hx[3 * 64]; unsigned short w16[64]; int hcu[3] = {0, 2, 3}; float ho[2 * 64];
+    for (int i = 0; i < H; ++i) { hx[i] = (i & 1) ? 1.f : -1.f; hx[H + i] = 1.f; hx[2 * H + i] = (i & 2) ? 1.f : -1.f; w16[i] = 0x3F80; }   /* bf16 1.0 */
+    float* dx; void* dw; int* dc; float* dout;
+    CHECK(hipMalloc((void**)&dx, sizeof(hx))); CHECK(hipMalloc(&dw, sizeof(w16))); CHECK(hipMalloc((void**)&dc, sizeof(hcu))); CHECK(hipMalloc((void**)&dout, sizeof(ho)));
+    CHECK(hipMemcpy(dx, hx, sizeof(hx), hipMemcpyHostToDevice)); CHECK(hipMemcpy(dw, w16, sizeof(w16), hipMemcpyHostToDevice)); CHECK(hipMemcpy(dc, hcu, sizeof(hcu), hipMemcpyHostToDevice));
+    LRX(lrx_pool_norm_mode(dx, dw, dc, 2, H, 0.f, LRX_POOL_MEAN, dout, H, H, 0, NULL, 0, NULL, 1, NULL));
+    CHECK(hipDeviceSynchronize()); CHECK(hipMemcpy(ho, dout, sizeof(ho), hipMemcpyDeviceToHost));
+    for (int i = 0; i < H; ++i) {
+      const float want0 = ((i & 1) ? 1.f : 0.f), want1 = (i & 2) ? 1.f : -1.f;                 /* mean(-1|+1, +1) and the single row of sequence 1 */
+      if (fabsf(ho[i] - want0) > 1e-5f || fabsf(ho[H + i] - want1) > 1e-5f) { if (bad < 5) printf("lrx_pool_norm_mode(mean): column %d: %g %g\n", i, ho[i], ho[H + i]); ++bad; }
+    }
+    if (lrx_pool_norm_mode(dx, dw, dc, 2, H, 0.f, 9, dout, H, H, 0, NULL, 0, NULL, 1, NULL) == 0) { printf("an unknown pooling strategy was accepted\n"); ++bad; }
+    hipFree(dx); hipFree(dw); hipFree(dc); hipFree(dout); }
   bad += attention_smoke();
   printf(bad ? "ABI SMOKE FAILED (%d mismatches)\n" : "ABI SMOKE OK\n", bad);
   return bad ? 4 : 0;
