@@ -137,7 +137,8 @@ template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
                const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope, MaxAggArgs mx, NormArgs nrm, EmitArgs em) {
-  __shared__ __attribute__((aligned(1024))) char smem[8 * HALF_BYTES];  // [buf 0/1][A0 | A1 | B0 | B1]
+  // [buf 0/1][A0 | A1 | B0 | B1]; EPI_EMIT: + 2304 B behind the ring for the tile's thresholds and hit counters (set up at kernel start)
+  __shared__ __attribute__((aligned(1024))) char smem[8 * HALF_BYTES + (EPI == EPI_EMIT ? 2304 : 0)];
   // ---- workgroup -> tile
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
@@ -157,6 +158,14 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  if constexpr (EPI == EPI_EMIT) {
+    // the epilogue's thresholds of this tile's 256 queries and its zeroed hit counters, parked behind the ring NOW: their global loads and the
+    // clearing barrier then cost the epilogue nothing (the K loop's barriers order these writes before the epilogue's reads)
+    float* xthr = (float*)(smem + 8 * HALF_BYTES);
+    unsigned int* xqc = (unsigned int*)(smem + 8 * HALF_BYTES + 1024);
+    if (tid < GBN) { xthr[tid] = n0 + tid < N ? em.thr[n0 + tid] : FLT_MAX; xqc[tid] = 0u; }
+    if (tid < 8) ((unsigned int*)(smem + 8 * HALF_BYTES + 2048))[tid] = 0u;
+  }
 
   // ---- LDS-DMA sources: per half-tile 2 instructions per lane; lane l of instruction i fills 16-B slot
   //      s = (wave*2+i)*64 + l  ->  row = s>>3 (0..127), chunk position s&7 holding logical chunk (s&7) ^ ((row>>1)&7)
@@ -351,21 +360,14 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
     constexpr int WCAP = 512;                                   // hits a wave can park in LDS; more go straight to the global lists
     unsigned long long* wl = (unsigned long long*)(smem + wave * (WCAP * 12 + 64));
     unsigned int* wq = (unsigned int*)(wl + WCAP);
-    unsigned int* wn = wq + WCAP;                                // the wave's hit count
-    unsigned int* qc = (unsigned int*)(smem + 8 * (WCAP * 12 + 64));   // hits of the workgroup per query column; then their global base
-    if (lane == 0) *wn = 0;
-    if (tid < GBN) qc[tid] = 0;
-    __syncthreads();
-    float t16[2][2][4];
+    unsigned int* wn = (unsigned int*)(smem + 8 * HALF_BYTES + 2048) + wave;   // the wave's hit count        (the three of them behind the ring:
+    unsigned int* qc = (unsigned int*)(smem + 8 * HALF_BYTES + 1024);          // hits of the workgroup per query column; then their global base
+    const float* xthr = (const float*)(smem + 8 * HALF_BYTES);                  // thresholds of queries n0 .. n0 + 255: written at kernel start)
+    f32x4 t16[2][2];
 #pragma unroll
     for (int hp = 0; hp < 2; ++hp)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = n0 + hp * 128 + wc * 32 + ni * 16 + fq * 4 + r;     // the query (n0 > 0: a further 256-query n-tile of a wide chunk)
-          t16[hp][ni][r] = col < N ? em.thr[col] : FLT_MAX;
-        }
+      for (int ni = 0; ni < 2; ++ni) t16[hp][ni] = *(const f32x4*)(xthr + hp * 128 + wc * 32 + ni * 16 + fq * 4);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
