@@ -56,6 +56,20 @@ def case_sharded(rank, world, dev):
         Dg2, Ig2 = ShardedFlatIPIndex(sh2, row_map=gl.to(dev)).search(q, k)
         assert torch.equal(Ig2, Iw) and torch.equal(Dg2, Dw), ("interleaved shards", k, rank, (Ig2 != Iw).sum().item())
     assert Iw[3, 0].item() == N // 7 and Iw[3, 1].item() == N // 3          # the duplicate pair really is the top of query 3, lower row first
+    # (c) round 6 -- a WIDE chunk over the exchange: 600 queries over a 1024-wide shadow are one GEMM pass per rank (three query n-tiles); the
+    # wire words of all 600 queries come from the chain's last kernels (per 128-query group), the row map applied
+    N2, D2, Q2, k2 = 40_003, 1024, 600, 50
+    X2 = corpus_rows(N2, D2, 8)
+    q2 = torch.from_numpy(corpus_rows(Q2, D2, 9)).to(dev)
+    full2 = FlatIPIndex(D2, capacity=N2, device=dev)
+    full2.add(torch.from_numpy(X2))
+    assert int(full2.lib.lrx_flat_ip_bounded_chunk_queries(N2, D2, Q2, k2, 0, 1)) == 608
+    Dw2, Iw2 = full2.search(q2, k2)
+    gl2 = local_to_global_rows(N2, 64, rank, world)
+    sh3 = FlatIPIndex(D2, capacity=len(gl2), device=dev)
+    sh3.add(torch.from_numpy(X2[gl2.numpy()]))
+    Dg3, Ig3 = ShardedFlatIPIndex(sh3, row_map=gl2.to(dev)).search(q2, k2)
+    assert torch.equal(Ig3, Iw2) and torch.equal(Dg3, Dw2), ("wide chunk, interleaved shards", rank, (Ig3 != Iw2).sum().item())
     return "sharded: %d rows over %d rank(s), k = 100 and 1000, contiguous + interleaved: bit-identical to one index" % (N, world)
 
 
