@@ -59,7 +59,7 @@ def main():
         err = np.abs(got - want.reshape(T, nq * d)).max()
         check("attn", err < 3e-2, (d, nq, nkv, lens, float(err)))
         # ---- search
-        N_ = int(rng.choice([300, 4097, 5000, 20000, 70001])); D = int(rng.choice([32, 64, 96, 128, 192, 256, 320, 512, 1024])); Q = int(rng.choice([1, 3, 17, 33, 100, 130, 150, 200, 256, 300])); kk = int(rng.choice([1, 5, 100, 257]))
+        N_ = int(rng.choice([300, 4097, 5000, 20000, 70001])); D = int(rng.choice([32, 64, 96, 128, 192, 256, 320, 512, 1024, 1088, 1536, 2048])); Q = int(rng.choice([1, 3, 17, 33, 100, 130, 150, 200, 256, 257, 300, 513, 700, 1024, 1100])); kk = int(rng.choice([1, 5, 100, 257]))      # (D >= 1024 with more than 256 queries: wide chunks, both passes on the GEMM kernel)
         X = O.l2_normalize(rng.standard_normal((N_, D)).astype(np.float32)) * rng.uniform(0.2, 2.0, size=(N_, 1)).astype(np.float32)
         qq = rng.standard_normal((Q, D)).astype(np.float32)
         idx = FlatIPIndex(D, capacity=N_); idx.shadow_f16 = bool(rng.integers(0, 4)); idx.add(X)
