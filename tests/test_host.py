@@ -200,6 +200,8 @@ def _bench_rank_worker(rank, world, port, index_rows, q, X, k, ret):
     fits = torch.tensor([0 if rank == 2 else 1], dtype=torch.int64)
     dist.all_reduce(fits, op=dist.ReduceOp.MIN)
     assert sizes10m.tolist() == [2_500_000] * 4 and int(fits.item()) == 0 and bench.reduce_max(float(rank), torch.device("cpu"), True) == 3.0
+    # (the helpers bench.py itself uses: over gloo the tiny collectives live on the host -- coll_device -- whatever device the rank computes on)
+    assert bench.coll_device(torch.device("cuda", 0)) == torch.device("cpu") and bench.gather_counts(100 + rank, torch.device("cuda", 0), True) == [100, 101, 102, 103]
     ret[rank] = (Dm, Im, sizes.tolist(), base, float(t.item()))
     dist.barrier()
     dist.destroy_process_group()
