@@ -36,6 +36,11 @@ Parity pin status
   reference functions).  The JSON converter is pinned against the reference's own torch variant
   (``convert_sparse_reps_to_json_pt``); its Rust crate ``sparse_emb_util`` is not in the reference tree -> **unpinned**.
 
+* Pooling strategies other than 'lasttoken' (cls / mean / second_to_last / third_to_last): PINNED by ``tests/golden/pooling.npz``
+  (``gen_pooling_goldens.py`` runs ``finetune/dense_pooling.pooling`` and ``HybridModel.encode_passage / encode_query`` with each strategy).
+* LM-head sparse QUERY vectors (``hybrid_use_sparse_vector``) and their pseudo text: PINNED by ``tests/golden/sparse_query.npz`` /
+  ``sparse_query_text.json`` (``gen_sparse_query_goldens.py``: ``HybridModel.encode_query`` and ``convert_sparse_reps_to_pseudo_text_pt``).
+
 * Hit-list fusion (row N3: RRF, min-max linear): PINNED by ``tests/golden/fusion.json`` (``gen_fusion_goldens.py`` runs
   ``retriever/score_fuse_utils.py``), exact float64 equality.
 
