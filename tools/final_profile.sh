@@ -28,5 +28,11 @@ prof sparse --legs sparse
 for leg in ${LEGS:-top_k_1000 search_per_shard_8way search_clustered config2_search_1Mx4096 config4_search_10Mx256 config3_per_rank_shard_1250kx4096 config4_per_rank_shard_1250kx256 config2_encode_llama31_8b ragged_encode_llama32_1b n1_embedding_bag_build}; do
   prof cfg_$leg --legs configs --config-legs $leg
 done
+# the legs that only exist over a communicator (BASELINE configs[3] / configs[4] + the 8B encoder), as ONE rank of an 8-GPU run sees them: a forced
+# one-rank RCCL group over 10M / 8 rows (the environment is exported BEFORE rocprofv3: the program itself follows `--`)
+export LRX_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
+prof sharded --legs sharded --sharded-rows 1250000
+tail -c 4000 $OUT/prof_sharded.log | grep -o '{"partial_run.*' > $OUT/sharded_line.json || true
+unset LRX_BENCH_FORCE_DIST MASTER_ADDR MASTER_PORT RANK WORLD_SIZE LOCAL_RANK
 rm -rf $OUT/prof_*/   # (the traces are tens of MB; the stats files and logs stay)
 ls $OUT
