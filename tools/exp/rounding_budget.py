@@ -117,7 +117,11 @@ def forward(enc, cfg, ids, fl):
         I = cfg.intermediate_size
         gu = gu.view(S, I // 16, 2, 16)
         g, u = gu[:, :, 0].reshape(S, I), gu[:, :, 1].reshape(S, I)
-        act = r16(torch.nn.functional.silu(g) * u, fl["act"])
+        act = torch.nn.functional.silu(g) * u
+        if "stats" in fl:                                                    # operand ranges (is fp16 wide enough?)
+            fl["stats"]["act"] = max(fl["stats"].get("act", 0.0), act.abs().max().item())
+            fl["stats"]["o"] = max(fl["stats"].get("o", 0.0), o.abs().max().item())
+        act = r16(act, fl["act"])
         lin = r16(act @ L["wdown"].float().T, fl["lin"])
         x = r16(x + lin, fl["stream"])
     h = x[-1]
