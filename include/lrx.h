@@ -145,9 +145,12 @@ int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_encoder_weights
 #define LRX_POOL_MEAN 2            /* mean of the final-norm rows of all its tokens (:35-36), fp32, tokens added in order */
 #define LRX_POOL_SECOND_TO_LAST 3  /* token len - 2 (:57-67) */
 #define LRX_POOL_THIRD_TO_LAST 4   /* token len - 3 (:69-79) */
+#define LRX_POOL_AVG_FIRST_LAST 5  /* mean over the tokens of (hidden_states[0] + hidden_states[-1]) / 2: the embedding rows and the final-norm rows (:38-41) */
+#define LRX_POOL_AVG_TOP2 6        /* ... of (hidden_states[-2] + hidden_states[-1]) / 2: the stream before the final layer and the final-norm rows (:43-46) */
 /* LASTTOKEN runs the final layer's O-projection / MLP on the pooled rows only; every other strategy runs all layers over all tokens and pools
  * from the residual stream (final norm inside the pooling kernel, fp32 when the stream is).  A sequence shorter than its strategy needs (the
- * reference asserts there) gets a zero row and raises lrx_device_error_count.  'avg_first_last' / 'avg_top2' (other layers' states): not served. */
+ * reference asserts there) gets a zero row and raises lrx_device_error_count.  The two-layer strategies add one column-sum pass over the other
+ * hidden state (the embedding rows; the stream as it enters the final layer) -- served here only: lrx_pool_norm_mode sees one hidden state. */
 int lrx_encode_packed_pooled(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* ids,
                              const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t pooling,
                              float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* shadow_out,
@@ -351,7 +354,7 @@ int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int3
                         int32_t hidden_size, float eps, float* out, int64_t out_row_stride, int32_t out_dim,
                         int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream);
 
-/* (ABI 8) ... and with the pooling strategy (LRX_POOL_*; cu_seqlens required for anything but LASTTOKEN): pooling(last_hidden, mask, strategy)
+/* (ABI 8) ... and with the pooling strategy (LRX_POOL_LASTTOKEN .. LRX_POOL_THIRD_TO_LAST; cu_seqlens required for anything but LASTTOKEN): pooling(last_hidden, mask, strategy)
  * of finetune/dense_pooling.py:12-82 over `hidden` = the residual stream before the final norm, which runs inside (per pooled token). */
 int lrx_pool_norm_mode(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
                        int32_t hidden_size, float eps, int32_t pooling, float* out, int64_t out_row_stride, int32_t out_dim,

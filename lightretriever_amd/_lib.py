@@ -35,7 +35,7 @@ class EncoderWeightsC(C.Structure):
 
 
 # LRX_POOL_* of include/lrx.h: `--pooling_strategy` (finetune/dense_pooling.py:12-82)
-POOLING = {"lasttoken": 0, "cls": 1, "mean": 2, "second_to_last": 3, "third_to_last": 4}
+POOLING = {"lasttoken": 0, "cls": 1, "mean": 2, "second_to_last": 3, "third_to_last": 4, "avg_first_last": 5, "avg_top2": 6}
 
 _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 

@@ -98,6 +98,7 @@ struct EncWs {
   char *x, *h, *qkv, *act;    // x: the bf16 residual stream, or (precise_stream) the bf16 A operand bf16(x32 * gamma_next) of the next projection
   char *xr, *ar, *hr, *actr;  // compact [n_seqs, .] buffers of the pooled tail of the final layer
   float *x32, *xr32;          // precise_stream: the fp32 residual stream (and its pooled-tail rows)
+  float* aux32;               // [n_seqs, H] column sums of the other hidden state (LRX_POOL_AVG_FIRST_LAST / AVG_TOP2)
   int32_t* pos;
   float *rsA, *rsB, *ssp;     // folded RMSNorm: row scales for the two norms of a layer, per-n-tile sum-of-squares partials
   int32_t* posr;              // final layer: positions / row scales of the last-token rows (the q projection runs on those rows only)
@@ -126,6 +127,7 @@ static EncWs carve(const lrx_encoder_config* c, int64_t T, int64_t B, char* base
   w.actr = base + off; off += align_up((size_t)B * I * 2, 1024);
   w.posr = (int32_t*)(base + off); off += align_up((size_t)B * 4 + 32, 1024);
   w.rsr = (float*)(base + off); off += align_up((size_t)B * 4 + 32, 1024);
+  w.aux32 = (float*)(base + off); off += align_up((size_t)B * H * 4, 1024);
   {
     // sized for the longest sequence a call may name (check_call: max_seqlen <= max_positions; the list size is non-decreasing in
     // max_seqlen and bounded by (T / 64 + B) x kv heads items of 16 bytes: ~300 KiB for 256 x 512 tokens and 8 kv heads)
@@ -170,6 +172,7 @@ struct LayerHooks {
   int (*after_qkv)(void* ctx, int l, hipStream_t s);   // may be NULL
   void* ctx;
   double attn_flops;            // per layer, for the profile
+  int (*before_layer)(void* ctx, int l, hipStream_t s) = nullptr;   // may be NULL: sees the stream as layer l is about to read it (hidden_states[l])
 };
 
 // Embedding + all layers over T packed tokens.  Leaves the residual stream BEFORE the final norm in ws.x (bf16) or ws.x32 (precise_stream) --
@@ -203,6 +206,7 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
   for (int l = 0; l < c->num_layers; ++l) {
     const lrx_layer_weights& L = w->layers[l];
     const bool last = l == c->num_layers - 1;
+    if (hk.before_layer && (rc = hk.before_layer(hk.ctx, l, s))) return rc;
     if (!scaled) { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln1, ws.h, T, H, c->rms_eps, s))) return rc; }
     const void* Aqkv = scaled ? ws.x : ws.h;
     const void* bq = c->qkv_bias ? L.bqkv : nullptr;
@@ -255,7 +259,15 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
 }
 
 // the batch callers: varlen causal attention over (cu, n_seqs)
-struct BatchAttn { const lrx_encoder_config* c; EncWs* ws; const int32_t* cu; int n_seqs, T, max_seqlen; };
+struct BatchAttn { const lrx_encoder_config* c; EncWs* ws; const int32_t* cu; int n_seqs, T, max_seqlen; bool sum_before_last; };
+// LRX_POOL_AVG_TOP2: hidden_states[-2] is the stream as it enters the final layer -- its per-sequence column sums go to ws.aux32
+static int batch_before_layer(void* ctx, int l, hipStream_t s) {
+  const BatchAttn& a = *(const BatchAttn*)ctx;
+  if (!a.sum_before_last || l != a.c->num_layers - 1) return LRX_OK;
+  ProfScope p(s, 6, 0);
+  const bool pr = a.c->precise_stream != 0;
+  return lrx_pool_sum_rows(pr ? (const void*)a.ws->x32 : (const void*)a.ws->x, pr ? 1 : 0, nullptr, 0, a.cu, a.n_seqs, a.c->hidden_size, a.ws->aux32, s);
+}
 static int batch_attn(void* ctx, int, bool last_tile, hipStream_t s) {
   const BatchAttn& a = *(const BatchAttn*)ctx;
   return lrx_attn_varlen_causal_items(a.ws->qkv, a.cu, last_tile ? a.ws->attn_items_tail : a.ws->attn_items,
@@ -263,7 +275,7 @@ static int batch_attn(void* ctx, int, bool last_tile, hipStream_t s) {
                                       a.c->num_kv_heads, a.c->head_dim, a.ws->h, last_tile ? 1 : 0, s);
 }
 static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu, int n_seqs,
-                          int T, int max_seqlen, EncWs& ws, bool pooled_tail, hipStream_t s) {
+                          int T, int max_seqlen, EncWs& ws, bool pooled_tail, hipStream_t s, bool sum_before_last = false) {
   int rc;
   { ProfScope p(s, 6, 0); if ((rc = lrx_build_positions(cu, n_seqs, T, ws.pos, s))) return rc; }
   // the attention work lists: one per batch, read by every layer's launch (the last layer of a pooled encode has its own: last q tiles only)
@@ -274,8 +286,9 @@ static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights
   // causal attention flops: sum over sequences is not known on the host without a sync; use the dense upper bound for
   // equal-length batches: n_seqs * S*(S+1)/2 with S = T / n_seqs (exact when all sequences have the same length)
   const double S = (double)T / (double)(n_seqs > 0 ? n_seqs : 1);
-  BatchAttn ba = {c, &ws, cu, n_seqs, T, max_seqlen};
+  BatchAttn ba = {c, &ws, cu, n_seqs, T, max_seqlen, sum_before_last};
   LayerHooks hk = {batch_attn, nullptr, &ba, 2.0 * 2.0 * c->head_dim * c->num_q_heads * (double)n_seqs * (S * (S + 1.0) / 2.0)};
+  if (sum_before_last) hk.before_layer = batch_before_layer;
   return run_layers(c, w, ids, T, ws, hk, pooled_tail ? cu : nullptr, n_seqs, s);
 }
 
@@ -311,7 +324,7 @@ extern "C" int lrx_encode_packed_pooled(const lrx_encoder_config* cfg, const lrx
   if (rc) return rc;
   LRX_CHECK_ARG(out && out_dim > 0 && out_dim <= cfg->hidden_size && out_row_stride >= out_dim, "encode: bad output spec (dim=%d stride=%lld)",
                 out_dim, (long long)out_row_stride);
-  LRX_CHECK_ARG(pooling >= LRX_POOL_LASTTOKEN && pooling <= LRX_POOL_THIRD_TO_LAST, "encode: pooling=%d (LRX_POOL_*)", pooling);
+  LRX_CHECK_ARG(pooling >= LRX_POOL_LASTTOKEN && pooling <= LRX_POOL_AVG_TOP2, "encode: pooling=%d (LRX_POOL_*)", pooling);
   hipStream_t s = (hipStream_t)stream;
   EncWs ws = carve(cfg, total_tokens, n_seqs, (char*)workspace);
   prof_begin();
@@ -325,10 +338,15 @@ extern "C" int lrx_encode_packed_pooled(const lrx_encoder_config* cfg, const lrx
       return rc;
   } else {
     // any other strategy of finetune/dense_pooling.py: every layer over every token, then the final norm + pooling over the stream's rows
-    if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, false, s))) return rc;
+    // (the two-layer strategies pool a second hidden state too: hidden_states[0] = the embedding rows, summed from the table; hidden_states[-2] =
+    // the stream as it enters the final layer, summed by the layer loop's hook)
+    if ((rc = forward_layers(cfg, w, ids, cu_seqlens, n_seqs, total_tokens, max_seqlen, ws, false, s, pooling == LRX_POOL_AVG_TOP2))) return rc;
     ProfScope p(s, 6, 0);
-    if ((rc = lrx_pool_norm_mode(pr ? (const void*)ws.x32 : (const void*)ws.x, w->final_norm, cu_seqlens, n_seqs, cfg->hidden_size, cfg->rms_eps,
-                                 pooling, out, out_row_stride, out_dim, normalize, shadow_out, shadow_row0, row_bounds, pr ? 1 : 0, s)))
+    if (pooling == LRX_POOL_AVG_FIRST_LAST &&
+        (rc = lrx_pool_sum_rows(w->embed, 2, ids, cfg->vocab_size, cu_seqlens, n_seqs, cfg->hidden_size, ws.aux32, s))) return rc;
+    if ((rc = lrx_pool_norm_aux(pr ? (const void*)ws.x32 : (const void*)ws.x, w->final_norm, cu_seqlens, n_seqs, cfg->hidden_size, cfg->rms_eps,
+                                pooling, pooling >= LRX_POOL_AVG_FIRST_LAST ? ws.aux32 : nullptr, out, out_row_stride, out_dim, normalize, shadow_out,
+                                shadow_row0, row_bounds, pr ? 1 : 0, s)))
       return rc;
   }
   return prof_end(s);

@@ -104,4 +104,10 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
                                   int K, hipStream_t stream);
 
 // lrx_elementwise.hip: dst[b] = src[cu_seqlens[b + 1] - 1] for 4-byte elements (positions, row scales of the last-token rows)
+// lrx_elementwise.hip: the two-layer pooling strategies (column sums of the other hidden state; the pooling kernel with them)
+int lrx_pool_sum_rows(const void* src, int src_kind, const int32_t* ids, int vocab, const int32_t* cu_seqlens, int n_seqs, int hidden_size, float* aux,
+                      hipStream_t stream);
+int lrx_pool_norm_aux(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs, int32_t hidden_size, float eps,
+                      int32_t pooling, const float* aux, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* shadow_out,
+                      int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream);
 int lrx_gather_rows_u32(const void* src, const int32_t* cu_seqlens, int32_t n_seqs, void* dst, hipStream_t stream);

@@ -352,7 +352,7 @@ template <bool F32>
 __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidden_v, const __bf16* __restrict__ w,
                                                    const int32_t* __restrict__ cu, int H, float eps, float* __restrict__ out,
                                                    int64_t out_stride, int out_dim, int normalize, __bf16* __restrict__ shadow,
-                                                   int64_t shadow_row0, float* __restrict__ bounds, int mode) {
+                                                   int64_t shadow_row0, float* __restrict__ bounds, int mode, const float* __restrict__ aux) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* row = (float*)smem_raw;  // H floats
   float* red = row + H;           // 4 floats
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidd
   bool bad = false;
   if (cu && mode != LRX_POOL_LASTTOKEN) {
     const int64_t s0 = cu[b], s1 = cu[b + 1];
-    if (mode == LRX_POOL_MEAN) { t0 = s0; t1 = s1; bad = s1 <= s0; }
+    if (mode == LRX_POOL_MEAN || mode >= LRX_POOL_AVG_FIRST_LAST) { t0 = s0; t1 = s1; bad = s1 <= s0; }
     else {
       t0 = mode == LRX_POOL_CLS ? s0 : s1 - (mode == LRX_POOL_SECOND_TO_LAST ? 2 : 3);
       t1 = t0 + 1;
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidd
     if (threadIdx.x == 0) atomicAdd(&g_bad_token_ids, 1u);
     t1 = t0;                                                            // nothing pooled: a zero row goes out
   }
-  const bool mean = mode == LRX_POOL_MEAN && cu != nullptr;
+  const bool mean = (mode == LRX_POOL_MEAN || mode >= LRX_POOL_AVG_FIRST_LAST) && cu != nullptr;
   if (mean || bad) for (int i = threadIdx.x; i < out_dim; i += 256) { if (mean) acc[i] = 0.f; else row[i] = 0.f; }
   float n2 = 0.f;
   for (int64_t t = t0; t < t1; ++t) {
@@ -394,7 +394,9 @@ __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidd
   }
   if (mean) {
     const float inv = t1 > t0 ? 1.0f / (float)(t1 - t0) : 0.f;
-    for (int i = threadIdx.x; i < out_dim; i += 256) row[i] = acc[i] * inv;
+    // two-layer strategies: aux = the other hidden state's column sums (k_pool_sum) -- mean over tokens of (other + last) / 2
+    if (aux != nullptr) for (int i = threadIdx.x; i < out_dim; i += 256) row[i] = (acc[i] + aux[(int64_t)b * H + i]) * (0.5f * inv);
+    else for (int i = threadIdx.x; i < out_dim; i += 256) row[i] = acc[i] * inv;
   }
   for (int i = threadIdx.x; i < out_dim; i += 256) n2 += row[i] * row[i];
   n2 = block_sum_256(n2, red);
@@ -426,26 +428,68 @@ __global__ void __launch_bounds__(256) k_pool_norm(const void* __restrict__ hidd
   }
 }
 
-extern "C" int lrx_pool_norm_mode(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
-                                  int32_t hidden_size, float eps, int32_t pooling, float* out, int64_t out_row_stride, int32_t out_dim,
-                                  int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream) {
+// Column sums of one sequence's rows of a second hidden state, for the two-layer strategies (finetune/dense_pooling.py:38-46): aux[b, :] =
+// sum over the sequence's tokens of src[t, :], fp32, tokens added in order.  SRC 0 / 1: bf16 / fp32 rows (the stream BEFORE the final
+// layer = hidden_states[-2], LRX_POOL_AVG_TOP2); SRC 2: the embedding rows of the tokens (= hidden_states[0], LRX_POOL_AVG_FIRST_LAST; an id
+// outside the table adds a zero row, as in the embedding kernel that counted it).  grid (n_seqs, ceil(H / 256)).
+template <int SRC>
+__global__ void __launch_bounds__(256) k_pool_sum(const void* __restrict__ src, const int32_t* __restrict__ ids, int vocab, const int32_t* __restrict__ cu,
+                                                  int H, float* __restrict__ aux) {
+  const int b = blockIdx.x, i = blockIdx.y * 256 + threadIdx.x;
+  if (i >= H) return;
+  float acc = 0.f;
+  for (int64_t t = cu[b]; t < cu[b + 1]; ++t) {
+    if (SRC == 2) {
+      const int id = ids[t];
+      if (id >= 0 && id < vocab) acc += bf2f(((const __bf16*)src)[(int64_t)id * H + i]);
+    } else
+      acc += SRC == 1 ? ((const float*)src)[t * H + i] : bf2f(((const __bf16*)src)[t * H + i]);
+  }
+  aux[(int64_t)b * H + i] = acc;
+}
+int lrx_pool_sum_rows(const void* src, int src_kind, const int32_t* ids, int vocab, const int32_t* cu_seqlens, int n_seqs, int hidden_size, float* aux,
+                      hipStream_t stream) {
+  LRX_CHECK_ARG(src && cu_seqlens && aux && src_kind >= 0 && src_kind <= 2 && (src_kind != 2 || ids != nullptr), "pool_sum: bad arguments");
+  if (n_seqs == 0) return LRX_OK;
+  const dim3 grid(n_seqs, lrx_cdiv(hidden_size, 256));
+  if (src_kind == 2) hipLaunchKernelGGL(k_pool_sum<2>, grid, dim3(256), 0, stream, src, ids, vocab, cu_seqlens, hidden_size, aux);
+  else if (src_kind == 1) hipLaunchKernelGGL(k_pool_sum<1>, grid, dim3(256), 0, stream, src, ids, vocab, cu_seqlens, hidden_size, aux);
+  else hipLaunchKernelGGL(k_pool_sum<0>, grid, dim3(256), 0, stream, src, ids, vocab, cu_seqlens, hidden_size, aux);
+  LRX_LAUNCH_CHECK();
+  return LRX_OK;
+}
+
+// (internal form: `aux` = the [n_seqs, hidden_size] column sums of the other hidden state for LRX_POOL_AVG_FIRST_LAST / AVG_TOP2, else NULL)
+int lrx_pool_norm_aux(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs, int32_t hidden_size, float eps,
+                      int32_t pooling, const float* aux, float* out, int64_t out_row_stride, int32_t out_dim, int32_t normalize, void* shadow_out,
+                      int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream) {
   LRX_CHECK_ARG(out_dim > 0 && out_dim <= hidden_size, "pool_norm: out_dim=%d out of range (H=%d)", out_dim, hidden_size);
   LRX_CHECK_ARG(shadow_out == nullptr || (out_dim % 64 == 0 && shadow_row0 >= 0), "pool_norm: the tiled shadow needs out_dim %% 64 == 0 (out_dim %d)", out_dim);
-  LRX_CHECK_ARG(pooling >= LRX_POOL_LASTTOKEN && pooling <= LRX_POOL_THIRD_TO_LAST, "pool_norm: pooling=%d (LRX_POOL_*)", pooling);
+  LRX_CHECK_ARG(pooling >= LRX_POOL_LASTTOKEN && pooling <= LRX_POOL_AVG_TOP2, "pool_norm: pooling=%d (LRX_POOL_*)", pooling);
+  LRX_CHECK_ARG((pooling >= LRX_POOL_AVG_FIRST_LAST) == (aux != nullptr), "pool_norm: pooling %d %s the other hidden state's sums (served through lrx_encode_packed_pooled)",
+                pooling, aux ? "does not take" : "needs");
   LRX_CHECK_ARG(pooling == LRX_POOL_LASTTOKEN || cu_seqlens != nullptr, "pool_norm: pooling %d needs cu_seqlens (rows already compacted are last-token rows)", pooling);
   if (n_seqs == 0) return LRX_OK;
-  size_t smem = (size_t)(hidden_size + 4 + (pooling == LRX_POOL_MEAN ? hidden_size : 0)) * sizeof(float);
+  const bool mean = pooling == LRX_POOL_MEAN || pooling >= LRX_POOL_AVG_FIRST_LAST;
+  size_t smem = (size_t)(hidden_size + 4 + (mean ? hidden_size : 0)) * sizeof(float);
   LRX_CHECK_ARG(smem <= 160 * 1024, "pool_norm: hidden_size=%d does not fit the LDS", hidden_size);
   if (smem > 64 * 1024)        // (beyond the default dynamic-LDS limit: H > 8188, or mean pooling at H > 8190 / 2)
     LRX_HIP(hipFuncSetAttribute(hidden_f32 ? (const void*)k_pool_norm<true> : (const void*)k_pool_norm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   if (hidden_f32)
     hipLaunchKernelGGL(k_pool_norm<true>, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, hidden, (const __bf16*)final_norm_w, cu_seqlens,
-                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row0, row_bounds, pooling);
+                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row0, row_bounds, pooling, aux);
   else
     hipLaunchKernelGGL(k_pool_norm<false>, dim3(n_seqs), dim3(256), smem, (hipStream_t)stream, hidden, (const __bf16*)final_norm_w, cu_seqlens,
-                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row0, row_bounds, pooling);
+                       hidden_size, eps, out, out_row_stride, out_dim, normalize, (__bf16*)shadow_out, shadow_row0, row_bounds, pooling, aux);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
+}
+
+extern "C" int lrx_pool_norm_mode(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,
+                                  int32_t hidden_size, float eps, int32_t pooling, float* out, int64_t out_row_stride, int32_t out_dim,
+                                  int32_t normalize, void* shadow_out, int64_t shadow_row0, float* row_bounds, int32_t hidden_f32, void* stream) {
+  return lrx_pool_norm_aux(hidden, final_norm_w, cu_seqlens, n_seqs, hidden_size, eps, pooling, nullptr, out, out_row_stride, out_dim, normalize, shadow_out,
+                           shadow_row0, row_bounds, hidden_f32, stream);
 }
 
 extern "C" int lrx_pool_norm_shard(const void* hidden, const void* final_norm_w, const int32_t* cu_seqlens, int32_t n_seqs,

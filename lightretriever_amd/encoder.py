@@ -301,10 +301,10 @@ class LrxEncoder:
                       out_dim: Optional[int] = None, normalize: bool = True, pooling: str = "lasttoken") -> torch.Tensor:
         """ids int32 [T], cu_seqlens int32 [B+1] (device).  Writes fp32 [B, out_dim] rows into `out` (e.g. a slice of the
         index shard: no host round trip) and returns it.  pooling: `--pooling_strategy` of the reference (finetune/dense_pooling.py:12-82):
-        'lasttoken' (the released models), 'cls', 'mean', 'second_to_last', 'third_to_last'."""
+        'lasttoken' (the released models), 'cls', 'mean', 'second_to_last', 'third_to_last', 'avg_first_last', 'avg_top2' (the last two pool
+        over a second hidden state: the embedding rows / the stream as it enters the final layer)."""
         if pooling not in _lib.POOLING:
-            raise NotImplementedError(f"pooling strategy {pooling!r}: served are {sorted(_lib.POOLING)} ('avg_first_last' / 'avg_top2' pool over "
-                                      "other layers' hidden states)")
+            raise NotImplementedError(f"pooling strategy {pooling!r}: served are {sorted(_lib.POOLING)}")
         self._check_batch(ids, cu_seqlens)
         T, B = ids.numel(), cu_seqlens.numel() - 1
         D = out_dim or self.cfg.hidden_size

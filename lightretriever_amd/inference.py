@@ -112,10 +112,9 @@ class InferenceArguments:
         if self.normalize is None:
             self.normalize = self.score_function == "cos_sim"   # finetune/arguments.py:312-317
         self.pad_token, self.sep_token = default_special_tokens(self.model_name_or_path, self.pad_token, self.sep_token)
-        if self.pooling_strategy not in (None, "lasttoken", "cls", "mean", "second_to_last", "third_to_last"):
-            raise NotImplementedError(f"--pooling_strategy {self.pooling_strategy}: 'avg_first_last' / 'avg_top2' pool over other layers' hidden states "
-                                      "(finetune/dense_pooling.py:38-46) and are not served; lasttoken (the released models), cls, mean, "
-                                      "second_to_last and third_to_last are")
+        if self.pooling_strategy not in (None, "lasttoken", "cls", "mean", "second_to_last", "third_to_last", "avg_first_last", "avg_top2"):
+            raise NotImplementedError(f"--pooling_strategy {self.pooling_strategy}: finetune/dense_pooling.py:12-82 knows lasttoken (the released models), "
+                                      "cls, mean, second_to_last, third_to_last, avg_first_last and avg_top2 ('none' returns no vector)")
         if self.fp16 and self.bf16:
             raise ValueError("--bf16 and --fp16 are mutually exclusive (inference/arguments.py:68-73)")
         # options whose non-default value selects a part of the reference this path does not implement: fail loudly, never silently

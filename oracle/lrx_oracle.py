@@ -36,7 +36,7 @@ Parity pin status
   reference functions).  The JSON converter is pinned against the reference's own torch variant
   (``convert_sparse_reps_to_json_pt``); its Rust crate ``sparse_emb_util`` is not in the reference tree -> **unpinned**.
 
-* Pooling strategies other than 'lasttoken' (cls / mean / second_to_last / third_to_last): PINNED by ``tests/golden/pooling.npz``
+* Pooling strategies other than 'lasttoken' (cls / mean / second_to_last / third_to_last / avg_first_last / avg_top2): PINNED by ``tests/golden/pooling.npz``
   (``gen_pooling_goldens.py`` runs ``finetune/dense_pooling.pooling`` and ``HybridModel.encode_passage / encode_query`` with each strategy).
 * LM-head sparse QUERY vectors (``hybrid_use_sparse_vector``) and their pseudo text: PINNED by ``tests/golden/sparse_query.npz`` /
   ``sparse_query_text.json`` (``gen_sparse_query_goldens.py``: ``HybridModel.encode_query`` and ``convert_sparse_reps_to_pseudo_text_pt``).
@@ -330,15 +330,20 @@ def lasttoken_pool_padded(last_hidden: np.ndarray, attention_mask: np.ndarray) -
     return last_hidden[np.arange(B), idx]
 
 
-POOLING_STRATEGIES = ("lasttoken", "cls", "mean", "second_to_last", "third_to_last")
+POOLING_STRATEGIES = ("lasttoken", "cls", "mean", "second_to_last", "third_to_last", "avg_first_last", "avg_top2")
 
 
-def pool_packed(last_hidden: np.ndarray, cu_seqlens: np.ndarray, strategy: str = "lasttoken") -> np.ndarray:
+def pool_packed(last_hidden: np.ndarray, cu_seqlens: np.ndarray, strategy: str = "lasttoken", other_hidden: Optional[np.ndarray] = None) -> np.ndarray:
     """pooling() of finetune/dense_pooling.py:12-82 in the packed layout [T, H] (right-padded rows in the reference; both branches of the
     x-to-last strategies select the same token there): 'cls' = first token (:32-33), 'mean' = sum over the sequence's tokens / its length
     (:35-36; fp32, tokens added in order), 'lasttoken' / 'second_to_last' / 'third_to_last' = token len-1 / len-2 / len-3 (:48-79; the
-    reference asserts len >= 2 / 3).  'avg_first_last' / 'avg_top2' (other layers' hidden states) are not served."""
+    reference asserts len >= 2 / 3).  'avg_first_last' / 'avg_top2' (:38-46): the mean over the tokens of (other + last) / 2 with
+    `other_hidden` = hidden_states[0] (the embedding rows) / hidden_states[-2] (the stream entering the final layer)."""
     cu = np.asarray(cu_seqlens, dtype=np.int64)
+    if strategy in ("avg_first_last", "avg_top2"):
+        assert other_hidden is not None and other_hidden.shape == last_hidden.shape
+        half = (other_hidden.astype(np.float32) + last_hidden.astype(np.float32)) / np.float32(2.0)
+        return pool_packed(half, cu, "mean")
     if strategy == "lasttoken":
         return lasttoken_pool_packed(last_hidden, cu_seqlens)
     if strategy == "cls":
@@ -358,10 +363,14 @@ def pool_packed(last_hidden: np.ndarray, cu_seqlens: np.ndarray, strategy: str =
     raise NotImplementedError(strategy)
 
 
-def pool_padded(last_hidden: np.ndarray, attention_mask: np.ndarray, strategy: str) -> np.ndarray:
-    """The same on the reference's padded layout [B, S, H] + mask (literal restatement, for the goldens of pooling() itself)."""
+def pool_padded(last_hidden: np.ndarray, attention_mask: np.ndarray, strategy: str, hidden_states=None) -> np.ndarray:
+    """The same on the reference's padded layout [B, S, H] + mask (literal restatement, for the goldens of pooling() itself);
+    hidden_states: the tuple the two-layer strategies index ([0] / [-2], and [-1] as the last state, :38-46)."""
     B = last_hidden.shape[0]
     m = attention_mask.astype(np.int64)
+    if strategy in ("avg_first_last", "avg_top2"):
+        other = hidden_states[0] if strategy == "avg_first_last" else hidden_states[-2]
+        return (((other + hidden_states[-1]) / np.float32(2.0) * m[..., None]).sum(1) / m.sum(-1)[..., None]).astype(np.float32)
     if strategy == "cls":
         return last_hidden[:, 0]
     if strategy == "mean":
@@ -383,8 +392,16 @@ def encode_passage(cfg: EncoderConfig, w, ids, cu_seqlens, dense_shrink_dim: Opt
                    normalize: bool = True, bf16: bool = False, pooling: str = "lasttoken") -> np.ndarray:
     """finetune/modeling_hybrid.py:205-278 dense branch: forward -> pooling(strategy; 'lasttoken' in the released models) -> MRL slice ->
     F.normalize."""
-    h = encoder_forward_packed(cfg, w, ids, cu_seqlens, bf16=bf16)
-    p = pool_packed(h, cu_seqlens, pooling)
+    other = None
+    if pooling in ("avg_first_last", "avg_top2"):
+        # HF's hidden_states tuple (modeling_hybrid.py:257 asks for it): [0] = the embedding rows, [i] = the stream after layer i, and the
+        # LAST entry is the final-norm output (= last_hidden_state), so [-2] is the stream after layer L - 1, unnormed (L = 1: the embeddings)
+        h, layers = encoder_forward_packed(cfg, w, ids, cu_seqlens, bf16=bf16, return_layers=True)
+        emb = w["embed_tokens.weight"][np.asarray(ids)].astype(np.float32)
+        other = emb if pooling == "avg_first_last" or cfg.num_layers == 1 else layers[-2]
+    else:
+        h = encoder_forward_packed(cfg, w, ids, cu_seqlens, bf16=bf16)
+    p = pool_packed(h, cu_seqlens, pooling, other)
     if dense_shrink_dim:
         p = p[..., :dense_shrink_dim]
     return l2_normalize(p) if normalize else p.astype(np.float32)

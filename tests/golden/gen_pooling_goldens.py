@@ -7,8 +7,8 @@
     them, on the `llama_small_d64` model of gen_goldens.py (weights from the oracle's seeded generator, seed 5: the fixture carries inputs
     and outputs only), full width and `dense_shrink_dim = 64`.
 
-('avg_first_last' / 'avg_top2' pool over other layers' hidden states and are not served.)  Same import shim as gen_goldens.py; runs only
-in the build container.
+'avg_first_last' / 'avg_top2' (:38-46) pool over two entries of the model's `hidden_states` tuple: pooling() gets a random three-entry tuple,
+the operators ask HF for the real one (modeling_hybrid.py:257).  Same import shim as gen_goldens.py; runs only in the build container.
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_pooling_goldens.py      -> tests/golden/pooling.npz
 """
@@ -26,7 +26,7 @@ from transformers import LlamaConfig, LlamaForCausalLM, PreTrainedTokenizerFast 
 
 from lightretriever.finetune.dense_pooling import pooling  # noqa: E402
 
-STRATEGIES = ("cls", "mean", "lasttoken", "second_to_last", "third_to_last")
+STRATEGIES = ("cls", "mean", "lasttoken", "second_to_last", "third_to_last", "avg_first_last", "avg_top2")
 
 
 def main():
@@ -41,8 +41,14 @@ def main():
         for b, n in enumerate(lens):
             mask[b, :n] = 1
         out[f"fn_{name}_hidden"], out[f"fn_{name}_mask"] = h, mask
+        # hidden_states for the two-layer strategies: (first, middle, last = h), the extra states from their own generator (the other
+        # entries of the fixture keep their values)
+        rng2 = np.random.default_rng(63 + len(lens))
+        hs = (rng2.standard_normal((B, S, H)).astype(np.float32), rng2.standard_normal((B, S, H)).astype(np.float32), h)
+        out[f"fn_{name}_hidden_first"], out[f"fn_{name}_hidden_middle"] = hs[0], hs[1]
         for st in STRATEGIES:
-            out[f"fn_{name}_{st}"] = pooling(last_hidden=torch.from_numpy(h), attention_mask=torch.from_numpy(mask), pooling_strategy=st).numpy()
+            out[f"fn_{name}_{st}"] = pooling(last_hidden=torch.from_numpy(h), hidden_states=tuple(torch.from_numpy(x) for x in hs),
+                                            attention_mask=torch.from_numpy(mask), pooling_strategy=st).numpy()
 
     # ---- through the reference's operators on the llama_small_d64 model
     tok_dir = os.path.join(HERE, "tok")

@@ -46,7 +46,7 @@ def test_golden_models_within_reference_bf16_band(name):
 
 @pytest.mark.parametrize("precise", [True, False])
 def test_pooling_strategies_against_the_reference_outputs(precise):
-    """`--pooling_strategy` cls / mean / second_to_last / third_to_last (and lasttoken through the same generic path): lrx_encode_packed_pooled
+    """`--pooling_strategy` cls / mean / second_to_last / third_to_last / avg_first_last / avg_top2 (and lasttoken through the same generic path): lrx_encode_packed_pooled
     against what the reference's HybridModel.encode_passage / encode_query returned for each strategy on the llama_small_d64 model
     (tests/golden/pooling.npz, made by gen_pooling_goldens.py importing the reference; finetune/dense_pooling.py:12-82,
     finetune/modeling_hybrid.py:262-278), full width and the MRL slice, both stream modes; rows written in place into an index shard carry
@@ -76,6 +76,12 @@ def test_pooling_strategies_against_the_reference_outputs(precise):
         np.testing.assert_allclose(out_mrl, O.l2_normalize(out[:, :s]), atol=2e-6)
         if st == "lasttoken":                                                   # the default entry point is this strategy
             assert np.array_equal(out, enc.encode_packed(ids_t, cu_t, max_len).cpu().numpy())
+        # the per-batch operators with the reference's padded dict (B3): the same rows
+        from lightretriever_amd.modeling import LrxHybridModel
+        hm = LrxHybridModel(enc, normalize=True, hybrid_use_dense_vector=True, hybrid_use_emb_vector=False, pooling_strategy=st)
+        batch = {"input_ids": to_dev(g["input_ids"], torch.int64), "attention_mask": to_dev(g["attention_mask"], torch.int64)}
+        assert np.array_equal(hm.encode_passage(batch)["dense_reps"].cpu().numpy(), out), st
+        assert np.array_equal(hm.encode_query(batch)["dense_reps"].cpu().numpy(), out), st         # (qry == psg in the fixture: one tied encoder)
     # 'mean' rows straight into an index shard: searchable at once (shadow + bounds written by the pooling kernel)
     idx = FlatIPIndex(cfg.hidden_size, capacity=16)
     enc.encode_packed(ids_t, cu_t, max_len, out=idx.append_slot(len(cu) - 1), pooling="mean")

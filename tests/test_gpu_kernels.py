@@ -248,6 +248,11 @@ def test_pool_norm_strategies_against_the_reference_pooling(pooling):
         got16 = ops.pool_norm(bf16_t(x), bf16_t(w), torch.from_numpy(cu).to(dev()), 1e-5, out_dim, normalize, pooling=pooling)
         pooled16 = O.pool_packed(O.rmsnorm(O.round_bf16(x), w, 1e-5, bf16=True), cu, pooling)[:, :out_dim]
         np.testing.assert_allclose(f32(got16), O.l2_normalize(pooled16) if normalize else pooled16, atol=3e-3 if not normalize else 3e-4, rtol=1e-2)
+    # the two-layer strategies need a second hidden state: not this entry point's (lrx_encode_packed_pooled serves them) -- refused, not guessed
+    if pooling == "mean":
+        for st in ("avg_first_last", "avg_top2"):
+            with pytest.raises(Exception, match="other hidden state"):
+                ops.pool_norm(torch.from_numpy(x).to(dev()), bf16_t(w), torch.from_numpy(cu).to(dev()), 1e-5, out_dim, True, pooling=st)
     # a sequence shorter than the strategy needs (the reference asserts, dense_pooling.py:63-66): a zero row + the input-error counter
     if pooling in ("second_to_last", "third_to_last"):
         lib = _lib.lib()

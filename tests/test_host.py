@@ -516,7 +516,7 @@ def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_m
     for bad in (["--hybrid_use_emb_vector", "--untie_encoder"], ["--hybrid_use_emb_vector", "--enable_bidirectional_attention"],
                 ["--hybrid_use_emb_vector", "--use_sparse_linear_projector"], ["--hybrid_use_emb_vector", "--sparse_remove_stopwords"],
                 ["--hybrid_use_emb_vector", "--hybrid_model_architecture", "bert"],
-                ["--hybrid_use_emb_vector", "--pooling_strategy", "avg_top2"], ["--hybrid_use_emb_vector", "--sparse_use_max_aggregation", "False"]):
+                ["--hybrid_use_emb_vector", "--pooling_strategy", "none"], ["--hybrid_use_emb_vector", "--sparse_use_max_aggregation", "False"]):
         with pytest.raises(NotImplementedError):
             parse(*bad)
     with pytest.raises(ValueError, match="no vector type selected"):
@@ -528,8 +528,8 @@ def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_m
     assert parse("--hybrid_use_emb_vector", "--fp16").dtype == torch.float16
     with pytest.raises(ValueError):
         parse("--hybrid_use_emb_vector", "--fp16", "--bf16")
-    # round 6: the single-layer pooling strategies of finetune/dense_pooling.py:12-82 are served
-    for st in ("cls", "mean", "second_to_last", "third_to_last"):
+    # round 6: every vector-returning pooling strategy of finetune/dense_pooling.py:12-82 is served
+    for st in ("cls", "mean", "second_to_last", "third_to_last", "avg_first_last", "avg_top2"):
         assert parse("--hybrid_use_dense_vector", "--pooling_strategy", st).pooling_strategy == st
     # the defaults are the reference's (finetune/arguments.py:175-195, inference/arguments.py:27,68): nothing selected, fp32 container, EncoderModel
     e = InferenceArguments(model_name_or_path="/x/llama")

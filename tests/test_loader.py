@@ -107,7 +107,7 @@ def test_reference_import_paths_resolve():
     assert HybridSearch.name() == "hybrid_search" and FlatIPFaissSearch.name() == "faiss_search"
     assert callable(PytorchRPCExactSearchModel)
     with pytest.raises(NotImplementedError):
-        InferenceArguments(model_name_or_path="/x", pooling_strategy="avg_first_last")      # (pools over other layers' states; cls / mean / x_to_last are served)
+        InferenceArguments(model_name_or_path="/x", pooling_strategy="none")                # ('none' returns no vector; every other strategy is served)
 
 
 # ---- round 2: loader hardening ------------------------------------------------------------------

@@ -333,14 +333,18 @@ def test_lm_encoded_query_modes_match_the_reference():
 
 def test_pooling_strategies_match_the_reference():
     """Round 6: pooling() itself (finetune/dense_pooling.py:12-82) and HybridModel.encode_passage / encode_query with `--pooling_strategy`
-    cls / mean / lasttoken / second_to_last / third_to_last (tests/golden/gen_pooling_goldens.py ran the reference on the llama_small_d64 model)."""
+    cls / mean / lasttoken / second_to_last / third_to_last / avg_first_last / avg_top2 (tests/golden/gen_pooling_goldens.py ran the reference
+    on the llama_small_d64 model; the last two read HF's `hidden_states` tuple: embedding rows, per-layer streams, final-norm output last)."""
     g = np.load(os.path.join(GOLDEN, "pooling.npz"))
     for name in ("ragged", "allfull"):
         h, m = g[f"fn_{name}_hidden"], g[f"fn_{name}_mask"]
         packed, cu = h[m.astype(bool)], np.concatenate([[0], np.cumsum(m.sum(1))])
+        hs = (g[f"fn_{name}_hidden_first"], g[f"fn_{name}_hidden_middle"], h)          # the tuple the two-layer strategies index ([0] / [-2], [-1])
         for st in O.POOLING_STRATEGIES:
-            np.testing.assert_allclose(O.pool_padded(h, m, st), g[f"fn_{name}_{st}"], atol=1e-6, err_msg=f"{name} {st}")
-            np.testing.assert_allclose(O.pool_packed(packed, cu, st), g[f"fn_{name}_{st}"], atol=1e-6, err_msg=f"{name} {st} (packed)")
+            other = {"avg_first_last": hs[0], "avg_top2": hs[1]}.get(st)
+            np.testing.assert_allclose(O.pool_padded(h, m, st, hs), g[f"fn_{name}_{st}"], atol=1e-6, err_msg=f"{name} {st}")
+            np.testing.assert_allclose(O.pool_packed(packed, cu, st, None if other is None else other[m.astype(bool)]), g[f"fn_{name}_{st}"],
+                                       atol=1e-6, err_msg=f"{name} {st} (packed)")
     cfg, w, _, _, _, _ = load_model_golden("llama_small_d64")
     ids, _, _, cu, _ = O.pack_padded(g["input_ids"], g["attention_mask"])
     for st in O.POOLING_STRATEGIES:
