@@ -79,8 +79,8 @@ class InferenceArguments:
     use_icu_word_pretokenizer: bool = False             # (*)
     sparse_remove_stopwords: bool = False               # (*)
     sparse_pool_from_unique_token_ids: bool = False     # (*)
-    sparse_pool_from_original_input_ids_qry: bool = False   # (*)
-    sparse_pool_from_original_input_ids_psg: bool = False   # (*)
+    sparse_pool_from_original_input_ids_qry: bool = False   # served: only the sequence's own tokens keep their aggregated logit (modeling_hybrid.py:175-180)
+    sparse_pool_from_original_input_ids_psg: bool = False
     sparse_pooling_strategy: Optional[str] = None
     pad_to_multiple_of: Optional[int] = None
     max_length: int = 1024                              # reranker only
@@ -121,7 +121,6 @@ class InferenceArguments:
         for name, default in (("hybrid_model_architecture", "gpt"), ("untie_encoder", False), ("enable_bidirectional_attention", False),
                               ("use_sparse_linear_projector", False), ("use_sparse_down_projector", False), ("use_icu_word_pretokenizer", False),
                               ("sparse_remove_stopwords", False), ("sparse_pool_from_unique_token_ids", False),
-                              ("sparse_pool_from_original_input_ids_qry", False), ("sparse_pool_from_original_input_ids_psg", False),
                               ("sparse_use_max_aggregation", True)):
             if getattr(self, name) != default:
                 raise NotImplementedError(f"--{name}={getattr(self, name)!r}: not implemented by the MI355X path (one tied gpt-style encoder, "
@@ -201,7 +200,9 @@ class PytorchRPCExactSearchModel(LrxExactSearchModel):
                             noncontextual_query_embedding=args.noncontextual_query_embedding if hybrid else False,
                             pooling_strategy=args.pooling_strategy, hybrid_use_sparse_vector=args.hybrid_use_sparse_vector if hybrid else False,
                             hybrid_use_token_id_vector=args.hybrid_use_token_id_vector if hybrid else False,
-                            sparse_top_k_qry=args.sparse_top_k_qry, sparse_top_p_qry=args.sparse_top_p_qry)
+                            sparse_top_k_qry=args.sparse_top_k_qry, sparse_top_p_qry=args.sparse_top_p_qry,
+                            sparse_pool_from_original_input_ids_qry=args.sparse_pool_from_original_input_ids_qry if hybrid else False,
+                            sparse_pool_from_original_input_ids_psg=args.sparse_pool_from_original_input_ids_psg if hybrid else False)
         super().__init__(model=hm, tokenizer=tok, q_max_len=args.q_max_len, p_max_len=args.p_max_len,
                          append_prompt_sep=args.append_prompt_sep, eval_batch_size_embedding_bag=args.eval_batch_size_embedding_bag,
                          token_id_vector_type=args.token_id_vector_type, noncontextual_prompt_prefix=args.noncontextual_prompt_prefix,

@@ -155,7 +155,8 @@ class LrxHybridModel:
                  sparse_top_k_psg: int = 0, sparse_top_p_psg: float = 1.0, sparse_min_tokens_to_keep: int = 8,
                  sparse_round_bf16: bool = True, hybrid_use_dense_vector: bool = False, hybrid_use_emb_vector: bool = True,
                  noncontextual_query_embedding: bool = True, pooling_strategy: Optional[str] = None, hybrid_use_sparse_vector: bool = False,
-                 sparse_top_k_qry: int = 0, sparse_top_p_qry: float = 1.0, hybrid_use_token_id_vector: Optional[bool] = None):
+                 sparse_top_k_qry: int = 0, sparse_top_p_qry: float = 1.0, hybrid_use_token_id_vector: Optional[bool] = None,
+                 sparse_pool_from_original_input_ids_qry: bool = False, sparse_pool_from_original_input_ids_psg: bool = False):
         """The sparse_* / add_sep_token / sep_token_id / hybrid_use_* / noncontextual_query_embedding fields carry the reference's
         ModelArguments of the same names (finetune/arguments.py:175-290); encode_sparse = hybrid_use_sparse_vector or
         hybrid_use_token_id_vector."""
@@ -176,6 +177,10 @@ class LrxHybridModel:
         self.hybrid_use_token_id_vector = (encode_sparse and not hybrid_use_sparse_vector) if hybrid_use_token_id_vector is None else hybrid_use_token_id_vector
         self.sparse_top_k_qry = sparse_top_k_qry
         self.sparse_top_p_qry = sparse_top_p_qry
+        # `--sparse_pool_from_original_input_ids_qry / _psg` (modeling_hybrid.py:175-180): the aggregated logits keep only the entries of the
+        # sequence's own tokens (sparse attention mask) before relu / log1p / top-k -- a sparse vector without expansion terms
+        self.sparse_pool_from_original_input_ids_qry = bool(sparse_pool_from_original_input_ids_qry)
+        self.sparse_pool_from_original_input_ids_psg = bool(sparse_pool_from_original_input_ids_psg)
         self.hybrid_use_emb_vector = hybrid_use_emb_vector
         self.noncontextual_query_embedding = noncontextual_query_embedding
         self._lm_emb_table: Optional[torch.Tensor] = None   # fp32 copy of embed_tokens, made on first use by the input-embedding bag
@@ -226,11 +231,12 @@ class LrxHybridModel:
         return pack_padded_batch(ids.to(self.device), batch["attention_mask"].to(self.device))
 
     def _encode_passage_sparse(self, psg: dict, normalize: bool, out: Optional[torch.Tensor], top_k: Optional[int] = None,
-                               top_p: Optional[float] = None, want_dense: bool = True):
-        """dense (optional) + sparse vectors of a batch in one pass.  top_k / top_p: the sampling ratios of get_sparse_emb (modeling_hybrid.py:189-200) --
-        the passage ones by default, the *_qry ones when encode_query calls."""
+                               top_p: Optional[float] = None, want_dense: bool = True, pool_from_input_ids: Optional[bool] = None):
+        """dense (optional) + sparse vectors of a batch in one pass.  top_k / top_p / pool_from_input_ids: the sampling ratios and the
+        own-tokens-only switch of get_sparse_emb (modeling_hybrid.py:175-200) -- the passage ones by default, the *_qry ones when encode_query calls."""
         top_k = self.sparse_top_k_psg if top_k is None else top_k
         top_p = self.sparse_top_p_psg if top_p is None else top_p
+        own_only = self.sparse_pool_from_original_input_ids_psg if pool_from_input_ids is None else bool(pool_from_input_ids)
         ids = psg["input_ids"]
         if "cu_seqlens" in psg:
             cu_host, ids_host = psg["cu_seqlens"], ids
@@ -240,11 +246,23 @@ class LrxHybridModel:
         tok_mask = psg.get("sparse_mask")
         if tok_mask is None:       # the collator normally ships it; built here from the host copy of the ids otherwise
             tok_mask = torch.from_numpy(sparse_token_mask(ids_host.cpu().numpy(), cu_host.cpu().numpy(), self.sep_token_id, self.add_sep_token))
+        ids_dev, cu_dev = ids_host.to(self.device, dtype=torch.int32), cu_host.to(self.device, dtype=torch.int32)
+        mask_dev = tok_mask.to(self.device, dtype=torch.uint8).contiguous()
         dense, sparse = self.encoder.encode_packed_sparse(
-            ids_host.to(self.device, dtype=torch.int32), cu_host.to(self.device, dtype=torch.int32), max_len,
-            tok_mask=tok_mask.to(self.device, dtype=torch.uint8).contiguous(), dense_dim=self.dense_shrink_dim, normalize=normalize, want_dense=want_dense,
-            relu=self.sparse_use_relu, log1p=self.sparse_use_log_saturation, round_bf16=self.sparse_round_bf16,
-            top_k=0 if 0 < top_p < 1 else top_k, min_tokens_to_keep=self.sparse_min_tokens_to_keep)
+            ids_dev, cu_dev, max_len, tok_mask=mask_dev, dense_dim=self.dense_shrink_dim, normalize=normalize, want_dense=want_dense,
+            relu=self.sparse_use_relu and not own_only, log1p=self.sparse_use_log_saturation and not own_only, round_bf16=self.sparse_round_bf16,
+            top_k=0 if (0 < top_p < 1 or own_only) else top_k, min_tokens_to_keep=self.sparse_min_tokens_to_keep)
+        if own_only:
+            # get_unique_token_ids + get_scores_with_indices (sparse_pooling.py:147-179) on the raw aggregated logits: every vocabulary entry that is
+            # not one of the sequence's own unmasked tokens becomes 0; relu / log1p (and top-k, unless top-p comes first) follow on the result
+            lens = (cu_dev[1:] - cu_dev[:-1]).long()
+            rows = torch.repeat_interleave(torch.arange(lens.numel(), device=self.device), lens)
+            sel = mask_dev.bool() & (ids_dev >= 0) & (ids_dev < sparse.shape[1])
+            keep = torch.zeros(sparse.shape, dtype=torch.bool, device=self.device)
+            keep[rows[sel], ids_dev[sel].long()] = True
+            sparse.masked_fill_(~keep, 0.0)
+            ops.sparsify_(sparse, relu=self.sparse_use_relu, log1p=self.sparse_use_log_saturation, round_bf16=self.sparse_round_bf16,
+                          top_k=0 if 0 < top_p < 1 else top_k, min_tokens_to_keep=self.sparse_min_tokens_to_keep)
         if 0 < top_p < 1:
             # optional nucleus filter (sparse_pooling.py:64-90), off in the published configuration: plain device tensor ops,
             # then the top-k threshold kernel on its result (the reference's order: top-p before top-k)
@@ -309,7 +327,8 @@ class LrxHybridModel:
             # sampling ratios; the dense vector of the same forward comes out of the same pass (last-token pooling)
             if encode_dense and self.pooling_strategy != "lasttoken":
                 raise NotImplementedError("dense + sparse query vectors in one pass pool the dense vector from the last token only")
-            out.update(self._encode_passage_sparse(qry, bool(normalize), None, top_k=self.sparse_top_k_qry, top_p=self.sparse_top_p_qry, want_dense=encode_dense))
+            out.update(self._encode_passage_sparse(qry, bool(normalize), None, top_k=self.sparse_top_k_qry, top_p=self.sparse_top_p_qry, want_dense=encode_dense,
+                                                   pool_from_input_ids=self.sparse_pool_from_original_input_ids_qry))
             encode_dense = False
         lm_in = self._packed_lm_inputs(qry, "encode_query") if (encode_dense or (encode_emb and not self.noncontextual_query_embedding)) else None
         if encode_dense:

@@ -40,6 +40,8 @@ Parity pin status
   (``gen_pooling_goldens.py`` runs ``finetune/dense_pooling.pooling`` and ``HybridModel.encode_passage / encode_query`` with each strategy).
 * LM-head sparse QUERY vectors (``hybrid_use_sparse_vector``) and their pseudo text: PINNED by ``tests/golden/sparse_query.npz`` /
   ``sparse_query_text.json`` (``gen_sparse_query_goldens.py``: ``HybridModel.encode_query`` and ``convert_sparse_reps_to_pseudo_text_pt``).
+* Sparse vectors restricted to the sequence's own tokens (``sparse_pool_from_original_input_ids_qry / _psg``): PINNED by
+  ``tests/golden/sparse_pool_ids.npz`` (``gen_sparse_pool_ids_goldens.py``: ``encode_passage`` / ``encode_query`` with the flags on).
 
 * Hit-list fusion (row N3: RRF, min-max linear): PINNED by ``tests/golden/fusion.json`` (``gen_fusion_goldens.py`` runs
   ``retriever/score_fuse_utils.py``), exact float64 equality.
@@ -729,18 +731,33 @@ def sparse_reps_to_pseudo_text(reps: np.ndarray, quantization_factor: int = 100,
     return [" ".join(tok for tok, freq in d.items() for _ in range(freq)) for d in sparse_reps_to_json(reps, quantization_factor, vocab)]
 
 
+def keep_input_token_scores(agg: np.ndarray, ids: np.ndarray, cu_seqlens: np.ndarray, tok_mask: np.ndarray, filter_value: float = 0.0) -> np.ndarray:
+    """`--sparse_pool_from_original_input_ids_qry / _psg` (modeling_hybrid.py:175-180): get_unique_token_ids over the sequence's tokens under the
+    sparse attention mask (sparse_pooling.py:147-156), then get_scores_with_indices (:158-179) -- every vocabulary entry that is not one of the
+    sequence's own (unmasked) tokens becomes filter_value BEFORE relu / log1p / top-p / top-k: a sparse vector without expansion terms."""
+    out = np.full_like(agg, np.float32(filter_value), dtype=np.float32)
+    for b in range(len(cu_seqlens) - 1):
+        s, e = int(cu_seqlens[b]), int(cu_seqlens[b + 1])
+        own = np.unique(np.asarray(ids[s:e])[np.asarray(tok_mask[s:e]).astype(bool)])
+        out[b, own] = agg[b, own]
+    return out
+
+
 def encode_query_sparse(cfg: EncoderConfig, w, ids, cu_seqlens, tok_mask, lm_head: Optional[np.ndarray] = None, bf16: bool = True, **sparsify_kw):
     """HybridModel.encode_query's sparse branch (modeling_hybrid.py:404-438): the passage pipeline on the query's tokens; get_sparse_emb(is_query=True)
     differs only in WHICH top-p / top-k ratios apply (sparse_top_p_qry / sparse_top_k_qry, :189-200) -- pass them as top_p / top_k."""
     return encode_passage_sparse(cfg, w, ids, cu_seqlens, tok_mask, lm_head=lm_head, bf16=bf16, **sparsify_kw)
 
 
-def encode_passage_sparse(cfg: EncoderConfig, w, ids, cu_seqlens, tok_mask, lm_head: Optional[np.ndarray] = None, bf16: bool = True, **sparsify_kw):
+def encode_passage_sparse(cfg: EncoderConfig, w, ids, cu_seqlens, tok_mask, lm_head: Optional[np.ndarray] = None, bf16: bool = True,
+                          pool_from_input_ids: bool = False, **sparsify_kw):
     """HybridModel.encode_passage's sparse branch (modeling_hybrid.py:280-323) on packed input: LM forward -> final-norm hidden
-    states -> max aggregation with the (tied unless given) LM head -> sparsify."""
+    states -> max aggregation with the (tied unless given) LM head -> (pool_from_input_ids: only the sequence's own tokens, :175-180) -> sparsify."""
     hidden = encoder_forward_packed(cfg, w, ids, cu_seqlens, bf16=bf16)
     W = lm_head if lm_head is not None else w["embed_tokens.weight"]
     agg = max_aggregate_packed(hidden, cu_seqlens, tok_mask, W, None, bf16=bf16)
+    if pool_from_input_ids:
+        agg = keep_input_token_scores(agg, ids, cu_seqlens, tok_mask)
     return sparsify(agg, bf16=bf16, **sparsify_kw)
 
 

@@ -528,6 +528,9 @@ def test_inference_arguments_accept_the_reference_cli_and_refuse_unimplemented_m
     assert parse("--hybrid_use_emb_vector", "--fp16").dtype == torch.float16
     with pytest.raises(ValueError):
         parse("--hybrid_use_emb_vector", "--fp16", "--bf16")
+    # round 6: sparse vectors restricted to the sequence's own tokens (modeling_hybrid.py:175-180) are served, each side by its own flag
+    po = parse("--hybrid_use_sparse_vector", "--sparse_pool_from_original_input_ids_qry")
+    assert po.sparse_pool_from_original_input_ids_qry and not po.sparse_pool_from_original_input_ids_psg
     # round 6: every vector-returning pooling strategy of finetune/dense_pooling.py:12-82 is served
     for st in ("cls", "mean", "second_to_last", "third_to_last", "avg_first_last", "avg_top2"):
         assert parse("--hybrid_use_dense_vector", "--pooling_strategy", st).pooling_strategy == st

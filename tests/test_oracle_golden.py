@@ -383,3 +383,29 @@ def test_sparse_query_vectors_match_the_reference():
     assert O.sparse_reps_to_pseudo_text(g["sparse_reps_top8_qry"], 100) == txt["quant100_top8"]
     assert O.sparse_reps_to_pseudo_text(np.array([[0.5 / 7, 1.5 / 7, 2.5 / 7, -3.0, 0.0, 0.07], [0.0] * 6], np.float32), 7) == txt["quant7_halves"]
     assert txt["quant7_halves"][1] == "-1"
+
+
+def test_sparse_vectors_pooled_from_the_input_ids_match_the_reference():
+    """`--sparse_pool_from_original_input_ids_psg / _qry` (finetune/modeling_hybrid.py:175-180; gen_sparse_pool_ids_goldens.py ran the reference's
+    encode_passage / encode_query with the flags on): only the sequence's own tokens under the sparse attention mask keep their aggregated logit."""
+    g = np.load(os.path.join(GOLDEN, "sparse_pool_ids.npz"))
+    sp = _sparse_golden()
+    cfg, w, _, _, _, _ = load_model_golden("llama_small_d64")
+    ids, _, _, cu, _ = O.pack_padded(g["input_ids"], g["attention_mask"])
+    tm = sp["mask_noprompt"][g["attention_mask"].astype(bool)]
+    got = O.encode_passage_sparse(cfg, w, ids, cu, tm, bf16=False, relu=True, log1p=True, pool_from_input_ids=True)
+    np.testing.assert_allclose(got, g["psg"], atol=2e-5)
+    np.testing.assert_array_equal(got > 0, g["psg"] > 0)
+    np.testing.assert_array_equal(g["qry"], g["psg"])
+    # on the reference's own aggregated logits: bit-level agreement of the masking + sampling
+    kept = O.keep_input_token_scores(sp["agg_noprompt"], ids, cu, tm)
+    np.testing.assert_allclose(O.sparsify(kept, relu=True, log1p=True), g["psg"], atol=1e-6)
+    top4 = O.sparsify(kept, relu=True, log1p=True, top_k=4, min_tokens_to_keep=2)
+    np.testing.assert_allclose(top4, g["psg_top4"], atol=1e-6)
+    np.testing.assert_array_equal(g["qry_top4"], g["psg_top4"])
+    # the vector has no expansion terms: every non-zero entry is one of the row's own unmasked tokens
+    for b in range(len(cu) - 1):
+        own = set(ids[cu[b]:cu[b + 1]][tm[cu[b]:cu[b + 1]].astype(bool)].tolist())
+        assert set(np.nonzero(g["psg"][b])[0].tolist()) <= own
+    assert (g["psg"] > 0).sum() < (sp["sparse_reps"] > 0).sum() / 10
+
