@@ -53,10 +53,13 @@ constexpr int attn_dma_waves(int insts, int nw) {   // largest divisor of insts 
   return d;
 }
 
+// the 16-bit output element: bf16, or (out_f16, the precise stream's fp16 GEMM operands) fp16 -- |o| <= max |v| <= 65504: no saturation to count
+__device__ __forceinline__ __bf16 o16(float v, int out_f16) { return out_f16 ? __builtin_bit_cast(__bf16, (_Float16)v) : f2bf(v); }
+
 template <int D, int GRP>
 __global__ void __launch_bounds__(128 * GRP)
 k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu, int nqt, int nq, int nkv,
-                     __bf16* __restrict__ out, float scale_log2, int last_tile_only, int nparts, int n_seqs, int n_items, int gs) {
+                     __bf16* __restrict__ out, float scale_log2, int last_tile_only, int nparts, int n_seqs, int n_items, int gs, int out_f16) {
   using G = AttnGeom<D>;
   constexpr int NW = 2 * GRP;
   constexpr int KS = D / 16;  // k-steps of the QK^T product
@@ -385,7 +388,7 @@ k_attn_varlen_causal(const __bf16* __restrict__ qkv, const int32_t* __restrict__
       for (int g4_ = 0; g4_ < 4; ++g4_) {
         bf16x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g4_ + e] * inv);
+        for (int e = 0; e < 4; ++e) v[e] = o16(o[dt][4 * g4_ + e] * inv, out_f16);
         *(bf16x4*)(sW + r * G::ROW_BYTES + ((((dt * 4 + g4_) ^ (r & (G::CH - 1))) << 4) | (h << 3))) = v;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // same wave wrote, same wave reads: no barrier
@@ -516,7 +519,7 @@ k_attn_build_items(const int32_t* __restrict__ cu, int32_t* __restrict__ list_st
 template <int D, int GRP>
 __global__ void __launch_bounds__(128 * GRP)
 k_attn_stream(const __bf16* __restrict__ qkv, const int32_t* __restrict__ list_start, const i32x4* __restrict__ items, int nq, int nkv,
-              __bf16* __restrict__ out, float scale_log2) {
+              __bf16* __restrict__ out, float scale_log2, int out_f16) {
   using G = AttnGeom<D>;
   constexpr int NW = 2 * GRP;
   constexpr int KS = D / 16, DT = D / 32;
@@ -816,7 +819,7 @@ k_attn_stream(const __bf16* __restrict__ qkv, const int32_t* __restrict__ list_s
       for (int g4_ = 0; g4_ < 4; ++g4_) {
         bf16x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g4_ + e] * inv);
+        for (int e = 0; e < 4; ++e) v[e] = o16(o[dt][4 * g4_ + e] * inv, out_f16);
         *(bf16x4*)(sW + r_ * G::ROW_BYTES + ((((dt * 4 + g4_) ^ (r_ & (G::CH - 1))) << 4) | (h_ << 3))) = v;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -853,7 +856,7 @@ k_attn_stream(const __bf16* __restrict__ qkv, const int32_t* __restrict__ list_s
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
 k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu, int nq, int nkv, __bf16* __restrict__ out,
-                  float scale_log2, int n_pairs) {
+                  float scale_log2, int n_pairs, int out_f16) {
   constexpr int D = 64;
   using G = AttnGeom<D>;
   constexpr int KS = D / 16, DT = D / 32;
@@ -1079,8 +1082,8 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           union { bf16x2 v; uint32_t u; } cv;
-          cv.v[0] = f2bf(o[dt][4 * g4 + 2 * e] * inv);
-          cv.v[1] = f2bf(o[dt][4 * g4 + 2 * e + 1] * inv);
+          cv.v[0] = o16(o[dt][4 * g4 + 2 * e] * inv, out_f16);
+          cv.v[1] = o16(o[dt][4 * g4 + 2 * e + 1] * inv, out_f16);
           pk[dt][g4][e] = cv.u;
         }
     static_assert(DT == 2, "the lane-pair exchange below assumes two 32-wide d tiles");
@@ -1114,7 +1117,7 @@ k_attn_resident64(const __bf16* __restrict__ qkv, const int32_t* __restrict__ cu
 template <int D>
 __global__ void __launch_bounds__(512)
 k_attn_prefix(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_kv, int n_seqs, int S2, int P1, int nq, int nkv,
-              __bf16* __restrict__ out, float scale) {
+              __bf16* __restrict__ out, float scale, int out_f16) {
   constexpr int E = D / 64;   // output elements per lane
   constexpr int JB = 4;       // queries handled per pass (they share the K/V reads)
   __shared__ float q_lds[8][JB][D];
@@ -1202,7 +1205,7 @@ k_attn_prefix(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_
         const float inv = 1.0f / l[jj];
 #pragma unroll
         for (int e = 0; e < E; ++e)
-          out[((int64_t)seq * S2 + j0 + jj) * ((int64_t)nq * D) + (int64_t)hq * D + lane * E + e] = f2bf(o[jj][e] * inv);
+          out[((int64_t)seq * S2 + j0 + jj) * ((int64_t)nq * D) + (int64_t)hq * D + lane * E + e] = o16(o[jj][e] * inv, out_f16);
       }
     }
   }
@@ -1218,7 +1221,7 @@ k_attn_prefix(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_
 template <int D>
 __global__ void __launch_bounds__(D == 64 ? 1024 : 768)     // d = 128 needs ~150 VGPRs: at most 12 waves per workgroup
 k_attn_prefix_mfma(const __bf16* __restrict__ qkv, const __bf16* __restrict__ prefix_kv, int n_seqs, int S2, int P1, int nq, int nkv,
-                   __bf16* __restrict__ out, float scale_log2) {
+                   __bf16* __restrict__ out, float scale_log2, int out_f16) {
   using G = AttnGeom<D>;
   constexpr int KS = D / 16, DT = D / 32;
   constexpr int MAXP = 64;                          // prefix keys held in LDS (two 32-key MFMA tiles)
@@ -1385,7 +1388,7 @@ k_attn_prefix_mfma(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pr
       for (int g = 0; g < 4; ++g) {
         bf16x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][4 * g + e] * inv);
+        for (int e = 0; e < 4; ++e) v[e] = o16(o[dt][4 * g + e] * inv, out_f16);
         *(bf16x4*)(op + dt * 32 + 8 * g) = v;
       }
   }
@@ -1393,6 +1396,11 @@ k_attn_prefix_mfma(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pr
 
 extern "C" int lrx_attn_prefix_suffix(const void* qkv, const void* prefix_kv, int32_t n_seqs, int32_t suffix_len, int32_t prefix_len,
                                       int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out, void* stream) {
+  return lrx_attn_prefix_suffix_ex(qkv, prefix_kv, n_seqs, suffix_len, prefix_len, num_q_heads, num_kv_heads, head_dim, out, 0, stream);
+}
+// (out_f16 != 0: the output rows are written as fp16 -- the O-projection's operand under lrx_encoder_config.precise_stream = 2)
+int lrx_attn_prefix_suffix_ex(const void* qkv, const void* prefix_kv, int32_t n_seqs, int32_t suffix_len, int32_t prefix_len, int32_t num_q_heads,
+                              int32_t num_kv_heads, int32_t head_dim, void* out, int out_f16, void* stream) {
   LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "attn_prefix: head_dim=%d unsupported", head_dim);
   LRX_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0 && num_q_heads / num_kv_heads <= 8, "attn_prefix: bad head counts");
   LRX_CHECK_ARG(suffix_len > 0 && prefix_len >= 0, "attn_prefix: bad lengths");
@@ -1404,20 +1412,20 @@ extern "C" int lrx_attn_prefix_suffix(const void* qkv, const void* prefix_kv, in
     const float sl2 = scale * 1.4426950408889634f;
     if (head_dim == 64)
       hipLaunchKernelGGL(k_attn_prefix_mfma<64>, g, b, 0, (hipStream_t)stream, (const __bf16*)qkv, (const __bf16*)prefix_kv, n_seqs, suffix_len,
-                         prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, sl2);
+                         prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, sl2, out_f16);
     else
       hipLaunchKernelGGL(k_attn_prefix_mfma<128>, g, b, 0, (hipStream_t)stream, (const __bf16*)qkv, (const __bf16*)prefix_kv, n_seqs, suffix_len,
-                         prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, sl2);
+                         prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, sl2, out_f16);
     LRX_LAUNCH_CHECK();
     return LRX_OK;
   }
   dim3 grid(n_seqs, num_kv_heads), block(64 * (num_q_heads / num_kv_heads));
   if (head_dim == 64)
     hipLaunchKernelGGL(k_attn_prefix<64>, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (const __bf16*)prefix_kv, n_seqs, suffix_len,
-                       prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, scale);
+                       prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, scale, out_f16);
   else
     hipLaunchKernelGGL(k_attn_prefix<128>, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (const __bf16*)prefix_kv, n_seqs, suffix_len,
-                       prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, scale);
+                       prefix_len, num_q_heads, num_kv_heads, (__bf16*)out, scale, out_f16);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -1435,7 +1443,7 @@ static int attn_cu_count() {
 
 template <int D, int GRP>
 static int launch_attn(const void* qkv, const int32_t* cu, int n_seqs, int max_seqlen, int nq, int nkv, void* out, int last_tile_only,
-                       hipStream_t s, int nparts = 1) {
+                       hipStream_t s, int nparts, int out_f16) {
   int nqt = (int)lrx_cdiv(max_seqlen, 64);
   float scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
   const int64_t n_items = (int64_t)(last_tile_only ? n_seqs : n_seqs * nqt) * nkv * nparts;
@@ -1454,7 +1462,7 @@ static int launch_attn(const void* qkv, const int32_t* cu, int n_seqs, int max_s
     while (gs * 2 <= nqt && gs * 2 <= spx && spx % (gs * 2) == 0) gs *= 2;
   }
   hipLaunchKernelGGL((k_attn_varlen_causal<D, GRP>), dim3((unsigned)(n_items < slots ? n_items : slots)), dim3(128 * GRP), 0, s,
-                     (const __bf16*)qkv, cu, nqt, nq, nkv, (__bf16*)out, scale_log2, last_tile_only, nparts, n_seqs, (int)n_items, gs);
+                     (const __bf16*)qkv, cu, nqt, nq, nkv, (__bf16*)out, scale_log2, last_tile_only, nparts, n_seqs, (int)n_items, gs, out_f16);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -1547,25 +1555,32 @@ static bool attn_uses_resident64(int head_dim, int max_seqlen, int last_tile_onl
   static const int force_tiled = lrx_dev_knob("LRX_ATTN_TILED", 0);
   return !force_tiled && head_dim == 64 && max_seqlen <= 512 && !last_tile_only;
 }
-static int launch_resident64(const void* qkv, const int32_t* cu_seqlens, int n_seqs, int num_q_heads, int num_kv_heads, void* out, hipStream_t s) {
+static int launch_resident64(const void* qkv, const int32_t* cu_seqlens, int n_seqs, int num_q_heads, int num_kv_heads, void* out, hipStream_t s, int out_f16 = 0) {
   const float scale_log2 = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
   const int n_cu64 = attn_cu_count();
   const int n_pairs = n_seqs * num_kv_heads;
   dim3 grid(n_pairs < n_cu64 ? n_pairs : n_cu64), block(1024);
-  hipLaunchKernelGGL(k_attn_resident64, grid, block, 0, s, (const __bf16*)qkv, cu_seqlens, num_q_heads, num_kv_heads, (__bf16*)out, scale_log2, n_pairs);
+  hipLaunchKernelGGL(k_attn_resident64, grid, block, 0, s, (const __bf16*)qkv, cu_seqlens, num_q_heads, num_kv_heads, (__bf16*)out, scale_log2, n_pairs, out_f16);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
 extern "C" int lrx_attn_varlen_causal_items(const void* qkv, const int32_t* cu_seqlens, const void* items, size_t items_bytes, int32_t n_seqs,
                                             int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
                                             void* out, int32_t last_tile_only, void* stream) {
+  return lrx_attn_varlen_causal_items_ex(qkv, cu_seqlens, items, items_bytes, n_seqs, total_tokens, max_seqlen, num_q_heads, num_kv_heads, head_dim, out,
+                                         last_tile_only, 0, stream);
+}
+// (out_f16 != 0: the output rows are written as fp16 -- the O-projection's operand under lrx_encoder_config.precise_stream = 2)
+int lrx_attn_varlen_causal_items_ex(const void* qkv, const int32_t* cu_seqlens, const void* items, size_t items_bytes, int32_t n_seqs, int32_t total_tokens,
+                                    int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out, int32_t last_tile_only,
+                                    int out_f16, void* stream) {
   int rc = attn_check_layout(num_q_heads, num_kv_heads, head_dim);
   if (rc) return rc;
   LRX_CHECK_ARG(max_seqlen > 0 || total_tokens == 0, "attn: max_seqlen must be > 0");
   if (total_tokens == 0 || n_seqs == 0) return LRX_OK;
   const int nq = num_q_heads, nkv = num_kv_heads;
   hipStream_t s = (hipStream_t)stream;
-  if (attn_uses_resident64(head_dim, max_seqlen, last_tile_only)) return launch_resident64(qkv, cu_seqlens, n_seqs, nq, nkv, out, s);
+  if (attn_uses_resident64(head_dim, max_seqlen, last_tile_only)) return launch_resident64(qkv, cu_seqlens, n_seqs, nq, nkv, out, s, out_f16);
   const AttnPlan p = attn_plan(n_seqs, max_seqlen, nq, nkv, head_dim, last_tile_only);
   const size_t need = attn_list_hdr_bytes(p) + 16 * (size_t)attn_list_item_bound(p, n_seqs, total_tokens, nkv, last_tile_only);
   LRX_CHECK_ARG(items != nullptr && items_bytes >= need, "attn: work list %zu B < required %zu B", items_bytes, need);
@@ -1575,7 +1590,7 @@ extern "C" int lrx_attn_varlen_causal_items(const void* qkv, const int32_t* cu_s
   const float scale_log2 = (1.0f / sqrtf((float)head_dim)) * 1.4426950408889634f;
 #define LRX_STREAM_CASE(DD, GG)                                                                                                                       \
   case GG: hipLaunchKernelGGL((k_attn_stream<DD, GG>), dim3((unsigned)p.n_wg), dim3(128 * GG), 0, s, (const __bf16*)qkv, (const int32_t*)items, \
-                              (const i32x4*)((const char*)items + attn_list_hdr_bytes(p)), nq, nkv, (__bf16*)out, scale_log2); break;
+                              (const i32x4*)((const char*)items + attn_list_hdr_bytes(p)), nq, nkv, (__bf16*)out, scale_log2, out_f16); break;
   if (head_dim == 64) {
     switch (p.grp) {
       LRX_STREAM_CASE(64, 1) LRX_STREAM_CASE(64, 2) LRX_STREAM_CASE(64, 3) LRX_STREAM_CASE(64, 4)
@@ -1592,20 +1607,24 @@ extern "C" int lrx_attn_varlen_causal_items(const void* qkv, const int32_t* cu_s
 extern "C" int lrx_attn_varlen_causal(const void* qkv, const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens,
                                       int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out,
                                       int32_t last_tile_only, void* stream) {
+  return lrx_attn_varlen_causal_ex(qkv, cu_seqlens, n_seqs, total_tokens, max_seqlen, num_q_heads, num_kv_heads, head_dim, out, last_tile_only, 0, stream);
+}
+int lrx_attn_varlen_causal_ex(const void* qkv, const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads,
+                              int32_t num_kv_heads, int32_t head_dim, void* out, int32_t last_tile_only, int out_f16, void* stream) {
   int rc = attn_check_layout(num_q_heads, num_kv_heads, head_dim);
   if (rc) return rc;
   LRX_CHECK_ARG(max_seqlen > 0 || total_tokens == 0, "attn: max_seqlen must be > 0");
   if (total_tokens == 0 || n_seqs == 0) return LRX_OK;
   int grp = num_q_heads / num_kv_heads;
   hipStream_t s = (hipStream_t)stream;
-  if (attn_uses_resident64(head_dim, max_seqlen, last_tile_only)) return launch_resident64(qkv, cu_seqlens, n_seqs, num_q_heads, num_kv_heads, out, s);
+  if (attn_uses_resident64(head_dim, max_seqlen, last_tile_only)) return launch_resident64(qkv, cu_seqlens, n_seqs, num_q_heads, num_kv_heads, out, s, out_f16);
   // No work list: the walker kernel (k_attn_varlen_causal) derives every item's (sequence, kv head, q tile) itself -- the variant for
   // callers without scratch memory; lrx_attn_varlen_causal_items is the faster launch.
   // Tiled kernel: GRP q heads per workgroup, nparts workgroups per kv head (heads beyond the group idle).  head_dim 64 takes up to 8
   // heads per workgroup; head_dim 128 needs ~190 VGPRs per wave, so at most 4 (more than 8 waves per workgroup would spill): groups
   // of 5-6 heads run as two workgroups of 3, 7-8 as two of 4 (the K/V tiles are staged twice, from L2), larger groups as ceil(grp/4).
 #define LRX_ATTN_CASE(DD, GG, PARTS) \
-  return launch_attn<DD, GG>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s, PARTS);
+  return launch_attn<DD, GG>(qkv, cu_seqlens, n_seqs, max_seqlen, num_q_heads, num_kv_heads, out, last_tile_only, s, PARTS, out_f16);
   if (head_dim == 64) {
     switch (grp) {
       case 1: LRX_ATTN_CASE(64, 1, 1)

@@ -159,6 +159,7 @@ static int check_cfg(const lrx_encoder_config* c) {
   LRX_CHECK_ARG(c->head_dim == 64 || c->head_dim == 128, "encode: head_dim=%d unsupported", c->head_dim);
   LRX_CHECK_ARG(c->num_kv_heads > 0 && c->num_q_heads % c->num_kv_heads == 0, "encode: bad head counts %d/%d", c->num_q_heads, c->num_kv_heads);
   LRX_CHECK_ARG(c->num_layers > 0 && c->vocab_size > 0 && c->max_positions > 0, "encode: bad config");
+  LRX_CHECK_ARG(c->precise_stream >= 0 && c->precise_stream <= 2, "encode: precise_stream=%d (0: bf16 stream, 1: fp32 stream, 2: fp32 stream + fp16 GEMM operands)", c->precise_stream);
   LRX_CHECK_ARG(!(c->precise_stream && c->norm_folded), "encode: precise_stream keeps the norm weight on the activation operand -- pass the unfolded weights (norm_folded = 0)");
   return LRX_OK;
 }
@@ -189,10 +190,11 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
   const int H = c->hidden_size, d = c->head_dim, nq = c->num_q_heads, nkv = c->num_kv_heads, I = c->intermediate_size;
   const int QKV = (nq + 2 * nkv) * d, QD = nq * d;
   const bool fold = c->norm_folded != 0, precise = c->precise_stream != 0;
+  const int f16 = c->precise_stream == 2 ? 1 : 0;      // fp16 GEMM operands (activations, attention / SwiGLU outputs, the four projection weights)
   const bool scaled = fold || precise;                 // the consumer GEMM multiplies its accumulator rows by rsqrt(mean(x^2) + eps)
   const int NP = (H + 255) / 256;                      // n-tiles of a residual GEMM (N = H)
   int rc;
-  if (precise) { ProfScope p(s, 6, 0); if ((rc = lrx_embed_stream32(w->embed, ids, T, H, c->vocab_size, w->layers[0].ln1, ws.x32, ws.x, ws.rsA, c->rms_eps, s))) return rc; }
+  if (precise) { ProfScope p(s, 6, 0); if ((rc = lrx_embed_stream32_ex(w->embed, ids, T, H, c->vocab_size, w->layers[0].ln1, ws.x32, ws.x, ws.rsA, c->rms_eps, f16, s))) return rc; }
   else {
     { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, ids, T, H, c->vocab_size, ws.x, s))) return rc; }
     if (fold) { ProfScope p(s, 4, 0); if ((rc = lrx_row_rscale(ws.x, T, H, c->rms_eps, ws.rsA, s))) return rc; }
@@ -200,7 +202,7 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
   // residual GEMM: stream += A . W^T over `rows` rows (+ what the next consumer needs: the bf16 operand in precise mode, the sum of squares)
   auto resid = [&](const void* A, const void* W, char* xb, float* x32, const void* gamma_next, bool want_next, int rows, int N, int K) -> int {
     ProfScope p(s, 1, 2.0 * rows * (double)N * K);
-    if (precise) return lrx_gemm_bf16_nt_resid32(A, W, x32, want_next ? xb : nullptr, want_next ? gamma_next : nullptr, rows, N, K, want_next ? ws.ssp : nullptr, s);
+    if (precise) return lrx_gemm_nt_resid32_ex(A, W, x32, want_next ? xb : nullptr, want_next ? gamma_next : nullptr, rows, N, K, want_next ? ws.ssp : nullptr, f16, s);
     return lrx_gemm_bf16_nt_fused(A, W, xb, nullptr, xb, rows, N, K, 1, nullptr, (fold && want_next) ? ws.ssp : nullptr, s);
   };
   for (int l = 0; l < c->num_layers; ++l) {
@@ -218,18 +220,18 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
       // (the previous layer's -- hence num_layers > 1: a one-layer model would leave uninitialised memory there), per-row independent, never read out.
       const int B = n_tail;
       { ProfScope p(s, 0, 2.0 * T * (double)(2 * nkv * d) * H + 2.0 * B * (double)QD * H);
-        if ((rc = lrx_gemm_qkv_rope_slice(Aqkv, L.wqkv, ws.qkv, bq, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, scaled ? ws.rsA : nullptr, nq, 2 * nkv, s))) return rc;
+        if ((rc = lrx_gemm_qkv_rope_slice_ex(Aqkv, L.wqkv, ws.qkv, bq, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, scaled ? ws.rsA : nullptr, nq, 2 * nkv, f16, s))) return rc;
         if ((rc = lrx_gather_last_rows(Aqkv, tail_cu, B, H, ws.hr, s))) return rc;
         if ((rc = lrx_gather_rows_u32(ws.pos, tail_cu, B, ws.posr, s))) return rc;
         if (scaled && (rc = lrx_gather_rows_u32(ws.rsA, tail_cu, B, ws.rsr, s))) return rc;
         // (num_kv_heads = 0 in this call: C = ws.ar is [B, QD] with row stride QD -- the q heads are the whole row; ws.ar holds B x max(H, QD)
         // elements, carve())
-        if ((rc = lrx_gemm_qkv_rope_slice(ws.hr, L.wqkv, ws.ar, bq, ws.posr, w->rope_cos, w->rope_sin, B, H, nq, 0, d, scaled ? ws.rsr : nullptr, 0, nq, s))) return rc;
+        if ((rc = lrx_gemm_qkv_rope_slice_ex(ws.hr, L.wqkv, ws.ar, bq, ws.posr, w->rope_cos, w->rope_sin, B, H, nq, 0, d, scaled ? ws.rsr : nullptr, 0, nq, f16, s))) return rc;
         if ((rc = lrx_scatter_last_rows(ws.ar, tail_cu, B, QD, ws.qkv, QKV, s))) return rc; }
     } else
     { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);   // QKV projection with (row scale,) bias + RoPE fused into the epilogue
-      if ((rc = lrx_gemm_qkv_rope_fused(Aqkv, L.wqkv, ws.qkv, bq, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d,
-                                        scaled ? ws.rsA : nullptr, s))) return rc; }
+      if ((rc = lrx_gemm_qkv_rope_slice_ex(Aqkv, L.wqkv, ws.qkv, bq, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d,
+                                           scaled ? ws.rsA : nullptr, 0, nq + 2 * nkv, f16, s))) return rc; }
     if (hk.after_qkv) { rc = hk.after_qkv(hk.ctx, l, s); if (rc == 1) break; if (rc) return rc; }
     if (tail_cu != nullptr && last) {
       const int B = n_tail;
@@ -242,7 +244,7 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
       if (scaled) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, B, H, c->rms_eps, ws.rsB, s))) return rc; }
       else { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.xr, L.ln2, ws.hr, B, H, c->rms_eps, s))) return rc; }
       { ProfScope p(s, 2, 2.0 * B * (double)(2 * I) * H);
-        if ((rc = lrx_gemm_bf16_nt_fused(scaled ? ws.xr : ws.hr, L.wgu, ws.actr, nullptr, nullptr, B, 2 * I, H, 2, scaled ? ws.rsB : nullptr, nullptr, s))) return rc; }
+        if ((rc = lrx_gemm_nt_fused_ex(scaled ? ws.xr : ws.hr, L.wgu, ws.actr, nullptr, nullptr, B, 2 * I, H, 2, scaled ? ws.rsB : nullptr, nullptr, f16, s))) return rc; }
       if ((rc = resid(ws.actr, L.wdown, ws.xr, ws.xr32, nullptr, false, B, H, I))) return rc;
       break;
     }
@@ -251,7 +253,7 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
     if (scaled) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, T, H, c->rms_eps, ws.rsB, s))) return rc; }
     else { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, T, H, c->rms_eps, s))) return rc; }
     { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H);
-      if ((rc = lrx_gemm_bf16_nt_fused(scaled ? ws.x : ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, scaled ? ws.rsB : nullptr, nullptr, s))) return rc; }
+      if ((rc = lrx_gemm_nt_fused_ex(scaled ? ws.x : ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, scaled ? ws.rsB : nullptr, nullptr, f16, s))) return rc; }
     if ((rc = resid(ws.act, L.wdown, ws.x, ws.x32, last ? nullptr : w->layers[l + 1].ln1, !last, T, H, I))) return rc;
     if (scaled && !last) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, T, H, c->rms_eps, ws.rsA, s))) return rc; }
   }
@@ -270,9 +272,9 @@ static int batch_before_layer(void* ctx, int l, hipStream_t s) {
 }
 static int batch_attn(void* ctx, int, bool last_tile, hipStream_t s) {
   const BatchAttn& a = *(const BatchAttn*)ctx;
-  return lrx_attn_varlen_causal_items(a.ws->qkv, a.cu, last_tile ? a.ws->attn_items_tail : a.ws->attn_items,
-                                      last_tile ? a.ws->attn_items_tail_bytes : a.ws->attn_items_bytes, a.n_seqs, a.T, a.max_seqlen, a.c->num_q_heads,
-                                      a.c->num_kv_heads, a.c->head_dim, a.ws->h, last_tile ? 1 : 0, s);
+  return lrx_attn_varlen_causal_items_ex(a.ws->qkv, a.cu, last_tile ? a.ws->attn_items_tail : a.ws->attn_items,
+                                         last_tile ? a.ws->attn_items_tail_bytes : a.ws->attn_items_bytes, a.n_seqs, a.T, a.max_seqlen, a.c->num_q_heads,
+                                         a.c->num_kv_heads, a.c->head_dim, a.ws->h, last_tile ? 1 : 0, a.c->precise_stream == 2, s);
 }
 static int forward_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w, const int32_t* ids, const int32_t* cu, int n_seqs,
                           int T, int max_seqlen, EncWs& ws, bool pooled_tail, hipStream_t s, bool sum_before_last = false) {
@@ -446,13 +448,13 @@ static int prefix_capture(void* ctx, int l, hipStream_t s) {          // K|V (po
 }
 static int prefix_attn(void* ctx, int, bool, hipStream_t s) {
   const PrefCtx& a = *(const PrefCtx*)ctx;
-  return lrx_attn_varlen_causal(a.pw->e.qkv, a.pw->cu, 1, a.P1, a.P1, a.c->num_q_heads, a.c->num_kv_heads, a.c->head_dim, a.pw->e.h, 0, s);
+  return lrx_attn_varlen_causal_ex(a.pw->e.qkv, a.pw->cu, 1, a.P1, a.P1, a.c->num_q_heads, a.c->num_kv_heads, a.c->head_dim, a.pw->e.h, 0, a.c->precise_stream == 2, s);
 }
 static int suffix_attn(void* ctx, int l, bool, hipStream_t s) {
   const PrefCtx& a = *(const PrefCtx*)ctx;
   const size_t KVW = (size_t)2 * a.c->num_kv_heads * a.c->head_dim;
-  return lrx_attn_prefix_suffix(a.pw->e.qkv, a.pw->kvcap + (size_t)l * a.P1 * KVW * 2, a.n_seqs, a.S2, a.P1, a.c->num_q_heads, a.c->num_kv_heads, a.c->head_dim,
-                                a.pw->e.h, s);
+  return lrx_attn_prefix_suffix_ex(a.pw->e.qkv, a.pw->kvcap + (size_t)l * a.P1 * KVW * 2, a.n_seqs, a.S2, a.P1, a.c->num_q_heads, a.c->num_kv_heads, a.c->head_dim,
+                                   a.pw->e.h, a.c->precise_stream == 2, s);
 }
 
 extern "C" int lrx_encode_prefixed(const lrx_encoder_config* cfg, const lrx_encoder_weights* w, const int32_t* prefix_ids, int32_t prefix_len,

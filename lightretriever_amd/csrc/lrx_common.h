@@ -104,6 +104,23 @@ int lrx_gemm_max_aggregate_launch(const void* A, const void* B, const void* bias
                                   int K, hipStream_t stream);
 
 // lrx_elementwise.hip: dst[b] = src[cu_seqlens[b + 1] - 1] for 4-byte elements (positions, row scales of the last-token rows)
+// fp16-operand forms of the encoder GEMMs (lrx_gemm.hip; lrx_encoder_config.precise_stream = 2).  The exported entry points are these with f16 = 0.
+int lrx_gemm_nt_fused_ex(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                         const float* rscale, float* ss_part, int f16, void* stream);
+int lrx_gemm_qkv_rope_slice_ex(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos, const float* sin,
+                               int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, const float* rscale, int32_t head0,
+                               int32_t n_heads, int f16, void* stream);
+int lrx_gemm_nt_resid32_ex(const void* A, const void* B, float* x32, void* a16_out, const void* gamma, int32_t M, int32_t N, int32_t K, float* ss_part,
+                           int f16, void* stream);
+int lrx_attn_varlen_causal_items_ex(const void* qkv, const int32_t* cu_seqlens, const void* items, size_t items_bytes, int32_t n_seqs, int32_t total_tokens,
+                                    int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out, int32_t last_tile_only,
+                                    int out_f16, void* stream);
+int lrx_attn_varlen_causal_ex(const void* qkv, const int32_t* cu_seqlens, int32_t n_seqs, int32_t total_tokens, int32_t max_seqlen, int32_t num_q_heads,
+                              int32_t num_kv_heads, int32_t head_dim, void* out, int32_t last_tile_only, int out_f16, void* stream);
+int lrx_attn_prefix_suffix_ex(const void* qkv, const void* prefix_kv, int32_t n_seqs, int32_t suffix_len, int32_t prefix_len, int32_t num_q_heads,
+                              int32_t num_kv_heads, int32_t head_dim, void* out, int out_f16, void* stream);
+int lrx_embed_stream32_ex(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, int32_t vocab, const void* gamma, float* x32, void* a16,
+                          float* rscale, float eps, int f16, void* stream);
 // lrx_elementwise.hip: the two-layer pooling strategies (column sums of the other hidden state; the pooling kernel with them)
 int lrx_pool_sum_rows(const void* src, int src_kind, const int32_t* ids, int vocab, const int32_t* cu_seqlens, int n_seqs, int hidden_size, float* aux,
                       hipStream_t stream);

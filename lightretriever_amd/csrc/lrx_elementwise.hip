@@ -38,9 +38,12 @@ extern "C" int lrx_embedding_gather(const void* table, const int32_t* ids, int32
   return LRX_OK;
 }
 
+__device__ unsigned int g_shadow_fp16_saturations = 0;   // (defined here: the first kernel that counts into it follows; described at lrx_device_saturation_count)
+
 // Precise residual stream (lrx_encoder_config.precise_stream): the embedding row becomes the fp32 stream x32, the first projection's bf16 A
 // operand a16 = bf16(x * gamma) (gamma = layer 0's input_layernorm weight: the norm weight rides on the operand, the weights stay exact) and
-// the row statistic rs = rsqrt(mean(x^2) + eps).  One wave per token.
+// the row statistic rs = rsqrt(mean(x^2) + eps).  One wave per token.  F16 (precise_stream = 2): a16 = fp16(x * gamma), saturating and counted.
+template <bool F16>
 __global__ void __launch_bounds__(256) k_embed_stream32(const bf16x8* __restrict__ table, const int32_t* __restrict__ ids, int n_tokens, int chunks,
                                                         int vocab, const bf16x8* __restrict__ gamma, float* __restrict__ x32, bf16x8* __restrict__ a16,
                                                         float* __restrict__ rs, float inv_h, float eps) {
@@ -61,7 +64,12 @@ __global__ void __launch_bounds__(256) k_embed_stream32(const bf16x8* __restrict
     for (int j = 0; j < 8; ++j) {
       const float f = bad ? 0.f : bf2f(v[j]);
       ss += f * f;
-      a[j] = f2bf(f * bf2f(g[j]));
+      const float t = f * bf2f(g[j]);
+      if constexpr (F16) {
+        a[j] = __builtin_bit_cast(__bf16, (_Float16)fminf(fmaxf(t, -65504.f), 65504.f));
+        if (!(fabsf(t) <= 65504.f)) atomicAdd(&g_shadow_fp16_saturations, 1u);          // (an embedding row times a norm weight: never on a sane checkpoint)
+      } else
+        a[j] = f2bf(t);
       if (j < 4) lo[j] = f; else hi[j - 4] = f;
     }
     *(f32x4*)(x32 + (dst + c) * 8) = lo;
@@ -74,10 +82,18 @@ __global__ void __launch_bounds__(256) k_embed_stream32(const bf16x8* __restrict
 
 extern "C" int lrx_embed_stream32(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, int32_t vocab, const void* gamma,
                                   float* x32, void* a16, float* rscale_out, float eps, void* stream) {
+  return lrx_embed_stream32_ex(table, ids, n_tokens, hidden, vocab, gamma, x32, a16, rscale_out, eps, 0, stream);
+}
+int lrx_embed_stream32_ex(const void* table, const int32_t* ids, int32_t n_tokens, int32_t hidden, int32_t vocab, const void* gamma, float* x32, void* a16,
+                          float* rscale_out, float eps, int f16, void* stream) {
   LRX_CHECK_ARG(hidden % 8 == 0 && n_tokens >= 0 && vocab > 0 && gamma && x32 && a16 && rscale_out, "embed_stream32: bad operand");
   if (n_tokens == 0) return LRX_OK;
-  hipLaunchKernelGGL(k_embed_stream32, dim3(lrx_cdiv(n_tokens, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)table, ids, n_tokens, hidden / 8,
-                     vocab, (const bf16x8*)gamma, x32, (bf16x8*)a16, rscale_out, 1.0f / (float)hidden, eps);
+  if (f16)
+    hipLaunchKernelGGL(k_embed_stream32<true>, dim3(lrx_cdiv(n_tokens, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)table, ids, n_tokens, hidden / 8,
+                       vocab, (const bf16x8*)gamma, x32, (bf16x8*)a16, rscale_out, 1.0f / (float)hidden, eps);
+  else
+    hipLaunchKernelGGL(k_embed_stream32<false>, dim3(lrx_cdiv(n_tokens, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)table, ids, n_tokens, hidden / 8,
+                       vocab, (const bf16x8*)gamma, x32, (bf16x8*)a16, rscale_out, 1.0f / (float)hidden, eps);
   LRX_LAUNCH_CHECK();
   return LRX_OK;
 }
@@ -131,7 +147,6 @@ extern "C" int lrx_probe_stream_read(const void* buf, size_t bytes, uint32_t* si
 
 // fp16 shadow elements k_pool_norm had to clamp (|v| > 65504 or NaN: an unnormalised row of a broken checkpoint); the shard's E bound keeps
 // the SEARCH exact in that case, this counter makes the event visible (lrx_device_saturation_count).
-__device__ unsigned int g_shadow_fp16_saturations = 0;
 unsigned int lrx_gemm_saturations(int* ok);                 // lrx_gemm.hip
 int lrx_gemm_saturations_reset();
 

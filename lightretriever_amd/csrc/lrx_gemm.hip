@@ -127,13 +127,17 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // bf16 x bf16 for the encoder GEMMs; the search filter's instantiation multiplies fp16 operands (same containers, same data movement)
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-template <int EPI>
+// F16 (round 6, lrx_encoder_config.precise_stream = 2): the encoder GEMM's operands are FP16 too -- activations fp16(x * gamma), the attention output, the
+// SwiGLU output, and the projection weights converted once at load (exact for |w| >= 6.1e-5): three more mantissa bits than bf16 at the
+// same MFMA rate, worth 14-42 x in 1 - cos against the fp32 model (tools/exp/rounding_fp16_o_act.py); what the epilogue WRITES as the
+// next GEMM's operand is fp16 then (saturating, counted like q|k|v).
+template <int EPI, bool F16>
 __device__ __forceinline__ f32x4 gemm_mfma(bf16x8 x, bf16x8 y, f32x4 c) {
-  if constexpr (EPI_IS_SEARCH(EPI)) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+  if constexpr (EPI_IS_SEARCH(EPI) || F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
 }
 
-template <int EPI>
+template <int EPI, bool F16 = false>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
                const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope, MaxAggArgs mx, NormArgs nrm, EmitArgs em) {
@@ -230,7 +234,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   do {                                                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[H][HP][mi][ni] =                        \
-            gemm_mfma<EPI>(b[ni][ks], a[mi][ks], acc[H][HP][mi][ni]); \
+            gemm_mfma<EPI, F16>(b[ni][ks], a[mi][ks], acc[H][HP][mi][ni]); \
   } while (0)
 
   // folded RMSNorm: this lane's 8 row scales, requested now so they have long arrived when the epilogue multiplies
@@ -268,7 +272,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
   do {                                                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[H][HP][mi][ni] =                        \
-            gemm_mfma<EPI>(b2[ni][ks], a[mi][ks], acc[H][HP][mi][ni]); \
+            gemm_mfma<EPI, F16>(b2[ni][ks], a[mi][ks], acc[H][HP][mi][ni]); \
   } while (0)
   // Lifetimes: A0,B0,B1 of K-tile t are read in P1(t) (B fragments stay in registers), A1 in P2(t).  Refill one phase after
   // the last read (stagger-safe): P2(t) issues A0,B0,B1 of t+2, P1(t) issues A1 of t+1 (t >= 1; K-tile 1's comes from the
@@ -460,8 +464,15 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
           *(f32x4*)(x32 + (int64_t)m * N + nq4) = v;
           if (C != nullptr) {
             bf16x4 a4;
+            if constexpr (F16) {
+              bool sat = false;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a4[e] = f2bf(v[e] * gm[e]);
+              for (int e = 0; e < 4; ++e) { const float t = v[e] * gm[e]; sat |= !(fabsf(t) <= 65504.f); a4[e] = f2h_bits(t); }
+              if (__any(sat)) { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_qkv_fp16_saturations, 1u); }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) a4[e] = f2bf(v[e] * gm[e]);
+            }
             *(bf16x4*)(C + (int64_t)m * N + nq4) = a4;
           }
         }
@@ -509,14 +520,18 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
         if (EPI == EPI_SWIGLU) {
           // wave columns [nb, nb+16) = gate, [nb+16, nb+32) = up of output columns nb/2 .. nb/2+15
           bf16x4 o;
+          bool sat = false;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            // silu(g) * u with the two raw transcendentals (v_exp_f32, v_rcp_f32: 1 ulp, far below the bf16 rounding that follows);
+            // silu(g) * u with the two raw transcendentals (v_exp_f32, v_rcp_f32: 1 ulp, far below the 16-bit rounding that follows);
             // the IEEE division sequence of `g / (1 + expf(-g))` cost ~2 us per 256x256 tile (timeline, tools/gemm_timeline.py)
             const float g = acc[h][hp][mi][0][r] * rs, u = acc[h][hp][mi][1][r] * rs;
             const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f));
-            o[r] = f2bf(g * sg * u);
+            const float t = g * sg * u;
+            if constexpr (F16) { sat |= !(fabsf(t) <= 65504.f); o[r] = f2h_bits(t); }
+            else o[r] = f2bf(t);
           }
+          if constexpr (F16) { if (__any(sat)) { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_qkv_fp16_saturations, 1u); } }
           const int col = hp * 64 + wc * 16 + fq * 4;  // within the 128-column output tile
           *(bf16x4*)(smem + row * (CW * 2) + ((((col >> 3) ^ (row & 15)) << 4) | ((col & 4) << 1))) = o;
         } else if (EPI == EPI_ROPE) {
@@ -692,7 +707,14 @@ extern "C" int lrx_gemm_bf16_nt(const void* A, const void* B, void* C, const voi
 
 extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N,
                                       int32_t K, int32_t epilogue, const float* rscale, float* ss_part, void* stream) {
+  return lrx_gemm_nt_fused_ex(A, B, C, bias, resid, M, N, K, epilogue, rscale, ss_part, 0, stream);
+}
+
+// (f16 != 0: fp16 operands, SwiGLU epilogue only -- the gate-up projection of precise_stream = 2; the output is fp16 then)
+int lrx_gemm_nt_fused_ex(const void* A, const void* B, void* C, const void* bias, const void* resid, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                         const float* rscale, float* ss_part, int f16, void* stream) {
   LRX_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  LRX_CHECK_ARG(!f16 || epilogue == EPI_SWIGLU, "gemm: fp16 operands are served for the SwiGLU epilogue (epilogue %d)", epilogue);
   LRX_CHECK_ARG(K % GBK == 0, "gemm: K=%d must be a multiple of %d", K, GBK);
   LRX_CHECK_ARG(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
   LRX_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "gemm: unknown epilogue %d", epilogue);
@@ -712,7 +734,10 @@ extern "C" int lrx_gemm_bf16_nt_fused(const void* A, const void* B, void* C, con
   switch (epilogue) {
     case EPI_STORE: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_STORE>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0}); break;
     case EPI_RESID: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0}); break;
-    default: hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0}); break;
+    default:
+      if (f16) hipLaunchKernelGGL((k_gemm_bf16_nt<EPI_SWIGLU, true>), grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0});
+      else hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_SWIGLU>, grid, block, 0, s, a, b, c, bi, re, M, N, K, tiles_m, tiles_n, none, nomx, nrm, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0});
+      break;
   }
   LRX_LAUNCH_CHECK();
   return LRX_OK;
@@ -738,6 +763,13 @@ extern "C" int lrx_gemm_qkv_rope_fused(const void* A, const void* Wqkv, void* C,
 extern "C" int lrx_gemm_qkv_rope_slice(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos,
                                        const float* sin, int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
                                        const float* rscale, int32_t head0, int32_t n_heads, void* stream) {
+  return lrx_gemm_qkv_rope_slice_ex(A, Wqkv, C, bias, positions, cos, sin, M, K, num_q_heads, num_kv_heads, head_dim, rscale, head0, n_heads, 0, stream);
+}
+
+// (f16 != 0: A and Wqkv hold fp16 values -- precise_stream = 2; the bias stays bf16, the output is fp16 either way)
+int lrx_gemm_qkv_rope_slice_ex(const void* A, const void* Wqkv, void* C, const void* bias, const int32_t* positions, const float* cos, const float* sin,
+                               int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, const float* rscale, int32_t head0,
+                               int32_t n_heads, int f16, void* stream) {
   const int n_all = num_q_heads + 2 * num_kv_heads;
   LRX_CHECK_ARG(M >= 0 && K > 0 && K % GBK == 0, "gemm_qkv_rope: bad shape M=%d K=%d", M, K);
   LRX_CHECK_ARG(head_dim == 64 || head_dim == 128, "gemm_qkv_rope: head_dim=%d unsupported", head_dim);
@@ -748,6 +780,12 @@ extern "C" int lrx_gemm_qkv_rope_slice(const void* A, const void* Wqkv, void* C,
   const int rope_cols = (num_q_heads + num_kv_heads) * head_dim - col0;          // rotating columns of the slice (<= 0: v heads only)
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
   RopeArgs rope = {positions, cos, sin, rope_cols < 0 ? 0 : (rope_cols > N ? N : rope_cols), head_dim, n_all * head_dim};
+  if (f16)
+    hipLaunchKernelGGL((k_gemm_bf16_nt<EPI_ROPE, true>), dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A,
+                       (const __bf16*)Wqkv + (int64_t)col0 * K, (__bf16*)C + col0, bias ? (const __bf16*)bias + col0 : (const __bf16*)nullptr,
+                       (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0}, NormArgs{rscale, nullptr, 8},
+                       EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0});
+  else
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_ROPE>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A,
                      (const __bf16*)Wqkv + (int64_t)col0 * K, (__bf16*)C + col0, bias ? (const __bf16*)bias + col0 : (const __bf16*)nullptr,
                      (const __bf16*)nullptr, M, N, K, tiles_m, tiles_n, rope, MaxAggArgs{nullptr, nullptr, 0}, NormArgs{rscale, nullptr, 8},
@@ -761,11 +799,22 @@ extern "C" int lrx_gemm_qkv_rope_slice(const void* A, const void* Wqkv, void* C,
 // backbones (lrx_encoder_config.precise_stream).
 extern "C" int lrx_gemm_bf16_nt_resid32(const void* A, const void* B, float* x32, void* a16_out, const void* gamma, int32_t M, int32_t N, int32_t K,
                                         float* ss_part, void* stream) {
+  return lrx_gemm_nt_resid32_ex(A, B, x32, a16_out, gamma, M, N, K, ss_part, 0, stream);
+}
+
+// (f16 != 0: A and B hold fp16 values and a16_out = fp16(x32 * gamma) -- precise_stream = 2; gamma stays bf16)
+int lrx_gemm_nt_resid32_ex(const void* A, const void* B, float* x32, void* a16_out, const void* gamma, int32_t M, int32_t N, int32_t K, float* ss_part,
+                           int f16, void* stream) {
   LRX_CHECK_ARG(M >= 0 && N > 0 && K > 0 && K % GBK == 0 && N % 8 == 0, "gemm_resid32: bad shape M=%d N=%d K=%d", M, N, K);
   LRX_CHECK_ARG(x32 != nullptr, "gemm_resid32: null residual stream");
   if (M == 0) return LRX_OK;
   int tiles_m = (int)lrx_cdiv(M, GBM), tiles_n = (int)lrx_cdiv(N, GBN);
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
+  if (f16)
+    hipLaunchKernelGGL((k_gemm_bf16_nt<EPI_RESID32, true>), dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)B,
+                       (__bf16*)a16_out, (const __bf16*)gamma, (const __bf16*)x32, M, N, K, tiles_m, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
+                       NormArgs{nullptr, ss_part, gemm_group_m(EPI_RESID, K)}, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0});
+  else
   hipLaunchKernelGGL(k_gemm_bf16_nt<EPI_RESID32>, dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)B,
                      (__bf16*)a16_out, (const __bf16*)gamma, (const __bf16*)x32, M, N, K, tiles_m, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
                      NormArgs{nullptr, ss_part, gemm_group_m(EPI_RESID, K)}, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0});

@@ -26,6 +26,13 @@ from . import _lib
 # the 1e-3 bar of BASELINE.json's north_star on the headline model, so no default configuration runs it any more (price: ~3 % of the 1B's
 # docs/s, bench.py -> configs.encode_llama32_1b_bf16_stream).  `EncoderConfig(precise_stream=False)` still selects it explicitly.
 PRECISE_FROM_LAYERS_X_HIDDEN = 0
+# When the fp32 stream's GEMM operands are FP16 by default (round 6): from 80 000 layers x hidden on -- Llama-3.2-3B (86 016), Qwen2.5-7B
+# (100 352), Llama-3.1-8B (131 072).  With bf16 operands the worst of 2 048 trained-like documents reads 4.6e-4 on Llama-3.2-1B, 8.1e-4
+# (MRL-256: 1.0e-3) on Llama-3.2-3B and 1.11e-3 on Llama-3.1-8B (3 documents over the 1e-3 bar; profiles/r06_trained_like_tail_2048.jsonl):
+# the tail grows with depth x width; with fp16 operands the same samples read 1-3e-5.  The price is the f16 MFMA's power: -4.3 % docs/s
+# at the package cap (1B, same box: 0.964 -> 0.923 of the bf16 stream's rate), so the backbones with margin to spare keep bf16 operands.
+# `EncoderConfig(operand_dtype="fp16" | "bf16")` selects either explicitly.
+F16_OPERANDS_FROM_LAYERS_X_HIDDEN = 80_000
 
 
 @dataclass
@@ -50,6 +57,20 @@ class EncoderConfig:
     # fp32 residual stream + exact weights, the norm weight on the bf16 activation operand (lrx_encoder_config.precise_stream): None = the
     # default (PRECISE_FROM_LAYERS_X_HIDDEN = 0: on for every backbone -- the bf16 stream and the folded weights spend the 1e-3 cosine budget)
     precise_stream: Optional[bool] = None
+    # GEMM operands of the fp32-stream pipeline (lrx_encoder_config.precise_stream = 1 / 2): "bf16", or "fp16" -- activations fp16(x * gamma),
+    # attention / SwiGLU outputs and the four projection weights in fp16 (converted once at load: exact for every |w| in [6.1e-5, 65504]), the
+    # f16 MFMA at the bf16 rate.  Three more mantissa bits on every operand: 1 - cos against the HF fp32 model drops 14-42 x on trained-like
+    # weights (tools/exp/rounding_fp16_o_act.py: 8B 3.4e-4 -> 8e-6); the range is fp16's, watched by the saturation counter the product path
+    # reads.  None = "fp16" with the fp32 stream from F16_OPERANDS_FROM_LAYERS_X_HIDDEN on (the backbones whose bf16-operand tail reaches the
+    # 1e-3 bar) unless a weight leaves fp16's range (then "bf16", with a warning); the bf16 stream is bf16.
+    operand_dtype: Optional[str] = None
+
+    def use_f16_operands(self) -> bool:
+        if not self.use_precise_stream():
+            return False
+        if self.operand_dtype is not None:
+            return self.operand_dtype == "fp16"
+        return self.num_layers * self.hidden_size >= F16_OPERANDS_FROM_LAYERS_X_HIDDEN
 
     def use_precise_stream(self) -> bool:
         if self.precise_stream is not None:
@@ -190,6 +211,30 @@ class LrxEncoder:
             L["wqkv_c"] = wq[perm].to(bf).contiguous()
             L["bqkv_c"] = L["bqkv"][perm].contiguous() if L["bqkv"] is not None else None
             L["wgu_c"] = (L["wgu"].float() * L["ln2"].float()[None, :]).to(bf).contiguous() if fold else L["wgu"]
+        # fp16 operands (fp32 stream only): the four projection matrices as fp16 -- checked once that nothing left fp16's range
+        if cfg.operand_dtype not in (None, "bf16", "fp16"):
+            raise ValueError(f"operand_dtype {cfg.operand_dtype!r}: 'bf16' or 'fp16'")
+        if cfg.operand_dtype == "fp16" and not self.precise:
+            raise ValueError("operand_dtype='fp16' belongs to the fp32 residual stream (precise_stream)")
+        self.operand_f16 = cfg.use_f16_operands()
+        if self.operand_f16:
+            h = torch.float16
+            bad = torch.zeros((), dtype=torch.bool, device=self.device)
+            for L in self.layers:
+                for key, src in (("wqkv_c", L["wqkv_c"]), ("wgu_c", L["wgu_c"]), ("wo_c", L["wo"]), ("wdown_c", L["wdown"])):
+                    L[key] = src.to(h).contiguous()
+                    bad |= ~torch.isfinite(L[key]).all()
+            if bool(bad):
+                if cfg.operand_dtype == "fp16":
+                    raise ValueError("operand_dtype='fp16': a projection weight is outside fp16's range (|w| > 65504 or non-finite)")
+                import warnings
+                warnings.warn("a projection weight is outside fp16's range: the encoder keeps bf16 GEMM operands", RuntimeWarning)
+                self.operand_f16 = False
+                for L in self.layers:
+                    L["wqkv_c"], L["wgu_c"] = L["wqkv"][perm].contiguous(), L["wgu"]
+        if not self.operand_f16:
+            for L in self.layers:
+                L["wo_c"], L["wdown_c"] = L["wo"], L["wdown"]
         # LM head for the sparse branch: tied to the embedding unless the checkpoint carries its own (`lm_head.weight`)
         self.lm_head = dev(g("lm_head.weight")) if "lm_head.weight" in state_dict else None
         self._build_c_structs()
@@ -260,11 +305,11 @@ class LrxEncoder:
         c = self.cfg
         self._ccfg = _lib.EncoderConfigC(c.vocab_size, c.hidden_size, c.num_layers, c.num_q_heads, c.num_kv_heads, c.head_dim,
                                          c.intermediate_size, c.rms_eps, int(c.qkv_bias), c.max_positions, int(c.fold_norm and not self.precise),
-                                         int(self.precise))
+                                         2 if self.operand_f16 else int(self.precise))
         arr = (_lib.LayerWeightsC * c.num_layers)()
         for i, L in enumerate(self.layers):
             arr[i] = _lib.LayerWeightsC(L["wqkv_c"].data_ptr(), L["bqkv_c"].data_ptr() if L["bqkv_c"] is not None else None,
-                                        L["wo"].data_ptr(), L["wgu_c"].data_ptr(), L["wdown"].data_ptr(), L["ln1"].data_ptr(),
+                                        L["wo_c"].data_ptr(), L["wgu_c"].data_ptr(), L["wdown_c"].data_ptr(), L["ln1"].data_ptr(),
                                         L["ln2"].data_ptr())
         self._clayers = arr
         self._cw = _lib.EncoderWeightsC(self.embed.data_ptr(), self.final_norm.data_ptr(), self.rope_cos.data_ptr(),

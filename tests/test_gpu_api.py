@@ -220,7 +220,7 @@ def test_checkpoint_dir_to_search_via_reference_entry_point(tmp_path):
     assert set(res) == {"q0", "q1"} and all(len(v) == 5 for v in res.values())
     # oracle on the same checkpoint weights + same tokenisation
     from dataclasses import asdict
-    cfg_o = O.EncoderConfig(**{k: v for k, v in asdict(model.model.encoder.cfg).items() if k not in ("fold_norm", "precise_stream")})
+    cfg_o = O.EncoderConfig(**{k: v for k, v in asdict(model.model.encoder.cfg).items() if k not in ("fold_norm", "precise_stream", "operand_dtype")})
     w = {k: v.float().numpy() for k, v in m.model.state_dict().items()}
     cids = O.sort_corpus_ids_longest_first(corpus)
     docs = [corpus[c] for c in cids]

@@ -177,7 +177,7 @@ def test_readme_symmetric_flag_set_through_the_reference_entry_points(tmp_path, 
     if model_type == "HybridModel":
         assert set(res) == {"den"}
         res = res["den"]
-    cfg_o = O.EncoderConfig(**{k: v for k, v in asdict(model.model.encoder.cfg).items() if k not in ("fold_norm", "precise_stream")})
+    cfg_o = O.EncoderConfig(**{k: v for k, v in asdict(model.model.encoder.cfg).items() if k not in ("fold_norm", "precise_stream", "operand_dtype")})
     w = {k: v.float().numpy() for k, v in m.model.state_dict().items()}
     qe = _oracle_dense(cfg_o, w, model.tokenizer, ["Instruct: retrieve\nQuery: " + t for t in queries.values()], 24)
     assert gap(q.cpu().numpy(), qe) < 5e-3

@@ -67,8 +67,9 @@ def test_trained_like_weights_full_depth_parity(preset, seed):
 def test_trained_like_wide_sample_where_the_tail_lives(preset, seed):
     """64 documents read 6-7e-4 for the 8B where the worst of an 8 000-document sample crosses 1e-3 by a
     tenth -- the asserted sample was too small to see the tail.  512 documents per backbone (one HF fp32 pass of ~130 k
-    tokens is the cost): the 99.9th percentile must hold the 1e-3 bar, the maximum and the count above it are reported, and the maximum itself
-    must stay within 1.25e-3 (the recorded tail) and 4 x closer to fp32 than HF's own bf16 run."""
+    tokens is the cost).  With bf16 GEMM operands the 8B's tail sat AT the bar (512 documents: max 8.1e-4; 2 048: 3 documents over, max 1.11e-3,
+    profiles/r06_trained_like_tail_2048.jsonl); the deep backbones run fp16 operands since (encoder.py:F16_OPERANDS_FROM_LAYERS_X_HIDDEN), and
+    the bar is asserted on EVERY document, full width and MRL slice, with a factor 10 in hand -- and 4 x closer to fp32 than HF's own bf16 run."""
     import parity_margin as pm
     rec = pm.measure(preset, seed=seed, profile="trained_like", n_docs=512)
     _record(rec, "r06_trained_like_wide.jsonl")
@@ -76,9 +77,9 @@ def test_trained_like_wide_sample_where_the_tail_lives(preset, seed):
     print("trained-like %s seed %d, 512 documents: lrx p50 %.2e p99 %.2e p99.9 %.2e max %.2e (%d over 1e-3; worst document %d tokens); MRL-256 p99.9 %.2e max %.2e; "
           "HF bf16 p99.9 %.2e max %.2e" % (preset, seed, full["p50"], full["p99"], full["p999"], full["max"], full["over_1e-3"], rec["worst_doc_len"],
                                         mrl["p999"], mrl["max"], hf16["p999"], hf16["max"]))
-    assert rec["stream"] == "precise_fp32" and rec["fp16_saturations"] == 0 and full["n"] == 512
-    assert full["p999"] <= COS_TOL and mrl["p999"] <= 1.25 * COS_TOL, (full, mrl)
-    assert full["max"] <= 1.25 * COS_TOL and full["max"] <= hf16["max"] / 4, (full, hf16)
+    assert rec["stream"] == "precise_fp32" and rec["operands"] == "fp16" and rec["fp16_saturations"] == 0 and full["n"] == 512
+    assert full["max"] <= COS_TOL / 10 and mrl["max"] <= COS_TOL / 10 and full["over_1e-3"] == 0, (full, mrl)
+    assert full["max"] <= hf16["max"] / 4, (full, hf16)
 
 
 @pytest.mark.parametrize("preset", ["llama32_1b", "llama31_8b"])

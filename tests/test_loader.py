@@ -39,7 +39,7 @@ def test_load_hf_checkpoint(tmp_path, bias):
     assert set(ref) <= set(sd)
     for k, v in ref.items():
         assert torch.equal(sd[k], v), k
-    ocfg = O.EncoderConfig(**{k: v for k, v in cfg.__dict__.items() if k not in ("fold_norm", "precise_stream")})
+    ocfg = O.EncoderConfig(**{k: v for k, v in cfg.__dict__.items() if k not in ("fold_norm", "precise_stream", "operand_dtype")})
     assert set(O.weight_names(ocfg)) <= set(sd)          # every tensor the encoder needs is present
 
 

@@ -30,6 +30,9 @@ bf = torch.bfloat16
 def r16(t, on=True):
     if on == "f16":                                                         # fp16 instead of bf16 (11 significant bits)
         return t.to(torch.float16).float()
+    if on == "hilo":                                                        # bf16 hi + bf16 lo (16 significant bits): two GEMM passes
+        hi = t.to(bf).float()
+        return hi + (t - hi).to(bf).float()
     return t.to(bf).float() if on else t
 
 
@@ -86,6 +89,10 @@ def forward(enc, cfg, ids, fl):
         rs = torch.rsqrt((a if fl["stream"] else x).pow(2).mean(-1, keepdim=True) + cfg.rms_eps)
         if fl.get("fold", True):
             t = (a @ folded(L, "wqkv", "ln1").float().T) * rs
+        elif fl.get("a_gamma"):                                              # the precise stream's operand: bf16(x * gamma) (or hi + lo / unrounded), row scale on the accumulator
+            if "stats" in fl:
+                fl["stats"]["a"] = max(fl["stats"].get("a", 0.0), (x * L["ln1"].float()).abs().max().item(), (x * L["ln2"].float()).abs().max().item())
+            t = (r16(x * L["ln1"].float(), fl.get("a_qkv", True)) @ L["wqkv"].float().T) * rs
         else:                                                                # exact weights and gamma (what HF fp32 multiplies)
             t = ((a if fl.get("a16", True) else x) * rs * L["ln1"].float()) @ L["wqkv"].float().T
         if L["bqkv"] is not None:
@@ -112,6 +119,8 @@ def forward(enc, cfg, ids, fl):
         rs = torch.rsqrt((a if fl["stream"] else x).pow(2).mean(-1, keepdim=True) + cfg.rms_eps)
         if fl.get("fold", True):
             gu = (a @ folded(L, "wgu", "ln2").float().T) * rs
+        elif fl.get("a_gamma"):
+            gu = (r16(x * L["ln2"].float(), fl.get("a_gu", True)) @ L["wgu"].float().T) * rs
         else:
             gu = ((a if fl.get("a16", True) else x) * rs * L["ln2"].float()) @ L["wgu"].float().T
         I = cfg.intermediate_size

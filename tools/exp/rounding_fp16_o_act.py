@@ -31,7 +31,16 @@ def main():
     cuh = cu.cpu().numpy()
     base = dict(lin=False, stream=False, qkv="f16", rope2=False, p="f16", o=True, act=True, fold=False, cs16=False)
     none = dict(lin=False, stream=False, qkv=False, rope2=False, p=False, o=False, act=False, fold=False, cs16=False, a16=False)
+    pa = dict(base, a_gamma=True)                                            # A = bf16(x * gamma), the product's operand exactly
     variants = {
+        "product arithmetic, A = bf16(x gamma)": pa,
+        "  A of QKV as bf16 hi + lo": dict(pa, a_qkv="hilo"),
+        "  A of gate-up as bf16 hi + lo": dict(pa, a_gu="hilo"),
+        "  both A as hi + lo": dict(pa, a_qkv="hilo", a_gu="hilo"),
+        "  both A hi + lo, o / act fp16": dict(pa, a_qkv="hilo", a_gu="hilo", o="f16", act="f16"),
+        "  A of QKV unrounded": dict(pa, a_qkv=False),
+        "  A of QKV fp16": dict(pa, a_qkv="f16"),
+        "  every GEMM operand fp16 (A qkv, A gate-up, o, act)": dict(pa, a_qkv="f16", a_gu="f16", o="f16", act="f16"),
         "product arithmetic (o, act bf16)": base,
         "o fp16": dict(base, o="f16"),
         "act fp16": dict(base, act="f16"),
@@ -43,9 +52,9 @@ def main():
         keep = rb.r16
         rb.r16 = lambda t, on=True: t                                        # noqa: E731
         stats = {}
-        ref = torch.stack([torch.nn.functional.normalize(rb.forward(enc, cfg, dc, dict(none, stats=stats)), dim=-1) for dc in docs])
+        ref = torch.stack([torch.nn.functional.normalize(rb.forward(enc, cfg, dc, dict(none, stats=stats, a_gamma=True)), dim=-1) for dc in docs])
         rb.r16 = keep
-        print("%s trained-like seed %d, %d documents: max |o| %.1f, max |act| %.1f" % (preset, seed, n_docs, stats["o"], stats["act"]))
+        print("%s trained-like seed %d, %d documents: max |o| %.1f, max |act| %.1f, max |x gamma| %.1f" % (preset, seed, n_docs, stats["o"], stats["act"], stats["a"]))
         g = (1 - (ref * out).sum(-1)).cpu().numpy()
         print("%-36s max %.3e  p50 %.3e  mean %.3e" % ("PRODUCT", g.max(), np.median(g), g.mean()))
         for name, fl in variants.items():

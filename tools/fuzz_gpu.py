@@ -114,13 +114,14 @@ def main():
         lens = [int(x) for x in rng.integers(3 if "to_last" in pool else 1, 200, size=int(rng.integers(1, 7)))]
         ids = rng.integers(0, 400, size=sum(lens)).astype(np.int32); cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         fold = bool(rng.random() < 0.7)
-        prec = bool(rng.random() < 0.35)                             # the fp32 residual stream of deep backbones
-        enc = LrxEncoder(EncoderConfig(**asdict(cfg), fold_norm=fold, precise_stream=prec), {k: torch.from_numpy(v) for k, v in w.items()})
+        prec = bool(rng.random() < 0.6)                             # the fp32 residual stream of deep backbones
+        ops16 = "fp16" if (prec and rng.random() < 0.6) else None     # fp32 stream: fp16 GEMM operands (the deep backbones' default) or bf16 ones
+        enc = LrxEncoder(EncoderConfig(**asdict(cfg), fold_norm=fold, precise_stream=prec, operand_dtype=ops16), {k: torch.from_numpy(v) for k, v in w.items()})
         shrink = int(rng.choice([H, H // 2]))
         got = enc.encode_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), max(lens), out_dim=shrink, pooling=pool).cpu().numpy()
         want = O.encode_passage(cfg, w, ids, cu, dense_shrink_dim=shrink, pooling=pool)
         cos = (got * want).sum(-1)
-        check("encoder", cos.min() > 1 - 6e-3 and np.isfinite(got).all(), (H, I, L, nq, nkv, d, cfg.rope_type, cfg.qkv_bias, fold, prec, pool, lens, float(1 - cos.min())))
+        check("encoder", cos.min() > 1 - 6e-3 and np.isfinite(got).all(), (H, I, L, nq, nkv, d, cfg.rope_type, cfg.qkv_bias, fold, prec, ops16, pool, lens, float(1 - cos.min())))
     # ---- sparse max aggregation, hit-list fusion, shared-prefix encode
     from lightretriever_amd.score_fuse_utils import fuse_hits
     BF16_ULP = 2.0 ** -7

@@ -80,11 +80,14 @@ def summary(g):
             "over_1e-3": int((g > 1e-3).sum()), "n": int(g.size)}
 
 
-def measure(preset: str, seed: int = 0, profile: str = "trained_like", n_docs: int = 64, mrl: int = 256, other_stream: bool = False, synth=None) -> dict:
+def measure(preset: str, seed: int = 0, profile: str = "trained_like", n_docs: int = 64, mrl: int = 256, other_stream: bool = False, synth=None,
+            operand_dtype=None) -> dict:
     """One backbone x one weight seed: lrx (default stream mode) and HF bf16 against HF fp32, full embedding and the MRL slice."""
     from lightretriever_amd import EncoderConfig, LrxEncoder, _lib
     from lightretriever_amd.synth import sink_token
     cfg = getattr(EncoderConfig, preset)()
+    if operand_dtype:
+        cfg = dataclasses.replace(cfg, operand_dtype=operand_dtype)
     enc = LrxEncoder.random_init(cfg, seed=seed, profile=profile, **(synth or {}))
     lens = document_lengths(n_docs, seed)
     ids, cu = documents(cfg, lens, seed, first_token=sink_token(cfg) if profile == "trained_like" else None)
@@ -94,7 +97,8 @@ def measure(preset: str, seed: int = 0, profile: str = "trained_like", n_docs: i
     out_mrl = enc.encode_packed(ids, cu, 512, out_dim=mrl)
     torch.cuda.synchronize()
     rec = {"preset": preset, "layers": cfg.num_layers, "profile": profile, "seed": seed, "docs": n_docs,
-           "stream": "precise_fp32" if enc.precise else "bf16_folded_norm", "fp16_saturations": int(_lib.lib().lrx_device_saturation_count(1))}
+           "stream": "precise_fp32" if enc.precise else "bf16_folded_norm", "operands": "fp16" if enc.operand_f16 else "bf16",
+           "fp16_saturations": int(_lib.lib().lrx_device_saturation_count(1))}
     if getattr(enc, "synth_stats", None):
         rec["weights"] = enc.synth_stats["summary"]
     sd = enc.hf_state_dict()
@@ -102,7 +106,7 @@ def measure(preset: str, seed: int = 0, profile: str = "trained_like", n_docs: i
     if other_stream:
         del enc
         torch.cuda.empty_cache()
-        enc_b = LrxEncoder(dataclasses.replace(cfg, precise_stream=rec["stream"] != "precise_fp32"), sd)
+        enc_b = LrxEncoder(dataclasses.replace(cfg, precise_stream=rec["stream"] != "precise_fp32", operand_dtype=None), sd)
         other = enc_b.encode_packed(ids, cu, 512).clone()
         del enc_b
     else:
@@ -136,10 +140,12 @@ def main():
     ap.add_argument("--streams", default="default")
     ap.add_argument("--out", default="")
     ap.add_argument("--synth", default="", help="JSON dict of synth.trained_like_state_dict keyword overrides (experiments)")
+    ap.add_argument("--operands", default="", help="bf16 | fp16: GEMM operands of the fp32 stream (default: the encoder's rule)")
     a = ap.parse_args()
     for preset in a.presets.split(","):
         for seed in [int(s) for s in a.seeds.split(",")]:
-            rec = measure(preset, seed, a.profile, a.docs, other_stream=a.streams == "both", synth=json.loads(a.synth) if a.synth else None)
+            rec = measure(preset, seed, a.profile, a.docs, other_stream=a.streams == "both", synth=json.loads(a.synth) if a.synth else None,
+                          operand_dtype=a.operands or None)
             if a.synth:
                 rec["synth_overrides"] = json.loads(a.synth)
             line = json.dumps(rec)
