@@ -549,7 +549,10 @@ def encode_8b_leg(args, dev):
     # ---- BASELINE configs[2]: Llama-3.1-8B dims, 128 documents x seq_len per step
     from lightretriever_amd import EncoderConfig, LrxEncoder
     cfg8 = EncoderConfig.llama31_8b(args.seq_len)
+    if os.environ.get("LRX_BENCH_OPERANDS") in ("bf16", "fp16"):             # dev switch (A/B of the fp32 stream's GEMM operands)
+        cfg8.operand_dtype = os.environ["LRX_BENCH_OPERANDS"]
     enc8 = LrxEncoder.random_init(cfg8, seed=0, device=dev)
+    ops8 = "fp16" if enc8.operand_f16 else "bf16"
     B8, S = 128, args.seq_len
     g8 = torch.Generator(device=dev).manual_seed(77)
     ids8 = torch.randint(1000, 127000, (3, B8 * S), generator=g8, device=dev, dtype=torch.int64).to(torch.int32)
@@ -567,8 +570,9 @@ def encode_8b_leg(args, dev):
     enc8.set_profiling(False)
     tf8 = gu8["flops"] / (gu8["ms"] * 1e-3) / 1e12 if gu8["ms"] > 0 else 0.0
     out = {
-        "workload": "lightretriever-llama3.1-8b dims bf16, %d docs/step x seq_len %d, 2 timed steps after 1 warm-up (BASELINE configs[2] encoder)" % (B8, S),
-        "docs_per_s": round(2 * B8 / t8, 2), "ms_per_step": round(1e3 * t8 / 2, 2),
+        "workload": "lightretriever-llama3.1-8b dims, fp32 residual stream + %s GEMM operands, %d docs/step x seq_len %d, 2 timed steps after 1 warm-up "
+                    "(BASELINE configs[2] encoder)" % (ops8, B8, S),
+        "operands": ops8, "docs_per_s": round(2 * B8 / t8, 2), "ms_per_step": round(1e3 * t8 / 2, 2),
         "end_to_end_tflops": round(2 * B8 / t8 * cfg8.flops_per_doc(S) / 1e12, 1),
         "roofline": {"bound": "mfma", "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (M=%d N=%d K=%d)" % (B8 * S, 2 * cfg8.intermediate_size, cfg8.hidden_size),
                      "achieved": round(tf8, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf8 / PEAK_BF16_TFLOPS, 4),
@@ -586,8 +590,9 @@ def other_stream_leg(args, dev):
     from lightretriever_amd import EncoderConfig, LrxEncoder
     B, S = 256, args.seq_len
     out = {}
-    for name, precise in (("bf16_stream_folded_norm", False), ("precise_fp32_stream", True)):
-        cfg = dataclasses.replace(EncoderConfig.llama32_1b(S), precise_stream=precise)
+    for name, precise, operands in (("bf16_stream_folded_norm", False, None), ("precise_fp32_stream", True, "bf16"),
+                                    ("precise_fp32_stream_fp16_operands", True, "fp16")):
+        cfg = dataclasses.replace(EncoderConfig.llama32_1b(S), precise_stream=precise, operand_dtype=operands)
         enc = LrxEncoder.random_init(cfg, seed=0, device=dev)
         g = torch.Generator(device=dev).manual_seed(79)
         ids = torch.randint(1000, 127000, (4, B * S), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
@@ -602,8 +607,10 @@ def other_stream_leg(args, dev):
         out[name] = {"docs_per_s": round(3 * B / (time.perf_counter() - t0), 1)}
         del enc, o, ids
         torch.cuda.empty_cache()
-    out["workload"] = "lightretriever-llama3.2-1b dims bf16, 256 docs/step x seq_len %d, 3 timed steps after 1 warm-up, both stream modes on this box" % S
+    out["workload"] = ("lightretriever-llama3.2-1b dims, 256 docs/step x seq_len %d, 3 timed steps after 1 warm-up: the bf16 stream, the fp32 stream with bf16 GEMM "
+                       "operands (this backbone's default) and with fp16 operands (the deep backbones' default), on this box" % S)
     out["precise_over_bf16"] = round(out["precise_fp32_stream"]["docs_per_s"] / out["bf16_stream_folded_norm"]["docs_per_s"], 4)
+    out["fp16_operands_over_bf16_operands"] = round(out["precise_fp32_stream_fp16_operands"]["docs_per_s"] / out["precise_fp32_stream"]["docs_per_s"], 4)
     return out
 
 
@@ -797,9 +804,10 @@ def sharded_encode_8b_leg(args, dev, rank, world, distributed):
     gu8 = enc8.get_profile()["gemm_swiglu"]
     enc8.set_profiling(False)
     tf8 = gu8["flops"] / (gu8["ms"] * 1e-3) / 1e12 if gu8["ms"] > 0 else 0.0
-    out = {"workload": "lightretriever-llama3.1-8b dims bf16, %d docs/step/GPU x seq_len %d on %d rank(s), %d timed steps after 1 warm-up, barrier + "
-                       "synchronize around them, MAX over ranks" % (B8, S, world, n_t),
-           "docs_per_s": round(world * n_t * B8 / t8, 2), "ms_per_step": round(1e3 * t8 / n_t, 2), "n_gpus": world, "scaling": "weak",
+    ops8 = "fp16" if enc8.operand_f16 else "bf16"
+    out = {"workload": "lightretriever-llama3.1-8b dims, fp32 residual stream + %s GEMM operands, %d docs/step/GPU x seq_len %d on %d rank(s), %d timed steps "
+                       "after 1 warm-up, barrier + synchronize around them, MAX over ranks" % (ops8, B8, S, world, n_t),
+           "operands": ops8, "docs_per_s": round(world * n_t * B8 / t8, 2), "ms_per_step": round(1e3 * t8 / n_t, 2), "n_gpus": world, "scaling": "weak",
            "end_to_end_tflops_per_gpu": round(n_t * B8 / t8 * cfg8.flops_per_doc(S) / 1e12, 1),
            "roofline": {"bound": "mfma", "kernel": "k_gemm_bf16_nt<EPI_SWIGLU> (M=%d N=%d K=%d), rank 0" % (B8 * S, 2 * cfg8.intermediate_size, cfg8.hidden_size),
                         "achieved": round(tf8, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf8 / PEAK_BF16_TFLOPS, 4),
@@ -904,7 +912,9 @@ def main():
     # 1e-3 cosine against the HF fp32 model on trained-like weights, tests/test_gpu_trained_like.py); LRX_BENCH_BF16_STREAM=1 is a dev switch
     if os.environ.get("LRX_BENCH_BF16_STREAM") == "1":
         cfg.precise_stream = False
-    stream_mode = "fp32-stream(precise)" if cfg.use_precise_stream() else "bf16-stream(folded-norm)"
+    if os.environ.get("LRX_BENCH_OPERANDS") in ("bf16", "fp16") and cfg.use_precise_stream():     # dev switch (A/B of the fp32 stream's GEMM operands)
+        cfg.operand_dtype = os.environ["LRX_BENCH_OPERANDS"]
+    stream_mode = ("fp32-stream(precise, %s operands)" % ("fp16" if cfg.use_f16_operands() else "bf16")) if cfg.use_precise_stream() else "bf16-stream(folded-norm)"
     enc = LrxEncoder.random_init(cfg, seed=0, device=dev) if need_enc else None
     D = args.mrl_dim or H                       # embedding / index width (MRL slice of the pooled state when < H)
     from lightretriever_amd import _lib
@@ -1219,7 +1229,7 @@ def main():
         "metric": "docs embedded/sec (%s dims, seq_len=%d, bf16) [+ queries/sec@top-%d over %d-doc index in `search`]" % (args.model, S, args.topk, args.index_rows),
         "value": round(docs_per_s, 2), "unit": "docs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * enc_s / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic (random-init weights, uniform random token ids, N(0,1) normalised index rows)",
+        "dtype": "fp16" if cfg.use_f16_operands() else "bf16", "data": "synthetic (random-init weights, uniform random token ids, N(0,1) normalised index rows)",
         "rccl_ranks": rccl_ranks,
         "config": {"workload": ("configs[1] %s bf16 %s, %d docs x %d tok/step/GPU, top-%d over %dx%d fp32 index"
                                 % (args.model, stream_mode, B, S, args.topk, args.index_rows, D)) if batches is None else
