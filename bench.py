@@ -549,10 +549,10 @@ def encode_8b_leg(args, dev):
     # ---- BASELINE configs[2]: Llama-3.1-8B dims, 128 documents x seq_len per step
     from lightretriever_amd import EncoderConfig, LrxEncoder
     cfg8 = EncoderConfig.llama31_8b(args.seq_len)
-    if os.environ.get("LRX_BENCH_OPERANDS") in ("bf16", "fp16"):             # dev switch (A/B of the fp32 stream's GEMM operands)
+    if os.environ.get("LRX_BENCH_OPERANDS") in ("bf16", "fp16", "fp16_qkv"):  # dev switch (A/B of the fp32 stream's GEMM operands)
         cfg8.operand_dtype = os.environ["LRX_BENCH_OPERANDS"]
     enc8 = LrxEncoder.random_init(cfg8, seed=0, device=dev)
-    ops8 = "fp16" if enc8.operand_f16 else "bf16"
+    ops8 = enc8.operand_mode
     B8, S = 128, args.seq_len
     g8 = torch.Generator(device=dev).manual_seed(77)
     ids8 = torch.randint(1000, 127000, (3, B8 * S), generator=g8, device=dev, dtype=torch.int64).to(torch.int32)
@@ -590,8 +590,8 @@ def other_stream_leg(args, dev):
     from lightretriever_amd import EncoderConfig, LrxEncoder
     B, S = 256, args.seq_len
     out = {}
-    for name, precise, operands in (("bf16_stream_folded_norm", False, None), ("precise_fp32_stream", True, "bf16"),
-                                    ("precise_fp32_stream_fp16_operands", True, "fp16")):
+    for name, precise, operands in (("bf16_stream_folded_norm", False, None), ("precise_fp32_stream_bf16_operands", True, "bf16"),
+                                    ("precise_fp32_stream", True, "fp16_qkv"), ("precise_fp32_stream_fp16_operands", True, "fp16")):
         cfg = dataclasses.replace(EncoderConfig.llama32_1b(S), precise_stream=precise, operand_dtype=operands)
         enc = LrxEncoder.random_init(cfg, seed=0, device=dev)
         g = torch.Generator(device=dev).manual_seed(79)
@@ -607,10 +607,12 @@ def other_stream_leg(args, dev):
         out[name] = {"docs_per_s": round(3 * B / (time.perf_counter() - t0), 1)}
         del enc, o, ids
         torch.cuda.empty_cache()
-    out["workload"] = ("lightretriever-llama3.2-1b dims, 256 docs/step x seq_len %d, 3 timed steps after 1 warm-up: the bf16 stream, the fp32 stream with bf16 GEMM "
-                       "operands (this backbone's default) and with fp16 operands (the deep backbones' default), on this box" % S)
+    out["workload"] = ("lightretriever-llama3.2-1b dims, 256 docs/step x seq_len %d, 3 timed steps after 1 warm-up: the bf16 stream; the fp32 stream with bf16 GEMM "
+                       "operands, with the QKV projection's operands in fp16 (this backbone's default) and with every operand in fp16 (the deep backbones' "
+                       "default), on this box" % S)
     out["precise_over_bf16"] = round(out["precise_fp32_stream"]["docs_per_s"] / out["bf16_stream_folded_norm"]["docs_per_s"], 4)
-    out["fp16_operands_over_bf16_operands"] = round(out["precise_fp32_stream_fp16_operands"]["docs_per_s"] / out["precise_fp32_stream"]["docs_per_s"], 4)
+    out["fp16_qkv_over_bf16_operands"] = round(out["precise_fp32_stream"]["docs_per_s"] / out["precise_fp32_stream_bf16_operands"]["docs_per_s"], 4)
+    out["fp16_operands_over_bf16_operands"] = round(out["precise_fp32_stream_fp16_operands"]["docs_per_s"] / out["precise_fp32_stream_bf16_operands"]["docs_per_s"], 4)
     return out
 
 
@@ -804,7 +806,7 @@ def sharded_encode_8b_leg(args, dev, rank, world, distributed):
     gu8 = enc8.get_profile()["gemm_swiglu"]
     enc8.set_profiling(False)
     tf8 = gu8["flops"] / (gu8["ms"] * 1e-3) / 1e12 if gu8["ms"] > 0 else 0.0
-    ops8 = "fp16" if enc8.operand_f16 else "bf16"
+    ops8 = enc8.operand_mode
     out = {"workload": "lightretriever-llama3.1-8b dims, fp32 residual stream + %s GEMM operands, %d docs/step/GPU x seq_len %d on %d rank(s), %d timed steps "
                        "after 1 warm-up, barrier + synchronize around them, MAX over ranks" % (ops8, B8, S, world, n_t),
            "operands": ops8, "docs_per_s": round(world * n_t * B8 / t8, 2), "ms_per_step": round(1e3 * t8 / n_t, 2), "n_gpus": world, "scaling": "weak",
@@ -912,9 +914,9 @@ def main():
     # 1e-3 cosine against the HF fp32 model on trained-like weights, tests/test_gpu_trained_like.py); LRX_BENCH_BF16_STREAM=1 is a dev switch
     if os.environ.get("LRX_BENCH_BF16_STREAM") == "1":
         cfg.precise_stream = False
-    if os.environ.get("LRX_BENCH_OPERANDS") in ("bf16", "fp16") and cfg.use_precise_stream():     # dev switch (A/B of the fp32 stream's GEMM operands)
+    if os.environ.get("LRX_BENCH_OPERANDS") in ("bf16", "fp16", "fp16_qkv") and cfg.use_precise_stream():     # dev switch (A/B of the fp32 stream's GEMM operands)
         cfg.operand_dtype = os.environ["LRX_BENCH_OPERANDS"]
-    stream_mode = ("fp32-stream(precise, %s operands)" % ("fp16" if cfg.use_f16_operands() else "bf16")) if cfg.use_precise_stream() else "bf16-stream(folded-norm)"
+    stream_mode = ("fp32-stream(precise, %s operands)" % {"fp16": "fp16", "fp16_qkv": "bf16 + fp16-QKV", "bf16": "bf16"}[cfg.operand_mode()]) if cfg.use_precise_stream() else "bf16-stream(folded-norm)"
     enc = LrxEncoder.random_init(cfg, seed=0, device=dev) if need_enc else None
     D = args.mrl_dim or H                       # embedding / index width (MRL slice of the pooled state when < H)
     from lightretriever_amd import _lib

@@ -58,12 +58,15 @@ typedef struct lrx_encoder_config {
                                  of the 1e-3 cosine budget against the fp32 model (tools/exp/rounding_budget.py); +6 B / element of traffic
                                  per residual GEMM (~3 % of a step).  LrxEncoder switches it on for EVERY backbone (since round 5: the mode that
                                  holds 1e-3 on trained-like weights; EncoderConfig(precise_stream=False) selects the bf16 stream).
-                                 2: the same with FP16 GEMM operands (round 6; LrxEncoder's default): wqkv / wo / wgu / wdown hold fp16 values
+                                 2: the same with FP16 GEMM operands (round 6; on request): wqkv / wo / wgu / wdown hold fp16 values
                                  (the caller converts the bf16 checkpoint once: exact for every |w| in [6.1e-5, 65504]; biases, norm weights
                                  and the embedding stay bf16), the activations fp16(x * gamma), the attention and SwiGLU outputs travel as fp16
                                  and every projection runs on the f16 MFMA (same rate).  Three more mantissa bits per operand: 1 - cos against
                                  the fp32 model drops 14-42 x (8B, trained-like weights: 3.4e-4 -> 8e-6, tools/exp/rounding_fp16_o_act.py).
-                                 Values outside fp16's range saturate and count (lrx_device_saturation_count).                          */
+                                 Values outside fp16's range saturate and count (lrx_device_saturation_count).  -3.5 % docs/s (f16 MFMA power).
+                                 3: the QKV projection only (LrxEncoder's default): wqkv as fp16, its A operand fp16(x * gamma) -- the one rounding
+                                 that is 70 % of mode 1's distance to the fp32 model (8B, worst of 2 048 documents: 1.11e-3 -> 2.4e-4) for -0.3 %;
+                                 wo / wgu / wdown stay bf16.                                                                             */
 } lrx_encoder_config;
 
 /* Per-layer weights, bf16, nn.Linear layout [out, in] row-major (K contiguous).

@@ -159,7 +159,7 @@ static int check_cfg(const lrx_encoder_config* c) {
   LRX_CHECK_ARG(c->head_dim == 64 || c->head_dim == 128, "encode: head_dim=%d unsupported", c->head_dim);
   LRX_CHECK_ARG(c->num_kv_heads > 0 && c->num_q_heads % c->num_kv_heads == 0, "encode: bad head counts %d/%d", c->num_q_heads, c->num_kv_heads);
   LRX_CHECK_ARG(c->num_layers > 0 && c->vocab_size > 0 && c->max_positions > 0, "encode: bad config");
-  LRX_CHECK_ARG(c->precise_stream >= 0 && c->precise_stream <= 2, "encode: precise_stream=%d (0: bf16 stream, 1: fp32 stream, 2: fp32 stream + fp16 GEMM operands)", c->precise_stream);
+  LRX_CHECK_ARG(c->precise_stream >= 0 && c->precise_stream <= 3, "encode: precise_stream=%d (0: bf16 stream, 1: fp32 stream, 2: + fp16 GEMM operands, 3: + fp16 QKV operands only)", c->precise_stream);
   LRX_CHECK_ARG(!(c->precise_stream && c->norm_folded), "encode: precise_stream keeps the norm weight on the activation operand -- pass the unfolded weights (norm_folded = 0)");
   return LRX_OK;
 }
@@ -190,19 +190,22 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
   const int H = c->hidden_size, d = c->head_dim, nq = c->num_q_heads, nkv = c->num_kv_heads, I = c->intermediate_size;
   const int QKV = (nq + 2 * nkv) * d, QD = nq * d;
   const bool fold = c->norm_folded != 0, precise = c->precise_stream != 0;
-  const int f16 = c->precise_stream == 2 ? 1 : 0;      // fp16 GEMM operands (activations, attention / SwiGLU outputs, the four projection weights)
+  // fp16 GEMM operands: precise_stream = 2 -- every projection (activations, attention / SwiGLU outputs, the four weight matrices); 3 -- the QKV
+  // projection only (its A operand fp16(x * gamma) and wqkv: 70 % of the pipeline's distance to the fp32 model for < 1 % of a step)
+  const int f16 = c->precise_stream == 2 ? 1 : 0, f16q = c->precise_stream >= 2 ? 1 : 0;
   const bool scaled = fold || precise;                 // the consumer GEMM multiplies its accumulator rows by rsqrt(mean(x^2) + eps)
   const int NP = (H + 255) / 256;                      // n-tiles of a residual GEMM (N = H)
   int rc;
-  if (precise) { ProfScope p(s, 6, 0); if ((rc = lrx_embed_stream32_ex(w->embed, ids, T, H, c->vocab_size, w->layers[0].ln1, ws.x32, ws.x, ws.rsA, c->rms_eps, f16, s))) return rc; }
+  if (precise) { ProfScope p(s, 6, 0); if ((rc = lrx_embed_stream32_ex(w->embed, ids, T, H, c->vocab_size, w->layers[0].ln1, ws.x32, ws.x, ws.rsA, c->rms_eps, f16q, s))) return rc; }
   else {
     { ProfScope p(s, 6, 0); if ((rc = lrx_embedding_gather(w->embed, ids, T, H, c->vocab_size, ws.x, s))) return rc; }
     if (fold) { ProfScope p(s, 4, 0); if ((rc = lrx_row_rscale(ws.x, T, H, c->rms_eps, ws.rsA, s))) return rc; }
   }
   // residual GEMM: stream += A . W^T over `rows` rows (+ what the next consumer needs: the bf16 operand in precise mode, the sum of squares)
-  auto resid = [&](const void* A, const void* W, char* xb, float* x32, const void* gamma_next, bool want_next, int rows, int N, int K) -> int {
+  // (next_f16: the operand written for the next projection is fp16 -- the gate-up's under mode 2, the QKV's under modes 2 and 3)
+  auto resid = [&](const void* A, const void* W, char* xb, float* x32, const void* gamma_next, bool want_next, int rows, int N, int K, int next_f16) -> int {
     ProfScope p(s, 1, 2.0 * rows * (double)N * K);
-    if (precise) return lrx_gemm_nt_resid32_ex(A, W, x32, want_next ? xb : nullptr, want_next ? gamma_next : nullptr, rows, N, K, want_next ? ws.ssp : nullptr, f16, s);
+    if (precise) return lrx_gemm_nt_resid32_ex(A, W, x32, want_next ? xb : nullptr, want_next ? gamma_next : nullptr, rows, N, K, want_next ? ws.ssp : nullptr, f16, next_f16, s);
     return lrx_gemm_bf16_nt_fused(A, W, xb, nullptr, xb, rows, N, K, 1, nullptr, (fold && want_next) ? ws.ssp : nullptr, s);
   };
   for (int l = 0; l < c->num_layers; ++l) {
@@ -220,18 +223,18 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
       // (the previous layer's -- hence num_layers > 1: a one-layer model would leave uninitialised memory there), per-row independent, never read out.
       const int B = n_tail;
       { ProfScope p(s, 0, 2.0 * T * (double)(2 * nkv * d) * H + 2.0 * B * (double)QD * H);
-        if ((rc = lrx_gemm_qkv_rope_slice_ex(Aqkv, L.wqkv, ws.qkv, bq, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, scaled ? ws.rsA : nullptr, nq, 2 * nkv, f16, s))) return rc;
+        if ((rc = lrx_gemm_qkv_rope_slice_ex(Aqkv, L.wqkv, ws.qkv, bq, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d, scaled ? ws.rsA : nullptr, nq, 2 * nkv, f16q, s))) return rc;
         if ((rc = lrx_gather_last_rows(Aqkv, tail_cu, B, H, ws.hr, s))) return rc;
         if ((rc = lrx_gather_rows_u32(ws.pos, tail_cu, B, ws.posr, s))) return rc;
         if (scaled && (rc = lrx_gather_rows_u32(ws.rsA, tail_cu, B, ws.rsr, s))) return rc;
         // (num_kv_heads = 0 in this call: C = ws.ar is [B, QD] with row stride QD -- the q heads are the whole row; ws.ar holds B x max(H, QD)
         // elements, carve())
-        if ((rc = lrx_gemm_qkv_rope_slice_ex(ws.hr, L.wqkv, ws.ar, bq, ws.posr, w->rope_cos, w->rope_sin, B, H, nq, 0, d, scaled ? ws.rsr : nullptr, 0, nq, f16, s))) return rc;
+        if ((rc = lrx_gemm_qkv_rope_slice_ex(ws.hr, L.wqkv, ws.ar, bq, ws.posr, w->rope_cos, w->rope_sin, B, H, nq, 0, d, scaled ? ws.rsr : nullptr, 0, nq, f16q, s))) return rc;
         if ((rc = lrx_scatter_last_rows(ws.ar, tail_cu, B, QD, ws.qkv, QKV, s))) return rc; }
     } else
     { ProfScope p(s, 0, 2.0 * T * (double)QKV * H);   // QKV projection with (row scale,) bias + RoPE fused into the epilogue
       if ((rc = lrx_gemm_qkv_rope_slice_ex(Aqkv, L.wqkv, ws.qkv, bq, ws.pos, w->rope_cos, w->rope_sin, T, H, nq, nkv, d,
-                                           scaled ? ws.rsA : nullptr, 0, nq + 2 * nkv, f16, s))) return rc; }
+                                           scaled ? ws.rsA : nullptr, 0, nq + 2 * nkv, f16q, s))) return rc; }
     if (hk.after_qkv) { rc = hk.after_qkv(hk.ctx, l, s); if (rc == 1) break; if (rc) return rc; }
     if (tail_cu != nullptr && last) {
       const int B = n_tail;
@@ -240,21 +243,21 @@ static int run_layers(const lrx_encoder_config* c, const lrx_encoder_weights* w,
       { ProfScope p(s, 6, 0); if ((rc = lrx_gather_last_rows(ws.h, tail_cu, B, QD, ws.ar, s))) return rc; }
       { ProfScope p(s, 6, 0);
         if ((rc = precise ? lrx_gather_last_rows(ws.x32, tail_cu, B, 2 * H, ws.xr32, s) : lrx_gather_last_rows(ws.x, tail_cu, B, H, ws.xr, s))) return rc; }
-      if ((rc = resid(ws.ar, L.wo, ws.xr, ws.xr32, L.ln2, true, B, H, QD))) return rc;
+      if ((rc = resid(ws.ar, L.wo, ws.xr, ws.xr32, L.ln2, true, B, H, QD, f16))) return rc;
       if (scaled) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, B, H, c->rms_eps, ws.rsB, s))) return rc; }
       else { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.xr, L.ln2, ws.hr, B, H, c->rms_eps, s))) return rc; }
       { ProfScope p(s, 2, 2.0 * B * (double)(2 * I) * H);
         if ((rc = lrx_gemm_nt_fused_ex(scaled ? ws.xr : ws.hr, L.wgu, ws.actr, nullptr, nullptr, B, 2 * I, H, 2, scaled ? ws.rsB : nullptr, nullptr, f16, s))) return rc; }
-      if ((rc = resid(ws.actr, L.wdown, ws.xr, ws.xr32, nullptr, false, B, H, I))) return rc;
+      if ((rc = resid(ws.actr, L.wdown, ws.xr, ws.xr32, nullptr, false, B, H, I, f16q))) return rc;
       break;
     }
     { ProfScope p(s, 3, hk.attn_flops); if ((rc = hk.attn(hk.ctx, l, false, s))) return rc; }
-    if ((rc = resid(ws.h, L.wo, ws.x, ws.x32, L.ln2, true, T, H, QD))) return rc;
+    if ((rc = resid(ws.h, L.wo, ws.x, ws.x32, L.ln2, true, T, H, QD, f16))) return rc;
     if (scaled) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, T, H, c->rms_eps, ws.rsB, s))) return rc; }
     else { ProfScope p(s, 4, 0); if ((rc = lrx_rmsnorm(ws.x, L.ln2, ws.h, T, H, c->rms_eps, s))) return rc; }
     { ProfScope p(s, 2, 2.0 * T * (double)(2 * I) * H);
       if ((rc = lrx_gemm_nt_fused_ex(scaled ? ws.x : ws.h, L.wgu, ws.act, nullptr, nullptr, T, 2 * I, H, 2, scaled ? ws.rsB : nullptr, nullptr, f16, s))) return rc; }
-    if ((rc = resid(ws.act, L.wdown, ws.x, ws.x32, last ? nullptr : w->layers[l + 1].ln1, !last, T, H, I))) return rc;
+    if ((rc = resid(ws.act, L.wdown, ws.x, ws.x32, last ? nullptr : w->layers[l + 1].ln1, !last, T, H, I, f16q))) return rc;
     if (scaled && !last) { ProfScope p(s, 4, 0); if ((rc = lrx_finalize_rscale(ws.ssp, NP, T, H, c->rms_eps, ws.rsA, s))) return rc; }
   }
   return LRX_OK;

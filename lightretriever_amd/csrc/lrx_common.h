@@ -111,7 +111,7 @@ int lrx_gemm_qkv_rope_slice_ex(const void* A, const void* Wqkv, void* C, const v
                                int32_t M, int32_t K, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, const float* rscale, int32_t head0,
                                int32_t n_heads, int f16, void* stream);
 int lrx_gemm_nt_resid32_ex(const void* A, const void* B, float* x32, void* a16_out, const void* gamma, int32_t M, int32_t N, int32_t K, float* ss_part,
-                           int f16, void* stream);
+                           int f16, int out_f16, void* stream);
 int lrx_attn_varlen_causal_items_ex(const void* qkv, const int32_t* cu_seqlens, const void* items, size_t items_bytes, int32_t n_seqs, int32_t total_tokens,
                                     int32_t max_seqlen, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, void* out, int32_t last_tile_only,
                                     int out_f16, void* stream);

@@ -137,7 +137,9 @@ __device__ __forceinline__ f32x4 gemm_mfma(bf16x8 x, bf16x8 y, f32x4 c) {
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
 }
 
-template <int EPI, bool F16 = false>
+// OUTH (EPI_RESID32): the operand this GEMM WRITES for the next projection is fp16 -- its own operands may still be bf16 (precise_stream = 3: only
+// the QKV projection multiplies fp16, so the down-projection, bf16 x bf16, hands it an fp16 operand).
+template <int EPI, bool F16 = false, bool OUTH = F16>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C, const __bf16* __restrict__ bias,
                const __bf16* resid, int M, int N, int K, int tiles_m, int tiles_n, RopeArgs rope, MaxAggArgs mx, NormArgs nrm, EmitArgs em) {
@@ -464,7 +466,7 @@ k_gemm_bf16_nt(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf1
           *(f32x4*)(x32 + (int64_t)m * N + nq4) = v;
           if (C != nullptr) {
             bf16x4 a4;
-            if constexpr (F16) {
+            if constexpr (OUTH) {
               bool sat = false;
 #pragma unroll
               for (int e = 0; e < 4; ++e) { const float t = v[e] * gm[e]; sat |= !(fabsf(t) <= 65504.f); a4[e] = f2h_bits(t); }
@@ -799,12 +801,14 @@ int lrx_gemm_qkv_rope_slice_ex(const void* A, const void* Wqkv, void* C, const v
 // backbones (lrx_encoder_config.precise_stream).
 extern "C" int lrx_gemm_bf16_nt_resid32(const void* A, const void* B, float* x32, void* a16_out, const void* gamma, int32_t M, int32_t N, int32_t K,
                                         float* ss_part, void* stream) {
-  return lrx_gemm_nt_resid32_ex(A, B, x32, a16_out, gamma, M, N, K, ss_part, 0, stream);
+  return lrx_gemm_nt_resid32_ex(A, B, x32, a16_out, gamma, M, N, K, ss_part, 0, 0, stream);
 }
 
-// (f16 != 0: A and B hold fp16 values and a16_out = fp16(x32 * gamma) -- precise_stream = 2; gamma stays bf16)
+// (f16 != 0: A and B hold fp16 values -- precise_stream = 2; out_f16 != 0: a16_out = fp16(x32 * gamma) -- always with f16, and for the GEMM that feeds the
+// QKV projection under precise_stream = 3; gamma stays bf16)
 int lrx_gemm_nt_resid32_ex(const void* A, const void* B, float* x32, void* a16_out, const void* gamma, int32_t M, int32_t N, int32_t K, float* ss_part,
-                           int f16, void* stream) {
+                           int f16, int out_f16, void* stream) {
+  LRX_CHECK_ARG(!f16 || out_f16 || a16_out == nullptr, "gemm_resid32: fp16 operands write an fp16 operand");
   LRX_CHECK_ARG(M >= 0 && N > 0 && K > 0 && K % GBK == 0 && N % 8 == 0, "gemm_resid32: bad shape M=%d N=%d K=%d", M, N, K);
   LRX_CHECK_ARG(x32 != nullptr, "gemm_resid32: null residual stream");
   if (M == 0) return LRX_OK;
@@ -812,6 +816,10 @@ int lrx_gemm_nt_resid32_ex(const void* A, const void* B, float* x32, void* a16_o
   RopeArgs none = {nullptr, nullptr, nullptr, 0, 64, 0};
   if (f16)
     hipLaunchKernelGGL((k_gemm_bf16_nt<EPI_RESID32, true>), dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)B,
+                       (__bf16*)a16_out, (const __bf16*)gamma, (const __bf16*)x32, M, N, K, tiles_m, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
+                       NormArgs{nullptr, ss_part, gemm_group_m(EPI_RESID, K)}, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0});
+  else if (out_f16 && a16_out != nullptr)
+    hipLaunchKernelGGL((k_gemm_bf16_nt<EPI_RESID32, false, true>), dim3(tiles_m * tiles_n), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, (const __bf16*)B,
                        (__bf16*)a16_out, (const __bf16*)gamma, (const __bf16*)x32, M, N, K, tiles_m, tiles_n, none, MaxAggArgs{nullptr, nullptr, 0},
                        NormArgs{nullptr, ss_part, gemm_group_m(EPI_RESID, K)}, EmitArgs{nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr, 0, 0});
   else

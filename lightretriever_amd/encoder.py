@@ -26,13 +26,13 @@ from . import _lib
 # the 1e-3 bar of BASELINE.json's north_star on the headline model, so no default configuration runs it any more (price: ~3 % of the 1B's
 # docs/s, bench.py -> configs.encode_llama32_1b_bf16_stream).  `EncoderConfig(precise_stream=False)` still selects it explicitly.
 PRECISE_FROM_LAYERS_X_HIDDEN = 0
-# When the fp32 stream's GEMM operands are FP16 by default (round 6): from 80 000 layers x hidden on -- Llama-3.2-3B (86 016), Qwen2.5-7B
-# (100 352), Llama-3.1-8B (131 072).  With bf16 operands the worst of 2 048 trained-like documents reads 4.6e-4 on Llama-3.2-1B, 8.1e-4
-# (MRL-256: 1.0e-3) on Llama-3.2-3B and 1.11e-3 on Llama-3.1-8B (3 documents over the 1e-3 bar; profiles/r06_trained_like_tail_2048.jsonl):
-# the tail grows with depth x width; with fp16 operands the same samples read 1-3e-5.  The price is the f16 MFMA's power: -4.3 % docs/s
-# at the package cap (1B, same box: 0.964 -> 0.923 of the bf16 stream's rate), so the backbones with margin to spare keep bf16 operands.
-# `EncoderConfig(operand_dtype="fp16" | "bf16")` selects either explicitly.
-F16_OPERANDS_FROM_LAYERS_X_HIDDEN = 80_000
+# The fp32 stream's GEMM operands (round 6).  With bf16 operands the worst of 2 048 trained-like documents reads 4.6e-4 on Llama-3.2-1B, 8.1e-4
+# (MRL-256: 1.0e-3) on Llama-3.2-3B and 1.11e-3 on Llama-3.1-8B -- 3 documents over the 1e-3 bar (profiles/r06_trained_like_tail_2048.jsonl) --
+# and 70 % of that distance is ONE rounding: the QKV projection's A operand bf16(x * gamma) (tools/exp/rounding_fp16_o_act.py).  Default
+# "fp16_qkv": that operand and wqkv in fp16 (f16 MFMA for the QKV projection only): 1B 9.7e-5, 3B 3.2e-4, 8B 2.4e-4 on the same samples for
+# -0.3 % docs/s (same box, alternating runs).  "fp16": every projection's operands (activations, attention / SwiGLU outputs, the four weight
+# matrices): 1-3e-5 for -3.5 ... -3.9 % (the f16 multiplier array draws more power at the package cap) -- on request, for callers that need the
+# fp32 model's embeddings to five digits.  "bf16": round 5's arithmetic.
 
 
 @dataclass
@@ -61,16 +61,21 @@ class EncoderConfig:
     # attention / SwiGLU outputs and the four projection weights in fp16 (converted once at load: exact for every |w| in [6.1e-5, 65504]), the
     # f16 MFMA at the bf16 rate.  Three more mantissa bits on every operand: 1 - cos against the HF fp32 model drops 14-42 x on trained-like
     # weights (tools/exp/rounding_fp16_o_act.py: 8B 3.4e-4 -> 8e-6); the range is fp16's, watched by the saturation counter the product path
-    # reads.  None = "fp16" with the fp32 stream from F16_OPERANDS_FROM_LAYERS_X_HIDDEN on (the backbones whose bf16-operand tail reaches the
-    # 1e-3 bar) unless a weight leaves fp16's range (then "bf16", with a warning); the bf16 stream is bf16.
+    # reads.  "fp16_qkv" (precise_stream = 3): the QKV projection only -- the default (None) of the fp32 stream, unless a weight leaves fp16's
+    # range (then "bf16", with a warning); the bf16 stream is bf16.
     operand_dtype: Optional[str] = None
 
-    def use_f16_operands(self) -> bool:
+    def operand_mode(self) -> str:
+        """"bf16" | "fp16" (every projection) | "fp16_qkv" (the QKV projection only: its bf16 operand is 70 % of the pipeline's distance to the fp32
+        model -- 8B 3.4e-4 -> 1.0e-4, 1B 1.1e-4 -> 2.4e-5 in the restatement -- and its fp16 form costs < 0.2 % of a step)."""
         if not self.use_precise_stream():
-            return False
+            return "bf16"
         if self.operand_dtype is not None:
-            return self.operand_dtype == "fp16"
-        return self.num_layers * self.hidden_size >= F16_OPERANDS_FROM_LAYERS_X_HIDDEN
+            return self.operand_dtype
+        return "fp16_qkv"
+
+    def use_f16_operands(self) -> bool:
+        return self.operand_mode() == "fp16"
 
     def use_precise_stream(self) -> bool:
         if self.precise_stream is not None:
@@ -212,29 +217,30 @@ class LrxEncoder:
             L["bqkv_c"] = L["bqkv"][perm].contiguous() if L["bqkv"] is not None else None
             L["wgu_c"] = (L["wgu"].float() * L["ln2"].float()[None, :]).to(bf).contiguous() if fold else L["wgu"]
         # fp16 operands (fp32 stream only): the four projection matrices as fp16 -- checked once that nothing left fp16's range
-        if cfg.operand_dtype not in (None, "bf16", "fp16"):
-            raise ValueError(f"operand_dtype {cfg.operand_dtype!r}: 'bf16' or 'fp16'")
-        if cfg.operand_dtype == "fp16" and not self.precise:
-            raise ValueError("operand_dtype='fp16' belongs to the fp32 residual stream (precise_stream)")
-        self.operand_f16 = cfg.use_f16_operands()
-        if self.operand_f16:
+        if cfg.operand_dtype not in (None, "bf16", "fp16", "fp16_qkv"):
+            raise ValueError(f"operand_dtype {cfg.operand_dtype!r}: 'bf16', 'fp16' or 'fp16_qkv'")
+        if cfg.operand_dtype in ("fp16", "fp16_qkv") and not self.precise:
+            raise ValueError(f"operand_dtype={cfg.operand_dtype!r} belongs to the fp32 residual stream (precise_stream)")
+        self.operand_mode = cfg.operand_mode()
+        for L in self.layers:
+            L["wo_c"], L["wdown_c"] = L["wo"], L["wdown"]
+        if self.operand_mode != "bf16":
             h = torch.float16
             bad = torch.zeros((), dtype=torch.bool, device=self.device)
+            keys = (("wqkv_c", "wqkv_c"), ("wgu_c", "wgu_c"), ("wo_c", "wo"), ("wdown_c", "wdown")) if self.operand_mode == "fp16" else (("wqkv_c", "wqkv_c"),)
             for L in self.layers:
-                for key, src in (("wqkv_c", L["wqkv_c"]), ("wgu_c", L["wgu_c"]), ("wo_c", L["wo"]), ("wdown_c", L["wdown"])):
-                    L[key] = src.to(h).contiguous()
+                for key, src in keys:
+                    L[key] = L[src].to(h).contiguous()
                     bad |= ~torch.isfinite(L[key]).all()
             if bool(bad):
-                if cfg.operand_dtype == "fp16":
-                    raise ValueError("operand_dtype='fp16': a projection weight is outside fp16's range (|w| > 65504 or non-finite)")
+                if cfg.operand_dtype is not None:
+                    raise ValueError(f"operand_dtype={cfg.operand_dtype!r}: a projection weight is outside fp16's range (|w| > 65504 or non-finite)")
                 import warnings
                 warnings.warn("a projection weight is outside fp16's range: the encoder keeps bf16 GEMM operands", RuntimeWarning)
-                self.operand_f16 = False
+                self.operand_mode = "bf16"
                 for L in self.layers:
-                    L["wqkv_c"], L["wgu_c"] = L["wqkv"][perm].contiguous(), L["wgu"]
-        if not self.operand_f16:
-            for L in self.layers:
-                L["wo_c"], L["wdown_c"] = L["wo"], L["wdown"]
+                    L["wqkv_c"], L["wgu_c"], L["wo_c"], L["wdown_c"] = L["wqkv"][perm].contiguous(), L["wgu"], L["wo"], L["wdown"]
+        self.operand_f16 = self.operand_mode == "fp16"
         # LM head for the sparse branch: tied to the embedding unless the checkpoint carries its own (`lm_head.weight`)
         self.lm_head = dev(g("lm_head.weight")) if "lm_head.weight" in state_dict else None
         self._build_c_structs()
@@ -305,7 +311,7 @@ class LrxEncoder:
         c = self.cfg
         self._ccfg = _lib.EncoderConfigC(c.vocab_size, c.hidden_size, c.num_layers, c.num_q_heads, c.num_kv_heads, c.head_dim,
                                          c.intermediate_size, c.rms_eps, int(c.qkv_bias), c.max_positions, int(c.fold_norm and not self.precise),
-                                         2 if self.operand_f16 else int(self.precise))
+                                         {"fp16": 2, "fp16_qkv": 3}.get(self.operand_mode, int(self.precise)))
         arr = (_lib.LayerWeightsC * c.num_layers)()
         for i, L in enumerate(self.layers):
             arr[i] = _lib.LayerWeightsC(L["wqkv_c"].data_ptr(), L["bqkv_c"].data_ptr() if L["bqkv_c"] is not None else None,

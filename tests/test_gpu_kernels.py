@@ -486,26 +486,29 @@ def test_precise_stream_encoder_is_closer_to_fp32_than_the_bf16_stream(name):
     sd = {k: torch.from_numpy(v) for k, v in w.items()}
     tid, tcu = torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda()
     out, hid = {}, {}
-    # lrx_encoder_config.precise_stream: 0 = bf16 stream (folded norms), 1 = fp32 stream with bf16 GEMM operands, 2 = fp32 stream with fp16
-    # operands (round 6: the default of the deep backbones, encoder.py:F16_OPERANDS_FROM_LAYERS_X_HIDDEN)
-    for mode, (precise, operands) in enumerate(((False, None), (True, None), (True, "fp16"))):
+    # lrx_encoder_config.precise_stream: 0 = bf16 stream (folded norms), 1 = fp32 stream with bf16 GEMM operands, 2 = with fp16 operands (round 6,
+    # on request), 3 = with the QKV projection's operands in fp16 (round 6: the default)
+    for mode, (precise, operands) in ((0, (False, None)), (1, (True, "bf16")), (2, (True, "fp16")), (3, (True, None))):
         enc = LrxEncoder(replace(EncoderConfig(**asdict(cfg_o)), precise_stream=precise, operand_dtype=operands), sd)
-        assert enc._ccfg.precise_stream == mode and enc._ccfg.norm_folded == int(not precise) and enc.operand_f16 == (mode == 2)
+        assert enc._ccfg.precise_stream == mode and enc._ccfg.norm_folded == int(not precise)
+        assert enc.operand_mode == ("bf16", "bf16", "fp16", "fp16_qkv")[mode] and enc.operand_f16 == (mode == 2)
         out[mode] = enc.encode_packed(tid, tcu, max_len).cpu().numpy()
         hid[mode] = enc.encode_hidden(tid, tcu, max_len).float()
         pooled = torch.nn.functional.normalize(hid[mode][tcu[1:].long() - 1], dim=-1).cpu().numpy()
         assert min_cos(pooled, out[mode]) > 1 - 2e-5                         # pooled tail == pooling the full forward (bf16 hidden output)
     ref = g["dense_reps"]
-    e_fast, e_prec, e_f16 = (1 - min_cos(out[m], ref) for m in (0, 1, 2))
-    print("%s: 1 - cos vs the reference's fp32 output: bf16 stream %.2e, fp32 stream + bf16 operands %.2e, + fp16 operands %.2e" % (name, e_fast, e_prec, e_f16))
+    e_fast, e_prec, e_f16, e_qkv = (1 - min_cos(out[m], ref) for m in (0, 1, 2, 3))
+    print("%s: 1 - cos vs the reference's fp32 output: bf16 stream %.2e, fp32 stream + bf16 operands %.2e, + fp16 QKV operands %.2e, + fp16 operands %.2e" % (
+        name, e_fast, e_prec, e_qkv, e_f16))
     assert e_prec <= max(1e-4, 0.8 * e_fast), (e_prec, e_fast)
     assert e_f16 <= max(1e-5, 0.5 * e_prec), (e_f16, e_prec)                  # three more mantissa bits on every GEMM operand
-    assert min_cos(out[1], out[0]) > 0.999 and min_cos(out[2], out[1]) > 0.9995
+    assert e_qkv <= max(1e-5, e_prec), (e_qkv, e_prec)                        # ... on the QKV projection's alone
+    assert min_cos(out[1], out[0]) > 0.999 and min_cos(out[2], out[1]) > 0.9995 and min_cos(out[3], out[1]) > 0.9995
     with pytest.raises(ValueError):                                           # fp16 operands belong to the fp32 stream
         LrxEncoder(replace(EncoderConfig(**asdict(cfg_o)), precise_stream=False, operand_dtype="fp16"), sd)
 
 
-@pytest.mark.parametrize("operands", [None, "fp16"])
+@pytest.mark.parametrize("operands", [None, "fp16", "bf16"])
 @pytest.mark.parametrize("name", ["llama_small_d64", "qwen2_small"])
 def test_precise_stream_covers_every_encode_entry_point(name, operands):
     """The fp32 residual stream (bf16 and fp16 GEMM operands) through the other users of the layer loop: lrx_encode_packed_sparse (dense rows equal lrx_encode_packed's, sparse
@@ -529,7 +532,7 @@ def test_precise_stream_covers_every_encode_entry_point(name, operands):
     tid, tcu = torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda()
     want = O.encode_passage(cfg_o, w, ids, cu, bf16=False)
     encs = {p: LrxEncoder(replace(EncoderConfig(**asdict(cfg_o)), precise_stream=p, operand_dtype=operands if p else None), sd) for p in (False, True)}
-    assert encs[True].operand_f16 == (operands == "fp16")
+    assert encs[True].operand_mode == (operands or "fp16_qkv")
     out = {p: e.encode_packed(tid, tcu, max_len) for p, e in encs.items()}
     assert 1 - min_cos(out[True].cpu().numpy(), want) <= max(1e-4, 0.8 * (1 - min_cos(out[False].cpu().numpy(), want)))
     dense, sparse = encs[True].encode_packed_sparse(tid, tcu, max_len)

@@ -115,7 +115,7 @@ def main():
         ids = rng.integers(0, 400, size=sum(lens)).astype(np.int32); cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         fold = bool(rng.random() < 0.7)
         prec = bool(rng.random() < 0.6)                             # the fp32 residual stream of deep backbones
-        ops16 = "fp16" if (prec and rng.random() < 0.6) else None     # fp32 stream: fp16 GEMM operands (the deep backbones' default) or bf16 ones
+        ops16 = str(rng.choice(["fp16", "fp16_qkv", "bf16"])) if prec else None     # the fp32 stream's GEMM operands
         enc = LrxEncoder(EncoderConfig(**asdict(cfg), fold_norm=fold, precise_stream=prec, operand_dtype=ops16), {k: torch.from_numpy(v) for k, v in w.items()})
         shrink = int(rng.choice([H, H // 2]))
         got = enc.encode_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), max(lens), out_dim=shrink, pooling=pool).cpu().numpy()

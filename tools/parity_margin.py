@@ -97,7 +97,7 @@ def measure(preset: str, seed: int = 0, profile: str = "trained_like", n_docs: i
     out_mrl = enc.encode_packed(ids, cu, 512, out_dim=mrl)
     torch.cuda.synchronize()
     rec = {"preset": preset, "layers": cfg.num_layers, "profile": profile, "seed": seed, "docs": n_docs,
-           "stream": "precise_fp32" if enc.precise else "bf16_folded_norm", "operands": "fp16" if enc.operand_f16 else "bf16",
+           "stream": "precise_fp32" if enc.precise else "bf16_folded_norm", "operands": enc.operand_mode,
            "fp16_saturations": int(_lib.lib().lrx_device_saturation_count(1))}
     if getattr(enc, "synth_stats", None):
         rec["weights"] = enc.synth_stats["summary"]
@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--streams", default="default")
     ap.add_argument("--out", default="")
     ap.add_argument("--synth", default="", help="JSON dict of synth.trained_like_state_dict keyword overrides (experiments)")
-    ap.add_argument("--operands", default="", help="bf16 | fp16: GEMM operands of the fp32 stream (default: the encoder's rule)")
+    ap.add_argument("--operands", default="", help="bf16 | fp16 | fp16_qkv: GEMM operands of the fp32 stream (default: the encoder's rule)")
     a = ap.parse_args()
     for preset in a.presets.split(","):
         for seed in [int(s) for s in a.seeds.split(",")]:
