@@ -608,8 +608,7 @@ def other_stream_leg(args, dev):
         del enc, o, ids
         torch.cuda.empty_cache()
     out["workload"] = ("lightretriever-llama3.2-1b dims, 256 docs/step x seq_len %d, 3 timed steps after 1 warm-up: the bf16 stream; the fp32 stream with bf16 GEMM "
-                       "operands, with the QKV projection's operands in fp16 (this backbone's default) and with every operand in fp16 (the deep backbones' "
-                       "default), on this box" % S)
+                       "operands, with the QKV projection's operands in fp16 (the default) and with every operand in fp16 (on request), on this box" % S)
     out["precise_over_bf16"] = round(out["precise_fp32_stream"]["docs_per_s"] / out["bf16_stream_folded_norm"]["docs_per_s"], 4)
     out["fp16_qkv_over_bf16_operands"] = round(out["precise_fp32_stream"]["docs_per_s"] / out["precise_fp32_stream_bf16_operands"]["docs_per_s"], 4)
     out["fp16_operands_over_bf16_operands"] = round(out["precise_fp32_stream_fp16_operands"]["docs_per_s"] / out["precise_fp32_stream_bf16_operands"]["docs_per_s"], 4)
