@@ -168,13 +168,19 @@ def load_hf_checkpoint(path: str, max_positions: int = 512, n_tokens: Optional[i
 
 
 def encoder_from_pretrained(path: str, max_positions: int = 512, device: Optional[torch.device] = None, tokenizer=None,
-                            pad_to_multiple_of: Optional[int] = None) -> LrxEncoder:
+                            pad_to_multiple_of: Optional[int] = None, precise_stream: Optional[bool] = None,
+                            operand_dtype: Optional[str] = None) -> LrxEncoder:
     """tokenizer: when given, the embedding matrix is grown to len(tokenizer) like the reference's resize_emb, and the result is
-    checked: every id the tokenizer can produce must have a row."""
+    checked: every id the tokenizer can produce must have a row.  precise_stream / operand_dtype: the arithmetic switches of EncoderConfig
+    (None = the defaults: fp32 residual stream, the QKV projection's operands in fp16)."""
     cfg, sd = load_hf_checkpoint(path, max_positions, n_tokens=len(tokenizer) if tokenizer is not None else None,
                                  pad_to_multiple_of=pad_to_multiple_of)
     if tokenizer is not None and len(tokenizer) > cfg.vocab_size:
         raise ValueError(f"tokenizer has {len(tokenizer)} tokens but the model only {cfg.vocab_size} embedding rows")
+    if precise_stream is not None:
+        cfg.precise_stream = bool(precise_stream)
+    if operand_dtype is not None:
+        cfg.operand_dtype = operand_dtype
     return LrxEncoder(cfg, sd, device)
 
 

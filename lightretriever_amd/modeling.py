@@ -580,9 +580,9 @@ class LrxExactSearchModel:
             raise _lib.LrxError(f"{what}: {bad} device-side input error(s) (token ids outside the embedding table or an attention work list that "
                                 "did not fit): the rows of this call are not the model's")
         if sat:
-            msg = (f"{what}: {sat} wave instruction(s) met q|k|v / embedding elements that were NaN or beyond fp16's +-65504 and stored them as "
-                   "+-65504: the embeddings of this call are not the model's (broken checkpoint, or activations outside the range the fp16 "
-                   "attention operands assume)")
+            msg = (f"{what}: {sat} wave instruction(s) met q|k|v / projection-operand / embedding elements that were NaN or beyond fp16's +-65504 and "
+                   "stored them as +-65504: the embeddings of this call are not the model's (broken checkpoint, or activations outside the range the "
+                   "fp16 operands assume -- EncoderConfig(operand_dtype='bf16') keeps the projection operands in bf16; q|k|v stay fp16)")
             if self.on_fp16_saturation == "raise":
                 raise _lib.LrxError(msg)
             import logging
