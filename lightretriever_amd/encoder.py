@@ -230,13 +230,18 @@ class LrxEncoder:
             keys = (("wqkv_c", "wqkv_c"), ("wgu_c", "wgu_c"), ("wo_c", "wo"), ("wdown_c", "wdown")) if self.operand_mode == "fp16" else (("wqkv_c", "wqkv_c"),)
             for L in self.layers:
                 for key, src in keys:
+                    w32 = L[src].float()
                     L[key] = L[src].to(h).contiguous()
-                    bad |= ~torch.isfinite(L[key]).all()
+                    # fp16 must hold the matrix: nothing beyond +-65504, and nothing that matters below its subnormals (a checkpoint whose
+                    # scale lives in the norm weights instead of the projection): the conversion may move the matrix by 1e-3 of its norm at most
+                    bad |= ~torch.isfinite(L[key]).all() | ((L[key].float() - w32).norm() > 1e-3 * w32.norm())
+                    del w32
             if bool(bad):
                 if cfg.operand_dtype is not None:
-                    raise ValueError(f"operand_dtype={cfg.operand_dtype!r}: a projection weight is outside fp16's range (|w| > 65504 or non-finite)")
+                    raise ValueError(f"operand_dtype={cfg.operand_dtype!r}: a projection matrix does not survive the conversion to fp16 "
+                                     "(|w| > 65504, non-finite, or a scale below fp16's subnormals)")
                 import warnings
-                warnings.warn("a projection weight is outside fp16's range: the encoder keeps bf16 GEMM operands", RuntimeWarning)
+                warnings.warn("a projection matrix does not survive the conversion to fp16 (range): the encoder keeps bf16 GEMM operands", RuntimeWarning)
                 self.operand_mode = "bf16"
                 for L in self.layers:
                     L["wqkv_c"], L["wgu_c"], L["wo_c"], L["wdown_c"] = L["wqkv"][perm].contiguous(), L["wgu"], L["wo"], L["wdown"]

@@ -508,6 +508,44 @@ def test_precise_stream_encoder_is_closer_to_fp32_than_the_bf16_stream(name):
         LrxEncoder(replace(EncoderConfig(**asdict(cfg_o)), precise_stream=False, operand_dtype="fp16"), sd)
 
 
+def test_fp16_operands_are_refused_where_fp16_cannot_hold_them():
+    """The two ways a checkpoint can leave fp16's range.  (1) Projection weights scaled below fp16's subnormals (the scale moved into the norm weight:
+    the same function in bf16 / fp32): the load-time check keeps bf16 operands by default, with a warning, and refuses an explicit 'fp16_qkv'.
+    (2) An activation operand x * gamma beyond 65504 with weights that convert fine (gamma scaled up, nothing scaled down): the store saturates and
+    the saturation counter -- the one LrxExactSearchModel turns into an error -- counts it; bf16 operands take the same checkpoint without a count
+    from the operand (q|k|v saturate on their own there, so that side is not asserted)."""
+    import warnings
+    from dataclasses import asdict, replace
+    from helpers import load_model_golden
+    from lightretriever_amd import EncoderConfig, LrxEncoder, _lib
+    cfg_o, w, _, ids, cu, max_len = load_model_golden("llama_small_d64")
+    tid, tcu = torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda()
+    base = EncoderConfig(**asdict(cfg_o))
+    # (1) wqkv * 2^-30, input_layernorm * 2^30: exact in bf16, gone in fp16
+    sd = {k: torch.from_numpy(v).clone() for k, v in w.items()}
+    for k in list(sd):
+        if k.endswith(("q_proj.weight", "k_proj.weight", "v_proj.weight")):
+            sd[k] = (sd[k].float() * 2.0 ** -30).to(torch.bfloat16)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        enc = LrxEncoder(base, sd)
+    assert enc.operand_mode == "bf16" and any("fp16" in str(r.message) for r in rec)
+    with pytest.raises(ValueError, match="fp16"):
+        LrxEncoder(replace(base, operand_dtype="fp16_qkv"), sd)
+    # (2) input_layernorm * 2^40 on the original projections: x * gamma ~ 1e10
+    sd2 = {k: torch.from_numpy(v).clone() for k, v in w.items()}
+    for k in list(sd2):
+        if k.endswith("input_layernorm.weight"):
+            sd2[k] = (sd2[k].float() * 2.0 ** 40).to(torch.bfloat16)
+    lib = _lib.lib()
+    enc2 = LrxEncoder(base, sd2)
+    assert enc2.operand_mode == "fp16_qkv"
+    lib.lrx_device_saturation_count(1)
+    enc2.encode_packed(tid, tcu, max_len)
+    torch.cuda.synchronize()
+    assert lib.lrx_device_saturation_count(1) > 0
+
+
 @pytest.mark.parametrize("operands", [None, "fp16", "bf16"])
 @pytest.mark.parametrize("name", ["llama_small_d64", "qwen2_small"])
 def test_precise_stream_covers_every_encode_entry_point(name, operands):
