@@ -69,7 +69,7 @@ typedef struct lrx_encoder_config {
                                  wo / wgu / wdown stay bf16.                                                                             */
 } lrx_encoder_config;
 
-/* Per-layer weights, bf16, nn.Linear layout [out, in] row-major (K contiguous).
+/* Per-layer weights, bf16 (precise_stream = 2: wqkv / wo / wgu / wdown as fp16; = 3: wqkv as fp16), nn.Linear layout [out, in] row-major (K contiguous).
  *   wqkv  [(nq + 2 nkv) * d, H]   rows = q_proj | k_proj | v_proj concatenated, the d rows of every q and k head in ROTARY-PAIR order:
  *                                 physical row 32 g + 16 i + t of a head = logical row i * d/2 + 16 g + t  (g < d/32, i < 2, t < 16), so that
  *                                 the fused QKV epilogue finds x_j and x_{j + d/2} in one lane and rotates on the fp32 accumulators; q and k
